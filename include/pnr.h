@@ -1,0 +1,149 @@
+/*
+ * pnr.h -- C ABI of libpnr_hip.so, the MI355X (gfx950) native replacement for the four CUDA
+ * extensions of zfkuang/PaletteNeRF (`_raymarching`, `_gridencoder`, `_shencoder`, `_palette_func`).
+ *
+ * Conventions (they mirror the reference's pybind layer):
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - the caller allocates every buffer (inputs, outputs, scratch); kernels never allocate;
+ *   - zero-initialisation contracts are the reference's (xyzs/dirs/deltas of the march kernels,
+ *     grad_embeddings, SH grad_inputs are caller-zeroed);
+ *   - sizes are passed explicitly, exactly as the reference's Python passes them;
+ *   - `stream` is a hipStream_t (the reference launches on the legacy default stream; here the
+ *     caller passes torch.cuda.current_stream().cuda_stream);
+ *   - return value: 0 on success, PNR_ERR_* (<0) otherwise; pnr_error_string() describes it.
+ *     The Python shim turns a non-zero return into RuntimeError (the reference raises
+ *     RuntimeError through TORCH_CHECK / std::runtime_error).
+ *
+ * Each entry point cites the reference interface it replaces (file:line under the reference).
+ */
+#ifndef PNR_H_
+#define PNR_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNR_OK 0
+#define PNR_ERR_INVALID (-1)      /* null pointer / bad size                                  */
+#define PNR_ERR_UNSUPPORTED (-2)  /* C not in {1,2,4,8}, D not in 1..5, n_channel > 128, ...  */
+#define PNR_ERR_LAUNCH (-3)       /* hipGetLastError() != hipSuccess after a launch           */
+
+#define PNR_DTYPE_F32 0
+#define PNR_DTYPE_F16 1
+
+#define PNR_CHANNEL_MAXIMUM 128   /* raymarching/src/raymarching.cu:13 */
+
+typedef void* pnr_stream_t; /* hipStream_t */
+
+const char* pnr_error_string(int code);
+/* ABI version of this header; bumped on any signature change. */
+int pnr_abi_version(void);
+
+/* ---------------------------------------------------------------- raymarching: utils ------- */
+
+/* replaces near_far_from_aabb, raymarching/src/raymarching.h:7, raymarching.cu:151-159 */
+int pnr_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N,
+                           float min_near, float* nears, float* fars, pnr_stream_t stream);
+/* replaces sph_from_ray, raymarching.h:8, raymarching.cu:204-212 */
+int pnr_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords,
+                     pnr_stream_t stream);
+/* replaces morton3D / morton3D_invert, raymarching.h:9-10, raymarching.cu:232-263 */
+int pnr_morton3d(const int32_t* coords, uint32_t N, int32_t* indices, pnr_stream_t stream);
+int pnr_morton3d_invert(const int32_t* indices, uint32_t N, int32_t* coords, pnr_stream_t stream);
+/* replaces packbits, raymarching.h:11, raymarching.cu:295-303 ; N = number of output bytes */
+int pnr_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, pnr_stream_t stream);
+
+/* ---------------------------------------------------------------- raymarching: training ---- */
+
+/* Scratch size (bytes) pnr_march_rays_train / pnr_compact_alive need for N elements. */
+uint64_t pnr_scan_scratch_bytes(uint32_t N);
+
+/* replaces march_rays_train, raymarching.h:13, raymarching.cu:485-493.
+ * Same arguments plus `scratch` (>= pnr_scan_scratch_bytes(N) bytes).  Row order of `rays` and the
+ * sample offsets are DETERMINISTIC (ray n -> row n, offset = counter[0] + exclusive prefix sum of
+ * the per-ray counts) instead of atomicAdd-ordered; counter[0] += total, counter[1] += N. */
+int pnr_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
+                         float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                         const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                         int32_t* rays, int32_t* counter, const float* noises, void* scratch,
+                         pnr_stream_t stream);
+
+/* replaces composite_rays_train_forward / _backward, raymarching.h:14-15, raymarching.cu:647-655, 821-829 */
+int pnr_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas,
+                                     const int32_t* rays, uint32_t M, uint32_t N, float T_thresh,
+                                     float* weights_sum, float* depth, float* image, pnr_stream_t stream);
+int pnr_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image, const float* sigmas,
+                                      const float* rgbs, const float* deltas, const int32_t* rays,
+                                      const float* weights_sum, const float* image, uint32_t M, uint32_t N,
+                                      float T_thresh, float* grad_sigmas, float* grad_rgbs, pnr_stream_t stream);
+/* replaces composite_rays_flex_train_forward / _backward, raymarching.h:16-17, raymarching.cu:657-668, 831-844 */
+int pnr_composite_rays_flex_train_forward(const float* sigmas, const float* input, const float* deltas,
+                                          const int32_t* rays, uint32_t M, uint32_t N, uint32_t n_channel,
+                                          float T_thresh, float* output, pnr_stream_t stream);
+int pnr_composite_rays_flex_train_backward(const float* grad_output, const float* sigmas, const float* input,
+                                           const float* deltas, const int32_t* rays, const float* output,
+                                           uint32_t M, uint32_t N, uint32_t n_channel, float T_thresh,
+                                           float* grad_input, pnr_stream_t stream);
+/* replaces spread_ray_to_sample, raymarching.h:18, raymarching.cu:884-894 */
+int pnr_spread_ray_to_sample(const float* input, const int32_t* rays, uint32_t M, uint32_t N, uint32_t n_channel,
+                             float* output, pnr_stream_t stream);
+
+/* ---------------------------------------------------------------- raymarching: inference --- */
+
+/* replaces march_rays, raymarching.h:20, raymarching.cu:1014-1021 */
+int pnr_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                   const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                   uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
+                   float* xyzs, float* dirs, float* deltas, const float* noises, pnr_stream_t stream);
+/* replaces composite_rays, raymarching.h:21, raymarching.cu:1187-1193 (in place) */
+int pnr_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
+                       const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum,
+                       float* depth, float* image, pnr_stream_t stream);
+/* replaces composite_rays_flex, raymarching.h:22, raymarching.cu:1195-1205 (in place on output) */
+int pnr_composite_rays_flex(uint32_t n_alive, uint32_t n_step, uint32_t n_channel, float T_thresh,
+                            const int32_t* rays_alive, const float* rays_t, const float* sigmas,
+                            const float* input, const float* deltas, const float* weights_sum, float* output,
+                            pnr_stream_t stream);
+
+/* Stable compaction replacing the host-side `rays_alive[rays_alive >= 0]` boolean mask
+ * (nerf/renderer.py:376, palette/renderer.py:521).  Writes the surviving ids, in order, to
+ * rays_alive_out and their number to n_alive_out[0].  scratch >= pnr_scan_scratch_bytes(n_alive). */
+int pnr_compact_alive(uint32_t n_alive, const int32_t* rays_alive_in, int32_t* rays_alive_out,
+                      int32_t* n_alive_out, void* scratch, pnr_stream_t stream);
+
+/* ---------------------------------------------------------------- grid encoder ------------- */
+
+/* replaces grid_encode_forward, gridencoder/src/gridencoder.h:12, gridencoder.cu:424-447.
+ * dtype selects the table/outputs/dy_dx element type (PNR_DTYPE_F32 / PNR_DTYPE_F16).
+ * outputs is [L,B,C] as in the reference; dy_dx may be NULL. offsets: device int32[L+1]. */
+int pnr_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                            uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
+                            uint32_t gridtype, int align_corners, int dtype, pnr_stream_t stream);
+/* replaces grid_encode_backward, gridencoder.h:13, gridencoder.cu:449-479.
+ * grad is [L,B,C]; grad_embeddings caller-zeroed; dy_dx/grad_inputs may both be NULL. */
+int pnr_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                             void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                             uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
+                             int align_corners, int dtype, pnr_stream_t stream);
+
+/* ---------------------------------------------------------------- SH encoder --------------- */
+
+/* replaces sh_encode_forward / sh_encode_backward, shencoder/src/shencoder.h:9-10, shencoder.cu:400-439.
+ * fp32 only (the reference's Python forces fp32, sphere_harmonics.py:16). dy_dx may be NULL. */
+int pnr_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C, float* dy_dx,
+                          pnr_stream_t stream);
+int pnr_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t C,
+                           const float* dy_dx, float* grad_inputs, pnr_stream_t stream);
+
+/* ---------------------------------------------------------------- palette ------------------ */
+
+/* replace rgb_to_hsv / hsv_to_rgb, palette/src/palette_func.h, palette.cu:135-149 */
+int pnr_rgb_to_hsv(uint32_t n, const float* input, float* output, pnr_stream_t stream);
+int pnr_hsv_to_rgb(uint32_t n, const float* input, float* output, pnr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNR_H_ */

@@ -1,0 +1,76 @@
+"""ctypes binding of libpnr_hip.so -- the C ABI declared in include/pnr.h.
+
+There is NO fallback: if the library is missing or a symbol is absent this module raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpnr_hip.so")
+
+_u32, _f32, _int, _ptr, _u64 = ctypes.c_uint32, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/pnr.h one to one
+SIGNATURES = {
+    "pnr_abi_version": [],
+    "pnr_error_string": [_int],
+    "pnr_scan_scratch_bytes": [_u32],
+    "pnr_near_far_from_aabb": [_ptr, _ptr, _ptr, _u32, _f32, _ptr, _ptr, _ptr],
+    "pnr_sph_from_ray": [_ptr, _ptr, _f32, _u32, _ptr, _ptr],
+    "pnr_morton3d": [_ptr, _u32, _ptr, _ptr],
+    "pnr_morton3d_invert": [_ptr, _u32, _ptr, _ptr],
+    "pnr_packbits": [_ptr, _u32, _f32, _ptr, _ptr],
+    "pnr_march_rays_train": [_ptr, _ptr, _ptr, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                             _ptr, _ptr, _ptr],
+    "pnr_composite_rays_train_forward": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _f32, _ptr, _ptr, _ptr, _ptr],
+    "pnr_composite_rays_train_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _f32, _ptr, _ptr, _ptr],
+    "pnr_composite_rays_flex_train_forward": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _f32, _ptr, _ptr],
+    "pnr_composite_rays_flex_train_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _f32, _ptr, _ptr],
+    "pnr_spread_ray_to_sample": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr],
+    "pnr_march_rays": [_u32, _u32, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "pnr_composite_rays": [_u32, _u32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "pnr_composite_rays_flex": [_u32, _u32, _u32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "pnr_compact_alive": [_u32, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "pnr_grid_encode_forward": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _u32, _ptr, _u32, _int, _int, _ptr],
+    "pnr_grid_encode_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _u32, _ptr, _ptr, _u32, _int, _int, _ptr],
+    "pnr_sh_encode_forward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr],
+    "pnr_sh_encode_backward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr, _ptr],
+    "pnr_rgb_to_hsv": [_u32, _ptr, _ptr, _ptr],
+    "pnr_hsv_to_rgb": [_u32, _ptr, _ptr, _ptr],
+}
+_RESTYPES = {"pnr_error_string": ctypes.c_char_p, "pnr_scan_scratch_bytes": _u64}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises RuntimeError (never falls back) if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"palettenerf_amd: {LIB_PATH} is missing. Build it with `python -m palettenerf_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"palettenerf_amd: symbol {name} missing from {LIB_PATH}; rebuild it") from e
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, _int)
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    """Turn a non-zero C-ABI return into RuntimeError (the reference raises RuntimeError via TORCH_CHECK)."""
+    if rc != 0:
+        msg = load().pnr_error_string(rc)
+        raise RuntimeError(f"{what}: {msg.decode() if msg else rc}")
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    check(rc, name)

@@ -1,0 +1,40 @@
+"""Small helpers shared by the operator modules: pointer extraction, stream lookup, input checks."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("palettenerf_amd: expected a CUDA(HIP) tensor, got a CPU tensor (no CPU fallback exists)")
+
+
+def require(t, dtype, name):
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be a {dtype} tensor")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be a contiguous tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    return t
+
+
+def call(name, *args):
+    _lib.call(name, *args, stream_ptr())
+
+
+def to_cuda(t):
+    return t if t.is_cuda else t.cuda()

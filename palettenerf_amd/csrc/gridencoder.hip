@@ -1,0 +1,396 @@
+// gridencoder.hip -- multiresolution hash / tiled grid encoder for gfx950 (MI355X).
+//
+// Computes what the reference's gridencoder extension computes (cited per kernel).  Host-side
+// differences: the per-level scale/resolution are evaluated once on the host (exp2f of the same
+// libm the oracle uses) and passed by value, so no transcendental runs per thread and the cell a
+// sample falls into cannot depend on the device's exp2 implementation.
+//
+// HBM layout: table [sum_l T_l, C] row-major (fp32 or fp16), offsets int32[L+1], inputs [B,D] fp32
+// in [0,1], outputs [L,B,C] (level-major: a block column works on ONE level so that level's
+// <= 4 MiB table stays resident in the XCD L2s while the samples stream through).
+#include "pnr_common.hpp"
+#include <math.h>
+
+namespace pnr {
+
+constexpr uint32_t kMaxLevels = 32;
+struct LevelParams {
+    float scale[kMaxLevels];
+    uint32_t resolution[kMaxLevels];
+};
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(__half v) { return __half2float(v); }
+
+// reference gridencoder.cu:35-72 (fast_hash + get_grid_index with ch = 0)
+template <uint32_t D, uint32_t C>
+__device__ __forceinline__ uint32_t grid_index(uint32_t gridtype, bool align_corners, uint32_t hashmap_size, uint32_t resolution,
+                                               const uint32_t pg[D]) {
+    constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+    uint32_t stride = 1, index = 0;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        if (stride <= hashmap_size) {
+            index += pg[d] * stride;
+            stride *= align_corners ? resolution : (resolution + 1);
+        }
+    }
+    if (gridtype == 0 && stride > hashmap_size) {
+        index = 0;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) index ^= pg[d] * primes[d];
+    }
+    return (index % hashmap_size) * C;
+}
+
+// accumulate one corner: fp32 table -> fmaf chain; fp16 table -> half accumulator with the
+// reference's two roundings (gridencoder.cu:142,165 with scalar_t = at::Half)
+template <uint32_t C>
+__device__ __forceinline__ void corner_accumulate(float acc[C], float w, const float* __restrict__ g) {
+    if constexpr (C == 2) {
+        const float2 v = *reinterpret_cast<const float2*>(g);
+        acc[0] = fmaf(w, v.x, acc[0]); acc[1] = fmaf(w, v.y, acc[1]);
+    } else if constexpr (C == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(g);
+        acc[0] = fmaf(w, v.x, acc[0]); acc[1] = fmaf(w, v.y, acc[1]); acc[2] = fmaf(w, v.z, acc[2]); acc[3] = fmaf(w, v.w, acc[3]);
+    } else {
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) acc[ch] = fmaf(w, g[ch], acc[ch]);
+    }
+}
+template <uint32_t C>
+__device__ __forceinline__ void corner_accumulate(__half acc[C], float w, const __half* __restrict__ g) {
+    __half v[C];
+    if constexpr (C == 2) {
+        *reinterpret_cast<__half2*>(v) = *reinterpret_cast<const __half2*>(g);
+    } else if constexpr (C == 4) {
+        *reinterpret_cast<uint2*>(v) = *reinterpret_cast<const uint2*>(g);
+    } else if constexpr (C == 8) {
+        *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(g);
+    } else {
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) v[ch] = g[ch];
+    }
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++)
+        acc[ch] = __float2half(__half2float(acc[ch]) + __half2float(__float2half(w * __half2float(v[ch]))));
+}
+
+template <typename T> __device__ __forceinline__ T zero_of();
+template <> __device__ __forceinline__ float zero_of<float>() { return 0.0f; }
+template <> __device__ __forceinline__ __half zero_of<__half>() { return __float2half(0.0f); }
+
+// reference gridencoder.cu:75-223  kernel_grid
+template <typename T, uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(256) k_grid_fwd(const float* __restrict__ inputs, const T* __restrict__ grid,
+                                                  const int32_t* __restrict__ offsets, T* __restrict__ outputs, uint32_t B, uint32_t L,
+                                                  LevelParams lp, T* __restrict__ dy_dx, uint32_t gridtype, bool align_corners) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y;
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    grid += (size_t)off0 * C;
+    inputs += (size_t)b * D;
+    outputs += ((size_t)level * B + b) * C;
+    const float scale = lp.scale[level];
+    const uint32_t resolution = lp.resolution[level];
+
+    float in[D];
+    bool oob = false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) { in[d] = inputs[d]; oob |= (in[d] < 0.0f) | (in[d] > 1.0f); }
+    if (oob) {
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) outputs[ch] = zero_of<T>();
+        if (dy_dx) {
+            T* dd = dy_dx + (size_t)b * D * L * C + (size_t)level * D * C;
+#pragma unroll
+            for (uint32_t i = 0; i < D * C; i++) dd[i] = zero_of<T>();
+        }
+        return;
+    }
+
+    float pos[D];
+    uint32_t pg[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        pos[d] = fmaf(in[d], scale, align_corners ? 0.0f : 0.5f);
+        const float fl = floorf(pos[d]);
+        pg[d] = (uint32_t)fl;
+        pos[d] -= (float)pg[d];
+    }
+
+    // issue all 2^D gathers first (independent loads in flight), then reduce in the reference's order
+    uint32_t idxs[1u << D];
+    float ws[1u << D];
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        float w = 1.0f;
+        uint32_t pl[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            if ((idx & (1u << d)) == 0) { w *= 1.0f - pos[d]; pl[d] = pg[d]; }
+            else { w *= pos[d]; pl[d] = pg[d] + 1; }
+        }
+        ws[idx] = w;
+        idxs[idx] = grid_index<D, C>(gridtype, align_corners, hashmap_size, resolution, pl);
+    }
+    T acc[C];
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) acc[ch] = zero_of<T>();
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) corner_accumulate<C>(acc, ws[idx], grid + idxs[idx]);
+
+    if constexpr (sizeof(T) == 4 && C == 2) {
+        *reinterpret_cast<float2*>(outputs) = make_float2(acc[0], acc[1]);
+    } else if constexpr (sizeof(T) == 2 && C == 2) {
+        *reinterpret_cast<__half2*>(outputs) = *reinterpret_cast<__half2*>(acc);
+    } else {
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) outputs[ch] = acc[ch];
+    }
+
+    if (dy_dx) {  // reference gridencoder.cu:179-222
+        T* dd = dy_dx + (size_t)b * D * L * C + (size_t)level * D * C;
+#pragma unroll
+        for (uint32_t gd = 0; gd < D; gd++) {
+            float ga[C];
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) ga[ch] = 0.0f;
+#pragma unroll
+            for (uint32_t idx = 0; idx < (1u << (D - 1)); idx++) {
+                float w = scale;
+                uint32_t pl[D];
+#pragma unroll
+                for (uint32_t nd = 0; nd < D - 1; nd++) {
+                    const uint32_t d = (nd >= gd) ? nd + 1 : nd;
+                    if ((idx & (1u << nd)) == 0) { w *= 1.0f - pos[d]; pl[d] = pg[d]; }
+                    else { w *= pos[d]; pl[d] = pg[d] + 1; }
+                }
+                pl[gd] = pg[gd];
+                const uint32_t il = grid_index<D, C>(gridtype, align_corners, hashmap_size, resolution, pl);
+                pl[gd] = pg[gd] + 1;
+                const uint32_t ir = grid_index<D, C>(gridtype, align_corners, hashmap_size, resolution, pl);
+#pragma unroll
+                for (uint32_t ch = 0; ch < C; ch++) {
+                    if constexpr (sizeof(T) == 4) ga[ch] = fmaf(w, to_f32(grid[ir + ch]) - to_f32(grid[il + ch]), ga[ch]);
+                    else ga[ch] = __half2float(__float2half(ga[ch] + __half2float(__float2half(w * __half2float(__hsub(grid[ir + ch], grid[il + ch]))))));
+                }
+            }
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) {
+                if constexpr (sizeof(T) == 4) dd[gd * C + ch] = ga[ch];
+                else dd[gd * C + ch] = __float2half(ga[ch]);
+            }
+        }
+    }
+}
+
+// reference gridencoder.cu:226-313  kernel_grid_backward.  One thread scatters all C channels of
+// one (sample, level) with hardware fp32 / packed-fp16 atomics (global_atomic_add_f32 /
+// global_atomic_pk_add_f16) -- no CAS loops.
+template <typename T, uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(256) k_grid_bwd(const T* __restrict__ grad, const float* __restrict__ inputs,
+                                                  const int32_t* __restrict__ offsets, T* __restrict__ grad_grid, uint32_t B, uint32_t L,
+                                                  LevelParams lp, uint32_t gridtype, bool align_corners) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y;
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    grad_grid += (size_t)off0 * C;
+    inputs += (size_t)b * D;
+    grad += ((size_t)level * B + b) * C;
+    const float scale = lp.scale[level];
+    const uint32_t resolution = lp.resolution[level];
+
+    float pos[D];
+    uint32_t pg[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        const float v = inputs[d];
+        if (v < 0.0f || v > 1.0f) return;  // grad_grid is zero-initialised by the caller
+        pos[d] = fmaf(v, scale, align_corners ? 0.0f : 0.5f);
+        const float fl = floorf(pos[d]);
+        pg[d] = (uint32_t)fl;
+        pos[d] -= (float)pg[d];
+    }
+    T g[C];
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) g[ch] = grad[ch];
+
+#pragma unroll
+    for (uint32_t idx = 0; idx < (1u << D); idx++) {
+        float w = 1.0f;
+        uint32_t pl[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            if ((idx & (1u << d)) == 0) { w *= 1.0f - pos[d]; pl[d] = pg[d]; }
+            else { w *= pos[d]; pl[d] = pg[d] + 1; }
+        }
+        const uint32_t index = grid_index<D, C>(gridtype, align_corners, hashmap_size, resolution, pl);
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) unsafeAtomicAdd(reinterpret_cast<float*>(grad_grid) + index + ch, w * to_f32(g[ch]));
+        } else if constexpr (C % 2 == 0) {
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch += 2) {
+                const __half2 v = __halves2half2(__float2half(w * __half2float(g[ch])), __float2half(w * __half2float(g[ch + 1])));
+                unsafeAtomicAdd(reinterpret_cast<__half2*>(reinterpret_cast<__half*>(grad_grid) + index + ch), v);
+            }
+        } else {
+            // C == 1 with an fp16 table: the reference never takes this path either (grid.py:38 keeps
+            // fp32 when C is odd); fall back to a 32-bit CAS on the containing word.
+            __half* addr = reinterpret_cast<__half*>(grad_grid) + index;
+            unsigned int* word = reinterpret_cast<unsigned int*>(reinterpret_cast<uintptr_t>(addr) & ~uintptr_t(3));
+            const bool hi = reinterpret_cast<uintptr_t>(addr) & 2;
+            unsigned int old = *word, assumed;
+            do {
+                assumed = old;
+                __half2 cur = *reinterpret_cast<__half2*>(&assumed);
+                const __half add = __float2half(w * __half2float(g[0]));
+                if (hi) cur = __halves2half2(__low2half(cur), __hadd(__high2half(cur), add));
+                else cur = __halves2half2(__hadd(__low2half(cur), add), __high2half(cur));
+                old = atomicCAS(word, assumed, *reinterpret_cast<unsigned int*>(&cur));
+            } while (assumed != old);
+        }
+    }
+}
+
+// reference gridencoder.cu:316-342  kernel_input_backward
+template <typename T>
+__global__ void __launch_bounds__(256) k_grid_input_bwd(const T* __restrict__ grad, const T* __restrict__ dy_dx, T* __restrict__ grad_inputs,
+                                                        uint32_t B, uint32_t D, uint32_t C, uint32_t L) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * D) return;
+    const uint32_t b = t / D, d = t - b * D;
+    const T* dd = dy_dx + (size_t)b * L * D * C;
+    float r = 0.0f;
+    for (uint32_t l = 0; l < L; l++)
+        for (uint32_t ch = 0; ch < C; ch++) {
+            const float a = to_f32(grad[((size_t)l * B + b) * C + ch]), v = to_f32(dd[l * D * C + d * C + ch]);
+            if constexpr (sizeof(T) == 4) r = fmaf(a, v, r);
+            else r = __half2float(__float2half(r + __half2float(__float2half(a * v))));
+        }
+    if constexpr (sizeof(T) == 4) grad_inputs[t] = r; else grad_inputs[t] = __float2half(r);
+}
+
+static LevelParams make_level_params(uint32_t L, float S, uint32_t H) {
+    LevelParams lp;
+    for (uint32_t l = 0; l < kMaxLevels; l++) { lp.scale[l] = 0; lp.resolution[l] = 0; }
+    for (uint32_t l = 0; l < L; l++) {
+        lp.scale[l] = exp2f((float)l * S) * (float)H - 1.0f;               // gridencoder.cu:125
+        lp.resolution[l] = (uint32_t)ceil((double)lp.scale[l]) + 1;        // gridencoder.cu:126
+    }
+    return lp;
+}
+
+template <typename T, uint32_t D>
+static int launch_fwd_c(const float* inputs, const T* emb, const int32_t* offsets, T* outputs, uint32_t B, uint32_t C, uint32_t L,
+                        const LevelParams& lp, T* dy_dx, uint32_t gridtype, bool ac, hipStream_t s) {
+    const dim3 grid(cdiv(B, 256), L), block(256);
+    switch (C) {
+        case 1: hipLaunchKernelGGL((k_grid_fwd<T, D, 1>), grid, block, 0, s, inputs, emb, offsets, outputs, B, L, lp, dy_dx, gridtype, ac); break;
+        case 2: hipLaunchKernelGGL((k_grid_fwd<T, D, 2>), grid, block, 0, s, inputs, emb, offsets, outputs, B, L, lp, dy_dx, gridtype, ac); break;
+        case 4: hipLaunchKernelGGL((k_grid_fwd<T, D, 4>), grid, block, 0, s, inputs, emb, offsets, outputs, B, L, lp, dy_dx, gridtype, ac); break;
+        case 8: hipLaunchKernelGGL((k_grid_fwd<T, D, 8>), grid, block, 0, s, inputs, emb, offsets, outputs, B, L, lp, dy_dx, gridtype, ac); break;
+        default: return PNR_ERR_UNSUPPORTED;  // "GridEncoding: C must be 1, 2, 4, or 8." (gridencoder.cu:354)
+    }
+    return check_launch();
+}
+template <typename T>
+static int launch_fwd(const float* inputs, const T* emb, const int32_t* offsets, T* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                      const LevelParams& lp, T* dy_dx, uint32_t gridtype, bool ac, hipStream_t s) {
+    switch (D) {
+        case 1: return launch_fwd_c<T, 1>(inputs, emb, offsets, outputs, B, C, L, lp, dy_dx, gridtype, ac, s);
+        case 2: return launch_fwd_c<T, 2>(inputs, emb, offsets, outputs, B, C, L, lp, dy_dx, gridtype, ac, s);
+        case 3: return launch_fwd_c<T, 3>(inputs, emb, offsets, outputs, B, C, L, lp, dy_dx, gridtype, ac, s);
+        case 4: return launch_fwd_c<T, 4>(inputs, emb, offsets, outputs, B, C, L, lp, dy_dx, gridtype, ac, s);
+        case 5: return launch_fwd_c<T, 5>(inputs, emb, offsets, outputs, B, C, L, lp, dy_dx, gridtype, ac, s);
+        default: return PNR_ERR_UNSUPPORTED;  // "GridEncoding: D must be 1, 2, 3, 4, or 5." (gridencoder.cu:372)
+    }
+}
+
+template <typename T, uint32_t D>
+static int launch_bwd_c(const T* grad, const float* inputs, const int32_t* offsets, T* gg, uint32_t B, uint32_t C, uint32_t L,
+                        const LevelParams& lp, uint32_t gridtype, bool ac, hipStream_t s) {
+    const dim3 grid(cdiv(B, 256), L), block(256);
+    switch (C) {
+        case 1: hipLaunchKernelGGL((k_grid_bwd<T, D, 1>), grid, block, 0, s, grad, inputs, offsets, gg, B, L, lp, gridtype, ac); break;
+        case 2: hipLaunchKernelGGL((k_grid_bwd<T, D, 2>), grid, block, 0, s, grad, inputs, offsets, gg, B, L, lp, gridtype, ac); break;
+        case 4: hipLaunchKernelGGL((k_grid_bwd<T, D, 4>), grid, block, 0, s, grad, inputs, offsets, gg, B, L, lp, gridtype, ac); break;
+        case 8: hipLaunchKernelGGL((k_grid_bwd<T, D, 8>), grid, block, 0, s, grad, inputs, offsets, gg, B, L, lp, gridtype, ac); break;
+        default: return PNR_ERR_UNSUPPORTED;
+    }
+    return check_launch();
+}
+template <typename T>
+static int launch_bwd(const T* grad, const float* inputs, const int32_t* offsets, T* gg, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                      const LevelParams& lp, uint32_t gridtype, bool ac, hipStream_t s) {
+    switch (D) {
+        case 1: return launch_bwd_c<T, 1>(grad, inputs, offsets, gg, B, C, L, lp, gridtype, ac, s);
+        case 2: return launch_bwd_c<T, 2>(grad, inputs, offsets, gg, B, C, L, lp, gridtype, ac, s);
+        case 3: return launch_bwd_c<T, 3>(grad, inputs, offsets, gg, B, C, L, lp, gridtype, ac, s);
+        case 4: return launch_bwd_c<T, 4>(grad, inputs, offsets, gg, B, C, L, lp, gridtype, ac, s);
+        case 5: return launch_bwd_c<T, 5>(grad, inputs, offsets, gg, B, C, L, lp, gridtype, ac, s);
+        default: return PNR_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace pnr
+
+using namespace pnr;
+
+extern "C" {
+
+int pnr_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B, uint32_t D,
+                            uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx, uint32_t gridtype, int align_corners, int dtype,
+                            pnr_stream_t stream) {
+    if (L == 0 || L > kMaxLevels) return PNR_ERR_UNSUPPORTED;
+    if (dtype != PNR_DTYPE_F32 && dtype != PNR_DTYPE_F16) return PNR_ERR_UNSUPPORTED;
+    if (B == 0) return PNR_OK;
+    if (!inputs || !embeddings || !offsets || !outputs) return PNR_ERR_INVALID;
+    const LevelParams lp = make_level_params(L, S, H);
+    if (dtype == PNR_DTYPE_F32)
+        return launch_fwd<float>(inputs, static_cast<const float*>(embeddings), offsets, static_cast<float*>(outputs), B, D, C, L, lp,
+                                 static_cast<float*>(dy_dx), gridtype, align_corners != 0, as_stream(stream));
+    return launch_fwd<__half>(inputs, static_cast<const __half*>(embeddings), offsets, static_cast<__half*>(outputs), B, D, C, L, lp,
+                              static_cast<__half*>(dy_dx), gridtype, align_corners != 0, as_stream(stream));
+}
+
+int pnr_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets, void* grad_embeddings,
+                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const void* dy_dx, void* grad_inputs,
+                             uint32_t gridtype, int align_corners, int dtype, pnr_stream_t stream) {
+    (void)embeddings;  // the reference passes it but its kernel never reads it (gridencoder.cu:230)
+    if (L == 0 || L > kMaxLevels) return PNR_ERR_UNSUPPORTED;
+    if (dtype != PNR_DTYPE_F32 && dtype != PNR_DTYPE_F16) return PNR_ERR_UNSUPPORTED;
+    if (D < 1 || D > 5) return PNR_ERR_UNSUPPORTED;
+    if (C != 1 && C != 2 && C != 4 && C != 8) return PNR_ERR_UNSUPPORTED;
+    if (B == 0) return PNR_OK;
+    if (!grad || !inputs || !offsets || !grad_embeddings) return PNR_ERR_INVALID;
+    if ((dy_dx == nullptr) != (grad_inputs == nullptr)) return PNR_ERR_INVALID;
+    const LevelParams lp = make_level_params(L, S, H);
+    hipStream_t s = as_stream(stream);
+    int rc;
+    if (dtype == PNR_DTYPE_F32) {
+        rc = launch_bwd<float>(static_cast<const float*>(grad), inputs, offsets, static_cast<float*>(grad_embeddings), B, D, C, L, lp, gridtype,
+                               align_corners != 0, s);
+        if (rc == PNR_OK && dy_dx) {
+            hipLaunchKernelGGL(k_grid_input_bwd<float>, dim3(cdiv(B * D, 256)), dim3(256), 0, s, static_cast<const float*>(grad),
+                               static_cast<const float*>(dy_dx), static_cast<float*>(grad_inputs), B, D, C, L);
+            rc = check_launch();
+        }
+    } else {
+        rc = launch_bwd<__half>(static_cast<const __half*>(grad), inputs, offsets, static_cast<__half*>(grad_embeddings), B, D, C, L, lp,
+                                gridtype, align_corners != 0, s);
+        if (rc == PNR_OK && dy_dx) {
+            hipLaunchKernelGGL(k_grid_input_bwd<__half>, dim3(cdiv(B * D, 256)), dim3(256), 0, s, static_cast<const __half*>(grad),
+                               static_cast<const __half*>(dy_dx), static_cast<__half*>(grad_inputs), B, D, C, L);
+            rc = check_launch();
+        }
+    }
+    return rc;
+}
+
+}  // extern "C"

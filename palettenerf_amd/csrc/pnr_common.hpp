@@ -1,0 +1,71 @@
+// pnr_common.hpp -- device-side scalar helpers and launch plumbing shared by the gfx950 kernels.
+//
+// Canonical scalar spec (DESIGN.md "Scalar semantics"): IEEE fp32, translation units are built
+// with -ffp-contract=off, and every contraction the reference's nvcc build performs is written
+// as an explicit fmaf().  Wavefront width is 64 everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include "../../include/pnr.h"
+
+#define PNR_WAVE 64
+
+namespace pnr {
+
+inline int check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PNR_OK : PNR_ERR_LAUNCH;
+}
+inline hipStream_t as_stream(pnr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
+__device__ __forceinline__ float signf(float x) { return copysignf(1.0f, x); }
+
+// 10-bit-per-axis bit interleave (reference raymarching.cu:59-84)
+__host__ __device__ __forceinline__ uint32_t spread3(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__host__ __device__ __forceinline__ uint32_t morton3(uint32_t x, uint32_t y, uint32_t z) {
+    return spread3(x) | (spread3(y) << 1) | (spread3(z) << 2);
+}
+__host__ __device__ __forceinline__ uint32_t gather3(uint32_t x) {
+    x &= 0x49249249u;
+    x = (x | (x >> 2)) & 0xc30c30c3u;
+    x = (x | (x >> 4)) & 0x0f00f00fu;
+    x = (x | (x >> 8)) & 0xff0000ffu;
+    x = (x | (x >> 16)) & 0x0000ffffu;
+    return x;
+}
+
+// cascade level selectors (reference raymarching.cu:45-57)
+__device__ __forceinline__ int mip_from_pos(float x, float y, float z, float max_cascade) {
+    const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+    int e;
+    frexpf(mx, &e);
+    return (int)fminf(max_cascade - 1.0f, fmaxf(0.0f, (float)e));
+}
+__device__ __forceinline__ int mip_from_dt(float dt, float H, float max_cascade) {
+    const float mx = (dt * H) * 0.5f;  // the reference multiplies by a double 0.5: exact either way
+    int e;
+    frexpf(mx, &e);
+    return (int)fminf(max_cascade - 1.0f, fmaxf(0.0f, (float)e));
+}
+
+// wave64 inclusive prefix sum of an int (DPP-free, shuffle based)
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+    const int lane = threadIdx.x & (PNR_WAVE - 1);
+#pragma unroll
+    for (int off = 1; off < PNR_WAVE; off <<= 1) {
+        int n = __shfl_up(v, off, PNR_WAVE);
+        if (lane >= off) v += n;
+    }
+    return v;
+}
+
+}  // namespace pnr

@@ -1,0 +1,126 @@
+"""Fields evaluated per sample on the hot path: `NeRFNetwork` (nerf/network.py:10-143) and
+`PaletteNetwork` (palette/network.py:10-280).  Same module/parameter names as the reference so a
+reference checkpoint's state_dict loads (encoder.embeddings, sigma_net.N.weight, color_net.N.weight,
+diff_net, basis_net, offsets_radiance_net, omega_net.0, encoder_palette, encoder_clip, clip_net,
+basis_color, density_grid, density_bitfield, aabb_*, step_counter).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .activation import trunc_exp
+from .encoding import get_encoder
+from .renderer import NeRFRenderer, PaletteRenderer
+
+
+def _mlp(dims):
+    """Bias-free Linear stack (nerf/network.py:33-47); activations are applied by the caller."""
+    return nn.ModuleList([nn.Linear(dims[i], dims[i + 1], bias=False) for i in range(len(dims) - 1)])
+
+
+def _run(net, h, act=F.relu):
+    for i, layer in enumerate(net):
+        h = layer(h)
+        if i != len(net) - 1:
+            h = act(h, inplace=True)
+    return h
+
+
+class NeRFNetwork(NeRFRenderer):
+    def __init__(self, encoding="hashgrid", encoding_dir="sphere_harmonics", num_layers=2, hidden_dim=64, geo_feat_dim=15,
+                 num_layers_color=3, hidden_dim_color=64, bound=1, **kwargs):
+        super().__init__(bound, **kwargs)
+        if self.bg_radius > 0:
+            raise NotImplementedError("background model (bg_radius > 0) is out of scope: every shipped scene config sets bg_radius=0")
+        self.num_layers, self.hidden_dim, self.geo_feat_dim = num_layers, hidden_dim, geo_feat_dim
+        self.num_layers_color, self.hidden_dim_color = num_layers_color, hidden_dim_color
+        self.encoder, self.in_dim = get_encoder(encoding, desired_resolution=2048 * bound)
+        self.sigma_net = _mlp([self.in_dim] + [hidden_dim] * (num_layers - 1) + [1 + geo_feat_dim])
+        self.encoder_dir, self.in_dim_dir = get_encoder(encoding_dir)
+        self.color_net = _mlp([self.in_dim_dir + geo_feat_dim] + [hidden_dim_color] * (num_layers_color - 1) + [3])
+        self.bg_net = None
+
+    def forward(self, x, d):
+        """x: [N,3] in [-bound,bound]; d: [N,3] unit.  Returns (sigma [N], rgb [N,3]).  nerf/network.py:95-124"""
+        h = _run(self.sigma_net, self.encoder(x, bound=self.bound))
+        sigma = trunc_exp(h[..., 0])
+        geo_feat = h[..., 1:]
+        h = _run(self.color_net, torch.cat([self.encoder_dir(d), geo_feat], dim=-1))
+        return sigma, torch.sigmoid(h)
+
+    def density(self, x):
+        """nerf/network.py:126-143"""
+        h = _run(self.sigma_net, self.encoder(x, bound=self.bound))
+        return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
+
+    def get_params(self, lr):
+        """nerf/network.py:186-206"""
+        return [{"params": self.encoder.parameters(), "lr": lr}, {"params": self.sigma_net.parameters(), "lr": lr},
+                {"params": self.encoder_dir.parameters(), "lr": lr}, {"params": self.color_net.parameters(), "lr": lr}]
+
+
+class PaletteNetwork(PaletteRenderer):
+    def __init__(self, opt, encoding="hashgrid", encoding_dir="sphere_harmonics", num_layers=2, hidden_dim=64, geo_feat_dim=15,
+                 num_layers_color=3, hidden_dim_color=64, bound=1, **kwargs):
+        super().__init__(opt, bound, **kwargs)
+        if self.bg_radius > 0:
+            raise NotImplementedError("background model (bg_radius > 0) is out of scope: every shipped scene config sets bg_radius=0")
+        self.num_layers, self.hidden_dim, self.geo_feat_dim = num_layers, hidden_dim, geo_feat_dim
+        self.num_layers_color, self.hidden_dim_color = num_layers_color, hidden_dim_color
+        self.encoder, self.in_dim = get_encoder(encoding, desired_resolution=2048 * bound)
+        self.encoder_palette, self.in_dim_palette = get_encoder(encoding, desired_resolution=2048 * bound)
+        self.encoder_clip, self.in_dim_clip = get_encoder(encoding, desired_resolution=2048 * bound)
+        self.num_basis = opt.num_basis
+        self.sigma_net = _mlp([self.in_dim] + [hidden_dim] * (num_layers - 1) + [1 + geo_feat_dim])
+        self.encoder_dir, self.in_dim_dir = get_encoder(encoding_dir)
+        # named color_net so that the vanilla NeRF checkpoint's colour head loads (palette/network.py:58-59)
+        self.color_net = _mlp([self.in_dim_dir + geo_feat_dim] + [hidden_dim] * (num_layers_color - 1) + [3])
+        self.diff_net = _mlp([geo_feat_dim] + [hidden_dim] * (num_layers_color - 1) + [3])
+        self.basis_net = _mlp([self.in_dim_palette + 3] + [hidden_dim] * (num_layers - 1) + [geo_feat_dim])
+        self.offsets_radiance_net = nn.Linear(geo_feat_dim, self.num_basis * 3 + 1)  # the only layer with a bias
+        self.omega_net = nn.Sequential(nn.Linear(geo_feat_dim, self.num_basis, bias=False), nn.Softplus())
+        if opt.pred_clip:
+            self.clip_net = _mlp([self.in_dim_clip] + [hidden_dim] * (num_layers - 1) + [opt.clip_dim])
+        self.bg_net = None
+
+    def forward(self, x, d):
+        """palette/network.py:156-185.  Returns sigma, clip_feat, omega, offsets_radiance, view_dep, diffuse."""
+        h = _run(self.sigma_net, self.encoder(x, bound=self.bound))
+        sigma = trunc_exp(h[..., 0])
+        geo_feat = h[..., 1:].detach()
+        if self.opt.pred_clip:
+            clip_feat = _run(self.clip_net, self.encoder_clip(x, bound=self.bound))
+        else:
+            clip_feat = torch.zeros_like(sigma[..., None].repeat(1, self.opt.clip_dim))
+        omega, offsets_radiance, view_dep, diffuse = self.color(x, d, geo_feat=geo_feat)
+        return sigma, clip_feat, omega, offsets_radiance, view_dep, diffuse
+
+    def density(self, x):
+        h = _run(self.sigma_net, self.encoder(x, bound=self.bound))
+        return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
+
+    def color(self, x, d, mask=None, geo_feat=None, **kwargs):
+        """palette/network.py:223-280 (unmasked form: the march path never passes a mask)."""
+        if mask is not None:
+            raise NotImplementedError("masked colour queries belong to the non-cuda_ray path, which is dead code in the reference")
+        g = geo_feat.detach()
+        diffuse = torch.sigmoid(_run(self.diff_net, g))
+        view_dep = torch.sigmoid(_run(self.color_net, torch.cat([self.encoder_dir(d), g], dim=-1)))
+        h = torch.cat([self.encoder_palette(x, bound=self.bound), diffuse.detach()], dim=-1)
+        h = _run(self.basis_net, h, act=F.elu)
+        offsets_radiance = self.offsets_radiance_net(h)
+        omega = self.omega_net(h) + 0.05
+        omega = omega / omega.sum(dim=-1, keepdim=True)
+        return omega, offsets_radiance, view_dep, diffuse
+
+    def get_params(self, lr):
+        """palette/network.py:283-308 -- basis_net (and clip_net unless pred_clip) are deliberately absent (quirk 8)."""
+        params = [{"params": m.parameters(), "lr": lr} for m in
+                  (self.encoder, self.encoder_palette, self.encoder_clip, self.sigma_net, self.encoder_dir, self.color_net, self.diff_net,
+                   self.offsets_radiance_net, self.omega_net)]
+        params.append({"params": self.basis_color, "lr": lr})
+        if self.opt.use_initialization_from_rgbxy and hasattr(self, "hist_weights"):
+            params.append({"params": self.hist_weights, "lr": lr})
+        if self.opt.pred_clip:
+            params.append({"params": self.clip_net.parameters(), "lr": lr})
+        return params

@@ -1,0 +1,319 @@
+"""Operator API of the ray-marching path -- same callables, argument order, defaults and return
+conventions as the reference's raymarching/raymarching.py (cited per function), backed by the
+gfx950 kernels behind the C ABI (include/pnr.h).  PyTorch is used for device memory, streams and
+autograd plumbing only.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.amp import custom_bwd, custom_fwd
+
+from . import _lib
+from ._torch_glue import call, ptr, require, to_cuda
+
+_u32, _f32 = ctypes.c_uint32, ctypes.c_float
+_fwd32 = custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_bwd = custom_bwd(device_type="cuda")
+
+
+def _scratch(n, device):
+    nbytes = int(_lib.load().pnr_scan_scratch_bytes(int(n)))
+    return torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=device)
+
+
+# ---------------------------------------------------------------------------- utils
+class _near_far_from_aabb(Function):
+    """raymarching/raymarching.py:19-49"""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, rays_o, rays_d, aabb, min_near=0.2):
+        rays_o = to_cuda(rays_o).contiguous().view(-1, 3)
+        rays_d = to_cuda(rays_d).contiguous().view(-1, 3)
+        aabb = to_cuda(aabb).contiguous()
+        N = rays_o.shape[0]
+        nears = torch.empty(N, dtype=rays_o.dtype, device=rays_o.device)
+        fars = torch.empty(N, dtype=rays_o.dtype, device=rays_o.device)
+        call("pnr_near_far_from_aabb", ptr(require(rays_o, torch.float32, "rays_o")), ptr(require(rays_d, torch.float32, "rays_d")),
+             ptr(require(aabb, torch.float32, "aabb")), _u32(N), _f32(min_near), ptr(nears), ptr(fars))
+        return nears, fars
+
+
+near_far_from_aabb = _near_far_from_aabb.apply
+
+
+class _sph_from_ray(Function):
+    """raymarching/raymarching.py:52-80"""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, rays_o, rays_d, radius):
+        rays_o = to_cuda(rays_o).contiguous().view(-1, 3)
+        rays_d = to_cuda(rays_d).contiguous().view(-1, 3)
+        N = rays_o.shape[0]
+        coords = torch.empty(N, 2, dtype=rays_o.dtype, device=rays_o.device)
+        call("pnr_sph_from_ray", ptr(require(rays_o, torch.float32, "rays_o")), ptr(require(rays_d, torch.float32, "rays_d")),
+             _f32(radius), _u32(N), ptr(coords))
+        return coords
+
+
+sph_from_ray = _sph_from_ray.apply
+
+
+class _morton3D(Function):
+    """raymarching/raymarching.py:83-104"""
+
+    @staticmethod
+    def forward(ctx, coords):
+        coords = to_cuda(coords).int().contiguous()
+        N = coords.shape[0]
+        indices = torch.empty(N, dtype=torch.int32, device=coords.device)
+        call("pnr_morton3d", ptr(coords), _u32(N), ptr(indices))
+        return indices
+
+
+morton3D = _morton3D.apply
+
+
+class _morton3D_invert(Function):
+    """raymarching/raymarching.py:106-126"""
+
+    @staticmethod
+    def forward(ctx, indices):
+        indices = to_cuda(indices).int().contiguous()
+        N = indices.shape[0]
+        coords = torch.empty(N, 3, dtype=torch.int32, device=indices.device)
+        call("pnr_morton3d_invert", ptr(indices), _u32(N), ptr(coords))
+        return coords
+
+
+morton3D_invert = _morton3D_invert.apply
+
+
+class _packbits(Function):
+    """raymarching/raymarching.py:129-155"""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, grid, thresh, bitfield=None):
+        grid = to_cuda(grid).contiguous()
+        C, H3 = grid.shape[0], grid.shape[1]
+        N = C * H3 // 8
+        if bitfield is None:
+            bitfield = torch.empty(N, dtype=torch.uint8, device=grid.device)
+        call("pnr_packbits", ptr(require(grid, torch.float32, "grid")), _u32(N), _f32(thresh), ptr(require(bitfield, torch.uint8, "bitfield")))
+        return bitfield
+
+
+packbits = _packbits.apply
+
+
+# ---------------------------------------------------------------------------- training
+class _march_rays_train(Function):
+    """raymarching/raymarching.py:161-235.  Same outputs; sample offsets and the row order of `rays`
+    are deterministic (prefix sum: row n == ray n) instead of atomics-ordered."""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1, perturb=False,
+                align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024):
+        rays_o = to_cuda(rays_o).contiguous().view(-1, 3)
+        rays_d = to_cuda(rays_d).contiguous().view(-1, 3)
+        density_bitfield = to_cuda(density_bitfield).contiguous()
+        dev = rays_o.device
+        N = rays_o.shape[0]
+        M = N * max_steps
+        if not force_all_rays and mean_count > 0:
+            if align > 0:
+                mean_count += align - mean_count % align
+            M = mean_count
+        xyzs = torch.zeros(M, 3, dtype=rays_o.dtype, device=dev)
+        dirs = torch.zeros(M, 3, dtype=rays_o.dtype, device=dev)
+        deltas = torch.zeros(M, 2, dtype=rays_o.dtype, device=dev)
+        rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
+        if step_counter is None:
+            step_counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        if perturb:
+            noises = torch.rand(N, dtype=rays_o.dtype, device=dev)
+        else:
+            noises = torch.zeros(N, dtype=rays_o.dtype, device=dev)
+        scratch = _scratch(N, dev)
+        call("pnr_march_rays_train", ptr(require(rays_o, torch.float32, "rays_o")), ptr(require(rays_d, torch.float32, "rays_d")),
+             ptr(require(density_bitfield, torch.uint8, "density_bitfield")), _f32(bound), _f32(dt_gamma), _u32(max_steps), _u32(N),
+             _u32(C), _u32(H), _u32(M), ptr(require(nears, torch.float32, "nears")), ptr(require(fars, torch.float32, "fars")),
+             ptr(xyzs), ptr(dirs), ptr(deltas), ptr(rays), ptr(require(step_counter, torch.int32, "step_counter")), ptr(noises),
+             ptr(scratch))
+        if force_all_rays or mean_count <= 0:
+            m = step_counter[0].item()
+            if align > 0:
+                m += align - m % align
+            xyzs, dirs, deltas = xyzs[:m], dirs[:m], deltas[:m]
+        return xyzs, dirs, deltas, rays
+
+
+march_rays_train = _march_rays_train.apply
+
+
+class _composite_rays_train(Function):
+    """raymarching/raymarching.py:238-291"""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, sigmas, rgbs, deltas, rays, T_thresh=1e-4):
+        sigmas, rgbs, deltas = sigmas.contiguous(), rgbs.contiguous(), deltas.contiguous()
+        M, N = sigmas.shape[0], rays.shape[0]
+        weights_sum = torch.empty(N, dtype=sigmas.dtype, device=sigmas.device)
+        depth = torch.empty(N, dtype=sigmas.dtype, device=sigmas.device)
+        image = torch.empty(N, 3, dtype=sigmas.dtype, device=sigmas.device)
+        call("pnr_composite_rays_train_forward", ptr(require(sigmas, torch.float32, "sigmas")), ptr(require(rgbs, torch.float32, "rgbs")),
+             ptr(require(deltas, torch.float32, "deltas")), ptr(require(rays, torch.int32, "rays")), _u32(M), _u32(N), _f32(T_thresh),
+             ptr(weights_sum), ptr(depth), ptr(image))
+        ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, depth, image)
+        ctx.dims = [M, N, T_thresh]
+        return weights_sum, depth, image
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, grad_weights_sum, grad_depth, grad_image):
+        # grad_depth is ignored, as in the reference (raymarching.py:275)
+        grad_weights_sum, grad_image = grad_weights_sum.contiguous(), grad_image.contiguous()
+        sigmas, rgbs, deltas, rays, weights_sum, depth, image = ctx.saved_tensors
+        M, N, T_thresh = ctx.dims
+        grad_sigmas, grad_rgbs = torch.zeros_like(sigmas), torch.zeros_like(rgbs)
+        call("pnr_composite_rays_train_backward", ptr(require(grad_weights_sum, torch.float32, "grad_weights_sum")),
+             ptr(require(grad_image, torch.float32, "grad_image")), ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays), ptr(weights_sum),
+             ptr(image), _u32(M), _u32(N), _f32(T_thresh), ptr(grad_sigmas), ptr(grad_rgbs))
+        return grad_sigmas, grad_rgbs, None, None, None
+
+
+composite_rays_train = _composite_rays_train.apply
+
+
+class _composite_rays_flex_train(Function):
+    """raymarching/raymarching.py:294-341"""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, sigmas, input, deltas, rays, T_thresh=1e-4):
+        sigmas, input, deltas = sigmas.contiguous(), input.contiguous(), deltas.contiguous()
+        M, N, n_channel = sigmas.shape[0], rays.shape[0], input.shape[-1]
+        output = torch.empty(N, n_channel, dtype=sigmas.dtype, device=sigmas.device)
+        call("pnr_composite_rays_flex_train_forward", ptr(require(sigmas, torch.float32, "sigmas")),
+             ptr(require(input, torch.float32, "input")), ptr(require(deltas, torch.float32, "deltas")),
+             ptr(require(rays, torch.int32, "rays")), _u32(M), _u32(N), _u32(n_channel), _f32(T_thresh), ptr(output))
+        ctx.save_for_backward(sigmas, input, deltas, rays, output)
+        ctx.dims = [M, N, n_channel, T_thresh]
+        return output
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, grad_output):
+        grad_output = grad_output.contiguous()
+        sigmas, input, deltas, rays, output = ctx.saved_tensors
+        M, N, n_channel, T_thresh = ctx.dims
+        grad_input = torch.zeros_like(input)
+        call("pnr_composite_rays_flex_train_backward", ptr(require(grad_output, torch.float32, "grad_output")), ptr(sigmas), ptr(input),
+             ptr(deltas), ptr(rays), ptr(output), _u32(M), _u32(N), _u32(n_channel), _f32(T_thresh), ptr(grad_input))
+        return None, grad_input, None, None, None
+
+
+composite_rays_flex_train = _composite_rays_flex_train.apply
+
+
+# ---------------------------------------------------------------------------- inference
+class _march_rays(Function):
+    """raymarching/raymarching.py:347-398 (including the always-pad alignment, :381-382)"""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, near, far, align=-1,
+                perturb=False, dt_gamma=0, max_steps=1024):
+        rays_o = to_cuda(rays_o).contiguous().view(-1, 3)
+        rays_d = to_cuda(rays_d).contiguous().view(-1, 3)
+        dev = rays_o.device
+        M = n_alive * n_step
+        if align > 0:
+            M += align - (M % align)
+        xyzs = torch.zeros(M, 3, dtype=rays_o.dtype, device=dev)
+        dirs = torch.zeros(M, 3, dtype=rays_o.dtype, device=dev)
+        deltas = torch.zeros(M, 2, dtype=rays_o.dtype, device=dev)
+        if perturb:
+            noises = torch.rand(n_alive, dtype=rays_o.dtype, device=dev)
+        else:
+            noises = torch.zeros(n_alive, dtype=rays_o.dtype, device=dev)
+        call("pnr_march_rays", _u32(n_alive), _u32(n_step), ptr(require(rays_alive, torch.int32, "rays_alive")),
+             ptr(require(rays_t, torch.float32, "rays_t")), ptr(require(rays_o, torch.float32, "rays_o")),
+             ptr(require(rays_d, torch.float32, "rays_d")), _f32(bound), _f32(dt_gamma), _u32(max_steps), _u32(C), _u32(H),
+             ptr(require(density_bitfield, torch.uint8, "density_bitfield")), ptr(require(near, torch.float32, "near")),
+             ptr(require(far, torch.float32, "far")), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(noises))
+        return xyzs, dirs, deltas
+
+
+march_rays = _march_rays.apply
+
+
+class _composite_rays(Function):
+    """raymarching/raymarching.py:401-423 (in place; returns an empty tuple)"""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh=1e-2):
+        sigmas, rgbs, deltas = sigmas.contiguous(), rgbs.contiguous(), deltas.contiguous()
+        call("pnr_composite_rays", _u32(n_alive), _u32(n_step), _f32(T_thresh), ptr(require(rays_alive, torch.int32, "rays_alive")),
+             ptr(require(rays_t, torch.float32, "rays_t")), ptr(require(sigmas, torch.float32, "sigmas")),
+             ptr(require(rgbs, torch.float32, "rgbs")), ptr(require(deltas, torch.float32, "deltas")),
+             ptr(require(weights_sum, torch.float32, "weights_sum")), ptr(require(depth, torch.float32, "depth")),
+             ptr(require(image, torch.float32, "image")))
+        return tuple()
+
+
+composite_rays = _composite_rays.apply
+
+
+class _composite_rays_flex(Function):
+    """raymarching/raymarching.py:425-447 (in place on `output`)"""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, n_alive, n_step, n_channel, rays_alive, rays_t, sigmas, input, deltas, weights_sum, output, T_thresh=1e-2):
+        sigmas, input, deltas = sigmas.contiguous(), input.contiguous(), deltas.contiguous()
+        call("pnr_composite_rays_flex", _u32(n_alive), _u32(n_step), _u32(n_channel), _f32(T_thresh),
+             ptr(require(rays_alive, torch.int32, "rays_alive")), ptr(require(rays_t, torch.float32, "rays_t")),
+             ptr(require(sigmas, torch.float32, "sigmas")), ptr(require(input, torch.float32, "input")),
+             ptr(require(deltas, torch.float32, "deltas")), ptr(require(weights_sum, torch.float32, "weights_sum")),
+             ptr(require(output, torch.float32, "output")))
+        return tuple()
+
+
+composite_rays_flex = _composite_rays_flex.apply
+
+
+class _spread_ray_to_sample(Function):
+    """raymarching/raymarching.py:451-473"""
+
+    @staticmethod
+    @_fwd32
+    def forward(ctx, input, rays, output):
+        input = input.contiguous()
+        N, M, n_channel = input.shape[0], output.shape[0], input.shape[-1]
+        call("pnr_spread_ray_to_sample", ptr(require(input, torch.float32, "input")), ptr(require(rays, torch.int32, "rays")), _u32(M),
+             _u32(N), _u32(n_channel), ptr(require(output, torch.float32, "output")))
+        return tuple()
+
+
+spread_ray_to_sample = _spread_ray_to_sample.apply
+
+
+# ---------------------------------------------------------------------------- MI355X-first additions
+def compact_alive(rays_alive, n_alive=None, out=None, count=None):
+    """Device-side, order-preserving replacement of `rays_alive[rays_alive >= 0]`
+    (nerf/renderer.py:376).  Returns (compacted ids buffer, device int32[1] count); no host sync."""
+    n = rays_alive.shape[0] if n_alive is None else n_alive
+    if out is None:
+        out = torch.empty_like(rays_alive)
+    if count is None:
+        count = torch.empty(1, dtype=torch.int32, device=rays_alive.device)
+    scratch = _scratch(max(n, 1), rays_alive.device)
+    call("pnr_compact_alive", _u32(n), ptr(require(rays_alive, torch.int32, "rays_alive")), ptr(out), ptr(count), ptr(scratch))
+    return out, count

@@ -1,0 +1,438 @@
+"""Host-side mirror of the reference's renderer classes for the occupancy-march path:
+`NeRFRenderer.run_cuda` (nerf/renderer.py:258-393) and `PaletteRenderer.run_cuda`
+(palette/renderer.py:296-552), with the same constructor arguments, buffers (state_dict names),
+keyword arguments and result dictionaries.
+
+Two execution modes for inference frames:
+  * "compat"  -- the reference's host-driven loop, step for step (one host sync per iteration for
+                 the boolean-mask compaction); used for parity against golden frames.
+  * "device"  -- same arithmetic and the same n_step schedule, but the alive list is compacted on
+                 the GPU (wave64 ballot + prefix sum) and n_alive only crosses to the host once per
+                 iteration through a pinned 4-byte read-back of the already-computed count.
+The pure-PyTorch (`cuda_ray=False`) renderer of the reference is dead code there
+ and is not mirrored here.
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import raymarching
+from .palette_utils import hsv_to_rgb, rgb_to_hsv
+
+
+def default_opt(**kw):
+    """The subset of main_palette.py's argparse namespace the hot path reads (main_palette.py:16-101)."""
+    opt = SimpleNamespace(num_basis=4, clip_dim=16, pred_clip=False, use_initialization_from_rgbxy=False, test=True,
+                          color_space="srgb", smooth_sigma_xyz=0.005, smooth_sigma_color=0.2, smooth_sigma_clip=0.0)
+    for k, v in kw.items():
+        setattr(opt, k, v)
+    return opt
+
+
+class _MarchState:
+    """Per-frame state of the inference loop (nerf/renderer.py:344-350)."""
+
+    def __init__(self, N, nears, device):
+        self.N = N
+        self.weights_sum = torch.zeros(N, dtype=torch.float32, device=device)
+        self.depth = torch.zeros(N, dtype=torch.float32, device=device)
+        self.image = torch.zeros(N, 3, dtype=torch.float32, device=device)
+        self.rays_alive = torch.arange(N, dtype=torch.int32, device=device)
+        self.rays_t = nears.clone()
+        self.n_samples = 0  # evaluated rows (incl. padding), host-side bookkeeping only
+
+
+class _RendererBase(nn.Module):
+    def _init_march_state(self, bound, cuda_ray, density_scale, min_near, density_thresh, bg_radius):
+        self.bound = bound
+        self.cascade = 1 + math.ceil(math.log2(bound))
+        self.grid_size = 128
+        self.density_scale = density_scale
+        self.min_near = min_near
+        self.density_thresh = density_thresh
+        self.bg_radius = bg_radius
+        self.march_mode = "compat"
+        aabb_train = torch.FloatTensor([-bound, -bound, -bound, bound, bound, bound])
+        self.register_buffer("aabb_train", aabb_train)
+        self.register_buffer("aabb_infer", aabb_train.clone())
+        self.cuda_ray = cuda_ray
+        if cuda_ray:
+            self.register_buffer("density_grid", torch.zeros([self.cascade, self.grid_size ** 3]))
+            self.register_buffer("density_bitfield", torch.zeros(self.cascade * self.grid_size ** 3 // 8, dtype=torch.uint8))
+            self.mean_density = 0
+            self.iter_density = 0
+            self.register_buffer("step_counter", torch.zeros(16, 2, dtype=torch.int32))
+            self.mean_count = 0
+            self.local_step = 0
+
+    def reset_extra_state(self):
+        if not self.cuda_ray:
+            return
+        self.density_grid.zero_()
+        self.mean_density = 0
+        self.iter_density = 0
+        self.step_counter.zero_()
+        self.mean_count = 0
+        self.local_step = 0
+
+    # ------------------------------------------------------------------ shared inference loop
+    def _infer_loop(self, rays_o, rays_d, nears, fars, perturb, dt_gamma, max_steps, shade):
+        """while step < max_steps: march -> shade(...) -> compaction (nerf/renderer.py:354-380).
+        `shade(st, n_alive, n_step, xyzs, dirs, deltas)` evaluates the field and runs the composites
+        (composite_rays last: it is the one that mutates rays_alive / rays_t)."""
+        N = rays_o.shape[0]
+        st = _MarchState(N, nears, rays_o.device)
+        device_mode = self.march_mode == "device"
+        if device_mode:
+            spare = torch.empty_like(st.rays_alive)
+            count = torch.empty(1, dtype=torch.int32, device=rays_o.device)
+            host_count = torch.empty(1, dtype=torch.int32).pin_memory()
+        n_alive = N
+        step = 0
+        while step < max_steps:
+            if n_alive <= 0:
+                break
+            n_step = max(min(N // n_alive, 8), 1)
+            xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, st.rays_alive, st.rays_t, rays_o, rays_d, self.bound,
+                                                        self.density_bitfield, self.cascade, self.grid_size, nears, fars, 128,
+                                                        perturb if step == 0 else False, dt_gamma, max_steps)
+            st.n_samples += xyzs.shape[0]
+            shade(st, n_alive, n_step, xyzs, dirs, deltas)
+            if device_mode:
+                out, _ = raymarching.compact_alive(st.rays_alive, n_alive, out=spare, count=count)
+                spare, st.rays_alive = st.rays_alive, out
+                host_count.copy_(count, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                n_alive = int(host_count.item())
+            else:
+                st.rays_alive = st.rays_alive[st.rays_alive >= 0]
+                n_alive = st.rays_alive.shape[0]
+            step += n_step
+        return st
+
+    def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
+        """nerf/renderer.py:564-603 / palette/renderer.py:554-573 -- never staged when cuda_ray."""
+        if not self.cuda_ray:
+            raise ValueError("Pure pytorch version is not available: the reference's non-cuda_ray path is dead code "
+                             "(nerf/renderer.py:591,601; palette/renderer.py:292-294)")
+        return self.run_cuda(rays_o, rays_d, **kwargs)
+
+
+class NeRFRenderer(_RendererBase):
+    """nerf/renderer.py:61-125"""
+
+    def __init__(self, bound=1, cuda_ray=False, density_scale=1, min_near=0.2, density_thresh=0.01, bg_radius=-1, filter_close_point=False):
+        super().__init__()
+        self.filter_close_point = filter_close_point
+        self._init_march_state(bound, cuda_ray, density_scale, min_near, density_thresh, bg_radius)
+
+    def forward(self, x, d):
+        raise NotImplementedError()
+
+    def density(self, x):
+        raise NotImplementedError()
+
+    def run_cuda(self, rays_o, rays_d, rays_gt=None, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024,
+                 T_thresh=1e-4, **kwargs):
+        """nerf/renderer.py:258-393"""
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        if rays_gt is not None:
+            rays_gt = rays_gt.contiguous().view(-1, 3)
+        N = rays_o.shape[0]
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer, self.min_near)
+        if self.bg_radius > 0:
+            sph = raymarching.sph_from_ray(rays_o, rays_d, self.bg_radius)
+            bg_color = self.background(sph, rays_d)
+        elif bg_color is None:
+            bg_color = 1
+        results = {}
+        if self.training:
+            counter = self.step_counter[self.local_step % 16]
+            counter.zero_()
+            self.local_step += 1
+            xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
+                                                                    self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
+                                                                    force_all_rays, dt_gamma, max_steps)
+            sigmas, rgbs = self(xyzs, dirs)
+            sigmas = self.density_scale * sigmas
+            if rays_gt is not None:
+                gt_rgbs = torch.zeros_like(xyzs)
+                raymarching.spread_ray_to_sample(rays_gt, rays, gt_rgbs)
+                rgb_norm = ((gt_rgbs - rgbs) ** 2).sum(-1, keepdim=True).repeat(1, 3)
+            else:
+                rgb_norm = torch.zeros_like(rgbs)
+            weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
+            _, _, rgb_norm_map = raymarching.composite_rays_train(sigmas, rgb_norm, deltas, rays, T_thresh)
+            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+            image = image.view(*prefix, 3)
+            depth = depth.view(*prefix)
+            rgb_norm_map = rgb_norm_map.mean(dim=-1).view(*prefix)
+            results["weights_sum"] = weights_sum
+        else:
+            def shade(st, n_alive, n_step, xyzs, dirs, deltas):
+                sigmas, rgbs = self(xyzs, dirs)
+                sigmas = self.density_scale * sigmas
+                raymarching.composite_rays(n_alive, n_step, st.rays_alive, st.rays_t, sigmas, rgbs, deltas, st.weights_sum, st.depth,
+                                           st.image, T_thresh)
+
+            st = self._infer_loop(rays_o, rays_d, nears, fars, perturb, dt_gamma, max_steps, shade)
+            weights_sum = st.weights_sum
+            image = st.image + (1 - weights_sum).unsqueeze(-1) * bg_color
+            depth = torch.clamp(st.depth - nears, min=0) / (fars - nears)
+            image = image.view(*prefix, 3)
+            depth = depth.view(*prefix)
+            rgb_norm_map = torch.zeros_like(image[..., 0])
+            results["n_samples"] = st.n_samples
+        results["depth"] = depth
+        results["image"] = image
+        results["rgb_norm"] = rgb_norm_map
+        results["weights_sum"] = weights_sum
+        return results
+
+
+class RegionEdit(nn.Module):
+    """Regional appearance editing controller (palette/renderer.py:84-147): hue shift and
+    saturation/value scaling per palette basis in HSV space, blended by a spatial / semantic
+    Gaussian window."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.mean_xyz = None
+        self.mean_clip = None
+        self.std_xyz = 1
+        self.std_clip = 1
+        self.weight_mode = False
+        self.delta_hsv = torch.zeros(self.opt.num_basis, 3)
+        self.delta_hsv[..., 1:3] = 1
+
+    def update_cent(self, mean_xyz=None, mean_clip=None):
+        self.mean_xyz = None if mean_xyz is None else mean_xyz[None, ...]
+        self.mean_clip = None if mean_clip is None else mean_clip[None, ...]
+
+    def update_std(self, std_xyz=None, std_clip=None):
+        if std_xyz is not None:
+            self.std_xyz = std_xyz
+        if std_clip is not None:
+            self.std_clip = std_clip
+
+    def update_delta_hsv(self, rgb_orig, rgb_new):
+        if rgb_orig.device != self.delta_hsv.device:
+            self.delta_hsv = self.delta_hsv.type_as(rgb_orig)
+        nb = self.opt.num_basis
+        hsv_all = rgb_to_hsv(torch.cat([rgb_orig, rgb_new], dim=0))
+        hsv_orig, hsv_new = hsv_all[:nb], hsv_all[nb:]
+        self.delta_hsv[:, 0] = torch.fmod((hsv_new[:, 0] - hsv_orig[:, 0] + 360), 360)
+        self.delta_hsv[:, 1] = (hsv_new[:, 1] / hsv_orig[:, 1] + 1e-9)
+        self.delta_hsv[:, 2] = (hsv_new[:, 2] / hsv_orig[:, 2] + 1e-9)
+
+    def forward(self, rgbs, xyz=None, clip_feat=None):
+        hsv = rgb_to_hsv(rgbs)
+        if rgbs.device != self.delta_hsv.device:
+            self.delta_hsv = self.delta_hsv.type_as(rgbs)
+        weight = torch.ones_like(rgbs[..., 0:1, 0])
+        if xyz is not None and self.mean_xyz is not None:
+            weight *= torch.exp(-((xyz - self.mean_xyz) ** 2.).sum(dim=-1, keepdim=True) / self.std_xyz)
+        if clip_feat is not None and self.mean_clip is not None:
+            weight *= torch.exp(-((clip_feat - self.mean_clip) ** 2.).sum(dim=-1, keepdim=True) / self.std_clip)
+        hsv_new = hsv.clone()
+        hsv_new[..., 0] = torch.fmod((hsv[..., 0] + self.delta_hsv[..., 0] + 360), 360)
+        hsv_new[..., 1] = torch.clip((hsv[..., 1] * self.delta_hsv[..., 1]), 0)
+        hsv_new[..., 2] = torch.clip((hsv[..., 2] * self.delta_hsv[..., 2]), 0)
+        rgb_new = hsv_to_rgb(hsv_new)
+        if self.weight_mode:
+            return weight[..., None].repeat(1, self.opt.num_basis, 3)
+        return torch.lerp(rgbs, rgb_new, weight[..., None])
+
+
+class PaletteRenderer(_RendererBase):
+    """palette/renderer.py:186-245"""
+
+    def __init__(self, opt, bound=1, cuda_ray=False, density_scale=1, min_near=0.2, density_thresh=0.01, bg_radius=-1):
+        super().__init__()
+        self.opt = opt
+        self.num_basis = opt.num_basis
+        self.freeze_basis_color = opt.use_initialization_from_rgbxy
+        self.require_smooth_loss = False
+        self.color_weight = 0
+        self.edit = None
+        self.stylizer = None
+        self.view_dep_weight = 1
+        self.offsets_weight = 1
+        self._init_march_state(bound, cuda_ray, density_scale, min_near, density_thresh, bg_radius)
+        if opt.test or not opt.use_initialization_from_rgbxy:
+            self.basis_color = nn.Parameter(torch.zeros([self.num_basis, 3]) + 0.5, requires_grad=True)
+        else:
+            self.basis_color = None
+
+    def initialize_palette(self, color_list=None, hist_weights=None):
+        """palette/renderer.py:247-268 (sRGB colour space only; srgb_to_linear is a harness utility)."""
+        if color_list is None:
+            if self.basis_color is None:
+                self.basis_color = nn.Parameter(torch.zeros([self.num_basis, 3]) + 0.5, requires_grad=True)
+        else:
+            dev = self.aabb_train.device
+            self.basis_color = nn.Parameter(torch.as_tensor(color_list, dtype=torch.float32, device=dev).reshape(self.num_basis, 3).clone(),
+                                            requires_grad=True)
+        self.basis_color_origin = nn.Parameter(self.basis_color.data.clone(), requires_grad=False)
+        if hist_weights is not None:
+            hw = torch.as_tensor(hist_weights).float().permute(3, 0, 1, 2).unsqueeze(0)
+            self.hist_weights = nn.Parameter(hw, requires_grad=False)
+
+    def forward(self, x, d):
+        raise NotImplementedError()
+
+    def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024, T_thresh=1e-4,
+                 gui_mode=False, **kwargs):
+        """palette/renderer.py:296-552"""
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        N = rays_o.shape[0]
+        device = rays_o.device
+        nb, clip_dim = self.num_basis, self.opt.clip_dim
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer, self.min_near)
+        if self.bg_radius > 0:
+            sph = raymarching.sph_from_ray(rays_o, rays_d, self.bg_radius)
+            bg_color = self.background(sph, rays_d)
+        elif bg_color is None:
+            bg_color = 1
+        results = {}
+
+        if self.training:
+            counter = self.step_counter[self.local_step % 16]
+            counter.zero_()
+            self.local_step += 1
+            xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
+                                                                    self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
+                                                                    force_all_rays, dt_gamma, max_steps)
+            M = xyzs.shape[0]
+            sigmas, clip_feat, omega, offsets_radiance, view_dep, diffuse = self(xyzs, dirs)
+            offsets, radiance = offsets_radiance[..., :-1], offsets_radiance[..., -1:]
+            sigmas = (self.density_scale * sigmas).detach()  # geometry is frozen (palette/renderer.py:334-335)
+            radiance = radiance.reshape(M, 1, 1)
+            offsets = offsets.reshape(M, nb, 3)
+            omega = omega.reshape(M, nb, 1)
+            view_dep = view_dep.reshape(M, 3)
+            diffuse = diffuse.reshape(M, 3)
+            clip_feat = clip_feat.reshape(M, clip_dim)
+            basis_color = self.basis_color[None, :, :].clamp(0, 1)
+            if self.freeze_basis_color:
+                basis_color = basis_color.detach()
+            final_color = F.softplus(radiance) * (basis_color + offsets)
+            basis_rgb = omega * final_color
+            rgbs = basis_rgb.sum(dim=-2) + view_dep.detach()
+            direct_rgb = diffuse + view_dep
+            weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
+
+            omega_sparsity = omega[..., 0].sum(dim=-1, keepdim=True) / ((omega[..., 0] ** 2).sum(dim=-1, keepdim=True) + 1e-6) - 1
+            offsets_norm = (offsets ** 2).sum(dim=-1).sum(dim=-1, keepdim=True)
+            view_dep_norm = (view_dep ** 2).sum(dim=-1, keepdim=True)
+            if self.require_smooth_loss:
+                xyzs_diff = (xyzs + torch.rand_like(xyzs) * self.bound * 0.03).clamp(-self.bound, self.bound)
+                _, clip_feat_diff, omega_diff, _, _, diffuse_diff = self(xyzs_diff, dirs)
+                omega_diff = omega_diff.reshape(M, nb, 1)
+                diffuse_diff = diffuse_diff.reshape(M, 3)
+                xyzs_weight = (xyzs - xyzs_diff).norm(dim=-1, keepdim=True) ** 2 / self.bound ** 2 / self.opt.smooth_sigma_xyz
+                rgb_weight = (diffuse - diffuse_diff).norm(dim=-1, keepdim=True) ** 2 / self.opt.smooth_sigma_color
+                if self.opt.pred_clip and self.opt.smooth_sigma_clip > 0:
+                    clip_weight = (clip_feat - clip_feat_diff).norm(dim=-1, keepdim=True) / self.opt.smooth_sigma_clip
+                else:
+                    clip_weight = 0
+                smooth_weight = torch.exp(-xyzs_weight - rgb_weight - clip_weight).detach()
+                smooth_norm = ((omega_diff - omega)[..., 0] ** 2).sum(dim=-1, keepdim=True) * smooth_weight
+                if self.opt.pred_clip:
+                    smooth_norm += ((clip_feat_diff - clip_feat) ** 2).sum(dim=-1, keepdim=True) * smooth_weight
+            else:
+                smooth_norm = torch.zeros_like(omega_sparsity)
+
+            # 13 + clip_dim + nb channels in ONE flex composite (palette/renderer.py:384-386)
+            all_buffer = torch.cat([omega_sparsity, view_dep_norm, offsets_norm, smooth_norm, view_dep, direct_rgb, diffuse, clip_feat,
+                                    omega[..., 0]], dim=-1)
+            all_map = raymarching.composite_rays_flex_train(sigmas, all_buffer, deltas, rays, T_thresh)
+            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+            results["depth"] = depth.view(*prefix)
+            results["image"] = image.view(*prefix, 3)
+            results["weights_sum"] = weights_sum
+            results["omega_sparsity"] = all_map[..., 0:1].view(*prefix)
+            results["view_dep_norm"] = all_map[..., 1:2].view(*prefix)
+            results["offsets_norm"] = all_map[..., 2:3].view(*prefix)
+            results["smooth_norm"] = all_map[..., 3:4].view(*prefix)
+            results["view_dep_rgb"] = all_map[..., 4:7].view(*prefix, 3)
+            results["direct_rgb"] = (all_map[..., 7:10] + (1 - weights_sum).unsqueeze(-1) * bg_color).view(*prefix, 3)
+            results["diffuse_rgb"] = all_map[..., 10:13].view(*prefix, 3)
+            results["clip_feat"] = all_map[..., 13:13 + clip_dim].view(*prefix, clip_dim)
+            results["basis_acc"] = all_map[..., 13 + clip_dim:13 + clip_dim + nb].view(*prefix, nb)
+            return results
+
+        f32 = dict(dtype=torch.float32, device=device)
+        view_dep_rgb_map = torch.zeros(N, 3, **f32)
+        direct_rgb_map = torch.zeros(N, 3, **f32)
+        basis_rgb_map = torch.zeros(N, 3 * nb, **f32)
+        unscaled_basis_rgb_map = torch.zeros(N, 3 * nb, **f32)
+        basis_acc_map = torch.zeros(N, nb, **f32)
+        clip_feat_map = torch.zeros(N, clip_dim, **f32)
+
+        def shade(st, n_alive, n_step, xyzs, dirs, deltas):
+            M = xyzs.shape[0]
+            sigmas, clip_feat, omega, offsets_radiance, view_dep, diffuse = self(xyzs, dirs)
+            offsets, radiance = offsets_radiance[..., :-1], offsets_radiance[..., -1:]
+            radiance = radiance.reshape(M, 1, 1)
+            offsets = offsets.reshape(M, nb, 3)
+            omega = omega.reshape(M, nb, 1)
+            view_dep = view_dep.reshape(M, 3)
+            diffuse = diffuse.reshape(M, 3)
+            clip_feat = clip_feat.reshape(M, clip_dim)
+            basis_color = self.basis_color[None, :, :].clamp(0, 1)
+            basis_rgb = unscaled_basis_rgb = None
+            if self.stylizer is not None:
+                rgbs = self.stylizer(radiance, omega, basis_color, offsets, view_dep)
+            else:
+                # the palette colour-basis composite (palette/renderer.py:482-494)
+                final_color = F.softplus(radiance) * (basis_color + self.offsets_weight * offsets)
+                unscaled_basis_rgb = basis_color + offsets
+                if self.edit is not None:
+                    final_color = self.edit(final_color, xyzs, clip_feat)
+                basis_rgb = omega * final_color
+                rgbs = basis_rgb.sum(dim=-2) + self.view_dep_weight * view_dep
+            sigmas = self.density_scale * sigmas
+            a = (n_alive, n_step)
+            if not gui_mode:
+                direct_rgb = diffuse + view_dep
+                fl = raymarching.composite_rays_flex
+                fl(*a, 3, st.rays_alive, st.rays_t, sigmas, direct_rgb, deltas, st.weights_sum, direct_rgb_map, T_thresh)
+                fl(*a, 3, st.rays_alive, st.rays_t, sigmas, view_dep, deltas, st.weights_sum, view_dep_rgb_map, T_thresh)
+                fl(*a, nb, st.rays_alive, st.rays_t, sigmas, omega, deltas, st.weights_sum, basis_acc_map, T_thresh)
+                fl(*a, nb * 3, st.rays_alive, st.rays_t, sigmas, basis_rgb.reshape(M, nb * 3), deltas, st.weights_sum, basis_rgb_map, T_thresh)
+                fl(*a, nb * 3, st.rays_alive, st.rays_t, sigmas, unscaled_basis_rgb.reshape(M, nb * 3), deltas, st.weights_sum,
+                   unscaled_basis_rgb_map, T_thresh)
+            raymarching.composite_rays_flex(*a, clip_dim, st.rays_alive, st.rays_t, sigmas, clip_feat, deltas, st.weights_sum, clip_feat_map,
+                                            T_thresh)
+            # must come last: the only composite that mutates rays_alive / rays_t / weights_sum (palette/renderer.py:517-519)
+            raymarching.composite_rays(*a, st.rays_alive, st.rays_t, sigmas, rgbs, deltas, st.weights_sum, st.depth, st.image, T_thresh)
+
+        st = self._infer_loop(rays_o, rays_d, nears, fars, perturb, dt_gamma, max_steps, shade)
+        weights_sum = st.weights_sum
+        image = st.image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        depth_origin = st.depth.clone()
+        depth = torch.clamp(st.depth - nears, min=0) / (fars - nears)
+        results["depth"] = depth.view(*prefix)
+        results["depth_origin"] = depth_origin.view(*prefix)
+        results["image"] = image.view(*prefix, 3)
+        results["weights_sum"] = weights_sum
+        results["clip_feat"] = clip_feat_map.view(*prefix, clip_dim)
+        results["n_samples"] = st.n_samples
+        if not gui_mode:
+            results["direct_rgb"] = (direct_rgb_map + (1 - weights_sum).unsqueeze(-1) * bg_color).view(*prefix, 3)
+            results["view_dep_rgb"] = view_dep_rgb_map.view(*prefix, 3)
+            results["basis_rgb"] = basis_rgb_map.view(*prefix, nb * 3)
+            results["unscaled_basis_rgb"] = unscaled_basis_rgb_map.view(*prefix, nb * 3)
+            results["basis_acc"] = basis_acc_map.view(*prefix, nb)
+        return results

@@ -1,0 +1,69 @@
+"""Spherical-harmonics direction encoder -- same API as the reference's
+shencoder/sphere_harmonics.py (`_sh_encoder`, `sh_encode`, `SHEncoder`), backed by
+pnr_sh_encode_{forward,backward}."""
+import ctypes
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.amp import custom_bwd, custom_fwd
+
+from ._torch_glue import call, ptr, require
+
+_u32 = ctypes.c_uint32
+
+
+class _sh_encoder(Function):
+    """shencoder/sphere_harmonics.py:14-55"""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, inputs, degree, calc_grad_inputs=False):
+        inputs = inputs.contiguous()
+        B, input_dim = inputs.shape
+        output_dim = degree ** 2
+        outputs = torch.empty(B, output_dim, dtype=inputs.dtype, device=inputs.device)
+        dy_dx = torch.empty(B, input_dim * output_dim, dtype=inputs.dtype, device=inputs.device) if calc_grad_inputs else None
+        call("pnr_sh_encode_forward", ptr(require(inputs, torch.float32, "inputs")), ptr(outputs), _u32(B), _u32(input_dim), _u32(degree),
+             ptr(dy_dx))
+        ctx.save_for_backward(inputs, dy_dx)
+        ctx.dims = [B, input_dim, degree]
+        return outputs
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad):
+        inputs, dy_dx = ctx.saved_tensors
+        if dy_dx is None:
+            return None, None, None
+        grad = grad.contiguous()
+        B, input_dim, degree = ctx.dims
+        grad_inputs = torch.zeros_like(inputs)
+        call("pnr_sh_encode_backward", ptr(require(grad, torch.float32, "grad")), ptr(inputs), _u32(B), _u32(input_dim), _u32(degree),
+             ptr(dy_dx), ptr(grad_inputs))
+        return grad_inputs, None, None
+
+
+sh_encode = _sh_encoder.apply
+
+
+class SHEncoder(nn.Module):
+    """shencoder/sphere_harmonics.py:61-86"""
+
+    def __init__(self, input_dim=3, degree=4):
+        super().__init__()
+        self.input_dim = input_dim
+        self.degree = degree
+        self.output_dim = degree ** 2
+        assert self.input_dim == 3, "SH encoder only support input dim == 3"
+        assert self.degree > 0 and self.degree <= 8, "SH encoder only supports degree in [1, 8]"
+
+    def __repr__(self):
+        return f"SHEncoder: input_dim={self.input_dim} degree={self.degree}"
+
+    def forward(self, inputs, size=1):
+        inputs = inputs / size
+        prefix_shape = list(inputs.shape[:-1])
+        inputs = inputs.reshape(-1, self.input_dim)
+        outputs = sh_encode(inputs, self.degree, inputs.requires_grad)
+        return outputs.reshape(prefix_shape + [self.output_dim])

@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ (run in the BUILD container only: it reads
+/root/reference, which does not exist on the GPU box; the fixtures it writes are data).
+
+What is pinned by the reference itself:
+  1. sh_torch.npz       -- the reference's own pure-PyTorch SH encoder `SHEncoder_torch`
+                           (testing/test_shencoder.py:8-89) evaluated on seeded unit vectors, deg 1..5.
+  2. sh_cuda_expr.npz   -- the 64 + 3*64 polynomial expressions of kernel_sh
+                           (shencoder/src/shencoder.cu:50-120, 131-349) parsed as arithmetic expressions
+                           and evaluated with NumPy float64 at seeded OFF-sphere points, degree 8 incl.
+                           the analytic derivative tables.  (No compilation: the expressions are data.)
+  3. frame_nerf_*.npz, frame_palette_*.npz, train_*.npz
+                        -- the reference's Python callers imported as they are
+                           (nerf/renderer.py:NeRFRenderer.run_cuda, nerf/network.py:NeRFNetwork,
+                           palette/renderer.py:PaletteRenderer.run_cuda, palette/network.py:PaletteNetwork,
+                           encoding.py, activation.py) with the CPU oracle injected as the
+                           `raymarching` / `gridencoder` / `shencoder` / `palette.utils` extension
+                           modules (those are CUDA extensions that cannot be built here).  This pins
+                           the control flow: n_step schedule, order-preserving compaction, composite
+                           call order, bg mix, depth normalisation, palette colour-basis composite.
+Weights are NOT stored (50 MB tables): fixtures carry the seed; palettenerf_amd.scene.seed_field_
+regenerates them bit-identically with the CPU torch.Generator.
+"""
+import ast
+import os
+import re
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+import oracle  # noqa: E402
+from palettenerf_amd import scene  # noqa: E402
+
+
+# ------------------------------------------------------------------------------------------ SH
+def gen_sh_torch():
+    src = open(os.path.join(REF, "testing", "test_shencoder.py")).read()
+    cls = [n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == "SHEncoder_torch"][0]
+    ns = {"torch": torch, "nn": torch.nn}
+    exec(compile(ast.Module([cls], []), "SHEncoder_torch", "exec"), ns)
+    rng = np.random.default_rng(1234)
+    x = rng.standard_normal((257, 3)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    out = {"x": x}
+    for deg in range(1, 6):
+        out[f"y{deg}"] = ns["SHEncoder_torch"](degree=deg)(torch.from_numpy(x)).numpy()
+    np.savez_compressed(os.path.join(HERE, "sh_torch.npz"), **out)
+
+
+def gen_sh_cuda_expr():
+    src = open(os.path.join(REF, "shencoder", "src", "shencoder.cu")).read()
+    rng = np.random.default_rng(4321)
+    P = rng.uniform(-1.2, 1.2, size=(64, 3)).astype(np.float32).astype(np.float64)  # off the unit sphere on purpose; fp32-representable
+    x, y, z = P[:, 0], P[:, 1], P[:, 2]
+    env = dict(x=x, y=y, z=z, xy=x * y, xz=x * z, yz=y * z, x2=x * x, y2=y * y, z2=z * z, xyz=x * y * z, pow=np.power)
+    env.update(x4=env["x2"] ** 2, y4=env["y2"] ** 2, z4=env["z2"] ** 2)
+    env.update(x6=env["x4"] * env["x2"], y6=env["y4"] * env["y2"], z6=env["z4"] * env["z2"])
+    tables = {}
+    for name in ("outputs", "dx", "dy", "dz"):
+        vals = np.zeros((64, 64))
+        found = 0
+        for m in re.finditer(r"^\s*" + name + r"\[(\d+)\]\s*=\s*([^;]+);", src, flags=re.M):
+            k, expr = int(m.group(1)), m.group(2)
+            expr = re.sub(r"(\d+\.?\d*(?:[eE][-+]?\d+)?)f\b", r"\1", expr)  # drop float suffixes
+            vals[:, k] = eval(expr, {"__builtins__": {}}, env) * np.ones(64)
+            found += 1
+        assert found == 64, (name, found)
+        tables[name] = vals
+    np.savez_compressed(os.path.join(HERE, "sh_cuda_expr.npz"), points=P, y=tables["outputs"], dx=tables["dx"], dy=tables["dy"], dz=tables["dz"])
+
+
+# ------------------------------------------------------------------------------------------ frames
+from tests.oracle_facade import make_oracle_modules, _t  # noqa: E402
+
+
+class _Stub(types.ModuleType):
+    """Stands in for harness-only third-party imports (trimesh, cv2, ...) the hot path never calls."""
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Stub(self.__name__ + "." + name)
+
+    def __call__(self, *a, **k):
+        raise RuntimeError(f"harness-only dependency {self.__name__} was called on the hot path")
+
+
+def import_reference():
+    rm, ge, sh, pu = make_oracle_modules()
+    sys.modules.update({"raymarching": rm, "gridencoder": ge, "shencoder": sh, "palette.utils": pu})
+    for name in ("trimesh", "cv2", "mcubes", "tensorboardX", "torch_ema", "lpips", "kornia", "imageio"):
+        sys.modules.setdefault(name, _Stub(name))
+    nu = types.ModuleType("nerf.utils")
+    nu.custom_meshgrid = lambda *a: torch.meshgrid(*a, indexing="ij")
+    nu.srgb_to_linear = lambda x: torch.where(x < 0.04045, x / 12.92, ((x + 0.055) / 1.055) ** 2.4)
+    sys.modules["nerf.utils"] = nu
+    sys.path.insert(0, REF)
+    # the CPU build of torch has no custom_fwd for 'cuda' autocast issues: activation.py only needs torch.cuda.amp
+    import nerf.network as ref_nerf_network  # noqa
+    import palette.network as ref_palette_network  # noqa
+    import palette.renderer as ref_palette_renderer  # noqa
+    return ref_nerf_network, ref_palette_network, ref_palette_renderer
+
+
+def frame_inputs(H, W, elev=30.0, azim=45.0):
+    pose = torch.from_numpy(scene.lookat_pose(elevation_deg=elev, azimuth_deg=azim))[None]
+    ro, rd = scene.get_rays(pose, scene.intrinsics_from_fov(H, W), H, W)
+    return ro, rd
+
+
+def setup_model(model, density_grid, thresh=0.5):
+    model.density_grid.copy_(torch.from_numpy(density_grid))
+    model.density_bitfield.copy_(torch.from_numpy(oracle.packbits(density_grid, thresh)))
+
+
+FRAME_CASES = [
+    # name, H, W, dt_gamma, density_scale, seed
+    ("a", 40, 40, 0.0, 1.0, 0),          # blender-style, opaque-ish field
+    ("b", 36, 28, 1.0 / 128, 0.02, 1),   # cone stepping (LLFF/Mip360 default), translucent: long marches, many iterations
+]
+
+
+def gen_frames():
+    ref_nerf, ref_pal, ref_pal_r = import_reference()
+    grid = scene.brick_density_grid()
+    for name, H, W, dt_gamma, dscale, seed in FRAME_CASES:
+        ro, rd = frame_inputs(H, W)
+        # ---------------- NeRF inference
+        m = ref_nerf.NeRFNetwork(bound=2, cuda_ray=True, density_scale=dscale, min_near=0.2)
+        scene.seed_field_(m, seed)
+        setup_model(m, grid)
+        m.eval()
+        with torch.no_grad():
+            r = m.run_cuda(ro, rd, dt_gamma=dt_gamma, bg_color=None, perturb=False, max_steps=1024, T_thresh=1e-4)
+        np.savez_compressed(os.path.join(HERE, f"frame_nerf_{name}.npz"), H=H, W=W, dt_gamma=dt_gamma, density_scale=dscale, seed=seed,
+                            image=r["image"].numpy(), depth=r["depth"].numpy(), weights_sum=r["weights_sum"].numpy())
+        print("nerf", name, float(r["weights_sum"].mean()), float(r["image"].mean()))
+        # ---------------- NeRF training-mode forward + grads
+        m.train()
+        m.zero_grad()
+        r = m.run_cuda(ro, rd, dt_gamma=dt_gamma, perturb=False, force_all_rays=True, max_steps=1024, T_thresh=1e-4)
+        loss = (r["image"] ** 2).mean() + 0.1 * r["weights_sum"].mean()
+        loss.backward()
+        ge_ = m.encoder.embeddings.grad
+        nz = ge_.abs().sum(1).nonzero()[:, 0]
+        sel = nz[:: max(1, nz.numel() // 512)][:512]
+        np.savez_compressed(os.path.join(HERE, f"train_nerf_{name}.npz"), H=H, W=W, dt_gamma=dt_gamma, density_scale=dscale, seed=seed,
+                            image=r["image"].detach().numpy(), depth=r["depth"].detach().numpy(), weights_sum=r["weights_sum"].detach().numpy(),
+                            counter=m.step_counter[0].numpy(), loss=float(loss),
+                            grad_color0=m.color_net[0].weight.grad.numpy(), grad_sigma1=m.sigma_net[1].weight.grad.numpy(),
+                            grad_emb_rows=sel.numpy(), grad_emb_vals=ge_[sel].numpy(), grad_emb_abs_sum=float(ge_.abs().sum()))
+        print("nerf train", name, int(m.step_counter[0, 0]), float(loss))
+        # ---------------- Palette inference (all 7 composites) and gui_mode
+        opt = types.SimpleNamespace(num_basis=4, clip_dim=16, pred_clip=(name == "b"), use_initialization_from_rgbxy=False, test=True,
+                                    color_space="srgb", smooth_sigma_xyz=0.005, smooth_sigma_color=0.2, smooth_sigma_clip=0.0)
+        p = ref_pal.PaletteNetwork(opt, bound=2, cuda_ray=True, density_scale=dscale, min_near=0.2)
+        scene.seed_field_(p, seed + 100)
+        setup_model(p, grid)
+        p.eval()
+        with torch.no_grad():
+            r = p.run_cuda(ro, rd, dt_gamma=dt_gamma, perturb=False, max_steps=1024, T_thresh=1e-4, gui_mode=False)
+            # regional edit active: exercises the HSV operators inside the loop
+            p.edit = ref_pal_r.RegionEdit(opt)
+            p.edit.update_cent(mean_xyz=torch.tensor([0.1, 0.0, -0.2]))
+            p.edit.update_std(std_xyz=0.5)
+            p.edit.update_delta_hsv(p.basis_color.data.clamp(0, 1), (p.basis_color.data * 0.6 + 0.2).flip(0).clamp(0, 1))
+            r2 = p.run_cuda(ro, rd, dt_gamma=dt_gamma, perturb=False, max_steps=1024, T_thresh=1e-4, gui_mode=True)
+            p.edit = None
+        keys = ["image", "depth", "depth_origin", "weights_sum", "clip_feat", "direct_rgb", "view_dep_rgb", "basis_rgb", "unscaled_basis_rgb", "basis_acc"]
+        np.savez_compressed(os.path.join(HERE, f"frame_palette_{name}.npz"), H=H, W=W, dt_gamma=dt_gamma, density_scale=dscale, seed=seed + 100,
+                            pred_clip=opt.pred_clip, edit_image=r2["image"].numpy(), edit_delta_hsv=np.zeros(1),
+                            **{k: r[k].numpy() for k in keys})
+        print("palette", name, float(r["weights_sum"].mean()), float((r["image"] - r2["image"]).abs().max()))
+        # ---------------- Palette training-mode forward + grads (config 3 path)
+        p.train()
+        p.zero_grad()
+        r = p.run_cuda(ro, rd, dt_gamma=dt_gamma, perturb=False, force_all_rays=True, max_steps=1024, T_thresh=1e-4)
+        loss = (r["image"] ** 2).mean() + 0.01 * r["omega_sparsity"].mean() + 0.1 * r["offsets_norm"].mean() + (r["direct_rgb"] ** 2).mean() \
+            + 0.1 * (r["clip_feat"] ** 2).mean() + 0.1 * r["basis_acc"].mean()
+        loss.backward()
+        gp = p.encoder_palette.embeddings.grad
+        nz = gp.abs().sum(1).nonzero()[:, 0]
+        sel = nz[:: max(1, nz.numel() // 512)][:512]
+        tk = ["image", "depth", "weights_sum", "omega_sparsity", "view_dep_norm", "offsets_norm", "direct_rgb", "view_dep_rgb", "diffuse_rgb", "clip_feat", "basis_acc"]
+        np.savez_compressed(os.path.join(HERE, f"train_palette_{name}.npz"), H=H, W=W, dt_gamma=dt_gamma, density_scale=dscale, seed=seed + 100,
+                            pred_clip=opt.pred_clip, loss=float(loss), counter=p.step_counter[0].numpy(),
+                            grad_offsets_radiance=p.offsets_radiance_net.weight.grad.numpy(), grad_basis_color=p.basis_color.grad.numpy(),
+                            grad_diff0=p.diff_net[0].weight.grad.numpy(), grad_emb_rows=sel.numpy(), grad_emb_vals=gp[sel].numpy(),
+                            grad_emb_abs_sum=float(gp.abs().sum()), encoder_grad_is_none=(p.encoder.embeddings.grad is None),
+                            **{k: r[k].detach().numpy() for k in tk})
+        print("palette train", name, int(p.step_counter[0, 0]), float(loss))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["sh", "frames"]
+    if "sh" in which:
+        gen_sh_torch()
+        gen_sh_cuda_expr()
+    if "frames" in which:
+        gen_frames()

@@ -1,0 +1,79 @@
+"""The C-ABI library loads and exports every symbol include/pnr.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "pnr.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pnr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_expected_surface():
+    syms = header_symbols()
+    for must in ("pnr_march_rays", "pnr_march_rays_train", "pnr_composite_rays", "pnr_composite_rays_flex", "pnr_grid_encode_forward",
+                 "pnr_grid_encode_backward", "pnr_sh_encode_forward", "pnr_rgb_to_hsv", "pnr_hsv_to_rgb", "pnr_morton3d", "pnr_packbits",
+                 "pnr_near_far_from_aabb", "pnr_compact_alive"):
+        assert must in syms
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from palettenerf_amd import build
+    lib_path = build.build()
+    lib = ctypes.CDLL(lib_path)
+    missing = [s for s in header_symbols() if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_python_binding_table_matches_header():
+    from palettenerf_amd import _lib
+    assert sorted(_lib.SIGNATURES) == header_symbols()
+    lib = _lib.load()
+    assert lib.pnr_abi_version() >= 1
+    assert lib.pnr_error_string(0) == b"ok"
+    assert b"unsupported" in lib.pnr_error_string(-2)
+    assert lib.pnr_scan_scratch_bytes(1000) >= 4 * 1000
+
+
+def test_argument_validation_without_gpu():
+    """Entry points validate before launching: these return error codes without touching a device."""
+    from palettenerf_amd import _lib
+    lib = _lib.load()
+    u32, f32, i32 = ctypes.c_uint32, ctypes.c_float, ctypes.c_int
+    # C not in {1,2,4,8}  (reference: "GridEncoding: C must be 1, 2, 4, or 8.")
+    assert lib.pnr_grid_encode_backward(None, None, None, None, None, u32(8), u32(3), u32(3), u32(16), f32(1.0), u32(16), None, None, u32(0), i32(0), i32(0), None) == -2
+    # D not in 1..5
+    assert lib.pnr_grid_encode_backward(None, None, None, None, None, u32(8), u32(6), u32(2), u32(16), f32(1.0), u32(16), None, None, u32(0), i32(0), i32(0), None) == -2
+    # n_channel > 128 (reference CHECK_CHANNEL)
+    assert lib.pnr_composite_rays_flex(u32(1), u32(1), u32(129), f32(1e-4), None, None, None, None, None, None, None, None) == -2
+    # SH degree outside [1,8], input_dim != 3
+    assert lib.pnr_sh_encode_forward(None, None, u32(4), u32(3), u32(9), None, None) == -2
+    assert lib.pnr_sh_encode_forward(None, None, u32(4), u32(2), u32(4), None, None) == -2
+    # null pointers
+    assert lib.pnr_morton3d(None, u32(4), None, None) == -1
+    # empty inputs are a no-op
+    assert lib.pnr_morton3d(None, u32(0), None, None) == 0
+    assert lib.pnr_march_rays(u32(0), u32(4), *([None] * 4), f32(2), f32(0), u32(1024), u32(2), u32(128), *([None] * 8)) == 0
+
+
+def test_product_path_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "palettenerf_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M), f
+                assert "liborc" not in text and "pnr_oracle" not in text, f
+
+
+def test_ops_fail_loudly_without_library(monkeypatch, tmp_path):
+    from palettenerf_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
+        _lib.load()

@@ -1,0 +1,415 @@
+"""CPU suite: the oracle against the golden vectors and against independent NumPy/PyTorch
+formulations of the same mathematics (no GPU, no reference tree needed)."""
+import colorsys
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from palettenerf_amd import scene
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ------------------------------------------------------------------------------------------ SH
+@pytest.mark.parametrize("deg", [1, 2, 3, 4, 5])
+def test_sh_matches_reference_torch_encoder(deg):
+    g = np.load(os.path.join(GOLDEN, "sh_torch.npz"))
+    np.testing.assert_allclose(oracle.sh_encode_forward(g["x"], deg), g[f"y{deg}"], atol=1e-6, rtol=0)
+
+
+def test_sh_matches_reference_cuda_polynomials_off_sphere():
+    g = np.load(os.path.join(GOLDEN, "sh_cuda_expr.npz"))
+    y, d = oracle.sh_encode_forward(g["points"].astype(np.float32), 8, True)
+    d = d.reshape(-1, 3, 64)
+    for got, want in ((y, g["y"]), (d[:, 0], g["dx"]), (d[:, 1], g["dy"]), (d[:, 2], g["dz"])):
+        np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-6)
+
+
+def test_sh_lower_degree_is_prefix_of_higher():
+    x = np.random.default_rng(0).standard_normal((50, 3)).astype(np.float32)
+    y8 = oracle.sh_encode_forward(x, 8)
+    for deg in range(1, 8):
+        np.testing.assert_array_equal(oracle.sh_encode_forward(x, deg), y8[:, :deg * deg])
+
+
+def test_sh_backward_is_grad_dot_dydx():
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((20, 3)).astype(np.float32)
+    y, d = oracle.sh_encode_forward(x, 4, True)
+    g = rng.standard_normal(y.shape).astype(np.float32)
+    gi = oracle.sh_encode_backward(g, 4, d)
+    want = np.einsum("bc,bdc->bd", g.astype(np.float64), d.reshape(20, 3, 16).astype(np.float64))
+    np.testing.assert_allclose(gi, want, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------ integer ops
+def test_morton_known_answer_and_roundtrip():
+    assert oracle.morton3D(np.array([[1, 2, 3]]))[0] == 53
+    rng = np.random.default_rng(2)
+    c = rng.integers(0, 128, size=(5000, 3)).astype(np.int32)
+    idx = oracle.morton3D(c)
+    np.testing.assert_array_equal(idx.astype(np.uint32), scene.morton3d_np(c[:, 0], c[:, 1], c[:, 2]))
+    np.testing.assert_array_equal(oracle.morton3D_invert(idx), c)
+    full = oracle.morton3D(np.stack(np.meshgrid(*[np.arange(16)] * 3, indexing="ij"), -1).reshape(-1, 3))
+    assert sorted(full.tolist()) == list(range(16 ** 3))  # bijection on the 16^3 sub-cube
+
+
+def test_morton_edge_cases():
+    assert oracle.morton3D(np.zeros((0, 3), np.int32)).shape == (0,)
+    assert oracle.morton3D(np.array([[127, 127, 127]]))[0] == 128 ** 3 - 1
+    assert oracle.morton3D(np.array([[1023, 1023, 1023]]))[0] == 2 ** 30 - 1  # 10 bits per axis is the maximum
+
+
+def test_packbits_matches_numpy_and_is_strict():
+    rng = np.random.default_rng(3)
+    g = rng.random((2, 4096)).astype(np.float32)
+    g[0, :8] = 0.5
+    bf = oracle.packbits(g, 0.5)
+    np.testing.assert_array_equal(bf, scene.packbits_np(g, 0.5))
+    assert bf[0] == 0  # strict '>'
+
+
+# ------------------------------------------------------------------------------------------ near/far
+def test_near_far_known_answers():
+    aabb = [-1, -1, -1, 1, 1, 1]
+    n, f = oracle.near_far_from_aabb([[0, 0, -3]], [[0, 0, 1]], aabb, 0.2)  # axis aligned: 1/dx = inf
+    assert (n[0], f[0]) == (2.0, 4.0)
+    n, f = oracle.near_far_from_aabb([[0, 5, -3]], [[0, 0, 1]], aabb, 0.2)  # miss
+    assert n[0] == f[0] == np.finfo(np.float32).max
+    n, f = oracle.near_far_from_aabb([[0, 0, 0]], [[0.6, 0.0, 0.8]], aabb, 0.2)  # inside the box: near clamps to min_near
+    assert n[0] == np.float32(0.2) and abs(f[0] - 1.25) < 1e-6
+
+
+def test_near_far_matches_vectorised_slab_test():
+    rng = np.random.default_rng(4)
+    o = rng.uniform(-3, 3, (4000, 3)).astype(np.float32)
+    d = rng.standard_normal((4000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    n, f = oracle.near_far_from_aabb(o, d, [-2, -2, -2, 2, 2, 2], 0.05)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rd = np.float32(1) / d
+        t0, t1 = (np.float32(-2) - o) * rd, (np.float32(2) - o) * rd
+    tn, tf = np.minimum(t0, t1).max(1), np.maximum(t0, t1).min(1)
+    hit = tn <= tf
+    np.testing.assert_array_equal(n[~hit], np.finfo(np.float32).max)
+    np.testing.assert_array_equal(f[hit], tf[hit])
+    np.testing.assert_array_equal(n[hit], np.maximum(tn[hit], np.float32(0.05)))
+
+
+# ------------------------------------------------------------------------------------------ HSV
+def test_hsv_against_colorsys_and_roundtrip():
+    rng = np.random.default_rng(5)
+    rgb = rng.random((500, 3)).astype(np.float32)
+    hsv = oracle.rgb_to_hsv(rgb)
+    want = np.array([colorsys.rgb_to_hsv(*map(float, p)) for p in rgb]) * [360, 100, 100]
+    np.testing.assert_allclose(hsv, want, rtol=1e-5, atol=2e-4)
+    np.testing.assert_allclose(oracle.hsv_to_rgb(hsv), rgb, atol=2e-6)
+    np.testing.assert_allclose(oracle.rgb_to_hsv([[0.2, 0.5, 0.7]])[0], [204.0, 71.42857, 70.0], rtol=1e-6)
+    np.testing.assert_array_equal(oracle.rgb_to_hsv([[0.25, 0.25, 0.25], [0, 0, 0]]), [[0, 0, 25], [0, 0, 0]])  # grey / black
+
+
+# ------------------------------------------------------------------------------------------ compositing
+def _rand_rays(rng, N, max_len, pad=3):
+    counts = rng.integers(0, max_len, N)
+    counts[0] = 0
+    offs = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    M = int(counts.sum()) + pad
+    rays = np.stack([rng.permutation(N), offs, counts], 1).astype(np.int32)
+    sig = (rng.random(M) * 30).astype(np.float32)
+    rgb = rng.random((M, 3)).astype(np.float32)
+    dl = np.stack([rng.random(M) * 0.02 + 0.003, rng.random(M) * 0.05 + 0.003], 1).astype(np.float32)
+    return rays, sig, rgb, dl, M
+
+
+def _torch_composite(sig, feat, dl, rays, N):
+    """Independent formulation: alpha compositing by exclusive cumprod, no early termination."""
+    out = torch.zeros(N, feat.shape[1], dtype=torch.float64)
+    ws = torch.zeros(N, dtype=torch.float64)
+    dep = torch.zeros(N, dtype=torch.float64)
+    for idx, off, cnt in rays.tolist():
+        if cnt == 0:
+            continue
+        s, d = sig[off:off + cnt], dl[off:off + cnt]
+        alpha = 1 - torch.exp(-s * d[:, 0])
+        T = torch.cumprod(torch.cat([torch.ones(1, dtype=torch.float64), 1 - alpha[:-1]]), 0)
+        w = alpha * T
+        out[idx] = (w[:, None] * feat[off:off + cnt]).sum(0)
+        ws[idx] = w.sum()
+        dep[idx] = (w * torch.cumsum(d[:, 1], 0)).sum()
+    return ws, dep, out
+
+
+def test_composite_train_forward_backward_against_autograd():
+    rng = np.random.default_rng(6)
+    N = 40
+    rays, sig, rgb, dl, M = _rand_rays(rng, N, 30)
+    ws, dep, img = oracle.composite_rays_train_forward(sig, rgb, dl, rays, T_thresh=0.0)  # T<0 never true: no early stop
+    ts = torch.tensor(sig, dtype=torch.float64, requires_grad=True)
+    tc = torch.tensor(rgb, dtype=torch.float64, requires_grad=True)
+    tws, tdep, timg = _torch_composite(ts, tc, torch.tensor(dl, dtype=torch.float64), rays, N)
+    np.testing.assert_allclose(ws, tws.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dep, tdep.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(img, timg.detach().numpy(), rtol=1e-5, atol=1e-6)
+    gws = rng.standard_normal(N).astype(np.float32)
+    gimg = rng.standard_normal((N, 3)).astype(np.float32)
+    (tws * torch.tensor(gws, dtype=torch.float64)).sum().add((timg * torch.tensor(gimg, dtype=torch.float64)).sum()).backward()
+    gs, gc = oracle.composite_rays_train_backward(gws, gimg, sig, rgb, dl, rays, ws, img, T_thresh=0.0)
+    np.testing.assert_allclose(gc, tc.grad.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(gs, ts.grad.numpy(), rtol=2e-3, atol=2e-5)
+
+
+def test_composite_quirks():
+    rng = np.random.default_rng(7)
+    N = 8
+    rays, sig, rgb, dl, M = _rand_rays(rng, N, 10, pad=0)
+    # quirk 1: '>' for rgb, '>=' for flex: a ray ending exactly at M is composited by the former, zeroed by the latter
+    last = int(np.argmax(rays[:, 1] + rays[:, 2]))
+    assert rays[last, 1] + rays[last, 2] == M
+    ws, dep, img = oracle.composite_rays_train_forward(sig, rgb, dl, rays)
+    flex = oracle.composite_rays_flex_train_forward(sig, rgb, dl, rays)
+    assert ws[rays[last, 0]] > 0 and np.all(flex[rays[last, 0]] == 0)
+    other = [i for i in range(N) if i != last and rays[i, 2] > 0]
+    np.testing.assert_array_equal(flex[rays[other, 0]], img[rays[other, 0]])
+    # quirk 2: flex backward gives the terminating sample no gradient
+    sig2 = np.full(6, 1e4, np.float32)
+    dl2 = np.full((6, 2), 0.01, np.float32)
+    r2 = np.array([[0, 0, 5]], np.int32)
+    gi = oracle.composite_rays_flex_train_backward(np.ones((1, 2), np.float32), sig2, np.ones((6, 2), np.float32), dl2, r2)
+    assert np.all(gi == 0)  # first sample already drives T below the threshold -> break before any write
+    out = oracle.composite_rays_flex_train_forward(sig2, np.ones((6, 2), np.float32), dl2, r2)
+    assert np.all(out > 0.99)  # ... while the forward did accumulate it
+    # quirk 3: training depth integrates deltas[:,1] from 0
+    ws, dep, img = oracle.composite_rays_train_forward(np.array([1e4, 0], np.float32), np.ones((2, 3), np.float32),
+                                                       np.array([[0.01, 0.7], [0, 0]], np.float32), np.array([[0, 0, 1]], np.int32))
+    assert abs(dep[0] - 0.7) < 1e-6
+
+
+def test_composite_inference_chunking_matches_training_recurrence():
+    """Feeding one ray's samples to composite_rays in chunks accumulates the same weights as the
+    training kernel (T = 1 - ws vs the running product differ only by rounding)."""
+    rng = np.random.default_rng(8)
+    cnt = 37
+    sig = (rng.random(cnt) * 20).astype(np.float32)
+    rgb = rng.random((cnt, 3)).astype(np.float32)
+    dl = np.stack([np.full(cnt, 0.01), np.full(cnt, 0.01)], 1).astype(np.float32)
+    ws_t, dep_t, img_t = oracle.composite_rays_train_forward(sig, rgb, dl, np.array([[0, 0, cnt]], np.int32), T_thresh=1e-4)
+    alive = np.array([0], np.int32)
+    rays_t = np.array([0.0], np.float32)
+    ws, dep, img = np.zeros(1, np.float32), np.zeros(1, np.float32), np.zeros((1, 3), np.float32)
+    pos, n_step = 0, 4
+    while alive[0] >= 0 and pos < cnt:
+        k = min(n_step, cnt - pos)
+        s = np.zeros(n_step, np.float32); c = np.zeros((n_step, 3), np.float32); d = np.zeros((n_step, 2), np.float32)
+        s[:k], c[:k], d[:k] = sig[pos:pos + k], rgb[pos:pos + k], dl[pos:pos + k]
+        oracle.composite_rays(1, n_step, alive, rays_t, s, c, d, ws, dep, img, T_thresh=1e-4)
+        pos += k
+    np.testing.assert_allclose(ws, ws_t, rtol=1e-5)
+    np.testing.assert_allclose(img, img_t, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dep, dep_t, rtol=1e-5, atol=1e-6)
+    assert alive[0] == -1  # ran out of samples (delta == 0 sentinel) or T fell below the threshold
+
+
+def test_composite_rays_flex_reads_but_never_writes_state():
+    rng = np.random.default_rng(9)
+    n_alive, n_step, nc = 5, 3, 20
+    alive = np.arange(n_alive, dtype=np.int32)
+    rays_t = rng.random(n_alive).astype(np.float32)
+    ws = (rng.random(n_alive) * 0.5).astype(np.float32)
+    sig = (rng.random(n_alive * n_step) * 10).astype(np.float32)
+    inp = rng.random((n_alive * n_step, nc)).astype(np.float32)
+    dl = np.full((n_alive * n_step, 2), 0.02, np.float32)
+    out = np.zeros((n_alive, nc), np.float32)
+    a0, t0, w0 = alive.copy(), rays_t.copy(), ws.copy()
+    oracle.composite_rays_flex(n_alive, n_step, nc, alive, rays_t, sig, inp, dl, ws, out)
+    assert (alive == a0).all() and (rays_t == t0).all() and (ws == w0).all() and out.any()
+    # and it equals composite_rays on the same weights, channel by channel
+    d, img = np.zeros(n_alive, np.float32), np.zeros((n_alive, 3), np.float32)
+    oracle.composite_rays(n_alive, n_step, alive, rays_t, sig, inp[:, :3].copy(), dl, ws, d, img)
+    np.testing.assert_array_equal(img, out[:, :3])
+
+
+# ------------------------------------------------------------------------------------------ hash grid
+def _torch_grid(x, emb, offsets, pls, H, L, C):
+    """Independent vectorised formulation (float64 interpolation, integer maths in int64)."""
+    primes = [1, 2654435761, 805459861]
+    scales, ress = oracle.grid_level_params(L, pls, H)  # host-precomputed per-level constants (inputs of the kernels)
+    outs = []
+    for l in range(L):
+        scale, res = scales[l], int(ress[l])
+        assert res == int(np.ceil(scale)) + 1 and abs(float(scale) - (H * float(pls) ** l - 1)) < 1e-3 * (float(scale) + 1)
+        T = int(offsets[l + 1] - offsets[l])
+        # single-rounded x*scale+0.5 (== fmaf): the product of two binary32 numbers is exact in binary64
+        pos = (x.detach().numpy() * np.float64(scale) + 0.5).astype(np.float32)
+        pg = np.floor(pos).astype(np.int64)
+        fr32 = torch.from_numpy((pos - pg.astype(np.float32)).astype(np.float64))  # the fp32 fractional part the kernel interpolates with
+        fr = x * float(scale) + 0.5 - torch.from_numpy(pg).double()
+        fr = fr + (fr32 - fr.detach())  # value of fr32, derivative d fr / d x = scale
+        acc = 0
+        for corner in range(8):
+            bits = [(corner >> d) & 1 for d in range(3)]
+            c = pg + np.array(bits)
+            w = torch.ones(x.shape[0], dtype=torch.float64)
+            for d in range(3):
+                w = w * (fr[:, d] if bits[d] else 1 - fr[:, d])
+            stride, idx, hashed = 1, np.zeros(len(c), np.int64), False
+            for d in range(3):
+                if stride <= T:
+                    idx += c[:, d] * stride
+                    stride *= res + 1
+            if stride > T:
+                idx = np.zeros(len(c), np.int64)
+                for d in range(3):
+                    idx ^= (c[:, d] * primes[d]) & 0xFFFFFFFF
+            idx = idx % T + int(offsets[l])
+            acc = acc + w[:, None] * emb[torch.from_numpy(idx)]
+        outs.append(acc)
+    return torch.cat(outs, 1)
+
+
+@pytest.mark.parametrize("cfg", [dict(L=16, H=16, log2T=19, desired=4096), dict(L=6, H=4, log2T=8, desired=None)])
+def test_grid_encode_forward_backward_against_independent_torch(cfg):
+    rng = np.random.default_rng(10)
+    L, H, C = cfg["L"], cfg["H"], 2
+    pls = np.exp2(np.log2(cfg["desired"] / H) / (L - 1)) if cfg["desired"] else 2.0
+    offsets = oracle.grid_offsets(3, L, pls, H, cfg["log2T"])
+    emb = (rng.random((int(offsets[-1]), C)) - 0.5).astype(np.float32)
+    x = rng.random((300, 3)).astype(np.float32)
+    out, dydx = oracle.grid_encode_forward(x, emb, offsets, pls, H, calc_grad_inputs=True)
+    te = torch.tensor(emb, dtype=torch.float64, requires_grad=True)
+    tx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    ref = _torch_grid(tx, te, offsets, pls, H, L, C)
+    np.testing.assert_allclose(out, ref.detach().numpy(), rtol=1e-4, atol=3e-6)
+    g = rng.standard_normal(out.shape).astype(np.float32)
+    (ref * torch.tensor(g, dtype=torch.float64)).sum().backward()
+    gg, gi = oracle.grid_encode_backward(g, x, emb.shape, offsets, pls, H, dy_dx=dydx)
+    np.testing.assert_allclose(gg, te.grad.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(gi, tx.grad.numpy(), rtol=2e-3, atol=2e-2 * np.abs(tx.grad.numpy()).max())
+
+
+def test_grid_encode_level_sizes_match_survey():
+    offsets = oracle.grid_offsets(3, 16, np.exp2(np.log2(4096 / 16) / 15), 16, 19)
+    sizes = np.diff(offsets)
+    assert sizes[:5].tolist() == [4920, 15632, 42880, 125000, 373248] and (sizes[5:] == 524288).all() and offsets[-1] == 6328848
+
+
+def test_grid_encode_out_of_range_inputs_give_zeros():
+    offsets = oracle.grid_offsets(3, 4, 2.0, 4, 8)
+    emb = np.ones((int(offsets[-1]), 2), np.float32)
+    x = np.array([[0.5, 0.5, 1.0001], [-1e-6, 0.2, 0.2], [0.0, 1.0, 0.5]], np.float32)
+    out, dydx = oracle.grid_encode_forward(x, emb, offsets, 2.0, 4, calc_grad_inputs=True)
+    assert np.all(out[:2] == 0) and np.all(dydx[:2] == 0) and np.all(out[2] > 0)  # boundaries 0 and 1 are inside
+    gg = oracle.grid_encode_backward(np.ones_like(out), x, emb.shape, offsets, 2.0, 4)
+    assert gg.sum() > 0 and np.isclose(gg.sum(), 8.0)  # only the in-range sample scatters: 4 levels * 2 channels * sum(w)=1
+
+
+def test_grid_encode_gradcheck_recipe_of_reference_test():
+    """testing/test_hashgrid_grad.py: L=4, C=2, H=4, T=2^8 (offsets without the /8 rounding there), one point,
+    eps=1e-2, atol=1e-3, rtol=0.01 -- central differences on the embeddings."""
+    rng = np.random.default_rng(11)
+    offsets = np.array([0, 125, 381, 637, 893], np.int32)  # min(2^8, (4*2^i+1)^3)
+    emb = (rng.standard_normal((893, 2)) * 0.1).astype(np.float32)
+    x = rng.random((1, 3)).astype(np.float32)
+    out = oracle.grid_encode_forward(x, emb, offsets, 2, 4)
+    g = np.ones_like(out)
+    gg = oracle.grid_encode_backward(g, x, emb.shape, offsets, 2, 4)
+    touched = np.argwhere(gg != 0)
+    assert 0 < len(touched) <= 4 * 8 * 2
+    for r, c in touched[:: max(1, len(touched) // 12)]:
+        e = emb.copy(); e[r, c] += 1e-2
+        up = oracle.grid_encode_forward(x, e, offsets, 2, 4).sum()
+        e[r, c] -= 2e-2
+        dn = oracle.grid_encode_forward(x, e, offsets, 2, 4).sum()
+        assert abs((up - dn) / 2e-2 - gg[r, c]) < 1e-3 + 0.01 * abs(gg[r, c])
+
+
+def test_grid_encode_half_table_accumulates_in_half():
+    rng = np.random.default_rng(12)
+    offsets = oracle.grid_offsets(3, 8, 1.6, 16, 14)
+    emb = (rng.random((int(offsets[-1]), 2)) - 0.5).astype(np.float16)
+    x = rng.random((200, 3)).astype(np.float32)
+    h = oracle.grid_encode_forward(x, emb, offsets, 1.6, 16)
+    f = oracle.grid_encode_forward(x, emb.astype(np.float32), offsets, 1.6, 16)
+    assert h.dtype == np.float16
+    np.testing.assert_allclose(h.astype(np.float32), f, atol=2e-3)
+    assert np.abs(h.astype(np.float32) - f).max() > 0  # the half accumulator is visibly not the fp32 one
+
+
+# ------------------------------------------------------------------------------------------ march
+@pytest.fixture(scope="module")
+def s0():
+    grid = scene.brick_density_grid()
+    return grid, oracle.packbits(grid, 0.5)
+
+
+def _rays(H, W):
+    pose = torch.from_numpy(scene.lookat_pose())[None]
+    ro, rd = scene.get_rays(pose, scene.intrinsics_from_fov(H, W), H, W)
+    return ro[0].numpy(), rd[0].numpy()
+
+
+def test_scene_s0_calibration(s0):
+    grid, bf = s0
+    assert int((grid[0] > 0).sum()) == 444528 and int((grid[1] > 0).sum()) == 55566
+    np.testing.assert_array_equal(bf, scene.packbits_np(grid, 0.5))
+
+
+@pytest.mark.parametrize("dt_gamma", [0.0, 1.0 / 128])
+def test_march_train_samples_are_in_occupied_cells_and_rows_are_prefix_sums(s0, dt_gamma):
+    grid, bf = s0
+    ro, rd = _rays(24, 24)
+    nears, fars = oracle.near_far_from_aabb(ro, rd, [-2, -2, -2, 2, 2, 2], 0.2)
+    cnt = np.zeros(2, np.int32)
+    xyzs, dirs, deltas, rays = oracle.march_rays_train(ro, rd, 2.0, bf, 2, 128, nears, fars, cnt, align=128, force_all_rays=True, dt_gamma=dt_gamma)
+    m = int(cnt[0])
+    assert cnt[1] == 576 and xyzs.shape[0] % 128 == 0 and xyzs.shape[0] >= m and m > 0
+    np.testing.assert_array_equal(rays[:, 0], np.arange(576))
+    np.testing.assert_array_equal(rays[:, 1], np.concatenate([[0], np.cumsum(rays[:, 2])[:-1]]))
+    assert rays[:, 2].sum() == m and np.all(deltas[m:] == 0) and np.all(deltas[:m, 0] > 0)
+    # every emitted sample sits in an occupied cell of the cascade the kernel picked for it
+    p = xyzs[:m]
+    mx = np.abs(p).max(1)
+    _, e = np.frexp(mx)
+    lvl_dt = np.maximum(np.frexp(deltas[:m, 0] * 128 * 0.5)[1], 0)
+    lvl = np.clip(np.maximum(e, lvl_dt), 0, 1)
+    mb = np.minimum(np.exp2(lvl), 2.0)[:, None]
+    cell = np.clip((0.5 * (p / mb + 1) * 128), 0, 127).astype(np.uint32)
+    index = lvl.astype(np.uint32) * 128 ** 3 + scene.morton3d_np(cell[:, 0], cell[:, 1], cell[:, 2])
+    assert np.all((bf[index // 8] >> (index % 8)) & 1)
+    if dt_gamma == 0:
+        assert np.all(deltas[:m, 0] == np.float32(2 * np.float32(1.7320508075688772) / 1024))
+
+
+def test_march_inference_single_chunk_equals_training_march(s0):
+    grid, bf = s0
+    ro, rd = _rays(20, 20)
+    N = ro.shape[0]
+    nears, fars = oracle.near_far_from_aabb(ro, rd, [-2, -2, -2, 2, 2, 2], 0.2)
+    cnt = np.zeros(2, np.int32)
+    xt, dtt, dlt, rays = oracle.march_rays_train(ro, rd, 2.0, bf, 2, 128, nears, fars, cnt, force_all_rays=True)
+    n_step = int(rays[:, 2].max())
+    x, d, dl = oracle.march_rays(N, n_step, np.arange(N, dtype=np.int32), nears.copy(), ro, rd, 2.0, bf, 2, 128, nears, fars, align=128)
+    assert x.shape[0] == N * n_step + (128 - (N * n_step) % 128)  # always pads, even when aligned (quirk 4)
+    for n in range(0, N, 7):
+        off, c = rays[n, 1], rays[n, 2]
+        np.testing.assert_array_equal(x[n * n_step:n * n_step + c], xt[off:off + c])
+        np.testing.assert_array_equal(dl[n * n_step:n * n_step + c], dlt[off:off + c])
+        assert np.all(dl[n * n_step + c:(n + 1) * n_step] == 0)
+
+
+def test_march_train_drops_rays_that_overflow_M(s0):
+    grid, bf = s0
+    ro, rd = _rays(16, 16)
+    nears, fars = oracle.near_far_from_aabb(ro, rd, [-2, -2, -2, 2, 2, 2], 0.2)
+    cnt = np.zeros(2, np.int32)
+    xyzs, dirs, deltas, rays = oracle.march_rays_train(ro, rd, 2.0, bf, 2, 128, nears, fars, cnt, mean_count=1000, align=128)
+    M = xyzs.shape[0]
+    assert M == 1024 and cnt[0] > M  # counter keeps counting past M
+    over = rays[:, 1] + rays[:, 2] > M
+    assert over.any()
+    first_over = int(np.argmax(over))
+    assert np.all(deltas[rays[first_over, 1]:M] == 0)  # nothing written for the overflowing ray
+    ws, dep, img = oracle.composite_rays_train_forward(np.ones(M, np.float32), np.ones((M, 3), np.float32), deltas, rays)
+    assert np.all(ws[rays[over, 0]] == 0)
