@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path's headline benchmark (BASELINE.json: rendered samples/sec + ms/frame @800x800).
+
+A "step" is one inference frame of the occupancy-march path over a batch of synthetic rays:
+configs[1] = NeRF-synthetic-lego geometry, `-m nerf` inference, 800x800, scene S0 (SURVEY.md 8d /
+Appendix B), seeded random-init field, inputs resident in HBM when the timed region starts.
+
+N > 1: the frame's rays are sharded over ranks in interleaved 32x32 tiles; every frame ends with one
+all_gather_into_tensor (RCCL) of the packed per-ray (rgb, depth, alpha) -- strong scaling.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+GRID_BYTES_PER_SAMPLE_FP32 = 12 + 16 * 8 * 2 * 4 + 32 * 4  # 1164 B: xyz + 16 levels x 8 corners x 2 x fp32 + 32 outputs
+GRID_BYTES_PER_SAMPLE_FP16 = 12 + 16 * 8 * 2 * 2 + 32 * 2  # 588 B
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--model", choices=["nerf", "palette"], default="nerf")
+    ap.add_argument("--density-scale", type=float, default=100.0, help="S0-opaque (trained-scene-like early termination); ~0 = translucent")
+    ap.add_argument("--fp16", action="store_true", help="the reference's -O mode: autocast, half hash tables")
+    ap.add_argument("--mode", choices=["compat", "device", "fused"], default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-crop", type=int, default=320, help="side of the centre crop timed on the CPU oracle")
+    return ap.parse_args()
+
+
+def build_model(args, device):
+    from palettenerf_amd import network, raymarching, renderer, scene
+    if args.model == "nerf":
+        m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=args.density_scale, min_near=0.2)
+    else:
+        m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True, density_scale=args.density_scale, min_near=0.2)
+    scene.seed_field_(m, 0)
+    m = m.to(device).eval()
+    m.density_grid.copy_(torch.from_numpy(scene.brick_density_grid()).to(device))
+    raymarching.packbits(m.density_grid, 0.5, m.density_bitfield)
+    m.count_rendered = True
+    return m
+
+
+def cpu_baseline(args):
+    """The oracle ("port") timed on this host, 1 thread, on a bounded centre crop of the same frame."""
+    import numpy as np
+    import oracle
+    from oracle.facade import make_oracle_modules
+    from palettenerf_amd import network, renderer, scene
+    import palettenerf_amd.gridencoder as pge
+    import palettenerf_amd.shencoder as psh
+    torch.set_num_threads(1)
+    rm, ge, sh, pu = make_oracle_modules()
+    saved = (renderer.raymarching, pge.GridEncoder, psh.SHEncoder)
+    renderer.raymarching, pge.GridEncoder, psh.SHEncoder = rm, ge.GridEncoder, sh.SHEncoder
+    try:
+        m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=args.density_scale, min_near=0.2)
+        scene.seed_field_(m, 0)
+        grid = scene.brick_density_grid()
+        m.density_grid.copy_(torch.from_numpy(grid))
+        m.density_bitfield.copy_(torch.from_numpy(oracle.packbits(grid, 0.5)))
+        m.eval()
+        m.count_rendered = True
+        H = W = args.res
+        pose = torch.from_numpy(scene.lookat_pose())[None]
+        ro, rd = scene.get_rays(pose, scene.intrinsics_from_fov(H, W), H, W)
+        c = args.cpu_crop
+        ys = torch.arange(H // 2 - c // 2, H // 2 + c // 2)
+        idx = (ys[:, None] * W + ys[None, :]).reshape(-1)
+        ro, rd = ro[:, idx].contiguous(), rd[:, idx].contiguous()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            r = m.render(ro, rd, perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+        dt = time.perf_counter() - t0
+        n = int(r["rendered"].item())
+    finally:
+        renderer.raymarching, pge.GridEncoder, psh.SHEncoder = saved
+    return {"value": n / dt, "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": f"centre {c}x{c} crop of the {H}x{W} frame ({idx.numel()} rays, {n} rendered samples, {dt:.1f} s; C oracle ops + torch CPU MLP, 1 thread; "
+                      f"host has {os.cpu_count()} cores)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from palettenerf_amd import _torch_glue, dist as pdist, scene
+    m = build_model(args, device)
+    m.march_mode = args.mode or "device"
+    H = W = args.res
+    pose = torch.from_numpy(scene.lookat_pose())[None]
+    ro, rd = scene.get_rays(pose, scene.intrinsics_from_fov(H, W), H, W)
+    idx, n_max = pdist.shard_indices(H, W, rank, world)
+    ro, rd = ro[:, idx].contiguous().to(device), rd[:, idx].contiguous().to(device)
+    kw = dict(perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+    if args.model == "palette":
+        kw["gui_mode"] = False
+
+    def frame():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=args.fp16):
+            r = m.render(ro, rd, **kw)
+        if world > 1:
+            local = torch.cat([r["image"][0], r["depth"][0][:, None], r["weights_sum"][:, None]], dim=1)
+            full = pdist.gather_frame(local, idx, n_max, H, W)
+            return r, full
+        return r, None
+
+    for _ in range(args.warmup):
+        frame()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    prof = _torch_glue.profile_kernels(["pnr_grid_encode_forward"]) if rank == 0 else None
+    rendered = torch.zeros(1, dtype=torch.int64, device=device)
+    rows = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r, _full = frame()
+        rendered += r["rendered"]
+        rows += r["n_samples"]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    _torch_glue.profile_kernels(None)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rendered, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    total_rendered = int(rendered.item())
+
+    if rank == 0:
+        per_sample = GRID_BYTES_PER_SAMPLE_FP16 if args.fp16 else GRID_BYTES_PER_SAMPLE_FP32
+        launches = prof["pnr_grid_encode_forward"]
+        k_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in launches)
+        k_units = sum(u for _, _, u in launches)
+        achieved = (k_units * per_sample) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            "metric": "rendered_samples_per_sec", "value": total_rendered / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f16" if args.fp16 else "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: NeRF-synthetic lego geometry (scene S0), -m {args.model} inference, {H}x{W}, 1 frame/step",
+                       "rays_per_frame": H * W, "rendered_samples_per_frame": total_rendered // args.steps,
+                       "evaluated_rows_per_frame_rank0": rows // args.steps, "density_scale": args.density_scale, "march_mode": m.march_mode,
+                       "parallelism": f"ray-tiles x{world} + all_gather" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "k_grid_fwd (pnr_grid_encode_forward)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": len(launches),
+                         "avg_launch_ms": k_ms / max(1, len(launches)), "avg_rows_per_launch": k_units / max(1, len(launches)),
+                         "algorithmic_bytes_per_row": per_sample},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

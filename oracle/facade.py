@@ -7,7 +7,7 @@ import types
 import numpy as np
 import torch
 
-import oracle
+from . import orc as oracle
 
 
 def _t(a):

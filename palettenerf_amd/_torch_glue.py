@@ -32,7 +32,25 @@ def require(t, dtype, name):
     return t
 
 
-def call(name, *args):
+_profile = None  # name -> list of (start_event, end_event, units); see profile_kernels()
+
+
+def profile_kernels(names=None):
+    """Enable (list of C-ABI entry names) or disable (None) HIP-event timing of individual launches.
+    Events are recorded on torch's current stream, the stream the kernels are launched on."""
+    global _profile
+    _profile = None if names is None else {n: [] for n in names}
+    return _profile
+
+
+def call(name, *args, units=0):
+    if _profile is not None and name in _profile:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.call(name, *args, stream_ptr())
+        e1.record()
+        _profile[name].append((e0, e1, units))
+        return
     _lib.call(name, *args, stream_ptr())
 
 

@@ -40,7 +40,7 @@ class _grid_encode(Function):
         dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=embeddings.dtype) if calc_grad_inputs else None
         call("pnr_grid_encode_forward", ptr(require(inputs, torch.float32, "inputs")), ptr(require(embeddings, embeddings.dtype, "embeddings")),
              ptr(require(offsets, torch.int32, "offsets")), ptr(outputs), _u32(B), _u32(D), _u32(C), _u32(L), _f32(S), _u32(H), ptr(dy_dx),
-             _u32(gridtype), _int(int(align_corners)), _int(_DTYPE_ID[embeddings.dtype]))
+             _u32(gridtype), _int(int(align_corners)), _int(_DTYPE_ID[embeddings.dtype]), units=B)
         outputs = outputs.permute(1, 0, 2).reshape(B, L * C)
         ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
         ctx.dims = [B, D, C, L, S, H, gridtype]

@@ -43,6 +43,7 @@ class _MarchState:
         self.rays_alive = torch.arange(N, dtype=torch.int32, device=device)
         self.rays_t = nears.clone()
         self.n_samples = 0  # evaluated rows (incl. padding), host-side bookkeeping only
+        self.rendered = torch.zeros(1, dtype=torch.int64, device=device)  # march-emitted samples (delta > 0), device-side
 
 
 class _RendererBase(nn.Module):
@@ -55,6 +56,7 @@ class _RendererBase(nn.Module):
         self.density_thresh = density_thresh
         self.bg_radius = bg_radius
         self.march_mode = "compat"
+        self.count_rendered = False
         aabb_train = torch.FloatTensor([-bound, -bound, -bound, bound, bound, bound])
         self.register_buffer("aabb_train", aabb_train)
         self.register_buffer("aabb_infer", aabb_train.clone())
@@ -100,6 +102,8 @@ class _RendererBase(nn.Module):
                                                         self.density_bitfield, self.cascade, self.grid_size, nears, fars, 128,
                                                         perturb if step == 0 else False, dt_gamma, max_steps)
             st.n_samples += xyzs.shape[0]
+            if self.count_rendered:
+                st.rendered += (deltas[:, 0] > 0).sum()
             shade(st, n_alive, n_step, xyzs, dirs, deltas)
             if device_mode:
                 out, _ = raymarching.compact_alive(st.rays_alive, n_alive, out=spare, count=count)
@@ -189,6 +193,7 @@ class NeRFRenderer(_RendererBase):
             depth = depth.view(*prefix)
             rgb_norm_map = torch.zeros_like(image[..., 0])
             results["n_samples"] = st.n_samples
+            results["rendered"] = st.rendered
         results["depth"] = depth
         results["image"] = image
         results["rgb_norm"] = rgb_norm_map
@@ -429,6 +434,7 @@ class PaletteRenderer(_RendererBase):
         results["weights_sum"] = weights_sum
         results["clip_feat"] = clip_feat_map.view(*prefix, clip_dim)
         results["n_samples"] = st.n_samples
+        results["rendered"] = st.rendered
         if not gui_mode:
             results["direct_rgb"] = (direct_rgb_map + (1 - weights_sum).unsqueeze(-1) * bg_color).view(*prefix, 3)
             results["view_dep_rgb"] = view_dep_rgb_map.view(*prefix, 3)

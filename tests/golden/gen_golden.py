@@ -77,7 +77,7 @@ def gen_sh_cuda_expr():
 
 
 # ------------------------------------------------------------------------------------------ frames
-from tests.oracle_facade import make_oracle_modules, _t  # noqa: E402
+from oracle.facade import make_oracle_modules, _t  # noqa: E402
 
 
 class _Stub(types.ModuleType):

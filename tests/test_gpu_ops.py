@@ -1,0 +1,393 @@
+"""GPU parity tests proper: every HIP kernel, called through the C ABI (via the operator mirror),
+against the CPU oracle on the same seeded inputs.  Integer / index / count outputs must be
+bit-exact; fp32 outputs carry the tolerance written next to each assertion."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from palettenerf_amd import gridencoder, palette_utils, raymarching, scene, shencoder
+
+pytestmark = pytest.mark.gpu
+
+EXP_TOL = dict(rtol=2e-5, atol=2e-6)  # __expf (v_exp_f32) vs libm expf in the compositing kernels
+
+
+def dev(a, cuda):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def s0():
+    grid = scene.brick_density_grid()
+    return grid, scene.packbits_np(grid, 0.5)
+
+
+def rays_of(H, W, elev=30.0, azim=45.0):
+    pose = torch.from_numpy(scene.lookat_pose(elevation_deg=elev, azimuth_deg=azim))[None]
+    ro, rd = scene.get_rays(pose, scene.intrinsics_from_fov(H, W), H, W)
+    return ro[0].numpy(), rd[0].numpy()
+
+
+# ------------------------------------------------------------------------------------------ integer / utils
+def test_morton_bit_exact(cuda):
+    rng = np.random.default_rng(0)
+    c = rng.integers(0, 1024, size=(100003, 3)).astype(np.int32)
+    idx = raymarching.morton3D(dev(c, cuda))
+    np.testing.assert_array_equal(host(idx), oracle.morton3D(c))
+    np.testing.assert_array_equal(host(raymarching.morton3D_invert(idx)), c)
+    full = np.stack(np.meshgrid(*[np.arange(128, dtype=np.int32)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    got = host(raymarching.morton3D(dev(full, cuda)))
+    np.testing.assert_array_equal(got, oracle.morton3D(full))
+    assert np.array_equal(np.sort(got), np.arange(128 ** 3))  # full-size sweep is a bijection
+    assert raymarching.morton3D(torch.zeros(0, 3, dtype=torch.int32, device=cuda)).shape == (0,)
+
+
+def test_packbits_bit_exact(cuda, s0):
+    grid, bf = s0
+    got = raymarching.packbits(dev(grid, cuda), 0.5)
+    np.testing.assert_array_equal(host(got), bf)
+    rng = np.random.default_rng(1)
+    g = rng.random((2, 128 ** 3)).astype(np.float32)
+    buf = torch.zeros(2 * 128 ** 3 // 8, dtype=torch.uint8, device=cuda)
+    out = raymarching.packbits(dev(g, cuda), 0.37, buf)
+    assert out.data_ptr() == buf.data_ptr()  # writes into the given buffer
+    np.testing.assert_array_equal(host(out), oracle.packbits(g, 0.37))
+
+
+def test_near_far_bit_exact(cuda):
+    rng = np.random.default_rng(2)
+    o = rng.uniform(-3, 3, (50001, 3)).astype(np.float32)
+    d = rng.standard_normal((50001, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:100, 0] = 0.0  # axis-aligned rays: 1/dx = inf
+    o[:50, 0] = 2.0   # origin exactly on a slab with dx = 0: 0*inf NaNs
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    n, f = raymarching.near_far_from_aabb(dev(o, cuda), dev(d, cuda), dev(aabb, cuda), 0.05)
+    on, of = oracle.near_far_from_aabb(o, d, aabb, 0.05)
+    np.testing.assert_array_equal(host(n), on)
+    np.testing.assert_array_equal(host(f), of)
+
+
+def test_sph_from_ray(cuda):
+    rng = np.random.default_rng(3)
+    o = rng.uniform(-0.5, 0.5, (1000, 3)).astype(np.float32)
+    d = rng.standard_normal((1000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    got = host(raymarching.sph_from_ray(dev(o, cuda), dev(d, cuda), 2.5))
+    np.testing.assert_allclose(got, oracle.sph_from_ray(o, d, 2.5), atol=2e-6)  # atan2f/sqrtf implementations differ by ulps
+
+
+# ------------------------------------------------------------------------------------------ march
+@pytest.mark.parametrize("dt_gamma,min_near", [(0.0, 0.2), (1.0 / 128, 0.02)])
+def test_march_rays_train_bit_exact(cuda, s0, dt_gamma, min_near):
+    grid, bf = s0
+    ro, rd = rays_of(64, 48)
+    N = ro.shape[0]
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    on, of = oracle.near_far_from_aabb(ro, rd, aabb, min_near)
+    cnt = np.zeros(2, np.int32)
+    ox, od, odl, orays = oracle.march_rays_train(ro, rd, 2.0, bf, 2, 128, on, of, cnt, align=128, force_all_rays=True, dt_gamma=dt_gamma)
+    counter = torch.zeros(2, dtype=torch.int32, device=cuda)
+    x, d, dl, rays = raymarching.march_rays_train(dev(ro, cuda), dev(rd, cuda), 2.0, dev(bf, cuda), 2, 128, dev(on, cuda), dev(of, cuda), counter,
+                                                  -1, False, 128, True, dt_gamma, 1024)
+    np.testing.assert_array_equal(host(counter), cnt)            # total sample count and ray count: bit-exact
+    np.testing.assert_array_equal(host(rays), orays)             # per-ray (id, offset, count): bit-exact, deterministic row order
+    assert x.shape == ox.shape
+    np.testing.assert_array_equal(host(x), ox)                   # positions bit-exact (canonical fmaf spec on both sides)
+    np.testing.assert_array_equal(host(d), od)
+    np.testing.assert_array_equal(host(dl), odl)
+
+
+def test_march_rays_train_perturbed_and_mean_count_overflow(cuda, s0):
+    grid, bf = s0
+    ro, rd = rays_of(32, 32)
+    N = ro.shape[0]
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    on, of = oracle.near_far_from_aabb(ro, rd, aabb, 0.2)
+    # overflow path: M = mean_count rounded up, rays that do not fit are dropped (raymarching.cu:419)
+    cnt = np.zeros(2, np.int32)
+    ox, od, odl, orays = oracle.march_rays_train(ro, rd, 2.0, bf, 2, 128, on, of, cnt, mean_count=5000, align=128)
+    counter = torch.zeros(2, dtype=torch.int32, device=cuda)
+    x, d, dl, rays = raymarching.march_rays_train(dev(ro, cuda), dev(rd, cuda), 2.0, dev(bf, cuda), 2, 128, dev(on, cuda), dev(of, cuda), counter,
+                                                  5000, False, 128, False, 0.0, 1024)
+    assert x.shape[0] == 5120 and int(counter[0]) > 5120
+    np.testing.assert_array_equal(host(counter), cnt)
+    np.testing.assert_array_equal(host(rays), orays)
+    np.testing.assert_array_equal(host(x), ox)
+    np.testing.assert_array_equal(host(dl), odl)
+    # perturb=True draws torch.rand noises on the device: check counts stay within one step of the unperturbed march
+    counter.zero_()
+    _, _, _, rays_p = raymarching.march_rays_train(dev(ro, cuda), dev(rd, cuda), 2.0, dev(bf, cuda), 2, 128, dev(on, cuda), dev(of, cuda), counter,
+                                                   -1, True, 128, True, 0.0, 1024)
+    cnt2 = np.zeros(2, np.int32)
+    _, _, _, rays0 = oracle.march_rays_train(ro, rd, 2.0, bf, 2, 128, on, of, cnt2, align=128, force_all_rays=True)
+    assert np.abs(host(rays_p)[:, 2] - rays0[:, 2]).max() <= 2
+
+
+@pytest.mark.parametrize("n_step", [1, 3, 8])
+def test_march_rays_inference_bit_exact(cuda, s0, n_step):
+    grid, bf = s0
+    ro, rd = rays_of(48, 40)
+    N = ro.shape[0]
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    on, of = oracle.near_far_from_aabb(ro, rd, aabb, 0.2)
+    rng = np.random.default_rng(4)
+    alive = np.sort(rng.choice(N, N // 2, replace=False)).astype(np.int32)
+    rays_t = on.copy()
+    rays_t[alive[::3]] += 0.5  # some rays already advanced
+    ox, od, odl = oracle.march_rays(len(alive), n_step, alive, rays_t, ro, rd, 2.0, bf, 2, 128, on, of, align=128, dt_gamma=1.0 / 256)
+    x, d, dl = raymarching.march_rays(len(alive), n_step, dev(alive, cuda), dev(rays_t, cuda), dev(ro, cuda), dev(rd, cuda), 2.0, dev(bf, cuda), 2, 128,
+                                      dev(on, cuda), dev(of, cuda), 128, False, 1.0 / 256, 1024)
+    assert x.shape == ox.shape and x.shape[0] % 128 == 0 and x.shape[0] > len(alive) * n_step - 1
+    np.testing.assert_array_equal(host(x), ox)
+    np.testing.assert_array_equal(host(d), od)
+    np.testing.assert_array_equal(host(dl), odl)
+    assert int((odl[:, 0] > 0).sum()) > 0
+
+
+def test_compact_alive_is_stable_and_exact(cuda):
+    rng = np.random.default_rng(5)
+    for n in (1, 63, 64, 65, 255, 256, 257, 100000, 640000):
+        a = rng.integers(0, 1 << 20, n).astype(np.int32)
+        a[rng.random(n) < 0.6] = -1
+        out, count = raymarching.compact_alive(dev(a, cuda))
+        k = int(count.item())
+        want = a[a >= 0]
+        assert k == len(want)
+        np.testing.assert_array_equal(host(out)[:k], want)
+    out, count = raymarching.compact_alive(dev(np.full(1000, -1, np.int32), cuda))
+    assert int(count.item()) == 0
+
+
+# ------------------------------------------------------------------------------------------ composite
+def _train_case(rng, N, max_len, nc):
+    counts = rng.integers(0, max_len, N)
+    counts[:3] = 0
+    offs = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    M = int(counts.sum())
+    rays = np.stack([rng.permutation(N), offs, counts], 1).astype(np.int32)
+    sig = (rng.random(M) * 40).astype(np.float32)
+    rgb = rng.random((M, 3)).astype(np.float32)
+    feat = rng.standard_normal((M, nc)).astype(np.float32)
+    dl = np.stack([rng.random(M) * 0.02 + 0.003, rng.random(M) * 0.05 + 0.003], 1).astype(np.float32)
+    return rays, sig, rgb, feat, dl, M
+
+
+def test_composite_train_forward_backward(cuda):
+    rng = np.random.default_rng(6)
+    N = 3000
+    rays, sig, rgb, feat, dl, M = _train_case(rng, N, 200, 33)
+    ts, tc = dev(sig, cuda).requires_grad_(True), dev(rgb, cuda).requires_grad_(True)
+    ws, dep, img = raymarching.composite_rays_train(ts, tc, dev(dl, cuda), dev(rays, cuda), 1e-4)
+    ows, odep, oimg = oracle.composite_rays_train_forward(sig, rgb, dl, rays, 1e-4)
+    np.testing.assert_allclose(host(ws), ows, **EXP_TOL)
+    np.testing.assert_allclose(host(dep), odep, **EXP_TOL)
+    np.testing.assert_allclose(host(img), oimg, **EXP_TOL)
+    gws, gimg = rng.standard_normal(N).astype(np.float32), rng.standard_normal((N, 3)).astype(np.float32)
+    ((ws * dev(gws, cuda)).sum() + (img * dev(gimg, cuda)).sum() + dep.sum()).backward()  # grad_depth is ignored by design
+    ogs, ogc = oracle.composite_rays_train_backward(gws, gimg, sig, rgb, dl, rays, ows, oimg, 1e-4)
+    np.testing.assert_allclose(host(tc.grad), ogc, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(host(ts.grad), ogs, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("nc", [1, 3, 16, 33, 128])
+def test_composite_flex_train_forward_backward(cuda, nc):
+    rng = np.random.default_rng(7)
+    N = 1500
+    rays, sig, rgb, feat, dl, M = _train_case(rng, N, 120, nc)
+    tf = dev(feat, cuda).requires_grad_(True)
+    out = raymarching.composite_rays_flex_train(dev(sig, cuda), tf, dev(dl, cuda), dev(rays, cuda), 1e-4)
+    oout = oracle.composite_rays_flex_train_forward(sig, feat, dl, rays, 1e-4)
+    np.testing.assert_allclose(host(out), oout, rtol=2e-5, atol=2e-5)
+    go = rng.standard_normal((N, nc)).astype(np.float32)
+    (out * dev(go, cuda)).sum().backward()
+    np.testing.assert_allclose(host(tf.grad), oracle.composite_rays_flex_train_backward(go, sig, feat, dl, rays, 1e-4), rtol=2e-5, atol=2e-6)
+
+
+def test_composite_flex_channel_limit(cuda):
+    with pytest.raises(RuntimeError, match="unsupported"):
+        raymarching.composite_rays_flex_train(torch.zeros(4, device=cuda), torch.zeros(4, 129, device=cuda), torch.zeros(4, 2, device=cuda),
+                                              torch.zeros(1, 3, dtype=torch.int32, device=cuda), 1e-4)
+
+
+@pytest.mark.parametrize("n_step", [1, 4, 8])
+def test_composite_rays_inference_in_place(cuda, n_step):
+    rng = np.random.default_rng(8)
+    N, n_alive = 5000, 3100
+    alive = np.sort(rng.choice(N, n_alive, replace=False)).astype(np.int32)
+    M = n_alive * n_step
+    sig = (rng.random(M) * 60).astype(np.float32)
+    rgb = rng.random((M, 3)).astype(np.float32)
+    dl = np.stack([rng.random(M) * 0.02 + 0.003, rng.random(M) * 0.05 + 0.003], 1).astype(np.float32)
+    dl[rng.random(M) < 0.1] = 0  # unfilled slots (delta == 0 sentinel)
+    st = dict(rays_t=rng.random(N).astype(np.float32), ws=(rng.random(N) * 0.7).astype(np.float32), dep=rng.random(N).astype(np.float32),
+              img=rng.random((N, 3)).astype(np.float32))
+    feat = rng.standard_normal((M, 50)).astype(np.float32)
+    out50 = rng.standard_normal((N, 50)).astype(np.float32)
+    # oracle (flex first: it must see the weights_sum of BEFORE composite_rays)
+    o_out = out50.copy()
+    o = {k: v.copy() for k, v in st.items()}
+    o_alive = alive.copy()
+    oracle.composite_rays_flex(n_alive, n_step, 50, o_alive, o["rays_t"], sig, feat, dl, o["ws"], o_out, 1e-4)
+    oracle.composite_rays(n_alive, n_step, o_alive, o["rays_t"], sig, rgb, dl, o["ws"], o["dep"], o["img"], 1e-4)
+    g = {k: dev(v, cuda) for k, v in st.items()}
+    g_alive, g_out = dev(alive, cuda), dev(out50, cuda)
+    r = raymarching.composite_rays_flex(n_alive, n_step, 50, g_alive, g["rays_t"], dev(sig, cuda), dev(feat, cuda), dev(dl, cuda), g["ws"], g_out, 1e-4)
+    assert r == tuple()
+    np.testing.assert_array_equal(host(g["ws"]), st["ws"])  # flex never writes weights_sum / rays_alive / rays_t
+    np.testing.assert_array_equal(host(g_alive), alive)
+    raymarching.composite_rays(n_alive, n_step, g_alive, g["rays_t"], dev(sig, cuda), dev(rgb, cuda), dev(dl, cuda), g["ws"], g["dep"], g["img"], 1e-4)
+    np.testing.assert_array_equal(host(g_alive), o_alive)      # which rays terminated: exact
+    np.testing.assert_allclose(host(g_out), o_out, rtol=2e-5, atol=2e-5)
+    for k in st:
+        np.testing.assert_allclose(host(g[k]), o[k], **EXP_TOL)
+
+
+def test_spread_ray_to_sample(cuda):
+    rng = np.random.default_rng(9)
+    N = 700
+    rays, sig, rgb, feat, dl, M = _train_case(rng, N, 50, 3)
+    inp = rng.random((N, 3)).astype(np.float32)
+    out = torch.zeros(M, 3, device=cuda)
+    raymarching.spread_ray_to_sample(dev(inp, cuda), dev(rays, cuda), out)
+    want = np.zeros((M, 3), np.float32)
+    oracle.spread_ray_to_sample(inp, rays, want)
+    np.testing.assert_array_equal(host(out), want)
+
+
+# ------------------------------------------------------------------------------------------ grid encoder
+def _grid_setup(rng, L, H, log2T, desired, C, B):
+    pls = float(np.exp2(np.log2(desired / H) / (L - 1))) if desired else 2.0
+    offsets = oracle.grid_offsets(3, L, pls, H, log2T)
+    emb = (rng.random((int(offsets[-1]), C)) - 0.5).astype(np.float32)
+    x = rng.random((B, 3)).astype(np.float32)
+    x[:5] = [[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [1.0000001, 0.5, 0.5], [-1e-7, 0.2, 0.3]]  # boundaries in, epsilon-outside out
+    return pls, offsets, emb, x
+
+
+@pytest.mark.parametrize("C", [1, 2, 4, 8])
+def test_grid_encode_forward_fp32_bit_exact(cuda, C):
+    rng = np.random.default_rng(10 + C)
+    L = 16 if C == 2 else 6
+    pls, offsets, emb, x = _grid_setup(rng, L, 16, 19 if C == 2 else 12, 4096 if C == 2 else None, C, 20011)
+    out = gridencoder.grid_encode(dev(x, cuda), dev(emb, cuda), dev(offsets, cuda), pls, 16, False, 0, False)
+    want = oracle.grid_encode_forward(x, emb, offsets, pls, 16)
+    assert out.shape == (x.shape[0], L * C)
+    np.testing.assert_array_equal(host(out), want)  # same fmaf chain, same host-computed level scales => bit-exact
+
+
+def test_grid_encode_tiled_and_align_corners(cuda):
+    rng = np.random.default_rng(20)
+    pls, offsets, emb, x = _grid_setup(rng, 6, 8, 10, None, 2, 3001)
+    for gridtype, ac in ((1, False), (0, True), (1, True)):
+        out = gridencoder.grid_encode(dev(x, cuda), dev(emb, cuda), dev(offsets, cuda), pls, 8, False, gridtype, ac)
+        np.testing.assert_array_equal(host(out), oracle.grid_encode_forward(x, emb, offsets, pls, 8, gridtype=gridtype, align_corners=ac))
+
+
+def test_grid_encode_forward_fp16_table_bit_exact(cuda):
+    rng = np.random.default_rng(21)
+    pls, offsets, emb, x = _grid_setup(rng, 16, 16, 19, 4096, 2, 10007)
+    emb16 = emb.astype(np.float16)
+    out = gridencoder.grid_encode(dev(x, cuda), dev(emb16, cuda), dev(offsets, cuda), pls, 16, False, 0, False)
+    assert out.dtype == torch.float16
+    want = oracle.grid_encode_forward(x, emb16, offsets, pls, 16)
+    np.testing.assert_array_equal(host(out).view(np.uint16), want.view(np.uint16))  # half accumulator reproduced bit for bit
+    # autocast path of the reference (grid.py:38-39): fp32 parameter, half table on the fly
+    with torch.autocast("cuda", dtype=torch.float16):
+        out2 = gridencoder.grid_encode(dev(x, cuda), dev(emb, cuda), dev(offsets, cuda), pls, 16, False, 0, False)
+    np.testing.assert_array_equal(host(out2).view(np.uint16), want.view(np.uint16))
+
+
+def test_grid_encode_backward_and_input_grad(cuda):
+    rng = np.random.default_rng(22)
+    pls, offsets, emb, x = _grid_setup(rng, 16, 16, 19, 4096, 2, 4099)
+    te = dev(emb, cuda).requires_grad_(True)
+    tx = dev(x, cuda).requires_grad_(True)
+    out = gridencoder.grid_encode(tx, te, dev(offsets, cuda), pls, 16, True, 0, False)
+    g = rng.standard_normal(out.shape).astype(np.float32)
+    (out * dev(g, cuda)).sum().backward()
+    oout, odydx = oracle.grid_encode_forward(x, emb, offsets, pls, 16, calc_grad_inputs=True)
+    ogg, ogi = oracle.grid_encode_backward(g, x, emb.shape, offsets, pls, 16, dy_dx=odydx)
+    np.testing.assert_array_equal(host(out), oout)
+    np.testing.assert_allclose(host(te.grad), ogg, rtol=1e-5, atol=1e-5)  # atomics order differs from the oracle's loop order
+    np.testing.assert_allclose(host(tx.grad), ogi, rtol=1e-5, atol=1e-3)  # |dy_dx| ~ scale ~ 4e3 at the finest level
+    assert abs(float(te.grad.double().sum()) - float(ogg.astype(np.float64).sum())) < 1e-2  # checksum of the scatter
+
+
+def test_grid_encode_backward_fp16(cuda):
+    rng = np.random.default_rng(23)
+    pls, offsets, emb, x = _grid_setup(rng, 8, 16, 14, None, 2, 2000)
+    te = dev(emb.astype(np.float16), cuda).requires_grad_(True)
+    out = gridencoder.grid_encode(dev(x, cuda), te, dev(offsets, cuda), pls, 16, False, 0, False)
+    g = (rng.standard_normal(out.shape) * 0.01).astype(np.float16)
+    (out * dev(g, cuda)).sum().backward()
+    ogg = oracle.grid_encode_backward(g.astype(np.float32), x, emb.shape, offsets, pls, 16)
+    np.testing.assert_allclose(host(te.grad).astype(np.float32), ogg, rtol=2e-2, atol=2e-3)  # packed-half atomics round every add
+
+
+def test_grid_encoder_module_state_dict_names_and_errors(cuda):
+    enc = gridencoder.GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=4096).to(cuda)
+    sd = enc.state_dict()
+    assert set(sd) == {"embeddings", "offsets"} and sd["embeddings"].shape == (6328848, 2) and sd["offsets"].dtype == torch.int32
+    assert enc.output_dim == 32 and float(sd["embeddings"].abs().max()) <= 1e-4
+    y = enc(torch.rand(7, 5, 3, device=cuda) * 4 - 2, bound=2)
+    assert y.shape == (7, 5, 32)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        gridencoder.grid_encode(torch.rand(4, 3, device=cuda), torch.rand(100, 3, device=cuda), torch.tensor([0, 50, 100], dtype=torch.int32, device=cuda), 2.0, 4)
+    with pytest.raises(RuntimeError):
+        gridencoder.grid_encode(torch.rand(4, 3), torch.rand(100, 2), torch.tensor([0, 50, 100], dtype=torch.int32), 2.0, 4)  # CPU tensors: no fallback
+
+
+# ------------------------------------------------------------------------------------------ SH
+@pytest.mark.parametrize("degree", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_sh_encode_forward_and_grad(cuda, degree, golden_dir):
+    rng = np.random.default_rng(30 + degree)
+    x = rng.standard_normal((10007, 3)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    tx = dev(x, cuda).requires_grad_(True)
+    y = shencoder.sh_encode(tx, degree, True)
+    oy, od = oracle.sh_encode_forward(x, degree, True)
+    np.testing.assert_allclose(host(y), oy, rtol=2e-6, atol=2e-6)  # fp32 Horner vs the oracle's fp64 closed form
+    g = rng.standard_normal(oy.shape).astype(np.float32)
+    (y * dev(g, cuda)).sum().backward()
+    np.testing.assert_allclose(host(tx.grad), oracle.sh_encode_backward(g, degree, od), rtol=1e-4, atol=1e-4)
+    if degree <= 5:  # the reference's own torch encoder
+        gold = np.load(f"{golden_dir}/sh_torch.npz")
+        np.testing.assert_allclose(host(shencoder.sh_encode(dev(gold["x"], cuda), degree, False)), gold[f"y{degree}"], atol=2e-6)
+
+
+def test_sh_matches_reference_cuda_polynomials_off_sphere(cuda, golden_dir):
+    import ctypes
+    from palettenerf_amd._torch_glue import call, ptr
+    gold = np.load(f"{golden_dir}/sh_cuda_expr.npz")
+    x = dev(gold["points"].astype(np.float32), cuda)
+    B = x.shape[0]
+    y = torch.empty(B, 64, device=cuda)
+    dydx = torch.empty(B, 3 * 64, device=cuda)
+    call("pnr_sh_encode_forward", ptr(x), ptr(y), ctypes.c_uint32(B), ctypes.c_uint32(3), ctypes.c_uint32(8), ptr(dydx))
+    np.testing.assert_allclose(host(y), gold["y"], rtol=1e-5, atol=2e-5)
+    d = host(dydx).reshape(B, 3, 64)
+    for axis, key in enumerate(("dx", "dy", "dz")):
+        np.testing.assert_allclose(d[:, axis], gold[key], rtol=1e-5, atol=1e-4)
+    assert shencoder.SHEncoder(degree=8).output_dim == 64
+    with pytest.raises(AssertionError):
+        shencoder.SHEncoder(degree=9)
+
+
+# ------------------------------------------------------------------------------------------ HSV
+def test_hsv_round_trip_and_parity(cuda):
+    rng = np.random.default_rng(40)
+    rgb = rng.random((100003, 3)).astype(np.float32)
+    rgb[:4] = [[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [1, 0, 0]]
+    rgb[4:2000] = rng.standard_normal((1996, 3)) * 0.5 + 0.3  # negative / >1 colours occur in the edit path
+    hsv = palette_utils.rgb_to_hsv(dev(rgb, cuda))
+    np.testing.assert_allclose(host(hsv), oracle.rgb_to_hsv(rgb), rtol=1e-5, atol=1e-3)
+    back = palette_utils.hsv_to_rgb(hsv)
+    np.testing.assert_allclose(host(back), oracle.hsv_to_rgb(host(hsv)), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(host(back)[2000:], rgb[2000:], atol=5e-6)  # round trip on in-gamut colours
+    assert palette_utils.rgb_to_hsv(torch.rand(3, 4, 5, 3, device=cuda)).shape == (3, 4, 5, 3)

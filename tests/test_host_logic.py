@@ -1,0 +1,98 @@
+"""CPU suite: this repo's renderer/network mirror (host logic), driven by the oracle facades instead
+of the HIP operators, reproduces the golden frames produced by the reference's own Python callers."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from palettenerf_amd import network, renderer, scene
+from oracle.facade import make_oracle_modules
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture()
+def facade(monkeypatch):
+    rm, ge, sh, pu = make_oracle_modules()
+    import palettenerf_amd.gridencoder as pge
+    import palettenerf_amd.shencoder as psh
+    monkeypatch.setattr(renderer, "raymarching", rm)
+    monkeypatch.setattr(renderer, "rgb_to_hsv", pu.rgb_to_hsv)
+    monkeypatch.setattr(renderer, "hsv_to_rgb", pu.hsv_to_rgb)
+    monkeypatch.setattr(pge, "GridEncoder", ge.GridEncoder)
+    monkeypatch.setattr(psh, "SHEncoder", sh.SHEncoder)
+    return rm
+
+
+def rays(g):
+    H, W = int(g["H"]), int(g["W"])
+    pose = torch.from_numpy(scene.lookat_pose())[None]
+    return scene.get_rays(pose, scene.intrinsics_from_fov(H, W), H, W)
+
+
+def put_scene(m):
+    grid = scene.brick_density_grid()
+    m.density_grid.copy_(torch.from_numpy(grid))
+    m.density_bitfield.copy_(torch.from_numpy(oracle.packbits(grid, 0.5)))
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_nerf_mirror_reproduces_reference_frames(facade, case):
+    g = np.load(os.path.join(GOLDEN, f"frame_nerf_{case}.npz"))
+    m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=float(g["density_scale"]), min_near=0.2)
+    scene.seed_field_(m, int(g["seed"]))
+    put_scene(m)
+    m.eval()
+    ro, rd = rays(g)
+    with torch.no_grad():
+        r = m.render(ro, rd, staged=True, dt_gamma=float(g["dt_gamma"]), perturb=False, max_steps=1024, T_thresh=1e-4)
+    for k in ("image", "depth", "weights_sum"):
+        np.testing.assert_allclose(r[k].numpy(), g[k], rtol=0, atol=1e-6, err_msg=k)
+    gt = np.load(os.path.join(GOLDEN, f"train_nerf_{case}.npz"))
+    m.train()
+    r = m.run_cuda(ro, rd, dt_gamma=float(gt["dt_gamma"]), perturb=False, force_all_rays=True, max_steps=1024, T_thresh=1e-4)
+    assert m.step_counter[0].numpy().tolist() == gt["counter"].tolist()
+    np.testing.assert_allclose(r["image"].detach().numpy(), gt["image"], atol=1e-6)
+
+
+def test_palette_mirror_reproduces_reference_frames(facade):
+    g = np.load(os.path.join(GOLDEN, "frame_palette_a.npz"))
+    opt = renderer.default_opt(pred_clip=bool(g["pred_clip"]))
+    m = network.PaletteNetwork(opt, bound=2, cuda_ray=True, density_scale=float(g["density_scale"]), min_near=0.2)
+    scene.seed_field_(m, int(g["seed"]))
+    put_scene(m)
+    m.eval()
+    ro, rd = rays(g)
+    with torch.no_grad():
+        r = m.render(ro, rd, dt_gamma=float(g["dt_gamma"]), perturb=False, max_steps=1024, T_thresh=1e-4, gui_mode=False)
+    for k in ("image", "depth", "depth_origin", "weights_sum", "clip_feat", "direct_rgb", "view_dep_rgb", "basis_rgb", "unscaled_basis_rgb", "basis_acc"):
+        np.testing.assert_allclose(r[k].numpy(), g[k], rtol=0, atol=1e-6, err_msg=k)
+    m.edit = renderer.RegionEdit(opt)
+    m.edit.update_cent(mean_xyz=torch.tensor([0.1, 0.0, -0.2]))
+    m.edit.update_std(std_xyz=0.5)
+    m.edit.update_delta_hsv(m.basis_color.data.clamp(0, 1), (m.basis_color.data * 0.6 + 0.2).flip(0).clamp(0, 1))
+    with torch.no_grad():
+        r2 = m.render(ro, rd, dt_gamma=float(g["dt_gamma"]), perturb=False, max_steps=1024, T_thresh=1e-4, gui_mode=True)
+    np.testing.assert_allclose(r2["image"].numpy(), g["edit_image"], atol=1e-6)
+
+
+def test_state_dict_names_match_reference_checkpoint_layout():
+    m = network.PaletteNetwork(renderer.default_opt(pred_clip=True), bound=2, cuda_ray=True)
+    keys = set(m.state_dict())
+    for k in ("encoder.embeddings", "encoder.offsets", "encoder_palette.embeddings", "encoder_clip.embeddings", "sigma_net.0.weight", "sigma_net.1.weight",
+              "color_net.0.weight", "color_net.2.weight", "diff_net.0.weight", "basis_net.1.weight", "offsets_radiance_net.weight",
+              "offsets_radiance_net.bias", "omega_net.0.weight", "clip_net.1.weight", "basis_color", "density_grid", "density_bitfield", "aabb_train",
+              "aabb_infer", "step_counter"):
+        assert k in keys, k
+    assert m.density_bitfield.numel() == 2 * 128 ** 3 // 8 and m.cascade == 2 and tuple(m.step_counter.shape) == (16, 2)
+    assert m.sigma_net[0].weight.shape == (64, 32) and m.basis_net[0].weight.shape == (64, 35) and m.offsets_radiance_net.weight.shape == (13, 15)
+    names = {id(p) for grp in m.get_params(1e-2) for p in (grp["params"] if isinstance(grp["params"], (list, tuple)) else [grp["params"]] if torch.is_tensor(grp["params"]) else list(grp["params"]))}
+    assert id(m.basis_net[0].weight) not in names  # reference quirk 8: basis_net is not optimised
+
+
+def test_render_refuses_pure_torch_path():
+    m = network.NeRFNetwork(bound=2, cuda_ray=False)
+    with pytest.raises(ValueError):
+        m.render(torch.zeros(1, 4, 3), torch.zeros(1, 4, 3))
