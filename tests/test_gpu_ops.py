@@ -126,7 +126,8 @@ def test_march_rays_train_perturbed_and_mean_count_overflow(cuda, s0):
                                                    -1, True, 128, True, 0.0, 1024)
     cnt2 = np.zeros(2, np.int32)
     _, _, _, rays0 = oracle.march_rays_train(ro, rd, 2.0, bf, 2, 128, on, of, cnt2, align=128, force_all_rays=True)
-    assert np.abs(host(rays_p)[:, 2] - rays0[:, 2]).max() <= 2
+    diff = np.abs(host(rays_p)[:, 2] - rays0[:, 2])  # a shift of the start by < one step moves a few cell crossings
+    assert diff.max() <= 8 and diff.mean() < 1.0 and abs(int(counter[0]) - int(cnt2[0])) < 0.01 * int(cnt2[0])
 
 
 @pytest.mark.parametrize("n_step", [1, 3, 8])
