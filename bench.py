@@ -109,7 +109,10 @@ def main():
 
     from palettenerf_amd import _torch_glue, dist as pdist, scene
     m = build_model(args, device)
-    m.march_mode = args.mode or "device"
+    mode = args.mode or "fused"
+    m.march_mode = "device" if mode == "fused" else mode
+    if mode == "fused" and args.model == "nerf" and not args.fp16:
+        m.fused_field = True
     H = W = args.res
     pose = torch.from_numpy(scene.lookat_pose())[None]
     ro, rd = scene.get_rays(pose, scene.intrinsics_from_fov(H, W), H, W)
@@ -165,7 +168,7 @@ def main():
             "vs_baseline": None, "dtype": "f16" if args.fp16 else "f32", "data": "synthetic",
             "config": {"workload": f"configs[1]: NeRF-synthetic lego geometry (scene S0), -m {args.model} inference, {H}x{W}, 1 frame/step",
                        "rays_per_frame": H * W, "rendered_samples_per_frame": total_rendered // args.steps,
-                       "evaluated_rows_per_frame_rank0": rows // args.steps, "density_scale": args.density_scale, "march_mode": m.march_mode,
+                       "evaluated_rows_per_frame_rank0": rows // args.steps, "density_scale": args.density_scale, "march_mode": m.march_mode, "fused_field": bool(getattr(m, "fused_field", False)),
                        "parallelism": f"ray-tiles x{world} + all_gather" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_grid_fwd (pnr_grid_encode_forward)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": len(launches),

@@ -107,6 +107,26 @@ int pnr_composite_rays_flex(uint32_t n_alive, uint32_t n_step, uint32_t n_channe
                             const float* input, const float* deltas, const float* weights_sum, float* output,
                             pnr_stream_t stream);
 
+/* MI355X-first additions: occupancy mip.  The bitfield is Morton-ordered, so a 4x4x4 brick of cells is one
+ * aligned 8-byte word; pnr_build_occupancy_mip reduces every brick to an any-bit and an all-bit
+ * (pnr_occupancy_mip_bytes(C,H) bytes, device) and appends the world-space bounding box of all occupied bricks
+ * (two-cell margin).  The *_mip march entry points stage it in LDS, answer probes in uniformly empty / full bricks
+ * without a global load and stop a ray once it has left the occupied box for good (no sample can follow).  Results are bit-identical to pnr_march_rays /
+ * pnr_march_rays_train (which are the same kernels with mip == NULL).  Requires H % 4 == 0 and an 8-byte aligned
+ * bitfield; the mip must be rebuilt whenever the bitfield changes.  `noises` may be NULL (= no perturbation). */
+uint64_t pnr_occupancy_mip_bytes(uint32_t C, uint32_t H);
+int pnr_build_occupancy_mip(const uint8_t* grid, uint32_t C, uint32_t H, float bound, void* mip, pnr_stream_t stream);
+int pnr_march_rays_mip(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                       const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                       uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
+                       float* xyzs, float* dirs, float* deltas, const float* noises, const void* mip,
+                       pnr_stream_t stream);
+int pnr_march_rays_train_mip(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
+                             float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                             const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                             int32_t* rays, int32_t* counter, const float* noises, void* scratch, const void* mip,
+                             pnr_stream_t stream);
+
 /* Stable compaction replacing the host-side `rays_alive[rays_alive >= 0]` boolean mask
  * (nerf/renderer.py:376, palette/renderer.py:521).  Writes the surviving ids, in order, to
  * rays_alive_out and their number to n_alive_out[0].  scratch >= pnr_scan_scratch_bytes(n_alive). */
@@ -127,6 +147,21 @@ int pnr_grid_encode_backward(const void* grad, const float* inputs, const void* 
                              void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                              uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
                              int align_corners, int dtype, pnr_stream_t stream);
+
+/* ---------------------------------------------------------------- fused field (MFMA) ------- */
+
+/* MI355X-first addition, no single-call counterpart in the reference: evaluates everything
+ * nerf/network.py:95-124 does after the hash-grid lookup (sigma_net 32->64->16, exp, SH degree 4, concat,
+ * color_net 31->64->64->3, sigmoid) in one kernel on the fp32 matrix cores.
+ *   pnr_nerf_field_pack: gathers the five bias-free nn.Linear weight matrices (row-major [out][in], device fp32)
+ *                        into the MFMA-fragment-ordered blob `packed` (pnr_nerf_field_packed_bytes() bytes).
+ *   pnr_nerf_field_forward: enc = raw [16,B,2] output of pnr_grid_encode_forward (fp32), dirs [B,3] -> sigmas [B]
+ *                        (= exp(h0), NOT multiplied by density_scale), rgbs [B,3]. */
+uint64_t pnr_nerf_field_packed_bytes(void);
+int pnr_nerf_field_pack(const float* w_sigma0, const float* w_sigma1, const float* w_color0, const float* w_color1,
+                        const float* w_color2, float* packed, pnr_stream_t stream);
+int pnr_nerf_field_forward(const float* enc, const float* dirs, const float* packed, uint32_t B, float* sigmas,
+                           float* rgbs, pnr_stream_t stream);
 
 /* ---------------------------------------------------------------- SH encoder --------------- */
 

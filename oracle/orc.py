@@ -326,3 +326,19 @@ def linear(x, W, bias=None):
     b = None if bias is None else _f32(bias)
     lib().orc_linear(_p(x), _p(W), _p(b), _p(y), _u(B), _u(K), _u(O))
     return y
+
+
+# ------------------------------------------------------------------ fields (nerf/network.py:95-124)
+def nerf_field_forward(enc, dirs, w_sigma0, w_sigma1, w_color0, w_color1, w_color2):
+    """enc: [B,32] hash-grid features, dirs: [B,3].  Returns (sigma [B], rgb [B,3]) -- every Linear is a
+    k-ordered fp32 fmaf chain (orc_linear), activations in fp32."""
+    h = np.maximum(linear(enc, w_sigma0), 0)
+    h = linear(h, w_sigma1)
+    sigma = np.exp(h[:, 0].astype(np.float32))
+    geo = h[:, 1:]
+    c = np.concatenate([sh_encode_forward(dirs, 4), geo], axis=1)
+    c = np.maximum(linear(c, w_color0), 0)
+    c = np.maximum(linear(c, w_color1), 0)
+    o = linear(c, w_color2)
+    rgb = (np.float32(1) / (np.float32(1) + np.exp(-o))).astype(np.float32)
+    return sigma, rgb

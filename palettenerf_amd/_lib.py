@@ -30,15 +30,23 @@ SIGNATURES = {
     "pnr_march_rays": [_u32, _u32, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "pnr_composite_rays": [_u32, _u32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "pnr_composite_rays_flex": [_u32, _u32, _u32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "pnr_occupancy_mip_bytes": [_u32, _u32],
+    "pnr_build_occupancy_mip": [_ptr, _u32, _u32, _f32, _ptr, _ptr],
+    "pnr_march_rays_mip": [_u32, _u32, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "pnr_march_rays_train_mip": [_ptr, _ptr, _ptr, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                                 _ptr, _ptr, _ptr, _ptr],
     "pnr_compact_alive": [_u32, _ptr, _ptr, _ptr, _ptr, _ptr],
     "pnr_grid_encode_forward": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _u32, _ptr, _u32, _int, _int, _ptr],
     "pnr_grid_encode_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _u32, _ptr, _ptr, _u32, _int, _int, _ptr],
+    "pnr_nerf_field_packed_bytes": [],
+    "pnr_nerf_field_pack": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "pnr_nerf_field_forward": [_ptr, _ptr, _ptr, _u32, _ptr, _ptr, _ptr],
     "pnr_sh_encode_forward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr],
     "pnr_sh_encode_backward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr, _ptr],
     "pnr_rgb_to_hsv": [_u32, _ptr, _ptr, _ptr],
     "pnr_hsv_to_rgb": [_u32, _ptr, _ptr, _ptr],
 }
-_RESTYPES = {"pnr_error_string": ctypes.c_char_p, "pnr_scan_scratch_bytes": _u64}
+_RESTYPES = {"pnr_error_string": ctypes.c_char_p, "pnr_scan_scratch_bytes": _u64, "pnr_nerf_field_packed_bytes": _u64, "pnr_occupancy_mip_bytes": _u64}
 
 _lib = None
 

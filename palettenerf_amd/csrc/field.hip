@@ -1,0 +1,195 @@
+// field.hip -- fused tiny-MLP evaluation of the NeRF field on the gfx950 matrix cores.
+//
+// Computes, per sample, what nerf/network.py:95-124 computes after the hash-grid lookup:
+//     h     = W_s1 . relu(W_s0 . enc)                 (32 -> 64 -> 16, no biases)
+//     sigma = exp(h[0]);  geo = h[1:16]
+//     rgb   = sigmoid(W_c2 . relu(W_c1 . relu(W_c0 . [SH16(d) ; geo])))   (31 -> 64 -> 64 -> 3)
+// in ONE kernel: five GEMMs, SH encoding, concat, four activations and the exp -- the reference
+// issues 5 GEMM + ~9 elementwise launches and round-trips every activation through HBM.
+//
+// MI355X mapping (this is not a GEMM-library call):
+//   * the products are evaluated TRANSPOSED, D[feature][sample] = W[feature][k] . act[k][sample], with
+//     v_mfma_f32_32x32x2_f32 (exact fp32 fmaf chain, MI355X_MICROARCH.md): weights are the A operand,
+//     activations the B operand.  In that orientation the D fragment of one layer (lane = sample,
+//     registers = features) IS the B fragment of the next layer: lanes 0-31 feed k=0, lanes 32-63
+//     feed k=1 of every MFMA with the accumulator register they already hold.  Activations never
+//     leave the register file -- no LDS round trip, no shuffles, no transposes between layers.
+//   * the price is a permuted reduction order over k, paid once on the weights: pnr_nerf_field_pack
+//     lays every layer out as [row tile][k step][lane] so that an A fragment is one conflict-free
+//     ds_read_b32 of 64 consecutive floats.  48 KiB of LDS per 512-thread workgroup holds all five
+//     layers; workgroups are persistent (grid-stride over 256-sample tiles) so the staging is
+//     amortised.
+//   * layer-1 B operands are read straight from the level-major encoder output [L,B,2]: the 64 lanes
+//     of a wave read 32 samples x 2 channels = 256 contiguous bytes per level.
+// One wave = 32 samples; 192 MFMAs per wave-tile (18 688 useful + padding FLOP per sample).
+#include "pnr_common.hpp"
+#include "sh_eval.hpp"
+
+namespace pnr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// packed weight blob: offsets (in floats) of each layer, layout [row tile][step][64 lanes]
+constexpr int kS0 = 0;                 // sigma_net[0]: 32 -> 64   : 2 row tiles x 16 steps
+constexpr int kS1 = kS0 + 2 * 16 * 64; // sigma_net[1]: 64 -> 16   : 1 row tile  x 32 steps
+constexpr int kC0 = kS1 + 1 * 32 * 64; // color_net[0]: 31 -> 64   : 2 row tiles x 16 steps
+constexpr int kC1 = kC0 + 2 * 16 * 64; // color_net[1]: 64 -> 64   : 2 row tiles x 32 steps
+constexpr int kC2 = kC1 + 2 * 32 * 64; // color_net[2]: 64 -> 3    : 1 row tile  x 32 steps
+constexpr int kPackedFloats = kC2 + 1 * 32 * 64;  // 12288 floats = 48 KiB
+
+// feature held by accumulator register r of a lane in half h (D layout of the 32x32 MFMA family)
+__host__ __device__ constexpr int frag_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// One thread per packed element: decode (layer, row tile, step, lane) and fetch the weight.
+__global__ void __launch_bounds__(256) k_nerf_field_pack(const float* __restrict__ Ws0, const float* __restrict__ Ws1,
+                                                         const float* __restrict__ Wc0, const float* __restrict__ Wc1,
+                                                         const float* __restrict__ Wc2, float* __restrict__ packed) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= kPackedFloats) return;
+    const int lane = e & 63, i = lane & 31, h = lane >> 5;
+    float v = 0.0f;
+    if (e < kS1) {                       // sigma_net[0]  W[64][32]; k order is the natural one
+        const int q = (e - kS0) >> 6, tile = q / 16, s = q % 16;
+        v = Ws0[(tile * 32 + i) * 32 + 2 * s + h];
+    } else if (e < kC0) {                // sigma_net[1]  W[16][64]
+        const int s = (e - kS1) >> 6, k = (s / 16) * 32 + frag_row(s % 16, h);
+        if (i < 16) v = Ws1[i * 64 + k];
+    } else if (e < kC1) {                // color_net[0]  W[64][31] ; columns: 0..15 SH, 16..30 geo_feat 1..15
+        const int q = (e - kC0) >> 6, tile = q / 16, s = q % 16;
+        int col;
+        if (s < 8) col = s + 8 * h;      // steps 0-7: SH coefficient s (lower half-wave) / 8+s (upper)
+        else { const int g = frag_row(s - 8, h); col = g >= 1 ? 15 + g : -1; }  // geo feature g; g == 0 is the sigma logit: zero weight
+        if (col >= 0) v = Wc0[(tile * 32 + i) * 31 + col];
+    } else if (e < kC2) {                // color_net[1]  W[64][64]
+        const int q = (e - kC1) >> 6, tile = q / 32, s = q % 32, k = (s / 16) * 32 + frag_row(s % 16, h);
+        v = Wc1[(tile * 32 + i) * 64 + k];
+    } else {                             // color_net[2]  W[3][64]
+        const int s = (e - kC2) >> 6, k = (s / 16) * 32 + frag_row(s % 16, h);
+        if (i < 3) v = Wc2[i * 64 + k];
+    }
+    packed[e] = v;
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; i++) z[i] = 0.0f;
+    return z;
+}
+__device__ __forceinline__ f32x16 relu16(f32x16 v) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = fmaxf(v[i], 0.0f);
+    return v;
+}
+// acc += W[tile] . act, act given as one accumulator fragment (16 k-steps)
+__device__ __forceinline__ f32x16 mma_frag(f32x16 acc, const float* __restrict__ w /* [16][64] */, const f32x16& act, int lane) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r * 64 + lane], act[r], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);  // keep hipcc from hoisting every later weight read above this group (VGPR blow-up, spills)
+    return acc;
+}
+
+constexpr int kFieldThreads = 512;  // 8 waves x 32 samples = 256 samples per workgroup tile
+
+__global__ void __launch_bounds__(kFieldThreads) k_nerf_field_fwd(const float* __restrict__ enc /* [16][B][2] */, const float* __restrict__ dirs /* [B][3] */,
+                                                                  const float* __restrict__ packed, uint32_t B, float* __restrict__ sigmas,
+                                                                  float* __restrict__ rgbs) {
+    __shared__ float w[kPackedFloats];
+    for (int i = threadIdx.x * 4; i < kPackedFloats; i += kFieldThreads * 4)
+        *reinterpret_cast<float4*>(&w[i]) = *reinterpret_cast<const float4*>(&packed[i]);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const uint32_t ntiles = (B + 255) / 256;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t n = tile * 256 + wave * 32 + (lane & 31);
+        const bool valid = n < B;
+        const uint32_t nc = valid ? n : (B - 1);
+
+        // ---- sigma_net[0]: B operand of step s = encoder level s, channel h  (coalesced 256-byte rows)
+        float x[16];
+#pragma unroll
+        for (int s = 0; s < 16; s++) x[s] = enc[((size_t)s * B + nc) * 2 + h];
+        f32x16 h0 = zero16(), h1 = zero16();
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            h0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kS0 + s * 64 + lane], x[s], h0, 0, 0, 0);
+            h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kS0 + (16 + s) * 64 + lane], x[s], h1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        h0 = relu16(h0); h1 = relu16(h1);
+
+        // ---- sigma_net[1]: 64 -> 16 (rows 16..31 of the tile are zero padding)
+        f32x16 g = zero16();
+        g = mma_frag(g, &w[kS1], h0, lane);
+        g = mma_frag(g, &w[kS1 + 16 * 64], h1, lane);
+        const float sigma_logit = g[0];  // row 0 lives in register 0 of the lower half-wave
+
+        // ---- color_net[0]: [SH16 ; geo15] -> 64
+        const float dx = dirs[(size_t)nc * 3], dy = dirs[(size_t)nc * 3 + 1], dz = dirs[(size_t)nc * 3 + 2];
+        float sh[16];
+        sh_eval<4>(dx, dy, dz, sh);
+        f32x16 c0 = zero16(), c1 = zero16();
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const float b = h ? sh[8 + s] : sh[s];
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kC0 + s * 64 + lane], b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kC0 + (16 + s) * 64 + lane], b, c1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {  // geo features: accumulator registers 0..7 of g (rows 0..15); row 0 carries a zero weight
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kC0 + (8 + r) * 64 + lane], g[r], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kC0 + (24 + r) * 64 + lane], g[r], c1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        c0 = relu16(c0); c1 = relu16(c1);
+
+        // ---- color_net[1]: 64 -> 64
+        f32x16 d0 = zero16(), d1 = zero16();
+        d0 = mma_frag(d0, &w[kC1], c0, lane);
+        d0 = mma_frag(d0, &w[kC1 + 16 * 64], c1, lane);
+        d1 = mma_frag(d1, &w[kC1 + 32 * 64], c0, lane);
+        d1 = mma_frag(d1, &w[kC1 + 48 * 64], c1, lane);
+        d0 = relu16(d0); d1 = relu16(d1);
+
+        // ---- color_net[2]: 64 -> 3
+        f32x16 o = zero16();
+        o = mma_frag(o, &w[kC2], d0, lane);
+        o = mma_frag(o, &w[kC2 + 16 * 64], d1, lane);
+
+        if (valid && h == 0) {
+            sigmas[n] = expf(sigma_logit);                       // trunc_exp forward (activation.py:9)
+            rgbs[(size_t)n * 3] = 1.0f / (1.0f + expf(-o[0]));   // sigmoid (nerf/network.py:122)
+            rgbs[(size_t)n * 3 + 1] = 1.0f / (1.0f + expf(-o[1]));
+            rgbs[(size_t)n * 3 + 2] = 1.0f / (1.0f + expf(-o[2]));
+        }
+    }
+}
+
+}  // namespace pnr
+
+using namespace pnr;
+
+extern "C" {
+
+uint64_t pnr_nerf_field_packed_bytes(void) { return (uint64_t)kPackedFloats * 4; }
+
+int pnr_nerf_field_pack(const float* w_sigma0, const float* w_sigma1, const float* w_color0, const float* w_color1, const float* w_color2,
+                        float* packed, pnr_stream_t stream) {
+    if (!w_sigma0 || !w_sigma1 || !w_color0 || !w_color1 || !w_color2 || !packed) return PNR_ERR_INVALID;
+    hipLaunchKernelGGL(k_nerf_field_pack, dim3(cdiv(kPackedFloats, 256)), dim3(256), 0, as_stream(stream), w_sigma0, w_sigma1, w_color0, w_color1,
+                       w_color2, packed);
+    return check_launch();
+}
+
+int pnr_nerf_field_forward(const float* enc, const float* dirs, const float* packed, uint32_t B, float* sigmas, float* rgbs, pnr_stream_t stream) {
+    if (B == 0) return PNR_OK;
+    if (!enc || !dirs || !packed || !sigmas || !rgbs) return PNR_ERR_INVALID;
+    const uint32_t ntiles = cdiv(B, 256);
+    const uint32_t grid = ntiles < 512u ? ntiles : 512u;  // 2 persistent workgroups per CU
+    hipLaunchKernelGGL(k_nerf_field_fwd, dim3(grid), dim3(kFieldThreads), 0, as_stream(stream), enc, dirs, packed, B, sigmas, rgbs);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -6,6 +6,7 @@
 // the same scan, and all launches take an explicit stream.
 #include "pnr_common.hpp"
 #include <float.h>
+#include <string.h>
 
 namespace pnr {
 
@@ -13,49 +14,134 @@ constexpr uint32_t kBlock = 256;  // 4 waves; one ray / element per thread
 
 // ------------------------------------------------------------------------------------------
 // per-ray constants + the march state machine (reference raymarching.cu:336-349, 362-403)
+//
+// Two latency levers that leave every result bit unchanged:
+//  * occupancy mip in LDS.  The bitfield is in Morton order, so a 4x4x4 brick of cells is 64
+//    CONSECUTIVE bits = one aligned 8-byte word.  pnr_build_occupancy_mip() reduces every brick to
+//    two bits (any cell set / all cells set; 2 x 8 KiB for C=2, H=128).  A march workgroup keeps both
+//    masks in LDS: a probe that lands in an all-empty or all-full brick is answered from LDS
+//    (~64 cycles) instead of a dependent global byte load (~500+ cycles under load) -- that is nearly
+//    every probe of the long empty-space walks that set the duration of a march launch.  The per-cell
+//    control flow (which t is probed next) is untouched.
+//  * occupied bounding box.  The mip builder also reduces the occupied bricks of every cascade to one
+//    world-space box B (expanded by two cells of the respective cascade).  No cell outside B is
+//    occupied, B is convex, so once a ray has left B no later probe can emit a sample: the march
+//    stops at min(far, exit(B)) instead of walking cell by cell to the scene AABB.  Those walks (rays
+//    that just left the object, rays that miss it) are what set the duration of a march launch;
+//    cutting them changes no output (a ray that would have found nothing still finds nothing).
+//  * when H and bound are powers of two (every shipped config) the reference's double-precision
+//    cell coordinate, its frexpf()/scalbnf() and the 1/mip_bound division are exact scalings by
+//    powers of two; the POW2 variants do them with one fp32 multiply / exponent-field arithmetic.
 // ------------------------------------------------------------------------------------------
 struct RayCtx {
     float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
-    float bound, dt_gamma, dt_min, dt_max, rH, fC, fH;
+    float bound, dt_gamma, dt_min, dt_max, rH, fC, fH, half_H;
     uint32_t H, H3;
+    int maxlevel;
     const uint8_t* __restrict__ grid;
+    const uint32_t* mip_any;  // LDS (or nullptr)
+    const uint32_t* mip_all;
+    const float* box;         // LDS: occupied box (min xyz, max xyz), or nullptr
 };
 
-__device__ __forceinline__ void ctx_init(RayCtx& c, const float* __restrict__ o, const float* __restrict__ d, float bound,
-                                         float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
-                                         const uint8_t* __restrict__ grid) {
+struct MarchParams {  // ray-independent constants, computed once on the host
+    float bound, dt_gamma, dt_min, dt_max;
+    uint32_t C, H, max_steps;
+    uint32_t mip_words;  // uint32 words per mask; 0 = no mip
+};
+
+static MarchParams make_march_params(float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, bool with_mip) {
+    MarchParams p;
+    const float two_sqrt3 = 2.0f * 1.7320508075688772f;          // raymarching.cu:22
+    p.bound = bound; p.dt_gamma = dt_gamma;
+    p.dt_min = two_sqrt3 / (float)max_steps;                        // :348
+    p.dt_max = two_sqrt3 * (float)(1 << (C - 1)) / (float)H;        // :349
+    p.C = C; p.H = H; p.max_steps = max_steps;
+    p.mip_words = with_mip ? (uint32_t)(((uint64_t)C * H * H * H / 64 + 31) / 32) : 0;
+    return p;
+}
+static inline bool is_pow2f(float v) {
+    uint32_t u; memcpy(&u, &v, 4);
+    return v > 0.0f && (u & 0x7fffffu) == 0 && ((u >> 23) & 0xff) != 0 && ((u >> 23) & 0xff) != 0xff;
+}
+
+__device__ __forceinline__ void ctx_init(RayCtx& c, const float* __restrict__ o, const float* __restrict__ d, const MarchParams& p,
+                                         const uint8_t* __restrict__ grid, const uint32_t* mip_lds) {
     c.ox = o[0]; c.oy = o[1]; c.oz = o[2];
     c.dx = d[0]; c.dy = d[1]; c.dz = d[2];
     c.rdx = 1.0f / c.dx; c.rdy = 1.0f / c.dy; c.rdz = 1.0f / c.dz;
-    c.bound = bound; c.dt_gamma = dt_gamma;
-    const float two_sqrt3 = 2.0f * 1.7320508075688772f;
-    c.dt_min = two_sqrt3 / (float)max_steps;
-    c.dt_max = two_sqrt3 * (float)(1 << (C - 1)) / (float)H;
-    c.rH = 1.0f / (float)H; c.fC = (float)C; c.fH = (float)H;
-    c.H = H; c.H3 = H * H * H; c.grid = grid;
+    c.bound = p.bound; c.dt_gamma = p.dt_gamma; c.dt_min = p.dt_min; c.dt_max = p.dt_max;
+    c.rH = 1.0f / (float)p.H; c.fC = (float)p.C; c.fH = (float)p.H; c.half_H = 0.5f * (float)p.H;
+    c.H = p.H; c.H3 = p.H * p.H * p.H; c.maxlevel = (int)p.C - 1; c.grid = grid;
+    c.mip_any = mip_lds;
+    c.mip_all = mip_lds ? mip_lds + p.mip_words : nullptr;
+    c.box = mip_lds ? reinterpret_cast<const float*>(mip_lds + 2 * p.mip_words) : nullptr;
+}
+
+// Parameter beyond which the ray is outside the occupied box for good (never larger than `far`).
+// Any NaN in the slab arithmetic (0 * inf) disables the clip for that ray.
+__device__ __forceinline__ float clip_far_to_box(const RayCtx& c, float far) {
+    if (!c.box) return far;
+    const float ax = (c.box[0] - c.ox) * c.rdx, bx = (c.box[3] - c.ox) * c.rdx;
+    const float ay = (c.box[1] - c.oy) * c.rdy, by = (c.box[4] - c.oy) * c.rdy;
+    const float az = (c.box[2] - c.oz) * c.rdz, bz = (c.box[5] - c.oz) * c.rdz;
+    if (ax != ax || bx != bx || ay != ay || by != by || az != az || bz != bz) return far;
+    const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    if (t_in > t_out) return -FLT_MAX;            // the ray never touches the occupied box
+    return fminf(far, fmaf(fabsf(t_out), 1e-5f, t_out));  // B already carries a two-cell margin; this only absorbs slab-test rounding
+}
+
+// frexpf exponent of a finite non-negative float, clamped to [0, maxlevel] (== reference mip_from_*)
+__device__ __forceinline__ int level_of(float mx, int maxlevel) {
+    const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu) - 126;  // zero / denormals give e <= -126 -> clamped to 0, as frexpf does
+    return min(maxlevel, max(0, e));
+}
+
+template <bool MIP>
+__device__ __forceinline__ bool cell_occupied(const RayCtx& c, uint32_t index) {
+    if constexpr (MIP) {
+        const uint32_t brick = index >> 6, word = brick >> 5, bit = 1u << (brick & 31u);
+        if (!(c.mip_any[word] & bit)) return false;
+        if (c.mip_all[word] & bit) return true;
+    }
+    return c.grid[index >> 3] & (1u << (index & 7u));
 }
 
 // Probe the cell containing the point at parameter t.  Occupied: returns true and the sample
 // (x,y,z,dt), t untouched.  Empty: advances t past the cell (do..while of the reference) and
 // returns false.
+template <bool MIP, bool POW2>
 __device__ __forceinline__ bool march_probe(const RayCtx& c, float& t, float& x, float& y, float& z, float& dt) {
     const float t0 = t;
     x = clampf(fmaf(t0, c.dx, c.ox), -c.bound, c.bound);
     y = clampf(fmaf(t0, c.dy, c.oy), -c.bound, c.bound);
     z = clampf(fmaf(t0, c.dz, c.oz), -c.bound, c.bound);
     dt = clampf(t0 * c.dt_gamma, c.dt_min, c.dt_max);
-    const int lp = mip_from_pos(x, y, z, c.fC), ld = mip_from_dt(dt, c.fH, c.fC);
-    const int level = lp > ld ? lp : ld;
-    const float mip_bound = fminf(scalbnf(1.0f, level), c.bound);
-    const float mip_rbound = 1.0f / mip_bound;
+    int level, nx, ny, nz;
+    float mip_bound;
     const float hi = (float)(c.H - 1);
-    // double intermediate exactly as the reference's `0.5 * (x * mip_rbound + 1) * H`
-    const int nx = (int)clampf((float)(0.5 * (double)fmaf(x, mip_rbound, 1.0f) * (double)c.H), 0.0f, hi);
-    const int ny = (int)clampf((float)(0.5 * (double)fmaf(y, mip_rbound, 1.0f) * (double)c.H), 0.0f, hi);
-    const int nz = (int)clampf((float)(0.5 * (double)fmaf(z, mip_rbound, 1.0f) * (double)c.H), 0.0f, hi);
+    if constexpr (POW2) {
+        const int lp = level_of(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))), c.maxlevel);
+        const int ld = level_of(dt * c.half_H, c.maxlevel);
+        level = lp > ld ? lp : ld;
+        mip_bound = fminf(__uint_as_float((uint32_t)(127 + level) << 23), c.bound);
+        const float mip_rbound = __uint_as_float((254u << 23) - (__float_as_uint(mip_bound) & 0x7f800000u));  // exact 1/2^k
+        nx = (int)clampf(fmaf(x, mip_rbound, 1.0f) * c.half_H, 0.0f, hi);
+        ny = (int)clampf(fmaf(y, mip_rbound, 1.0f) * c.half_H, 0.0f, hi);
+        nz = (int)clampf(fmaf(z, mip_rbound, 1.0f) * c.half_H, 0.0f, hi);
+    } else {
+        const int lp = mip_from_pos(x, y, z, c.fC), ld = mip_from_dt(dt, c.fH, c.fC);
+        level = lp > ld ? lp : ld;
+        mip_bound = fminf(scalbnf(1.0f, level), c.bound);
+        const float mip_rbound = 1.0f / mip_bound;
+        // double intermediate exactly as the reference's `0.5 * (x * mip_rbound + 1) * H`
+        nx = (int)clampf((float)(0.5 * (double)fmaf(x, mip_rbound, 1.0f) * (double)c.H), 0.0f, hi);
+        ny = (int)clampf((float)(0.5 * (double)fmaf(y, mip_rbound, 1.0f) * (double)c.H), 0.0f, hi);
+        nz = (int)clampf((float)(0.5 * (double)fmaf(z, mip_rbound, 1.0f) * (double)c.H), 0.0f, hi);
+    }
     const uint32_t index = (uint32_t)level * c.H3 + morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
-    const bool occ = c.grid[index >> 3] & (1u << (index & 7u));
-    if (occ) return true;
+    if (cell_occupied<MIP>(c, index)) return true;
     const float tx = fmaf(fmaf(fmaf(0.5f, signf(c.dx), (float)nx + 0.5f) * c.rH, 2.0f, -1.0f), mip_bound, -x) * c.rdx;
     const float ty = fmaf(fmaf(fmaf(0.5f, signf(c.dy), (float)ny + 0.5f) * c.rH, 2.0f, -1.0f), mip_bound, -y) * c.rdy;
     const float tz = fmaf(fmaf(fmaf(0.5f, signf(c.dz), (float)nz + 0.5f) * c.rH, 2.0f, -1.0f), mip_bound, -z) * c.rdz;
@@ -64,6 +150,32 @@ __device__ __forceinline__ bool march_probe(const RayCtx& c, float& t, float& x,
     do { tc += clampf(tc * c.dt_gamma, c.dt_min, c.dt_max); } while (tc < tt);
     t = tc;
     return false;
+}
+
+// stage both mip masks into LDS (no-op when the launch has no mip)
+__device__ __forceinline__ const uint32_t* stage_mip(const uint32_t* __restrict__ mip, uint32_t words_per_mask) {
+    extern __shared__ uint32_t mip_lds[];
+    if (words_per_mask == 0) return nullptr;
+    const uint32_t n = 2 * words_per_mask + 8;  // 'any' mask, 'all' mask, occupied box (6 floats + 2 pad)
+    for (uint32_t i = threadIdx.x * 4; i < n; i += blockDim.x * 4) {
+        if (i + 3 < n) *reinterpret_cast<uint4*>(&mip_lds[i]) = *reinterpret_cast<const uint4*>(&mip[i]);
+        else for (uint32_t j = i; j < n; j++) mip_lds[j] = mip[j];
+    }
+    __syncthreads();
+    return mip_lds;
+}
+
+// one thread per 4x4x4 brick: 64 Morton-consecutive cells = one aligned uint64 of the bitfield
+__global__ void __launch_bounds__(256) k_build_mip(const unsigned long long* __restrict__ grid64, uint32_t nbricks, uint32_t words_per_mask,
+                                                   uint32_t* __restrict__ mip) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long w = b < nbricks ? grid64[b] : 0ull;
+    const unsigned long long any = __ballot(w != 0ull), all = __ballot(b < nbricks && w == ~0ull);
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t word = b >> 5;  // first of the two 32-brick words this wave covers
+        if (word < words_per_mask) { mip[word] = (uint32_t)any; mip[words_per_mask + word] = (uint32_t)all; }
+        if (word + 1 < words_per_mask) { mip[word + 1] = (uint32_t)(any >> 32); mip[words_per_mask + word + 1] = (uint32_t)(all >> 32); }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -209,21 +321,24 @@ __global__ void __launch_bounds__(1024) k_scan_block_sums(int32_t* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // training march (reference raymarching.cu:315-483), split at the two atomicAdd()s
 // ------------------------------------------------------------------------------------------
+template <bool MIP, bool POW2>
 __global__ void __launch_bounds__(kBlock) k_march_train_count(
-    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid, float bound,
-    float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, const float* __restrict__ nears,
-    const float* __restrict__ fars, const float* __restrict__ noises, int32_t* __restrict__ scratch) {
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid, MarchParams p, uint32_t N,
+    const float* __restrict__ nears, const float* __restrict__ fars, const float* __restrict__ noises, int32_t* __restrict__ scratch,
+    const uint32_t* __restrict__ mip) {
+    const uint32_t* mip_lds = stage_mip(mip, MIP ? p.mip_words : 0);
     const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t max_steps = p.max_steps;
     int num_steps = 0;
     if (n < N) {
         RayCtx c;
-        ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, grid);
-        const float far = fars[n];
+        ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, p, grid, mip_lds);
+        const float far = clip_far_to_box(c, fars[n]);
         float t = nears[n];
-        t = fmaf(clampf(t * dt_gamma, c.dt_min, c.dt_max), noises[n], t);
+        t = fmaf(clampf(t * c.dt_gamma, c.dt_min, c.dt_max), noises[n], t);
         float x, y, z, dt;
         while (t < far && (uint32_t)num_steps < max_steps) {
-            if (march_probe(c, t, x, y, z, dt)) { num_steps++; t += dt; }
+            if (march_probe<MIP, POW2>(c, t, x, y, z, dt)) { num_steps++; t += dt; }
         }
         scratch[kScanHdr + gridDim.x + n] = num_steps;  // per-ray counts live behind the block sums
     }
@@ -232,11 +347,13 @@ __global__ void __launch_bounds__(kBlock) k_march_train_count(
     if (threadIdx.x == 0) scratch[kScanHdr + blockIdx.x] = total;
 }
 
+template <bool MIP, bool POW2>
 __global__ void __launch_bounds__(kBlock) k_march_train_write(
-    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid, float bound,
-    float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* __restrict__ nears,
-    const float* __restrict__ fars, const float* __restrict__ noises, float* __restrict__ xyzs, float* __restrict__ dirs,
-    float* __restrict__ deltas, int32_t* __restrict__ rays, const int32_t* __restrict__ scratch) {
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid, MarchParams p, uint32_t N, uint32_t M,
+    const float* __restrict__ nears, const float* __restrict__ fars, const float* __restrict__ noises, float* __restrict__ xyzs,
+    float* __restrict__ dirs, float* __restrict__ deltas, int32_t* __restrict__ rays, const int32_t* __restrict__ scratch,
+    const uint32_t* __restrict__ mip) {
+    const uint32_t* mip_lds = stage_mip(mip, MIP ? p.mip_words : 0);
     const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
     const int num_steps = n < N ? scratch[kScanHdr + gridDim.x + n] : 0;
     int total;
@@ -256,17 +373,17 @@ __global__ void __launch_bounds__(kBlock) k_march_train_write(
     if (point_index + (uint32_t)num_steps > M) return;
 
     RayCtx c;
-    ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, grid);
-    const float far = fars[n];
+    ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, p, grid, mip_lds);
+    const float far = clip_far_to_box(c, fars[n]);
     float t = nears[n];
-    t = fmaf(clampf(t * dt_gamma, c.dt_min, c.dt_max), noises[n], t);
+    t = fmaf(clampf(t * c.dt_gamma, c.dt_min, c.dt_max), noises[n], t);
     float* px = xyzs + (size_t)point_index * 3;
     float* pd = dirs + (size_t)point_index * 3;
     float* pl = deltas + (size_t)point_index * 2;
     float last_t = t, x, y, z, dt;
     int step = 0;
     while (t < far && step < num_steps) {
-        if (march_probe(c, t, x, y, z, dt)) {
+        if (march_probe<MIP, POW2>(c, t, x, y, z, dt)) {
             px[0] = x; px[1] = y; px[2] = z;
             pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
             t += dt;
@@ -294,32 +411,34 @@ __global__ void __launch_bounds__(kBlock) k_spread_ray_to_sample(const float* __
 // ------------------------------------------------------------------------------------------
 // inference march (reference raymarching.cu:907-1011)
 // ------------------------------------------------------------------------------------------
+template <bool MIP, bool POW2>
 __global__ void __launch_bounds__(kBlock) k_march_rays(
     uint32_t n_alive, uint32_t n_step, const int32_t* __restrict__ rays_alive, const float* __restrict__ rays_t,
-    const float* __restrict__ rays_o, const float* __restrict__ rays_d, float bound, float dt_gamma, uint32_t max_steps,
-    uint32_t C, uint32_t H, const uint8_t* __restrict__ grid, const float* __restrict__ fars, float* __restrict__ xyzs,
-    float* __restrict__ dirs, float* __restrict__ deltas, const float* __restrict__ noises) {
-    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
-    if (n >= n_alive) return;
-    const int index = rays_alive[n];
-    RayCtx c;
-    ctx_init(c, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid);
-    float* px = xyzs + (size_t)n * n_step * 3;
-    float* pd = dirs + (size_t)n * n_step * 3;
-    float* pl = deltas + (size_t)n * n_step * 2;
-    float t = rays_t[index];
-    const float far = fars[index];
-    t = fmaf(clampf(t * dt_gamma, c.dt_min, c.dt_max), noises[n], t);  // noise is slot-indexed (quirk 5)
-    float last_t = t, x, y, z, dt;
-    uint32_t step = 0;
-    while (t < far && step < n_step) {
-        if (march_probe(c, t, x, y, z, dt)) {
-            px[0] = x; px[1] = y; px[2] = z;
-            pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
-            t += dt;
-            pl[0] = dt; pl[1] = t - last_t;
-            last_t = t;
-            px += 3; pd += 3; pl += 2; step++;
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, MarchParams p, const uint8_t* __restrict__ grid,
+    const float* __restrict__ fars, float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas,
+    const float* __restrict__ noises, const uint32_t* __restrict__ mip) {
+    const uint32_t* mip_lds = stage_mip(mip, MIP ? p.mip_words : 0);
+    for (uint32_t n = blockIdx.x * kBlock + threadIdx.x; n < n_alive; n += gridDim.x * kBlock) {
+        const int index = rays_alive[n];
+        RayCtx c;
+        ctx_init(c, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, p, grid, mip_lds);
+        float* px = xyzs + (size_t)n * n_step * 3;
+        float* pd = dirs + (size_t)n * n_step * 3;
+        float* pl = deltas + (size_t)n * n_step * 2;
+        float t = rays_t[index];
+        const float far = clip_far_to_box(c, fars[index]);
+        t = fmaf(clampf(t * c.dt_gamma, c.dt_min, c.dt_max), noises ? noises[n] : 0.0f, t);  // noise is slot-indexed (quirk 5)
+        float last_t = t, x, y, z, dt;
+        uint32_t step = 0;
+        while (t < far && step < n_step) {
+            if (march_probe<MIP, POW2>(c, t, x, y, z, dt)) {
+                px[0] = x; px[1] = y; px[2] = z;
+                pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
+                t += dt;
+                pl[0] = dt; pl[1] = t - last_t;
+                last_t = t;
+                px += 3; pd += 3; pl += 2; step++;
+            }
         }
     }
 }
@@ -355,6 +474,45 @@ __global__ void __launch_bounds__(kBlock) k_alive_write(uint32_t n, const int32_
     for (int w = 0; w < wave; w++) woff += wsum[w];
     const int rank = __popcll(m & ((1ull << lane) - 1ull));  // stable in-wave rank
     if (keep) alive_out[scratch[kScanHdr + blockIdx.x] + woff + rank] = id;
+}
+
+// single workgroup: reduce the 'any' mask to the world-space box of occupied bricks (+2 cells per cascade)
+__global__ void __launch_bounds__(1024) k_mip_bounds(uint32_t* __restrict__ mip, uint32_t words_per_mask, uint32_t nbricks, uint32_t C, uint32_t H,
+                                                     float bound) {
+    __shared__ float red[6][1024 / PNR_WAVE];
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    const uint32_t bricks_per_level = nbricks / C;
+    for (uint32_t wd = threadIdx.x; wd < words_per_mask; wd += blockDim.x) {
+        uint32_t bits = mip[wd];
+        while (bits) {
+            const uint32_t b = wd * 32 + (uint32_t)__ffs((int)bits) - 1;
+            bits &= bits - 1;
+            if (b >= nbricks) break;
+            const uint32_t level = b / bricks_per_level, local = b % bricks_per_level;
+            const float mb = fminf(scalbnf(1.0f, (int)level), bound);
+            const float cell = 2.0f * mb / (float)H;
+            const uint32_t bc[3] = {gather3(local), gather3(local >> 1), gather3(local >> 2)};
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                lo[a] = fminf(lo[a], ((float)(4 * bc[a]) / (float)H * 2.0f - 1.0f) * mb - 2.0f * cell);
+                hi[a] = fmaxf(hi[a], ((float)(4 * bc[a] + 4) / (float)H * 2.0f - 1.0f) * mb + 2.0f * cell);
+            }
+        }
+    }
+    const int lane = threadIdx.x & (PNR_WAVE - 1), wave = threadIdx.x / PNR_WAVE;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        float l = lo[a], h = hi[a];
+        for (int off = PNR_WAVE / 2; off > 0; off >>= 1) { l = fminf(l, __shfl_xor(l, off, PNR_WAVE)); h = fmaxf(h, __shfl_xor(h, off, PNR_WAVE)); }
+        if (lane == 0) { red[a][wave] = l; red[3 + a][wave] = h; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = red[threadIdx.x][0];
+        for (int w = 1; w < (int)(blockDim.x / PNR_WAVE); w++) v = threadIdx.x < 3 ? fminf(v, red[threadIdx.x][w]) : fmaxf(v, red[threadIdx.x][w]);
+        reinterpret_cast<float*>(mip + 2 * words_per_mask)[threadIdx.x] = v;  // empty grid: min = +FLT_MAX > max = -FLT_MAX => every ray "misses"
+    }
+    if (threadIdx.x >= 6 && threadIdx.x < 8) mip[2 * words_per_mask + threadIdx.x] = 0;
 }
 
 }  // namespace pnr
@@ -416,10 +574,31 @@ int pnr_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* b
     return check_launch();
 }
 
-int pnr_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma, uint32_t max_steps,
-                         uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears, const float* fars, float* xyzs,
-                         float* dirs, float* deltas, int32_t* rays, int32_t* counter, const float* noises, void* scratch,
-                         pnr_stream_t stream) {
+uint64_t pnr_occupancy_mip_bytes(uint32_t C, uint32_t H) {
+    return ((uint64_t)2 * (((uint64_t)C * H * H * H / 64 + 31) / 32) + 8) * 4;  // any mask, all mask, occupied box
+}
+
+int pnr_build_occupancy_mip(const uint8_t* grid, uint32_t C, uint32_t H, float bound, void* mip, pnr_stream_t stream) {
+    if (!grid || !mip) return PNR_ERR_INVALID;
+    if (C == 0 || C > 16 || H == 0 || (H % 4) != 0 || (reinterpret_cast<uintptr_t>(grid) & 7)) return PNR_ERR_UNSUPPORTED;
+    const uint32_t nbricks = (uint32_t)((uint64_t)C * H * H * H / 64);
+    const uint32_t words = (nbricks + 31) / 32;
+    hipLaunchKernelGGL(k_build_mip, dim3(cdiv(nbricks, 256)), dim3(256), 0, as_stream(stream), reinterpret_cast<const unsigned long long*>(grid),
+                       nbricks, words, static_cast<uint32_t*>(mip));
+    hipLaunchKernelGGL(k_mip_bounds, dim3(1), dim3(1024), 0, as_stream(stream), static_cast<uint32_t*>(mip), words, nbricks, C, H, bound);
+    return check_launch();
+}
+
+// LDS needed by a march launch that uses the mip; 0 when the mip is absent or does not fit (then the plain path runs)
+static uint32_t mip_lds_bytes(const MarchParams& p) { return p.mip_words ? (2 * p.mip_words + 8) * 4 : 0; }
+static bool mip_usable(const void* mip, uint32_t C, uint32_t H) {
+    return mip && (H % 4) == 0 && pnr_occupancy_mip_bytes(C, H) <= 64 * 1024;
+}
+
+int pnr_march_rays_train_mip(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma, uint32_t max_steps,
+                             uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears, const float* fars, float* xyzs, float* dirs,
+                             float* deltas, int32_t* rays, int32_t* counter, const float* noises, void* scratch, const void* mip,
+                             pnr_stream_t stream) {
     if (N == 0) return PNR_OK;
     if (!rays_o || !rays_d || !grid || !nears || !fars || !rays || !counter || !noises || !scratch) return PNR_ERR_INVALID;
     if (M > 0 && (!xyzs || !dirs || !deltas)) return PNR_ERR_INVALID;
@@ -427,12 +606,30 @@ int pnr_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t
     hipStream_t s = as_stream(stream);
     int32_t* sc = static_cast<int32_t*>(scratch);
     const uint32_t nb = cdiv(N, kBlock);
-    hipLaunchKernelGGL(k_march_train_count, dim3(nb), dim3(kBlock), 0, s, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H,
-                       nears, fars, noises, sc);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, sc, nb, counter, N, (int32_t*)nullptr);
-    hipLaunchKernelGGL(k_march_train_write, dim3(nb), dim3(kBlock), 0, s, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M,
-                       nears, fars, noises, xyzs, dirs, deltas, rays, sc);
+    const bool use_mip = mip_usable(mip, C, H);
+    const bool pow2 = is_pow2f(bound) && (H & (H - 1)) == 0;
+    const MarchParams p = make_march_params(bound, dt_gamma, max_steps, C, H, use_mip);
+    const uint32_t lds = mip_lds_bytes(p);
+    const uint32_t* m = static_cast<const uint32_t*>(mip);
+#define PNR_LAUNCH_TRAIN(MIPV, P2V)                                                                                                           \
+    hipLaunchKernelGGL((k_march_train_count<MIPV, P2V>), dim3(nb), dim3(kBlock), lds, s, rays_o, rays_d, grid, p, N, nears, fars, noises, sc, m); \
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, sc, nb, counter, N, (int32_t*)nullptr);                                    \
+    hipLaunchKernelGGL((k_march_train_write<MIPV, P2V>), dim3(nb), dim3(kBlock), lds, s, rays_o, rays_d, grid, p, N, M, nears, fars, noises,     \
+                       xyzs, dirs, deltas, rays, sc, m)
+    if (use_mip && pow2) { PNR_LAUNCH_TRAIN(true, true); }
+    else if (use_mip) { PNR_LAUNCH_TRAIN(true, false); }
+    else if (pow2) { PNR_LAUNCH_TRAIN(false, true); }
+    else { PNR_LAUNCH_TRAIN(false, false); }
+#undef PNR_LAUNCH_TRAIN
     return check_launch();
+}
+
+int pnr_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma, uint32_t max_steps,
+                         uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears, const float* fars, float* xyzs,
+                         float* dirs, float* deltas, int32_t* rays, int32_t* counter, const float* noises, void* scratch,
+                         pnr_stream_t stream) {
+    return pnr_march_rays_train_mip(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, counter,
+                                    noises, scratch, nullptr, stream);
 }
 
 int pnr_spread_ray_to_sample(const float* input, const int32_t* rays, uint32_t M, uint32_t N, uint32_t n_channel, float* output,
@@ -444,17 +641,41 @@ int pnr_spread_ray_to_sample(const float* input, const int32_t* rays, uint32_t M
     return check_launch();
 }
 
+int pnr_march_rays_mip(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t, const float* rays_o,
+                       const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid,
+                       const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas, const float* noises, const void* mip,
+                       pnr_stream_t stream) {
+    (void)nears;
+    if (n_alive == 0 || n_step == 0) return PNR_OK;
+    if (!rays_alive || !rays_t || !rays_o || !rays_d || !grid || !fars || !xyzs || !dirs || !deltas) return PNR_ERR_INVALID;
+    if (C == 0 || C > 16 || H == 0 || max_steps == 0) return PNR_ERR_INVALID;
+    const bool use_mip = mip_usable(mip, C, H);
+    const bool pow2 = is_pow2f(bound) && (H & (H - 1)) == 0;
+    const MarchParams p = make_march_params(bound, dt_gamma, max_steps, C, H, use_mip);
+    const uint32_t lds = mip_lds_bytes(p);
+    const uint32_t nb = cdiv(n_alive, kBlock);
+    const uint32_t grid_dim = use_mip ? (nb < 2048u ? nb : 2048u) : nb;  // with the mip staged per workgroup, keep workgroups persistent
+    const dim3 g(grid_dim), b(kBlock);
+    hipStream_t s = as_stream(stream);
+    const uint32_t* m = static_cast<const uint32_t*>(mip);
+    if (use_mip && pow2)
+        hipLaunchKernelGGL((k_march_rays<true, true>), g, b, lds, s, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, p, grid, fars, xyzs, dirs, deltas, noises, m);
+    else if (use_mip)
+        hipLaunchKernelGGL((k_march_rays<true, false>), g, b, lds, s, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, p, grid, fars, xyzs, dirs, deltas, noises, m);
+    else if (pow2)
+        hipLaunchKernelGGL((k_march_rays<false, true>), g, b, lds, s, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, p, grid, fars, xyzs, dirs, deltas, noises, m);
+    else
+        hipLaunchKernelGGL((k_march_rays<false, false>), g, b, lds, s, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, p, grid, fars, xyzs, dirs, deltas, noises, m);
+    return check_launch();
+}
+
 int pnr_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t, const float* rays_o,
                    const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid,
                    const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas, const float* noises,
                    pnr_stream_t stream) {
-    (void)nears;
-    if (n_alive == 0 || n_step == 0) return PNR_OK;
-    if (!rays_alive || !rays_t || !rays_o || !rays_d || !grid || !fars || !xyzs || !dirs || !deltas || !noises) return PNR_ERR_INVALID;
-    if (C == 0 || C > 16 || H == 0 || max_steps == 0) return PNR_ERR_INVALID;
-    hipLaunchKernelGGL(k_march_rays, dim3(cdiv(n_alive, kBlock)), dim3(kBlock), 0, as_stream(stream), n_alive, n_step, rays_alive, rays_t,
-                       rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises);
-    return check_launch();
+    if (n_alive != 0 && n_step != 0 && !noises) return PNR_ERR_INVALID;
+    return pnr_march_rays_mip(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears, fars, xyzs, dirs,
+                              deltas, noises, nullptr, stream);
 }
 
 int pnr_compact_alive(uint32_t n_alive, const int32_t* rays_alive_in, int32_t* rays_alive_out, int32_t* n_alive_out, void* scratch,

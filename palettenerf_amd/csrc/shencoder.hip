@@ -7,16 +7,9 @@
 // Horner chain in z^2 per (l,m).  Everything is unrolled at compile time per degree; outputs are
 // written as 16-byte vectors.
 #include "pnr_common.hpp"
+#include "sh_eval.hpp"
 
 namespace pnr {
-
-#include "sh_tables.inc"
-
-__device__ __forceinline__ float sh_poly(const ShPoly& p, float z, float z2) {
-    float r = p.c[p.n - 1];
-    for (int i = p.n - 2; i >= 0; i--) r = fmaf(r, z2, p.c[i]);
-    return p.par ? r * z : r;
-}
 
 template <int DEG, bool GRAD>
 __global__ void __launch_bounds__(256) k_sh_fwd(const float* __restrict__ inputs, float* __restrict__ outputs, uint32_t B, uint32_t D,

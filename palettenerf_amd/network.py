@@ -39,9 +39,16 @@ class NeRFNetwork(NeRFRenderer):
         self.encoder_dir, self.in_dim_dir = get_encoder(encoding_dir)
         self.color_net = _mlp([self.in_dim_dir + geo_feat_dim] + [hidden_dim_color] * (num_layers_color - 1) + [3])
         self.bg_net = None
+        self.fused_field = False  # True: inference batches go through the fused MFMA field kernel (fp32, no autograd)
+        self._fused = None
 
     def forward(self, x, d):
         """x: [N,3] in [-bound,bound]; d: [N,3] unit.  Returns (sigma [N], rgb [N,3]).  nerf/network.py:95-124"""
+        if self.fused_field and not torch.is_grad_enabled() and not torch.is_autocast_enabled():
+            if self._fused is None:
+                from .fused import NeRFFieldFused
+                self._fused = NeRFFieldFused(self)
+            return self._fused(x, d)
         h = _run(self.sigma_net, self.encoder(x, bound=self.bound))
         sigma = trunc_exp(h[..., 0])
         geo_feat = h[..., 1:]

@@ -17,6 +17,35 @@ _fwd32 = custom_fwd(device_type="cuda", cast_inputs=torch.float32)
 _bwd = custom_bwd(device_type="cuda")
 
 
+USE_MIP = True  # stage the any/all occupancy mip in LDS for the march kernels (bit-identical results, far fewer global probes)
+_mip_cache = {}  # bitfield.data_ptr() -> (key, mip tensor)
+
+
+def occupancy_mip(bitfield, C, H, bound):
+    """Cached any/all brick mip of a density bitfield (pnr_build_occupancy_mip).  The cache is keyed on the tensor's
+    storage pointer and version counter: torch in-place ops and this module's packbits() bump the version; code that
+    rewrites the bitfield behind torch's back must call invalidate_occupancy_mip()."""
+    if not USE_MIP or H % 4 != 0 or bitfield.data_ptr() % 8 != 0:
+        return None
+    nbytes = int(_lib.load().pnr_occupancy_mip_bytes(int(C), int(H)))
+    if nbytes > 64 * 1024:
+        return None
+    key = (bitfield._version, int(C), int(H), float(bound), bitfield.numel())
+    ent = _mip_cache.get(bitfield.data_ptr())
+    if ent is not None and ent[0] == key and ent[1].device == bitfield.device:
+        return ent[1]
+    mip = torch.empty(nbytes // 4, dtype=torch.int32, device=bitfield.device)
+    call("pnr_build_occupancy_mip", ptr(require(bitfield, torch.uint8, "density_bitfield")), _u32(C), _u32(H), _f32(bound), ptr(mip))
+    if len(_mip_cache) > 64:
+        _mip_cache.clear()
+    _mip_cache[bitfield.data_ptr()] = (key, mip)
+    return mip
+
+
+def invalidate_occupancy_mip():
+    _mip_cache.clear()
+
+
 def _scratch(n, device):
     nbytes = int(_lib.load().pnr_scan_scratch_bytes(int(n)))
     return torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=device)
@@ -103,6 +132,7 @@ class _packbits(Function):
         if bitfield is None:
             bitfield = torch.empty(N, dtype=torch.uint8, device=grid.device)
         call("pnr_packbits", ptr(require(grid, torch.float32, "grid")), _u32(N), _f32(thresh), ptr(require(bitfield, torch.uint8, "bitfield")))
+        torch.autograd.graph.increment_version(bitfield)  # written by a raw kernel: invalidates the cached occupancy mip
         return bitfield
 
 
@@ -139,11 +169,12 @@ class _march_rays_train(Function):
         else:
             noises = torch.zeros(N, dtype=rays_o.dtype, device=dev)
         scratch = _scratch(N, dev)
-        call("pnr_march_rays_train", ptr(require(rays_o, torch.float32, "rays_o")), ptr(require(rays_d, torch.float32, "rays_d")),
+        mip = occupancy_mip(density_bitfield, C, H, bound)
+        call("pnr_march_rays_train_mip", ptr(require(rays_o, torch.float32, "rays_o")), ptr(require(rays_d, torch.float32, "rays_d")),
              ptr(require(density_bitfield, torch.uint8, "density_bitfield")), _f32(bound), _f32(dt_gamma), _u32(max_steps), _u32(N),
              _u32(C), _u32(H), _u32(M), ptr(require(nears, torch.float32, "nears")), ptr(require(fars, torch.float32, "fars")),
              ptr(xyzs), ptr(dirs), ptr(deltas), ptr(rays), ptr(require(step_counter, torch.int32, "step_counter")), ptr(noises),
-             ptr(scratch))
+             ptr(scratch), ptr(mip))
         if force_all_rays or mean_count <= 0:
             m = step_counter[0].item()
             if align > 0:
@@ -238,15 +269,13 @@ class _march_rays(Function):
         xyzs = torch.zeros(M, 3, dtype=rays_o.dtype, device=dev)
         dirs = torch.zeros(M, 3, dtype=rays_o.dtype, device=dev)
         deltas = torch.zeros(M, 2, dtype=rays_o.dtype, device=dev)
-        if perturb:
-            noises = torch.rand(n_alive, dtype=rays_o.dtype, device=dev)
-        else:
-            noises = torch.zeros(n_alive, dtype=rays_o.dtype, device=dev)
-        call("pnr_march_rays", _u32(n_alive), _u32(n_step), ptr(require(rays_alive, torch.int32, "rays_alive")),
+        noises = torch.rand(n_alive, dtype=rays_o.dtype, device=dev) if perturb else None  # NULL = zeros (no perturbation)
+        mip = occupancy_mip(density_bitfield, C, H, bound)
+        call("pnr_march_rays_mip", _u32(n_alive), _u32(n_step), ptr(require(rays_alive, torch.int32, "rays_alive")),
              ptr(require(rays_t, torch.float32, "rays_t")), ptr(require(rays_o, torch.float32, "rays_o")),
              ptr(require(rays_d, torch.float32, "rays_d")), _f32(bound), _f32(dt_gamma), _u32(max_steps), _u32(C), _u32(H),
              ptr(require(density_bitfield, torch.uint8, "density_bitfield")), ptr(require(near, torch.float32, "near")),
-             ptr(require(far, torch.float32, "far")), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(noises))
+             ptr(require(far, torch.float32, "far")), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(noises), ptr(mip))
         return xyzs, dirs, deltas
 
 

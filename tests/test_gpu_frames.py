@@ -40,14 +40,15 @@ def close(got, want, tol=COLOUR_TOL, what=""):
 
 
 @pytest.mark.parametrize("case", ["a", "b"])
-@pytest.mark.parametrize("mode", ["compat", "device"])
+@pytest.mark.parametrize("mode", ["compat", "device", "fused"])
 def test_nerf_inference_frame(cuda, golden_dir, case, mode):
     g = load(golden_dir, f"frame_nerf_{case}")
     m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=float(g["density_scale"]), min_near=0.2)
     scene.seed_field_(m, int(g["seed"]))
     m = m.to(cuda).eval()
     put_scene(m, cuda)
-    m.march_mode = mode
+    m.march_mode = "device" if mode == "fused" else mode
+    m.fused_field = mode == "fused"
     ro, rd = frame_rays(g, cuda)
     with torch.no_grad():
         r = m.render(ro, rd, staged=True, dt_gamma=float(g["dt_gamma"]), perturb=False, max_steps=1024, T_thresh=1e-4)

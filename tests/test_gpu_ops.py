@@ -83,18 +83,52 @@ def test_sph_from_ray(cuda):
 
 
 # ------------------------------------------------------------------------------------------ march
-@pytest.mark.parametrize("dt_gamma,min_near", [(0.0, 0.2), (1.0 / 128, 0.02)])
-def test_march_rays_train_bit_exact(cuda, s0, dt_gamma, min_near):
+@pytest.fixture(params=["mip", "nomip"])
+def mip_mode(request):
+    """Every march test runs through both kernel variants: occupancy mip in LDS, and plain global probes."""
+    old = raymarching.USE_MIP
+    raymarching.USE_MIP = request.param == "mip"
+    yield request.param
+    raymarching.USE_MIP = old
+
+
+def test_occupancy_mip_matches_numpy(cuda, s0):
+    grid, bf = s0
+    rng = np.random.default_rng(77)
+    bf2 = bf.copy()
+    bf2[rng.integers(0, bf2.size, 5000)] = 0xFF
+    bf2[:64] = 0xFF
+    t = dev(bf2, cuda)
+    mip = raymarching.occupancy_mip(t, 2, 128, 2.0)
+    words = bf2.view(np.uint64)
+    any_bits = np.packbits(words != 0, bitorder="little").view(np.uint32)
+    all_bits = np.packbits(words == np.uint64(0xFFFFFFFFFFFFFFFF), bitorder="little").view(np.uint32)
+    got = host(mip).view(np.uint32)
+    np.testing.assert_array_equal(got[:2048], any_bits)
+    np.testing.assert_array_equal(got[2048:4096], all_bits)
+    box = got[4096:4102].view(np.float32)
+    assert np.all(box[:3] <= -2.0) and np.all(box[3:] >= 2.0)  # bricks set at random all over the volume: the box covers it
+    s0box = host(raymarching.occupancy_mip(dev(bf, cuda), 2, 128, 2.0)).view(np.uint32)[4096:4102].view(np.float32)
+    np.testing.assert_allclose(s0box, [-0.8125] * 3 + [0.8125] * 3, atol=1e-6)  # S0: bricks of cascade 1 reach +-0.75, plus two 1/32 cells
+    assert raymarching.occupancy_mip(t, 2, 128, 2.0) is mip          # cached
+    t.bitwise_or_(torch.tensor(1, dtype=torch.uint8, device=cuda))  # torch in-place write bumps the version -> rebuilt
+    assert raymarching.occupancy_mip(t, 2, 128, 2.0) is not mip
+    raymarching.invalidate_occupancy_mip()
+
+
+@pytest.mark.parametrize("dt_gamma,min_near,bound", [(0.0, 0.2, 2.0), (1.0 / 128, 0.02, 2.0), (1.0 / 256, 0.05, 1.5)])
+def test_march_rays_train_bit_exact(cuda, s0, mip_mode, dt_gamma, min_near, bound):
     grid, bf = s0
     ro, rd = rays_of(64, 48)
     N = ro.shape[0]
-    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    aabb = np.array([-bound, -bound, -bound, bound, bound, bound], np.float32)
     on, of = oracle.near_far_from_aabb(ro, rd, aabb, min_near)
     cnt = np.zeros(2, np.int32)
-    ox, od, odl, orays = oracle.march_rays_train(ro, rd, 2.0, bf, 2, 128, on, of, cnt, align=128, force_all_rays=True, dt_gamma=dt_gamma)
+    ox, od, odl, orays = oracle.march_rays_train(ro, rd, bound, bf, 2, 128, on, of, cnt, align=128, force_all_rays=True, dt_gamma=dt_gamma)
     counter = torch.zeros(2, dtype=torch.int32, device=cuda)
-    x, d, dl, rays = raymarching.march_rays_train(dev(ro, cuda), dev(rd, cuda), 2.0, dev(bf, cuda), 2, 128, dev(on, cuda), dev(of, cuda), counter,
+    x, d, dl, rays = raymarching.march_rays_train(dev(ro, cuda), dev(rd, cuda), bound, dev(bf, cuda), 2, 128, dev(on, cuda), dev(of, cuda), counter,
                                                   -1, False, 128, True, dt_gamma, 1024)
+    assert int(cnt[0]) > 10000
     np.testing.assert_array_equal(host(counter), cnt)            # total sample count and ray count: bit-exact
     np.testing.assert_array_equal(host(rays), orays)             # per-ray (id, offset, count): bit-exact, deterministic row order
     assert x.shape == ox.shape
@@ -130,19 +164,19 @@ def test_march_rays_train_perturbed_and_mean_count_overflow(cuda, s0):
     assert diff.max() <= 8 and diff.mean() < 1.0 and abs(int(counter[0]) - int(cnt2[0])) < 0.01 * int(cnt2[0])
 
 
-@pytest.mark.parametrize("n_step", [1, 3, 8])
-def test_march_rays_inference_bit_exact(cuda, s0, n_step):
+@pytest.mark.parametrize("n_step,bound", [(1, 2.0), (3, 2.0), (8, 2.0), (4, 1.5)])
+def test_march_rays_inference_bit_exact(cuda, s0, mip_mode, n_step, bound):
     grid, bf = s0
     ro, rd = rays_of(48, 40)
     N = ro.shape[0]
-    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    aabb = np.array([-bound, -bound, -bound, bound, bound, bound], np.float32)
     on, of = oracle.near_far_from_aabb(ro, rd, aabb, 0.2)
     rng = np.random.default_rng(4)
     alive = np.sort(rng.choice(N, N // 2, replace=False)).astype(np.int32)
     rays_t = on.copy()
     rays_t[alive[::3]] += 0.5  # some rays already advanced
-    ox, od, odl = oracle.march_rays(len(alive), n_step, alive, rays_t, ro, rd, 2.0, bf, 2, 128, on, of, align=128, dt_gamma=1.0 / 256)
-    x, d, dl = raymarching.march_rays(len(alive), n_step, dev(alive, cuda), dev(rays_t, cuda), dev(ro, cuda), dev(rd, cuda), 2.0, dev(bf, cuda), 2, 128,
+    ox, od, odl = oracle.march_rays(len(alive), n_step, alive, rays_t, ro, rd, bound, bf, 2, 128, on, of, align=128, dt_gamma=1.0 / 256)
+    x, d, dl = raymarching.march_rays(len(alive), n_step, dev(alive, cuda), dev(rays_t, cuda), dev(ro, cuda), dev(rd, cuda), bound, dev(bf, cuda), 2, 128,
                                       dev(on, cuda), dev(of, cuda), 128, False, 1.0 / 256, 1024)
     assert x.shape == ox.shape and x.shape[0] % 128 == 0 and x.shape[0] > len(alive) * n_step - 1
     np.testing.assert_array_equal(host(x), ox)
@@ -392,3 +426,39 @@ def test_hsv_round_trip_and_parity(cuda):
     np.testing.assert_allclose(host(back), oracle.hsv_to_rgb(host(hsv)), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(host(back)[2000:], rgb[2000:], atol=5e-6)  # round trip on in-gamut colours
     assert palette_utils.rgb_to_hsv(torch.rand(3, 4, 5, 3, device=cuda)).shape == (3, 4, 5, 3)
+
+
+# ------------------------------------------------------------------------------------------ fused MFMA field
+def test_fused_nerf_field_matches_oracle_and_torch(cuda):
+    from palettenerf_amd import network
+    rng = np.random.default_rng(50)
+    m = network.NeRFNetwork(bound=2, cuda_ray=True)
+    scene.seed_field_(m, 3)
+    m = m.to(cuda).eval()
+    for B in (1, 31, 32, 33, 255, 256, 257, 5000, 70001):
+        x = (rng.random((B, 3)).astype(np.float32) * 4 - 2)
+        d = rng.standard_normal((B, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        tx, td = dev(x, cuda), dev(d, cuda)
+        with torch.no_grad():
+            m.fused_field = False
+            s_ref, c_ref = m(tx, td)
+            m.fused_field = True
+            s, c = m(tx, td)
+        # vs the unfused torch/rocBLAS evaluation of the same module
+        np.testing.assert_allclose(host(s), host(s_ref), rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(host(c), host(c_ref), rtol=0, atol=2e-6)
+        if B <= 5000:  # vs the oracle (sequential-k fmaf chains; the MFMA kernel permutes k within each layer)
+            enc = oracle.grid_encode_forward((x + 2) / 4, host(m.encoder.embeddings), host(m.encoder.offsets), m.encoder.per_level_scale, 16)
+            w = [host(l.weight) for l in list(m.sigma_net) + list(m.color_net)]
+            so, co = oracle.nerf_field_forward(enc, d, *w)
+            np.testing.assert_allclose(host(s), so, rtol=2e-5, atol=1e-7)
+            np.testing.assert_allclose(host(c), co, rtol=0, atol=2e-6)
+    # weights changed in place -> the packed blob must be refreshed
+    with torch.no_grad():
+        m.color_net[2].weight.mul_(0.5)
+        s2, c2 = m(tx, td)
+        m.fused_field = False
+        s3, c3 = m(tx, td)
+    np.testing.assert_allclose(host(c2), host(c3), atol=2e-6)
+    assert np.abs(host(c2) - host(c)).max() > 1e-3
