@@ -163,6 +163,44 @@ int pnr_nerf_field_pack(const float* w_sigma0, const float* w_sigma1, const floa
 int pnr_nerf_field_forward(const float* enc, const float* dirs, const float* packed, uint32_t B, float* sigmas,
                            float* rgbs, pnr_stream_t stream);
 
+/* Device-driven inference frame of the NeRF path: the loop of nerf/renderer.py:344-380 (same n_step schedule,
+ * same per-ray arithmetic, order-preserving compaction) with n_alive / n_step / step kept in a device control
+ * block, so the host does not synchronise per iteration.  Outputs are the raw accumulations (weights_sum [N],
+ * depth [N], image [N,3]) BEFORE the background mix / depth normalisation of nerf/renderer.py:382-383.
+ * perturb is False (inference).  workspace: pnr_nerf_frame_workspace_bytes(N) bytes of device memory. */
+typedef struct pnr_nerf_frame_args {
+    uint32_t N;
+    const float* rays_o;           /* [N,3] */
+    const float* rays_d;           /* [N,3] */
+    const float* nears;            /* [N]   (pnr_near_far_from_aabb) */
+    const float* fars;             /* [N]   */
+    const uint8_t* bitfield;       /* density bitfield, uint8[C*H^3/8] */
+    const void* mip;               /* pnr_build_occupancy_mip output, or NULL */
+    float bound;
+    uint32_t C, H;
+    float dt_gamma;
+    uint32_t max_steps;
+    float T_thresh;
+    const float* embeddings;       /* fp32 hash table [sum T_l, 2] */
+    const int32_t* offsets;        /* int32[num_levels+1] */
+    uint32_t num_levels;           /* must be 16 (the fused field kernel's input width) */
+    float S;                       /* log2(per_level_scale) */
+    uint32_t base_resolution;
+    uint32_t gridtype;             /* 0 hash, 1 tiled */
+    const float* packed_weights;   /* pnr_nerf_field_pack output */
+    float density_scale;
+    float* weights_sum;            /* [N]   out */
+    float* depth;                  /* [N]   out */
+    float* image;                  /* [N,3] out */
+    void* workspace;
+    uint64_t workspace_bytes;
+    uint64_t* stats;               /* HOST, optional: [iterations, rendered samples, evaluated rows, enqueued iterations] */
+    float* kernel_ms;              /* HOST, optional: [0] = summed HIP-event time (ms) of the grid-encode launches that did work,
+                                      [1] = their number; events are recorded on `stream` around each launch */
+} pnr_nerf_frame_args;
+uint64_t pnr_nerf_frame_workspace_bytes(uint32_t N);
+int pnr_nerf_render_frame(const pnr_nerf_frame_args* args, pnr_stream_t stream);
+
 /* ---------------------------------------------------------------- SH encoder --------------- */
 
 /* replaces sh_encode_forward / sh_encode_backward, shencoder/src/shencoder.h:9-10, shencoder.cu:400-439.

@@ -1,0 +1,483 @@
+// frame.hip -- device-driven inference frame of the NeRF path (MI355X-first; no reference counterpart as
+// one call).  It runs the loop of nerf/renderer.py:344-380
+//     while step < max_steps: n_step = max(min(N // n_alive, 8), 1); march; field; composite; compact
+// with the SAME schedule and the same per-ray arithmetic, but
+//   * n_alive / n_step / step live in a device control block that every kernel reads; the host
+//     enqueues iterations back to back and looks at the block only every few iterations (one 64-byte
+//     read-back) instead of synchronising on a boolean-mask compaction every iteration;
+//   * the alive list is compacted on the device (wave64 ballot + prefix sum, stable);
+//   * no staging buffers are zero-filled: the march writes the delta == 0 sentinel itself, padding
+//     rows do not exist, dead slots are skipped by the grid and field kernels;
+//   * world -> [0,1] normalisation, density_scale and the sample counter are folded into kernels.
+// Per iteration: march, grid (level-major, L2-resident tables), field (fp32 MFMA), composite(+count),
+// scan(+schedule), write = 6 launches, no host round trip.
+#include "pnr_common.hpp"
+#include "march_core.hpp"
+#include "grid_core.hpp"
+#include "field_core.hpp"
+#include <vector>
+
+namespace pnr {
+
+struct FrameCtl {  // 64 bytes, two copies ping-ponged by iteration parity
+    int32_t n_alive, n_step, step, done;
+    int32_t iterations, pad0;
+    unsigned long long rendered;  // march-emitted samples (delta > 0)
+    unsigned long long rows;      // evaluated rows, sum of n_alive * n_step
+    int32_t pad1[6];
+};
+static_assert(sizeof(FrameCtl) == 64, "FrameCtl layout");
+
+constexpr uint32_t kRayBlock = 256;
+constexpr uint32_t kHdr = 4;  // scratch header ints before the per-chunk counts
+
+__device__ __forceinline__ int schedule_n_step(int N, int n_alive) {  // nerf/renderer.py:364
+    return n_alive > 0 ? max(min(N / n_alive, 8), 1) : 1;
+}
+
+__global__ void __launch_bounds__(kRayBlock) k_frame_init(uint32_t N, const float* __restrict__ nears, int32_t* __restrict__ alive,
+                                                          float* __restrict__ rays_t, float* __restrict__ weights_sum, float* __restrict__ depth,
+                                                          float* __restrict__ image, FrameCtl* __restrict__ ctl) {
+    const uint32_t i = blockIdx.x * kRayBlock + threadIdx.x;
+    if (i < N) {
+        alive[i] = (int32_t)i;
+        rays_t[i] = nears[i];
+        weights_sum[i] = 0.0f; depth[i] = 0.0f;
+        image[i * 3] = 0.0f; image[i * 3 + 1] = 0.0f; image[i * 3 + 2] = 0.0f;
+    }
+    if (i == 0) {
+        FrameCtl c = {};
+        c.n_alive = (int32_t)N; c.n_step = schedule_n_step((int)N, (int)N); c.done = N == 0;
+        ctl[0] = c; ctl[1] = c;
+    }
+}
+
+// reference raymarching.cu:907-1011, n_alive / n_step from the control block; also writes the delta == 0
+// sentinel of unfilled slots (the reference relies on zero-initialised buffers) and counts emitted samples.
+template <bool MIP, bool POW2>
+__global__ void __launch_bounds__(kRayBlock) k_frame_march(FrameCtl* __restrict__ ctl, const int32_t* __restrict__ rays_alive,
+                                                           const float* __restrict__ rays_t, const float* __restrict__ rays_o,
+                                                           const float* __restrict__ rays_d, MarchParams p, const uint8_t* __restrict__ grid,
+                                                           const float* __restrict__ fars, float* __restrict__ xyzs, float* __restrict__ dirs,
+                                                           float* __restrict__ deltas, const uint32_t* __restrict__ mip,
+                                                           int32_t* __restrict__ emitted_partials /* [gridDim.x] */) {
+    if (ctl->done) return;
+    const uint32_t n_alive = (uint32_t)ctl->n_alive, n_step = (uint32_t)ctl->n_step;
+    if (blockIdx.x * kRayBlock >= n_alive) { if (threadIdx.x == 0) emitted_partials[blockIdx.x] = 0; return; }
+    const uint32_t* mip_lds = stage_mip(mip, MIP ? p.mip_words : 0);
+    uint32_t emitted = 0;
+    for (uint32_t n = blockIdx.x * kRayBlock + threadIdx.x; n < n_alive; n += gridDim.x * kRayBlock) {
+        const int index = rays_alive[n];
+        RayCtx c;
+        ctx_init(c, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, p, grid, mip_lds);
+        float* px = xyzs + (size_t)n * n_step * 3;
+        float* pd = dirs + (size_t)n * n_step * 3;
+        float* pl = deltas + (size_t)n * n_step * 2;
+        float t = rays_t[index];
+        const float far = clip_far_to_box(c, fars[index]);
+        t = fmaf(clampf(t * c.dt_gamma, c.dt_min, c.dt_max), 0.0f, t);  // perturb == False on the inference path
+        float last_t = t, x, y, z, dt;
+        uint32_t step = 0;
+        while (t < far && step < n_step) {
+            if (march_probe<MIP, POW2>(c, t, x, y, z, dt)) {
+                px[0] = x; px[1] = y; px[2] = z;
+                pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
+                t += dt;
+                pl[0] = dt; pl[1] = t - last_t;
+                last_t = t;
+                px += 3; pd += 3; pl += 2; step++;
+            }
+        }
+        emitted += step;
+        for (; step < n_step; step++) { pl[0] = 0.0f; pl[1] = 0.0f; pl += 2; }
+    }
+    // one partial per workgroup, summed by k_frame_scan: thousands of same-address atomics would serialise in L2
+    __shared__ uint32_t wsum[kRayBlock / PNR_WAVE];
+    for (int off = PNR_WAVE / 2; off > 0; off >>= 1) emitted += __shfl_xor(emitted, off, PNR_WAVE);
+    if ((threadIdx.x & (PNR_WAVE - 1)) == 0) wsum[threadIdx.x / PNR_WAVE] = emitted;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int wv = 0; wv < (int)(kRayBlock / PNR_WAVE); wv++) tot += wsum[wv];
+        emitted_partials[blockIdx.x] = (int32_t)tot;
+    }
+}
+
+// gridencoder.cu:75-175 for D = 3, C = 2, fp32, fused with GridEncoder.forward's (x + bound) / (2 bound)
+// (gridencoder/grid.py:142); rows from the control block; dead slots (delta == 0) are skipped.
+__global__ void __launch_bounds__(256) k_frame_grid(const FrameCtl* __restrict__ ctl, const float* __restrict__ xyzs, const float* __restrict__ deltas,
+                                                    const float* __restrict__ table, const int32_t* __restrict__ offsets, LevelParams lp,
+                                                    float* __restrict__ enc, uint32_t level_stride, float bound, float two_bound, uint32_t gridtype) {
+    if (ctl->done) return;
+    const uint32_t rows = (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step;
+    const uint32_t level = blockIdx.y;
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    const float* g = table + (size_t)off0 * 2;
+    const float scale = lp.scale[level];
+    const uint32_t resolution = lp.resolution[level];
+    for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < rows; b += gridDim.x * 256) {
+        if (deltas[(size_t)b * 2] == 0.0f) continue;
+        float in[3];
+        bool oob = false;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            in[d] = (xyzs[(size_t)b * 3 + d] + bound) / two_bound;
+            oob |= (in[d] < 0.0f) | (in[d] > 1.0f);
+        }
+        float2 out = make_float2(0.0f, 0.0f);
+        if (!oob) {
+            float pos[3];
+            uint32_t pg[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                pos[d] = fmaf(in[d], scale, 0.5f);
+                const float fl = floorf(pos[d]);
+                pg[d] = (uint32_t)fl;
+                pos[d] -= (float)pg[d];
+            }
+            uint32_t idxs[8];
+            float ws[8];
+#pragma unroll
+            for (uint32_t idx = 0; idx < 8; idx++) {
+                float w = 1.0f;
+                uint32_t pl[3];
+#pragma unroll
+                for (uint32_t d = 0; d < 3; d++) {
+                    if ((idx & (1u << d)) == 0) { w *= 1.0f - pos[d]; pl[d] = pg[d]; }
+                    else { w *= pos[d]; pl[d] = pg[d] + 1; }
+                }
+                ws[idx] = w;
+                idxs[idx] = grid_index<3, 2>(gridtype, false, hashmap_size, resolution, pl);
+            }
+            float acc[2] = {0.0f, 0.0f};
+#pragma unroll
+            for (uint32_t idx = 0; idx < 8; idx++) corner_accumulate<2>(acc, ws[idx], g + idxs[idx]);
+            out = make_float2(acc[0], acc[1]);
+        }
+        *reinterpret_cast<float2*>(enc + ((size_t)level * level_stride + b) * 2) = out;
+    }
+}
+
+// the fused MFMA field of field.hip with rows from the control block, dead-slot skipping and density_scale
+constexpr int kFieldThreads = 512;
+__global__ void __launch_bounds__(kFieldThreads) k_frame_field(const FrameCtl* __restrict__ ctl, const float* __restrict__ enc, uint32_t level_stride,
+                                                               const float* __restrict__ dirs, const float* __restrict__ deltas,
+                                                               const float* __restrict__ packed, float density_scale, float* __restrict__ sigmas,
+                                                               float* __restrict__ rgbs) {
+    if (ctl->done) return;
+    const uint32_t B = (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step;
+    const uint32_t ntiles = (B + 255) / 256;
+    if (blockIdx.x >= ntiles) return;
+    __shared__ float w[kPackedFloats];
+    for (int i = threadIdx.x * 4; i < kPackedFloats; i += kFieldThreads * 4)
+        *reinterpret_cast<float4*>(&w[i]) = *reinterpret_cast<const float4*>(&packed[i]);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t n = tile * 256 + wave * 32 + (lane & 31);
+        const bool valid = n < B && deltas[(size_t)(n < B ? n : 0) * 2] != 0.0f;
+        if (!__any(valid)) continue;  // wave-uniform: all 32 slots of this wave are dead or out of range
+        const uint32_t nc = n < B ? n : (B - 1);
+        float x[16];
+#pragma unroll
+        for (int s = 0; s < 16; s++) x[s] = valid ? enc[((size_t)s * level_stride + nc) * 2 + h] : 0.0f;
+        f32x16 h0 = zero16(), h1 = zero16();
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            h0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kS0 + s * 64 + lane], x[s], h0, 0, 0, 0);
+            h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kS0 + (16 + s) * 64 + lane], x[s], h1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        h0 = relu16(h0); h1 = relu16(h1);
+        f32x16 g = zero16();
+        g = mma_frag(g, &w[kS1], h0, lane);
+        g = mma_frag(g, &w[kS1 + 16 * 64], h1, lane);
+        const float sigma_logit = g[0];
+        float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+        if (valid) { dx = dirs[(size_t)nc * 3]; dy = dirs[(size_t)nc * 3 + 1]; dz = dirs[(size_t)nc * 3 + 2]; }
+        float sh[16];
+        sh_eval<4>(dx, dy, dz, sh);
+        f32x16 c0 = zero16(), c1 = zero16();
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const float b = h ? sh[8 + s] : sh[s];
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kC0 + s * 64 + lane], b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kC0 + (16 + s) * 64 + lane], b, c1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kC0 + (8 + r) * 64 + lane], g[r], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kC0 + (24 + r) * 64 + lane], g[r], c1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        c0 = relu16(c0); c1 = relu16(c1);
+        f32x16 d0 = zero16(), d1 = zero16();
+        d0 = mma_frag(d0, &w[kC1], c0, lane);
+        d0 = mma_frag(d0, &w[kC1 + 16 * 64], c1, lane);
+        d1 = mma_frag(d1, &w[kC1 + 32 * 64], c0, lane);
+        d1 = mma_frag(d1, &w[kC1 + 48 * 64], c1, lane);
+        d0 = relu16(d0); d1 = relu16(d1);
+        f32x16 o = zero16();
+        o = mma_frag(o, &w[kC2], d0, lane);
+        o = mma_frag(o, &w[kC2 + 16 * 64], d1, lane);
+        if (valid && h == 0) {
+            sigmas[n] = density_scale * expf(sigma_logit);   // nerf/renderer.py:372
+            rgbs[(size_t)n * 3] = 1.0f / (1.0f + expf(-o[0]));
+            rgbs[(size_t)n * 3 + 1] = 1.0f / (1.0f + expf(-o[1]));
+            rgbs[(size_t)n * 3 + 2] = 1.0f / (1.0f + expf(-o[2]));
+        }
+    }
+}
+
+// reference raymarching.cu:1025-1111 + the per-chunk survivor count of the compaction
+__global__ void __launch_bounds__(kRayBlock) k_frame_composite(const FrameCtl* __restrict__ ctl, float T_thresh, int32_t* __restrict__ rays_alive,
+                                                               float* __restrict__ rays_t, const float* __restrict__ sigmas,
+                                                               const float* __restrict__ rgbs, const float* __restrict__ deltas,
+                                                               float* __restrict__ weights_sum, float* __restrict__ depth, float* __restrict__ image,
+                                                               int32_t* __restrict__ scratch) {
+    if (ctl->done) return;
+    const uint32_t n_alive = (uint32_t)ctl->n_alive, n_step = (uint32_t)ctl->n_step;
+    const uint32_t nchunks = (n_alive + kRayBlock - 1) / kRayBlock;
+    __shared__ int wsum[kRayBlock / PNR_WAVE];
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const uint32_t n = chunk * kRayBlock + threadIdx.x;
+        int keep = 0;
+        if (n < n_alive) {
+            const int index = rays_alive[n];
+            const float* s = sigmas + (size_t)n * n_step;
+            const float* c = rgbs + (size_t)n * n_step * 3;
+            const float* dl = deltas + (size_t)n * n_step * 2;
+            float t = rays_t[index], ws = weights_sum[index], d = depth[index];
+            float r = image[index * 3], g = image[index * 3 + 1], b = image[index * 3 + 2];
+            uint32_t step = 0;
+            while (step < n_step) {
+                if (dl[0] == 0) break;
+                const float alpha = 1.0f - __expf(-s[0] * dl[0]);
+                const float T = 1.0f - ws;
+                const float wgt = alpha * T;
+                ws += wgt;
+                t += dl[1];
+                d = fmaf(wgt, t, d);
+                r = fmaf(wgt, c[0], r); g = fmaf(wgt, c[1], g); b = fmaf(wgt, c[2], b);
+                if (T < T_thresh) break;
+                s++; c += 3; dl += 2; step++;
+            }
+            if (step < n_step) rays_alive[n] = -1; else { rays_t[index] = t; keep = 1; }
+            weights_sum[index] = ws; depth[index] = d;
+            image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+        }
+        const unsigned long long m = __ballot(keep);
+        if ((threadIdx.x & (PNR_WAVE - 1)) == 0) wsum[threadIdx.x / PNR_WAVE] = __popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            for (int wv = 0; wv < (int)(kRayBlock / PNR_WAVE); wv++) tot += wsum[wv];
+            scratch[kHdr + chunk] = tot;
+        }
+        __syncthreads();
+    }
+}
+
+// single workgroup: exclusive scan of the chunk counts, then the schedule of the NEXT iteration
+__global__ void __launch_bounds__(1024) k_frame_scan(const FrameCtl* __restrict__ cur, FrameCtl* __restrict__ nxt, int32_t* __restrict__ scratch,
+                                                     uint32_t N, uint32_t max_steps, const int32_t* __restrict__ emitted_partials,
+                                                     uint32_t n_partials) {
+    if (cur->done) { if (threadIdx.x == 0) *nxt = *cur; return; }
+    __shared__ int wsum[1024 / PNR_WAVE];
+    __shared__ int carry_s;
+    __shared__ unsigned long long emitted_s;
+    {   // total of the march kernel's per-workgroup sample counts
+        unsigned long long e = 0;
+        for (uint32_t i = threadIdx.x; i < n_partials; i += 1024) e += (unsigned long long)emitted_partials[i];
+        for (int off = PNR_WAVE / 2; off > 0; off >>= 1) e += __shfl_xor(e, off, PNR_WAVE);
+        if (threadIdx.x == 0) emitted_s = 0;
+        __syncthreads();
+        if ((threadIdx.x & (PNR_WAVE - 1)) == 0 && e) atomicAdd(&emitted_s, e);
+        __syncthreads();
+    }
+    const uint32_t nchunks = ((uint32_t)cur->n_alive + kRayBlock - 1) / kRayBlock;
+    int32_t* sums = scratch + kHdr;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & (PNR_WAVE - 1), wave = threadIdx.x / PNR_WAVE;
+    for (uint32_t base = 0; base < nchunks; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const int v = i < nchunks ? sums[i] : 0;
+        const int incl = wave_inclusive_scan(v);
+        if (lane == PNR_WAVE - 1) wsum[wave] = incl;
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int wv = 0; wv < 1024 / PNR_WAVE; wv++) { const int s = wsum[wv]; if (wv < wave) woff += s; tot += s; }
+        const int carry = carry_s;
+        if (i < nchunks) sums[i] = carry + woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        FrameCtl c = *cur;
+        c.rendered += emitted_s;
+        c.rows += (unsigned long long)c.n_alive * (unsigned long long)c.n_step;
+        c.step += c.n_step;
+        c.iterations += 1;
+        c.n_alive = carry_s;
+        c.n_step = schedule_n_step((int)N, c.n_alive);
+        c.done = (c.n_alive <= 0) || ((uint32_t)c.step >= max_steps);
+        *nxt = c;
+    }
+}
+
+__global__ void __launch_bounds__(kRayBlock) k_frame_alive_write(const FrameCtl* __restrict__ cur, const int32_t* __restrict__ alive_in,
+                                                                 int32_t* __restrict__ alive_out, const int32_t* __restrict__ scratch) {
+    if (cur->done) return;
+    const uint32_t n_alive = (uint32_t)cur->n_alive;
+    const uint32_t nchunks = (n_alive + kRayBlock - 1) / kRayBlock;
+    __shared__ int wsum[kRayBlock / PNR_WAVE];
+    const int lane = threadIdx.x & (PNR_WAVE - 1), wave = threadIdx.x / PNR_WAVE;
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const uint32_t i = chunk * kRayBlock + threadIdx.x;
+        const int id = i < n_alive ? alive_in[i] : -1;
+        const int keep = id >= 0 ? 1 : 0;
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int woff = 0;
+        for (int wv = 0; wv < wave; wv++) woff += wsum[wv];
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (keep) alive_out[scratch[kHdr + chunk] + woff + rank] = id;
+        __syncthreads();
+    }
+}
+
+static inline uint64_t align256(uint64_t v) { return (v + 255) & ~uint64_t(255); }
+
+struct FrameWorkspace {
+    FrameCtl* ctl;
+    int32_t* alive[2];
+    float *rays_t, *xyzs, *dirs, *deltas, *enc, *sigmas, *rgbs;
+    int32_t* scratch;
+    int32_t* partials;
+    uint64_t bytes;
+};
+static FrameWorkspace carve(void* base, uint32_t N) {
+    FrameWorkspace w;
+    uint64_t off = 0;
+    auto take = [&](uint64_t nbytes) { char* p = base ? static_cast<char*>(base) + off : nullptr; off += align256(nbytes); return p; };
+    const uint64_t n = N ? N : 1;
+    w.ctl = reinterpret_cast<FrameCtl*>(take(2 * sizeof(FrameCtl)));
+    w.alive[0] = reinterpret_cast<int32_t*>(take(n * 4));
+    w.alive[1] = reinterpret_cast<int32_t*>(take(n * 4));
+    w.rays_t = reinterpret_cast<float*>(take(n * 4));
+    w.xyzs = reinterpret_cast<float*>(take(n * 12));
+    w.dirs = reinterpret_cast<float*>(take(n * 12));
+    w.deltas = reinterpret_cast<float*>(take(n * 8));
+    w.enc = reinterpret_cast<float*>(take(n * 16 * 2 * 4));
+    w.sigmas = reinterpret_cast<float*>(take(n * 4));
+    w.rgbs = reinterpret_cast<float*>(take(n * 12));
+    w.scratch = reinterpret_cast<int32_t*>(take((kHdr + n / kRayBlock + 2) * 4));
+    w.partials = reinterpret_cast<int32_t*>(take(2048 * 4));
+    w.bytes = off;
+    return w;
+}
+
+}  // namespace pnr
+
+using namespace pnr;
+
+extern "C" {
+
+uint64_t pnr_nerf_frame_workspace_bytes(uint32_t N) { return carve(nullptr, N).bytes; }
+
+int pnr_nerf_render_frame(const pnr_nerf_frame_args* a, pnr_stream_t stream) {
+    if (!a) return PNR_ERR_INVALID;
+    if (a->N == 0) return PNR_OK;
+    if (!a->rays_o || !a->rays_d || !a->nears || !a->fars || !a->bitfield || !a->embeddings || !a->offsets || !a->packed_weights || !a->weights_sum ||
+        !a->depth || !a->image || !a->workspace)
+        return PNR_ERR_INVALID;
+    if (a->C == 0 || a->C > 16 || a->H == 0 || a->max_steps == 0 || a->num_levels != 16) return PNR_ERR_UNSUPPORTED;
+    if (a->workspace_bytes < pnr_nerf_frame_workspace_bytes(a->N)) return PNR_ERR_INVALID;
+    hipStream_t s = as_stream(stream);
+    const uint32_t N = a->N;
+    FrameWorkspace w = carve(a->workspace, N);
+
+    static FrameCtl* host_ctl = nullptr;  // pinned read-back slot (one in-flight frame per process)
+    if (!host_ctl && hipHostMalloc(reinterpret_cast<void**>(&host_ctl), sizeof(FrameCtl), hipHostMallocDefault) != hipSuccess) return PNR_ERR_LAUNCH;
+
+    const bool use_mip = a->mip && (a->H % 4) == 0 && pnr_occupancy_mip_bytes(a->C, a->H) <= 64 * 1024;
+    const bool pow2 = is_pow2f(a->bound) && (a->H & (a->H - 1)) == 0;
+    const MarchParams mp = make_march_params(a->bound, a->dt_gamma, a->max_steps, a->C, a->H, use_mip);
+    const uint32_t march_lds = mp.mip_words ? (2 * mp.mip_words + 8) * 4 : 0;
+    const LevelParams lp = make_level_params(16, a->S, a->base_resolution);
+    const uint32_t* mip = static_cast<const uint32_t*>(a->mip);
+
+    hipLaunchKernelGGL(k_frame_init, dim3(cdiv(N, kRayBlock)), dim3(kRayBlock), 0, s, N, a->nears, w.alive[0], w.rays_t, a->weights_sum, a->depth,
+                       a->image, w.ctl);
+    // optional live timing of the roofline kernel: HIP events on the launch stream around every k_frame_grid launch
+    static std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    auto next_event = [&]() -> hipEvent_t {
+        if (ev_used == ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; ev.push_back(e); }
+        return ev[ev_used++];
+    };
+    const bool timing = a->kernel_ms != nullptr;
+    uint32_t alive_ub = N;   // host-side upper bound of n_alive (it only shrinks)
+    uint32_t chunk = 4;      // iterations enqueued between two looks at the control block
+    int iter = 0;
+    for (;;) {
+        for (uint32_t k = 0; k < chunk; k++, iter++) {
+            FrameCtl* cur = w.ctl + (iter & 1);
+            FrameCtl* nxt = w.ctl + ((iter + 1) & 1);
+            int32_t* alive_in = w.alive[iter & 1];
+            int32_t* alive_out = w.alive[(iter + 1) & 1];
+            const uint32_t ray_blocks = cdiv(alive_ub, kRayBlock);
+            const uint32_t rows_ub = (uint64_t)alive_ub * 8 < N ? alive_ub * 8 : N;
+            const dim3 gm(ray_blocks < 2048u ? ray_blocks : 2048u), bm(kRayBlock);
+            if (use_mip && pow2)
+                hipLaunchKernelGGL((k_frame_march<true, true>), gm, bm, march_lds, s, cur, alive_in, w.rays_t, a->rays_o, a->rays_d, mp, a->bitfield, a->fars, w.xyzs, w.dirs, w.deltas, mip, w.partials);
+            else if (use_mip)
+                hipLaunchKernelGGL((k_frame_march<true, false>), gm, bm, march_lds, s, cur, alive_in, w.rays_t, a->rays_o, a->rays_d, mp, a->bitfield, a->fars, w.xyzs, w.dirs, w.deltas, mip, w.partials);
+            else if (pow2)
+                hipLaunchKernelGGL((k_frame_march<false, true>), gm, bm, march_lds, s, cur, alive_in, w.rays_t, a->rays_o, a->rays_d, mp, a->bitfield, a->fars, w.xyzs, w.dirs, w.deltas, mip, w.partials);
+            else
+                hipLaunchKernelGGL((k_frame_march<false, false>), gm, bm, march_lds, s, cur, alive_in, w.rays_t, a->rays_o, a->rays_d, mp, a->bitfield, a->fars, w.xyzs, w.dirs, w.deltas, mip, w.partials);
+            const uint32_t gx = cdiv(rows_ub, 256);
+            hipEvent_t e0 = timing ? next_event() : nullptr, e1 = timing ? next_event() : nullptr;
+            if (e0) hipEventRecord(e0, s);
+            hipLaunchKernelGGL(k_frame_grid, dim3(gx < 1024u ? gx : 1024u, 16), dim3(256), 0, s, cur, w.xyzs, w.deltas, a->embeddings, a->offsets, lp, w.enc, N,
+                               a->bound, 2.0f * a->bound, a->gridtype);
+            if (e1) hipEventRecord(e1, s);
+            hipLaunchKernelGGL(k_frame_field, dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas, a->packed_weights,
+                               a->density_scale, w.sigmas, w.rgbs);
+            hipLaunchKernelGGL(k_frame_composite, gm, bm, 0, s, cur, a->T_thresh, alive_in, w.rays_t, w.sigmas, w.rgbs, w.deltas, a->weights_sum, a->depth,
+                               a->image, w.scratch);
+            hipLaunchKernelGGL(k_frame_scan, dim3(1), dim3(1024), 0, s, cur, nxt, w.scratch, N, a->max_steps, w.partials, gm.x);
+            hipLaunchKernelGGL(k_frame_alive_write, gm, bm, 0, s, cur, alive_in, alive_out, w.scratch);
+        }
+        if (hipMemcpyAsync(host_ctl, w.ctl + (iter & 1), sizeof(FrameCtl), hipMemcpyDeviceToHost, s) != hipSuccess) return PNR_ERR_LAUNCH;
+        if (hipStreamSynchronize(s) != hipSuccess) return PNR_ERR_LAUNCH;
+        if (host_ctl->done) break;
+        alive_ub = (uint32_t)host_ctl->n_alive;
+        if (chunk < 16) chunk *= 2;
+    }
+    if (timing) {  // only the iterations that did work (the tail of the last chunk are no-op launches)
+        float total = 0.0f;
+        uint32_t counted = 0;
+        for (size_t i = 0; i + 1 < ev_used && counted < (uint32_t)host_ctl->iterations; i += 2, counted++) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) total += ms;
+        }
+        a->kernel_ms[0] = total;
+        a->kernel_ms[1] = (float)counted;
+    }
+    if (a->stats) {
+        a->stats[0] = (uint64_t)host_ctl->iterations;
+        a->stats[1] = host_ctl->rendered;
+        a->stats[2] = host_ctl->rows;
+        a->stats[3] = (uint64_t)iter;  // iterations enqueued (>= executed)
+    }
+    return check_launch();
+}
+
+}  // extern "C"

@@ -9,72 +9,9 @@
 // in [0,1], outputs [L,B,C] (level-major: a block column works on ONE level so that level's
 // <= 4 MiB table stays resident in the XCD L2s while the samples stream through).
 #include "pnr_common.hpp"
-#include <math.h>
+#include "grid_core.hpp"
 
 namespace pnr {
-
-constexpr uint32_t kMaxLevels = 32;
-struct LevelParams {
-    float scale[kMaxLevels];
-    uint32_t resolution[kMaxLevels];
-};
-
-__device__ __forceinline__ float to_f32(float v) { return v; }
-__device__ __forceinline__ float to_f32(__half v) { return __half2float(v); }
-
-// reference gridencoder.cu:35-72 (fast_hash + get_grid_index with ch = 0)
-template <uint32_t D, uint32_t C>
-__device__ __forceinline__ uint32_t grid_index(uint32_t gridtype, bool align_corners, uint32_t hashmap_size, uint32_t resolution,
-                                               const uint32_t pg[D]) {
-    constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
-    uint32_t stride = 1, index = 0;
-#pragma unroll
-    for (uint32_t d = 0; d < D; d++) {
-        if (stride <= hashmap_size) {
-            index += pg[d] * stride;
-            stride *= align_corners ? resolution : (resolution + 1);
-        }
-    }
-    if (gridtype == 0 && stride > hashmap_size) {
-        index = 0;
-#pragma unroll
-        for (uint32_t d = 0; d < D; d++) index ^= pg[d] * primes[d];
-    }
-    return (index % hashmap_size) * C;
-}
-
-// accumulate one corner: fp32 table -> fmaf chain; fp16 table -> half accumulator with the
-// reference's two roundings (gridencoder.cu:142,165 with scalar_t = at::Half)
-template <uint32_t C>
-__device__ __forceinline__ void corner_accumulate(float acc[C], float w, const float* __restrict__ g) {
-    if constexpr (C == 2) {
-        const float2 v = *reinterpret_cast<const float2*>(g);
-        acc[0] = fmaf(w, v.x, acc[0]); acc[1] = fmaf(w, v.y, acc[1]);
-    } else if constexpr (C == 4) {
-        const float4 v = *reinterpret_cast<const float4*>(g);
-        acc[0] = fmaf(w, v.x, acc[0]); acc[1] = fmaf(w, v.y, acc[1]); acc[2] = fmaf(w, v.z, acc[2]); acc[3] = fmaf(w, v.w, acc[3]);
-    } else {
-#pragma unroll
-        for (uint32_t ch = 0; ch < C; ch++) acc[ch] = fmaf(w, g[ch], acc[ch]);
-    }
-}
-template <uint32_t C>
-__device__ __forceinline__ void corner_accumulate(__half acc[C], float w, const __half* __restrict__ g) {
-    __half v[C];
-    if constexpr (C == 2) {
-        *reinterpret_cast<__half2*>(v) = *reinterpret_cast<const __half2*>(g);
-    } else if constexpr (C == 4) {
-        *reinterpret_cast<uint2*>(v) = *reinterpret_cast<const uint2*>(g);
-    } else if constexpr (C == 8) {
-        *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(g);
-    } else {
-#pragma unroll
-        for (uint32_t ch = 0; ch < C; ch++) v[ch] = g[ch];
-    }
-#pragma unroll
-    for (uint32_t ch = 0; ch < C; ch++)
-        acc[ch] = __float2half(__half2float(acc[ch]) + __half2float(__float2half(w * __half2float(v[ch]))));
-}
 
 template <typename T> __device__ __forceinline__ T zero_of();
 template <> __device__ __forceinline__ float zero_of<float>() { return 0.0f; }
@@ -274,16 +211,6 @@ __global__ void __launch_bounds__(256) k_grid_input_bwd(const T* __restrict__ gr
             else r = __half2float(__float2half(r + __half2float(__float2half(a * v))));
         }
     if constexpr (sizeof(T) == 4) grad_inputs[t] = r; else grad_inputs[t] = __float2half(r);
-}
-
-static LevelParams make_level_params(uint32_t L, float S, uint32_t H) {
-    LevelParams lp;
-    for (uint32_t l = 0; l < kMaxLevels; l++) { lp.scale[l] = 0; lp.resolution[l] = 0; }
-    for (uint32_t l = 0; l < L; l++) {
-        lp.scale[l] = exp2f((float)l * S) * (float)H - 1.0f;               // gridencoder.cu:125
-        lp.resolution[l] = (uint32_t)ceil((double)lp.scale[l]) + 1;        // gridencoder.cu:126
-    }
-    return lp;
 }
 
 template <typename T, uint32_t D>

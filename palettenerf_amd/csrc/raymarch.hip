@@ -5,165 +5,11 @@
 // wave64 prefix sum instead of global atomics, the alive-ray list is compacted on the device with
 // the same scan, and all launches take an explicit stream.
 #include "pnr_common.hpp"
-#include <float.h>
-#include <string.h>
+#include "march_core.hpp"
 
 namespace pnr {
 
 constexpr uint32_t kBlock = 256;  // 4 waves; one ray / element per thread
-
-// ------------------------------------------------------------------------------------------
-// per-ray constants + the march state machine (reference raymarching.cu:336-349, 362-403)
-//
-// Two latency levers that leave every result bit unchanged:
-//  * occupancy mip in LDS.  The bitfield is in Morton order, so a 4x4x4 brick of cells is 64
-//    CONSECUTIVE bits = one aligned 8-byte word.  pnr_build_occupancy_mip() reduces every brick to
-//    two bits (any cell set / all cells set; 2 x 8 KiB for C=2, H=128).  A march workgroup keeps both
-//    masks in LDS: a probe that lands in an all-empty or all-full brick is answered from LDS
-//    (~64 cycles) instead of a dependent global byte load (~500+ cycles under load) -- that is nearly
-//    every probe of the long empty-space walks that set the duration of a march launch.  The per-cell
-//    control flow (which t is probed next) is untouched.
-//  * occupied bounding box.  The mip builder also reduces the occupied bricks of every cascade to one
-//    world-space box B (expanded by two cells of the respective cascade).  No cell outside B is
-//    occupied, B is convex, so once a ray has left B no later probe can emit a sample: the march
-//    stops at min(far, exit(B)) instead of walking cell by cell to the scene AABB.  Those walks (rays
-//    that just left the object, rays that miss it) are what set the duration of a march launch;
-//    cutting them changes no output (a ray that would have found nothing still finds nothing).
-//  * when H and bound are powers of two (every shipped config) the reference's double-precision
-//    cell coordinate, its frexpf()/scalbnf() and the 1/mip_bound division are exact scalings by
-//    powers of two; the POW2 variants do them with one fp32 multiply / exponent-field arithmetic.
-// ------------------------------------------------------------------------------------------
-struct RayCtx {
-    float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
-    float bound, dt_gamma, dt_min, dt_max, rH, fC, fH, half_H;
-    uint32_t H, H3;
-    int maxlevel;
-    const uint8_t* __restrict__ grid;
-    const uint32_t* mip_any;  // LDS (or nullptr)
-    const uint32_t* mip_all;
-    const float* box;         // LDS: occupied box (min xyz, max xyz), or nullptr
-};
-
-struct MarchParams {  // ray-independent constants, computed once on the host
-    float bound, dt_gamma, dt_min, dt_max;
-    uint32_t C, H, max_steps;
-    uint32_t mip_words;  // uint32 words per mask; 0 = no mip
-};
-
-static MarchParams make_march_params(float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, bool with_mip) {
-    MarchParams p;
-    const float two_sqrt3 = 2.0f * 1.7320508075688772f;          // raymarching.cu:22
-    p.bound = bound; p.dt_gamma = dt_gamma;
-    p.dt_min = two_sqrt3 / (float)max_steps;                        // :348
-    p.dt_max = two_sqrt3 * (float)(1 << (C - 1)) / (float)H;        // :349
-    p.C = C; p.H = H; p.max_steps = max_steps;
-    p.mip_words = with_mip ? (uint32_t)(((uint64_t)C * H * H * H / 64 + 31) / 32) : 0;
-    return p;
-}
-static inline bool is_pow2f(float v) {
-    uint32_t u; memcpy(&u, &v, 4);
-    return v > 0.0f && (u & 0x7fffffu) == 0 && ((u >> 23) & 0xff) != 0 && ((u >> 23) & 0xff) != 0xff;
-}
-
-__device__ __forceinline__ void ctx_init(RayCtx& c, const float* __restrict__ o, const float* __restrict__ d, const MarchParams& p,
-                                         const uint8_t* __restrict__ grid, const uint32_t* mip_lds) {
-    c.ox = o[0]; c.oy = o[1]; c.oz = o[2];
-    c.dx = d[0]; c.dy = d[1]; c.dz = d[2];
-    c.rdx = 1.0f / c.dx; c.rdy = 1.0f / c.dy; c.rdz = 1.0f / c.dz;
-    c.bound = p.bound; c.dt_gamma = p.dt_gamma; c.dt_min = p.dt_min; c.dt_max = p.dt_max;
-    c.rH = 1.0f / (float)p.H; c.fC = (float)p.C; c.fH = (float)p.H; c.half_H = 0.5f * (float)p.H;
-    c.H = p.H; c.H3 = p.H * p.H * p.H; c.maxlevel = (int)p.C - 1; c.grid = grid;
-    c.mip_any = mip_lds;
-    c.mip_all = mip_lds ? mip_lds + p.mip_words : nullptr;
-    c.box = mip_lds ? reinterpret_cast<const float*>(mip_lds + 2 * p.mip_words) : nullptr;
-}
-
-// Parameter beyond which the ray is outside the occupied box for good (never larger than `far`).
-// Any NaN in the slab arithmetic (0 * inf) disables the clip for that ray.
-__device__ __forceinline__ float clip_far_to_box(const RayCtx& c, float far) {
-    if (!c.box) return far;
-    const float ax = (c.box[0] - c.ox) * c.rdx, bx = (c.box[3] - c.ox) * c.rdx;
-    const float ay = (c.box[1] - c.oy) * c.rdy, by = (c.box[4] - c.oy) * c.rdy;
-    const float az = (c.box[2] - c.oz) * c.rdz, bz = (c.box[5] - c.oz) * c.rdz;
-    if (ax != ax || bx != bx || ay != ay || by != by || az != az || bz != bz) return far;
-    const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-    const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    if (t_in > t_out) return -FLT_MAX;            // the ray never touches the occupied box
-    return fminf(far, fmaf(fabsf(t_out), 1e-5f, t_out));  // B already carries a two-cell margin; this only absorbs slab-test rounding
-}
-
-// frexpf exponent of a finite non-negative float, clamped to [0, maxlevel] (== reference mip_from_*)
-__device__ __forceinline__ int level_of(float mx, int maxlevel) {
-    const int e = (int)((__float_as_uint(mx) >> 23) & 0xffu) - 126;  // zero / denormals give e <= -126 -> clamped to 0, as frexpf does
-    return min(maxlevel, max(0, e));
-}
-
-template <bool MIP>
-__device__ __forceinline__ bool cell_occupied(const RayCtx& c, uint32_t index) {
-    if constexpr (MIP) {
-        const uint32_t brick = index >> 6, word = brick >> 5, bit = 1u << (brick & 31u);
-        if (!(c.mip_any[word] & bit)) return false;
-        if (c.mip_all[word] & bit) return true;
-    }
-    return c.grid[index >> 3] & (1u << (index & 7u));
-}
-
-// Probe the cell containing the point at parameter t.  Occupied: returns true and the sample
-// (x,y,z,dt), t untouched.  Empty: advances t past the cell (do..while of the reference) and
-// returns false.
-template <bool MIP, bool POW2>
-__device__ __forceinline__ bool march_probe(const RayCtx& c, float& t, float& x, float& y, float& z, float& dt) {
-    const float t0 = t;
-    x = clampf(fmaf(t0, c.dx, c.ox), -c.bound, c.bound);
-    y = clampf(fmaf(t0, c.dy, c.oy), -c.bound, c.bound);
-    z = clampf(fmaf(t0, c.dz, c.oz), -c.bound, c.bound);
-    dt = clampf(t0 * c.dt_gamma, c.dt_min, c.dt_max);
-    int level, nx, ny, nz;
-    float mip_bound;
-    const float hi = (float)(c.H - 1);
-    if constexpr (POW2) {
-        const int lp = level_of(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))), c.maxlevel);
-        const int ld = level_of(dt * c.half_H, c.maxlevel);
-        level = lp > ld ? lp : ld;
-        mip_bound = fminf(__uint_as_float((uint32_t)(127 + level) << 23), c.bound);
-        const float mip_rbound = __uint_as_float((254u << 23) - (__float_as_uint(mip_bound) & 0x7f800000u));  // exact 1/2^k
-        nx = (int)clampf(fmaf(x, mip_rbound, 1.0f) * c.half_H, 0.0f, hi);
-        ny = (int)clampf(fmaf(y, mip_rbound, 1.0f) * c.half_H, 0.0f, hi);
-        nz = (int)clampf(fmaf(z, mip_rbound, 1.0f) * c.half_H, 0.0f, hi);
-    } else {
-        const int lp = mip_from_pos(x, y, z, c.fC), ld = mip_from_dt(dt, c.fH, c.fC);
-        level = lp > ld ? lp : ld;
-        mip_bound = fminf(scalbnf(1.0f, level), c.bound);
-        const float mip_rbound = 1.0f / mip_bound;
-        // double intermediate exactly as the reference's `0.5 * (x * mip_rbound + 1) * H`
-        nx = (int)clampf((float)(0.5 * (double)fmaf(x, mip_rbound, 1.0f) * (double)c.H), 0.0f, hi);
-        ny = (int)clampf((float)(0.5 * (double)fmaf(y, mip_rbound, 1.0f) * (double)c.H), 0.0f, hi);
-        nz = (int)clampf((float)(0.5 * (double)fmaf(z, mip_rbound, 1.0f) * (double)c.H), 0.0f, hi);
-    }
-    const uint32_t index = (uint32_t)level * c.H3 + morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
-    if (cell_occupied<MIP>(c, index)) return true;
-    const float tx = fmaf(fmaf(fmaf(0.5f, signf(c.dx), (float)nx + 0.5f) * c.rH, 2.0f, -1.0f), mip_bound, -x) * c.rdx;
-    const float ty = fmaf(fmaf(fmaf(0.5f, signf(c.dy), (float)ny + 0.5f) * c.rH, 2.0f, -1.0f), mip_bound, -y) * c.rdy;
-    const float tz = fmaf(fmaf(fmaf(0.5f, signf(c.dz), (float)nz + 0.5f) * c.rH, 2.0f, -1.0f), mip_bound, -z) * c.rdz;
-    const float tt = t0 + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
-    float tc = t0;
-    do { tc += clampf(tc * c.dt_gamma, c.dt_min, c.dt_max); } while (tc < tt);
-    t = tc;
-    return false;
-}
-
-// stage both mip masks into LDS (no-op when the launch has no mip)
-__device__ __forceinline__ const uint32_t* stage_mip(const uint32_t* __restrict__ mip, uint32_t words_per_mask) {
-    extern __shared__ uint32_t mip_lds[];
-    if (words_per_mask == 0) return nullptr;
-    const uint32_t n = 2 * words_per_mask + 8;  // 'any' mask, 'all' mask, occupied box (6 floats + 2 pad)
-    for (uint32_t i = threadIdx.x * 4; i < n; i += blockDim.x * 4) {
-        if (i + 3 < n) *reinterpret_cast<uint4*>(&mip_lds[i]) = *reinterpret_cast<const uint4*>(&mip[i]);
-        else for (uint32_t j = i; j < n; j++) mip_lds[j] = mip[j];
-    }
-    __syncthreads();
-    return mip_lds;
-}
 
 // one thread per 4x4x4 brick: 64 Morton-consecutive cells = one aligned uint64 of the bitfield
 __global__ void __launch_bounds__(256) k_build_mip(const unsigned long long* __restrict__ grid64, uint32_t nbricks, uint32_t words_per_mask,

@@ -30,6 +30,7 @@ class NeRFFieldFused:
         self.model = model
         self.packed = None
         self.versions = None
+        self.time_grid_kernel = False  # bench.py: HIP-event timing of the grid-encode launches inside the native frame loop
         m = model
         ok = (m.encoder.num_levels == 16 and m.encoder.level_dim == 2 and m.encoder.input_dim == 3 and m.hidden_dim == 64 and m.geo_feat_dim == 15
               and m.num_layers == 2 and m.num_layers_color == 3 and m.hidden_dim_color == 64 and m.encoder_dir.degree == 4)
@@ -51,6 +52,49 @@ class NeRFFieldFused:
             call("pnr_nerf_field_pack", *[ptr(w) for w in ws], ptr(self.packed))
             self.versions = versions
         return self.packed
+
+    @torch.no_grad()
+    def render_frame(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh):
+        """One inference frame through the device-driven loop (pnr_nerf_render_frame).  Returns
+        (weights_sum [N], depth [N], image [N,3], stats dict); raw accumulations, bg mix is the caller's."""
+        from . import raymarching
+        m = self.model
+        N = rays_o.shape[0]
+        dev = rays_o.device
+        lib = _lib.load()
+        ws = torch.empty(N, dtype=torch.float32, device=dev)
+        depth = torch.empty(N, dtype=torch.float32, device=dev)
+        image = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        nbytes = int(lib.pnr_nerf_frame_workspace_bytes(N))
+        if getattr(self, "_ws", None) is None or self._ws.numel() < nbytes or self._ws.device != dev:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        mip = raymarching.occupancy_mip(m.density_bitfield, m.cascade, m.grid_size, m.bound)
+        enc = m.encoder
+        emb = require(enc.embeddings.detach(), torch.float32, "embeddings")
+        stats = (ctypes.c_uint64 * 4)()
+        a = _lib.NerfFrameArgs()
+        a.N = N
+        a.rays_o, a.rays_d = rays_o.data_ptr(), rays_d.data_ptr()
+        a.nears, a.fars = nears.data_ptr(), fars.data_ptr()
+        a.bitfield = m.density_bitfield.data_ptr()
+        a.mip = mip.data_ptr() if mip is not None else None
+        a.bound, a.C, a.H = float(m.bound), int(m.cascade), int(m.grid_size)
+        a.dt_gamma, a.max_steps, a.T_thresh = float(dt_gamma), int(max_steps), float(T_thresh)
+        a.embeddings, a.offsets = emb.data_ptr(), enc.offsets.data_ptr()
+        a.num_levels, a.S, a.base_resolution, a.gridtype = enc.num_levels, float(np.log2(enc.per_level_scale)), enc.base_resolution, enc.gridtype_id
+        a.packed_weights = self._pack().data_ptr()
+        a.density_scale = float(m.density_scale)
+        a.weights_sum, a.depth, a.image = ws.data_ptr(), depth.data_ptr(), image.data_ptr()
+        a.workspace, a.workspace_bytes = self._ws.data_ptr(), nbytes
+        a.stats = ctypes.cast(stats, ctypes.c_void_p)
+        kms = (ctypes.c_float * 2)()
+        a.kernel_ms = ctypes.cast(kms, ctypes.c_void_p) if self.time_grid_kernel else None
+        for t, name in ((rays_o, "rays_o"), (rays_d, "rays_d"), (nears, "nears"), (fars, "fars")):
+            require(t, torch.float32, name)
+        rc = lib.pnr_nerf_render_frame(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "pnr_nerf_render_frame")
+        return ws, depth, image, {"iterations": int(stats[0]), "rendered": int(stats[1]), "rows": int(stats[2]), "enqueued": int(stats[3]),
+                                  "grid_ms": float(kms[0]), "grid_launches": int(kms[1])}
 
     @torch.no_grad()
     def __call__(self, x, d):

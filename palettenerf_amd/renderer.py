@@ -178,6 +178,23 @@ class NeRFRenderer(_RendererBase):
             depth = depth.view(*prefix)
             rgb_norm_map = rgb_norm_map.mean(dim=-1).view(*prefix)
             results["weights_sum"] = weights_sum
+        elif self.march_mode == "native":
+            # device-driven loop: same schedule and arithmetic, no per-iteration host sync (pnr_nerf_render_frame)
+            if getattr(self, "_fused", None) is None:
+                from .fused import NeRFFieldFused
+                self._fused = NeRFFieldFused(self)
+            if perturb or torch.is_autocast_enabled():
+                raise RuntimeError("march_mode='native' covers fp32 inference without perturbation")
+            weights_sum, depth_acc, image_acc, stats = self._fused.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh)
+            image = image_acc + (1 - weights_sum).unsqueeze(-1) * bg_color
+            depth = torch.clamp(depth_acc - nears, min=0) / (fars - nears)
+            image = image.view(*prefix, 3)
+            depth = depth.view(*prefix)
+            rgb_norm_map = torch.zeros_like(image[..., 0])
+            results["n_samples"] = stats["rows"]
+            results["rendered"] = torch.tensor([stats["rendered"]], dtype=torch.int64, device=rays_o.device)
+            results["iterations"] = stats["iterations"]
+            results["grid_ms"], results["grid_launches"] = stats["grid_ms"], stats["grid_launches"]
         else:
             def shade(st, n_alive, n_step, xyzs, dirs, deltas):
                 sigmas, rgbs = self(xyzs, dirs)

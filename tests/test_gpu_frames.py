@@ -40,7 +40,7 @@ def close(got, want, tol=COLOUR_TOL, what=""):
 
 
 @pytest.mark.parametrize("case", ["a", "b"])
-@pytest.mark.parametrize("mode", ["compat", "device", "fused"])
+@pytest.mark.parametrize("mode", ["compat", "device", "fused", "native"])
 def test_nerf_inference_frame(cuda, golden_dir, case, mode):
     g = load(golden_dir, f"frame_nerf_{case}")
     m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=float(g["density_scale"]), min_near=0.2)
@@ -48,7 +48,8 @@ def test_nerf_inference_frame(cuda, golden_dir, case, mode):
     m = m.to(cuda).eval()
     put_scene(m, cuda)
     m.march_mode = "device" if mode == "fused" else mode
-    m.fused_field = mode == "fused"
+    m.fused_field = mode in ("fused", "native")
+    m.count_rendered = True
     ro, rd = frame_rays(g, cuda)
     with torch.no_grad():
         r = m.render(ro, rd, staged=True, dt_gamma=float(g["dt_gamma"]), perturb=False, max_steps=1024, T_thresh=1e-4)
@@ -56,6 +57,13 @@ def test_nerf_inference_frame(cuda, golden_dir, case, mode):
     close(r["weights_sum"], g["weights_sum"], what="weights_sum")
     close(r["depth"], g["depth"], tol=2e-4, what="depth")
     assert scene.psnr(r["image"].cpu(), torch.from_numpy(g["image"])) > 80.0
+    _RENDERED.setdefault(case, {})[mode] = (int(r["rendered"].item()), int(r["n_samples"]))
+    if len(_RENDERED[case]) == 4:  # every execution mode marched exactly the same samples (schedule and compaction identical)
+        counts = {k: v[0] for k, v in _RENDERED[case].items()}
+        assert len(set(counts.values())) == 1, counts
+
+
+_RENDERED = {}
 
 
 @pytest.mark.parametrize("case", ["a", "b"])
