@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--density-scale", type=float, default=100.0, help="S0-opaque (trained-scene-like early termination); ~0 = translucent")
     ap.add_argument("--fp16", action="store_true", help="the reference's -O mode: autocast, half hash tables")
     ap.add_argument("--mode", choices=["compat", "device", "fused", "native"], default=None)
+    ap.add_argument("--field-precision", choices=["f16x3", "fp32"], default="f16x3",
+                    help="matrix path of the fused field: split-fp16 (3 MFMAs per product, ~2^-22 relative) or exact fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-crop", type=int, default=320, help="side of the centre crop timed on the CPU oracle")
     return ap.parse_args()
@@ -111,8 +113,11 @@ def main():
     m = build_model(args, device)
     mode = args.mode or ("native" if args.model == "nerf" and not args.fp16 else "fused")
     m.march_mode = "device" if mode == "fused" else mode
-    if mode == "fused" and args.model == "nerf" and not args.fp16:
+    if mode in ("fused", "native") and args.model == "nerf" and not args.fp16:
+        from palettenerf_amd.fused import NeRFFieldFused
         m.fused_field = True
+        m._fused = NeRFFieldFused(m)
+        m._fused.precision = 0 if args.field_precision == "fp32" else 1
     H = W = args.res
     pose = torch.from_numpy(scene.lookat_pose())[None]
     ro, rd = scene.get_rays(pose, scene.intrinsics_from_fov(H, W), H, W)
@@ -177,7 +182,7 @@ def main():
             "vs_baseline": None, "dtype": "f16" if args.fp16 else "f32", "data": "synthetic",
             "config": {"workload": f"configs[1]: NeRF-synthetic lego geometry (scene S0), -m {args.model} inference, {H}x{W}, 1 frame/step",
                        "rays_per_frame": H * W, "rendered_samples_per_frame": total_rendered // args.steps,
-                       "evaluated_rows_per_frame_rank0": rows // args.steps, "density_scale": args.density_scale, "march_mode": m.march_mode, "fused_field": bool(getattr(m, "fused_field", False)),
+                       "evaluated_rows_per_frame_rank0": rows // args.steps, "density_scale": args.density_scale, "march_mode": m.march_mode, "fused_field": bool(getattr(m, "fused_field", False)), "field_precision": args.field_precision,
                        "parallelism": f"ray-tiles x{world} + all_gather" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": n_launches,

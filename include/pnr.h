@@ -33,6 +33,11 @@ extern "C" {
 #define PNR_DTYPE_F32 0
 #define PNR_DTYPE_F16 1
 
+/* arithmetic of the fused field kernels: exact-fp32 matrix path (v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain)
+ * or split-fp16 (3 x v_mfma_f32_32x32x16_f16 per product, ~2^-22 relative, fp32 accumulate; ~5x fewer MFMA cycles) */
+#define PNR_FIELD_FP32 0
+#define PNR_FIELD_F16X3 1
+
 #define PNR_CHANNEL_MAXIMUM 128   /* raymarching/src/raymarching.cu:13 */
 
 typedef void* pnr_stream_t; /* hipStream_t */
@@ -159,9 +164,9 @@ int pnr_grid_encode_backward(const void* grad, const float* inputs, const void* 
  *                        (= exp(h0), NOT multiplied by density_scale), rgbs [B,3]. */
 uint64_t pnr_nerf_field_packed_bytes(void);
 int pnr_nerf_field_pack(const float* w_sigma0, const float* w_sigma1, const float* w_color0, const float* w_color1,
-                        const float* w_color2, float* packed, pnr_stream_t stream);
+                        const float* w_color2, float* packed, int precision, pnr_stream_t stream);
 int pnr_nerf_field_forward(const float* enc, const float* dirs, const float* packed, uint32_t B, float* sigmas,
-                           float* rgbs, pnr_stream_t stream);
+                           float* rgbs, int precision, pnr_stream_t stream);
 
 /* Device-driven inference frame of the NeRF path: the loop of nerf/renderer.py:344-380 (same n_step schedule,
  * same per-ray arithmetic, order-preserving compaction) with n_alive / n_step / step kept in a device control
@@ -187,7 +192,8 @@ typedef struct pnr_nerf_frame_args {
     float S;                       /* log2(per_level_scale) */
     uint32_t base_resolution;
     uint32_t gridtype;             /* 0 hash, 1 tiled */
-    const float* packed_weights;   /* pnr_nerf_field_pack output */
+    const float* packed_weights;   /* pnr_nerf_field_pack output (packed with the same precision) */
+    int field_precision;           /* PNR_FIELD_FP32 or PNR_FIELD_F16X3 */
     float density_scale;
     float* weights_sum;            /* [N]   out */
     float* depth;                  /* [N]   out */

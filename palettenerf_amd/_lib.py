@@ -39,8 +39,8 @@ SIGNATURES = {
     "pnr_grid_encode_forward": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _u32, _ptr, _u32, _int, _int, _ptr],
     "pnr_grid_encode_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _u32, _ptr, _ptr, _u32, _int, _int, _ptr],
     "pnr_nerf_field_packed_bytes": [],
-    "pnr_nerf_field_pack": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
-    "pnr_nerf_field_forward": [_ptr, _ptr, _ptr, _u32, _ptr, _ptr, _ptr],
+    "pnr_nerf_field_pack": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _int, _ptr],
+    "pnr_nerf_field_forward": [_ptr, _ptr, _ptr, _u32, _ptr, _ptr, _int, _ptr],
     "pnr_nerf_frame_workspace_bytes": [_u32],
     "pnr_nerf_render_frame": [_ptr, _ptr],
     "pnr_sh_encode_forward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr],
@@ -54,7 +54,7 @@ class NerfFrameArgs(ctypes.Structure):
     """Mirror of `pnr_nerf_frame_args` (include/pnr.h)."""
     _fields_ = [("N", _u32), ("rays_o", _ptr), ("rays_d", _ptr), ("nears", _ptr), ("fars", _ptr), ("bitfield", _ptr), ("mip", _ptr), ("bound", _f32),
                 ("C", _u32), ("H", _u32), ("dt_gamma", _f32), ("max_steps", _u32), ("T_thresh", _f32), ("embeddings", _ptr), ("offsets", _ptr),
-                ("num_levels", _u32), ("S", _f32), ("base_resolution", _u32), ("gridtype", _u32), ("packed_weights", _ptr), ("density_scale", _f32),
+                ("num_levels", _u32), ("S", _f32), ("base_resolution", _u32), ("gridtype", _u32), ("packed_weights", _ptr), ("field_precision", _int), ("density_scale", _f32),
                 ("weights_sum", _ptr), ("depth", _ptr), ("image", _ptr), ("workspace", _ptr), ("workspace_bytes", _u64), ("stats", _ptr), ("kernel_ms", _ptr)]
 
 

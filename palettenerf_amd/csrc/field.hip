@@ -57,8 +57,29 @@ __global__ void __launch_bounds__(256) k_nerf_field_pack(const float* __restrict
     packed[e] = v;
 }
 
+// pack kernel of the split-fp16 blob: one thread per (block, lane, element)
+__global__ void __launch_bounds__(256) k_nerf_field_pack_f16x3(const float* __restrict__ Ws0, const float* __restrict__ Ws1,
+                                                               const float* __restrict__ Wc0, const float* __restrict__ Wc1,
+                                                               const float* __restrict__ Wc2, unsigned char* __restrict__ packed) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= kF16Blocks * 64 * 8) return;
+    const int q = e / 512, lane = (e / 8) & 63, j = e & 7, i = lane & 31, h = lane >> 5;
+    float v = 0.0f;
+    if (q < 4) { const int rt = q / 2, kb = q % 2; v = Ws0[(rt * 32 + i) * 32 + f16_col_S0(kb, h, j)]; }
+    else if (q < 8) { const int kb = q - 4; if (i < 16) v = Ws1[i * 64 + f16_col_from_frag(kb, h, j)]; }
+    else if (q < 12) { const int rt = (q - 8) / 2, kb = (q - 8) % 2, col = f16_col_C0(kb, h, j); if (col >= 0) v = Wc0[(rt * 32 + i) * 31 + col]; }
+    else if (q < 20) { const int rt = (q - 12) / 4, kb = (q - 12) % 4; v = Wc1[(rt * 32 + i) * 64 + f16_col_from_frag(kb, h, j)]; }
+    else { const int kb = q - 20; if (i < 3) v = Wc2[i * 64 + f16_col_from_frag(kb, h, j)]; }
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    _Float16* blk = reinterpret_cast<_Float16*>(packed + (size_t)q * kF16BlockBytes);
+    blk[lane * 8 + j] = hi;
+    blk[512 + lane * 8 + j] = lo;
+}
+
 constexpr int kFieldThreads = 512;  // 8 waves x 32 samples = 256 samples per workgroup tile
 
+template <int PREC>
 __global__ void __launch_bounds__(kFieldThreads) k_nerf_field_fwd(const float* __restrict__ enc /* [16][B][2] */, const float* __restrict__ dirs /* [B][3] */,
                                                                   const float* __restrict__ packed, uint32_t B, float* __restrict__ sigmas,
                                                                   float* __restrict__ rgbs) {
@@ -66,71 +87,19 @@ __global__ void __launch_bounds__(kFieldThreads) k_nerf_field_fwd(const float* _
     for (int i = threadIdx.x * 4; i < kPackedFloats; i += kFieldThreads * 4)
         *reinterpret_cast<float4*>(&w[i]) = *reinterpret_cast<const float4*>(&packed[i]);
     __syncthreads();
-
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     const uint32_t ntiles = (B + 255) / 256;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t n = tile * 256 + wave * 32 + (lane & 31);
         const bool valid = n < B;
         const uint32_t nc = valid ? n : (B - 1);
-
-        // ---- sigma_net[0]: B operand of step s = encoder level s, channel h  (coalesced 256-byte rows)
-        float x[16];
-#pragma unroll
-        for (int s = 0; s < 16; s++) x[s] = enc[((size_t)s * B + nc) * 2 + h];
-        f32x16 h0 = zero16(), h1 = zero16();
-#pragma unroll
-        for (int s = 0; s < 16; s++) {
-            h0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kS0 + s * 64 + lane], x[s], h0, 0, 0, 0);
-            h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kS0 + (16 + s) * 64 + lane], x[s], h1, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        h0 = relu16(h0); h1 = relu16(h1);
-
-        // ---- sigma_net[1]: 64 -> 16 (rows 16..31 of the tile are zero padding)
-        f32x16 g = zero16();
-        g = mma_frag(g, &w[kS1], h0, lane);
-        g = mma_frag(g, &w[kS1 + 16 * 64], h1, lane);
-        const float sigma_logit = g[0];  // row 0 lives in register 0 of the lower half-wave
-
-        // ---- color_net[0]: [SH16 ; geo15] -> 64
         const float dx = dirs[(size_t)nc * 3], dy = dirs[(size_t)nc * 3 + 1], dz = dirs[(size_t)nc * 3 + 2];
-        float sh[16];
-        sh_eval<4>(dx, dy, dz, sh);
-        f32x16 c0 = zero16(), c1 = zero16();
-#pragma unroll
-        for (int s = 0; s < 8; s++) {
-            const float b = h ? sh[8 + s] : sh[s];
-            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kC0 + s * 64 + lane], b, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kC0 + (16 + s) * 64 + lane], b, c1, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < 8; r++) {  // geo features: accumulator registers 0..7 of g (rows 0..15); row 0 carries a zero weight
-            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kC0 + (8 + r) * 64 + lane], g[r], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kC0 + (24 + r) * 64 + lane], g[r], c1, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        c0 = relu16(c0); c1 = relu16(c1);
-
-        // ---- color_net[1]: 64 -> 64
-        f32x16 d0 = zero16(), d1 = zero16();
-        d0 = mma_frag(d0, &w[kC1], c0, lane);
-        d0 = mma_frag(d0, &w[kC1 + 16 * 64], c1, lane);
-        d1 = mma_frag(d1, &w[kC1 + 32 * 64], c0, lane);
-        d1 = mma_frag(d1, &w[kC1 + 48 * 64], c1, lane);
-        d0 = relu16(d0); d1 = relu16(d1);
-
-        // ---- color_net[2]: 64 -> 3
-        f32x16 o = zero16();
-        o = mma_frag(o, &w[kC2], d0, lane);
-        o = mma_frag(o, &w[kC2 + 16 * 64], d1, lane);
-
+        const FieldOut o = nerf_field_tile<PREC>(w, lane, valid, enc, B, nc, dx, dy, dz);
         if (valid && h == 0) {
-            sigmas[n] = expf(sigma_logit);                       // trunc_exp forward (activation.py:9)
-            rgbs[(size_t)n * 3] = 1.0f / (1.0f + expf(-o[0]));   // sigmoid (nerf/network.py:122)
-            rgbs[(size_t)n * 3 + 1] = 1.0f / (1.0f + expf(-o[1]));
-            rgbs[(size_t)n * 3 + 2] = 1.0f / (1.0f + expf(-o[2]));
+            sigmas[n] = expf(o.sigma_logit);                      // trunc_exp forward (activation.py:9)
+            rgbs[(size_t)n * 3] = 1.0f / (1.0f + expf(-o.o0));    // sigmoid (nerf/network.py:122)
+            rgbs[(size_t)n * 3 + 1] = 1.0f / (1.0f + expf(-o.o1));
+            rgbs[(size_t)n * 3 + 2] = 1.0f / (1.0f + expf(-o.o2));
         }
     }
 }
@@ -144,19 +113,30 @@ extern "C" {
 uint64_t pnr_nerf_field_packed_bytes(void) { return (uint64_t)kPackedFloats * 4; }
 
 int pnr_nerf_field_pack(const float* w_sigma0, const float* w_sigma1, const float* w_color0, const float* w_color1, const float* w_color2,
-                        float* packed, pnr_stream_t stream) {
+                        float* packed, int precision, pnr_stream_t stream) {
     if (!w_sigma0 || !w_sigma1 || !w_color0 || !w_color1 || !w_color2 || !packed) return PNR_ERR_INVALID;
-    hipLaunchKernelGGL(k_nerf_field_pack, dim3(cdiv(kPackedFloats, 256)), dim3(256), 0, as_stream(stream), w_sigma0, w_sigma1, w_color0, w_color1,
-                       w_color2, packed);
+    if (precision == PNR_FIELD_FP32)
+        hipLaunchKernelGGL(k_nerf_field_pack, dim3(cdiv(kPackedFloats, 256)), dim3(256), 0, as_stream(stream), w_sigma0, w_sigma1, w_color0, w_color1,
+                           w_color2, packed);
+    else if (precision == PNR_FIELD_F16X3)
+        hipLaunchKernelGGL(k_nerf_field_pack_f16x3, dim3(cdiv(kF16Blocks * 512, 256)), dim3(256), 0, as_stream(stream), w_sigma0, w_sigma1, w_color0,
+                           w_color1, w_color2, reinterpret_cast<unsigned char*>(packed));
+    else
+        return PNR_ERR_UNSUPPORTED;
     return check_launch();
 }
 
-int pnr_nerf_field_forward(const float* enc, const float* dirs, const float* packed, uint32_t B, float* sigmas, float* rgbs, pnr_stream_t stream) {
+int pnr_nerf_field_forward(const float* enc, const float* dirs, const float* packed, uint32_t B, float* sigmas, float* rgbs, int precision,
+                           pnr_stream_t stream) {
+    if (precision != PNR_FIELD_FP32 && precision != PNR_FIELD_F16X3) return PNR_ERR_UNSUPPORTED;
     if (B == 0) return PNR_OK;
     if (!enc || !dirs || !packed || !sigmas || !rgbs) return PNR_ERR_INVALID;
     const uint32_t ntiles = cdiv(B, 256);
     const uint32_t grid = ntiles < 512u ? ntiles : 512u;  // 2 persistent workgroups per CU
-    hipLaunchKernelGGL(k_nerf_field_fwd, dim3(grid), dim3(kFieldThreads), 0, as_stream(stream), enc, dirs, packed, B, sigmas, rgbs);
+    if (precision == PNR_FIELD_FP32)
+        hipLaunchKernelGGL(k_nerf_field_fwd<0>, dim3(grid), dim3(kFieldThreads), 0, as_stream(stream), enc, dirs, packed, B, sigmas, rgbs);
+    else
+        hipLaunchKernelGGL(k_nerf_field_fwd<1>, dim3(grid), dim3(kFieldThreads), 0, as_stream(stream), enc, dirs, packed, B, sigmas, rgbs);
     return check_launch();
 }
 

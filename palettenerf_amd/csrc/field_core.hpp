@@ -37,4 +37,192 @@ __device__ __forceinline__ f32x16 mma_frag(f32x16 acc, const float* __restrict__
     return acc;
 }
 
+// ------------------------------------------------------------------------------------------
+// split-fp16 ("f16x3") variant: fp32-class accuracy at the fp16 matrix-core rate.
+// Every fp32 operand v is split as v = hi + lo with hi = fp16(v), lo = fp16(v - hi) (22 significant bits),
+// and a.b is evaluated as a_hi.b_hi + a_hi.b_lo + a_lo.b_hi on v_mfma_f32_32x32x16_f16 with fp32
+// accumulation: 3 MFMAs of K = 16 at 32 cycles replace 8 fp32 MFMAs of K = 2 at 64 cycles (5.3x fewer
+// matrix-pipe cycles); the dropped a_lo.b_lo term is ~2^-22 relative.  Weights are split once at pack time.
+// Same register-resident chaining as the fp32 path: the D fragment of a layer is the B operand of the next,
+// eight accumulator registers per K = 16 block.
+// Blob layout: 24 blocks of 2 KiB, block = [hi: 64 lanes x 8 halfs][lo: 64 lanes x 8 halfs]
+//   S0: q = rt*2 + kb (0..3) | S1: 4 + kb (kb 0..3) | C0: 8 + rt*2 + kb | C1: 12 + rt*4 + kb | C2: 20 + kb
+// ------------------------------------------------------------------------------------------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+constexpr int kF16Blocks = 24;
+constexpr int kF16BlockBytes = 2048;
+constexpr int kPackedBytesF16 = kF16Blocks * kF16BlockBytes;  // 48 KiB, same LDS footprint as the fp32 blob
+static_assert(kPackedBytesF16 == kPackedFloats * 4, "both blobs are 48 KiB");
+
+// weight column (input feature) that element j of lane-half h multiplies in k-block kb of each layer; -1 = zero pad
+__host__ __device__ constexpr int f16_col_S0(int kb, int h, int j) { return 16 * kb + 8 * h + j; }
+__host__ __device__ constexpr int f16_col_from_frag(int kb, int h, int j) { return (kb / 2) * 32 + frag_row((kb % 2) * 8 + j, h); }
+__host__ __device__ constexpr int f16_col_C0(int kb, int h, int j) {
+    if (kb == 0) return 8 * h + j;               // SH coefficient
+    const int g = frag_row(j, h);                // geo feature g (row g of the sigma_net[1] tile); g == 0 is the sigma logit
+    return g >= 1 ? 15 + g : -1;
+}
+
+__device__ __forceinline__ void split8(const float v[8], h8& hi, h8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const _Float16 hj = (_Float16)v[j];
+        hi[j] = hj;
+        lo[j] = (_Float16)(v[j] - (float)hj);
+    }
+}
+__device__ __forceinline__ void split_frag(const f32x16& a, int half_idx, h8& hi, h8& lo) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = a[half_idx * 8 + j];
+    split8(v, hi, lo);
+}
+__device__ __forceinline__ f32x16 mma3(f32x16 acc, const unsigned char* __restrict__ wblock, const h8& bhi, const h8& blo, int lane) {
+    const h8 ahi = *reinterpret_cast<const h8*>(wblock + lane * 16);
+    const h8 alo = *reinterpret_cast<const h8*>(wblock + 1024 + lane * 16);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc, 0, 0, 0);
+    return acc;
+}
+
+struct FieldOut { float sigma_logit, o0, o1, o2; };
+
+// One wave-tile (32 samples) of the NeRF field, split-fp16 matrix path.  w: the 48 KiB blob in LDS.
+__device__ __forceinline__ FieldOut nerf_field_tile_f16x3(const unsigned char* __restrict__ w, int lane, bool valid, const float* __restrict__ enc,
+                                                          size_t level_stride, uint32_t row, float dx, float dy, float dz) {
+    const int h = lane >> 5;
+    h8 bh[4], bl[4];
+    {   // sigma_net[0] inputs: k-block kb, element j  <-  encoder feature 16 kb + 8 h + j  = (level 8 kb + 4 h + j/2, channel j&1)
+        float x[2][8];
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int level = 8 * kb + 4 * h + q;
+                const float2 v = valid ? *reinterpret_cast<const float2*>(enc + ((size_t)level * level_stride + row) * 2) : make_float2(0.0f, 0.0f);
+                x[kb][2 * q] = v.x; x[kb][2 * q + 1] = v.y;
+            }
+        split8(x[0], bh[0], bl[0]);
+        split8(x[1], bh[1], bl[1]);
+    }
+    f32x16 h0 = zero16(), h1 = zero16();
+    h0 = mma3(h0, w + 0 * kF16BlockBytes, bh[0], bl[0], lane);
+    h0 = mma3(h0, w + 1 * kF16BlockBytes, bh[1], bl[1], lane);
+    h1 = mma3(h1, w + 2 * kF16BlockBytes, bh[0], bl[0], lane);
+    h1 = mma3(h1, w + 3 * kF16BlockBytes, bh[1], bl[1], lane);
+    __builtin_amdgcn_sched_barrier(0);
+    h0 = relu16(h0); h1 = relu16(h1);
+
+    // sigma_net[1]: 64 -> 16
+    split_frag(h0, 0, bh[0], bl[0]); split_frag(h0, 1, bh[1], bl[1]);
+    split_frag(h1, 0, bh[2], bl[2]); split_frag(h1, 1, bh[3], bl[3]);
+    f32x16 g = zero16();
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) g = mma3(g, w + (4 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
+    __builtin_amdgcn_sched_barrier(0);
+    FieldOut out;
+    out.sigma_logit = g[0];
+
+    // color_net[0]: [SH16 ; geo15] -> 64
+    float sh[16];
+    sh_eval<4>(dx, dy, dz, sh);
+    {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = h ? sh[8 + j] : sh[j];
+        split8(v, bh[0], bl[0]);
+    }
+    split_frag(g, 0, bh[1], bl[1]);
+    f32x16 c0 = zero16(), c1 = zero16();
+    c0 = mma3(c0, w + 8 * kF16BlockBytes, bh[0], bl[0], lane);
+    c0 = mma3(c0, w + 9 * kF16BlockBytes, bh[1], bl[1], lane);
+    c1 = mma3(c1, w + 10 * kF16BlockBytes, bh[0], bl[0], lane);
+    c1 = mma3(c1, w + 11 * kF16BlockBytes, bh[1], bl[1], lane);
+    __builtin_amdgcn_sched_barrier(0);
+    c0 = relu16(c0); c1 = relu16(c1);
+
+    // color_net[1]: 64 -> 64
+    split_frag(c0, 0, bh[0], bl[0]); split_frag(c0, 1, bh[1], bl[1]);
+    split_frag(c1, 0, bh[2], bl[2]); split_frag(c1, 1, bh[3], bl[3]);
+    f32x16 d0 = zero16(), d1 = zero16();
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) d0 = mma3(d0, w + (12 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) d1 = mma3(d1, w + (16 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
+    __builtin_amdgcn_sched_barrier(0);
+    d0 = relu16(d0); d1 = relu16(d1);
+
+    // color_net[2]: 64 -> 3
+    split_frag(d0, 0, bh[0], bl[0]); split_frag(d0, 1, bh[1], bl[1]);
+    split_frag(d1, 0, bh[2], bl[2]); split_frag(d1, 1, bh[3], bl[3]);
+    f32x16 o = zero16();
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) o = mma3(o, w + (20 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
+    out.o0 = o[0]; out.o1 = o[1]; out.o2 = o[2];
+    return out;
+}
+
+// One wave-tile of the NeRF field, exact-fp32 matrix path.  w: the 48 KiB fp32 blob in LDS.
+__device__ __forceinline__ FieldOut nerf_field_tile_f32(const float* __restrict__ w, int lane, bool valid, const float* __restrict__ enc,
+                                                        size_t level_stride, uint32_t row, float dx, float dy, float dz) {
+    const int h = lane >> 5;
+    // sigma_net[0]: B operand of step s = encoder level s, channel h  (coalesced 256-byte rows)
+    float x[16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) x[s] = valid ? enc[((size_t)s * level_stride + row) * 2 + h] : 0.0f;
+    f32x16 h0 = zero16(), h1 = zero16();
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        h0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kS0 + s * 64 + lane], x[s], h0, 0, 0, 0);
+        h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kS0 + (16 + s) * 64 + lane], x[s], h1, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    h0 = relu16(h0); h1 = relu16(h1);
+    // sigma_net[1]: 64 -> 16 (rows 16..31 of the tile are zero padding)
+    f32x16 g = zero16();
+    g = mma_frag(g, &w[kS1], h0, lane);
+    g = mma_frag(g, &w[kS1 + 16 * 64], h1, lane);
+    FieldOut out;
+    out.sigma_logit = g[0];  // row 0 lives in register 0 of the lower half-wave
+    // color_net[0]: [SH16 ; geo15] -> 64
+    float sh[16];
+    sh_eval<4>(dx, dy, dz, sh);
+    f32x16 c0 = zero16(), c1 = zero16();
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const float b = h ? sh[8 + s] : sh[s];
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kC0 + s * 64 + lane], b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kC0 + (16 + s) * 64 + lane], b, c1, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {  // geo features: accumulator registers 0..7 of g (rows 0..15); row 0 carries a zero weight
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kC0 + (8 + r) * 64 + lane], g[r], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kC0 + (24 + r) * 64 + lane], g[r], c1, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    c0 = relu16(c0); c1 = relu16(c1);
+    // color_net[1]: 64 -> 64
+    f32x16 d0 = zero16(), d1 = zero16();
+    d0 = mma_frag(d0, &w[kC1], c0, lane);
+    d0 = mma_frag(d0, &w[kC1 + 16 * 64], c1, lane);
+    d1 = mma_frag(d1, &w[kC1 + 32 * 64], c0, lane);
+    d1 = mma_frag(d1, &w[kC1 + 48 * 64], c1, lane);
+    d0 = relu16(d0); d1 = relu16(d1);
+    // color_net[2]: 64 -> 3
+    f32x16 o = zero16();
+    o = mma_frag(o, &w[kC2], d0, lane);
+    o = mma_frag(o, &w[kC2 + 16 * 64], d1, lane);
+    out.o0 = o[0]; out.o1 = o[1]; out.o2 = o[2];
+    return out;
+}
+
+template <int PREC>
+__device__ __forceinline__ FieldOut nerf_field_tile(const float* __restrict__ w, int lane, bool valid, const float* __restrict__ enc,
+                                                    size_t level_stride, uint32_t row, float dx, float dy, float dz) {
+    if constexpr (PREC == 0) return nerf_field_tile_f32(w, lane, valid, enc, level_stride, row, dx, dy, dz);
+    else return nerf_field_tile_f16x3(reinterpret_cast<const unsigned char*>(w), lane, valid, enc, level_stride, row, dx, dy, dz);
+}
+
 }  // namespace pnr

@@ -161,6 +161,7 @@ __global__ void __launch_bounds__(256) k_frame_grid(const FrameCtl* __restrict__
 
 // the fused MFMA field of field.hip with rows from the control block, dead-slot skipping and density_scale
 constexpr int kFieldThreads = 512;
+template <int PREC>
 __global__ void __launch_bounds__(kFieldThreads) k_frame_field(const FrameCtl* __restrict__ ctl, const float* __restrict__ enc, uint32_t level_stride,
                                                                const float* __restrict__ dirs, const float* __restrict__ deltas,
                                                                const float* __restrict__ packed, float density_scale, float* __restrict__ sigmas,
@@ -179,54 +180,14 @@ __global__ void __launch_bounds__(kFieldThreads) k_frame_field(const FrameCtl* _
         const bool valid = n < B && deltas[(size_t)(n < B ? n : 0) * 2] != 0.0f;
         if (!__any(valid)) continue;  // wave-uniform: all 32 slots of this wave are dead or out of range
         const uint32_t nc = n < B ? n : (B - 1);
-        float x[16];
-#pragma unroll
-        for (int s = 0; s < 16; s++) x[s] = valid ? enc[((size_t)s * level_stride + nc) * 2 + h] : 0.0f;
-        f32x16 h0 = zero16(), h1 = zero16();
-#pragma unroll
-        for (int s = 0; s < 16; s++) {
-            h0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kS0 + s * 64 + lane], x[s], h0, 0, 0, 0);
-            h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kS0 + (16 + s) * 64 + lane], x[s], h1, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        h0 = relu16(h0); h1 = relu16(h1);
-        f32x16 g = zero16();
-        g = mma_frag(g, &w[kS1], h0, lane);
-        g = mma_frag(g, &w[kS1 + 16 * 64], h1, lane);
-        const float sigma_logit = g[0];
         float dx = 0.0f, dy = 0.0f, dz = 0.0f;
         if (valid) { dx = dirs[(size_t)nc * 3]; dy = dirs[(size_t)nc * 3 + 1]; dz = dirs[(size_t)nc * 3 + 2]; }
-        float sh[16];
-        sh_eval<4>(dx, dy, dz, sh);
-        f32x16 c0 = zero16(), c1 = zero16();
-#pragma unroll
-        for (int s = 0; s < 8; s++) {
-            const float b = h ? sh[8 + s] : sh[s];
-            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kC0 + s * 64 + lane], b, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kC0 + (16 + s) * 64 + lane], b, c1, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kC0 + (8 + r) * 64 + lane], g[r], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kC0 + (24 + r) * 64 + lane], g[r], c1, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        c0 = relu16(c0); c1 = relu16(c1);
-        f32x16 d0 = zero16(), d1 = zero16();
-        d0 = mma_frag(d0, &w[kC1], c0, lane);
-        d0 = mma_frag(d0, &w[kC1 + 16 * 64], c1, lane);
-        d1 = mma_frag(d1, &w[kC1 + 32 * 64], c0, lane);
-        d1 = mma_frag(d1, &w[kC1 + 48 * 64], c1, lane);
-        d0 = relu16(d0); d1 = relu16(d1);
-        f32x16 o = zero16();
-        o = mma_frag(o, &w[kC2], d0, lane);
-        o = mma_frag(o, &w[kC2 + 16 * 64], d1, lane);
+        const FieldOut o = nerf_field_tile<PREC>(w, lane, valid, enc, level_stride, nc, dx, dy, dz);
         if (valid && h == 0) {
-            sigmas[n] = density_scale * expf(sigma_logit);   // nerf/renderer.py:372
-            rgbs[(size_t)n * 3] = 1.0f / (1.0f + expf(-o[0]));
-            rgbs[(size_t)n * 3 + 1] = 1.0f / (1.0f + expf(-o[1]));
-            rgbs[(size_t)n * 3 + 2] = 1.0f / (1.0f + expf(-o[2]));
+            sigmas[n] = density_scale * expf(o.sigma_logit);   // nerf/renderer.py:372
+            rgbs[(size_t)n * 3] = 1.0f / (1.0f + expf(-o.o0));
+            rgbs[(size_t)n * 3 + 1] = 1.0f / (1.0f + expf(-o.o1));
+            rgbs[(size_t)n * 3 + 2] = 1.0f / (1.0f + expf(-o.o2));
         }
     }
 }
@@ -397,6 +358,7 @@ int pnr_nerf_render_frame(const pnr_nerf_frame_args* a, pnr_stream_t stream) {
         !a->depth || !a->image || !a->workspace)
         return PNR_ERR_INVALID;
     if (a->C == 0 || a->C > 16 || a->H == 0 || a->max_steps == 0 || a->num_levels != 16) return PNR_ERR_UNSUPPORTED;
+    if (a->field_precision != PNR_FIELD_FP32 && a->field_precision != PNR_FIELD_F16X3) return PNR_ERR_UNSUPPORTED;
     if (a->workspace_bytes < pnr_nerf_frame_workspace_bytes(a->N)) return PNR_ERR_INVALID;
     hipStream_t s = as_stream(stream);
     const uint32_t N = a->N;
@@ -444,12 +406,16 @@ int pnr_nerf_render_frame(const pnr_nerf_frame_args* a, pnr_stream_t stream) {
                 hipLaunchKernelGGL((k_frame_march<false, false>), gm, bm, march_lds, s, cur, alive_in, w.rays_t, a->rays_o, a->rays_d, mp, a->bitfield, a->fars, w.xyzs, w.dirs, w.deltas, mip, w.partials);
             const uint32_t gx = cdiv(rows_ub, 256);
             hipEvent_t e0 = timing ? next_event() : nullptr, e1 = timing ? next_event() : nullptr;
-            if (e0) hipEventRecord(e0, s);
+            if (e0) (void)hipEventRecord(e0, s);
             hipLaunchKernelGGL(k_frame_grid, dim3(gx < 1024u ? gx : 1024u, 16), dim3(256), 0, s, cur, w.xyzs, w.deltas, a->embeddings, a->offsets, lp, w.enc, N,
                                a->bound, 2.0f * a->bound, a->gridtype);
-            if (e1) hipEventRecord(e1, s);
-            hipLaunchKernelGGL(k_frame_field, dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas, a->packed_weights,
-                               a->density_scale, w.sigmas, w.rgbs);
+            if (e1) (void)hipEventRecord(e1, s);
+            if (a->field_precision == PNR_FIELD_FP32)
+                hipLaunchKernelGGL(k_frame_field<0>, dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas,
+                                   a->packed_weights, a->density_scale, w.sigmas, w.rgbs);
+            else
+                hipLaunchKernelGGL(k_frame_field<1>, dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas,
+                                   a->packed_weights, a->density_scale, w.sigmas, w.rgbs);
             hipLaunchKernelGGL(k_frame_composite, gm, bm, 0, s, cur, a->T_thresh, alive_in, w.rays_t, w.sigmas, w.rgbs, w.deltas, a->weights_sum, a->depth,
                                a->image, w.scratch);
             hipLaunchKernelGGL(k_frame_scan, dim3(1), dim3(1024), 0, s, cur, nxt, w.scratch, N, a->max_steps, w.partials, gm.x);

@@ -30,6 +30,7 @@ class NeRFFieldFused:
         self.model = model
         self.packed = None
         self.versions = None
+        self.precision = 1  # PNR_FIELD_F16X3 (split-fp16 matrix path, ~2^-22 relative); 0 = PNR_FIELD_FP32 (exact fmaf chains)
         self.time_grid_kernel = False  # bench.py: HIP-event timing of the grid-encode launches inside the native frame loop
         m = model
         ok = (m.encoder.num_levels == 16 and m.encoder.level_dim == 2 and m.encoder.input_dim == 3 and m.hidden_dim == 64 and m.geo_feat_dim == 15
@@ -43,13 +44,13 @@ class NeRFFieldFused:
 
     def _pack(self):
         ws = self._weights()
-        versions = tuple((w.data_ptr(), w._version) for w in ws)
+        versions = tuple((w.data_ptr(), w._version) for w in ws) + (self.precision,)
         if self.packed is None or versions != self.versions:
             dev = ws[0].device
             if self.packed is None or self.packed.device != dev:
                 self.packed = torch.empty(int(_lib.load().pnr_nerf_field_packed_bytes()) // 4, dtype=torch.float32, device=dev)
             ws = [require(w.detach().contiguous(), torch.float32, "weight") for w in ws]
-            call("pnr_nerf_field_pack", *[ptr(w) for w in ws], ptr(self.packed))
+            call("pnr_nerf_field_pack", *[ptr(w) for w in ws], ptr(self.packed), _int(self.precision))
             self.versions = versions
         return self.packed
 
@@ -83,6 +84,7 @@ class NeRFFieldFused:
         a.embeddings, a.offsets = emb.data_ptr(), enc.offsets.data_ptr()
         a.num_levels, a.S, a.base_resolution, a.gridtype = enc.num_levels, float(np.log2(enc.per_level_scale)), enc.base_resolution, enc.gridtype_id
         a.packed_weights = self._pack().data_ptr()
+        a.field_precision = int(self.precision)
         a.density_scale = float(m.density_scale)
         a.weights_sum, a.depth, a.image = ws.data_ptr(), depth.data_ptr(), image.data_ptr()
         a.workspace, a.workspace_bytes = self._ws.data_ptr(), nbytes
@@ -105,5 +107,5 @@ class NeRFFieldFused:
         sigmas = torch.empty(B, dtype=torch.float32, device=x.device)
         rgbs = torch.empty(B, 3, dtype=torch.float32, device=x.device)
         call("pnr_nerf_field_forward", ptr(enc), ptr(require(d.contiguous(), torch.float32, "dirs")), ptr(self._pack()), _u32(B), ptr(sigmas),
-             ptr(rgbs), units=B)
+             ptr(rgbs), _int(self.precision), units=B)
         return sigmas, rgbs

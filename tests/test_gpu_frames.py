@@ -40,16 +40,20 @@ def close(got, want, tol=COLOUR_TOL, what=""):
 
 
 @pytest.mark.parametrize("case", ["a", "b"])
-@pytest.mark.parametrize("mode", ["compat", "device", "fused", "native"])
+@pytest.mark.parametrize("mode", ["compat", "device", "fused", "native", "native_fp32"])
 def test_nerf_inference_frame(cuda, golden_dir, case, mode):
     g = load(golden_dir, f"frame_nerf_{case}")
     m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=float(g["density_scale"]), min_near=0.2)
     scene.seed_field_(m, int(g["seed"]))
     m = m.to(cuda).eval()
     put_scene(m, cuda)
-    m.march_mode = "device" if mode == "fused" else mode
-    m.fused_field = mode in ("fused", "native")
+    m.march_mode = {"fused": "device", "native_fp32": "native"}.get(mode, mode)
+    m.fused_field = mode in ("fused", "native", "native_fp32")
     m.count_rendered = True
+    if mode == "native_fp32":
+        from palettenerf_amd.fused import NeRFFieldFused
+        m._fused = NeRFFieldFused(m)
+        m._fused.precision = 0
     ro, rd = frame_rays(g, cuda)
     with torch.no_grad():
         r = m.render(ro, rd, staged=True, dt_gamma=float(g["dt_gamma"]), perturb=False, max_steps=1024, T_thresh=1e-4)
@@ -58,7 +62,7 @@ def test_nerf_inference_frame(cuda, golden_dir, case, mode):
     close(r["depth"], g["depth"], tol=2e-4, what="depth")
     assert scene.psnr(r["image"].cpu(), torch.from_numpy(g["image"])) > 80.0
     _RENDERED.setdefault(case, {})[mode] = (int(r["rendered"].item()), int(r["n_samples"]))
-    if len(_RENDERED[case]) == 4:  # every execution mode marched exactly the same samples (schedule and compaction identical)
+    if len(_RENDERED[case]) == 5:  # every execution mode marched exactly the same samples (schedule and compaction identical)
         counts = {k: v[0] for k, v in _RENDERED[case].items()}
         assert len(set(counts.values())) == 1, counts
 

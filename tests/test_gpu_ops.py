@@ -429,12 +429,16 @@ def test_hsv_round_trip_and_parity(cuda):
 
 
 # ------------------------------------------------------------------------------------------ fused MFMA field
-def test_fused_nerf_field_matches_oracle_and_torch(cuda):
+@pytest.mark.parametrize("precision", [0, 1])  # PNR_FIELD_FP32 (exact fmaf chains) / PNR_FIELD_F16X3 (split-fp16 matrix path)
+def test_fused_nerf_field_matches_oracle_and_torch(cuda, precision):
     from palettenerf_amd import network
+    from palettenerf_amd.fused import NeRFFieldFused
     rng = np.random.default_rng(50)
     m = network.NeRFNetwork(bound=2, cuda_ray=True)
     scene.seed_field_(m, 3)
     m = m.to(cuda).eval()
+    m._fused = NeRFFieldFused(m)
+    m._fused.precision = precision
     for B in (1, 31, 32, 33, 255, 256, 257, 5000, 70001):
         x = (rng.random((B, 3)).astype(np.float32) * 4 - 2)
         d = rng.standard_normal((B, 3)).astype(np.float32)
