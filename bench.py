@@ -118,6 +118,8 @@ def main():
         m.fused_field = True
         m._fused = NeRFFieldFused(m)
         m._fused.precision = 0 if args.field_precision == "fp32" else 1
+    if mode in ("fused", "native") and args.model == "palette" and not args.fp16:
+        m.fused_field = True
     H = W = args.res
     pose = torch.from_numpy(scene.lookat_pose())[None]
     ro, rd = scene.get_rays(pose, scene.intrinsics_from_fov(H, W), H, W)

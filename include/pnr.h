@@ -207,6 +207,45 @@ typedef struct pnr_nerf_frame_args {
 uint64_t pnr_nerf_frame_workspace_bytes(uint32_t N);
 int pnr_nerf_render_frame(const pnr_nerf_frame_args* args, pnr_stream_t stream);
 
+/* Fused PaletteNeRF field + palette colour-basis composite (palette/network.py:156-280, palette/renderer.py:470-500,
+ * inference branch without RegionEdit / Stylizer).  Split-fp16 matrix path.  All weights are row-major [out][in]
+ * device fp32 pointers of the bias-free nn.Linear layers; offsets_radiance has a bias (passed to the forward call). */
+typedef struct pnr_palette_weights {
+    const float *sigma0, *sigma1;              /* [64,32], [16,64]            */
+    const float *diff0, *diff1, *diff2;        /* [64,15], [64,64], [3,64]    */
+    const float *color0, *color1, *color2;     /* [64,31], [64,64], [3,64]    */
+    const float *basis0, *basis1;              /* [64,35], [15,64]            */
+    const float *offsets_radiance;             /* [3 nb + 1, 15]              */
+    const float *omega;                        /* [nb, 15]                    */
+    const float *clip0, *clip1;                /* [64,32], [clip_dim,64] (pred_clip only) */
+    uint32_t num_basis, clip_dim;              /* nb <= 5, clip_dim <= 16     */
+    int pred_clip;
+} pnr_palette_weights;
+typedef struct pnr_palette_field_args {
+    const void* ctl;               /* NULL for the stand-alone op (rows = B); internal frame control block otherwise */
+    uint32_t B;                    /* rows */
+    const float* enc;              /* [16, level_stride, 2] raw grid output of `encoder` */
+    const float* enc_palette;      /* same for `encoder_palette` */
+    const float* enc_clip;         /* same for `encoder_clip` (pred_clip only) */
+    uint32_t level_stride;
+    const float* dirs;             /* [B,3] */
+    const float* deltas;           /* [B,2] or NULL; rows with deltas[:,0] == 0 are skipped */
+    const void* packed;            /* pnr_palette_field_pack output */
+    const float* basis_color;      /* HOST [nb,3] (clamped to [0,1] by the callee) */
+    const float* or_bias;          /* HOST [3 nb + 1] offsets_radiance_net.bias */
+    uint32_t num_basis, clip_dim;
+    int pred_clip;
+    float density_scale, offsets_weight, view_dep_weight;
+    uint32_t aux_stride;           /* floats per aux row, >= pnr_palette_aux_channels(nb, clip_dim) semantics below */
+    float* sigmas;                 /* [B]   = density_scale * exp(h0) */
+    float* rgbs;                   /* [B,3] */
+    float* aux;                    /* [B, aux_stride] = direct_rgb 3 | view_dep 3 | omega nb | basis_rgb 3nb | unscaled 3nb | clip | 0 pad */
+} pnr_palette_field_args;
+uint64_t pnr_palette_field_packed_bytes(int pred_clip);
+uint32_t pnr_palette_aux_channels(uint32_t num_basis, uint32_t clip_dim);   /* 6 + 7 nb + clip_dim rounded up to a multiple of 4 */
+int pnr_palette_field_pack(const pnr_palette_weights* weights, void* packed, pnr_stream_t stream);
+int pnr_palette_field_forward(const pnr_palette_field_args* args, pnr_stream_t stream);
+
 /* ---------------------------------------------------------------- SH encoder --------------- */
 
 /* replaces sh_encode_forward / sh_encode_backward, shencoder/src/shencoder.h:9-10, shencoder.cu:400-439.

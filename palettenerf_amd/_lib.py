@@ -43,12 +43,17 @@ SIGNATURES = {
     "pnr_nerf_field_forward": [_ptr, _ptr, _ptr, _u32, _ptr, _ptr, _int, _ptr],
     "pnr_nerf_frame_workspace_bytes": [_u32],
     "pnr_nerf_render_frame": [_ptr, _ptr],
+    "pnr_palette_field_packed_bytes": [_int],
+    "pnr_palette_aux_channels": [_u32, _u32],
+    "pnr_palette_field_pack": [_ptr, _ptr, _ptr],
+    "pnr_palette_field_forward": [_ptr, _ptr],
     "pnr_sh_encode_forward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr],
     "pnr_sh_encode_backward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr, _ptr],
     "pnr_rgb_to_hsv": [_u32, _ptr, _ptr, _ptr],
     "pnr_hsv_to_rgb": [_u32, _ptr, _ptr, _ptr],
 }
-_RESTYPES = {"pnr_error_string": ctypes.c_char_p, "pnr_scan_scratch_bytes": _u64, "pnr_nerf_field_packed_bytes": _u64, "pnr_occupancy_mip_bytes": _u64, "pnr_nerf_frame_workspace_bytes": _u64}
+_RESTYPES = {"pnr_error_string": ctypes.c_char_p, "pnr_scan_scratch_bytes": _u64, "pnr_nerf_field_packed_bytes": _u64, "pnr_occupancy_mip_bytes": _u64, "pnr_nerf_frame_workspace_bytes": _u64, "pnr_palette_field_packed_bytes": _u64,
+             "pnr_palette_aux_channels": _u32}
 
 class NerfFrameArgs(ctypes.Structure):
     """Mirror of `pnr_nerf_frame_args` (include/pnr.h)."""
@@ -56,6 +61,20 @@ class NerfFrameArgs(ctypes.Structure):
                 ("C", _u32), ("H", _u32), ("dt_gamma", _f32), ("max_steps", _u32), ("T_thresh", _f32), ("embeddings", _ptr), ("offsets", _ptr),
                 ("num_levels", _u32), ("S", _f32), ("base_resolution", _u32), ("gridtype", _u32), ("packed_weights", _ptr), ("field_precision", _int), ("density_scale", _f32),
                 ("weights_sum", _ptr), ("depth", _ptr), ("image", _ptr), ("workspace", _ptr), ("workspace_bytes", _u64), ("stats", _ptr), ("kernel_ms", _ptr)]
+
+
+class PaletteWeights(ctypes.Structure):
+    """Mirror of `pnr_palette_weights` (include/pnr.h)."""
+    _fields_ = [(n, _ptr) for n in ("sigma0", "sigma1", "diff0", "diff1", "diff2", "color0", "color1", "color2", "basis0", "basis1",
+                                    "offsets_radiance", "omega", "clip0", "clip1")] + [("num_basis", _u32), ("clip_dim", _u32), ("pred_clip", _int)]
+
+
+class PaletteFieldArgs(ctypes.Structure):
+    """Mirror of `pnr_palette_field_args` (include/pnr.h)."""
+    _fields_ = [("ctl", _ptr), ("B", _u32), ("enc", _ptr), ("enc_palette", _ptr), ("enc_clip", _ptr), ("level_stride", _u32), ("dirs", _ptr),
+                ("deltas", _ptr), ("packed", _ptr), ("basis_color", _ptr), ("or_bias", _ptr), ("num_basis", _u32), ("clip_dim", _u32),
+                ("pred_clip", _int), ("density_scale", _f32), ("offsets_weight", _f32), ("view_dep_weight", _f32), ("aux_stride", _u32),
+                ("sigmas", _ptr), ("rgbs", _ptr), ("aux", _ptr)]
 
 
 _lib = None

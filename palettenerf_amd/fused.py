@@ -109,3 +109,91 @@ class NeRFFieldFused:
         call("pnr_nerf_field_forward", ptr(enc), ptr(require(d.contiguous(), torch.float32, "dirs")), ptr(self._pack()), _u32(B), ptr(sigmas),
              ptr(rgbs), _int(self.precision), units=B)
         return sigmas, rgbs
+
+
+class PaletteFieldFused:
+    """Fused PaletteNeRF field + colour-basis composite (pnr_palette_field_forward).  Produces, per sample,
+    sigma * density_scale, rgb and one packed aux row [direct 3 | view_dep 3 | omega nb | basis_rgb 3nb | unscaled 3nb | clip | pad]."""
+
+    def __init__(self, model):
+        self.model = model
+        self.packed = None
+        self.versions = None
+        m = model
+        ok = (m.encoder.num_levels == 16 and m.encoder.level_dim == 2 and m.hidden_dim == 64 and m.geo_feat_dim == 15 and m.num_layers == 2
+              and m.num_layers_color == 3 and m.encoder_dir.degree == 4 and 1 <= m.num_basis <= 5 and m.opt.clip_dim <= 16)
+        if not ok:
+            raise RuntimeError("fused palette field kernel is specialised for the shipped architecture")
+        self.nb, self.clip_dim, self.pred_clip = int(m.num_basis), int(m.opt.clip_dim), bool(m.opt.pred_clip)
+        self.aux_channels = int(_lib.load().pnr_palette_aux_channels(self.nb, self.clip_dim))
+
+    def _weights(self):
+        m = self.model
+        ws = [m.sigma_net[0].weight, m.sigma_net[1].weight, m.diff_net[0].weight, m.diff_net[1].weight, m.diff_net[2].weight,
+              m.color_net[0].weight, m.color_net[1].weight, m.color_net[2].weight, m.basis_net[0].weight, m.basis_net[1].weight,
+              m.offsets_radiance_net.weight, m.omega_net[0].weight]
+        if self.pred_clip:
+            ws += [m.clip_net[0].weight, m.clip_net[1].weight]
+        return ws
+
+    def _pack(self):
+        ws = self._weights()
+        versions = tuple((w.data_ptr(), w._version) for w in ws)
+        if self.packed is None or versions != self.versions:
+            dev = ws[0].device
+            lib = _lib.load()
+            self.packed = torch.empty(int(lib.pnr_palette_field_packed_bytes(int(self.pred_clip))), dtype=torch.uint8, device=dev)
+            self._keep = [require(w.detach().contiguous(), torch.float32, "weight") for w in ws]
+            pw = _lib.PaletteWeights()
+            names = ["sigma0", "sigma1", "diff0", "diff1", "diff2", "color0", "color1", "color2", "basis0", "basis1", "offsets_radiance", "omega"]
+            if self.pred_clip:
+                names += ["clip0", "clip1"]
+            for name, w in zip(names, self._keep):
+                setattr(pw, name, w.data_ptr())
+            pw.num_basis, pw.clip_dim, pw.pred_clip = self.nb, self.clip_dim, int(self.pred_clip)
+            rc = lib.pnr_palette_field_pack(ctypes.byref(pw), ctypes.c_void_p(self.packed.data_ptr()),
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            _lib.check(rc, "pnr_palette_field_pack")
+            self.versions = versions
+        return self.packed
+
+    def _host_params(self):
+        m = self.model
+        key = (m.basis_color._version, m.offsets_radiance_net.bias._version)
+        if getattr(self, "_hp_key", None) != key:  # two tiny D2H copies, only when the parameters change
+            self._bc = (ctypes.c_float * (3 * self.nb))(*m.basis_color.detach().float().cpu().reshape(-1).tolist())
+            self._bias = (ctypes.c_float * (3 * self.nb + 1))(*m.offsets_radiance_net.bias.detach().float().cpu().tolist())
+            self._hp_key = key
+        return self._bc, self._bias
+
+    @torch.no_grad()
+    def __call__(self, x, d, deltas=None):
+        """x [B,3] world positions, d [B,3] -> (sigmas [B] scaled by density_scale, rgbs [B,3], aux [B, aux_channels])."""
+        m = self.model
+        lib = _lib.load()
+        B = x.shape[0]
+        dev = x.device
+        x01 = ((x + m.bound) / (2 * m.bound)).contiguous()
+        enc = grid_encode_raw(m.encoder, x01)
+        enc_pal = grid_encode_raw(m.encoder_palette, x01)
+        enc_clip = grid_encode_raw(m.encoder_clip, x01) if self.pred_clip else None
+        sigmas = torch.empty(B, dtype=torch.float32, device=dev)
+        rgbs = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        aux = torch.empty(B, self.aux_channels, dtype=torch.float32, device=dev)
+        bc, bias = self._host_params()
+        a = _lib.PaletteFieldArgs()
+        a.ctl, a.B = None, B
+        a.enc, a.enc_palette = enc.data_ptr(), enc_pal.data_ptr()
+        a.enc_clip = enc_clip.data_ptr() if enc_clip is not None else None
+        a.level_stride = B
+        a.dirs = require(d.contiguous(), torch.float32, "dirs").data_ptr()
+        a.deltas = deltas.data_ptr() if deltas is not None else None
+        a.packed = self._pack().data_ptr()
+        a.basis_color, a.or_bias = ctypes.cast(bc, ctypes.c_void_p), ctypes.cast(bias, ctypes.c_void_p)
+        a.num_basis, a.clip_dim, a.pred_clip = self.nb, self.clip_dim, int(self.pred_clip)
+        a.density_scale, a.offsets_weight, a.view_dep_weight = float(m.density_scale), float(m.offsets_weight), float(m.view_dep_weight)
+        a.aux_stride = self.aux_channels
+        a.sigmas, a.rgbs, a.aux = sigmas.data_ptr(), rgbs.data_ptr(), aux.data_ptr()
+        rc = lib.pnr_palette_field_forward(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "pnr_palette_field_forward")
+        return sigmas, rgbs, aux

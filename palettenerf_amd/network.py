@@ -89,6 +89,8 @@ class PaletteNetwork(PaletteRenderer):
         if opt.pred_clip:
             self.clip_net = _mlp([self.in_dim_clip] + [hidden_dim] * (num_layers - 1) + [opt.clip_dim])
         self.bg_net = None
+        self.fused_field = False  # True: inference goes through the fused palette field + packed-aux composite (no edit / stylizer)
+        self._fused = None
 
     def forward(self, x, d):
         """palette/network.py:156-185.  Returns sigma, clip_feat, omega, offsets_radiance, view_dep, diffuse."""

@@ -402,6 +402,20 @@ class PaletteRenderer(_RendererBase):
         basis_acc_map = torch.zeros(N, nb, **f32)
         clip_feat_map = torch.zeros(N, clip_dim, **f32)
 
+        use_fused = bool(getattr(self, "fused_field", False)) and self.edit is None and self.stylizer is None and not torch.is_autocast_enabled()
+        if use_fused:
+            if getattr(self, "_fused", None) is None:
+                from .fused import PaletteFieldFused
+                self._fused = PaletteFieldFused(self)
+            aux_map = torch.zeros(N, self._fused.aux_channels, **f32)
+
+        def shade_fused(st, n_alive, n_step, xyzs, dirs, deltas):
+            # one fused field launch + ONE flex composite over the packed aux row instead of ~40 launches and 6 flex composites
+            sigmas, rgbs, aux = self._fused(xyzs, dirs, deltas)
+            raymarching.composite_rays_flex(n_alive, n_step, self._fused.aux_channels, st.rays_alive, st.rays_t, sigmas, aux, deltas, st.weights_sum,
+                                            aux_map, T_thresh)
+            raymarching.composite_rays(n_alive, n_step, st.rays_alive, st.rays_t, sigmas, rgbs, deltas, st.weights_sum, st.depth, st.image, T_thresh)
+
         def shade(st, n_alive, n_step, xyzs, dirs, deltas):
             M = xyzs.shape[0]
             sigmas, clip_feat, omega, offsets_radiance, view_dep, diffuse = self(xyzs, dirs)
@@ -440,7 +454,13 @@ class PaletteRenderer(_RendererBase):
             # must come last: the only composite that mutates rays_alive / rays_t / weights_sum (palette/renderer.py:517-519)
             raymarching.composite_rays(*a, st.rays_alive, st.rays_t, sigmas, rgbs, deltas, st.weights_sum, st.depth, st.image, T_thresh)
 
-        st = self._infer_loop(rays_o, rays_d, nears, fars, perturb, dt_gamma, max_steps, shade)
+        st = self._infer_loop(rays_o, rays_d, nears, fars, perturb, dt_gamma, max_steps, shade_fused if use_fused else shade)
+        if use_fused:  # unpack the composited aux row into the reference's maps
+            direct_rgb_map, view_dep_rgb_map = aux_map[:, 0:3], aux_map[:, 3:6]
+            basis_acc_map = aux_map[:, 6:6 + nb]
+            basis_rgb_map = aux_map[:, 6 + nb:6 + 4 * nb]
+            unscaled_basis_rgb_map = aux_map[:, 6 + 4 * nb:6 + 7 * nb]
+            clip_feat_map = aux_map[:, 6 + 7 * nb:6 + 7 * nb + clip_dim]
         weights_sum = st.weights_sum
         image = st.image + (1 - weights_sum).unsqueeze(-1) * bg_color
         depth_origin = st.depth.clone()
@@ -449,13 +469,13 @@ class PaletteRenderer(_RendererBase):
         results["depth_origin"] = depth_origin.view(*prefix)
         results["image"] = image.view(*prefix, 3)
         results["weights_sum"] = weights_sum
-        results["clip_feat"] = clip_feat_map.view(*prefix, clip_dim)
+        results["clip_feat"] = clip_feat_map.reshape(*prefix, clip_dim)
         results["n_samples"] = st.n_samples
         results["rendered"] = st.rendered
         if not gui_mode:
             results["direct_rgb"] = (direct_rgb_map + (1 - weights_sum).unsqueeze(-1) * bg_color).view(*prefix, 3)
-            results["view_dep_rgb"] = view_dep_rgb_map.view(*prefix, 3)
-            results["basis_rgb"] = basis_rgb_map.view(*prefix, nb * 3)
-            results["unscaled_basis_rgb"] = unscaled_basis_rgb_map.view(*prefix, nb * 3)
-            results["basis_acc"] = basis_acc_map.view(*prefix, nb)
+            results["view_dep_rgb"] = view_dep_rgb_map.reshape(*prefix, 3)
+            results["basis_rgb"] = basis_rgb_map.reshape(*prefix, nb * 3)
+            results["unscaled_basis_rgb"] = unscaled_basis_rgb_map.reshape(*prefix, nb * 3)
+            results["basis_acc"] = basis_acc_map.reshape(*prefix, nb)
         return results

@@ -103,15 +103,16 @@ def test_palette_inference_frame_all_maps_and_edit(cuda, golden_dir, case):
     m = m.to(cuda).eval()
     put_scene(m, cuda)
     ro, rd = frame_rays(g, cuda)
-    for mode in ("compat", "device"):
-        m.march_mode = mode
+    for mode in ("compat", "device", "fused"):
+        m.march_mode = "device" if mode == "fused" else mode
+        m.fused_field = mode == "fused"
         with torch.no_grad():
             r = m.render(ro, rd, dt_gamma=float(g["dt_gamma"]), perturb=False, max_steps=1024, T_thresh=1e-4, gui_mode=False)
         for k in ("image", "weights_sum", "clip_feat", "direct_rgb", "view_dep_rgb", "basis_rgb", "unscaled_basis_rgb", "basis_acc"):
             close(r[k], g[k], what=f"{mode}:{k}")
         close(r["depth"], g["depth"], tol=2e-4, what="depth")
         close(r["depth_origin"], g["depth_origin"], tol=5e-4, what="depth_origin")
-    # regional edit: RGB->HSV->RGB inside the loop
+    # regional edit: RGB->HSV->RGB inside the loop (the fused field steps aside when an edit is active)
     m.edit = renderer.RegionEdit(opt)
     m.edit.update_cent(mean_xyz=torch.tensor([0.1, 0.0, -0.2], device=cuda))
     m.edit.update_std(std_xyz=0.5)

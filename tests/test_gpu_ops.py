@@ -466,3 +466,37 @@ def test_fused_nerf_field_matches_oracle_and_torch(cuda, precision):
         s3, c3 = m(tx, td)
     np.testing.assert_allclose(host(c2), host(c3), atol=2e-6)
     assert np.abs(host(c2) - host(c)).max() > 1e-3
+
+
+@pytest.mark.parametrize("pred_clip", [False, True])
+def test_fused_palette_field_matches_torch_module(cuda, pred_clip):
+    """Fused PaletteNeRF field + colour-basis composite vs the unfused module + the torch statement of palette/renderer.py:470-500."""
+    import torch.nn.functional as F
+    from palettenerf_amd import network, renderer
+    from palettenerf_amd.fused import PaletteFieldFused
+    rng = np.random.default_rng(60)
+    opt = renderer.default_opt(pred_clip=pred_clip)
+    m = network.PaletteNetwork(opt, bound=2, cuda_ray=True, density_scale=3.0)
+    scene.seed_field_(m, 5)
+    m = m.to(cuda).eval()
+    m.offsets_weight, m.view_dep_weight = 0.7, 1.3
+    fused = PaletteFieldFused(m)
+    nb = 4
+    for B in (1, 33, 256, 4097):
+        x = dev(rng.random((B, 3)).astype(np.float32) * 4 - 2, cuda)
+        d = rng.standard_normal((B, 3)).astype(np.float32)
+        d = dev(d / np.linalg.norm(d, axis=1, keepdims=True), cuda)
+        with torch.no_grad():
+            sigma, clip_feat, omega, offsets_radiance, view_dep, diffuse = m(x, d)
+            offsets, radiance = offsets_radiance[..., :-1].reshape(B, nb, 3), offsets_radiance[..., -1:].reshape(B, 1, 1)
+            basis_color = m.basis_color[None].clamp(0, 1)
+            final = F.softplus(radiance) * (basis_color + m.offsets_weight * offsets)
+            basis_rgb = omega.reshape(B, nb, 1) * final
+            rgbs = basis_rgb.sum(-2) + m.view_dep_weight * view_dep
+            want_aux = torch.cat([diffuse + view_dep, view_dep, omega, basis_rgb.reshape(B, -1), (basis_color + offsets).reshape(B, -1), clip_feat], dim=1)
+            s, c, aux = fused(x, d)
+        assert aux.shape == (B, 52)
+        np.testing.assert_allclose(host(s), host(sigma) * 3.0, rtol=3e-5, atol=1e-7)
+        np.testing.assert_allclose(host(c), host(rgbs), rtol=0, atol=5e-6)
+        np.testing.assert_allclose(host(aux[:, :50]), host(want_aux), rtol=0, atol=5e-6)
+        assert float(aux[:, 50:].abs().max()) == 0.0
