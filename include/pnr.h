@@ -207,6 +207,25 @@ typedef struct pnr_nerf_frame_args {
 uint64_t pnr_nerf_frame_workspace_bytes(uint32_t N);
 int pnr_nerf_render_frame(const pnr_nerf_frame_args* args, pnr_stream_t stream);
 
+/* The same device-driven loop for the PaletteNeRF model (palette/renderer.py:430-550 without RegionEdit / Stylizer):
+ * `base.embeddings` is the `encoder` table, `base.packed_weights` the pnr_palette_field_pack blob, base.field_precision must be
+ * PNR_FIELD_F16X3.  aux_map [N, pnr_palette_aux_channels(nb, clip_dim)] receives the composited packed row
+ * direct_rgb 3 | view_dep 3 | basis_acc nb | basis_rgb 3nb | unscaled_basis_rgb 3nb | clip_feat clip_dim | pad
+ * (raw accumulations: the background mix of direct_rgb is the caller's, palette/renderer.py:541). */
+typedef struct pnr_palette_frame_args {
+    pnr_nerf_frame_args base;
+    const float* embeddings_palette;   /* `encoder_palette` table (same offsets / level parameters as `encoder`) */
+    const float* embeddings_clip;      /* `encoder_clip` table (pred_clip only) */
+    const float* basis_color;          /* HOST [nb,3] */
+    const float* or_bias;              /* HOST [3 nb + 1] */
+    uint32_t num_basis, clip_dim;
+    int pred_clip;
+    float offsets_weight, view_dep_weight;
+    float* aux_map;                    /* [N, aux channels] out */
+} pnr_palette_frame_args;
+uint64_t pnr_palette_frame_workspace_bytes(uint32_t N, uint32_t num_basis, uint32_t clip_dim, int pred_clip);
+int pnr_palette_render_frame(const pnr_palette_frame_args* args, pnr_stream_t stream);
+
 /* Fused PaletteNeRF field + palette colour-basis composite (palette/network.py:156-280, palette/renderer.py:470-500,
  * inference branch without RegionEdit / Stylizer).  Split-fp16 matrix path.  All weights are row-major [out][in]
  * device fp32 pointers of the bias-free nn.Linear layers; offsets_radiance has a bias (passed to the forward call). */

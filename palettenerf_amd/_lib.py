@@ -47,12 +47,14 @@ SIGNATURES = {
     "pnr_palette_aux_channels": [_u32, _u32],
     "pnr_palette_field_pack": [_ptr, _ptr, _ptr],
     "pnr_palette_field_forward": [_ptr, _ptr],
+    "pnr_palette_frame_workspace_bytes": [_u32, _u32, _u32, _int],
+    "pnr_palette_render_frame": [_ptr, _ptr],
     "pnr_sh_encode_forward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr],
     "pnr_sh_encode_backward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr, _ptr],
     "pnr_rgb_to_hsv": [_u32, _ptr, _ptr, _ptr],
     "pnr_hsv_to_rgb": [_u32, _ptr, _ptr, _ptr],
 }
-_RESTYPES = {"pnr_error_string": ctypes.c_char_p, "pnr_scan_scratch_bytes": _u64, "pnr_nerf_field_packed_bytes": _u64, "pnr_occupancy_mip_bytes": _u64, "pnr_nerf_frame_workspace_bytes": _u64, "pnr_palette_field_packed_bytes": _u64,
+_RESTYPES = {"pnr_error_string": ctypes.c_char_p, "pnr_scan_scratch_bytes": _u64, "pnr_nerf_field_packed_bytes": _u64, "pnr_occupancy_mip_bytes": _u64, "pnr_nerf_frame_workspace_bytes": _u64, "pnr_palette_field_packed_bytes": _u64, "pnr_palette_frame_workspace_bytes": _u64,
              "pnr_palette_aux_channels": _u32}
 
 class NerfFrameArgs(ctypes.Structure):
@@ -61,6 +63,12 @@ class NerfFrameArgs(ctypes.Structure):
                 ("C", _u32), ("H", _u32), ("dt_gamma", _f32), ("max_steps", _u32), ("T_thresh", _f32), ("embeddings", _ptr), ("offsets", _ptr),
                 ("num_levels", _u32), ("S", _f32), ("base_resolution", _u32), ("gridtype", _u32), ("packed_weights", _ptr), ("field_precision", _int), ("density_scale", _f32),
                 ("weights_sum", _ptr), ("depth", _ptr), ("image", _ptr), ("workspace", _ptr), ("workspace_bytes", _u64), ("stats", _ptr), ("kernel_ms", _ptr)]
+
+
+class PaletteFrameArgs(ctypes.Structure):
+    """Mirror of `pnr_palette_frame_args` (include/pnr.h)."""
+    _fields_ = [("base", NerfFrameArgs), ("embeddings_palette", _ptr), ("embeddings_clip", _ptr), ("basis_color", _ptr), ("or_bias", _ptr),
+                ("num_basis", _u32), ("clip_dim", _u32), ("pred_clip", _int), ("offsets_weight", _f32), ("view_dep_weight", _f32), ("aux_map", _ptr)]
 
 
 class PaletteWeights(ctypes.Structure):

@@ -105,10 +105,14 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_march(FrameCtl* __restrict_
 
 // gridencoder.cu:75-175 for D = 3, C = 2, fp32, fused with GridEncoder.forward's (x + bound) / (2 bound)
 // (gridencoder/grid.py:142); rows from the control block; dead slots (delta == 0) are skipped.
+struct GridSet { const float* table[3]; float* enc[3]; };  // up to three hash tables (encoder, encoder_palette, encoder_clip): blockIdx.z
+
 __global__ void __launch_bounds__(256) k_frame_grid(const FrameCtl* __restrict__ ctl, const float* __restrict__ xyzs, const float* __restrict__ deltas,
-                                                    const float* __restrict__ table, const int32_t* __restrict__ offsets, LevelParams lp,
-                                                    float* __restrict__ enc, uint32_t level_stride, float bound, float two_bound, uint32_t gridtype) {
+                                                    GridSet gs, const int32_t* __restrict__ offsets, LevelParams lp,
+                                                    uint32_t level_stride, float bound, float two_bound, uint32_t gridtype) {
     if (ctl->done) return;
+    const float* __restrict__ table = gs.table[blockIdx.z];
+    float* __restrict__ enc = gs.enc[blockIdx.z];
     const uint32_t rows = (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step;
     const uint32_t level = blockIdx.y;
     const uint32_t off0 = (uint32_t)offsets[level];
@@ -192,12 +196,15 @@ __global__ void __launch_bounds__(kFieldThreads) k_frame_field(const FrameCtl* _
     }
 }
 
-// reference raymarching.cu:1025-1111 + the per-chunk survivor count of the compaction
+// reference raymarching.cu:1025-1111 (+ :1114-1185 for the packed aux row of the palette model: every channel
+// is composited with the SAME weights, starting from the weights_sum of BEFORE this iteration, exactly as the
+// reference's composite_rays_flex calls that precede composite_rays) + the per-chunk survivor count of the compaction
 __global__ void __launch_bounds__(kRayBlock) k_frame_composite(const FrameCtl* __restrict__ ctl, float T_thresh, int32_t* __restrict__ rays_alive,
                                                                float* __restrict__ rays_t, const float* __restrict__ sigmas,
                                                                const float* __restrict__ rgbs, const float* __restrict__ deltas,
                                                                float* __restrict__ weights_sum, float* __restrict__ depth, float* __restrict__ image,
-                                                               int32_t* __restrict__ scratch) {
+                                                               int32_t* __restrict__ scratch, const float* __restrict__ aux, float* __restrict__ aux_map,
+                                                               uint32_t aux_stride) {
     if (ctl->done) return;
     const uint32_t n_alive = (uint32_t)ctl->n_alive, n_step = (uint32_t)ctl->n_step;
     const uint32_t nchunks = (n_alive + kRayBlock - 1) / kRayBlock;
@@ -207,10 +214,46 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_composite(const FrameCtl* _
         int keep = 0;
         if (n < n_alive) {
             const int index = rays_alive[n];
+            const float ws0 = weights_sum[index];
+            if (aux) {  // 16-channel register chunks, recurrence re-run per chunk (identical weights)
+                float* out = aux_map + (size_t)index * aux_stride;
+                for (uint32_t c0 = 0; c0 < aux_stride; c0 += 16) {
+                    const float* s = sigmas + (size_t)n * n_step;
+                    const float* in = aux + (size_t)n * n_step * aux_stride + c0;
+                    const float* dl = deltas + (size_t)n * n_step * 2;
+                    float acc[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i += 4) {
+                        if (c0 + i < aux_stride) { const float4 v = *reinterpret_cast<const float4*>(out + c0 + i); acc[i] = v.x; acc[i + 1] = v.y; acc[i + 2] = v.z; acc[i + 3] = v.w; }
+                        else { acc[i] = acc[i + 1] = acc[i + 2] = acc[i + 3] = 0.0f; }
+                    }
+                    float ws = ws0;
+                    for (uint32_t step = 0; step < n_step; step++) {
+                        if (dl[0] == 0) break;
+                        const float alpha = 1.0f - __expf(-s[0] * dl[0]);
+                        const float T = 1.0f - ws;
+                        const float wgt = alpha * T;
+                        ws += wgt;
+#pragma unroll
+                        for (int i = 0; i < 16; i += 4) {
+                            if (c0 + i < aux_stride) {
+                                const float4 v = *reinterpret_cast<const float4*>(in + i);
+                                acc[i] = fmaf(wgt, v.x, acc[i]); acc[i + 1] = fmaf(wgt, v.y, acc[i + 1]);
+                                acc[i + 2] = fmaf(wgt, v.z, acc[i + 2]); acc[i + 3] = fmaf(wgt, v.w, acc[i + 3]);
+                            }
+                        }
+                        if (T < T_thresh) break;
+                        s++; in += aux_stride; dl += 2;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; i += 4)
+                        if (c0 + i < aux_stride) *reinterpret_cast<float4*>(out + c0 + i) = make_float4(acc[i], acc[i + 1], acc[i + 2], acc[i + 3]);
+                }
+            }
             const float* s = sigmas + (size_t)n * n_step;
             const float* c = rgbs + (size_t)n * n_step * 3;
             const float* dl = deltas + (size_t)n * n_step * 2;
-            float t = rays_t[index], ws = weights_sum[index], d = depth[index];
+            float t = rays_t[index], ws = ws0, d = depth[index];
             float r = image[index * 3], g = image[index * 3 + 1], b = image[index * 3 + 2];
             uint32_t step = 0;
             while (step < n_step) {
@@ -318,11 +361,12 @@ struct FrameWorkspace {
     FrameCtl* ctl;
     int32_t* alive[2];
     float *rays_t, *xyzs, *dirs, *deltas, *enc, *sigmas, *rgbs;
+    float *enc_pal, *enc_clip, *aux;  // palette model only
     int32_t* scratch;
     int32_t* partials;
     uint64_t bytes;
 };
-static FrameWorkspace carve(void* base, uint32_t N) {
+static FrameWorkspace carve(void* base, uint32_t N, uint32_t aux_stride = 0, bool with_clip = false) {
     FrameWorkspace w;
     uint64_t off = 0;
     auto take = [&](uint64_t nbytes) { char* p = base ? static_cast<char*>(base) + off : nullptr; off += align256(nbytes); return p; };
@@ -339,6 +383,12 @@ static FrameWorkspace carve(void* base, uint32_t N) {
     w.rgbs = reinterpret_cast<float*>(take(n * 12));
     w.scratch = reinterpret_cast<int32_t*>(take((kHdr + n / kRayBlock + 2) * 4));
     w.partials = reinterpret_cast<int32_t*>(take(2048 * 4));
+    w.enc_pal = w.enc_clip = w.aux = nullptr;
+    if (aux_stride) {
+        w.enc_pal = reinterpret_cast<float*>(take(n * 16 * 2 * 4));
+        if (with_clip) w.enc_clip = reinterpret_cast<float*>(take(n * 16 * 2 * 4));
+        w.aux = reinterpret_cast<float*>(take(n * aux_stride * 4));
+    }
     w.bytes = off;
     return w;
 }
@@ -350,8 +400,22 @@ using namespace pnr;
 extern "C" {
 
 uint64_t pnr_nerf_frame_workspace_bytes(uint32_t N) { return carve(nullptr, N).bytes; }
+uint64_t pnr_palette_frame_workspace_bytes(uint32_t N, uint32_t num_basis, uint32_t clip_dim, int pred_clip) {
+    return carve(nullptr, N, pnr_palette_aux_channels(num_basis, clip_dim), pred_clip != 0).bytes;
+}
 
-int pnr_nerf_render_frame(const pnr_nerf_frame_args* a, pnr_stream_t stream) {
+static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_frame_args* pal, pnr_stream_t stream);
+
+int pnr_nerf_render_frame(const pnr_nerf_frame_args* a, pnr_stream_t stream) { return render_frame_impl(a, nullptr, stream); }
+
+int pnr_palette_render_frame(const pnr_palette_frame_args* p, pnr_stream_t stream) {
+    if (!p) return PNR_ERR_INVALID;
+    if (p->num_basis < 1 || p->num_basis > 5 || p->clip_dim > 16) return PNR_ERR_UNSUPPORTED;
+    if (p->base.N && (!p->embeddings_palette || !p->basis_color || !p->or_bias || !p->aux_map || (p->pred_clip && !p->embeddings_clip))) return PNR_ERR_INVALID;
+    return render_frame_impl(&p->base, p, stream);
+}
+
+static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_frame_args* pal, pnr_stream_t stream) {
     if (!a) return PNR_ERR_INVALID;
     if (a->N == 0) return PNR_OK;
     if (!a->rays_o || !a->rays_d || !a->nears || !a->fars || !a->bitfield || !a->embeddings || !a->offsets || !a->packed_weights || !a->weights_sum ||
@@ -359,10 +423,26 @@ int pnr_nerf_render_frame(const pnr_nerf_frame_args* a, pnr_stream_t stream) {
         return PNR_ERR_INVALID;
     if (a->C == 0 || a->C > 16 || a->H == 0 || a->max_steps == 0 || a->num_levels != 16) return PNR_ERR_UNSUPPORTED;
     if (a->field_precision != PNR_FIELD_FP32 && a->field_precision != PNR_FIELD_F16X3) return PNR_ERR_UNSUPPORTED;
-    if (a->workspace_bytes < pnr_nerf_frame_workspace_bytes(a->N)) return PNR_ERR_INVALID;
+    if (pal && a->field_precision != PNR_FIELD_F16X3) return PNR_ERR_UNSUPPORTED;
+    const uint32_t aux_stride = pal ? pnr_palette_aux_channels(pal->num_basis, pal->clip_dim) : 0;
+    const bool with_clip = pal && pal->pred_clip;
     hipStream_t s = as_stream(stream);
     const uint32_t N = a->N;
-    FrameWorkspace w = carve(a->workspace, N);
+    FrameWorkspace w = carve(a->workspace, N, aux_stride, with_clip);
+    if (a->workspace_bytes < w.bytes) return PNR_ERR_INVALID;
+    if (pal && hipMemsetAsync(pal->aux_map, 0, (size_t)N * aux_stride * 4, s) != hipSuccess) return PNR_ERR_LAUNCH;
+    GridSet gs;
+    gs.table[0] = a->embeddings; gs.enc[0] = w.enc;
+    gs.table[1] = pal ? pal->embeddings_palette : nullptr; gs.enc[1] = w.enc_pal;
+    gs.table[2] = with_clip ? pal->embeddings_clip : nullptr; gs.enc[2] = w.enc_clip;
+    const uint32_t n_enc = pal ? (with_clip ? 3u : 2u) : 1u;
+    pnr_palette_field_args pf = {};
+    if (pal) {
+        pf.enc = w.enc; pf.enc_palette = w.enc_pal; pf.enc_clip = w.enc_clip; pf.level_stride = N; pf.dirs = w.dirs; pf.deltas = w.deltas;
+        pf.packed = a->packed_weights; pf.basis_color = pal->basis_color; pf.or_bias = pal->or_bias; pf.num_basis = pal->num_basis;
+        pf.clip_dim = pal->clip_dim; pf.pred_clip = pal->pred_clip; pf.density_scale = a->density_scale; pf.offsets_weight = pal->offsets_weight;
+        pf.view_dep_weight = pal->view_dep_weight; pf.aux_stride = aux_stride; pf.sigmas = w.sigmas; pf.rgbs = w.rgbs; pf.aux = w.aux;
+    }
 
     static FrameCtl* host_ctl = nullptr;  // pinned read-back slot (one in-flight frame per process)
     if (!host_ctl && hipHostMalloc(reinterpret_cast<void**>(&host_ctl), sizeof(FrameCtl), hipHostMallocDefault) != hipSuccess) return PNR_ERR_LAUNCH;
@@ -407,17 +487,21 @@ int pnr_nerf_render_frame(const pnr_nerf_frame_args* a, pnr_stream_t stream) {
             const uint32_t gx = cdiv(rows_ub, 256);
             hipEvent_t e0 = timing ? next_event() : nullptr, e1 = timing ? next_event() : nullptr;
             if (e0) (void)hipEventRecord(e0, s);
-            hipLaunchKernelGGL(k_frame_grid, dim3(gx < 1024u ? gx : 1024u, 16), dim3(256), 0, s, cur, w.xyzs, w.deltas, a->embeddings, a->offsets, lp, w.enc, N,
+            hipLaunchKernelGGL(k_frame_grid, dim3(gx < 1024u ? gx : 1024u, 16, n_enc), dim3(256), 0, s, cur, w.xyzs, w.deltas, gs, a->offsets, lp, N,
                                a->bound, 2.0f * a->bound, a->gridtype);
             if (e1) (void)hipEventRecord(e1, s);
-            if (a->field_precision == PNR_FIELD_FP32)
+            if (pal) {
+                pf.ctl = cur; pf.B = rows_ub;
+                const int rc = pnr_palette_field_forward(&pf, stream);
+                if (rc != PNR_OK) return rc;
+            } else if (a->field_precision == PNR_FIELD_FP32)
                 hipLaunchKernelGGL(k_frame_field<0>, dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas,
                                    a->packed_weights, a->density_scale, w.sigmas, w.rgbs);
             else
                 hipLaunchKernelGGL(k_frame_field<1>, dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas,
                                    a->packed_weights, a->density_scale, w.sigmas, w.rgbs);
             hipLaunchKernelGGL(k_frame_composite, gm, bm, 0, s, cur, a->T_thresh, alive_in, w.rays_t, w.sigmas, w.rgbs, w.deltas, a->weights_sum, a->depth,
-                               a->image, w.scratch);
+                               a->image, w.scratch, (const float*)w.aux, pal ? pal->aux_map : nullptr, aux_stride);
             hipLaunchKernelGGL(k_frame_scan, dim3(1), dim3(1024), 0, s, cur, nxt, w.scratch, N, a->max_steps, w.partials, gm.x);
             hipLaunchKernelGGL(k_frame_alive_write, gm, bm, 0, s, cur, alive_in, alive_out, w.scratch);
         }
@@ -435,7 +519,7 @@ int pnr_nerf_render_frame(const pnr_nerf_frame_args* a, pnr_stream_t stream) {
             if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) total += ms;
         }
         a->kernel_ms[0] = total;
-        a->kernel_ms[1] = (float)counted;
+        a->kernel_ms[1] = (float)counted * (float)n_enc;  // one k_frame_grid launch covers n_enc tables: count table-launches
     }
     if (a->stats) {
         a->stats[0] = (uint64_t)host_ctl->iterations;

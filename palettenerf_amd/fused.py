@@ -167,6 +167,62 @@ class PaletteFieldFused:
         return self._bc, self._bias
 
     @torch.no_grad()
+    def render_frame(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh):
+        """One PaletteNeRF inference frame through the device-driven loop (pnr_palette_render_frame).
+        Returns (weights_sum [N], depth [N], image [N,3], aux_map [N, aux_channels], stats); raw accumulations."""
+        from . import raymarching
+        m = self.model
+        N = rays_o.shape[0]
+        dev = rays_o.device
+        lib = _lib.load()
+        ws = torch.empty(N, dtype=torch.float32, device=dev)
+        depth = torch.empty(N, dtype=torch.float32, device=dev)
+        image = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        aux_map = torch.empty(N, self.aux_channels, dtype=torch.float32, device=dev)
+        nbytes = int(lib.pnr_palette_frame_workspace_bytes(N, self.nb, self.clip_dim, int(self.pred_clip)))
+        if getattr(self, "_ws", None) is None or self._ws.numel() < nbytes or self._ws.device != dev:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        mip = raymarching.occupancy_mip(m.density_bitfield, m.cascade, m.grid_size, m.bound)
+        enc = m.encoder
+        for other in (m.encoder_palette, m.encoder_clip):
+            if not torch.equal(other.offsets, enc.offsets) or other.per_level_scale != enc.per_level_scale:
+                raise RuntimeError("the three hash grids must share one level layout")
+        stats = (ctypes.c_uint64 * 4)()
+        kms = (ctypes.c_float * 2)()
+        bc, bias = self._host_params()
+        p = _lib.PaletteFrameArgs()
+        a = p.base
+        a.N = N
+        a.rays_o, a.rays_d = rays_o.data_ptr(), rays_d.data_ptr()
+        a.nears, a.fars = nears.data_ptr(), fars.data_ptr()
+        a.bitfield = m.density_bitfield.data_ptr()
+        a.mip = mip.data_ptr() if mip is not None else None
+        a.bound, a.C, a.H = float(m.bound), int(m.cascade), int(m.grid_size)
+        a.dt_gamma, a.max_steps, a.T_thresh = float(dt_gamma), int(max_steps), float(T_thresh)
+        a.embeddings = require(enc.embeddings.detach(), torch.float32, "embeddings").data_ptr()
+        a.offsets = enc.offsets.data_ptr()
+        a.num_levels, a.S, a.base_resolution, a.gridtype = enc.num_levels, float(np.log2(enc.per_level_scale)), enc.base_resolution, enc.gridtype_id
+        a.packed_weights = self._pack().data_ptr()
+        a.field_precision = 1
+        a.density_scale = float(m.density_scale)
+        a.weights_sum, a.depth, a.image = ws.data_ptr(), depth.data_ptr(), image.data_ptr()
+        a.workspace, a.workspace_bytes = self._ws.data_ptr(), nbytes
+        a.stats = ctypes.cast(stats, ctypes.c_void_p)
+        a.kernel_ms = ctypes.cast(kms, ctypes.c_void_p) if getattr(self, "time_grid_kernel", False) else None
+        p.embeddings_palette = require(m.encoder_palette.embeddings.detach(), torch.float32, "embeddings").data_ptr()
+        p.embeddings_clip = require(m.encoder_clip.embeddings.detach(), torch.float32, "embeddings").data_ptr() if self.pred_clip else None
+        p.basis_color, p.or_bias = ctypes.cast(bc, ctypes.c_void_p), ctypes.cast(bias, ctypes.c_void_p)
+        p.num_basis, p.clip_dim, p.pred_clip = self.nb, self.clip_dim, int(self.pred_clip)
+        p.offsets_weight, p.view_dep_weight = float(m.offsets_weight), float(m.view_dep_weight)
+        p.aux_map = aux_map.data_ptr()
+        for t, name in ((rays_o, "rays_o"), (rays_d, "rays_d"), (nears, "nears"), (fars, "fars")):
+            require(t, torch.float32, name)
+        rc = lib.pnr_palette_render_frame(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "pnr_palette_render_frame")
+        return ws, depth, image, aux_map, {"iterations": int(stats[0]), "rendered": int(stats[1]), "rows": int(stats[2]), "enqueued": int(stats[3]),
+                                           "grid_ms": float(kms[0]), "grid_launches": int(kms[1])}
+
+    @torch.no_grad()
     def __call__(self, x, d, deltas=None):
         """x [B,3] world positions, d [B,3] -> (sigmas [B] scaled by density_scale, rgbs [B,3], aux [B, aux_channels])."""
         m = self.model

@@ -454,7 +454,15 @@ class PaletteRenderer(_RendererBase):
             # must come last: the only composite that mutates rays_alive / rays_t / weights_sum (palette/renderer.py:517-519)
             raymarching.composite_rays(*a, st.rays_alive, st.rays_t, sigmas, rgbs, deltas, st.weights_sum, st.depth, st.image, T_thresh)
 
-        st = self._infer_loop(rays_o, rays_d, nears, fars, perturb, dt_gamma, max_steps, shade_fused if use_fused else shade)
+        native = use_fused and self.march_mode == "native" and not perturb
+        if native:  # device-driven loop: same schedule and arithmetic, no per-iteration host sync (pnr_palette_render_frame)
+            ws_n, depth_n, image_n, aux_map, stats = self._fused.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh)
+            st = _MarchState.__new__(_MarchState)
+            st.weights_sum, st.depth, st.image, st.n_samples = ws_n, depth_n, image_n, stats["rows"]
+            st.rendered = torch.tensor([stats["rendered"]], dtype=torch.int64, device=device)
+            results["iterations"], results["grid_ms"], results["grid_launches"] = stats["iterations"], stats["grid_ms"], stats["grid_launches"]
+        else:
+            st = self._infer_loop(rays_o, rays_d, nears, fars, perturb, dt_gamma, max_steps, shade_fused if use_fused else shade)
         if use_fused:  # unpack the composited aux row into the reference's maps
             direct_rgb_map, view_dep_rgb_map = aux_map[:, 0:3], aux_map[:, 3:6]
             basis_acc_map = aux_map[:, 6:6 + nb]

@@ -103,9 +103,9 @@ def test_palette_inference_frame_all_maps_and_edit(cuda, golden_dir, case):
     m = m.to(cuda).eval()
     put_scene(m, cuda)
     ro, rd = frame_rays(g, cuda)
-    for mode in ("compat", "device", "fused"):
+    for mode in ("compat", "device", "fused", "native"):
         m.march_mode = "device" if mode == "fused" else mode
-        m.fused_field = mode == "fused"
+        m.fused_field = mode in ("fused", "native")
         with torch.no_grad():
             r = m.render(ro, rd, dt_gamma=float(g["dt_gamma"]), perturb=False, max_steps=1024, T_thresh=1e-4, gui_mode=False)
         for k in ("image", "weights_sum", "clip_feat", "direct_rgb", "view_dep_rgb", "basis_rgb", "unscaled_basis_rgb", "basis_acc"):
