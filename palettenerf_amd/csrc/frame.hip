@@ -210,46 +210,42 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_composite(const FrameCtl* _
     const uint32_t nchunks = (n_alive + kRayBlock - 1) / kRayBlock;
     __shared__ int wsum[kRayBlock / PNR_WAVE];
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        if (aux) {
+            // Phase 1 (palette): the packed aux row.  16 lanes per ray, one float4 of channels per lane: a ray's row is one
+            // coalesced 208-byte read per sample and per map instead of a 208-byte-strided walk by a single thread.  Every
+            // lane re-derives the (cheap) weights; they start from the weights_sum of BEFORE this iteration because phase 2,
+            // which updates it, runs after the barrier.
+            const uint32_t q = threadIdx.x & 15u, nq = aux_stride / 4;
+            for (uint32_t r = threadIdx.x >> 4; r < kRayBlock; r += kRayBlock / 16) {
+                const uint32_t n = chunk * kRayBlock + r;
+                if (n >= n_alive || q >= nq) continue;
+                const int index = rays_alive[n];
+                const float* s = sigmas + (size_t)n * n_step;
+                const float* in = aux + (size_t)n * n_step * aux_stride + q * 4;
+                const float* dl = deltas + (size_t)n * n_step * 2;
+                float4* out = reinterpret_cast<float4*>(aux_map + (size_t)index * aux_stride) + q;
+                float4 acc = *out;
+                float ws = weights_sum[index];
+                for (uint32_t step = 0; step < n_step; step++) {
+                    if (dl[0] == 0) break;
+                    const float alpha = 1.0f - __expf(-s[0] * dl[0]);
+                    const float T = 1.0f - ws;
+                    const float wgt = alpha * T;
+                    ws += wgt;
+                    const float4 v = *reinterpret_cast<const float4*>(in);
+                    acc.x = fmaf(wgt, v.x, acc.x); acc.y = fmaf(wgt, v.y, acc.y); acc.z = fmaf(wgt, v.z, acc.z); acc.w = fmaf(wgt, v.w, acc.w);
+                    if (T < T_thresh) break;
+                    s++; in += aux_stride; dl += 2;
+                }
+                *out = acc;
+            }
+            __syncthreads();
+        }
         const uint32_t n = chunk * kRayBlock + threadIdx.x;
         int keep = 0;
         if (n < n_alive) {
             const int index = rays_alive[n];
             const float ws0 = weights_sum[index];
-            if (aux) {  // 16-channel register chunks, recurrence re-run per chunk (identical weights)
-                float* out = aux_map + (size_t)index * aux_stride;
-                for (uint32_t c0 = 0; c0 < aux_stride; c0 += 16) {
-                    const float* s = sigmas + (size_t)n * n_step;
-                    const float* in = aux + (size_t)n * n_step * aux_stride + c0;
-                    const float* dl = deltas + (size_t)n * n_step * 2;
-                    float acc[16];
-#pragma unroll
-                    for (int i = 0; i < 16; i += 4) {
-                        if (c0 + i < aux_stride) { const float4 v = *reinterpret_cast<const float4*>(out + c0 + i); acc[i] = v.x; acc[i + 1] = v.y; acc[i + 2] = v.z; acc[i + 3] = v.w; }
-                        else { acc[i] = acc[i + 1] = acc[i + 2] = acc[i + 3] = 0.0f; }
-                    }
-                    float ws = ws0;
-                    for (uint32_t step = 0; step < n_step; step++) {
-                        if (dl[0] == 0) break;
-                        const float alpha = 1.0f - __expf(-s[0] * dl[0]);
-                        const float T = 1.0f - ws;
-                        const float wgt = alpha * T;
-                        ws += wgt;
-#pragma unroll
-                        for (int i = 0; i < 16; i += 4) {
-                            if (c0 + i < aux_stride) {
-                                const float4 v = *reinterpret_cast<const float4*>(in + i);
-                                acc[i] = fmaf(wgt, v.x, acc[i]); acc[i + 1] = fmaf(wgt, v.y, acc[i + 1]);
-                                acc[i + 2] = fmaf(wgt, v.z, acc[i + 2]); acc[i + 3] = fmaf(wgt, v.w, acc[i + 3]);
-                            }
-                        }
-                        if (T < T_thresh) break;
-                        s++; in += aux_stride; dl += 2;
-                    }
-#pragma unroll
-                    for (int i = 0; i < 16; i += 4)
-                        if (c0 + i < aux_stride) *reinterpret_cast<float4*>(out + c0 + i) = make_float4(acc[i], acc[i + 1], acc[i + 2], acc[i + 3]);
-                }
-            }
             const float* s = sigmas + (size_t)n * n_step;
             const float* c = rgbs + (size_t)n * n_step * 3;
             const float* dl = deltas + (size_t)n * n_step * 2;

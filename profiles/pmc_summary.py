@@ -8,6 +8,8 @@ import os
 import sys
 
 KERNELS = {"k_grid_fwd": "grid_fwd", "k_nerf_field_fwd": "nerf_field_fwd", "k_march_rays": "march_rays", "k_composite_rays": "composite_rays",
+           "k_frame_grid": "frame_grid", "k_frame_field": "frame_field", "k_palette_field_fwd": "palette_field", "k_frame_march": "frame_march",
+           "k_frame_composite": "frame_composite",
            "k_fused": "fused"}
 
 
