@@ -18,6 +18,13 @@ constexpr int kPackedFloats = kC2 + 1 * 32 * 64;  // 12288 floats = 48 KiB
 // feature held by accumulator register r of a lane in half h (D layout of the 32x32 MFMA family)
 __host__ __device__ constexpr int frag_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// lane-half select that stays in registers: hipcc turns `h ? a[8 + j] : a[j]` over a local array into an indexed
+// scratch load; a bitfield insert cannot be rewritten that way and is exact.
+__device__ __forceinline__ float select_half(int h, float lower, float upper) {
+    const uint32_t m = 0u - (uint32_t)h;  // 0 or all-ones
+    return __uint_as_float((__float_as_uint(lower) & ~m) | (__float_as_uint(upper) & m));
+}
+
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
 #pragma unroll
@@ -130,7 +137,7 @@ __device__ __forceinline__ FieldOut nerf_field_tile_f16x3(const unsigned char* _
     {
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = h ? sh[8 + j] : sh[j];
+        for (int j = 0; j < 8; j++) v[j] = select_half(h, sh[j], sh[8 + j]);
         split8(v, bh[0], bl[0]);
     }
     split_frag(g, 0, bh[1], bl[1]);
@@ -191,7 +198,7 @@ __device__ __forceinline__ FieldOut nerf_field_tile_f32(const float* __restrict_
     f32x16 c0 = zero16(), c1 = zero16();
 #pragma unroll
     for (int s = 0; s < 8; s++) {
-        const float b = h ? sh[8 + s] : sh[s];
+        const float b = select_half(h, sh[s], sh[8 + s]);
         c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kC0 + s * 64 + lane], b, c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[kC0 + (16 + s) * 64 + lane], b, c1, 0, 0, 0);
     }

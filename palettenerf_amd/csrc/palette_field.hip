@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
             float sh[16], v[8];
             sh_eval<4>(dx, dy, dz, sh);
 #pragma unroll
-            for (int j = 0; j < 8; j++) v[j] = h ? sh[8 + j] : sh[j];
+            for (int j = 0; j < 8; j++) v[j] = select_half(h, sh[j], sh[8 + j]);
             split8(v, bh[0], bl[0]);
         }
         t0 = mma3(zero16(), w + (PB_C0 + 0) * kF16BlockBytes, bh[0], bl[0], lane);
