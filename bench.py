@@ -71,7 +71,10 @@ def cpu_baseline(args):
     saved = (renderer.raymarching, pge.GridEncoder, psh.SHEncoder)
     renderer.raymarching, pge.GridEncoder, psh.SHEncoder = rm, ge.GridEncoder, sh.SHEncoder
     try:
-        m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=args.density_scale, min_near=0.2)
+        if args.model == "nerf":
+            m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=args.density_scale, min_near=0.2)
+        else:
+            m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True, density_scale=args.density_scale, min_near=0.2)
         scene.seed_field_(m, 0)
         grid = scene.brick_density_grid()
         m.density_grid.copy_(torch.from_numpy(grid))
@@ -87,13 +90,13 @@ def cpu_baseline(args):
         ro, rd = ro[:, idx].contiguous(), rd[:, idx].contiguous()
         t0 = time.perf_counter()
         with torch.no_grad():
-            r = m.render(ro, rd, perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+            r = m.render(ro, rd, perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4, **({"gui_mode": False} if args.model == "palette" else {}))
         dt = time.perf_counter() - t0
         n = int(r["rendered"].item())
     finally:
         renderer.raymarching, pge.GridEncoder, psh.SHEncoder = saved
     return {"value": n / dt, "unit": "samples/s", "cores": 1, "kind": "port",
-            "sample": f"centre {c}x{c} crop of the {H}x{W} frame ({idx.numel()} rays, {n} rendered samples, {dt:.1f} s; C oracle ops + torch CPU MLP, 1 thread; "
+            "sample": f"centre {c}x{c} crop of the {H}x{W} frame ({idx.numel()} rays, {n} rendered samples, {dt:.1f} s; -m {args.model}, C oracle ops + torch CPU MLP, 1 thread; "
                       f"host has {os.cpu_count()} cores)"}
 
 
@@ -182,6 +185,12 @@ def main():
         if m.march_mode == "native":  # events recorded inside pnr_nerf_render_frame around every k_frame_grid launch
             k_ms, k_units, n_launches, kernel_name = native_ms, rows * n_tables, native_launches, "k_frame_grid (device-driven frame loop)"
         achieved = (k_units * per_sample) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic = None  # HBM-side bytes per launch from the committed PMC passes of this exact workload (profiles/r01_traffic.json)
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if m.march_mode == "native" and H == 800 and args.density_scale == 100.0 and not args.fp16 and world == 1 and os.path.exists(tpath):
+            t = json.load(open(tpath)).get(args.model)
+            if t:
+                traffic = t["traffic_bytes_per_launch"] / n_tables
         out = {
             "metric": "rendered_samples_per_sec", "value": total_rendered / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
@@ -191,9 +200,10 @@ def main():
                        "evaluated_rows_per_frame_rank0": rows // args.steps, "density_scale": args.density_scale, "march_mode": m.march_mode, "fused_field": bool(getattr(m, "fused_field", False)), "field_precision": args.field_precision,
                        "parallelism": f"ray-tiles x{world} + all_gather" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": n_launches,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": n_launches,
                          "avg_launch_ms": k_ms / max(1, n_launches), "avg_rows_per_launch": k_units / max(1, n_launches),
-                         "algorithmic_bytes_per_row": per_sample},
+                         "algorithmic_bytes_per_row": per_sample,
+                         "algorithmic_bytes_per_launch": per_sample * k_units / max(1, n_launches)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
