@@ -105,9 +105,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("PNR_BENCH_FORCE_DIST") == "1"  # the latter exercises the RCCL path on a 1-GPU box
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -135,7 +138,7 @@ def main():
     def frame():
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=args.fp16):
             r = m.render(ro, rd, **kw)
-        if world > 1:
+        if use_dist:
             local = torch.cat([r["image"][0], r["depth"][0][:, None], r["weights_sum"][:, None]], dim=1)
             full = pdist.gather_frame(local, idx, n_max, H, W)
             return r, full
@@ -143,7 +146,7 @@ def main():
 
     for _ in range(args.warmup):
         frame()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     prof = _torch_glue.profile_kernels(["pnr_grid_encode_forward"]) if rank == 0 else None
@@ -163,12 +166,12 @@ def main():
         native_ms += r.get("grid_ms", 0.0)
         native_launches += r.get("grid_launches", 0)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     _torch_glue.profile_kernels(None)
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rendered, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
@@ -208,7 +211,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
