@@ -135,13 +135,13 @@ def main():
     if args.model == "palette":
         kw["gui_mode"] = False
 
+    gatherer = pdist.FrameGatherer(H, W, 5, device) if use_dist else None
+
     def frame():
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=args.fp16):
             r = m.render(ro, rd, **kw)
-        if use_dist:
-            local = torch.cat([r["image"][0], r["depth"][0][:, None], r["weights_sum"][:, None]], dim=1)
-            full = pdist.gather_frame(local, idx, n_max, H, W)
-            return r, full
+        if use_dist:  # one all-gather of the packed (rgb, depth, alpha) rows; every rank ends up with the full frame
+            return r, gatherer([r["image"][0], r["depth"][0][:, None], r["weights_sum"][:, None]])
         return r, None
 
     for _ in range(args.warmup):

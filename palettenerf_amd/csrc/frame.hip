@@ -461,7 +461,8 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     };
     const bool timing = a->kernel_ms != nullptr;
     uint32_t alive_ub = N;   // host-side upper bound of n_alive (it only shrinks)
-    uint32_t chunk = 4;      // iterations enqueued between two looks at the control block
+    uint32_t chunk = 8;      // iterations enqueued between two looks at the control block (grows for long, translucent marches)
+    uint32_t looks = 0;
     int iter = 0;
     for (;;) {
         for (uint32_t k = 0; k < chunk; k++, iter++) {
@@ -505,7 +506,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
         if (hipStreamSynchronize(s) != hipSuccess) return PNR_ERR_LAUNCH;
         if (host_ctl->done) break;
         alive_ub = (uint32_t)host_ctl->n_alive;
-        if (chunk < 16) chunk *= 2;
+        if (++looks >= 4 && chunk < 64) chunk *= 2;
     }
     if (timing) {  // only the iterations that did work (the tail of the last chunk are no-op launches)
         float total = 0.0f;

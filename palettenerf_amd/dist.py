@@ -6,8 +6,9 @@ Partitioning: the frame is cut into TILE x TILE pixel tiles assigned round-robin
 varies by >100x between empty-space and object rays; contiguous stripes would leave most ranks
 idle).  Every rank renders its rays with the unmodified single-GPU loop -- there is no collective
 on the data path of the march -- then ONE all_gather_into_tensor per frame moves the packed
-[n_per_rank, K] fp32 buffer (K = 5 for rgb+depth+alpha).  Payload at 800x800, K=5: 1.6 MB per rank;
-latency-bound, not bandwidth-bound, on 7 x 153 GB/s xGMI links.
+[n_max, K] fp32 buffer (K = 5 for rgb+depth+alpha).  Payload at 800x800, K=5: 1.6 MB per rank;
+latency-bound, not bandwidth-bound, on 7 x 153 GB/s xGMI links.  The tile map is static, so the
+un-tiling is a precomputed gather index: no masks, no host synchronisation per frame.
 """
 import torch
 import torch.distributed as dist
@@ -32,18 +33,37 @@ def shard_indices(H, W, rank, world_size, tile=TILE):
     return idx, int(counts.max())
 
 
+class FrameGatherer:
+    """Static plan of one frame's all-gather: send/receive buffers and the pixel -> gathered-row index."""
+
+    def __init__(self, H, W, K, device, group=None, tile=TILE):
+        self.H, self.W, self.K, self.group = H, W, K, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        owner = tile_assignment(H, W, self.world, tile)
+        counts = torch.bincount(owner, minlength=self.world)
+        self.n_max = int(counts.max())
+        # position of pixel p inside its owner's (ascending) index list
+        local_pos = torch.empty(H * W, dtype=torch.int64)
+        for r in range(self.world):
+            sel = torch.nonzero(owner == r, as_tuple=False).reshape(-1)
+            local_pos[sel] = torch.arange(sel.numel())
+            if r == self.rank:
+                self.idx = sel
+        self.gather_index = (owner * self.n_max + local_pos).to(device)
+        self.send = torch.zeros(self.n_max, K, dtype=torch.float32, device=device)
+        self.recv = torch.empty(self.world * self.n_max, K, dtype=torch.float32, device=device)
+
+    def __call__(self, parts):
+        """parts: tensors [n_local, k_i] (sum k_i == K), rows ordered like self.idx.  Returns the [H*W, K] frame on every rank."""
+        n = self.idx.numel()
+        torch.cat(parts, dim=1, out=self.send[:n])
+        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+        return self.recv.index_select(0, self.gather_index)
+
+
 def gather_frame(local, idx, n_max, H, W, group=None):
-    """local: [n_local, K] fp32 per-ray outputs of this rank (rows ordered like `idx`).
-    Returns the assembled [H*W, K] frame on every rank (one all_gather_into_tensor)."""
-    world = dist.get_world_size(group)
-    K = local.shape[1]
-    send = torch.zeros(n_max, K + 1, dtype=torch.float32, device=local.device)
-    send[: local.shape[0], :K] = local
-    send[: local.shape[0], K] = idx.to(local.device, torch.float32) + 1.0  # 0 marks padding; exact for H*W < 2^24
-    recv = torch.empty(world * n_max, K + 1, dtype=torch.float32, device=local.device)
-    dist.all_gather_into_tensor(recv, send, group=group)
-    pix = recv[:, K].long() - 1
-    valid = pix >= 0
-    frame = torch.zeros(H * W, K, dtype=torch.float32, device=local.device)
-    frame[pix[valid]] = recv[valid, :K]
-    return frame
+    """One-shot form of FrameGatherer (builds the plan every call; tests and small scripts)."""
+    g = FrameGatherer(H, W, local.shape[1], local.device, group)
+    assert g.n_max == n_max and torch.equal(g.idx, idx.cpu())
+    return g([local])

@@ -33,6 +33,11 @@ def _worker(rank, world, port, H, W, K):
         full_ref = torch.arange(H * W * K, dtype=torch.float32).reshape(H * W, K) * 0.5 + 1.0
         frame = pdist.gather_frame(full_ref[idx].clone(), idx, n_max, H, W)
         assert torch.equal(frame, full_ref), f"rank {rank}: assembled frame differs"
+        g = pdist.FrameGatherer(H, W, K, torch.device("cpu"))
+        for rep in range(2):  # the static plan is reusable frame after frame
+            ref = full_ref + rep
+            frame = g([ref[g.idx, :3].clone(), ref[g.idx, 3:4].clone(), ref[g.idx, 4:].clone()])
+            assert torch.equal(frame, ref), f"rank {rank}: FrameGatherer frame differs"
     finally:
         dist.destroy_process_group()
 
