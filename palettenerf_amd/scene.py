@@ -89,21 +89,28 @@ def intrinsics_from_fov(H, W, camera_angle_x=LEGO_CAMERA_ANGLE_X):
 
 @torch.no_grad()
 def get_rays(poses, intrinsics, H, W):
-    """Full-image rays: poses [B,4,4] c2w, intrinsics (fx,fy,cx,cy) -> rays_o, rays_d [B, H*W, 3]."""
+    """Full-image rays: poses [B,4,4] c2w, intrinsics (fx,fy,cx,cy) -> rays_o, rays_d [B, H*W, 3] (on poses.device).
+
+    Same formulas as the reference's get_rays (pixel centres +0.5, normalise, rotate), but evaluated in float64 with
+    element-wise NumPy arithmetic and rounded once to float32: torch's CPU kernels (vectorised norm, BLAS matmul) are not
+    bit-reproducible across host CPUs, and a last-bit change of a direction changes march counts at full frame size."""
     device = poses.device
-    B = poses.shape[0]
+    P = poses.detach().cpu().numpy().astype(np.float64)
+    B = P.shape[0]
     fx, fy, cx, cy = [float(v) for v in intrinsics]
-    jj, ii = torch.meshgrid(torch.linspace(0, H - 1, H, device=device), torch.linspace(0, W - 1, W, device=device), indexing="ij")
-    i = ii.reshape(1, H * W).expand(B, H * W) + 0.5
-    j = jj.reshape(1, H * W).expand(B, H * W) + 0.5
-    zs = torch.ones_like(i)
-    xs = (i - cx) / fx * zs
-    ys = (j - cy) / fy * zs
-    directions = torch.stack((xs, ys, zs), dim=-1)
-    directions = directions / torch.norm(directions, dim=-1, keepdim=True)
-    rays_d = directions @ poses[:, :3, :3].transpose(-1, -2)
-    rays_o = poses[..., :3, 3][..., None, :].expand_as(rays_d)
-    return rays_o.contiguous(), rays_d.contiguous()
+    jj, ii = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    xs = ((ii.reshape(-1) + 0.5) - cx) / fx
+    ys = ((jj.reshape(-1) + 0.5) - cy) / fy
+    inv = 1.0 / np.sqrt(xs * xs + ys * ys + 1.0)
+    xs, ys, zs = xs * inv, ys * inv, inv
+    rays_d = np.empty((B, H * W, 3), dtype=np.float32)
+    rays_o = np.empty((B, H * W, 3), dtype=np.float32)
+    for b in range(B):
+        R = P[b, :3, :3]
+        for k in range(3):
+            rays_d[b, :, k] = (xs * R[k, 0] + ys * R[k, 1] + zs * R[k, 2]).astype(np.float32)
+            rays_o[b, :, k] = np.float32(P[b, k, 3])
+    return torch.from_numpy(rays_o).to(device), torch.from_numpy(rays_d).to(device)
 
 
 def seed_field_(model, seed=0, table_range=0.5):
