@@ -46,6 +46,103 @@ class _MarchState:
         self.rendered = torch.zeros(1, dtype=torch.int64, device=device)  # march-emitted samples (delta > 0), device-side
 
 
+def _sweep_blocks(G, S, device):
+    """Yield int32 [n,3] cell coordinates of the G^3 grid in S^3 blocks (x-major inside a block)."""
+    axes = torch.arange(G, dtype=torch.int32, device=device).split(S)
+    for xs in axes:
+        for ys in axes:
+            for zs in axes:
+                xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
+                yield torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], dim=-1)
+
+
+class _OccupancyMaintenance:
+    """Producer of the density bitfield the march consumes: the reference's
+    NeRFRenderer.mark_untrained_grid / update_extra_state (nerf/renderer.py:395-561), on the HIP morton / packbits ops."""
+
+    @torch.no_grad()
+    def mark_untrained_grid(self, poses, intrinsic, S=64):
+        """Cells no training camera sees (or that sit closer than min_near) get density -1 and are never sampled."""
+        if not self.cuda_ray:
+            return
+        poses = torch.as_tensor(poses)
+        B = poses.shape[0]
+        fx, fy, cx, cy = intrinsic
+        G = self.grid_size
+        dev = self.density_bitfield.device
+        count = torch.zeros_like(self.density_grid)
+        too_close = torch.zeros_like(self.density_grid)
+        poses = poses.to(dev)
+        for coords in _sweep_blocks(G, S, dev):
+            indices = raymarching.morton3D(coords).long()
+            world_xyzs = (2 * coords.float() / (G - 1) - 1).unsqueeze(0)
+            for cas in range(self.cascade):
+                bound = min(2 ** cas, self.bound)
+                half_grid_size = bound / G
+                cas_world_xyzs = world_xyzs * (bound - half_grid_size)
+                for head in range(0, B, S):
+                    tail = min(head + S, B)
+                    cam_xyzs = (cas_world_xyzs - poses[head:tail, :3, 3].unsqueeze(1)) @ poses[head:tail, :3, :3]
+                    mask_z = cam_xyzs[:, :, 2] > 0
+                    mask_x = torch.abs(cam_xyzs[:, :, 0]) < cx / fx * cam_xyzs[:, :, 2] + half_grid_size * 2
+                    mask_y = torch.abs(cam_xyzs[:, :, 1]) < cy / fy * cam_xyzs[:, :, 2] + half_grid_size * 2
+                    seen = mask_z & mask_x & mask_y
+                    count[cas, indices] += seen.sum(0).reshape(-1)
+                    too_close[cas, indices] += ((cam_xyzs[:, :, 2] < self.min_near) & seen).sum(0).reshape(-1)
+                    if getattr(self, "filter_close_point", False):
+                        too_close[cas, indices] += (cam_xyzs.norm(dim=-1) < self.min_near).sum(0).reshape(-1)
+        count = count * (too_close == 0).long()
+        self.density_grid[count == 0] = -1
+        return int((count == 0).sum())
+
+    def _query_cells(self, cas, coords):
+        """sigma * density_scale at a jittered point inside every given cell of cascade `cas`."""
+        G = self.grid_size
+        xyzs = 2 * coords.float() / (G - 1) - 1
+        bound = min(2 ** cas, self.bound)
+        half_grid_size = bound / G
+        cas_xyzs = xyzs * (bound - half_grid_size)
+        cas_xyzs += (torch.rand_like(cas_xyzs) * 2 - 1) * half_grid_size
+        sigmas = self.density(cas_xyzs)["sigma"].reshape(-1).detach().float()
+        return sigmas * self.density_scale
+
+    @torch.no_grad()
+    def update_extra_state(self, decay=0.95, S=128):
+        """EMA-max update of density_grid from the field, repack the bitfield, refresh mean_count (nerf/renderer.py:467-561)."""
+        if not self.cuda_ray:
+            return
+        G = self.grid_size
+        dev = self.density_bitfield.device
+        tmp_grid = -torch.ones_like(self.density_grid)
+        if self.iter_density < 16:  # full sweeps while the field is young
+            for coords in _sweep_blocks(G, S, dev):
+                indices = raymarching.morton3D(coords).long()
+                for cas in range(self.cascade):
+                    tmp_grid[cas, indices] = self._query_cells(cas, coords)
+        else:  # afterwards: G^3/4 uniform cells + G^3/4 currently occupied cells per cascade
+            n = G ** 3 // 4
+            for cas in range(self.cascade):
+                coords = torch.randint(0, G, (n, 3), device=dev)
+                indices = raymarching.morton3D(coords).long()
+                occ_indices = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
+                if occ_indices.numel() > 0:
+                    occ_indices = occ_indices[torch.randint(0, occ_indices.shape[0], [n], dtype=torch.long, device=dev)]
+                    occ_coords = raymarching.morton3D_invert(occ_indices)
+                    indices = torch.cat([indices, occ_indices], dim=0)
+                    coords = torch.cat([coords, occ_coords], dim=0)
+                tmp_grid[cas, indices] = self._query_cells(cas, coords)
+        valid_mask = (self.density_grid >= 0) & (tmp_grid >= 0)
+        self.density_grid[valid_mask] = torch.maximum(self.density_grid[valid_mask] * decay, tmp_grid[valid_mask])
+        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
+        self.iter_density += 1
+        density_thresh = min(self.mean_density, self.density_thresh)
+        self.density_bitfield = raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
+        total_step = min(16, self.local_step)
+        if total_step > 0:
+            self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+        self.local_step = 0
+
+
 class _RendererBase(nn.Module):
     def _init_march_state(self, bound, cuda_ray, density_scale, min_near, density_thresh, bg_radius):
         self.bound = bound
@@ -125,7 +222,7 @@ class _RendererBase(nn.Module):
         return self.run_cuda(rays_o, rays_d, **kwargs)
 
 
-class NeRFRenderer(_RendererBase):
+class NeRFRenderer(_OccupancyMaintenance, _RendererBase):
     """nerf/renderer.py:61-125"""
 
     def __init__(self, bound=1, cuda_ray=False, density_scale=1, min_near=0.2, density_thresh=0.01, bg_radius=-1, filter_close_point=False):

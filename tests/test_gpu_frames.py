@@ -146,3 +146,55 @@ def test_palette_training_step(cuda, golden_dir, case):
     rows = torch.from_numpy(g["grad_emb_rows"]).to(cuda)
     close(m.encoder_palette.embeddings.grad[rows], g["grad_emb_vals"], tol=2e-3 * scale(g["grad_emb_vals"]), what="grad_emb_palette")
     assert (m.encoder.embeddings.grad is None) == bool(g["encoder_grad_is_none"])  # sigma is detached: geometry frozen
+
+
+def test_occupancy_maintenance_produces_the_bitfield(cuda):
+    """f1: update_extra_state / mark_untrained_grid on the HIP morton + packbits ops.  With an analytic density the swept
+    grid, the EMA-max, the threshold and the packed bitfield can all be checked in closed form."""
+    m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=2.0, density_thresh=0.5, min_near=0.2).to(cuda)
+
+    def density(x):  # sigma = 1 inside the sphere |x| < 0.9, else 0: piecewise constant away from the surface
+        return {"sigma": (x.norm(dim=-1) < 0.9).float()}
+
+    m.density = density
+    m.local_step, m.step_counter[:3, 0] = 3, torch.tensor([100, 200, 330], dtype=torch.int32, device=cuda)
+    m.update_extra_state()
+    assert m.iter_density == 1 and m.local_step == 0 and m.mean_count == 210
+    G = 128
+    full = torch.stack(torch.meshgrid(*[torch.arange(G, dtype=torch.int32, device=cuda)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    idx = raymarching.morton3D(full).long()
+    for cas in range(2):
+        bound = min(2 ** cas, 2)
+        centre = (2 * full.float() / (G - 1) - 1) * (bound - bound / G)
+        r = centre.norm(dim=-1)
+        margin = 2 * bound / G * 1.8  # a jittered point stays within half a cell (x sqrt 3) of the centre
+        inside, outside = r < 0.9 - margin, r > 0.9 + margin
+        assert bool((m.density_grid[cas, idx[inside]] == 2.0).all())   # sigma * density_scale
+        assert bool((m.density_grid[cas, idx[outside]] == 0.0).all())
+    mean_density = float(m.density_grid.clamp(min=0).mean())
+    assert abs(m.mean_density - mean_density) < 1e-6
+    want = scene.packbits_np(m.density_grid.cpu().numpy(), min(mean_density, 0.5))
+    assert np.array_equal(m.density_bitfield.cpu().numpy(), want)
+    assert raymarching.occupancy_mip(m.density_bitfield, 2, 128, 2.0) is not None
+    # EMA-max: a second sweep with a vanished field decays instead of clearing
+    m.density = lambda x: {"sigma": torch.zeros(x.shape[0], device=x.device)}
+    before = m.density_grid.clone()
+    m.update_extra_state(decay=0.5)
+    assert torch.allclose(m.density_grid, before * 0.5)
+    # partial-update branch (iter_density >= 16) keeps the invariants
+    m.iter_density = 16
+    m.update_extra_state()
+    assert m.iter_density == 17 and bool((m.density_grid >= 0).all())
+    # mark_untrained_grid: one camera at +z looking down -z sees the cone in front of it only
+    m2 = network.NeRFNetwork(bound=2, cuda_ray=True, min_near=0.2).to(cuda)
+    pose = torch.eye(4)
+    pose[:3, 3] = torch.tensor([0.0, 0.0, 3.0])
+    pose[:3, 2] = torch.tensor([0.0, 0.0, -1.0])  # forward = -z
+    pose[:3, 0] = torch.tensor([-1.0, 0.0, 0.0])
+    n_marked = m2.mark_untrained_grid(pose[None], (100.0, 100.0, 50.0, 50.0))
+    assert 0 < n_marked < 2 * G ** 3
+    behind = raymarching.morton3D(torch.tensor([[64, 64, 127]], dtype=torch.int32, device=cuda)).long()  # z ~ +1 * (bound): in front of the camera? no: camera at z=3 looks to -z, so all cells have z < 3
+    centre_cell = raymarching.morton3D(torch.tensor([[64, 64, 64]], dtype=torch.int32, device=cuda)).long()
+    assert float(m2.density_grid[0, centre_cell]) == 0.0       # seen: stays trainable
+    corner = raymarching.morton3D(torch.tensor([[0, 0, 127]], dtype=torch.int32, device=cuda)).long()
+    assert float(m2.density_grid[1, corner]) == -1.0           # far off-axis next to the camera plane: never seen
