@@ -279,6 +279,10 @@ int pnr_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, u
 /* replace rgb_to_hsv / hsv_to_rgb, palette/src/palette_func.h, palette.cu:135-149 */
 int pnr_rgb_to_hsv(uint32_t n, const float* input, float* output, pnr_stream_t stream);
 int pnr_hsv_to_rgb(uint32_t n, const float* input, float* output, pnr_stream_t stream);
+/* device counterpart of compute_RGB_histogram (CPU C++ in the reference, palette/src/bindings.cpp:40-91):
+ * colors_rgb [n,3], weights [n] -> bin_weights double[2^(3 bpc)] (zeroed by the callee), bin_centers float[2^(3 bpc), 3] */
+int pnr_rgb_histogram(const float* colors_rgb, const float* weights, uint32_t n, int bits_per_channel, double* bin_weights,
+                      float* bin_centers, pnr_stream_t stream);
 
 #ifdef __cplusplus
 }

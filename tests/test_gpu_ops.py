@@ -500,3 +500,18 @@ def test_fused_palette_field_matches_torch_module(cuda, pred_clip):
         np.testing.assert_allclose(host(c), host(rgbs), rtol=0, atol=5e-6)
         np.testing.assert_allclose(host(aux[:, :50]), host(want_aux), rtol=0, atol=5e-6)
         assert float(aux[:, 50:].abs().max()) == 0.0
+
+
+def test_rgb_histogram_matches_oracle(cuda):
+    rng = np.random.default_rng(70)
+    rgb = (rng.random((200003, 3)) * 1.2 - 0.1).astype(np.float32)   # includes values below 0 and above 0.999 (clamped)
+    w = rng.random(200003).astype(np.float32)
+    for bpc in (1, 3, 5):
+        bw, bc = palette_utils.compute_RGB_histogram(rgb, w, bpc)
+        obw, obc = oracle.compute_RGB_histogram(rgb, w, bpc)
+        assert bw.dtype == np.float64 and bc.dtype == np.float32 and bw.shape == (1 << (3 * bpc),) and bc.shape == (1 << (3 * bpc), 3)
+        np.testing.assert_array_equal(bc, obc)
+        np.testing.assert_allclose(bw, obw, rtol=1e-12)   # fp64 atomics: summation order differs from the serial loop
+        assert abs(bw.sum() - w.astype(np.float64).sum()) < 1e-6
+    bw, bc = palette_utils.compute_RGB_histogram(np.zeros((0, 3), np.float32), np.zeros(0, np.float32), 2)
+    assert bw.sum() == 0 and bc.shape == (64, 3)
