@@ -198,3 +198,46 @@ def test_occupancy_maintenance_produces_the_bitfield(cuda):
     assert float(m2.density_grid[0, centre_cell]) == 0.0       # seen: stays trainable
     corner = raymarching.morton3D(torch.tensor([[0, 0, 127]], dtype=torch.int32, device=cuda)).long()
     assert float(m2.density_grid[1, corner]) == -1.0           # far off-axis next to the camera plane: never seen
+
+
+@pytest.mark.parametrize("model_kind", ["nerf", "palette"])
+def test_native_loop_edge_cases_match_reference_style_loop(cuda, model_kind):
+    """Device-driven loop vs the host-driven mirror on awkward inputs: a single ray, rays that all miss the scene box,
+    a step budget that ends the loop early, a translucent field (hundreds of iterations, n_step growing to 8)."""
+    if model_kind == "nerf":
+        m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=1.0, min_near=0.2)
+    else:
+        m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True, density_scale=1.0, min_near=0.2)
+    scene.seed_field_(m, 11)
+    m = m.to(cuda).eval()
+    put_scene(m, cuda)
+    m.count_rendered = True
+    pose = torch.from_numpy(scene.lookat_pose())[None]
+    ro, rd = scene.get_rays(pose, scene.intrinsics_from_fov(48, 48), 48, 48)
+    ro, rd = ro.to(cuda), rd.to(cuda)
+
+    def both(ro_, rd_, **kw):
+        out = {}
+        for mode in ("compat", "native"):
+            m.march_mode, m.fused_field = mode, mode == "native"
+            with torch.no_grad():
+                out[mode] = m.render(ro_, rd_, perturb=False, T_thresh=1e-4, **kw)
+        a, b = out["compat"], out["native"]
+        assert int(a["rendered"].item()) == int(b["rendered"].item()), kw
+        for k in ("image", "weights_sum"):
+            close(b[k], a[k].cpu().numpy(), tol=1e-4, what=k)
+        close(b["depth"], a["depth"].cpu().numpy(), tol=3e-4, what="depth")   # NaN pattern (0/0 for missed rays) must agree too
+        return a, b
+
+    a, b = both(ro[:, 1000:1001].contiguous(), rd[:, 1000:1001].contiguous(), dt_gamma=0, max_steps=1024)       # N = 1
+    a, b = both(ro[:, :7].contiguous(), rd[:, :7].contiguous(), dt_gamma=0, max_steps=1024)                     # N < one wave
+    away = ro.clone()
+    away[..., 1] += 50.0                                                                                             # every ray misses the +-2 box
+    a, b = both(away, rd, dt_gamma=0, max_steps=1024)
+    assert int(b["rendered"].item()) == 0 and float(b["weights_sum"].abs().max()) == 0.0
+    a, b = both(ro, rd, dt_gamma=0, max_steps=16)                                                                 # step budget ends the loop
+    assert int(b["rendered"].item()) > 0
+    m.density_scale = 0.02                                                                                           # translucent: long marches
+    a, b = both(ro, rd, dt_gamma=1.0 / 128, max_steps=1024)
+    a, b = both(ro, rd, dt_gamma=0, max_steps=1024)
+    assert b["iterations"] > 40
