@@ -5,8 +5,11 @@ A "step" is one inference frame of the occupancy-march path over a batch of synt
 configs[1] = NeRF-synthetic-lego geometry, `-m nerf` inference, 800x800, scene S0 (SURVEY.md 8d /
 Appendix B), seeded random-init field, inputs resident in HBM when the timed region starts.
 
-N > 1: the frame's rays are sharded over ranks in interleaved 32x32 tiles; every frame ends with one
-all_gather_into_tensor (RCCL) of the packed per-ray (rgb, depth, alpha) -- strong scaling.
+N > 1: rays are sharded over ranks in interleaved 32x32 pixel tiles (no collective on the march data path); every step ends
+with ONE all_gather_into_tensor (RCCL) of the packed per-ray (rgb, depth, alpha) rows, after which every rank holds the full
+output.  --scaling weak (default): a step renders N views of the scene (800x800 each, azimuths spread over the orbit), i.e.
+per-GPU work is fixed -- each rank gets 1/N of the tiles of EVERY view, which also balances the load.  --scaling strong: a step
+is ONE 800x800 frame split N ways (latency-bound below ~2.5 ms/frame: see DESIGN.md section 4).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -39,6 +42,7 @@ def parse():
     ap.add_argument("--mode", choices=["compat", "device", "fused", "native"], default=None)
     ap.add_argument("--field-precision", choices=["f16x3", "fp32"], default="f16x3",
                     help="matrix path of the fused field: split-fp16 (3 MFMAs per product, ~2^-22 relative) or exact fp32 MFMA")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-crop", type=int, default=320, help="side of the centre crop timed on the CPU oracle")
     return ap.parse_args()
@@ -127,15 +131,19 @@ def main():
     if mode in ("fused", "native") and args.model == "palette" and not args.fp16:
         m.fused_field = True
     H = W = args.res
-    pose = torch.from_numpy(scene.lookat_pose())[None]
-    ro, rd = scene.get_rays(pose, scene.intrinsics_from_fov(H, W), H, W)
-    idx, n_max = pdist.shard_indices(H, W, rank, world)
+    n_views = world if args.scaling == "weak" else 1
+    import numpy as np
+    poses = torch.from_numpy(np.stack([scene.lookat_pose(azimuth_deg=45.0 + 360.0 * v / n_views) for v in range(n_views)]))
+    ro, rd = scene.get_rays(poses, scene.intrinsics_from_fov(H, W), H, W)          # [n_views, H*W, 3]
+    ro, rd = ro.reshape(1, n_views * H * W, 3), rd.reshape(1, n_views * H * W, 3)  # the views stacked vertically: one (n_views*H) x W image
+    VH = n_views * H
+    idx, n_max = pdist.shard_indices(VH, W, rank, world)
     ro, rd = ro[:, idx].contiguous().to(device), rd[:, idx].contiguous().to(device)
     kw = dict(perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
     if args.model == "palette":
         kw["gui_mode"] = False
 
-    gatherer = pdist.FrameGatherer(H, W, 5, device) if use_dist else None
+    gatherer = pdist.FrameGatherer(VH, W, 5, device) if use_dist else None
 
     def frame():
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=args.fp16):
@@ -196,12 +204,12 @@ def main():
                 traffic = t["traffic_bytes_per_launch"] / n_tables
         out = {
             "metric": "rendered_samples_per_sec", "value": total_rendered / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f16" if args.fp16 else "f32", "data": "synthetic",
-            "config": {"workload": f"configs[{1 if args.model == 'nerf' else 2}]: NeRF-synthetic lego geometry (scene S0), -m {args.model} inference, {H}x{W}, 1 frame/step",
-                       "rays_per_frame": H * W, "rendered_samples_per_frame": total_rendered // args.steps,
-                       "evaluated_rows_per_frame_rank0": rows // args.steps, "density_scale": args.density_scale, "march_mode": m.march_mode, "fused_field": bool(getattr(m, "fused_field", False)), "field_precision": args.field_precision,
-                       "parallelism": f"ray-tiles x{world} + all_gather" if world > 1 else "single GPU"},
+            "config": {"workload": f"configs[{1 if args.model == 'nerf' else 2}]: NeRF-synthetic lego geometry (scene S0), -m {args.model} inference, {H}x{W}, {n_views} view(s)/step",
+                       "rays_per_step": n_views * H * W, "rendered_samples_per_step": total_rendered // args.steps,
+                       "evaluated_rows_per_step_rank0": rows // args.steps, "density_scale": args.density_scale, "march_mode": m.march_mode, "fused_field": bool(getattr(m, "fused_field", False)), "field_precision": args.field_precision,
+                       "parallelism": f"32x32 ray tiles of {n_views} view(s) round-robin over {world} GPUs + one all_gather/step" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": n_launches,
                          "avg_launch_ms": k_ms / max(1, n_launches), "avg_rows_per_launch": k_units / max(1, n_launches),
