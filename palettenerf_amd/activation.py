@@ -1,21 +1,24 @@
-"""activation.py of the reference (activation.py:5-17): exp with a clamped backward."""
+"""Density activation of the fields: exp() with a clamped gradient (what the reference calls trunc_exp, activation.py:5-17)."""
 import torch
-from torch.autograd import Function
 from torch.amp import custom_bwd, custom_fwd
+from torch.autograd import Function
 
 
-class _trunc_exp(Function):
+class _TruncExp(Function):
+    """y = exp(x) in fp32; dy/dx is evaluated at clamp(x, -15, 15) so that a runaway logit cannot produce an infinite gradient."""
+
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, x):
-        ctx.save_for_backward(x)
-        return torch.exp(x)
+    def forward(ctx, logits):
+        ctx.save_for_backward(logits)
+        return logits.exp()
 
     @staticmethod
     @custom_bwd(device_type="cuda")
-    def backward(ctx, g):
-        x = ctx.saved_tensors[0]
-        return g * torch.exp(x.clamp(-15, 15))
+    def backward(ctx, grad_out):
+        (logits,) = ctx.saved_tensors
+        return grad_out * logits.clamp(min=-15.0, max=15.0).exp()
 
 
-trunc_exp = _trunc_exp.apply
+def trunc_exp(x):
+    return _TruncExp.apply(x)

@@ -18,48 +18,54 @@ _gridtype_to_id = {"hash": 0, "tiled": 1}
 _DTYPE_ID = {torch.float32: 0, torch.float16: 1}
 
 
+def level_offsets(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size, align_corners=False):
+    """Row offset of every level inside the shared table (same sizing rule as the reference, gridencoder/grid.py:111-121):
+    a level holds min(2^log2_hashmap_size, (res [+1])^D) rows rounded up to a multiple of 8."""
+    res = np.ceil(base_resolution * per_level_scale ** np.arange(num_levels)).astype(np.int64)
+    side = res if align_corners else res + 1
+    rows = np.minimum(2 ** log2_hashmap_size, side.astype(object) ** input_dim).astype(np.int64)
+    rows = (rows + 7) // 8 * 8
+    return np.concatenate([[0], np.cumsum(rows)]).astype(np.int32)
+
+
 class _grid_encode(Function):
-    """gridencoder/grid.py:19-84"""
+    """(inputs [B,D] in [0,1], embeddings [rows,C], offsets [L+1]) -> [B, L*C]; same positional signature as the reference's
+    `_grid_encode` (gridencoder/grid.py:19-84).  The native kernels work level-major ([L,B,C])."""
 
     @staticmethod
     @custom_fwd(device_type="cuda")
     def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0, align_corners=False):
         inputs = inputs.contiguous()
         B, D = inputs.shape
-        L = offsets.shape[0] - 1
-        C = embeddings.shape[1]
-        S = np.log2(per_level_scale)
-        H = base_resolution
-        # manual autocast handling, as the reference (grid.py:36-39): only the table goes to half
+        L, C = offsets.shape[0] - 1, embeddings.shape[1]
+        S, H = np.log2(per_level_scale), base_resolution
         if torch.is_autocast_enabled() and C % 2 == 0:
-            embeddings = embeddings.to(torch.half)
+            embeddings = embeddings.to(torch.half)  # under autocast only the TABLE goes to half (gridencoder/grid.py:36-39)
         if embeddings.dtype not in _DTYPE_ID:
             raise RuntimeError("embeddings must be a float32 or float16 tensor")
         embeddings = embeddings.contiguous()
-        outputs = torch.empty(L, B, C, device=inputs.device, dtype=embeddings.dtype)
-        dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=embeddings.dtype) if calc_grad_inputs else None
-        call("pnr_grid_encode_forward", ptr(require(inputs, torch.float32, "inputs")), ptr(require(embeddings, embeddings.dtype, "embeddings")),
-             ptr(require(offsets, torch.int32, "offsets")), ptr(outputs), _u32(B), _u32(D), _u32(C), _u32(L), _f32(S), _u32(H), ptr(dy_dx),
-             _u32(gridtype), _int(int(align_corners)), _int(_DTYPE_ID[embeddings.dtype]), units=B)
-        outputs = outputs.permute(1, 0, 2).reshape(B, L * C)
+        table_dtype = embeddings.dtype
+        level_major = torch.empty(L, B, C, device=inputs.device, dtype=table_dtype)
+        dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=table_dtype) if calc_grad_inputs else None
+        call("pnr_grid_encode_forward", ptr(require(inputs, torch.float32, "inputs")), ptr(require(embeddings, table_dtype, "embeddings")),
+             ptr(require(offsets, torch.int32, "offsets")), ptr(level_major), _u32(B), _u32(D), _u32(C), _u32(L), _f32(S), _u32(H), ptr(dy_dx),
+             _u32(gridtype), _int(int(align_corners)), _int(_DTYPE_ID[table_dtype]), units=B)
         ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
-        ctx.dims = [B, D, C, L, S, H, gridtype]
-        ctx.align_corners = align_corners
-        return outputs
+        ctx.meta = (B, D, C, L, S, H, gridtype, bool(align_corners))
+        return level_major.permute(1, 0, 2).reshape(B, L * C)
 
     @staticmethod
     @custom_bwd(device_type="cuda")
     def backward(ctx, grad):
         inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
-        B, D, C, L, S, H, gridtype = ctx.dims
-        align_corners = ctx.align_corners
-        grad = grad.view(B, L, C).permute(1, 0, 2).contiguous().to(embeddings.dtype)
-        grad_embeddings = torch.zeros_like(embeddings)
+        B, D, C, L, S, H, gridtype, align_corners = ctx.meta
+        grad_level_major = grad.view(B, L, C).permute(1, 0, 2).contiguous().to(embeddings.dtype)
+        grad_embeddings = torch.zeros_like(embeddings)  # the scatter accumulates into it
         grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if dy_dx is not None else None
-        call("pnr_grid_encode_backward", ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets), ptr(grad_embeddings), _u32(B), _u32(D),
+        call("pnr_grid_encode_backward", ptr(grad_level_major), ptr(inputs), ptr(embeddings), ptr(offsets), ptr(grad_embeddings), _u32(B), _u32(D),
              _u32(C), _u32(L), _f32(S), _u32(H), ptr(dy_dx), ptr(grad_inputs), _u32(gridtype), _int(int(align_corners)),
              _int(_DTYPE_ID[embeddings.dtype]))
-        if dy_dx is not None:
+        if grad_inputs is not None:
             grad_inputs = grad_inputs.to(inputs.dtype)
         return grad_inputs, grad_embeddings, None, None, None, None, None, None
 
@@ -68,52 +74,39 @@ grid_encode = _grid_encode.apply
 
 
 class GridEncoder(nn.Module):
-    """gridencoder/grid.py:91-153 -- same constructor, attributes, parameter/buffer names and init."""
+    """Multiresolution hash / tiled grid with the reference's constructor, attributes and state_dict layout
+    (parameter `embeddings` [rows, level_dim] ~ U(-1e-4, 1e-4), buffer `offsets` int32 [L+1]; gridencoder/grid.py:91-153)."""
 
     def __init__(self, input_dim=3, num_levels=16, level_dim=4, per_level_scale=2, base_resolution=16, log2_hashmap_size=19,
                  desired_resolution=None, gridtype="hash", align_corners=False):
         super().__init__()
-        if desired_resolution is not None:
+        if desired_resolution is not None:  # geometric progression from base_resolution to desired_resolution
             per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
-        self.input_dim = input_dim
-        self.num_levels = num_levels
-        self.level_dim = level_dim
-        self.per_level_scale = per_level_scale
-        self.log2_hashmap_size = log2_hashmap_size
-        self.base_resolution = base_resolution
+        self.input_dim, self.num_levels, self.level_dim = input_dim, num_levels, level_dim
+        self.per_level_scale, self.base_resolution, self.log2_hashmap_size = per_level_scale, base_resolution, log2_hashmap_size
         self.output_dim = num_levels * level_dim
-        self.gridtype = gridtype
-        self.gridtype_id = _gridtype_to_id[gridtype]
-        self.align_corners = align_corners
-
-        offsets, offset = [], 0
+        self.gridtype, self.gridtype_id, self.align_corners = gridtype, _gridtype_to_id[gridtype], align_corners
         self.max_params = 2 ** log2_hashmap_size
-        for i in range(num_levels):
-            resolution = int(np.ceil(base_resolution * per_level_scale ** i))
-            params_in_level = min(self.max_params, (resolution if align_corners else resolution + 1) ** input_dim)
-            params_in_level = int(np.ceil(params_in_level / 8) * 8)
-            offsets.append(offset)
-            offset += params_in_level
-        offsets.append(offset)
-        self.register_buffer("offsets", torch.from_numpy(np.array(offsets, dtype=np.int32)))
-        self.n_params = offsets[-1] * level_dim
-        self.embeddings = nn.Parameter(torch.empty(offset, level_dim))
+        offsets = level_offsets(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size, align_corners)
+        self.register_buffer("offsets", torch.from_numpy(offsets))
+        self.n_params = int(offsets[-1]) * level_dim
+        self.embeddings = nn.Parameter(torch.empty(int(offsets[-1]), level_dim))
         self.reset_parameters()
 
     def reset_parameters(self):
-        std = 1e-4
-        self.embeddings.data.uniform_(-std, std)
+        self.embeddings.data.uniform_(-1e-4, 1e-4)
 
     def __repr__(self):
+        finest = int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))
         return (f"GridEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
-                f"resolution={self.base_resolution} -> {int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))} "
-                f"per_level_scale={self.per_level_scale:.4f} params={tuple(self.embeddings.shape)} gridtype={self.gridtype} "
-                f"align_corners={self.align_corners}")
+                f"resolution={self.base_resolution} -> {finest} per_level_scale={self.per_level_scale:.4f} "
+                f"params={tuple(self.embeddings.shape)} gridtype={self.gridtype} align_corners={self.align_corners}")
 
     def forward(self, inputs, bound=1):
-        inputs = (inputs + bound) / (2 * bound)
-        prefix_shape = list(inputs.shape[:-1])
-        inputs = inputs.view(-1, self.input_dim)
-        outputs = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution, inputs.requires_grad,
+        """inputs [..., input_dim] in [-bound, bound] -> [..., num_levels * level_dim]"""
+        unit = (inputs + bound) / (2 * bound)
+        lead = list(unit.shape[:-1])
+        flat = unit.view(-1, self.input_dim)
+        encoded = grid_encode(flat, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution, flat.requires_grad,
                               self.gridtype_id, self.align_corners)
-        return outputs.view(prefix_shape + [self.output_dim])
+        return encoded.view(lead + [self.output_dim])

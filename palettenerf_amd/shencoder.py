@@ -1,12 +1,11 @@
-"""Spherical-harmonics direction encoder -- same API as the reference's
-shencoder/sphere_harmonics.py (`_sh_encoder`, `sh_encode`, `SHEncoder`), backed by
-pnr_sh_encode_{forward,backward}."""
+"""Real spherical-harmonics direction encoder with the reference's operator surface (`_sh_encoder`, `sh_encode`, `SHEncoder`;
+shencoder/sphere_harmonics.py), evaluated by pnr_sh_encode_{forward,backward} (degree 1..8, fp32)."""
 import ctypes
 
 import torch
 import torch.nn as nn
-from torch.autograd import Function
 from torch.amp import custom_bwd, custom_fwd
+from torch.autograd import Function
 
 from ._torch_glue import call, ptr, require
 
@@ -14,56 +13,49 @@ _u32 = ctypes.c_uint32
 
 
 class _sh_encoder(Function):
-    """shencoder/sphere_harmonics.py:14-55"""
+    """inputs [B,3] -> [B, degree^2]; with calc_grad_inputs the analytic Jacobian [B, 3*degree^2] is kept for backward."""
 
     @staticmethod
-    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)  # directions are always encoded in fp32
     def forward(ctx, inputs, degree, calc_grad_inputs=False):
-        inputs = inputs.contiguous()
-        B, input_dim = inputs.shape
-        output_dim = degree ** 2
-        outputs = torch.empty(B, output_dim, dtype=inputs.dtype, device=inputs.device)
-        dy_dx = torch.empty(B, input_dim * output_dim, dtype=inputs.dtype, device=inputs.device) if calc_grad_inputs else None
-        call("pnr_sh_encode_forward", ptr(require(inputs, torch.float32, "inputs")), ptr(outputs), _u32(B), _u32(input_dim), _u32(degree),
-             ptr(dy_dx))
-        ctx.save_for_backward(inputs, dy_dx)
-        ctx.dims = [B, input_dim, degree]
-        return outputs
+        dirs = require(inputs.contiguous(), torch.float32, "inputs")
+        n, dim = dirs.shape
+        width = degree * degree
+        basis = torch.empty(n, width, dtype=torch.float32, device=dirs.device)
+        jac = torch.empty(n, dim * width, dtype=torch.float32, device=dirs.device) if calc_grad_inputs else None
+        call("pnr_sh_encode_forward", ptr(dirs), ptr(basis), _u32(n), _u32(dim), _u32(degree), ptr(jac))
+        ctx.save_for_backward(dirs, jac)
+        ctx.shape = (n, dim, degree)
+        return basis
 
     @staticmethod
     @custom_bwd(device_type="cuda")
     def backward(ctx, grad):
-        inputs, dy_dx = ctx.saved_tensors
-        if dy_dx is None:
+        dirs, jac = ctx.saved_tensors
+        if jac is None:
             return None, None, None
-        grad = grad.contiguous()
-        B, input_dim, degree = ctx.dims
-        grad_inputs = torch.zeros_like(inputs)
-        call("pnr_sh_encode_backward", ptr(require(grad, torch.float32, "grad")), ptr(inputs), _u32(B), _u32(input_dim), _u32(degree),
-             ptr(dy_dx), ptr(grad_inputs))
-        return grad_inputs, None, None
+        n, dim, degree = ctx.shape
+        grad_dirs = torch.zeros_like(dirs)  # the kernel accumulates into it
+        call("pnr_sh_encode_backward", ptr(require(grad.contiguous(), torch.float32, "grad")), ptr(dirs), _u32(n), _u32(dim), _u32(degree), ptr(jac),
+             ptr(grad_dirs))
+        return grad_dirs, None, None
 
 
 sh_encode = _sh_encoder.apply
 
 
 class SHEncoder(nn.Module):
-    """shencoder/sphere_harmonics.py:61-86"""
-
     def __init__(self, input_dim=3, degree=4):
         super().__init__()
-        self.input_dim = input_dim
-        self.degree = degree
-        self.output_dim = degree ** 2
-        assert self.input_dim == 3, "SH encoder only support input dim == 3"
-        assert self.degree > 0 and self.degree <= 8, "SH encoder only supports degree in [1, 8]"
+        assert input_dim == 3, "SH encoder only support input dim == 3"
+        assert 0 < degree <= 8, "SH encoder only supports degree in [1, 8]"
+        self.input_dim, self.degree, self.output_dim = input_dim, degree, degree ** 2
 
     def __repr__(self):
         return f"SHEncoder: input_dim={self.input_dim} degree={self.degree}"
 
     def forward(self, inputs, size=1):
-        inputs = inputs / size
-        prefix_shape = list(inputs.shape[:-1])
-        inputs = inputs.reshape(-1, self.input_dim)
-        outputs = sh_encode(inputs, self.degree, inputs.requires_grad)
-        return outputs.reshape(prefix_shape + [self.output_dim])
+        """inputs [..., 3] in [-size, size] -> [..., degree^2]"""
+        scaled = inputs / size
+        flat = scaled.reshape(-1, self.input_dim)
+        return sh_encode(flat, self.degree, flat.requires_grad).reshape(list(scaled.shape[:-1]) + [self.output_dim])
