@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--field-precision", choices=["f16x3", "fp32"], default="f16x3",
                     help="matrix path of the fused field: split-fp16 (3 MFMAs per product, ~2^-22 relative) or exact fp32 MFMA")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--ray-order", choices=["tile8", "tile4", "tile16", "morton", "rowmajor"], default="tile8", help="initial order of the alive list in the native loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-crop", type=int, default=320, help="side of the centre crop timed on the CPU oracle")
     return ap.parse_args()
@@ -166,6 +167,15 @@ def main():
     if timed_native and getattr(m, "_fused", None) is None:
         from palettenerf_amd.fused import PaletteFieldFused
         m._fused = PaletteFieldFused(m)
+    if m.march_mode == "native" and args.ray_order != "rowmajor":
+        from palettenerf_amd.fused import tile_ray_order
+        if getattr(m, "_fused", None) is None:
+            from palettenerf_amd.fused import PaletteFieldFused
+            m._fused = PaletteFieldFused(m)
+        m._fused.ray_order = tile_ray_order(idx, W, {"tile8": 8, "tile4": 4, "tile16": 16, "morton": 0}[args.ray_order]).to(device)   # idx: row-major pixel ids (of the stacked views) this rank renders
+        for _ in range(2):
+            frame()                                               # re-warm with the final ordering
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         # HIP events around every grid-encode launch cost ~6 us each (two per iteration): instrument the launches of the
@@ -212,7 +222,7 @@ def main():
             "vs_baseline": None, "dtype": "f16" if args.fp16 else "f32", "data": "synthetic",
             "config": {"workload": f"configs[{1 if args.model == 'nerf' else 2}]: NeRF-synthetic lego geometry (scene S0), -m {args.model} inference, {H}x{W}, {n_views} view(s)/step",
                        "rays_per_step": n_views * H * W, "rendered_samples_per_step": total_rendered // args.steps,
-                       "evaluated_rows_per_step_rank0": rows // args.steps, "density_scale": args.density_scale, "march_mode": m.march_mode, "fused_field": bool(getattr(m, "fused_field", False)), "field_precision": args.field_precision,
+                       "evaluated_rows_per_step_rank0": rows // args.steps, "density_scale": args.density_scale, "march_mode": m.march_mode, "fused_field": bool(getattr(m, "fused_field", False)), "field_precision": args.field_precision, "ray_order": args.ray_order,
                        "parallelism": f"32x32 ray tiles of {n_views} view(s) round-robin over {world} GPUs + one all_gather/step" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": n_launches,

@@ -17,6 +17,7 @@ LIB = os.path.join(HERE, "libpnr_hip.so")
 ARCH = "gfx950"
 # -ffp-contract=off: the canonical scalar spec uses explicit fmaf() only.
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("PNR_EXTRA_HIPCC_FLAGS", "").split()   # experiment builds only (e.g. -DPNR_MARCH_STATS)
 
 
 def hipcc():

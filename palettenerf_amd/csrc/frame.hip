@@ -37,10 +37,13 @@ __device__ __forceinline__ int schedule_n_step(int N, int n_alive) {  // nerf/re
 
 __global__ void __launch_bounds__(kRayBlock) k_frame_init(uint32_t N, const float* __restrict__ nears, int32_t* __restrict__ alive,
                                                           float* __restrict__ rays_t, float* __restrict__ weights_sum, float* __restrict__ depth,
-                                                          float* __restrict__ image, FrameCtl* __restrict__ ctl) {
+                                                          float* __restrict__ image, FrameCtl* __restrict__ ctl, const int32_t* __restrict__ ray_order) {
     const uint32_t i = blockIdx.x * kRayBlock + threadIdx.x;
     if (i < N) {
-        alive[i] = (int32_t)i;
+        // initial alive list: identity (the reference's arange) or a caller-supplied permutation.  Per-ray results do not
+        // depend on the slot a ray occupies (no perturbation on this path); a tile-ordered list keeps the 64 rays of a
+        // wave spatially compact, which is what the hash-grid gathers and the march like.
+        alive[i] = ray_order ? ray_order[i] : (int32_t)i;
         rays_t[i] = nears[i];
         weights_sum[i] = 0.0f; depth[i] = 0.0f;
         image[i * 3] = 0.0f; image[i * 3 + 1] = 0.0f; image[i * 3 + 2] = 0.0f;
@@ -54,6 +57,9 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_init(uint32_t N, const floa
 
 // reference raymarching.cu:907-1011, n_alive / n_step from the control block; also writes the delta == 0
 // sentinel of unfilled slots (the reference relies on zero-initialised buffers) and counts emitted samples.
+#ifdef PNR_MARCH_STATS
+__device__ unsigned long long g_march_stats[8];  // probes, empty probes, (unused), ray-launches
+#endif
 template <bool MIP, bool POW2>
 __global__ void __launch_bounds__(kRayBlock) k_frame_march(FrameCtl* __restrict__ ctl, const int32_t* __restrict__ rays_alive,
                                                            const float* __restrict__ rays_t, const float* __restrict__ rays_o,
@@ -74,11 +80,19 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_march(FrameCtl* __restrict_
         float* pd = dirs + (size_t)n * n_step * 3;
         float* pl = deltas + (size_t)n * n_step * 2;
         float t = rays_t[index];
-        const float far = clip_far_to_box(c, fars[index]);
+        const BoxHit bh = clip_to_box(c, fars[index]);
+        const float far = bh.far;
         t = fmaf(clampf(t * c.dt_gamma, c.dt_min, c.dt_max), 0.0f, t);  // perturb == False on the inference path
         float last_t = t, x, y, z, dt;
+        t = skip_to_box<MIP && POW2>(c, bh, t);
         uint32_t step = 0;
+#ifdef PNR_MARCH_STATS
+        unsigned long long probes = 0, empties = 0;
+#endif
         while (t < far && step < n_step) {
+#ifdef PNR_MARCH_STATS
+            probes++;
+#endif
             if (march_probe<MIP, POW2>(c, t, x, y, z, dt)) {
                 px[0] = x; px[1] = y; px[2] = z;
                 pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
@@ -87,7 +101,19 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_march(FrameCtl* __restrict_
                 last_t = t;
                 px += 3; pd += 3; pl += 2; step++;
             }
+#ifdef PNR_MARCH_STATS
+            else empties++;
+#endif
         }
+#ifdef PNR_MARCH_STATS
+        const int so = ctl->iterations == 0 ? 0 : 4;
+        atomicAdd(&g_march_stats[so + 0], probes); atomicAdd(&g_march_stats[so + 1], empties); atomicAdd(&g_march_stats[so + 3], 1ull);
+        {   // wave-level: max probes over the wave (what the wave actually executes)
+            unsigned long long mx = probes;
+            for (int off = 32; off > 0; off >>= 1) { unsigned long long o = __shfl_xor(mx, off, 64); mx = o > mx ? o : mx; }
+            if ((threadIdx.x & 63) == 0) atomicAdd(&g_march_stats[so + 2], mx);
+        }
+#endif
         emitted += step;
         for (; step < n_step; step++) { pl[0] = 0.0f; pl[1] = 0.0f; pl += 2; }
     }
@@ -451,7 +477,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     const uint32_t* mip = static_cast<const uint32_t*>(a->mip);
 
     hipLaunchKernelGGL(k_frame_init, dim3(cdiv(N, kRayBlock)), dim3(kRayBlock), 0, s, N, a->nears, w.alive[0], w.rays_t, a->weights_sum, a->depth,
-                       a->image, w.ctl);
+                       a->image, w.ctl, a->ray_order);
     // optional live timing of the roofline kernel: HIP events on the launch stream around every k_frame_grid launch
     static std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
@@ -528,3 +554,12 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
 }
 
 }  // extern "C"
+
+#ifdef PNR_MARCH_STATS
+extern "C" int pnr_debug_march_stats(unsigned long long* out, int reset) {
+    hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pnr::g_march_stats), 64) != hipSuccess) return -3;
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(pnr::g_march_stats), z, 64); }
+    return 0;
+}
+#endif

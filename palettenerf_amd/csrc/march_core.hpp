@@ -2,6 +2,7 @@
 // and frame.hip (device-driven frame loop).
 #pragma once
 #include "pnr_common.hpp"
+#include "lattice.hpp"
 #include <float.h>
 #include <string.h>
 
@@ -73,18 +74,70 @@ __device__ __forceinline__ void ctx_init(RayCtx& c, const float* __restrict__ o,
     c.box = mip_lds ? reinterpret_cast<const float*>(mip_lds + 2 * p.mip_words) : nullptr;
 }
 
-// Parameter beyond which the ray is outside the occupied box for good (never larger than `far`).
-// Any NaN in the slab arithmetic (0 * inf) disables the clip for that ray.
-__device__ __forceinline__ float clip_far_to_box(const RayCtx& c, float far) {
-    if (!c.box) return far;
+// Slab test of the ray against the occupied box.  `far`: parameter beyond which the ray is outside the box for good
+// (never larger than the far passed in).  `t_in` and the entry plane (coordinate `face` on axis `axis`, the LAST slab
+// the ray enters) feed skip_to_box().  Any NaN in the slab arithmetic (0 * inf) disables both for that ray.
+struct BoxHit { float far, t_in, face, o, rd; bool entry_valid; };
+
+__device__ __forceinline__ BoxHit clip_to_box(const RayCtx& c, float far) {
+    BoxHit h; h.far = far; h.t_in = -FLT_MAX; h.face = 0.0f; h.o = 0.0f; h.rd = 0.0f; h.entry_valid = false;
+    if (!c.box) return h;
     const float ax = (c.box[0] - c.ox) * c.rdx, bx = (c.box[3] - c.ox) * c.rdx;
     const float ay = (c.box[1] - c.oy) * c.rdy, by = (c.box[4] - c.oy) * c.rdy;
     const float az = (c.box[2] - c.oz) * c.rdz, bz = (c.box[5] - c.oz) * c.rdz;
-    if (ax != ax || bx != bx || ay != ay || by != by || az != az || bz != bz) return far;
-    const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    if (ax != ax || bx != bx || ay != ay || by != by || az != az || bz != bz) return h;
+    const float ex = fminf(ax, bx), ey = fminf(ay, by), ez = fminf(az, bz);
+    const float t_in = fmaxf(fmaxf(ex, ey), ez);
     const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    if (t_in > t_out) return -FLT_MAX;            // the ray never touches the occupied box
-    return fminf(far, fmaf(fabsf(t_out), 1e-5f, t_out));  // B already carries a two-cell margin; this only absorbs slab-test rounding
+    if (t_in > t_out) { h.far = -FLT_MAX; return h; }   // the ray never touches the occupied box
+    h.far = fminf(far, fmaf(fabsf(t_out), 1e-5f, t_out));  // B already carries a two-cell margin; this only absorbs slab-test rounding
+    h.t_in = t_in; h.entry_valid = true;
+    if (ex >= ey && ex >= ez) { h.face = ax <= bx ? c.box[0] : c.box[3]; h.o = c.ox; h.rd = c.rdx; }
+    else if (ey >= ez)        { h.face = ay <= by ? c.box[1] : c.box[4]; h.o = c.oy; h.rd = c.rdy; }
+    else                      { h.face = az <= bz ? c.box[2] : c.box[5]; h.o = c.oz; h.rd = c.rdz; }
+    return h;
+}
+__device__ __forceinline__ float clip_far_to_box(const RayCtx& c, float far) { return clip_to_box(c, far).far; }
+
+// Exact jump over the empty space in front of the occupied box (POW2 configurations with an aligned box only).
+//
+// Let P be the entry plane of the last slab the ray enters (axis a, coordinate `face`), b its crossing parameter.  B's
+// faces lie on the cell grid of the coarsest cascade, which every finer cascade's grid refines, so every cell on the
+// outer side of P is entirely outside B and therefore empty, and the ray is on the outer side of P for all t < b.
+// Claim: if no lattice point of the ray lies in [b - 2 eps, b + 2 eps], the first lattice point q after b is one the
+// reference probes, and the reference emits nothing before it.  (Every lattice point s < b - 2 eps has a computed
+// position at least 2 eps |d_a| outside P, more than the position and cell-index rounding, so whatever the reference
+// probes there is an empty cell.  Let p be the last point it probes before b: its cell ends at or before P, so the
+// reference's tt(p) = p + min(tx,ty,tz) <= p + t_a <= b + eps, and its do/while stops at the first lattice point
+// >= tt(p); that point is > p, hence > b - 2 eps, hence >= q, and <= q because tt(p) < q.)
+// eps bounds the rounding of t_a and of our own b: 2^-24 * bound * |rd_a| from the sample position, a few ulps of t
+// from the rest; the constants below carry a 4x margin.  When the window is not free the next coarse-cell plane
+// further out is tried (same argument); if none qualifies the ray walks cell by cell as before.
+// The lattice point is obtained with lattice_advance() when the step is constant over the jump, else by walking the
+// lattice itself (no probes), which is the reference loop verbatim.
+template <bool POW2>
+__device__ __forceinline__ float skip_to_box(const RayCtx& c, const BoxHit& h, float t) {
+    if constexpr (!POW2) return t;
+    if (!h.entry_valid || !c.box || __float_as_uint(c.box[6]) != 1u) return t;
+    if (!(h.t_in > t)) return t;
+    const float cell = c.box[7];
+    const float ard = fabsf(h.rd);
+    if (!(ard < 1e6f)) return t;
+    const float out = h.rd > 0.0f ? -cell : cell;  // along the axis, away from the box: the ray enters through the low face iff d > 0
+    const bool const_min = c.dt_gamma == 0.0f || (h.t_in + c.dt_max) * c.dt_gamma <= c.dt_min;
+    const bool const_max = !const_min && t * c.dt_gamma >= c.dt_max;
+    for (int k = 0; k < 8; k++) {
+        const float plane = fmaf((float)k, out, h.face);                 // exact: multiples of a power of two
+        const float b = (plane - h.o) * h.rd;
+        const float eps = fmaf(c.bound * 2.3841858e-7f, ard, (fabsf(b) + 1.0f) * 9.5367432e-7f);  // 2^-22 bound |rd| + 2^-20 (|b| + 1)
+        if (!(b - t > 2.0f * eps)) return t;
+        float q, prev;
+        if (const_min) lattice_advance(t, c.dt_min, b, q, prev);
+        else if (const_max) lattice_advance(t, c.dt_max, b, q, prev);
+        else lattice_walk(t, c.dt_gamma, c.dt_min, c.dt_max, b, q, prev);
+        if (q - b > 2.0f * eps && b - prev > 2.0f * eps) return q;
+    }
+    return t;
 }
 
 // frexpf exponent of a finite non-negative float, clamped to [0, maxlevel] (== reference mip_from_*)

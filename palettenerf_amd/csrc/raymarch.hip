@@ -179,9 +179,11 @@ __global__ void __launch_bounds__(kBlock) k_march_train_count(
     if (n < N) {
         RayCtx c;
         ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, p, grid, mip_lds);
-        const float far = clip_far_to_box(c, fars[n]);
+        const BoxHit bh = clip_to_box(c, fars[n]);
+    const float far = bh.far;
         float t = nears[n];
         t = fmaf(clampf(t * c.dt_gamma, c.dt_min, c.dt_max), noises[n], t);
+        t = skip_to_box<MIP && POW2>(c, bh, t);
         float x, y, z, dt;
         while (t < far && (uint32_t)num_steps < max_steps) {
             if (march_probe<MIP, POW2>(c, t, x, y, z, dt)) { num_steps++; t += dt; }
@@ -220,13 +222,15 @@ __global__ void __launch_bounds__(kBlock) k_march_train_write(
 
     RayCtx c;
     ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, p, grid, mip_lds);
-    const float far = clip_far_to_box(c, fars[n]);
+    const BoxHit bh = clip_to_box(c, fars[n]);
+    const float far = bh.far;
     float t = nears[n];
     t = fmaf(clampf(t * c.dt_gamma, c.dt_min, c.dt_max), noises[n], t);
     float* px = xyzs + (size_t)point_index * 3;
     float* pd = dirs + (size_t)point_index * 3;
     float* pl = deltas + (size_t)point_index * 2;
-    float last_t = t, x, y, z, dt;
+    float last_t = t, x, y, z, dt;   // delta[1] of the first sample spans the skipped empty space too (raymarching.cu:428)
+    t = skip_to_box<MIP && POW2>(c, bh, t);
     int step = 0;
     while (t < far && step < num_steps) {
         if (march_probe<MIP, POW2>(c, t, x, y, z, dt)) {
@@ -272,9 +276,11 @@ __global__ void __launch_bounds__(kBlock) k_march_rays(
         float* pd = dirs + (size_t)n * n_step * 3;
         float* pl = deltas + (size_t)n * n_step * 2;
         float t = rays_t[index];
-        const float far = clip_far_to_box(c, fars[index]);
+        const BoxHit bh = clip_to_box(c, fars[index]);
+        const float far = bh.far;
         t = fmaf(clampf(t * c.dt_gamma, c.dt_min, c.dt_max), noises ? noises[n] : 0.0f, t);  // noise is slot-indexed (quirk 5)
         float last_t = t, x, y, z, dt;
+        t = skip_to_box<MIP && POW2>(c, bh, t);
         uint32_t step = 0;
         while (t < far && step < n_step) {
             if (march_probe<MIP, POW2>(c, t, x, y, z, dt)) {
@@ -353,12 +359,20 @@ __global__ void __launch_bounds__(1024) k_mip_bounds(uint32_t* __restrict__ mip,
         if (lane == 0) { red[a][wave] = l; red[3 + a][wave] = h; }
     }
     __syncthreads();
+    // Power-of-two bound and H: every cascade's cell grid refines the coarsest one (cell = 2 bound / H), so faces rounded
+    // outward to that grid are cell boundaries of ALL cascades -- the property skip_to_box() needs.  [6] = 1 flags it,
+    // [7] = the coarse cell size.  Otherwise the box is left as is and only clips the far end.
+    const bool aligned = (H & (H - 1)) == 0 && (__float_as_uint(bound) & 0x7fffffu) == 0 && bound > 0.0f;
+    const float coarse = 2.0f * bound / (float)H;
     if (threadIdx.x < 6) {
         float v = red[threadIdx.x][0];
         for (int w = 1; w < (int)(blockDim.x / PNR_WAVE); w++) v = threadIdx.x < 3 ? fminf(v, red[threadIdx.x][w]) : fmaxf(v, red[threadIdx.x][w]);
+        if (aligned && fabsf(v) <= 2.0f * bound)   // (an empty grid keeps its +-FLT_MAX sentinels)
+            v = (threadIdx.x < 3 ? floorf((v + bound) / coarse) : ceilf((v + bound) / coarse)) * coarse - bound;  // exact: powers of two
         reinterpret_cast<float*>(mip + 2 * words_per_mask)[threadIdx.x] = v;  // empty grid: min = +FLT_MAX > max = -FLT_MAX => every ray "misses"
     }
-    if (threadIdx.x >= 6 && threadIdx.x < 8) mip[2 * words_per_mask + threadIdx.x] = 0;
+    if (threadIdx.x == 6) mip[2 * words_per_mask + 6] = aligned ? 1u : 0u;
+    if (threadIdx.x == 7) reinterpret_cast<float*>(mip + 2 * words_per_mask)[7] = coarse;
 }
 
 }  // namespace pnr

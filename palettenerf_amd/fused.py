@@ -23,6 +23,21 @@ def grid_encode_raw(encoder, x01):
     return out
 
 
+def tile_ray_order(pixel_index, W, tile=8):
+    """Permutation that visits rays tile by tile (tile x tile pixels, row-major inside a tile): one wave = one 8x8 tile.
+    pixel_index: int64 [N] row-major pixel id of every ray (arange(H*W) for a full frame, the shard's ids otherwise)."""
+    y, x = pixel_index // W, pixel_index % W
+    if tile == 0:                                   # full Z-order over pixels
+        def spread(v):
+            v = (v | (v << 8)) & 0x00FF00FF
+            v = (v | (v << 4)) & 0x0F0F0F0F
+            v = (v | (v << 2)) & 0x33333333
+            return (v | (v << 1)) & 0x55555555
+        return torch.argsort(spread(x) | (spread(y) << 1)).to(torch.int32)
+    key = ((y // tile) * ((W + tile - 1) // tile) + (x // tile)) * (tile * tile) + (y % tile) * tile + (x % tile)
+    return torch.argsort(key).to(torch.int32)
+
+
 class NeRFFieldFused:
     """Caches the MFMA-ordered weight blob of a NeRFNetwork and evaluates (sigma, rgb) for sample batches."""
 
@@ -91,6 +106,8 @@ class NeRFFieldFused:
         a.stats = ctypes.cast(stats, ctypes.c_void_p)
         kms = (ctypes.c_float * 2)()
         a.kernel_ms = ctypes.cast(kms, ctypes.c_void_p) if self.time_grid_kernel else None
+        order = getattr(self, "ray_order", None)
+        a.ray_order = order.data_ptr() if order is not None and order.numel() == N else None
         for t, name in ((rays_o, "rays_o"), (rays_d, "rays_d"), (nears, "nears"), (fars, "fars")):
             require(t, torch.float32, name)
         rc = lib.pnr_nerf_render_frame(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
@@ -209,6 +226,8 @@ class PaletteFieldFused:
         a.workspace, a.workspace_bytes = self._ws.data_ptr(), nbytes
         a.stats = ctypes.cast(stats, ctypes.c_void_p)
         a.kernel_ms = ctypes.cast(kms, ctypes.c_void_p) if getattr(self, "time_grid_kernel", False) else None
+        order = getattr(self, "ray_order", None)
+        a.ray_order = order.data_ptr() if order is not None and order.numel() == N else None
         p.embeddings_palette = require(m.encoder_palette.embeddings.detach(), torch.float32, "embeddings").data_ptr()
         p.embeddings_clip = require(m.encoder_clip.embeddings.detach(), torch.float32, "embeddings").data_ptr() if self.pred_clip else None
         p.basis_color, p.or_bias = ctypes.cast(bc, ctypes.c_void_p), ctypes.cast(bias, ctypes.c_void_p)

@@ -1,0 +1,28 @@
+"""Probe statistics of the native frame loop's march kernel (needs a -DPNR_MARCH_STATS build:
+PNR_EXTRA_HIPCC_FLAGS=-DPNR_MARCH_STATS python -m palettenerf_amd.build --force)."""
+import ctypes
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from palettenerf_amd import _lib, scene
+
+sys.argv = [sys.argv[0], "--no-cpu-baseline"]
+args = bench.parse()
+dev = torch.device("cuda", 0)
+m = bench.build_model(args, dev)
+m.march_mode = "native"
+H = W = 800
+pose = torch.from_numpy(scene.lookat_pose())[None]
+ro, rd = scene.get_rays(pose, scene.intrinsics_from_fov(H, W), H, W)
+ro, rd = ro.to(dev), rd.to(dev)
+lib = _lib.load()
+out = (ctypes.c_ulonglong * 8)()
+with torch.no_grad():
+    r = m.render(ro, rd, perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+    lib.pnr_debug_march_stats(out, 1)
+    r = m.render(ro, rd, perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+    lib.pnr_debug_march_stats(out, 1)
+print("first launch:", list(out[0:4]), "later launches:", list(out[4:8]))
+print("probes", out[0], "empty", out[1], "sum over waves of max-lane probes x64", out[2] * 64, "ray-launches", out[3], "rendered", int(r["rendered"].item()))

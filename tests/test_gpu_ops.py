@@ -164,6 +164,56 @@ def test_march_rays_train_perturbed_and_mean_count_overflow(cuda, s0):
     assert diff.max() <= 8 and diff.mean() < 1.0 and abs(int(counter[0]) - int(cnt2[0])) < 0.01 * int(cnt2[0])
 
 
+def _far_rays(n, seed):
+    """Cameras far outside the occupied cube of an S0 scene (bound 8): long empty walks in front of the box, which the
+    GPU path jumps over exactly (csrc/march_core.hpp skip_to_box).  Mixed in: axis-parallel rays, rays that graze a
+    face plane of the occupied box, rays that start inside it, rays that miss."""
+    rng = np.random.default_rng(seed)
+    o = rng.normal(size=(n, 3)); o = o / np.linalg.norm(o, axis=1, keepdims=True) * rng.uniform(3.0, 7.5, size=(n, 1))
+    target = rng.uniform(-0.9, 0.9, size=(n, 3))
+    k = n // 8
+    target[:k, 2] = 0.8125                                   # on the +z face plane of the S0 box
+    o[k:2 * k] = rng.uniform(-0.5, 0.5, size=(k, 3))         # inside the box
+    target[2 * k:3 * k] = rng.uniform(2.0, 6.0, size=(k, 3))  # mostly misses
+    d = target - o
+    d[3 * k:4 * k, 0] = 0.0                                  # parallel to the x slabs
+    d[4 * k:5 * k, :2] = 0.0; o[4 * k:5 * k, :2] = rng.uniform(-0.6, 0.6, size=(k, 2))  # straight down the z axis
+    d = d / np.linalg.norm(d, axis=1, keepdims=True)
+    return o.astype(np.float32), d.astype(np.float32)
+
+
+@pytest.mark.parametrize("dt_gamma", [0.0, 1.0 / 128, 1.0 / 32])
+@pytest.mark.parametrize("perturb", [False, True])
+def test_march_far_cameras_exact_empty_space_jump(cuda, dt_gamma, perturb):
+    bound, C = 8.0, 4
+    grid = scene.brick_density_grid(bound=8)
+    bf = scene.packbits_np(grid, 0.5)
+    ro, rd = _far_rays(6000, 5)
+    N = ro.shape[0]
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    on, of = oracle.near_far_from_aabb(ro, rd, aabb, 0.05)
+    torch.manual_seed(77)
+    noises = host(torch.rand(N, dtype=torch.float32, device=cuda)) if perturb else np.zeros(N, np.float32)
+    cnt = np.zeros(2, np.int32)
+    ox, od, odl, orays = oracle.march_rays_train(ro, rd, bound, bf, C, 128, on, of, cnt, noises=noises, align=128, force_all_rays=True, dt_gamma=dt_gamma)
+    counter = torch.zeros(2, dtype=torch.int32, device=cuda)
+    torch.manual_seed(77)
+    x, d, dl, rays = raymarching.march_rays_train(dev(ro, cuda), dev(rd, cuda), bound, dev(bf, cuda), C, 128, dev(on, cuda), dev(of, cuda), counter,
+                                                  -1, perturb, 128, True, dt_gamma, 1024)
+    assert int(cnt[0]) > 50000 and int((orays[:, 2] == 0).sum()) > 100
+    np.testing.assert_array_equal(host(counter), cnt)
+    np.testing.assert_array_equal(host(rays), orays)
+    np.testing.assert_array_equal(host(x), ox)
+    np.testing.assert_array_equal(host(dl), odl)       # delta[1] of a ray's first sample spans the jumped-over space
+    # inference march from the same starts (n_step 2), half of the rays
+    alive = np.arange(0, N, 2, dtype=np.int32)
+    ix, idr, idl = oracle.march_rays(len(alive), 2, alive, on, ro, rd, bound, bf, C, 128, on, of, align=128, dt_gamma=dt_gamma)
+    gx, gd, gdl = raymarching.march_rays(len(alive), 2, dev(alive, cuda), dev(on, cuda), dev(ro, cuda), dev(rd, cuda), bound, dev(bf, cuda), C, 128,
+                                         dev(on, cuda), dev(of, cuda), 128, False, dt_gamma, 1024)
+    np.testing.assert_array_equal(host(gx), ix)
+    np.testing.assert_array_equal(host(gdl), idl)
+
+
 @pytest.mark.parametrize("n_step,bound", [(1, 2.0), (3, 2.0), (8, 2.0), (4, 1.5)])
 def test_march_rays_inference_bit_exact(cuda, s0, mip_mode, n_step, bound):
     grid, bf = s0

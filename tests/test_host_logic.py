@@ -96,3 +96,33 @@ def test_render_refuses_pure_torch_path():
     m = network.NeRFNetwork(bound=2, cuda_ray=False)
     with pytest.raises(ValueError):
         m.render(torch.zeros(1, 4, 3), torch.zeros(1, 4, 3))
+
+
+# ------------------------------------------------------------------ exact lattice jump (csrc/lattice.hpp, compiled for the host)
+def _lattice_lib(tmp_path_factory):
+    import ctypes
+    import subprocess
+    out = tmp_path_factory.mktemp("lattice") / "liblattice_check.so"
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "lattice_check.cpp")
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", str(out), src])
+    lib = ctypes.CDLL(str(out))
+    lib.lattice_fuzz.argtypes = [ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.lattice_case.argtypes = [ctypes.c_float] * 3 + [ctypes.c_void_p] * 4
+    return lib
+
+
+def test_lattice_advance_equals_the_stepping_loop(tmp_path_factory):
+    """lattice_advance() must return bit-for-bit what `do { t += d } while (t < tt)` returns (raymarching.cu:399-401):
+    generic steps, the steps the shipped configs produce, and steps with few mantissa bits (exact rounding ties)."""
+    lib = _lattice_lib(tmp_path_factory)
+    bad = np.zeros(3, np.float32)
+    for mode in (0, 1, 2):
+        for seed in (1, 2, 3):
+            n = lib.lattice_fuzz(seed * 7919 + mode, 200000, mode, bad.ctypes.data)
+            assert n == 0, f"mode {mode} seed {seed}: {n} mismatches, first at (tc, d, tt) = {bad}"
+    # hand-picked: binade crossings landing exactly on a power of two, a target equal to the start, a NaN target
+    out = [np.zeros(1, np.float32) for _ in range(4)]
+    ptrs = [o.ctypes.data for o in out]
+    for tc, d, tt in [(0.5, 0.25, 4.0), (1.0, 2.0 ** -23, 1.0 + 2.0 ** -20), (3.999999, 0.003382, 4.1), (1.5, 0.003382, 1.5),
+                      (1.5, 0.003382, float("nan")), (0.2, 0.0270632, 7.9), (2.0 ** -130, 0.01, 0.5)]:
+        assert lib.lattice_case(tc, d, tt, *ptrs) == 1, (tc, d, tt, [float(o[0]) for o in out])
