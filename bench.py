@@ -176,7 +176,9 @@ def main():
         for _ in range(2):
             frame()                                               # re-warm with the final ordering
         torch.cuda.synchronize()
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # diagnostics only (no sync inside the loop)
     t0 = time.perf_counter()
+    step_ev[0].record()
     for i in range(args.steps):
         # HIP events around every grid-encode launch cost ~6 us each (two per iteration): instrument the launches of the
         # FIRST timed step only, so the measurement lives inside the timed region without distorting it
@@ -187,6 +189,7 @@ def main():
         rows += r["n_samples"]
         if timed_native and i == 0:
             native_ms, native_launches, native_rows = r.get("grid_ms", 0.0), r.get("grid_launches", 0), r["n_samples"]
+        step_ev[i + 1].record()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -216,9 +219,11 @@ def main():
             t = json.load(open(tpath)).get(args.model)
             if t:
                 traffic = t["traffic_bytes_per_launch"] / n_tables
+        per_step = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps))
         out = {
             "metric": "rendered_samples_per_sec", "value": total_rendered / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "step_ms": {"min": per_step[0], "median": per_step[len(per_step) // 2], "max": per_step[-1]}, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f16" if args.fp16 else "f32", "data": "synthetic",
             "config": {"workload": f"configs[{1 if args.model == 'nerf' else 2}]: NeRF-synthetic lego geometry (scene S0), -m {args.model} inference, {H}x{W}, {n_views} view(s)/step",
                        "rays_per_step": n_views * H * W, "rendered_samples_per_step": total_rendered // args.steps,

@@ -10,7 +10,7 @@
 //     rows do not exist, dead slots are skipped by the grid and field kernels;
 //   * world -> [0,1] normalisation, density_scale and the sample counter are folded into kernels.
 // Per iteration: march, grid (level-major, L2-resident tables), field (fp32 MFMA), composite(+count),
-// scan(+schedule), write = 6 launches, no host round trip.
+// compact(+schedule) = 5 launches, no host round trip.
 #include "pnr_common.hpp"
 #include "march_core.hpp"
 #include "grid_core.hpp"
@@ -58,7 +58,9 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_init(uint32_t N, const floa
 // reference raymarching.cu:907-1011, n_alive / n_step from the control block; also writes the delta == 0
 // sentinel of unfilled slots (the reference relies on zero-initialised buffers) and counts emitted samples.
 #ifdef PNR_MARCH_STATS
-__device__ unsigned long long g_march_stats[8];  // probes, empty probes, (unused), ray-launches
+__device__ unsigned long long g_march_stats[8];
+__device__ unsigned int g_march_max[64];   // per iteration: max probes of any ray
+__device__ unsigned int g_march_kinds[64][8];   // per iteration: probe kinds of (one of) the slowest rays  // probes, empty probes, (unused), ray-launches
 #endif
 template <bool MIP, bool POW2>
 __global__ void __launch_bounds__(kRayBlock) k_frame_march(FrameCtl* __restrict__ ctl, const int32_t* __restrict__ rays_alive,
@@ -88,12 +90,18 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_march(FrameCtl* __restrict_
         uint32_t step = 0;
 #ifdef PNR_MARCH_STATS
         unsigned long long probes = 0, empties = 0;
+        unsigned int kinds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
         while (t < far && step < n_step) {
 #ifdef PNR_MARCH_STATS
             probes++;
-#endif
+            int kind = 7;
+            const bool hit = march_probe<MIP, POW2>(c, t, x, y, z, dt, &kind);
+            kinds[kind & 7]++;
+            if (hit) {
+#else
             if (march_probe<MIP, POW2>(c, t, x, y, z, dt)) {
+#endif
                 px[0] = x; px[1] = y; px[2] = z;
                 pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
                 t += dt;
@@ -107,6 +115,8 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_march(FrameCtl* __restrict_
         }
 #ifdef PNR_MARCH_STATS
         const int so = ctl->iterations == 0 ? 0 : 4;
+        if (atomicMax(&g_march_max[ctl->iterations & 63], (unsigned int)probes) < (unsigned int)probes)
+            for (int kk = 0; kk < 8; kk++) g_march_kinds[ctl->iterations & 63][kk] = kinds[kk];
         atomicAdd(&g_march_stats[so + 0], probes); atomicAdd(&g_march_stats[so + 1], empties); atomicAdd(&g_march_stats[so + 3], 1ull);
         {   // wave-level: max probes over the wave (what the wave actually executes)
             unsigned long long mx = probes;
@@ -117,7 +127,7 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_march(FrameCtl* __restrict_
         emitted += step;
         for (; step < n_step; step++) { pl[0] = 0.0f; pl[1] = 0.0f; pl += 2; }
     }
-    // one partial per workgroup, summed by k_frame_scan: thousands of same-address atomics would serialise in L2
+    // one partial per workgroup, summed by k_frame_compact: thousands of same-address atomics would serialise in L2
     __shared__ uint32_t wsum[kRayBlock / PNR_WAVE];
     for (int off = PNR_WAVE / 2; off > 0; off >>= 1) emitted += __shfl_xor(emitted, off, PNR_WAVE);
     if ((threadIdx.x & (PNR_WAVE - 1)) == 0) wsum[threadIdx.x / PNR_WAVE] = emitted;
@@ -306,63 +316,36 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_composite(const FrameCtl* _
     }
 }
 
-// single workgroup: exclusive scan of the chunk counts, then the schedule of the NEXT iteration
-__global__ void __launch_bounds__(1024) k_frame_scan(const FrameCtl* __restrict__ cur, FrameCtl* __restrict__ nxt, int32_t* __restrict__ scratch,
-                                                     uint32_t N, uint32_t max_steps, const int32_t* __restrict__ emitted_partials,
-                                                     uint32_t n_partials) {
-    if (cur->done) { if (threadIdx.x == 0) *nxt = *cur; return; }
-    __shared__ int wsum[1024 / PNR_WAVE];
-    __shared__ int carry_s;
-    __shared__ unsigned long long emitted_s;
-    {   // total of the march kernel's per-workgroup sample counts
-        unsigned long long e = 0;
-        for (uint32_t i = threadIdx.x; i < n_partials; i += 1024) e += (unsigned long long)emitted_partials[i];
-        for (int off = PNR_WAVE / 2; off > 0; off >>= 1) e += __shfl_xor(e, off, PNR_WAVE);
-        if (threadIdx.x == 0) emitted_s = 0;
-        __syncthreads();
-        if ((threadIdx.x & (PNR_WAVE - 1)) == 0 && e) atomicAdd(&emitted_s, e);
-        __syncthreads();
-    }
-    const uint32_t nchunks = ((uint32_t)cur->n_alive + kRayBlock - 1) / kRayBlock;
-    int32_t* sums = scratch + kHdr;
-    if (threadIdx.x == 0) carry_s = 0;
+// Stable compaction of the alive list + the schedule of the NEXT iteration, one launch.  Every workgroup derives the output
+// offset of its chunk itself by summing the per-chunk survivor counts in front of it (k_frame_composite wrote them; a few
+// coalesced loads per thread from L2) -- no separate scan launch.  Workgroup 0 also totals the counts and the march's
+// sample partials and writes the next control block.
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long* sh /* [kRayBlock / 64] */) {
+    for (int off = PNR_WAVE / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, PNR_WAVE);
     __syncthreads();
-    const int lane = threadIdx.x & (PNR_WAVE - 1), wave = threadIdx.x / PNR_WAVE;
-    for (uint32_t base = 0; base < nchunks; base += 1024) {
-        const uint32_t i = base + threadIdx.x;
-        const int v = i < nchunks ? sums[i] : 0;
-        const int incl = wave_inclusive_scan(v);
-        if (lane == PNR_WAVE - 1) wsum[wave] = incl;
-        __syncthreads();
-        int woff = 0, tot = 0;
-        for (int wv = 0; wv < 1024 / PNR_WAVE; wv++) { const int s = wsum[wv]; if (wv < wave) woff += s; tot += s; }
-        const int carry = carry_s;
-        if (i < nchunks) sums[i] = carry + woff + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s = carry + tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        FrameCtl c = *cur;
-        c.rendered += emitted_s;
-        c.rows += (unsigned long long)c.n_alive * (unsigned long long)c.n_step;
-        c.step += c.n_step;
-        c.iterations += 1;
-        c.n_alive = carry_s;
-        c.n_step = schedule_n_step((int)N, c.n_alive);
-        c.done = (c.n_alive <= 0) || ((uint32_t)c.step >= max_steps);
-        *nxt = c;
-    }
+    if ((threadIdx.x & (PNR_WAVE - 1)) == 0) sh[threadIdx.x / PNR_WAVE] = v;
+    __syncthreads();
+    unsigned long long t = 0;
+    for (int wv = 0; wv < (int)(kRayBlock / PNR_WAVE); wv++) t += sh[wv];
+    return t;
 }
 
-__global__ void __launch_bounds__(kRayBlock) k_frame_alive_write(const FrameCtl* __restrict__ cur, const int32_t* __restrict__ alive_in,
-                                                                 int32_t* __restrict__ alive_out, const int32_t* __restrict__ scratch) {
-    if (cur->done) return;
+__global__ void __launch_bounds__(kRayBlock) k_frame_compact(const FrameCtl* __restrict__ cur, FrameCtl* __restrict__ nxt, const int32_t* __restrict__ alive_in,
+                                                             int32_t* __restrict__ alive_out, const int32_t* __restrict__ scratch, uint32_t N,
+                                                             uint32_t max_steps, const int32_t* __restrict__ emitted_partials, uint32_t n_partials) {
+    if (cur->done) { if (blockIdx.x == 0 && threadIdx.x == 0) *nxt = *cur; return; }
     const uint32_t n_alive = (uint32_t)cur->n_alive;
     const uint32_t nchunks = (n_alive + kRayBlock - 1) / kRayBlock;
+    const int32_t* counts = scratch + kHdr;
     __shared__ int wsum[kRayBlock / PNR_WAVE];
+    __shared__ unsigned long long red[kRayBlock / PNR_WAVE];
     const int lane = threadIdx.x & (PNR_WAVE - 1), wave = threadIdx.x / PNR_WAVE;
+    uint32_t base = 0, summed_to = 0;   // base = sum of counts[0 .. summed_to)
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        unsigned long long part = 0;
+        for (uint32_t j = summed_to + threadIdx.x; j < chunk; j += kRayBlock) part += (unsigned long long)counts[j];
+        base += (uint32_t)block_sum_u64(part, red);
+        summed_to = chunk;
         const uint32_t i = chunk * kRayBlock + threadIdx.x;
         const int id = i < n_alive ? alive_in[i] : -1;
         const int keep = id >= 0 ? 1 : 0;
@@ -372,8 +355,26 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_alive_write(const FrameCtl*
         int woff = 0;
         for (int wv = 0; wv < wave; wv++) woff += wsum[wv];
         const int rank = __popcll(m & ((1ull << lane) - 1ull));
-        if (keep) alive_out[scratch[kHdr + chunk] + woff + rank] = id;
+        if (keep) alive_out[base + woff + rank] = id;
         __syncthreads();
+    }
+    if (blockIdx.x == 0) {
+        unsigned long long part = 0, e = 0;
+        for (uint32_t j = threadIdx.x; j < nchunks; j += kRayBlock) part += (unsigned long long)counts[j];
+        for (uint32_t j = threadIdx.x; j < n_partials; j += kRayBlock) e += (unsigned long long)emitted_partials[j];
+        const unsigned long long total = block_sum_u64(part, red);
+        const unsigned long long emitted = block_sum_u64(e, red);
+        if (threadIdx.x == 0) {
+            FrameCtl c = *cur;
+            c.rendered += emitted;
+            c.rows += (unsigned long long)c.n_alive * (unsigned long long)c.n_step;
+            c.step += c.n_step;
+            c.iterations += 1;
+            c.n_alive = (int32_t)total;
+            c.n_step = schedule_n_step((int)N, c.n_alive);
+            c.done = (c.n_alive <= 0) || ((uint32_t)c.step >= max_steps);
+            *nxt = c;
+        }
     }
 }
 
@@ -487,7 +488,11 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     };
     const bool timing = a->kernel_ms != nullptr;
     uint32_t alive_ub = N;   // host-side upper bound of n_alive (it only shrinks)
-    uint32_t chunk = 8;      // iterations enqueued between two looks at the control block (grows for long, translucent marches)
+    // Iterations enqueued between two looks at the control block.  Consecutive frames of a camera path need nearly the same
+    // number of iterations, so the first chunk is the previous frame's count (one look per frame when the guess holds; launches
+    // past the end are no-ops that cost a few microseconds each); after that, short chunks that grow for long, translucent marches.
+    static uint32_t predicted_iterations = 0;
+    uint32_t chunk = predicted_iterations ? (predicted_iterations < 1024u ? predicted_iterations : 1024u) : 8u;
     uint32_t looks = 0;
     int iter = 0;
     for (;;) {
@@ -525,15 +530,16 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
                                    a->packed_weights, a->density_scale, w.sigmas, w.rgbs);
             hipLaunchKernelGGL(k_frame_composite, gm, bm, 0, s, cur, a->T_thresh, alive_in, w.rays_t, w.sigmas, w.rgbs, w.deltas, a->weights_sum, a->depth,
                                a->image, w.scratch, (const float*)w.aux, pal ? pal->aux_map : nullptr, aux_stride);
-            hipLaunchKernelGGL(k_frame_scan, dim3(1), dim3(1024), 0, s, cur, nxt, w.scratch, N, a->max_steps, w.partials, gm.x);
-            hipLaunchKernelGGL(k_frame_alive_write, gm, bm, 0, s, cur, alive_in, alive_out, w.scratch);
+            hipLaunchKernelGGL(k_frame_compact, gm, bm, 0, s, cur, nxt, alive_in, alive_out, w.scratch, N, a->max_steps, w.partials, gm.x);
         }
         if (hipMemcpyAsync(host_ctl, w.ctl + (iter & 1), sizeof(FrameCtl), hipMemcpyDeviceToHost, s) != hipSuccess) return PNR_ERR_LAUNCH;
         if (hipStreamSynchronize(s) != hipSuccess) return PNR_ERR_LAUNCH;
         if (host_ctl->done) break;
         alive_ub = (uint32_t)host_ctl->n_alive;
+        if (looks == 0) chunk = predicted_iterations ? 4u : 8u;
         if (++looks >= 4 && chunk < 64) chunk *= 2;
     }
+    predicted_iterations = (uint32_t)host_ctl->iterations;
     if (timing) {  // only the iterations that did work (the tail of the last chunk are no-op launches)
         float total = 0.0f;
         uint32_t counted = 0;
@@ -556,6 +562,16 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
 }  // extern "C"
 
 #ifdef PNR_MARCH_STATS
+extern "C" int pnr_debug_march_kinds(unsigned int* out) {
+    hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pnr::g_march_kinds), 64 * 8 * 4) == hipSuccess ? 0 : -3;
+}
+extern "C" int pnr_debug_march_max(unsigned int* out, int reset) {
+    hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pnr::g_march_max), 256) != hipSuccess) return -3;
+    if (reset) { unsigned int z[64] = {}; hipMemcpyToSymbol(HIP_SYMBOL(pnr::g_march_max), z, 256); }
+    return 0;
+}
 extern "C" int pnr_debug_march_stats(unsigned long long* out, int reset) {
     hipDeviceSynchronize();
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pnr::g_march_stats), 64) != hipSuccess) return -3;

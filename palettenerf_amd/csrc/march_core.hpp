@@ -38,6 +38,7 @@ struct RayCtx {
     const uint32_t* mip_any;  // LDS (or nullptr)
     const uint32_t* mip_all;
     const float* box;         // LDS: occupied box (min xyz, max xyz), or nullptr
+    bool block_skip;          // empty 4^3/8^3/16^3 blocks may be jumped (needs H % 64 == 0 so that blocks nest in the cascades)
 };
 
 struct MarchParams {  // ray-independent constants, computed once on the host
@@ -72,6 +73,7 @@ __device__ __forceinline__ void ctx_init(RayCtx& c, const float* __restrict__ o,
     c.mip_any = mip_lds;
     c.mip_all = mip_lds ? mip_lds + p.mip_words : nullptr;
     c.box = mip_lds ? reinterpret_cast<const float*>(mip_lds + 2 * p.mip_words) : nullptr;
+    c.block_skip = mip_lds != nullptr && (p.H % 64u) == 0;
 }
 
 // Slab test of the ray against the occupied box.  `far`: parameter beyond which the ray is outside the box for good
@@ -156,11 +158,33 @@ __device__ __forceinline__ bool cell_occupied(const RayCtx& c, uint32_t index) {
     return c.grid[index >> 3] & (1u << (index & 7u));
 }
 
+// Largest all-empty aligned block around cell `index`, as log2 of its edge in cells: 4 (16^3 cells = 64 consecutive
+// bricks = one aligned 64-bit word of the 'any' mask, Morton order), 3 (8^3 = one byte), 2 (4^3 = one bit); 0 = the
+// brick holds something.
+__device__ __forceinline__ int empty_block_log2(const RayCtx& c, uint32_t index) {
+    const uint32_t brick = index >> 6;
+    const uint32_t lo = c.mip_any[(brick >> 6) * 2], hi = c.mip_any[(brick >> 6) * 2 + 1];
+    if ((lo | hi) == 0) return 4;
+    const uint32_t w = (brick & 32u) ? hi : lo;
+    if (((w >> (brick & 24u)) & 0xffu) == 0) return 3;
+    return ((w >> (brick & 31u)) & 1u) ? 0 : 2;
+}
+
 // Probe the cell containing the point at parameter t.  Occupied: returns true and the sample
 // (x,y,z,dt), t untouched.  Empty: advances t past the cell (do..while of the reference) and
 // returns false.
+//
+// MIP && POW2: when the cell lies in an all-empty aligned block R of 4^3 / 8^3 / 16^3 cells, t is advanced past R in
+// one go -- exactly.  With b the parameter at which the ray leaves R (through the far face of axis a) the argument of
+// skip_to_box() applies unchanged provided that, in addition, (i) every point of R is probed at this same cascade
+// (blocks never straddle a cascade boundary because their size divides H/4, and the dt-derived cascade is checked at
+// both ends of the jump), and (ii) the ray keeps a margin m (4x the position + cell-index rounding) from R's other
+// faces at both ends of the jump, hence throughout: then every lattice point before b - 2 eps is computed into a cell
+// of R (empty), the reference's last probe p in R has tt(p) <= b + eps (its cell's a-face is at or before R's), and
+// with a lattice-free window around b it lands on the same next point q.  Any check failing = the reference's own
+// one-cell step.
 template <bool MIP, bool POW2>
-__device__ __forceinline__ bool march_probe(const RayCtx& c, float& t, float& x, float& y, float& z, float& dt) {
+__device__ __forceinline__ bool march_probe(const RayCtx& c, float& t, float& x, float& y, float& z, float& dt, int* kind = nullptr) {
     const float t0 = t;
     x = clampf(fmaf(t0, c.dx, c.ox), -c.bound, c.bound);
     y = clampf(fmaf(t0, c.dy, c.oy), -c.bound, c.bound);
@@ -189,7 +213,58 @@ __device__ __forceinline__ bool march_probe(const RayCtx& c, float& t, float& x,
         nz = (int)clampf((float)(0.5 * (double)fmaf(z, mip_rbound, 1.0f) * (double)c.H), 0.0f, hi);
     }
     const uint32_t index = (uint32_t)level * c.H3 + morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
-    if (cell_occupied<MIP>(c, index)) return true;
+    if constexpr (MIP && POW2) {
+        int sh = c.block_skip ? empty_block_log2(c, index) : 0;
+        if (kind) *kind = sh == 0 ? 1 : 5;   // instrumented builds only: 0 emit, 1 cell step in a non-empty brick, 2/3/4 block jump, 5 block checks failed
+        if (sh == 0) { if (cell_occupied<MIP>(c, index)) { if (kind) *kind = 0; return true; } }
+        else {
+            const float s = (float)(1 << sh);
+            const float lox = (float)((nx >> sh) << sh), loy = (float)((ny >> sh) << sh), loz = (float)((nz >> sh) << sh);
+            // world coordinates of R's faces (exact: powers of two), far face per axis in the direction of travel
+            const float wlx = fmaf(lox * c.rH, 2.0f, -1.0f) * mip_bound, whx = fmaf((lox + s) * c.rH, 2.0f, -1.0f) * mip_bound;
+            const float wly = fmaf(loy * c.rH, 2.0f, -1.0f) * mip_bound, why = fmaf((loy + s) * c.rH, 2.0f, -1.0f) * mip_bound;
+            const float wlz = fmaf(loz * c.rH, 2.0f, -1.0f) * mip_bound, whz = fmaf((loz + s) * c.rH, 2.0f, -1.0f) * mip_bound;
+            const float bx = signf(c.dx) < 0.0f ? wlx : whx;   // same convention as the one-cell step below
+            const float by = signf(c.dy) < 0.0f ? wly : why;   // same convention as the one-cell step below
+            const float bz = signf(c.dz) < 0.0f ? wlz : whz;   // same convention as the one-cell step below
+            const float ux = (bx - x) * c.rdx, uy = (by - y) * c.rdy, uz = (bz - z) * c.rdz;
+            const float tmin = fminf(ux, fminf(uy, uz));
+            const float m = c.bound * 4.7683716e-7f;  // 2^-21 bound
+            bool ok = tmin == tmin && tmin > 0.0f && tmin < 1e30f;
+            // margins at the start ...
+            ok = ok && (x - wlx > m) && (whx - x > m) && (y - wly > m) && (why - y > m) && (z - wlz > m) && (whz - z > m);
+            // ... and where the ray leaves R: the two axes that do not exit stay inside by m
+            const float ex = fmaf(tmin, c.dx, x), ey = fmaf(tmin, c.dy, y), ez = fmaf(tmin, c.dz, z);
+            float ard, face, xc, rdc;
+            if (ux <= uy && ux <= uz) { ard = fabsf(c.rdx); face = bx; xc = x; rdc = c.rdx; ok = ok && (ey - wly > m) && (why - ey > m) && (ez - wlz > m) && (whz - ez > m); }
+            else if (uy <= uz)        { ard = fabsf(c.rdy); face = by; xc = y; rdc = c.rdy; ok = ok && (ex - wlx > m) && (whx - ex > m) && (ez - wlz > m) && (whz - ez > m); }
+            else                      { ard = fabsf(c.rdz); face = bz; xc = z; rdc = c.rdz; ok = ok && (ex - wlx > m) && (whx - ex > m) && (ey - wly > m) && (why - ey > m); }
+            ok = ok && ard < 1e6f;
+            // block jumps need a constant step over the jump (then the dt-derived cascade is constant too); rays whose step
+            // grows with t (dt_gamma > 0 between the clamps) walk cell by cell as the reference does
+            const float b0 = t0 + tmin;
+            const bool const_min = c.dt_gamma == 0.0f || (b0 + c.dt_max) * c.dt_gamma <= c.dt_min;
+            const bool const_max = !const_min && t0 * c.dt_gamma >= c.dt_max;
+            ok = ok && (const_min || const_max);
+            if (ok) {
+                // Exit plane first; when a lattice point sits in its window, the cell planes just inside R serve equally (R minus
+                // its last cell layers is still an aligned box of empty cells): the ray then needs one or two ordinary steps more.
+                const float d = const_min ? c.dt_min : c.dt_max;
+                const float back = (rdc > 0.0f ? -2.0f : 2.0f) * mip_bound * c.rH;   // one cell, against the direction of travel
+#pragma unroll 1
+                for (int k = 0; k < 3; k++) {
+                    const float b = t0 + (fmaf((float)k, back, face) - xc) * rdc;
+                    const float eps = fmaf(c.bound * 2.3841858e-7f, ard, (fabsf(b) + 1.0f) * 9.5367432e-7f);  // as in skip_to_box()
+                    if (!(b - t0 > 2.0f * eps)) break;
+                    float q, prev;
+                    lattice_advance(t0, d, b, q, prev);
+                    if (q - b > 2.0f * eps && b - prev > 2.0f * eps) { t = q; if (kind) *kind = 2; return false; }
+                }
+            }
+        }
+    } else {
+        if (cell_occupied<MIP>(c, index)) return true;
+    }
     const float tx = fmaf(fmaf(fmaf(0.5f, signf(c.dx), (float)nx + 0.5f) * c.rH, 2.0f, -1.0f), mip_bound, -x) * c.rdx;
     const float ty = fmaf(fmaf(fmaf(0.5f, signf(c.dy), (float)ny + 0.5f) * c.rH, 2.0f, -1.0f), mip_bound, -y) * c.rdy;
     const float tz = fmaf(fmaf(fmaf(0.5f, signf(c.dz), (float)nz + 0.5f) * c.rH, 2.0f, -1.0f), mip_bound, -z) * c.rdz;

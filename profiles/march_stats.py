@@ -22,7 +22,16 @@ out = (ctypes.c_ulonglong * 8)()
 with torch.no_grad():
     r = m.render(ro, rd, perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
     lib.pnr_debug_march_stats(out, 1)
+    lib.pnr_debug_march_max((ctypes.c_uint * 64)(), 1)
     r = m.render(ro, rd, perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
     lib.pnr_debug_march_stats(out, 1)
+mx = (ctypes.c_uint * 64)()
+lib.pnr_debug_march_max(mx, 1)
+print("per-iteration max probes of a ray:", list(mx)[:36])
+kd = (ctypes.c_uint * 512)()
+lib.pnr_debug_march_kinds(kd)
+print("kinds of a slowest ray per iteration [emit, cell, -, s8?, ...]:")
+for it in range(30):
+    print(it, list(kd)[it * 8:it * 8 + 8])
 print("first launch:", list(out[0:4]), "later launches:", list(out[4:8]))
 print("probes", out[0], "empty", out[1], "sum over waves of max-lane probes x64", out[2] * 64, "ray-launches", out[3], "rendered", int(r["rendered"].item()))
