@@ -277,6 +277,18 @@ int pnr_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint3
 int pnr_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t C,
                            const float* dy_dx, float* grad_inputs, pnr_stream_t stream);
 
+/* ---------------------------------------------------------------- ray generation ----------- */
+
+/* device counterpart of the deterministic core of get_rays (nerf/utils.py:53-149; torch ops on the GPU in the reference):
+ * pinhole rays through pixel centres (+0.5), normalised, rotated by the camera-to-world pose.
+ *   poses [B,4,4] row-major cam2world; intrinsics = fx, fy, cx, cy (utils.py:67); inds [B,N] int64 flat pixel ids (y*W + x) or
+ *   NULL = all H*W pixels in row-major order (then N must be H*W); outputs rays_o, rays_d [B,N,3].
+ * Scalar spec (same in the oracle): xs = ((x + 0.5) - cx) / fx, ys likewise, n = sqrt(fma(xs,xs, fma(ys,ys, 1))),
+ * d = (xs/n, ys/n, 1/n), rays_d[k] = fma(d2,R[k][2], fma(d1,R[k][1], d0*R[k][0])), rays_o[k] = pose[k][3].
+ * The index selection (random / patch / error-map sampling, utils.py:75-131) stays on the torch side. */
+int pnr_get_rays(const float* poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, const int64_t* inds,
+                 uint32_t N, float* rays_o, float* rays_d, pnr_stream_t stream);
+
 /* ---------------------------------------------------------------- palette ------------------ */
 
 /* replace rgb_to_hsv / hsv_to_rgb, palette/src/palette_func.h, palette.cu:135-149 */

@@ -310,6 +310,19 @@ def hsv_to_rgb(x):
     return out.reshape(shp)
 
 
+def get_rays(poses, intrinsics, H, W, inds=None):
+    """nerf/utils.py:53-149, deterministic core: poses [B,4,4], intrinsics (fx,fy,cx,cy), inds [B,N] int64 or None (all pixels)."""
+    poses = _f32(poses).reshape(-1, 4, 4)
+    B = poses.shape[0]
+    fx, fy, cx, cy = [float(v) for v in intrinsics]
+    if inds is not None:
+        inds = np.ascontiguousarray(np.broadcast_to(np.asarray(inds, dtype=np.int64), (B, np.asarray(inds).shape[-1])))
+    N = H * W if inds is None else inds.shape[1]
+    rays_o, rays_d = np.empty((B, N, 3), np.float32), np.empty((B, N, 3), np.float32)
+    lib().orc_get_rays(_p(poses), _u(B), _f(fx), _f(fy), _f(cx), _f(cy), _u(H), _u(W), _p(inds), _u(N), _p(rays_o), _p(rays_d))
+    return rays_o, rays_d
+
+
 def compute_RGB_histogram(colors_rgb, weights, bits_per_channel):
     colors_rgb, weights = _f32(colors_rgb), _f32(weights)
     nb = 1 << (3 * bits_per_channel)

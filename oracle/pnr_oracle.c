@@ -717,6 +717,26 @@ ORC_API void orc_hsv_to_rgb(uint32_t n, const float* input, float* output) {
     }
 }
 
+/* nerf/utils.py:53-149 get_rays, deterministic core (the reference evaluates it with torch ops: linspace + 0.5, (i - cx) / fx,
+ * torch.norm, directions @ R^T; reduction orders inside norm / matmul are not specified there, the fma order below is ours) */
+ORC_API void orc_get_rays(const float* poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, const int64_t* inds,
+                          uint32_t N, float* rays_o, float* rays_d) {
+    (void)H;
+    for (uint32_t b = 0; b < B; b++)
+        for (uint32_t n = 0; n < N; n++) {
+            const uint32_t p = inds ? (uint32_t)inds[(size_t)b * N + n] : n;
+            const float xs = (((float)(p % W) + 0.5f) - cx) / fx;
+            const float ys = (((float)(p / W) + 0.5f) - cy) / fy;
+            const float nrm = sqrtf(fmaf(xs, xs, fmaf(ys, ys, 1.0f)));
+            const float d0 = xs / nrm, d1 = ys / nrm, d2 = 1.0f / nrm;
+            const float* P = poses + (size_t)b * 16;
+            for (int k = 0; k < 3; k++) {
+                rays_d[((size_t)b * N + n) * 3 + k] = fmaf(d2, P[k * 4 + 2], fmaf(d1, P[k * 4 + 1], d0 * P[k * 4 + 0]));
+                rays_o[((size_t)b * N + n) * 3 + k] = P[k * 4 + 3];
+            }
+        }
+}
+
 /* palette/src/bindings.cpp:40-91 compute_RGB_histogram */
 ORC_API void orc_rgb_histogram(const float* rgb, const float* weights, uint32_t n, int bpc, double* bin_weights, float* bin_centers) {
     const int num_bins = 1 << (bpc * 3);

@@ -375,6 +375,27 @@ __global__ void __launch_bounds__(1024) k_mip_bounds(uint32_t* __restrict__ mip,
     if (threadIdx.x == 7) reinterpret_cast<float*>(mip + 2 * words_per_mask)[7] = coarse;
 }
 
+// nerf/utils.py:53-149, deterministic core (pixel ids -> rays)
+__global__ void __launch_bounds__(kBlock) k_get_rays(const float* __restrict__ poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t W,
+                                                     const long long* __restrict__ inds, uint32_t N, float* __restrict__ rays_o,
+                                                     float* __restrict__ rays_d) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x, b = blockIdx.y;
+    if (n >= N) return;
+    const uint32_t p = inds ? (uint32_t)inds[(size_t)b * N + n] : n;
+    const float xs = (((float)(p % W) + 0.5f) - cx) / fx;
+    const float ys = (((float)(p / W) + 0.5f) - cy) / fy;
+    const float nrm = sqrtf(fmaf(xs, xs, fmaf(ys, ys, 1.0f)));
+    const float d0 = xs / nrm, d1 = ys / nrm, d2 = 1.0f / nrm;
+    const float* P = poses + (size_t)b * 16;
+    float* o = rays_o + ((size_t)b * N + n) * 3;
+    float* d = rays_d + ((size_t)b * N + n) * 3;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        d[k] = fmaf(d2, P[k * 4 + 2], fmaf(d1, P[k * 4 + 1], d0 * P[k * 4 + 0]));
+        o[k] = P[k * 4 + 3];
+    }
+}
+
 }  // namespace pnr
 
 // ==========================================================================================
@@ -394,6 +415,16 @@ const char* pnr_error_string(int code) {
         case PNR_ERR_LAUNCH: return "HIP kernel launch failed";
         default: return "unknown error";
     }
+}
+
+int pnr_get_rays(const float* poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, const int64_t* inds, uint32_t N,
+                 float* rays_o, float* rays_d, pnr_stream_t stream) {
+    if (B == 0 || N == 0) return PNR_OK;
+    if (!poses || !rays_o || !rays_d || H == 0 || W == 0 || fx == 0.0f || fy == 0.0f) return PNR_ERR_INVALID;
+    if (!inds && N != H * W) return PNR_ERR_INVALID;
+    hipLaunchKernelGGL(k_get_rays, dim3(cdiv(N, kBlock), B), dim3(kBlock), 0, as_stream(stream), poses, B, fx, fy, cx, cy, W,
+                       reinterpret_cast<const long long*>(inds), N, rays_o, rays_d);
+    return check_launch();
 }
 
 uint64_t pnr_scan_scratch_bytes(uint32_t N) { return ((uint64_t)kScanHdr + cdiv(N, kBlock) + N + 4) * 4; }

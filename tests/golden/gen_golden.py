@@ -198,8 +198,67 @@ def gen_frames():
         print("palette train", name, int(p.step_counter[0, 0]), float(loss))
 
 
+# ------------------------------------------------------------------------------------------ get_rays / checkpoint layout
+def _reference_get_rays():
+    """nerf/utils.py:get_rays as it is (function body executed from the reference file; its module imports cv2, tensorboardX, ...,
+    which are absent here, so only the two function definitions are evaluated)."""
+    src = open(os.path.join(REF, "nerf", "utils.py")).read()
+    fns = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name in ("custom_meshgrid", "get_rays")]
+    for f in fns:
+        f.decorator_list = []
+    from packaging import version as pver
+    ns = {"torch": torch, "pver": pver, "np": np}
+    exec(compile(ast.Module(fns, []), "nerf_utils_get_rays", "exec"), ns)
+    return ns["get_rays"]
+
+
+def gen_get_rays():
+    get_rays = _reference_get_rays()
+    H, W = 36, 52
+    poses = torch.from_numpy(np.stack([scene.lookat_pose(elevation_deg=30.0, azimuth_deg=45.0), scene.lookat_pose(elevation_deg=-10.0, azimuth_deg=200.0)]))
+    intr = scene.intrinsics_from_fov(H, W)
+    out = {"poses": poses.numpy(), "intrinsics": np.asarray(intr, np.float64), "HW": np.array([H, W])}
+    r = get_rays(poses, intr, H, W, -1)
+    out.update(full_o=r["rays_o"].numpy(), full_d=r["rays_d"].numpy())
+    torch.manual_seed(11)
+    r = get_rays(poses, intr, H, W, 64)
+    out.update(rand_inds=r["inds"].numpy(), rand_o=r["rays_o"].numpy(), rand_d=r["rays_d"].numpy())
+    torch.manual_seed(12)
+    r = get_rays(poses, intr, H, W, 64, patch_size=4)
+    out.update(patch_inds=r["inds"].numpy(), patch_d=r["rays_d"].numpy())
+    torch.manual_seed(13)
+    r = get_rays(poses, intr, H, W, 64, random_size=3)
+    out.update(pair_inds=r["inds"].numpy(), pair_d=r["rays_d"].numpy())
+    torch.manual_seed(14)
+    emap = torch.rand(2, 128 * 128)
+    torch.manual_seed(15)
+    r = get_rays(poses, intr, H, W, 64, error_map=emap)
+    out.update(err_seed_map=np.array([14]), err_inds=r["inds"].numpy(), err_coarse=r["inds_coarse"].numpy(), err_d=r["rays_d"].numpy())
+    np.savez_compressed(os.path.join(HERE, "get_rays.npz"), **out)
+    print("get_rays", out["full_d"].shape)
+
+
+def gen_state_dict_layout():
+    """Names, shapes and dtypes of the reference models' state_dict (what its checkpoints hold under 'model')."""
+    import json
+    ref_nerf, ref_pal, _ = import_reference()
+    layout = {}
+    n = ref_nerf.NeRFNetwork(bound=2, cuda_ray=True)
+    layout["nerf"] = {k: [list(v.shape), str(v.dtype)] for k, v in n.state_dict().items()}
+    opt = types.SimpleNamespace(num_basis=4, clip_dim=16, pred_clip=True, use_initialization_from_rgbxy=False, test=True,
+                                color_space="srgb", smooth_sigma_xyz=0.005, smooth_sigma_color=0.2, smooth_sigma_clip=0.0)
+    p = ref_pal.PaletteNetwork(opt, bound=2, cuda_ray=True)
+    layout["palette"] = {k: [list(v.shape), str(v.dtype)] for k, v in p.state_dict().items()}
+    json.dump(layout, open(os.path.join(HERE, "state_dict_layout.json"), "w"), indent=0, sort_keys=True)
+    print("state_dict layout", len(layout["nerf"]), len(layout["palette"]))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["sh", "frames"]
+    if "rays" in which:
+        gen_get_rays()
+    if "layout" in which:
+        gen_state_dict_layout()
     if "sh" in which:
         gen_sh_torch()
         gen_sh_cuda_expr()

@@ -565,3 +565,32 @@ def test_rgb_histogram_matches_oracle(cuda):
         assert abs(bw.sum() - w.astype(np.float64).sum()) < 1e-6
     bw, bc = palette_utils.compute_RGB_histogram(np.zeros((0, 3), np.float32), np.zeros(0, np.float32), 2)
     assert bw.sum() == 0 and bc.shape == (64, 3)
+
+
+# ------------------------------------------------------------------------------------------ ray generation (f2)
+def test_get_rays_bit_exact_vs_oracle_and_reference_golden(cuda, golden_dir):
+    from palettenerf_amd import rays
+    g = np.load(f"{golden_dir}/get_rays.npz")
+    H, W = [int(v) for v in g["HW"]]
+    poses = dev(g["poses"], cuda)
+    ro, rd = rays.rays_from_indices(poses, g["intrinsics"], H, W)
+    oo, od = oracle.get_rays(g["poses"], g["intrinsics"], H, W)
+    np.testing.assert_array_equal(host(rd), od)                               # same scalar spec, correctly rounded sqrt / div on both sides
+    np.testing.assert_array_equal(host(ro), oo)
+    np.testing.assert_allclose(host(rd), g["full_d"], atol=1e-6, rtol=0)      # the reference's torch evaluation
+    for key in ("rand", "patch", "pair", "err"):
+        inds = dev(g[key + "_inds"], cuda)
+        _, d = rays.rays_from_indices(poses, g["intrinsics"], H, W, inds)
+        np.testing.assert_array_equal(host(d), oracle.get_rays(g["poses"], g["intrinsics"], H, W, g[key + "_inds"])[1])
+        np.testing.assert_allclose(host(d), g[key + "_d"], atol=1e-6, rtol=0)
+    # the drop-in surface: keys, shapes, index ranges of every sampling mode
+    torch.manual_seed(3)
+    for kw in (dict(N=-1), dict(N=128), dict(N=128, patch_size=4), dict(N=128, random_size=5), dict(N=128, error_map=torch.rand(2, 128 * 128))):
+        r = rays.get_rays(poses, g["intrinsics"], H, W, **kw)
+        n = H * W if kw["N"] < 0 else 128
+        assert r["rays_o"].shape == (2, n, 3) and r["rays_d"].shape == (2, n, 3) and r["inds"].shape == (2, n)
+        assert int(r["inds"].min()) >= 0 and int(r["inds"].max()) < H * W
+        assert ("inds_coarse" in r) == ("error_map" in kw)
+        np.testing.assert_allclose(host(r["rays_d"].norm(dim=-1)), 1.0, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        rays.rays_from_indices(poses.double(), g["intrinsics"], H, W)

@@ -126,3 +126,75 @@ def test_lattice_advance_equals_the_stepping_loop(tmp_path_factory):
     for tc, d, tt in [(0.5, 0.25, 4.0), (1.0, 2.0 ** -23, 1.0 + 2.0 ** -20), (3.999999, 0.003382, 4.1), (1.5, 0.003382, 1.5),
                       (1.5, 0.003382, float("nan")), (0.2, 0.0270632, 7.9), (2.0 ** -130, 0.01, 0.5)]:
         assert lib.lattice_case(tc, d, tt, *ptrs) == 1, (tc, d, tt, [float(o[0]) for o in out])
+
+
+# ------------------------------------------------------------------ f3: the reference's checkpoint files
+def _layout():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "state_dict_layout.json")))
+
+
+def test_state_dict_layout_equals_the_reference_models():
+    """Names, shapes and dtypes of both models' state_dict against the layout dumped from the reference's own modules
+    (tests/golden/gen_golden.py layout): what makes its .pth files loadable here."""
+    lay = _layout()
+    n = network.NeRFNetwork(bound=2, cuda_ray=True)
+    opt = renderer.default_opt()
+    opt.pred_clip = True
+    p = network.PaletteNetwork(opt, bound=2, cuda_ray=True)
+    for name, m in (("nerf", n), ("palette", p)):
+        mine = {k: [list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()}
+        assert mine == lay[name], (name, set(mine) ^ set(lay[name]))
+
+
+def test_checkpoint_round_trip_in_the_reference_format(tmp_path):
+    from palettenerf_amd import checkpoint
+    src = network.NeRFNetwork(bound=2, cuda_ray=True)
+    scene.seed_field_(src, 3)
+    src.mean_count, src.mean_density = 4321, 0.125
+    src.density_grid.uniform_(0, 2)
+    src.density_bitfield.copy_(torch.from_numpy(oracle.packbits(src.density_grid.numpy(), 0.5)))
+    # a trainer checkpoint as Trainer.save_checkpoint writes it (utils.py:1083-1143), the 'best' flavour (no density_grid) and a bare state_dict
+    full = checkpoint.save_model(src, str(tmp_path / "ngp_ep0007.pth"), epoch=7, global_step=700)
+    best = checkpoint.save_model(src, str(tmp_path / "ngp.pth"), best=True)
+    bare = str(tmp_path / "bare.pth")
+    torch.save(src.state_dict(), bare)
+    raw = torch.load(full, weights_only=False)
+    assert set(raw) >= {"epoch", "global_step", "stats", "model", "mean_count", "mean_density"} and set(raw["model"]) == set(_layout()["nerf"])
+
+    dst = network.NeRFNetwork(bound=2, cuda_ray=True)
+    info = checkpoint.load_model(dst, full)
+    assert info["missing"] == [] and info["unexpected"] == [] and info["epoch"] == 7 and dst.mean_count == 4321 and dst.mean_density == 0.125
+    for k, v in src.state_dict().items():
+        assert torch.equal(v, dst.state_dict()[k]), k
+    dst2 = network.NeRFNetwork(bound=2, cuda_ray=True)
+    info = checkpoint.load_model(dst2, best)
+    assert info["missing"] == ["density_grid"] and torch.equal(dst2.density_bitfield, src.density_bitfield)
+    dst3 = network.NeRFNetwork(bound=2, cuda_ray=True)
+    assert checkpoint.load_model(dst3, bare)["bare"] and torch.equal(dst3.encoder.embeddings, src.encoder.embeddings)
+    # PaletteNeRF starts from a trained NeRF checkpoint: the shared sub-modules load, the palette heads are reported missing
+    pal = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True)
+    info = checkpoint.load_model(pal, full)
+    assert info["unexpected"] == [] and "basis_color" in info["missing"] and torch.equal(pal.sigma_net[1].weight, src.sigma_net[1].weight)
+    assert torch.equal(pal.encoder.embeddings, src.encoder.embeddings)
+    with pytest.raises(RuntimeError):  # a bare state_dict loads strictly, like the reference
+        checkpoint.load_model(network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True), bare)
+
+
+# ------------------------------------------------------------------ f2: get_rays
+def test_get_rays_oracle_and_index_selection_against_the_reference():
+    """tests/golden/get_rays.npz holds outputs of the reference's own get_rays (nerf/utils.py:53-149, run on CPU by gen_golden.py):
+    the oracle's ray arithmetic within 1e-6 of torch's, and the mirror's pixel selection identical under the same torch seed."""
+    from palettenerf_amd import rays
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "get_rays.npz"))
+    H, W = [int(v) for v in g["HW"]]
+    o, d = oracle.get_rays(g["poses"], g["intrinsics"], H, W)
+    np.testing.assert_allclose(d, g["full_d"], atol=1e-6, rtol=0)
+    np.testing.assert_array_equal(o, g["full_o"])
+    o, d = oracle.get_rays(g["poses"], g["intrinsics"], H, W, g["rand_inds"])
+    np.testing.assert_allclose(d, g["rand_d"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(oracle.get_rays(g["poses"], g["intrinsics"], H, W, g["err_inds"])[1], g["err_d"], atol=1e-6, rtol=0)
+    torch.manual_seed(12)
+    np.testing.assert_array_equal(rays._patch_indices(H, W, 64, 4, "cpu").numpy(), g["patch_inds"][0])
+    torch.manual_seed(13)
+    np.testing.assert_array_equal(rays._pair_indices(H, W, 64, 3, "cpu").numpy(), g["pair_inds"][0])
