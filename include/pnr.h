@@ -277,6 +277,18 @@ int pnr_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint3
 int pnr_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t C,
                            const float* dy_dx, float* grad_inputs, pnr_stream_t stream);
 
+/* ---------------------------------------------------------------- training: dense-layer weight gradient */
+
+/* dW[o][i] (+)= sum_b dY[b][o] * X[b][i]: the weight gradient autograd computes for every nn.Linear(in, out, bias=False) of the
+ * fields (nerf/network.py:60-93, palette/network.py:60-153; torch sends it to the BLAS library in the reference).
+ *   x [B, in_dim], dy [B, out_dim] row-major, fp32 or fp16 (PNR_DTYPE_*; autocast hands over halves), dw [out_dim, in_dim] fp32;
+ *   in_dim, out_dim <= 64 (every layer of both models), else PNR_ERR_UNSUPPORTED; accumulate != 0 adds to dw;
+ *   workspace: pnr_linear_wgrad_workspace_bytes(B, in_dim, out_dim) bytes of device memory (per-workgroup partials, reduced in a
+ *   fixed order: the result is deterministic).  Products and sums are fp32 (v_mfma_f32_32x32x2_f32). */
+uint64_t pnr_linear_wgrad_workspace_bytes(uint32_t B, uint32_t in_dim, uint32_t out_dim);
+int pnr_linear_wgrad(const void* x, int x_dtype, const void* dy, int dy_dtype, uint32_t B, uint32_t in_dim, uint32_t out_dim, float* dw,
+                     int accumulate, void* workspace, uint64_t workspace_bytes, pnr_stream_t stream);
+
 /* ---------------------------------------------------------------- ray generation ----------- */
 
 /* device counterpart of the deterministic core of get_rays (nerf/utils.py:53-149; torch ops on the GPU in the reference):

@@ -10,12 +10,13 @@ import torch.nn.functional as F
 
 from .activation import trunc_exp
 from .encoding import get_encoder
+from .linear import Linear
 from .renderer import NeRFRenderer, PaletteRenderer
 
 
 def _mlp(dims):
     """Bias-free Linear stack (nerf/network.py:33-47); activations are applied by the caller."""
-    return nn.ModuleList([nn.Linear(dims[i], dims[i + 1], bias=False) for i in range(len(dims) - 1)])
+    return nn.ModuleList([Linear(dims[i], dims[i + 1], bias=False) for i in range(len(dims) - 1)])
 
 
 def _run(net, h, act=F.relu):
@@ -85,7 +86,7 @@ class PaletteNetwork(PaletteRenderer):
         self.diff_net = _mlp([geo_feat_dim] + [hidden_dim] * (num_layers_color - 1) + [3])
         self.basis_net = _mlp([self.in_dim_palette + 3] + [hidden_dim] * (num_layers - 1) + [geo_feat_dim])
         self.offsets_radiance_net = nn.Linear(geo_feat_dim, self.num_basis * 3 + 1)  # the only layer with a bias
-        self.omega_net = nn.Sequential(nn.Linear(geo_feat_dim, self.num_basis, bias=False), nn.Softplus())
+        self.omega_net = nn.Sequential(Linear(geo_feat_dim, self.num_basis, bias=False), nn.Softplus())
         if opt.pred_clip:
             self.clip_net = _mlp([self.in_dim_clip] + [hidden_dim] * (num_layers - 1) + [opt.clip_dim])
         self.bg_net = None

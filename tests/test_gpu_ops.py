@@ -594,3 +594,45 @@ def test_get_rays_bit_exact_vs_oracle_and_reference_golden(cuda, golden_dir):
         np.testing.assert_allclose(host(r["rays_d"].norm(dim=-1)), 1.0, atol=1e-6)
     with pytest.raises(RuntimeError):
         rays.rays_from_indices(poses.double(), g["intrinsics"], H, W)
+
+
+# ------------------------------------------------------------------------------------------ dense-layer weight gradient (training)
+@pytest.mark.parametrize("n_in,n_out", [(32, 64), (64, 16), (31, 64), (64, 64), (64, 3), (15, 13), (35, 64), (1, 1)])
+@pytest.mark.parametrize("dtypes", [(torch.float32, torch.float32), (torch.float16, torch.float16), (torch.float32, torch.float16)])
+def test_linear_weight_grad_matches_float64(cuda, n_in, n_out, dtypes):
+    from palettenerf_amd import linear
+    g = torch.Generator().manual_seed(n_in * 100 + n_out)
+    for B in (1, 2, 4097, 100003):
+        x = torch.randn(B, n_in, generator=g).to(dtypes[0])
+        dy = (torch.randn(B, n_out, generator=g) * 0.1).to(dtypes[1])
+        ref = dy.double().t() @ x.double()                                      # exact products of the given (possibly fp16) values
+        got = linear.weight_grad(x.to(cuda), dy.to(cuda))
+        assert got.shape == (n_out, n_in) and got.dtype == torch.float32
+        scale = float((dy.double().abs().t() @ x.double().abs()).max()) + 1e-30
+        np.testing.assert_allclose(host(got), ref.numpy(), atol=4e-7 * scale, rtol=0)   # fp32 accumulation of B terms, pairwise-ish order
+    # accumulate into an existing gradient, deterministic across calls
+    out = torch.ones(n_out, n_in, device=cuda)
+    linear.weight_grad(x.to(cuda), dy.to(cuda), out=out, accumulate=True)
+    np.testing.assert_array_equal(host(out), host(got + 1.0))
+    np.testing.assert_array_equal(host(linear.weight_grad(x.to(cuda), dy.to(cuda))), host(got))
+
+
+def test_linear_module_gradients_match_nn_linear(cuda):
+    from palettenerf_amd import linear
+    torch.manual_seed(0)
+    ours, theirs = linear.Linear(31, 64, bias=False).to(cuda), torch.nn.Linear(31, 64, bias=False).to(cuda)
+    theirs.weight.data.copy_(ours.weight.data)
+    x = torch.randn(50000, 31, device=cuda, requires_grad=True)
+    x2 = x.detach().clone().requires_grad_(True)
+    w = torch.randn(50000, 64, device=cuda)
+    (ours(x) * w).sum().backward()
+    (theirs(x2) * w).sum().backward()
+    np.testing.assert_allclose(host(ours.weight.grad), host(theirs.weight.grad), rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(host(x.grad), host(x2.grad), rtol=1e-5, atol=1e-6)
+    assert set(ours.state_dict()) == {"weight"}
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = ours(x.detach())
+    assert y.dtype == torch.float16
+    y.float().sum().backward()                  # fp16 dY, fp32 X through the kernel
+    with pytest.raises(RuntimeError):
+        linear.weight_grad(torch.zeros(4, 65, device=cuda), torch.zeros(4, 3, device=cuda))
