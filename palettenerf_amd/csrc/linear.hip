@@ -80,13 +80,24 @@ __global__ void __launch_bounds__(kLinThreads) k_linear_wgrad(const TX* __restri
         }
 }
 
+// dw[e] (+)= sum over the workgroup partials, fixed order: 32 elements x 8 partial groups per workgroup (128-byte coalesced rows),
+// group g sums partials g, g + 8, ...; the 8 group sums are added in order.
 __global__ void __launch_bounds__(256) k_linear_wgrad_reduce(const float* __restrict__ partial, uint32_t nparts, uint32_t n, float* __restrict__ dw,
                                                              int accumulate) {
-    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= n) return;
+    __shared__ float red[8][32];
+    const uint32_t c = threadIdx.x & 31u, g = threadIdx.x >> 5;
+    const uint32_t e = blockIdx.x * 32 + c;
     float s = 0.0f;
-    for (uint32_t p = 0; p < nparts; p++) s += partial[(size_t)p * n + e];
-    dw[e] = accumulate ? dw[e] + s : s;
+    if (e < n)
+        for (uint32_t p = g; p < nparts; p += 8) s += partial[(size_t)p * n + e];
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0 && e < n) {
+        float t = red[0][c];
+#pragma unroll
+        for (int k = 1; k < 8; k++) t += red[k][c];
+        dw[e] = accumulate ? dw[e] + t : t;
+    }
 }
 
 static uint32_t wgrad_blocks(uint32_t B) {
@@ -136,7 +147,7 @@ int pnr_linear_wgrad(const void* x, int x_dtype, const void* dy, int dy_dtype, u
     else PNR_WG_T(__half, float);
 #undef PNR_WG_T
 #undef PNR_WG
-    hipLaunchKernelGGL(k_linear_wgrad_reduce, dim3(cdiv(n, 256)), dim3(256), 0, s, partial, blocks, n, dw, accumulate);
+    hipLaunchKernelGGL(k_linear_wgrad_reduce, dim3(cdiv(n, 32)), dim3(256), 0, s, partial, blocks, n, dw, accumulate);
     return check_launch();
 }
 
