@@ -83,11 +83,12 @@ __global__ void __launch_bounds__(kBlock) k_composite_flex_train_fwd(const float
     }
 }
 
-// Same arithmetic with 16 lanes per ray (n_channel % 4 == 0): a training batch has only a few thousand rays, one thread per ray
-// leaves the chip idle and walks a 4 n_channel-byte-strided column.  Every lane re-runs the cheap transmittance recurrence
-// (identical weights, identical order) and owns one float4 of channels: a sample's row is one coalesced read; four samples are
-// fetched ahead of the serial recurrence.
+// Same arithmetic with 16 lanes per ray: a training batch has only a few thousand rays, one thread per ray leaves the chip idle
+// and walks a 4 n_channel-byte-strided column.  Every lane re-runs the cheap transmittance recurrence (identical weights,
+// identical order) and owns channels q, q + 16, q + 32, q + 48 of a 64-channel pass: the 16 lanes of a ray read 64 contiguous
+// bytes per load; four samples are fetched ahead of the serial recurrence.
 constexpr uint32_t kLanesPerRay = 16;
+constexpr int kCoopCh = 4;   // channels per lane and pass
 __global__ void __launch_bounds__(kBlock) k_composite_flex_train_fwd_coop(const float* __restrict__ sigmas, const float* __restrict__ input,
                                                                           const float* __restrict__ deltas, const int32_t* __restrict__ rays,
                                                                           uint32_t M, uint32_t N, uint32_t n_channel, float T_thresh,
@@ -96,8 +97,8 @@ __global__ void __launch_bounds__(kBlock) k_composite_flex_train_fwd_coop(const 
     if (n >= N) return;
     const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
     const bool empty = num_steps == 0 || offset + num_steps >= M;   // '>=' here, '>' in the rgb variant (reference quirk)
-    for (uint32_t c0 = q * 4; c0 < n_channel; c0 += kLanesPerRay * 4) {
-        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (uint32_t c0 = q; c0 < n_channel; c0 += kLanesPerRay * kCoopCh) {
+        float acc[kCoopCh] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (!empty) {
             const float* s = sigmas + offset;
             const float* dl = deltas + (size_t)offset * 2;
@@ -105,26 +106,28 @@ __global__ void __launch_bounds__(kBlock) k_composite_flex_train_fwd_coop(const 
             float T = 1.0f;
             bool stop = false;
             for (uint32_t base = 0; base < num_steps && !stop; base += 4) {
-                float sg[4], dt[4];
-                float4 v[4];
+                float sg[4], dt[4], v[4][kCoopCh];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const uint32_t k = base + u < num_steps ? base + u : num_steps - 1;   // clamped: stays inside the ray's rows
                     sg[u] = s[k]; dt[u] = dl[(size_t)k * 2];
-                    v[u] = *reinterpret_cast<const float4*>(in + (size_t)k * n_channel);
+#pragma unroll
+                    for (int j = 0; j < kCoopCh; j++) v[u][j] = c0 + j * kLanesPerRay < n_channel ? in[(size_t)k * n_channel + j * kLanesPerRay] : 0.0f;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     if (stop || base + u >= num_steps) break;
                     const float alpha = alpha_of(sg[u], dt[u]);
                     const float w = alpha * T;
-                    acc.x = fmaf(w, v[u].x, acc.x); acc.y = fmaf(w, v[u].y, acc.y); acc.z = fmaf(w, v[u].z, acc.z); acc.w = fmaf(w, v[u].w, acc.w);
+#pragma unroll
+                    for (int j = 0; j < kCoopCh; j++) acc[j] = fmaf(w, v[u][j], acc[j]);
                     T *= 1.0f - alpha;
                     if (T < T_thresh) stop = true;
                 }
             }
         }
-        *reinterpret_cast<float4*>(output + (size_t)index * n_channel + c0) = acc;
+#pragma unroll
+        for (int j = 0; j < kCoopCh; j++) if (c0 + j * kLanesPerRay < n_channel) output[(size_t)index * n_channel + c0 + j * kLanesPerRay] = acc[j];
     }
 }
 
@@ -137,8 +140,10 @@ __global__ void __launch_bounds__(kBlock) k_composite_flex_train_bwd_coop(const 
     if (n >= N) return;
     const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
     if (num_steps == 0 || offset + num_steps >= M) return;
-    for (uint32_t c0 = q * 4; c0 < n_channel; c0 += kLanesPerRay * 4) {
-        const float4 go = *reinterpret_cast<const float4*>(grad_output + (size_t)index * n_channel + c0);
+    for (uint32_t c0 = q; c0 < n_channel; c0 += kLanesPerRay * kCoopCh) {
+        float go[kCoopCh];
+#pragma unroll
+        for (int j = 0; j < kCoopCh; j++) go[j] = c0 + j * kLanesPerRay < n_channel ? grad_output[(size_t)index * n_channel + c0 + j * kLanesPerRay] : 0.0f;
         const float* s = sigmas + offset;
         const float* dl = deltas + (size_t)offset * 2;
         float* gin = grad_input + (size_t)offset * n_channel + c0;
@@ -158,7 +163,9 @@ __global__ void __launch_bounds__(kBlock) k_composite_flex_train_bwd_coop(const 
                 const float w = alpha * T;
                 T *= 1.0f - alpha;
                 if (T < T_thresh) { stop = true; break; }   // break BEFORE the write: the breaking sample gets no gradient (reference quirk)
-                *reinterpret_cast<float4*>(gin + (size_t)(base + u) * n_channel) = make_float4(go.x * w, go.y * w, go.z * w, go.w * w);
+#pragma unroll
+                for (int j = 0; j < kCoopCh; j++)
+                    if (c0 + j * kLanesPerRay < n_channel) gin[(size_t)(base + u) * n_channel + j * kLanesPerRay] = go[j] * w;
             }
         }
     }
@@ -324,7 +331,7 @@ int pnr_composite_rays_flex_train_forward(const float* sigmas, const float* inpu
     if (N == 0 || n_channel == 0) return PNR_OK;
     if (!rays || !output) return PNR_ERR_INVALID;
     if (M > 0 && (!sigmas || !input || !deltas)) return PNR_ERR_INVALID;
-    if (n_channel % 4 == 0)
+    if (n_channel >= 4)
         hipLaunchKernelGGL(k_composite_flex_train_fwd_coop, dim3(cdiv(N * kLanesPerRay, kBlock)), dim3(kBlock), 0, as_stream(stream), sigmas, input,
                            deltas, rays, M, N, n_channel, T_thresh, output);
     else
@@ -340,7 +347,7 @@ int pnr_composite_rays_flex_train_backward(const float* grad_output, const float
     if (n_channel > PNR_CHANNEL_MAXIMUM) return PNR_ERR_UNSUPPORTED;
     if (N == 0 || M == 0 || n_channel == 0) return PNR_OK;
     if (!grad_output || !sigmas || !deltas || !rays || !grad_input) return PNR_ERR_INVALID;
-    if (n_channel % 4 == 0)
+    if (n_channel >= 4)
         hipLaunchKernelGGL(k_composite_flex_train_bwd_coop, dim3(cdiv(N * kLanesPerRay, kBlock)), dim3(kBlock), 0, as_stream(stream), grad_output,
                            sigmas, deltas, rays, M, N, n_channel, T_thresh, grad_input);
     else
