@@ -277,6 +277,16 @@ int pnr_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint3
 int pnr_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t C,
                            const float* dy_dx, float* grad_inputs, pnr_stream_t stream);
 
+/* Table gradient of the hash grid for D = 3, C = 2, fp32 (the shipped fields) without global atomics in the inner loop: records are
+ * binned by 8192-row table bucket, each bucket is accumulated in LDS and added to the table once (csrc/grid_binned.hip).  Same
+ * contract as the embeddings part of pnr_grid_encode_backward (gridencoder.cu:216-286: grad [L,B,C] level-major, accumulates into
+ * the caller-zeroed grad_embeddings); total_rows = rows of the table (offsets[L]); other shapes return PNR_ERR_UNSUPPORTED (use
+ * pnr_grid_encode_backward).  workspace: pnr_grid_backward_binned_workspace_bytes(B, L, total_rows) bytes (10 B per record). */
+uint64_t pnr_grid_backward_binned_workspace_bytes(uint32_t B, uint32_t L, uint64_t total_rows);
+int pnr_grid_encode_backward_binned(const float* grad, const float* inputs, const int32_t* offsets, float* grad_embeddings, uint32_t B, uint32_t D,
+                                    uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, uint64_t total_rows,
+                                    void* workspace, uint64_t workspace_bytes, pnr_stream_t stream);
+
 /* ---------------------------------------------------------------- training: dense-layer weight gradient */
 
 /* dW[o][i] (+)= sum_b dY[b][o] * X[b][i]: the weight gradient autograd computes for every nn.Linear(in, out, bias=False) of the

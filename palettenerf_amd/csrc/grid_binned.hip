@@ -1,0 +1,277 @@
+// grid_binned.hip -- hash-grid table gradient without global atomics in the inner loop (D = 3, C = 2, fp32 tables).
+//
+// The scatter of gridencoder.cu:216-286 issues 8 corners x 2 channels float atomics per (sample, level): 160 M per 627 k-sample
+// training batch.  On MI355X fp32 atomics execute memory-side (pinning a level's atomics to one XCD changes nothing), at
+// 17-29 G/s that is 5.5 ms of a 13.6 ms PaletteNeRF step.  Here the table is cut into buckets of kBinRows rows (64 KiB of
+// gradient = it fits the LDS of a CU) and the update is reorganised in three sweeps:
+//   count    every workgroup histograms the buckets its (sample, level, corner) records fall into (LDS), adds the non-empty bins
+//            to the global bucket counts;
+//   scatter  after a scan of the counts, the same traversal writes each record (row inside its bucket: 2 bytes, weighted
+//            gradient: 8 bytes) to its bucket's contiguous segment (a workgroup reserves its slice per bucket with one returning
+//            atomic, ranks inside the slice come from LDS);
+//   gather   one workgroup per (bucket, <= kBinChunk records): accumulates its records into a 64 KiB LDS image of the bucket
+//            with LDS atomics, then adds the image to the table -- plainly when it owns the bucket, with global atomics on the
+//            non-zero rows when a crowded bucket (the dense coarse levels) is split between several workgroups.
+// Records cost 10 B each written + read once (1.6 GB of HBM traffic per 627 k batch), the table is touched once per bucket.
+// Sums are formed in a different order than the atomic scatter: same values up to fp32 rounding order, like any atomic run.
+#include "pnr_common.hpp"
+#include "grid_core.hpp"
+
+namespace pnr {
+
+constexpr uint32_t kBinRows = 8192;     // rows per bucket (x 2 channels x 4 B = 64 KiB)
+constexpr uint32_t kBinChunk = 65536;   // records per gather workgroup
+constexpr uint32_t kBinSamples = 4;     // samples per thread in count / scatter: 1024 per workgroup
+constexpr uint32_t kBinThreads = 256;
+constexpr uint32_t kMaxBucketsPerLaunch = 8192;  // LDS histogram bound (counts of one level's buckets)
+
+struct BinJob { uint32_t row_base, nrows, rec_begin, rec_end, exclusive; };
+
+// first global bucket of `level`: buckets are numbered level by level
+__device__ __forceinline__ uint32_t level_bucket_base(const int32_t* __restrict__ offsets, uint32_t level) {
+    uint32_t base = 0;
+    for (uint32_t l = 0; l < level; l++) base += ((uint32_t)(offsets[l + 1] - offsets[l]) + kBinRows - 1) / kBinRows;
+    return base;
+}
+
+// the 8 (row, weight) pairs of one sample on one level: gridencoder.cu:100-175 indexing, identical to k_grid_bwd
+struct Corners { uint32_t row[8]; float w[8]; bool active; };
+__device__ __forceinline__ Corners corners_of(const float* __restrict__ inputs, uint32_t b, uint32_t B, float scale, uint32_t resolution,
+                                              uint32_t hashmap_size, uint32_t gridtype, bool align_corners) {
+    Corners c;
+    c.active = b < B;
+    float pos[3];
+    uint32_t pg[3];
+#pragma unroll
+    for (uint32_t d = 0; d < 3; d++) {
+        const float v = c.active ? inputs[(size_t)b * 3 + d] : 0.0f;
+        if (v < 0.0f || v > 1.0f) c.active = false;
+        pos[d] = fmaf(v, scale, align_corners ? 0.0f : 0.5f);
+        const float fl = floorf(pos[d]);
+        pg[d] = (uint32_t)fl;
+        pos[d] -= (float)pg[d];
+    }
+#pragma unroll
+    for (uint32_t idx = 0; idx < 8; idx++) {
+        float w = 1.0f;
+        uint32_t pl[3];
+#pragma unroll
+        for (uint32_t d = 0; d < 3; d++) {
+            if ((idx & (1u << d)) == 0) { w *= 1.0f - pos[d]; pl[d] = pg[d]; }
+            else { w *= pos[d]; pl[d] = pg[d] + 1; }
+        }
+        c.w[idx] = w;
+        c.row[idx] = grid_index<3, 1>(gridtype, align_corners, hashmap_size, resolution, pl);
+    }
+    return c;
+}
+
+// sweep 1: bucket counts
+__global__ void __launch_bounds__(kBinThreads) k_bin_count(const float* __restrict__ inputs, const int32_t* __restrict__ offsets, uint32_t B,
+                                                           LevelParams lp, uint32_t gridtype, bool align_corners, uint32_t* __restrict__ counts) {
+    extern __shared__ uint32_t hist[];
+    const uint32_t level = blockIdx.y;
+    const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+    const uint32_t nb = (hashmap_size + kBinRows - 1) / kBinRows;
+    for (uint32_t k = threadIdx.x; k < nb; k += kBinThreads) hist[k] = 0;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < kBinSamples; u++) {
+        const uint32_t b = (blockIdx.x * kBinSamples + u) * kBinThreads + threadIdx.x;
+        const Corners c = corners_of(inputs, b, B, lp.scale[level], lp.resolution[level], hashmap_size, gridtype, align_corners);
+        if (!c.active) continue;
+#pragma unroll
+        for (uint32_t idx = 0; idx < 8; idx++) atomicAdd(&hist[c.row[idx] / kBinRows], 1u);
+    }
+    __syncthreads();
+    const uint32_t base = level_bucket_base(offsets, level);
+    for (uint32_t k = threadIdx.x; k < nb; k += kBinThreads)
+        if (hist[k]) atomicAdd(&counts[base + k], hist[k]);
+}
+
+// single workgroup: record offsets of the buckets (exclusive scan), the write cursors, and the gather job list
+__global__ void __launch_bounds__(1024) k_bin_plan(const int32_t* __restrict__ offsets, uint32_t L, const uint32_t* __restrict__ counts,
+                                                   uint32_t* __restrict__ rec_off, uint32_t* __restrict__ cursor, BinJob* __restrict__ jobs,
+                                                   uint32_t* __restrict__ n_jobs) {
+    __shared__ uint32_t wsum[2][1024 / PNR_WAVE];
+    __shared__ uint32_t carry[2];
+    const uint32_t total_buckets = level_bucket_base(offsets, L);
+    if (threadIdx.x == 0) { carry[0] = 0; carry[1] = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & (PNR_WAVE - 1), wave = threadIdx.x / PNR_WAVE;
+    for (uint32_t base = 0; base < total_buckets; base += 1024) {
+        const uint32_t k = base + threadIdx.x;
+        const uint32_t cnt = k < total_buckets ? counts[k] : 0;
+        const uint32_t nj = (cnt + kBinChunk - 1) / kBinChunk;
+        const uint32_t inc0 = (uint32_t)wave_inclusive_scan((int)cnt), inc1 = (uint32_t)wave_inclusive_scan((int)nj);
+        if (lane == PNR_WAVE - 1) { wsum[0][wave] = inc0; wsum[1][wave] = inc1; }
+        __syncthreads();
+        uint32_t off0 = carry[0], off1 = carry[1], tot0 = 0, tot1 = 0;
+        for (int wv = 0; wv < 1024 / PNR_WAVE; wv++) {
+            if (wv < wave) { off0 += wsum[0][wv]; off1 += wsum[1][wv]; }
+            tot0 += wsum[0][wv]; tot1 += wsum[1][wv];
+        }
+        if (k < total_buckets) {
+            const uint32_t r0 = off0 + inc0 - cnt, j0 = off1 + inc1 - nj;
+            rec_off[k] = r0;
+            cursor[k] = r0;
+            // which level / bucket-in-level is k?
+            uint32_t level = 0, lb = 0;
+            for (uint32_t l = 0; l < L; l++) {
+                const uint32_t nbl = ((uint32_t)(offsets[l + 1] - offsets[l]) + kBinRows - 1) / kBinRows;
+                if (k < lb + nbl) { level = l; break; }
+                lb += nbl;
+            }
+            const uint32_t rows_l = (uint32_t)(offsets[level + 1] - offsets[level]);
+            const uint32_t first_row = (k - lb) * kBinRows;
+            for (uint32_t j = 0; j < nj; j++) {
+                BinJob jb;
+                jb.row_base = (uint32_t)offsets[level] + first_row;
+                jb.nrows = rows_l - first_row < kBinRows ? rows_l - first_row : kBinRows;
+                jb.rec_begin = r0 + j * kBinChunk;
+                jb.rec_end = j + 1 < nj ? r0 + (j + 1) * kBinChunk : r0 + cnt;
+                jb.exclusive = nj == 1;
+                jobs[j0 + j] = jb;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { carry[0] += tot0; carry[1] += tot1; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { rec_off[total_buckets] = carry[0]; *n_jobs = carry[1]; }
+}
+
+// sweep 2: write the records into their buckets' segments
+__global__ void __launch_bounds__(kBinThreads) k_bin_scatter(const float* __restrict__ grad, const float* __restrict__ inputs,
+                                                             const int32_t* __restrict__ offsets, uint32_t B, LevelParams lp, uint32_t gridtype,
+                                                             bool align_corners, uint32_t* __restrict__ cursor, uint16_t* __restrict__ rec_row,
+                                                             float2* __restrict__ rec_val) {
+    extern __shared__ uint32_t lds[];   // [nb] counts, then [nb] slice bases
+    const uint32_t level = blockIdx.y;
+    const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+    const uint32_t nb = (hashmap_size + kBinRows - 1) / kBinRows;
+    uint32_t* hist = lds;
+    uint32_t* slice = lds + nb;
+    for (uint32_t k = threadIdx.x; k < nb; k += kBinThreads) hist[k] = 0;
+    __syncthreads();
+    Corners c[kBinSamples];
+    uint32_t rank[kBinSamples][8];
+#pragma unroll
+    for (uint32_t u = 0; u < kBinSamples; u++) {
+        const uint32_t b = (blockIdx.x * kBinSamples + u) * kBinThreads + threadIdx.x;
+        c[u] = corners_of(inputs, b, B, lp.scale[level], lp.resolution[level], hashmap_size, gridtype, align_corners);
+        if (!c[u].active) continue;
+#pragma unroll
+        for (uint32_t idx = 0; idx < 8; idx++) rank[u][idx] = atomicAdd(&hist[c[u].row[idx] / kBinRows], 1u);
+    }
+    __syncthreads();
+    const uint32_t base = level_bucket_base(offsets, level);
+    for (uint32_t k = threadIdx.x; k < nb; k += kBinThreads) slice[k] = hist[k] ? atomicAdd(&cursor[base + k], hist[k]) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < kBinSamples; u++) {
+        if (!c[u].active) continue;
+        const uint32_t b = (blockIdx.x * kBinSamples + u) * kBinThreads + threadIdx.x;
+        const float2 g = *reinterpret_cast<const float2*>(grad + ((size_t)level * B + b) * 2);
+#pragma unroll
+        for (uint32_t idx = 0; idx < 8; idx++) {
+            const uint32_t bucket = c[u].row[idx] / kBinRows;
+            const uint32_t pos = slice[bucket] + rank[u][idx];
+            rec_row[pos] = (uint16_t)(c[u].row[idx] % kBinRows);
+            rec_val[pos] = make_float2(c[u].w[idx] * g.x, c[u].w[idx] * g.y);
+        }
+    }
+}
+
+// sweep 3: accumulate one job's records in LDS, add the bucket image to the table
+__global__ void __launch_bounds__(1024) k_bin_gather(const BinJob* __restrict__ jobs, const uint32_t* __restrict__ n_jobs,
+                                                     const uint16_t* __restrict__ rec_row, const float2* __restrict__ rec_val,
+                                                     float* __restrict__ grad_grid) {
+    extern __shared__ float acc[];   // [kBinRows][2]
+    for (uint32_t job = blockIdx.x; job < *n_jobs; job += gridDim.x) {
+        const BinJob jb = jobs[job];
+        for (uint32_t i = threadIdx.x; i < jb.nrows * 2; i += 1024) acc[i] = 0.0f;
+        __syncthreads();
+        for (uint32_t r = jb.rec_begin + threadIdx.x; r < jb.rec_end; r += 1024) {
+            const uint32_t row = rec_row[r];
+            const float2 v = rec_val[r];
+            atomicAdd(&acc[row * 2], v.x);
+            atomicAdd(&acc[row * 2 + 1], v.y);
+        }
+        __syncthreads();
+        float* dst = grad_grid + (size_t)jb.row_base * 2;
+        if (jb.exclusive) {
+            for (uint32_t i = threadIdx.x; i < jb.nrows * 2; i += 1024) dst[i] += acc[i];
+        } else {
+            for (uint32_t i = threadIdx.x; i < jb.nrows * 2; i += 1024)
+                if (acc[i] != 0.0f) unsafeAtomicAdd(dst + i, acc[i]);
+        }
+        __syncthreads();
+    }
+}
+
+struct BinLayout { uint64_t counts, rec_off, cursor, n_jobs, jobs, rec_row, rec_val, total; uint32_t bucket_bound, job_bound; };
+static BinLayout bin_layout(uint32_t B, uint32_t L, uint64_t total_rows) {
+    BinLayout l;
+    const uint64_t n_rec = (uint64_t)B * L * 8;
+    l.bucket_bound = (uint32_t)(total_rows / kBinRows + L);
+    l.job_bound = (uint32_t)(n_rec / kBinChunk + l.bucket_bound);
+    auto al = [](uint64_t v) { return (v + 255) & ~uint64_t(255); };
+    uint64_t o = 0;
+    l.counts = o; o = al(o + (uint64_t)l.bucket_bound * 4);
+    l.rec_off = o; o = al(o + ((uint64_t)l.bucket_bound + 1) * 4);
+    l.cursor = o; o = al(o + (uint64_t)l.bucket_bound * 4);
+    l.n_jobs = o; o = al(o + 4);
+    l.jobs = o; o = al(o + (uint64_t)l.job_bound * sizeof(BinJob));
+    l.rec_row = o; o = al(o + n_rec * 2);
+    l.rec_val = o; o = al(o + n_rec * 8);
+    l.total = o;
+    return l;
+}
+
+}  // namespace pnr
+
+using namespace pnr;
+
+extern "C" {
+
+uint64_t pnr_grid_backward_binned_workspace_bytes(uint32_t B, uint32_t L, uint64_t total_rows) { return bin_layout(B, L, total_rows).total; }
+
+int pnr_grid_encode_backward_binned(const float* grad, const float* inputs, const int32_t* offsets, float* grad_embeddings, uint32_t B, uint32_t D,
+                                    uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, uint64_t total_rows,
+                                    void* workspace, uint64_t workspace_bytes, pnr_stream_t stream) {
+    if (D != 3 || C != 2 || L == 0 || L > kMaxLevels) return PNR_ERR_UNSUPPORTED;
+    if (B == 0) return PNR_OK;
+    if (!grad || !inputs || !offsets || !grad_embeddings || !workspace || total_rows == 0) return PNR_ERR_INVALID;
+    const BinLayout lay = bin_layout(B, L, total_rows);
+    if (workspace_bytes < lay.total) return PNR_ERR_INVALID;
+    if (lay.bucket_bound > kMaxBucketsPerLaunch || (uint64_t)B * L * 8 >= (1ull << 32)) return PNR_ERR_UNSUPPORTED;
+    hipStream_t s = as_stream(stream);
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    uint32_t* counts = reinterpret_cast<uint32_t*>(ws + lay.counts);
+    uint32_t* rec_off = reinterpret_cast<uint32_t*>(ws + lay.rec_off);
+    uint32_t* cursor = reinterpret_cast<uint32_t*>(ws + lay.cursor);
+    uint32_t* n_jobs = reinterpret_cast<uint32_t*>(ws + lay.n_jobs);
+    BinJob* jobs = reinterpret_cast<BinJob*>(ws + lay.jobs);
+    uint16_t* rec_row = reinterpret_cast<uint16_t*>(ws + lay.rec_row);
+    float2* rec_val = reinterpret_cast<float2*>(ws + lay.rec_val);
+    const LevelParams lp = make_level_params(L, S, H);
+    if (hipMemsetAsync(counts, 0, (size_t)lay.bucket_bound * 4, s) != hipSuccess) return PNR_ERR_LAUNCH;
+    const dim3 grid(cdiv(B, kBinThreads * kBinSamples), L);
+    const uint32_t hist_bytes = lay.bucket_bound * 4;
+    hipLaunchKernelGGL(k_bin_count, grid, dim3(kBinThreads), hist_bytes, s, inputs, offsets, B, lp, gridtype, align_corners != 0, counts);
+    hipLaunchKernelGGL(k_bin_plan, dim3(1), dim3(1024), 0, s, offsets, L, counts, rec_off, cursor, jobs, n_jobs);
+    hipLaunchKernelGGL(k_bin_scatter, grid, dim3(kBinThreads), 2 * hist_bytes, s, grad, inputs, offsets, B, lp, gridtype, align_corners != 0, cursor,
+                       rec_row, rec_val);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_gather), hipFuncAttributeMaxDynamicSharedMemorySize, kBinRows * 2 * 4) != hipSuccess)
+            return PNR_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const uint32_t gather_blocks = lay.job_bound < 1024u ? lay.job_bound : 1024u;
+    hipLaunchKernelGGL(k_bin_gather, dim3(gather_blocks), dim3(1024), kBinRows * 2 * 4, s, jobs, n_jobs, rec_row, rec_val, grad_embeddings);
+    return check_launch();
+}
+
+}  // extern "C"

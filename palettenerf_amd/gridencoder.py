@@ -10,12 +10,14 @@ import torch.nn as nn
 from torch.autograd import Function
 from torch.amp import custom_bwd, custom_fwd
 
+from . import _lib
 from ._torch_glue import call, ptr, require
 
 _u32, _f32, _int = ctypes.c_uint32, ctypes.c_float, ctypes.c_int
 
 _gridtype_to_id = {"hash": 0, "tiled": 1}
 _DTYPE_ID = {torch.float32: 0, torch.float16: 1}
+BINNED_MIN_ROWS = 32768   # batches from this size on use the bucket-binned table gradient
 
 
 def level_offsets(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size, align_corners=False):
@@ -61,6 +63,14 @@ class _grid_encode(Function):
         B, D, C, L, S, H, gridtype, align_corners = ctx.meta
         grad_level_major = grad.view(B, L, C).permute(1, 0, 2).contiguous().to(embeddings.dtype)
         grad_embeddings = torch.zeros_like(embeddings)  # the scatter accumulates into it
+        if dy_dx is None and D == 3 and C == 2 and embeddings.dtype == torch.float32 and B >= BINNED_MIN_ROWS and B * L * 8 < 2 ** 32:
+            # large training batches: bucket-binned accumulation in LDS instead of 16 L B float atomics (csrc/grid_binned.hip)
+            rows = embeddings.shape[0]
+            nbytes = int(_lib.load().pnr_grid_backward_binned_workspace_bytes(B, L, rows))
+            ws = torch.empty(nbytes // 4 + 1, dtype=torch.int32, device=embeddings.device)
+            call("pnr_grid_encode_backward_binned", ptr(grad_level_major), ptr(inputs), ptr(offsets), ptr(grad_embeddings), _u32(B), _u32(D), _u32(C),
+                 _u32(L), _f32(S), _u32(H), _u32(gridtype), _int(int(align_corners)), ctypes.c_uint64(rows), ptr(ws), ctypes.c_uint64(nbytes))
+            return None, grad_embeddings, None, None, None, None, None, None
         grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if dy_dx is not None else None
         call("pnr_grid_encode_backward", ptr(grad_level_major), ptr(inputs), ptr(embeddings), ptr(offsets), ptr(grad_embeddings), _u32(B), _u32(D),
              _u32(C), _u32(L), _f32(S), _u32(H), ptr(dy_dx), ptr(grad_inputs), _u32(gridtype), _int(int(align_corners)),

@@ -636,3 +636,41 @@ def test_linear_module_gradients_match_nn_linear(cuda):
     y.float().sum().backward()                  # fp16 dY, fp32 X through the kernel
     with pytest.raises(RuntimeError):
         linear.weight_grad(torch.zeros(4, 65, device=cuda), torch.zeros(4, 3, device=cuda))
+
+
+@pytest.mark.parametrize("case", ["hash16", "tiled", "small_table", "clustered"])
+def test_grid_backward_binned_matches_oracle(cuda, case, monkeypatch):
+    """The bucket-binned table gradient (csrc/grid_binned.hip) against the oracle's scatter loop and against the atomic kernel."""
+    rng = np.random.default_rng(31)
+    monkeypatch.setattr(gridencoder, "BINNED_MIN_ROWS", 1)
+    if case == "hash16":
+        pls, offsets, emb, x = _grid_setup(rng, 16, 16, 19, 4096, 2, 70001)
+        gridtype = 0
+    elif case == "tiled":
+        pls, offsets, emb, x = _grid_setup(rng, 8, 16, 15, None, 2, 9001)
+        gridtype = 1
+    elif case == "small_table":          # every level a single partial bucket
+        pls, offsets, emb, x = _grid_setup(rng, 4, 4, 10, None, 2, 3000)
+        gridtype = 0
+    else:                                # all samples in one cell neighbourhood: one crowded bucket on the dense levels, split jobs
+        pls, offsets, emb, x = _grid_setup(rng, 16, 16, 19, 4096, 2, 150000)
+        x = (0.4 + 0.01 * rng.random(x.shape)).astype(np.float32)
+        gridtype = 0
+    L = len(offsets) - 1
+    te = dev(emb, cuda).requires_grad_(True)
+    out = gridencoder.grid_encode(dev(x, cuda), te, dev(offsets, cuda), pls, 16 if case != "small_table" else 4, False, gridtype, False)
+    g = rng.standard_normal(out.shape).astype(np.float32)
+    (out * dev(g, cuda)).sum().backward()
+    binned = host(te.grad).copy()
+    ogg = oracle.grid_encode_backward(g, x, emb.shape, offsets, pls, 16 if case != "small_table" else 4, gridtype=gridtype)
+    scale = np.abs(ogg).max()
+    # 'clustered': ~1e5 addends per table row; the oracle's sequential fp32 loop, the atomics and the LDS image each round in a
+    # different order, so the tolerance there is the fp32 accumulation error of such sums (~1e-4 relative), not the kernel's
+    rtol, atol = (5e-4, 5e-3) if case == "clustered" else (1e-5, 2e-6 * max(1.0, scale))
+    np.testing.assert_allclose(binned, ogg, rtol=rtol, atol=atol)
+    assert abs(float(binned.astype(np.float64).sum()) - float(ogg.astype(np.float64).sum())) < 1e-3 * max(1.0, float(np.abs(ogg).astype(np.float64).sum()) * 1e-4)
+    monkeypatch.setattr(gridencoder, "BINNED_MIN_ROWS", 1 << 30)
+    te.grad = None
+    out = gridencoder.grid_encode(dev(x, cuda), te, dev(offsets, cuda), pls, 16 if case != "small_table" else 4, False, gridtype, False)
+    (out * dev(g, cuda)).sum().backward()
+    np.testing.assert_allclose(binned, host(te.grad), rtol=rtol, atol=atol)
