@@ -20,7 +20,7 @@
 namespace pnr {
 
 constexpr uint32_t kBinRows = 8192;     // rows per bucket (x 2 channels x 4 B = 64 KiB)
-constexpr uint32_t kBinChunk = 65536;   // records per gather workgroup
+constexpr uint32_t kBinChunk = 131072;  // records per gather workgroup (a uniformly hit bucket of a 627 k batch holds ~78 k: it stays in one piece)
 constexpr uint32_t kBinSamples = 4;     // samples per thread in count / scatter: 1024 per workgroup
 constexpr uint32_t kBinThreads = 256;
 constexpr uint32_t kMaxBucketsPerLaunch = 8192;  // LDS histogram bound (counts of one level's buckets)
@@ -66,11 +66,54 @@ __device__ __forceinline__ Corners corners_of(const float* __restrict__ inputs, 
     return c;
 }
 
+// Runs of consecutive lanes that hit the same table row (coarse levels: samples arrive ordered along rays, ~25 per cell on
+// level 0) are merged into ONE record carried by the run's last lane -- same ballot + segmented-scan scheme as k_grid_bwd<COMBINE>.
+struct Run { bool tail; int start; };
+__device__ __forceinline__ Run run_of(uint32_t key, int lane) {
+    const uint32_t prev = __shfl_up(key, 1, PNR_WAVE);
+    const bool head = lane == 0 || prev != key;
+    const unsigned long long heads = __ballot(head);
+    Run r;
+    r.start = 63 - __clzll((long long)(heads & ((2ull << lane) - 1ull)));
+    r.tail = lane == PNR_WAVE - 1 || ((heads >> (lane + 1)) & 1ull);
+    return r;
+}
+__device__ __forceinline__ float run_sum(float v, const Run& r, int lane) {
+#pragma unroll
+    for (int off = 1; off < PNR_WAVE; off <<= 1) {
+        const float up = __shfl_up(v, off, PNR_WAVE);
+        if (lane - off >= r.start) v += up;
+    }
+    return v;
+}
+
+// One LDS counter update per (wave, distinct bucket) instead of one per lane: on the dense levels a whole wave lands in one or
+// two buckets and per-lane atomics on a single LDS word serialise.  Returns the lane's rank inside its bucket's workgroup slice.
+__device__ __forceinline__ uint32_t reserve_in_bucket(uint32_t* hist, uint32_t bucket, bool emit, int lane, bool aggregate) {
+    if (!aggregate) return emit ? atomicAdd(&hist[bucket], 1u) : 0u;
+    uint32_t rank = 0;
+    unsigned long long todo = __ballot(emit);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t b0 = (uint32_t)__shfl((int)bucket, leader, PNR_WAVE);
+        const unsigned long long same = __ballot(emit && bucket == b0);
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&hist[b0], (uint32_t)__popcll(same));
+        base = (uint32_t)__shfl((int)base, leader, PNR_WAVE);
+        if (emit && bucket == b0) rank = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return rank;
+}
+
 // sweep 1: bucket counts
+template <bool COMBINE>
 __global__ void __launch_bounds__(kBinThreads) k_bin_count(const float* __restrict__ inputs, const int32_t* __restrict__ offsets, uint32_t B,
-                                                           LevelParams lp, uint32_t gridtype, bool align_corners, uint32_t* __restrict__ counts) {
+                                                           LevelParams lp, uint32_t gridtype, bool align_corners, uint32_t* __restrict__ counts,
+                                                           uint32_t level0) {
     extern __shared__ uint32_t hist[];
-    const uint32_t level = blockIdx.y;
+    const uint32_t level = level0 + blockIdx.y;
+    const int lane = threadIdx.x & (PNR_WAVE - 1);
     const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
     const uint32_t nb = (hashmap_size + kBinRows - 1) / kBinRows;
     for (uint32_t k = threadIdx.x; k < nb; k += kBinThreads) hist[k] = 0;
@@ -79,9 +122,15 @@ __global__ void __launch_bounds__(kBinThreads) k_bin_count(const float* __restri
     for (uint32_t u = 0; u < kBinSamples; u++) {
         const uint32_t b = (blockIdx.x * kBinSamples + u) * kBinThreads + threadIdx.x;
         const Corners c = corners_of(inputs, b, B, lp.scale[level], lp.resolution[level], hashmap_size, gridtype, align_corners);
-        if (!c.active) continue;
 #pragma unroll
-        for (uint32_t idx = 0; idx < 8; idx++) atomicAdd(&hist[c.row[idx] / kBinRows], 1u);
+        for (uint32_t idx = 0; idx < 8; idx++) {
+            bool emit = c.active;
+            if constexpr (COMBINE) {
+                const Run r = run_of(c.active ? c.row[idx] : 0xFFFFFFFFu, lane);   // wave-collective: every lane takes part
+                emit = emit && r.tail;
+            }
+            reserve_in_bucket(hist, c.row[idx] / kBinRows, emit, lane, nb <= 8);
+        }
     }
     __syncthreads();
     const uint32_t base = level_bucket_base(offsets, level);
@@ -142,12 +191,14 @@ __global__ void __launch_bounds__(1024) k_bin_plan(const int32_t* __restrict__ o
 }
 
 // sweep 2: write the records into their buckets' segments
+template <bool COMBINE>
 __global__ void __launch_bounds__(kBinThreads) k_bin_scatter(const float* __restrict__ grad, const float* __restrict__ inputs,
                                                              const int32_t* __restrict__ offsets, uint32_t B, LevelParams lp, uint32_t gridtype,
                                                              bool align_corners, uint32_t* __restrict__ cursor, uint16_t* __restrict__ rec_row,
-                                                             float2* __restrict__ rec_val) {
+                                                             float2* __restrict__ rec_val, uint32_t level0) {
     extern __shared__ uint32_t lds[];   // [nb] counts, then [nb] slice bases
-    const uint32_t level = blockIdx.y;
+    const uint32_t level = level0 + blockIdx.y;
+    const int lane = threadIdx.x & (PNR_WAVE - 1);
     const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
     const uint32_t nb = (hashmap_size + kBinRows - 1) / kBinRows;
     uint32_t* hist = lds;
@@ -155,14 +206,31 @@ __global__ void __launch_bounds__(kBinThreads) k_bin_scatter(const float* __rest
     for (uint32_t k = threadIdx.x; k < nb; k += kBinThreads) hist[k] = 0;
     __syncthreads();
     Corners c[kBinSamples];
+    float wy[kBinSamples][8];
     uint32_t rank[kBinSamples][8];
+    uint32_t emit_bits[kBinSamples];
 #pragma unroll
     for (uint32_t u = 0; u < kBinSamples; u++) {
         const uint32_t b = (blockIdx.x * kBinSamples + u) * kBinThreads + threadIdx.x;
         c[u] = corners_of(inputs, b, B, lp.scale[level], lp.resolution[level], hashmap_size, gridtype, align_corners);
-        if (!c[u].active) continue;
+        float2 g = make_float2(0.0f, 0.0f);
+        if (c[u].active) g = *reinterpret_cast<const float2*>(grad + ((size_t)level * B + b) * 2);
+        emit_bits[u] = 0;
 #pragma unroll
-        for (uint32_t idx = 0; idx < 8; idx++) rank[u][idx] = atomicAdd(&hist[c[u].row[idx] / kBinRows], 1u);
+        for (uint32_t idx = 0; idx < 8; idx++) {
+            bool emit = c[u].active;
+            float vx = c[u].w[idx] * g.x, vy = c[u].w[idx] * g.y;
+            if constexpr (COMBINE) {
+                const Run r = run_of(c[u].active ? c[u].row[idx] : 0xFFFFFFFFu, lane);
+                vx = run_sum(c[u].active ? vx : 0.0f, r, lane);
+                vy = run_sum(c[u].active ? vy : 0.0f, r, lane);
+                emit = emit && r.tail;
+            }
+            c[u].w[idx] = vx;                                    // from here on: the record's value (x in w[], y in wy[])
+            wy[u][idx] = vy;
+            rank[u][idx] = reserve_in_bucket(hist, c[u].row[idx] / kBinRows, emit, lane, nb <= 8);
+            if (emit) emit_bits[u] |= 1u << idx;
+        }
     }
     __syncthreads();
     const uint32_t base = level_bucket_base(offsets, level);
@@ -170,15 +238,13 @@ __global__ void __launch_bounds__(kBinThreads) k_bin_scatter(const float* __rest
     __syncthreads();
 #pragma unroll
     for (uint32_t u = 0; u < kBinSamples; u++) {
-        if (!c[u].active) continue;
-        const uint32_t b = (blockIdx.x * kBinSamples + u) * kBinThreads + threadIdx.x;
-        const float2 g = *reinterpret_cast<const float2*>(grad + ((size_t)level * B + b) * 2);
 #pragma unroll
         for (uint32_t idx = 0; idx < 8; idx++) {
+            if (!((emit_bits[u] >> idx) & 1u)) continue;
             const uint32_t bucket = c[u].row[idx] / kBinRows;
             const uint32_t pos = slice[bucket] + rank[u][idx];
             rec_row[pos] = (uint16_t)(c[u].row[idx] % kBinRows);
-            rec_val[pos] = make_float2(c[u].w[idx] * g.x, c[u].w[idx] * g.y);
+            rec_val[pos] = make_float2(c[u].w[idx], wy[u][idx]);
         }
     }
 }
@@ -192,7 +258,17 @@ __global__ void __launch_bounds__(1024) k_bin_gather(const BinJob* __restrict__ 
         const BinJob jb = jobs[job];
         for (uint32_t i = threadIdx.x; i < jb.nrows * 2; i += 1024) acc[i] = 0.0f;
         __syncthreads();
-        for (uint32_t r = jb.rec_begin + threadIdx.x; r < jb.rec_end; r += 1024) {
+        constexpr uint32_t U = 8;   // records in flight per thread: the loop is a latency chain otherwise (~76 HBM round trips per job)
+        uint32_t r = jb.rec_begin + threadIdx.x;
+        for (; r + (U - 1) * 1024 < jb.rec_end; r += U * 1024) {
+            uint32_t row[U];
+            float2 v[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) { row[u] = rec_row[r + u * 1024]; v[u] = rec_val[r + u * 1024]; }
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) { atomicAdd(&acc[row[u] * 2], v[u].x); atomicAdd(&acc[row[u] * 2 + 1], v[u].y); }
+        }
+        for (; r < jb.rec_end; r += 1024) {
             const uint32_t row = rec_row[r];
             const float2 v = rec_val[r];
             atomicAdd(&acc[row * 2], v.x);
@@ -257,12 +333,18 @@ int pnr_grid_encode_backward_binned(const float* grad, const float* inputs, cons
     float2* rec_val = reinterpret_cast<float2*>(ws + lay.rec_val);
     const LevelParams lp = make_level_params(L, S, H);
     if (hipMemsetAsync(counts, 0, (size_t)lay.bucket_bound * 4, s) != hipSuccess) return PNR_ERR_LAUNCH;
-    const dim3 grid(cdiv(B, kBinThreads * kBinSamples), L);
+    uint32_t nc = 0;   // levels whose cells are wide compared with the sample spacing: run-combined records (as k_grid_bwd<COMBINE>)
+    while (nc < L && lp.scale[nc] <= 384.0f) nc++;
+    const uint32_t gx = cdiv(B, kBinThreads * kBinSamples);
     const uint32_t hist_bytes = lay.bucket_bound * 4;
-    hipLaunchKernelGGL(k_bin_count, grid, dim3(kBinThreads), hist_bytes, s, inputs, offsets, B, lp, gridtype, align_corners != 0, counts);
+    const bool ac = align_corners != 0;
+    if (nc) hipLaunchKernelGGL(k_bin_count<true>, dim3(gx, nc), dim3(kBinThreads), hist_bytes, s, inputs, offsets, B, lp, gridtype, ac, counts, 0u);
+    if (nc < L) hipLaunchKernelGGL(k_bin_count<false>, dim3(gx, L - nc), dim3(kBinThreads), hist_bytes, s, inputs, offsets, B, lp, gridtype, ac, counts, nc);
     hipLaunchKernelGGL(k_bin_plan, dim3(1), dim3(1024), 0, s, offsets, L, counts, rec_off, cursor, jobs, n_jobs);
-    hipLaunchKernelGGL(k_bin_scatter, grid, dim3(kBinThreads), 2 * hist_bytes, s, grad, inputs, offsets, B, lp, gridtype, align_corners != 0, cursor,
-                       rec_row, rec_val);
+    if (nc) hipLaunchKernelGGL(k_bin_scatter<true>, dim3(gx, nc), dim3(kBinThreads), 2 * hist_bytes, s, grad, inputs, offsets, B, lp, gridtype, ac, cursor,
+                               rec_row, rec_val, 0u);
+    if (nc < L) hipLaunchKernelGGL(k_bin_scatter<false>, dim3(gx, L - nc), dim3(kBinThreads), 2 * hist_bytes, s, grad, inputs, offsets, B, lp, gridtype, ac,
+                                   cursor, rec_row, rec_val, nc);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_gather), hipFuncAttributeMaxDynamicSharedMemorySize, kBinRows * 2 * 4) != hipSuccess)

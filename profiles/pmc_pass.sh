@@ -10,7 +10,7 @@ cd /tmp
 i=0
 for g in "${groups[@]}"; do
   first=${g%% *}
-  rocprofv3 --pmc $g --kernel-trace --output-format csv -d $R/gpurun_out/$out/$first -o p -- python3 $R/bench.py "$@" > $R/gpurun_out/$out.$i.log 2>&1
+  rocprofv3 --pmc $g --kernel-trace --output-format csv -d $R/gpurun_out/$out/$first -o p -- python3 $R/${PNR_PMC_SCRIPT:-bench.py} "$@" > $R/gpurun_out/$out.$i.log 2>&1
   i=$((i+1))
 done
 python3 $R/profiles/pmc_summary.py $R/gpurun_out/$out > $R/gpurun_out/$out.txt
