@@ -203,9 +203,9 @@ typedef struct pnr_nerf_frame_args {
     uint64_t* stats;               /* HOST, optional: [iterations, rendered samples, evaluated rows, enqueued iterations] */
     float* kernel_ms;              /* HOST, optional: [0] = summed HIP-event time (ms) of the grid-encode launches that did work,
                                       [1] = their number; events are recorded on `stream` around each launch */
-    const int32_t* ray_order;      /* optional permutation of 0..N-1 (device): initial order of the alive list, e.g. 8x8 pixel
-                                      tiles per wave; NULL = identity (the reference's arange).  Outputs are indexed by ray id
-                                      either way and do not depend on the order */
+    const int32_t* ray_order;      /* optional permutation of 0..N-1 (device): processing order of the rays, e.g. 8x8 pixel tiles per
+                                      wave; NULL = as given.  The frame then runs on copies of the per-ray inputs gathered into that
+                                      order; outputs are scattered back, indexed by ray id either way, and do not depend on the order */
 } pnr_nerf_frame_args;
 uint64_t pnr_nerf_frame_workspace_bytes(uint32_t N);
 int pnr_nerf_render_frame(const pnr_nerf_frame_args* args, pnr_stream_t stream);

@@ -37,13 +37,10 @@ __device__ __forceinline__ int schedule_n_step(int N, int n_alive) {  // nerf/re
 
 __global__ void __launch_bounds__(kRayBlock) k_frame_init(uint32_t N, const float* __restrict__ nears, int32_t* __restrict__ alive,
                                                           float* __restrict__ rays_t, float* __restrict__ weights_sum, float* __restrict__ depth,
-                                                          float* __restrict__ image, FrameCtl* __restrict__ ctl, const int32_t* __restrict__ ray_order) {
+                                                          float* __restrict__ image, FrameCtl* __restrict__ ctl) {
     const uint32_t i = blockIdx.x * kRayBlock + threadIdx.x;
     if (i < N) {
-        // initial alive list: identity (the reference's arange) or a caller-supplied permutation.  Per-ray results do not
-        // depend on the slot a ray occupies (no perturbation on this path); a tile-ordered list keeps the 64 rays of a
-        // wave spatially compact, which is what the hash-grid gathers and the march like.
-        alive[i] = ray_order ? ray_order[i] : (int32_t)i;
+        alive[i] = (int32_t)i;   // the reference's arange (nerf/renderer.py:352)
         rays_t[i] = nears[i];
         weights_sum[i] = 0.0f; depth[i] = 0.0f;
         image[i * 3] = 0.0f; image[i * 3 + 1] = 0.0f; image[i * 3 + 2] = 0.0f;
@@ -53,6 +50,35 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_init(uint32_t N, const floa
         c.n_alive = (int32_t)N; c.n_step = schedule_n_step((int)N, (int)N); c.done = N == 0;
         ctl[0] = c; ctl[1] = c;
     }
+}
+
+// Optional processing order (pnr_nerf_frame_args::ray_order): the frame runs on copies of the per-ray inputs gathered into that
+// order and on outputs kept in that order, scattered back to ray ids at the end.  Per-ray results do not depend on the slot a
+// ray occupies (no perturbation on this path); listing rays tile by tile (8x8 pixels per wave) keeps the 64 rays of a wave
+// spatially compact, which the hash-grid gathers and the march like, and the copies keep every per-ray access coalesced.
+__global__ void __launch_bounds__(kRayBlock) k_frame_sort_inputs(uint32_t N, const int32_t* __restrict__ order, const float* __restrict__ rays_o,
+                                                                 const float* __restrict__ rays_d, const float* __restrict__ nears,
+                                                                 const float* __restrict__ fars, float* __restrict__ so, float* __restrict__ sd,
+                                                                 float* __restrict__ sn, float* __restrict__ sf) {
+    const uint32_t i = blockIdx.x * kRayBlock + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t r = (uint32_t)order[i];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { so[i * 3 + k] = rays_o[(size_t)r * 3 + k]; sd[i * 3 + k] = rays_d[(size_t)r * 3 + k]; }
+    sn[i] = nears[r]; sf[i] = fars[r];
+}
+__global__ void __launch_bounds__(kRayBlock) k_frame_unsort_outputs(uint32_t N, const int32_t* __restrict__ order, const float* __restrict__ sws,
+                                                                    const float* __restrict__ sdepth, const float* __restrict__ simage,
+                                                                    const float* __restrict__ saux, uint32_t aux_stride, float* __restrict__ ws,
+                                                                    float* __restrict__ depth, float* __restrict__ image, float* __restrict__ aux) {
+    // 16 lanes per ray so that an aux row (up to 64 floats) moves as float4s
+    const uint32_t i = (blockIdx.x * kRayBlock + threadIdx.x) / 16, q = threadIdx.x & 15u;
+    if (i >= N) return;
+    const uint32_t r = (uint32_t)order[i];
+    if (q == 0) { ws[r] = sws[i]; depth[r] = sdepth[i]; }
+    if (q < 3) image[(size_t)r * 3 + q] = simage[(size_t)i * 3 + q];
+    if (saux && q * 4 < aux_stride)
+        *reinterpret_cast<float4*>(aux + (size_t)r * aux_stride + q * 4) = *reinterpret_cast<const float4*>(saux + (size_t)i * aux_stride + q * 4);
 }
 
 // reference raymarching.cu:907-1011, n_alive / n_step from the control block; also writes the delta == 0
@@ -385,6 +411,7 @@ struct FrameWorkspace {
     int32_t* alive[2];
     float *rays_t, *xyzs, *dirs, *deltas, *enc, *sigmas, *rgbs;
     float *enc_pal, *enc_clip, *aux;  // palette model only
+    float *s_o, *s_d, *s_near, *s_far, *s_ws, *s_depth, *s_image, *s_aux;  // ray_order: inputs / outputs in processing order
     int32_t* scratch;
     int32_t* partials;
     uint64_t bytes;
@@ -412,6 +439,11 @@ static FrameWorkspace carve(void* base, uint32_t N, uint32_t aux_stride = 0, boo
         if (with_clip) w.enc_clip = reinterpret_cast<float*>(take(n * 16 * 2 * 4));
         w.aux = reinterpret_cast<float*>(take(n * aux_stride * 4));
     }
+    w.s_o = reinterpret_cast<float*>(take(n * 12)); w.s_d = reinterpret_cast<float*>(take(n * 12));
+    w.s_near = reinterpret_cast<float*>(take(n * 4)); w.s_far = reinterpret_cast<float*>(take(n * 4));
+    w.s_ws = reinterpret_cast<float*>(take(n * 4)); w.s_depth = reinterpret_cast<float*>(take(n * 4));
+    w.s_image = reinterpret_cast<float*>(take(n * 12));
+    w.s_aux = aux_stride ? reinterpret_cast<float*>(take(n * aux_stride * 4)) : nullptr;
     w.bytes = off;
     return w;
 }
@@ -453,7 +485,16 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     const uint32_t N = a->N;
     FrameWorkspace w = carve(a->workspace, N, aux_stride, with_clip);
     if (a->workspace_bytes < w.bytes) return PNR_ERR_INVALID;
-    if (pal && hipMemsetAsync(pal->aux_map, 0, (size_t)N * aux_stride * 4, s) != hipSuccess) return PNR_ERR_LAUNCH;
+    const bool sorted = a->ray_order != nullptr;
+    const float *in_o = a->rays_o, *in_d = a->rays_d, *in_near = a->nears, *in_far = a->fars;
+    float *out_ws = a->weights_sum, *out_depth = a->depth, *out_image = a->image, *out_aux = pal ? pal->aux_map : nullptr;
+    if (sorted) {
+        hipLaunchKernelGGL(k_frame_sort_inputs, dim3(cdiv(N, kRayBlock)), dim3(kRayBlock), 0, s, N, a->ray_order, a->rays_o, a->rays_d, a->nears, a->fars,
+                           w.s_o, w.s_d, w.s_near, w.s_far);
+        in_o = w.s_o; in_d = w.s_d; in_near = w.s_near; in_far = w.s_far;
+        out_ws = w.s_ws; out_depth = w.s_depth; out_image = w.s_image; out_aux = pal ? w.s_aux : nullptr;
+    }
+    if (pal && hipMemsetAsync(out_aux, 0, (size_t)N * aux_stride * 4, s) != hipSuccess) return PNR_ERR_LAUNCH;
     GridSet gs;
     gs.table[0] = a->embeddings; gs.enc[0] = w.enc;
     gs.table[1] = pal ? pal->embeddings_palette : nullptr; gs.enc[1] = w.enc_pal;
@@ -467,7 +508,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
         pf.view_dep_weight = pal->view_dep_weight; pf.aux_stride = aux_stride; pf.sigmas = w.sigmas; pf.rgbs = w.rgbs; pf.aux = w.aux;
     }
 
-    static FrameCtl* host_ctl = nullptr;  // pinned read-back slot (one in-flight frame per process)
+    static thread_local FrameCtl* host_ctl = nullptr;  // pinned read-back slot (one in-flight frame per host thread)
     if (!host_ctl && hipHostMalloc(reinterpret_cast<void**>(&host_ctl), sizeof(FrameCtl), hipHostMallocDefault) != hipSuccess) return PNR_ERR_LAUNCH;
 
     const bool use_mip = a->mip && (a->H % 4) == 0 && pnr_occupancy_mip_bytes(a->C, a->H) <= 64 * 1024;
@@ -477,10 +518,10 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     const LevelParams lp = make_level_params(16, a->S, a->base_resolution);
     const uint32_t* mip = static_cast<const uint32_t*>(a->mip);
 
-    hipLaunchKernelGGL(k_frame_init, dim3(cdiv(N, kRayBlock)), dim3(kRayBlock), 0, s, N, a->nears, w.alive[0], w.rays_t, a->weights_sum, a->depth,
-                       a->image, w.ctl, a->ray_order);
+    hipLaunchKernelGGL(k_frame_init, dim3(cdiv(N, kRayBlock)), dim3(kRayBlock), 0, s, N, in_near, w.alive[0], w.rays_t, out_ws, out_depth, out_image,
+                       w.ctl);
     // optional live timing of the roofline kernel: HIP events on the launch stream around every k_frame_grid launch
-    static std::vector<hipEvent_t> ev;
+    static thread_local std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
     auto next_event = [&]() -> hipEvent_t {
         if (ev_used == ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; ev.push_back(e); }
@@ -491,7 +532,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     // Iterations enqueued between two looks at the control block.  Consecutive frames of a camera path need nearly the same
     // number of iterations, so the first chunk is the previous frame's count (one look per frame when the guess holds; launches
     // past the end are no-ops that cost a few microseconds each); after that, short chunks that grow for long, translucent marches.
-    static uint32_t predicted_iterations = 0;
+    static thread_local uint32_t predicted_iterations = 0;
     uint32_t chunk = predicted_iterations ? (predicted_iterations < 1024u ? predicted_iterations : 1024u) : 8u;
     uint32_t looks = 0;
     int iter = 0;
@@ -505,13 +546,13 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             const uint32_t rows_ub = (uint64_t)alive_ub * 8 < N ? alive_ub * 8 : N;
             const dim3 gm(ray_blocks < 2048u ? ray_blocks : 2048u), bm(kRayBlock);
             if (use_mip && pow2)
-                hipLaunchKernelGGL((k_frame_march<true, true>), gm, bm, march_lds, s, cur, alive_in, w.rays_t, a->rays_o, a->rays_d, mp, a->bitfield, a->fars, w.xyzs, w.dirs, w.deltas, mip, w.partials);
+                hipLaunchKernelGGL((k_frame_march<true, true>), gm, bm, march_lds, s, cur, alive_in, w.rays_t, in_o, in_d, mp, a->bitfield, in_far, w.xyzs, w.dirs, w.deltas, mip, w.partials);
             else if (use_mip)
-                hipLaunchKernelGGL((k_frame_march<true, false>), gm, bm, march_lds, s, cur, alive_in, w.rays_t, a->rays_o, a->rays_d, mp, a->bitfield, a->fars, w.xyzs, w.dirs, w.deltas, mip, w.partials);
+                hipLaunchKernelGGL((k_frame_march<true, false>), gm, bm, march_lds, s, cur, alive_in, w.rays_t, in_o, in_d, mp, a->bitfield, in_far, w.xyzs, w.dirs, w.deltas, mip, w.partials);
             else if (pow2)
-                hipLaunchKernelGGL((k_frame_march<false, true>), gm, bm, march_lds, s, cur, alive_in, w.rays_t, a->rays_o, a->rays_d, mp, a->bitfield, a->fars, w.xyzs, w.dirs, w.deltas, mip, w.partials);
+                hipLaunchKernelGGL((k_frame_march<false, true>), gm, bm, march_lds, s, cur, alive_in, w.rays_t, in_o, in_d, mp, a->bitfield, in_far, w.xyzs, w.dirs, w.deltas, mip, w.partials);
             else
-                hipLaunchKernelGGL((k_frame_march<false, false>), gm, bm, march_lds, s, cur, alive_in, w.rays_t, a->rays_o, a->rays_d, mp, a->bitfield, a->fars, w.xyzs, w.dirs, w.deltas, mip, w.partials);
+                hipLaunchKernelGGL((k_frame_march<false, false>), gm, bm, march_lds, s, cur, alive_in, w.rays_t, in_o, in_d, mp, a->bitfield, in_far, w.xyzs, w.dirs, w.deltas, mip, w.partials);
             const uint32_t gx = cdiv(rows_ub, 256);
             hipEvent_t e0 = timing ? next_event() : nullptr, e1 = timing ? next_event() : nullptr;
             if (e0) (void)hipEventRecord(e0, s);
@@ -528,8 +569,8 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             else
                 hipLaunchKernelGGL(k_frame_field<1>, dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas,
                                    a->packed_weights, a->density_scale, w.sigmas, w.rgbs);
-            hipLaunchKernelGGL(k_frame_composite, gm, bm, 0, s, cur, a->T_thresh, alive_in, w.rays_t, w.sigmas, w.rgbs, w.deltas, a->weights_sum, a->depth,
-                               a->image, w.scratch, (const float*)w.aux, pal ? pal->aux_map : nullptr, aux_stride);
+            hipLaunchKernelGGL(k_frame_composite, gm, bm, 0, s, cur, a->T_thresh, alive_in, w.rays_t, w.sigmas, w.rgbs, w.deltas, out_ws, out_depth, out_image,
+                               w.scratch, (const float*)w.aux, out_aux, aux_stride);
             hipLaunchKernelGGL(k_frame_compact, gm, bm, 0, s, cur, nxt, alive_in, alive_out, w.scratch, N, a->max_steps, w.partials, gm.x);
         }
         if (hipMemcpyAsync(host_ctl, w.ctl + (iter & 1), sizeof(FrameCtl), hipMemcpyDeviceToHost, s) != hipSuccess) return PNR_ERR_LAUNCH;
@@ -540,6 +581,9 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
         if (++looks >= 4 && chunk < 64) chunk *= 2;
     }
     predicted_iterations = (uint32_t)host_ctl->iterations;
+    if (sorted)
+        hipLaunchKernelGGL(k_frame_unsort_outputs, dim3(cdiv(N * 16, kRayBlock)), dim3(kRayBlock), 0, s, N, a->ray_order, w.s_ws, w.s_depth, w.s_image,
+                           pal ? w.s_aux : nullptr, aux_stride, a->weights_sum, a->depth, a->image, pal ? pal->aux_map : nullptr);
     if (timing) {  // only the iterations that did work (the tail of the last chunk are no-op launches)
         float total = 0.0f;
         uint32_t counted = 0;

@@ -241,3 +241,37 @@ def test_native_loop_edge_cases_match_reference_style_loop(cuda, model_kind):
     a, b = both(ro, rd, dt_gamma=1.0 / 128, max_steps=1024)
     a, b = both(ro, rd, dt_gamma=0, max_steps=1024)
     assert b["iterations"] > 40
+
+
+@pytest.mark.parametrize("model_kind", ["nerf", "palette"])
+def test_native_loop_ray_order_leaves_every_output_bit_identical(cuda, model_kind):
+    """pnr_*_frame_args::ray_order (tile order, a random permutation) changes the processing order only: image, depth, weights_sum,
+    every palette map and the sample count must be bit-identical to the unordered frame."""
+    from palettenerf_amd.fused import NeRFFieldFused, PaletteFieldFused, tile_ray_order
+    if model_kind == "nerf":
+        m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=30.0, min_near=0.2)
+    else:
+        m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True, density_scale=30.0, min_near=0.2)
+    scene.seed_field_(m, 5)
+    m = m.to(cuda).eval()
+    put_scene(m, cuda)
+    m.count_rendered = True
+    m.march_mode, m.fused_field = "native", True
+    H, W = 40, 56
+    pose = torch.from_numpy(scene.lookat_pose())[None]
+    ro, rd = scene.get_rays(pose, scene.intrinsics_from_fov(H, W), H, W)
+    ro, rd = ro.to(cuda), rd.to(cuda)
+    m._fused = (NeRFFieldFused if model_kind == "nerf" else PaletteFieldFused)(m)
+    kw = dict(perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+    with torch.no_grad():
+        base = m.render(ro, rd, **kw)
+        outs = []
+        for order in (tile_ray_order(torch.arange(H * W), W, 8), torch.randperm(H * W, generator=torch.Generator().manual_seed(1)).to(torch.int32)):
+            m._fused.ray_order = order.to(cuda)
+            outs.append(m.render(ro, rd, **kw))
+    assert int(base["rendered"].item()) > 1000
+    for o in outs:
+        assert int(o["rendered"].item()) == int(base["rendered"].item())
+        for k, v in base.items():
+            if torch.is_tensor(v) and v.dtype.is_floating_point and v.numel() > 1:
+                assert torch.equal(torch.nan_to_num(o[k], nan=-7.0), torch.nan_to_num(v, nan=-7.0)), k
