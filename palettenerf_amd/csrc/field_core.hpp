@@ -33,7 +33,9 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 __device__ __forceinline__ f32x16 relu16(f32x16 v) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) v[i] = fmaxf(v[i], 0.0f);
+    // max on the bit pattern as a signed integer: negative floats (sign bit set) are negative integers, non-negative floats keep
+    // their order -- one v_max_i32 per element, where fmaxf costs an extra canonicalising v_max_f32 on MFMA results
+    for (int i = 0; i < 16; i++) v[i] = __int_as_float(max(__float_as_int(v[i]), 0));
     return v;
 }
 // acc += W[tile] . act, act given as one accumulator fragment (16 k-steps)
@@ -70,12 +72,19 @@ __host__ __device__ constexpr int f16_col_C0(int kb, int h, int j) {
     return g >= 1 ? 15 + g : -1;
 }
 
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split8(const float v[8], h8& hi, h8& lo) {
+    // hi = fp16(v) (round to nearest even, two per v_cvt_pk_f16_f32); lo = fp16(v - hi) with the exact difference formed by
+    // v_fma_mix_f32 straight from the packed halves (its f16 source converts in the instruction): 4 VALU per pair instead of 5
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const _Float16 hj = (_Float16)v[j];
-        hi[j] = hj;
-        lo[j] = (_Float16)(v[j] - (float)hj);
+    for (int j = 0; j < 8; j += 2) {
+        const h2v hp = {(_Float16)v[j], (_Float16)v[j + 1]};
+        const uint32_t hb = __builtin_bit_cast(uint32_t, hp);
+        float l0, l1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hb), "v"(v[j]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hb), "v"(v[j + 1]));
+        hi[j] = hp[0]; hi[j + 1] = hp[1];
+        lo[j] = (_Float16)l0; lo[j + 1] = (_Float16)l1;
     }
 }
 __device__ __forceinline__ void split_frag(const f32x16& a, int half_idx, h8& hi, h8& lo) {

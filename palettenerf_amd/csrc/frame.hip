@@ -67,12 +67,12 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_sort_inputs(uint32_t N, con
     for (int k = 0; k < 3; k++) { so[i * 3 + k] = rays_o[(size_t)r * 3 + k]; sd[i * 3 + k] = rays_d[(size_t)r * 3 + k]; }
     sn[i] = nears[r]; sf[i] = fars[r];
 }
+template <uint32_t LANES>   // lanes per ray: 16 with an aux row to move (float4 each), 4 without
 __global__ void __launch_bounds__(kRayBlock) k_frame_unsort_outputs(uint32_t N, const int32_t* __restrict__ order, const float* __restrict__ sws,
                                                                     const float* __restrict__ sdepth, const float* __restrict__ simage,
                                                                     const float* __restrict__ saux, uint32_t aux_stride, float* __restrict__ ws,
                                                                     float* __restrict__ depth, float* __restrict__ image, float* __restrict__ aux) {
-    // 16 lanes per ray so that an aux row (up to 64 floats) moves as float4s
-    const uint32_t i = (blockIdx.x * kRayBlock + threadIdx.x) / 16, q = threadIdx.x & 15u;
+    const uint32_t i = (blockIdx.x * kRayBlock + threadIdx.x) / LANES, q = threadIdx.x % LANES;
     if (i >= N) return;
     const uint32_t r = (uint32_t)order[i];
     if (q == 0) { ws[r] = sws[i]; depth[r] = sdepth[i]; }
@@ -581,9 +581,12 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
         if (++looks >= 4 && chunk < 64) chunk *= 2;
     }
     predicted_iterations = (uint32_t)host_ctl->iterations;
-    if (sorted)
-        hipLaunchKernelGGL(k_frame_unsort_outputs, dim3(cdiv(N * 16, kRayBlock)), dim3(kRayBlock), 0, s, N, a->ray_order, w.s_ws, w.s_depth, w.s_image,
-                           pal ? w.s_aux : nullptr, aux_stride, a->weights_sum, a->depth, a->image, pal ? pal->aux_map : nullptr);
+    if (sorted && pal)
+        hipLaunchKernelGGL(k_frame_unsort_outputs<16>, dim3(cdiv(N * 16, kRayBlock)), dim3(kRayBlock), 0, s, N, a->ray_order, w.s_ws, w.s_depth, w.s_image,
+                           w.s_aux, aux_stride, a->weights_sum, a->depth, a->image, pal->aux_map);
+    else if (sorted)
+        hipLaunchKernelGGL(k_frame_unsort_outputs<4>, dim3(cdiv(N * 4, kRayBlock)), dim3(kRayBlock), 0, s, N, a->ray_order, w.s_ws, w.s_depth, w.s_image,
+                           (const float*)nullptr, 0u, a->weights_sum, a->depth, a->image, (float*)nullptr);
     if (timing) {  // only the iterations that did work (the tail of the last chunk are no-op launches)
         float total = 0.0f;
         uint32_t counted = 0;
