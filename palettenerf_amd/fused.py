@@ -141,7 +141,10 @@ class PaletteFieldFused:
               and m.num_layers_color == 3 and m.encoder_dir.degree == 4 and 1 <= m.num_basis <= 5 and m.opt.clip_dim <= 16)
         if not ok:
             raise RuntimeError("fused palette field kernel is specialised for the shipped architecture")
-        self.nb, self.clip_dim, self.pred_clip = int(m.num_basis), int(m.opt.clip_dim), bool(m.opt.pred_clip)
+        self.nb, self.pred_clip = int(m.num_basis), bool(m.opt.pred_clip)
+        # without a clip head the reference composites clip_dim channels of zeros (palette/renderer.py:477,510): the map is zero whatever
+        # happens, so those channels are left out of the packed aux row (52 -> 36 floats per sample for 4 bases) and returned as zeros
+        self.clip_dim = int(m.opt.clip_dim) if self.pred_clip else 0
         self.aux_channels = int(_lib.load().pnr_palette_aux_channels(self.nb, self.clip_dim))
 
     def _weights(self):

@@ -565,7 +565,8 @@ class PaletteRenderer(_RendererBase):
             basis_acc_map = aux_map[:, 6:6 + nb]
             basis_rgb_map = aux_map[:, 6 + nb:6 + 4 * nb]
             unscaled_basis_rgb_map = aux_map[:, 6 + 4 * nb:6 + 7 * nb]
-            clip_feat_map = aux_map[:, 6 + 7 * nb:6 + 7 * nb + clip_dim]
+            if self._fused.clip_dim == clip_dim:
+                clip_feat_map = aux_map[:, 6 + 7 * nb:6 + 7 * nb + clip_dim]
         weights_sum = st.weights_sum
         image = st.image + (1 - weights_sum).unsqueeze(-1) * bg_color
         depth_origin = st.depth.clone()

@@ -287,4 +287,4 @@ def test_training_converges_on_a_synthetic_scene(cuda):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     log = mod.main(["--steps", "500", "--res", "96", "--views", "12", "--rays", "2048"])
-    assert log[0][1] < 15.0 and log[-1][1] > 30.0, log
+    assert log[0][1] < 20.0 and log[-1][1] > 30.0 and log[-1][1] - log[0][1] > 15.0, log
