@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--ray-order", choices=["tile8", "tile4", "tile16", "morton", "rowmajor"], default="tile8", help="initial order of the alive list in the native loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-crop", type=int, default=320, help="side of the centre crop timed on the CPU oracle")
+    ap.add_argument("--cpu-crop", type=int, default=480, help="side of the centre crop timed on the CPU oracle")
     return ap.parse_args()
 
 
