@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--ray-order", choices=["tile8", "tile4", "tile16", "morton", "rowmajor"], default="tile8", help="initial order of the alive list in the native loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dt-gamma", type=float, default=0.0, help="march step growth (0 = the lego config; 1/128 = the LLFF / 360 configs)")
     ap.add_argument("--cpu-crop", type=int, default=480, help="side of the centre crop timed on the CPU oracle")
     return ap.parse_args()
 
@@ -95,7 +96,7 @@ def cpu_baseline(args):
         ro, rd = ro[:, idx].contiguous(), rd[:, idx].contiguous()
         t0 = time.perf_counter()
         with torch.no_grad():
-            r = m.render(ro, rd, perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4, **({"gui_mode": False} if args.model == "palette" else {}))
+            r = m.render(ro, rd, perturb=False, dt_gamma=args.dt_gamma, max_steps=1024, T_thresh=1e-4, **({"gui_mode": False} if args.model == "palette" else {}))
         dt = time.perf_counter() - t0
         n = int(r["rendered"].item())
     finally:
@@ -140,7 +141,7 @@ def main():
     VH = n_views * H
     idx, n_max = pdist.shard_indices(VH, W, rank, world)
     ro, rd = ro[:, idx].contiguous().to(device), rd[:, idx].contiguous().to(device)
-    kw = dict(perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+    kw = dict(perturb=False, dt_gamma=args.dt_gamma, max_steps=1024, T_thresh=1e-4)
     if args.model == "palette":
         kw["gui_mode"] = False
 
@@ -227,7 +228,7 @@ def main():
             "vs_baseline": None, "dtype": "f16" if args.fp16 else "f32", "data": "synthetic",
             "config": {"workload": f"configs[{1 if args.model == 'nerf' else 2}]: NeRF-synthetic lego geometry (scene S0), -m {args.model} inference, {H}x{W}, {n_views} view(s)/step",
                        "rays_per_step": n_views * H * W, "rendered_samples_per_step": total_rendered // args.steps,
-                       "evaluated_rows_per_step_rank0": rows // args.steps, "density_scale": args.density_scale, "march_mode": m.march_mode, "fused_field": bool(getattr(m, "fused_field", False)), "field_precision": args.field_precision, "ray_order": args.ray_order,
+                       "evaluated_rows_per_step_rank0": rows // args.steps, "density_scale": args.density_scale, "dt_gamma": args.dt_gamma, "march_mode": m.march_mode, "fused_field": bool(getattr(m, "fused_field", False)), "field_precision": args.field_precision, "ray_order": args.ray_order,
                        "parallelism": f"32x32 ray tiles of {n_views} view(s) round-robin over {world} GPUs + one all_gather/step" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": n_launches,
