@@ -675,3 +675,28 @@ def test_grid_backward_binned_matches_oracle(cuda, case, monkeypatch):
     out = gridencoder.grid_encode(dev(x, cuda), te, dev(offsets, cuda), pls, 16 if case != "small_table" else 4, False, gridtype, False)
     (out * dev(g, cuda)).sum().backward()
     np.testing.assert_allclose(binned, host(te.grad), rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("bound,H", [(1.0, 64), (4.0, 32), (2.0, 256), (1.0, 16)])
+def test_march_other_grid_sizes_bit_exact(cuda, bound, H):
+    """Occupancy grids other than 128^3 / two cascades: H = 64 (blocks of 16 cells still nest), H = 32 / 16 (block jumps off: H % 64 != 0;
+    16 has no 4^3-brick mip words to spare), H = 256 (mip too large for LDS: plain path), one to three cascades."""
+    C = 1 + int(np.ceil(np.log2(bound)))
+    grid = scene.brick_density_grid(H=H, bound=bound, extent=0.65 * min(bound, 1.0))
+    bf = scene.packbits_np(grid, 0.5)
+    ro, rd = _far_rays(3000, 9)
+    ro = ro * (bound / 8.0) * 2.0
+    N = ro.shape[0]
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    on, of = oracle.near_far_from_aabb(ro, rd, aabb, 0.05)
+    for dt_gamma in (0.0, 1.0 / 128):
+        cnt = np.zeros(2, np.int32)
+        ox, od, odl, orays = oracle.march_rays_train(ro, rd, bound, bf, C, H, on, of, cnt, align=128, force_all_rays=True, dt_gamma=dt_gamma, max_steps=512)
+        counter = torch.zeros(2, dtype=torch.int32, device=cuda)
+        x, d, dl, rays = raymarching.march_rays_train(dev(ro, cuda), dev(rd, cuda), bound, dev(bf, cuda), C, H, dev(on, cuda), dev(of, cuda), counter,
+                                                      -1, False, 128, True, dt_gamma, 512)
+        assert int(cnt[0]) > 1000
+        np.testing.assert_array_equal(host(counter), cnt)
+        np.testing.assert_array_equal(host(rays), orays)
+        np.testing.assert_array_equal(host(x), ox)
+        np.testing.assert_array_equal(host(dl), odl)
