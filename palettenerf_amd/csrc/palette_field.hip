@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
                                                                    uint32_t level_stride, const float* __restrict__ dirs,
                                                                    const float* __restrict__ deltas, const unsigned char* __restrict__ packed,
                                                                    uint32_t packed_bytes, PaletteParams pp, float* __restrict__ sigmas,
-                                                                   float* __restrict__ rgbs, float* __restrict__ aux) {
+                                                                   float* __restrict__ rgbs, float* __restrict__ aux, uint32_t stage_stride) {
     if (ctl && ctl->done) return;
     const uint32_t B = ctl ? (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step : B_arg;
     const uint32_t ntiles = (B + 255) / 256;
@@ -233,7 +233,10 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
             for (int b = 0; b < 5; b++) if (b < nb) { omega[b] = softplusf(om[b]) + 0.05f; osum += omega[b]; }
             const float sp = softplusf(orr[3 * nb]);  // radiance is the LAST of the 3 nb + 1 outputs (palette/renderer.py:471)
             float rgb[3] = {0.0f, 0.0f, 0.0f};
-            float* a = aux + (size_t)n * pp.aux_stride;
+            // aux row: straight to global (one 4-byte store per channel and lane, rows aux_stride apart), or -- when the LDS has room --
+            // into this wave's staging slab, from where the whole 32-row tile (contiguous in memory) goes out as 16-byte stores
+            float* a = stage_stride ? reinterpret_cast<float*>(w + packed_bytes) + ((size_t)wave * 32 + (lane & 31)) * stage_stride
+                                    : aux + (size_t)n * pp.aux_stride;
 #pragma unroll
             for (int k = 0; k < 3; k++) { a[k] = diffuse[k] + view_dep[k]; a[3 + k] = view_dep[k]; }   // direct_rgb, view_dep_rgb
 #pragma unroll
@@ -257,6 +260,16 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
             sigmas[n] = pp.density_scale * __expf(sigma_logit);
 #pragma unroll
             for (int k = 0; k < 3; k++) rgbs[(size_t)n * 3 + k] = rgb[k] + pp.view_dep_weight * view_dep[k];
+        }
+        if (stage_stride) {   // same wave wrote the slab: DS operations of a wave complete in order
+            const float* slab = reinterpret_cast<const float*>(w + packed_bytes) + (size_t)wave * 32 * stage_stride;
+            const uint32_t n0 = tile * 256 + wave * 32, nq = (uint32_t)pp.aux_stride / 4;
+            const unsigned long long live = __ballot(valid && h == 0);     // rows of dead / out-of-range slots hold stale slab data: skip them
+            for (uint32_t i = (uint32_t)lane; i < 32 * nq; i += 64) {
+                const uint32_t row = i / nq, q = i - row * nq;
+                if ((live >> row) & 1ull)
+                    *reinterpret_cast<float4*>(aux + (size_t)(n0 + row) * pp.aux_stride + q * 4) = *reinterpret_cast<const float4*>(slab + row * stage_stride + q * 4);
+            }
         }
     }
 }
@@ -322,15 +335,20 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
     const uint32_t rows_ub = a->B;
     const uint32_t ntiles = cdiv(rows_ub ? rows_ub : 1, 256);
     const uint32_t grid = ntiles < 256u ? ntiles : 256u;  // one persistent 512-thread workgroup per CU (100-116 KiB of LDS)
+    constexpr uint32_t kLdsLimit = 160 * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_palette_field_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, PB_END_CLIP * kF16BlockBytes) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_palette_field_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit) != hipSuccess)
             return PNR_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_palette_field_fwd, dim3(grid), dim3(kPalThreads), packed_bytes, as_stream(stream), static_cast<const FrameCtlView*>(a->ctl), a->B,
+    // staging slab for coalesced aux rows: 8 waves x 32 rows x (aux_stride + 4) floats, when it fits next to the weights
+    uint32_t stage_stride = a->aux_stride + 4;
+    uint32_t lds = packed_bytes + (kPalThreads / 64) * 32 * stage_stride * 4;
+    if (lds > kLdsLimit || (a->aux_stride & 3u)) { stage_stride = 0; lds = packed_bytes; }
+    hipLaunchKernelGGL(k_palette_field_fwd, dim3(grid), dim3(kPalThreads), lds, as_stream(stream), static_cast<const FrameCtlView*>(a->ctl), a->B,
                        a->enc, a->enc_palette, a->enc_clip, a->level_stride, a->dirs, a->deltas, static_cast<const unsigned char*>(a->packed), packed_bytes, pp,
-                       a->sigmas, a->rgbs, a->aux);
+                       a->sigmas, a->rgbs, a->aux, stage_stride);
     return check_launch();
 }
 
