@@ -273,14 +273,16 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_composite(const FrameCtl* _
     __shared__ int wsum[kRayBlock / PNR_WAVE];
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         if (aux) {
-            // Phase 1 (palette): the packed aux row.  16 lanes per ray, one float4 of channels per lane: a ray's row is one
+            // Phase 1 (palette): the packed aux row.  aux_stride / 4 lanes per ray, one float4 of channels per lane: a ray's row is one
             // coalesced 208-byte read per sample and per map instead of a 208-byte-strided walk by a single thread.  Every
             // lane re-derives the (cheap) weights; they start from the weights_sum of BEFORE this iteration because phase 2,
             // which updates it, runs after the barrier.
-            const uint32_t q = threadIdx.x & 15u, nq = aux_stride / 4;
-            for (uint32_t r = threadIdx.x >> 4; r < kRayBlock; r += kRayBlock / 16) {
+            // nq lanes per ray (one float4 of channels each), kRayBlock / nq rays per pass
+            const uint32_t nq = aux_stride / 4, rays_per_pass = kRayBlock / nq;
+            const uint32_t slot = threadIdx.x / nq, q = threadIdx.x - slot * nq;
+            for (uint32_t r = slot; r < kRayBlock && slot < rays_per_pass; r += rays_per_pass) {
                 const uint32_t n = chunk * kRayBlock + r;
-                if (n >= n_alive || q >= nq) continue;
+                if (n >= n_alive) continue;
                 const int index = rays_alive[n];
                 const float* s = sigmas + (size_t)n * n_step;
                 const float* in = aux + (size_t)n * n_step * aux_stride + q * 4;
