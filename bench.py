@@ -161,6 +161,7 @@ def main():
     torch.cuda.synchronize()
     prof = _torch_glue.profile_kernels(["pnr_grid_encode_forward"]) if rank == 0 else None
     rendered = torch.zeros(1, dtype=torch.int64, device=device)
+    rendered_host = 0
     rows = 0
     native_ms, native_launches = 0.0, 0
     native_rows = 0
@@ -186,7 +187,10 @@ def main():
         if timed_native:
             m._fused.time_grid_kernel = i == 0
         r, _full = frame()
-        rendered += r["rendered"]
+        if r["rendered"].is_cuda:
+            rendered += r["rendered"]
+        else:
+            rendered_host += int(r["rendered"])   # native loop: the count is already on the host (it came back with the control block)
         rows += r["n_samples"]
         if timed_native and i == 0:
             native_ms, native_launches, native_rows = r.get("grid_ms", 0.0), r.get("grid_launches", 0), r["n_samples"]
@@ -195,6 +199,7 @@ def main():
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    rendered += rendered_host
     _torch_glue.profile_kernels(None)
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if use_dist:
@@ -220,11 +225,13 @@ def main():
             t = json.load(open(tpath)).get(args.model)
             if t:
                 traffic = t["traffic_bytes_per_launch"] / n_tables
-        per_step = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps))
+        raw_steps = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
+        slowest = max(range(args.steps), key=lambda i: raw_steps[i])
+        per_step = sorted(raw_steps)
         out = {
             "metric": "rendered_samples_per_sec", "value": total_rendered / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "step_ms": {"min": per_step[0], "median": per_step[len(per_step) // 2], "max": per_step[-1]}, "higher_is_better": True, "scaling": args.scaling,
+            "step_ms": {"min": per_step[0], "median": per_step[len(per_step) // 2], "max": per_step[-1], "slowest_step": slowest}, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f16" if args.fp16 else "f32", "data": "synthetic",
             "config": {"workload": f"configs[{1 if args.model == 'nerf' else 2}]: NeRF-synthetic lego geometry (scene S0), -m {args.model} inference, {H}x{W}, {n_views} view(s)/step",
                        "rays_per_step": n_views * H * W, "rendered_samples_per_step": total_rendered // args.steps,

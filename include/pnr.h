@@ -206,6 +206,11 @@ typedef struct pnr_nerf_frame_args {
     const int32_t* ray_order;      /* optional permutation of 0..N-1 (device): processing order of the rays, e.g. 8x8 pixel tiles per
                                       wave; NULL = as given.  The frame then runs on copies of the per-ray inputs gathered into that
                                       order; outputs are scattered back, indexed by ray id either way, and do not depend on the order */
+    int finish;                    /* bit mask: apply the caller-side epilogue of run_cuda (nerf/renderer.py:382-384) before returning --
+                                      bit 0: image += (1 - weights_sum) * bg_color;  bit 1: depth = max(depth - near, 0) / (far - near)
+                                      (same fp32 operations, in the same order, as the reference's torch expressions) */
+    float bg_color[3];             /* used when finish != 0 and bg_map == NULL (the reference's default is 1) */
+    const float* bg_map;           /* optional per-ray background [N,3] (device) for finish */
 } pnr_nerf_frame_args;
 uint64_t pnr_nerf_frame_workspace_bytes(uint32_t N);
 int pnr_nerf_render_frame(const pnr_nerf_frame_args* args, pnr_stream_t stream);

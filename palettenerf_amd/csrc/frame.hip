@@ -67,16 +67,33 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_sort_inputs(uint32_t N, con
     for (int k = 0; k < 3; k++) { so[i * 3 + k] = rays_o[(size_t)r * 3 + k]; sd[i * 3 + k] = rays_d[(size_t)r * 3 + k]; }
     sn[i] = nears[r]; sf[i] = fars[r];
 }
+// The epilogue of run_cuda (nerf/renderer.py:382-384) on request: the same fp32 operations as the torch expressions
+//   image + (1 - weights_sum).unsqueeze(-1) * bg_color ;  torch.clamp(depth - nears, min=0) / (fars - nears)
+struct FrameFinish { int on; float bg[3]; const float* bg_map; const float* nears; const float* fars; };
+__device__ __forceinline__ float finish_channel(const FrameFinish& f, float v, float ws, uint32_t ray, uint32_t ch) {
+    const float t = 1.0f - ws;
+    const float bg = f.bg_map ? f.bg_map[(size_t)ray * 3 + ch] : f.bg[ch];
+    return v + t * bg;
+}
+__device__ __forceinline__ float finish_depth(const FrameFinish& f, float d, uint32_t ray) {
+    return fmaxf(d - f.nears[ray], 0.0f) / (f.fars[ray] - f.nears[ray]);
+}
+
 template <uint32_t LANES>   // lanes per ray: 16 with an aux row to move (float4 each), 4 without
 __global__ void __launch_bounds__(kRayBlock) k_frame_unsort_outputs(uint32_t N, const int32_t* __restrict__ order, const float* __restrict__ sws,
                                                                     const float* __restrict__ sdepth, const float* __restrict__ simage,
                                                                     const float* __restrict__ saux, uint32_t aux_stride, float* __restrict__ ws,
-                                                                    float* __restrict__ depth, float* __restrict__ image, float* __restrict__ aux) {
+                                                                    float* __restrict__ depth, float* __restrict__ image, float* __restrict__ aux,
+                                                                    FrameFinish fin) {
     const uint32_t i = (blockIdx.x * kRayBlock + threadIdx.x) / LANES, q = threadIdx.x % LANES;
     if (i >= N) return;
-    const uint32_t r = (uint32_t)order[i];
-    if (q == 0) { ws[r] = sws[i]; depth[r] = sdepth[i]; }
-    if (q < 3) image[(size_t)r * 3 + q] = simage[(size_t)i * 3 + q];
+    const uint32_t r = order ? (uint32_t)order[i] : i;   // order == nullptr: finish in place (sws == ws, ...)
+    if (q == 0) {
+        const float d = sdepth[i];
+        if (order) ws[r] = sws[i];
+        depth[r] = (fin.on & 2) ? finish_depth(fin, d, r) : d;
+    }
+    if (q < 3) { const float v = simage[(size_t)i * 3 + q]; image[(size_t)r * 3 + q] = (fin.on & 1) ? finish_channel(fin, v, sws[i], r, q) : v; }
     if (saux && q * 4 < aux_stride)
         *reinterpret_cast<float4*>(aux + (size_t)r * aux_stride + q * 4) = *reinterpret_cast<const float4*>(saux + (size_t)i * aux_stride + q * 4);
 }
@@ -583,12 +600,18 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
         if (++looks >= 4 && chunk < 64) chunk *= 2;
     }
     predicted_iterations = (uint32_t)host_ctl->iterations;
+    FrameFinish fin;
+    fin.on = a->finish; fin.bg[0] = a->bg_color[0]; fin.bg[1] = a->bg_color[1]; fin.bg[2] = a->bg_color[2];
+    fin.bg_map = a->bg_map; fin.nears = a->nears; fin.fars = a->fars;   // indexed by ray id
     if (sorted && pal)
         hipLaunchKernelGGL(k_frame_unsort_outputs<16>, dim3(cdiv(N * 16, kRayBlock)), dim3(kRayBlock), 0, s, N, a->ray_order, w.s_ws, w.s_depth, w.s_image,
-                           w.s_aux, aux_stride, a->weights_sum, a->depth, a->image, pal->aux_map);
+                           w.s_aux, aux_stride, a->weights_sum, a->depth, a->image, pal->aux_map, fin);
     else if (sorted)
         hipLaunchKernelGGL(k_frame_unsort_outputs<4>, dim3(cdiv(N * 4, kRayBlock)), dim3(kRayBlock), 0, s, N, a->ray_order, w.s_ws, w.s_depth, w.s_image,
-                           (const float*)nullptr, 0u, a->weights_sum, a->depth, a->image, (float*)nullptr);
+                           (const float*)nullptr, 0u, a->weights_sum, a->depth, a->image, (float*)nullptr, fin);
+    else if (fin.on)   // unsorted frame: the same kernel in place
+        hipLaunchKernelGGL(k_frame_unsort_outputs<4>, dim3(cdiv(N * 4, kRayBlock)), dim3(kRayBlock), 0, s, N, (const int32_t*)nullptr, a->weights_sum, a->depth,
+                           a->image, (const float*)nullptr, 0u, a->weights_sum, a->depth, a->image, (float*)nullptr, fin);
     if (timing) {  // only the iterations that did work (the tail of the last chunk are no-op launches)
         float total = 0.0f;
         uint32_t counted = 0;

@@ -38,6 +38,31 @@ def tile_ray_order(pixel_index, W, tile=8):
     return torch.argsort(key).to(torch.int32)
 
 
+def _set_finish(a, bg_color, N, mask):
+    """Fill the finish / bg fields of a frame-args struct; returns True when the call will apply the epilogue."""
+    a.finish, a.bg_map = 0, None
+    if bg_color is None:
+        return False
+    if torch.is_tensor(bg_color):
+        if bg_color.numel() == 3:
+            vals = [float(v) for v in bg_color.flatten().tolist()]
+        elif bg_color.shape[-1] == 3 and bg_color.numel() == 3 * N and bg_color.is_cuda and bg_color.dtype == torch.float32 and bg_color.is_contiguous():
+            a.bg_map = bg_color.data_ptr()
+            vals = [0.0, 0.0, 0.0]
+        else:
+            return False
+    elif isinstance(bg_color, (int, float)):
+        vals = [float(bg_color)] * 3
+    else:
+        vals = [float(v) for v in bg_color]
+        if len(vals) != 3:
+            return False
+    for k in range(3):
+        a.bg_color[k] = vals[k]
+    a.finish = mask
+    return True
+
+
 class NeRFFieldFused:
     """Caches the MFMA-ordered weight blob of a NeRFNetwork and evaluates (sigma, rgb) for sample batches."""
 
@@ -70,9 +95,11 @@ class NeRFFieldFused:
         return self.packed
 
     @torch.no_grad()
-    def render_frame(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh):
+    def render_frame(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color=None):
         """One inference frame through the device-driven loop (pnr_nerf_render_frame).  Returns
-        (weights_sum [N], depth [N], image [N,3], stats dict); raw accumulations, bg mix is the caller's."""
+        (weights_sum [N], depth [N], image [N,3], stats dict).  bg_color None: raw accumulations (bg mix and depth normalisation are
+        the caller's); a number, 3 numbers or an [N,3] tensor: the call also applies run_cuda's epilogue (image + (1 - ws) bg,
+        normalised depth) -- stats['finished'] says so."""
         from . import raymarching
         m = self.model
         N = rays_o.shape[0]
@@ -108,12 +135,13 @@ class NeRFFieldFused:
         a.kernel_ms = ctypes.cast(kms, ctypes.c_void_p) if self.time_grid_kernel else None
         order = getattr(self, "ray_order", None)
         a.ray_order = order.data_ptr() if order is not None and order.numel() == N else None
+        finished = _set_finish(a, bg_color, N, 3)
         for t, name in ((rays_o, "rays_o"), (rays_d, "rays_d"), (nears, "nears"), (fars, "fars")):
             require(t, torch.float32, name)
         rc = lib.pnr_nerf_render_frame(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         _lib.check(rc, "pnr_nerf_render_frame")
         return ws, depth, image, {"iterations": int(stats[0]), "rendered": int(stats[1]), "rows": int(stats[2]), "enqueued": int(stats[3]),
-                                  "grid_ms": float(kms[0]), "grid_launches": int(kms[1])}
+                                  "grid_ms": float(kms[0]), "grid_launches": int(kms[1]), "finished": finished}
 
     @torch.no_grad()
     def __call__(self, x, d):

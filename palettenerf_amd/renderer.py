@@ -282,14 +282,17 @@ class NeRFRenderer(_OccupancyMaintenance, _RendererBase):
                 self._fused = NeRFFieldFused(self)
             if perturb or torch.is_autocast_enabled():
                 raise RuntimeError("march_mode='native' covers fp32 inference without perturbation")
-            weights_sum, depth_acc, image_acc, stats = self._fused.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh)
-            image = image_acc + (1 - weights_sum).unsqueeze(-1) * bg_color
-            depth = torch.clamp(depth_acc - nears, min=0) / (fars - nears)
+            weights_sum, depth_acc, image_acc, stats = self._fused.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color=bg_color)
+            if stats["finished"]:   # the frame call applied the epilogue below itself (same fp32 operations, one launch less each)
+                image, depth = image_acc, depth_acc
+            else:
+                image = image_acc + (1 - weights_sum).unsqueeze(-1) * bg_color
+                depth = torch.clamp(depth_acc - nears, min=0) / (fars - nears)
             image = image.view(*prefix, 3)
             depth = depth.view(*prefix)
             rgb_norm_map = torch.zeros_like(image[..., 0])
             results["n_samples"] = stats["rows"]
-            results["rendered"] = torch.tensor([stats["rendered"]], dtype=torch.int64, device=rays_o.device)
+            results["rendered"] = torch.tensor([stats["rendered"]], dtype=torch.int64)   # host tensor: the count came back with the control block
             results["iterations"] = stats["iterations"]
             results["grid_ms"], results["grid_launches"] = stats["grid_ms"], stats["grid_launches"]
         else:
@@ -556,7 +559,7 @@ class PaletteRenderer(_RendererBase):
             ws_n, depth_n, image_n, aux_map, stats = self._fused.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh)
             st = _MarchState.__new__(_MarchState)
             st.weights_sum, st.depth, st.image, st.n_samples = ws_n, depth_n, image_n, stats["rows"]
-            st.rendered = torch.tensor([stats["rendered"]], dtype=torch.int64, device=device)
+            st.rendered = torch.tensor([stats["rendered"]], dtype=torch.int64)   # host tensor: the count came back with the control block
             results["iterations"], results["grid_ms"], results["grid_launches"] = stats["iterations"], stats["grid_ms"], stats["grid_launches"]
         else:
             st = self._infer_loop(rays_o, rays_d, nears, fars, perturb, dt_gamma, max_steps, shade_fused if use_fused else shade)
