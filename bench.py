@@ -245,9 +245,15 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        try:   # RCCL prints its version banner through C stdio, which is flushed at exit: push it out first so the JSON line is the last one
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
