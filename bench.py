@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--ray-order", choices=["tile8", "tile4", "tile16", "morton", "rowmajor"], default="tile8", help="initial order of the alive list in the native loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scene", choices=["s0", "s1"], default="s0", help="s0: dense 8^3 bricks (the headline scene); s1: sparse 4^3 bricks, the occupied box ~94 %% air")
     ap.add_argument("--dt-gamma", type=float, default=0.0, help="march step growth (0 = the lego config; 1/128 = the LLFF / 360 configs)")
     ap.add_argument("--cpu-crop", type=int, default=480, help="side of the centre crop timed on the CPU oracle")
     return ap.parse_args()
@@ -58,7 +59,7 @@ def build_model(args, device):
         m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True, density_scale=args.density_scale, min_near=0.2)
     scene.seed_field_(m, 0)
     m = m.to(device).eval()
-    m.density_grid.copy_(torch.from_numpy(scene.brick_density_grid()).to(device))
+    m.density_grid.copy_(torch.from_numpy(scene.brick_density_grid() if args.scene == "s0" else scene.sparse_density_grid()).to(device))
     raymarching.packbits(m.density_grid, 0.5, m.density_bitfield)
     m.count_rendered = True
     return m
@@ -82,7 +83,7 @@ def cpu_baseline(args):
         else:
             m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True, density_scale=args.density_scale, min_near=0.2)
         scene.seed_field_(m, 0)
-        grid = scene.brick_density_grid()
+        grid = scene.brick_density_grid() if args.scene == "s0" else scene.sparse_density_grid()
         m.density_grid.copy_(torch.from_numpy(grid))
         m.density_bitfield.copy_(torch.from_numpy(oracle.packbits(grid, 0.5)))
         m.eval()
@@ -233,7 +234,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "step_ms": {"min": per_step[0], "median": per_step[len(per_step) // 2], "max": per_step[-1], "slowest_step": slowest}, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f16" if args.fp16 else "f32", "data": "synthetic",
-            "config": {"workload": f"configs[{1 if args.model == 'nerf' else 2}]: NeRF-synthetic lego geometry (scene S0), -m {args.model} inference, {H}x{W}, {n_views} view(s)/step",
+            "config": {"workload": f"configs[{1 if args.model == 'nerf' else 2}]: NeRF-synthetic lego geometry (scene {args.scene.upper()}), -m {args.model} inference, {H}x{W}, {n_views} view(s)/step",
                        "rays_per_step": n_views * H * W, "rendered_samples_per_step": total_rendered // args.steps,
                        "evaluated_rows_per_step_rank0": rows // args.steps, "density_scale": args.density_scale, "dt_gamma": args.dt_gamma, "march_mode": m.march_mode, "fused_field": bool(getattr(m, "fused_field", False)), "field_precision": args.field_precision, "ray_order": args.ray_order,
                        "parallelism": f"32x32 ray tiles of {n_views} view(s) round-robin over {world} GPUs + one all_gather/step" if world > 1 else "single GPU"},

@@ -5,6 +5,7 @@
 #include "lattice.hpp"
 #include <float.h>
 #include <string.h>
+#include <stdlib.h>
 
 namespace pnr {
 
@@ -45,6 +46,7 @@ struct MarchParams {  // ray-independent constants, computed once on the host
     float bound, dt_gamma, dt_min, dt_max;
     uint32_t C, H, max_steps;
     uint32_t mip_words;  // uint32 words per mask; 0 = no mip
+    uint32_t block_skip; // empty-block jumps allowed (PNR_NO_BLOCK_SKIP=1 in the environment turns them off for A/B measurements)
 };
 
 static MarchParams make_march_params(float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, bool with_mip) {
@@ -55,6 +57,8 @@ static MarchParams make_march_params(float bound, float dt_gamma, uint32_t max_s
     p.dt_max = two_sqrt3 * (float)(1 << (C - 1)) / (float)H;        // :349
     p.C = C; p.H = H; p.max_steps = max_steps;
     p.mip_words = with_mip ? (uint32_t)(((uint64_t)C * H * H * H / 64 + 31) / 32) : 0;
+    static const bool no_block_skip = getenv("PNR_NO_BLOCK_SKIP") != nullptr;
+    p.block_skip = no_block_skip ? 0u : 1u;
     return p;
 }
 static inline bool is_pow2f(float v) {
@@ -73,7 +77,7 @@ __device__ __forceinline__ void ctx_init(RayCtx& c, const float* __restrict__ o,
     c.mip_any = mip_lds;
     c.mip_all = mip_lds ? mip_lds + p.mip_words : nullptr;
     c.box = mip_lds ? reinterpret_cast<const float*>(mip_lds + 2 * p.mip_words) : nullptr;
-    c.block_skip = mip_lds != nullptr && (p.H % 64u) == 0;
+    c.block_skip = mip_lds != nullptr && (p.H % 64u) == 0 && p.block_skip != 0;
 }
 
 // Slab test of the ray against the occupied box.  `far`: parameter beyond which the ray is outside the box for good

@@ -49,6 +49,30 @@ def brick_density_grid(H=128, seed=0, extent=0.65, bound=2):
     return grid
 
 
+def sparse_density_grid(H=128, seed=0, extent=0.8, bound=2, fill=0.06):
+    """Scene S1: like S0 but mostly air -- 4^3-cell bricks inside max|p| < extent are occupied with probability `fill`
+    (thin, scattered structure: the occupied box is ~94 % empty), coarser cascades derived as in S0."""
+    cascade = 1 + math.ceil(math.log2(bound))
+    idx = np.arange(H, dtype=np.uint32)
+    i, j, k = np.meshgrid(idx, idx, idx, indexing="ij")
+    c = (idx.astype(np.float64) + 0.5) / H * 2 - 1
+    px, py, pz = np.meshgrid(c, c, c, indexing="ij")
+    inside = np.maximum(np.maximum(np.abs(px), np.abs(py)), np.abs(pz)) < extent
+    a, b, cc = i >> 2, j >> 2, k >> 2
+    h = (a * np.uint32(73856093)) ^ (b * np.uint32(19349663)) ^ (cc * np.uint32(83492791)) ^ np.uint32((seed * 2654435761 + 12345) & 0xFFFFFFFF)
+    h = (h ^ (h >> np.uint32(13))) * np.uint32(0x5bd1e995)
+    occ = inside & (((h >> np.uint32(8)) % np.uint32(10000)) < np.uint32(int(fill * 10000)))
+    grid = np.zeros((cascade, H ** 3), dtype=np.float32)
+    grid[0, morton3d_np(i[occ], j[occ], k[occ])] = 1.0
+    for cas in range(1, cascade):
+        s = float(min(2 ** cas, bound))
+        qi = np.floor((px[occ] / s + 1) / 2 * H).astype(np.uint32)
+        qj = np.floor((py[occ] / s + 1) / 2 * H).astype(np.uint32)
+        qk = np.floor((pz[occ] / s + 1) / 2 * H).astype(np.uint32)
+        grid[cas, morton3d_np(qi, qj, qk)] = 1.0
+    return grid
+
+
 def slab_density_grid(H=128, half_thickness=0.8, bound=2):
     """Frozen slab occupancy |z| < half_thickness used for the forward-facing training config (3)."""
     cascade = 1 + math.ceil(math.log2(bound))
