@@ -147,12 +147,17 @@ def main():
         kw["gui_mode"] = False
 
     gatherer = pdist.FrameGatherer(VH, W, 5, device) if use_dist else None
+    pending = []   # all-gather of the previous frame, still in flight
 
     def frame():
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=args.fp16):
             r = m.render(ro, rd, **kw)
-        if use_dist:  # one all-gather of the packed (rgb, depth, alpha) rows; every rank ends up with the full frame
-            return r, gatherer([r["image"][0], r["depth"][0][:, None], r["weights_sum"][:, None]])
+        if use_dist:  # one all-gather of the packed (rgb, depth, alpha) rows; every rank ends up with the full frame.  It is started here
+            # and completed after the NEXT frame has been rendered (or at the end of the timed region): communication overlaps compute
+            handle = gatherer.start([r["image"][0], r["depth"][0][:, None], r["weights_sum"][:, None]])
+            full = gatherer.finish(pending.pop()) if pending else None
+            pending.append(handle)
+            return r, full
         return r, None
 
     for _ in range(args.warmup):
@@ -196,6 +201,8 @@ def main():
         if timed_native and i == 0:
             native_ms, native_launches, native_rows = r.get("grid_ms", 0.0), r.get("grid_launches", 0), r["n_samples"]
         step_ev[i + 1].record()
+    if pending:
+        _full = gatherer.finish(pending.pop())   # the last frame's all-gather completes inside the timed region
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()

@@ -51,15 +51,30 @@ class FrameGatherer:
             if r == self.rank:
                 self.idx = sel
         self.gather_index = (owner * self.n_max + local_pos).to(device)
-        self.send = torch.zeros(self.n_max, K, dtype=torch.float32, device=device)
-        self.recv = torch.empty(self.world * self.n_max, K, dtype=torch.float32, device=device)
+        # two buffer pairs: the all-gather of frame k may still be in flight while frame k+1 is packed (start / finish below)
+        self.send = [torch.zeros(self.n_max, K, dtype=torch.float32, device=device) for _ in range(2)]
+        self.recv = [torch.empty(self.world * self.n_max, K, dtype=torch.float32, device=device) for _ in range(2)]
+        self._turn = 0
+
+    def start(self, parts):
+        """Pack this rank's rows and launch the all-gather WITHOUT making the compute stream wait for it: the collective runs on the
+        communicator's stream while the next frame is rendered.  Returns a handle for finish().  At most two frames in flight."""
+        n = self.idx.numel()
+        slot = self._turn
+        self._turn ^= 1
+        torch.cat(parts, dim=1, out=self.send[slot][:n])
+        work = dist.all_gather_into_tensor(self.recv[slot], self.send[slot], group=self.group, async_op=True)
+        return work, slot
+
+    def finish(self, handle):
+        """Wait for a started all-gather and return the [H*W, K] frame (every rank gets the full frame)."""
+        work, slot = handle
+        work.wait()
+        return self.recv[slot].index_select(0, self.gather_index)
 
     def __call__(self, parts):
         """parts: tensors [n_local, k_i] (sum k_i == K), rows ordered like self.idx.  Returns the [H*W, K] frame on every rank."""
-        n = self.idx.numel()
-        torch.cat(parts, dim=1, out=self.send[:n])
-        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
-        return self.recv.index_select(0, self.gather_index)
+        return self.finish(self.start(parts))
 
 
 def gather_frame(local, idx, n_max, H, W, group=None):

@@ -38,6 +38,17 @@ def _worker(rank, world, port, H, W, K):
             ref = full_ref + rep
             frame = g([ref[g.idx, :3].clone(), ref[g.idx, 3:4].clone(), ref[g.idx, 4:].clone()])
             assert torch.equal(frame, ref), f"rank {rank}: FrameGatherer frame differs"
+        # pipelined use (bench.py): the all-gather of frame k is finished only after frame k+1 has been packed and started
+        refs = [full_ref * (rep + 2) for rep in range(4)]
+        pending, done = None, []
+        for ref in refs:
+            handle = g.start([ref[g.idx].clone()])
+            if pending is not None:
+                done.append(g.finish(pending))
+            pending = handle
+        done.append(g.finish(pending))
+        for ref, frame in zip(refs, done):
+            assert torch.equal(frame, ref), f"rank {rank}: pipelined frame differs"
     finally:
         dist.destroy_process_group()
 
