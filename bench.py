@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--model", choices=["nerf", "palette"], default="nerf")
     ap.add_argument("--density-scale", type=float, default=100.0, help="S0-opaque (trained-scene-like early termination); ~0 = translucent")
@@ -183,6 +183,19 @@ def main():
         m._fused.ray_order = tile_ray_order(idx, W, {"tile8": 8, "tile4": 4, "tile16": 16, "morton": 0}[args.ray_order]).to(device)   # idx: row-major pixel ids (of the stacked views) this rank renders
         for _ in range(2):
             frame()                                               # re-warm with the final ordering
+        torch.cuda.synchronize()
+    if m.march_mode == "native":   # untimed, on every rank (a frame holds a collective): one frame with the in-library HIP-event timing on,
+        fused = getattr(m, "_fused", None)   # so that the events exist before the timed region
+        if fused is not None:
+            fused.time_grid_kernel = True
+        frame()
+        if fused is not None:
+            fused.time_grid_kernel = False
+        torch.cuda.synchronize()
+    if use_dist:
+        if pending:
+            gatherer.finish(pending.pop())
+        dist.barrier()
         torch.cuda.synchronize()
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # diagnostics only (no sync inside the loop)
     t0 = time.perf_counter()
