@@ -238,7 +238,8 @@ def main():
         n_launches = len(launches)
         kernel_name = "k_grid_fwd (pnr_grid_encode_forward)"
         if m.march_mode == "native":  # events recorded inside pnr_nerf_render_frame around every k_frame_grid launch
-            k_ms, k_units, n_launches, kernel_name = native_ms, native_rows * n_tables, native_launches, "k_frame_grid (device-driven frame loop)"
+            k_ms, k_units, n_launches = native_ms, native_rows * n_tables, native_launches
+            kernel_name = "k_frame_grid (device-driven frame loop)" if args.model == "nerf" else "k_frame_grid_pair (device-driven frame loop, encoder + encoder_palette interleaved)"
         achieved = (k_units * per_sample) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic = None  # HBM-side bytes per launch from the committed PMC passes of this exact workload (profiles/r01_traffic.json)
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")

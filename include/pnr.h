@@ -230,7 +230,12 @@ typedef struct pnr_palette_frame_args {
     int pred_clip;
     float offsets_weight, view_dep_weight;
     float* aux_map;                    /* [N, aux channels] out */
+    const float* embeddings_pair;      /* optional: `encoder` and `encoder_palette` interleaved row by row ([rows][4] floats, built by
+                                          pnr_interleave_tables; rebuild when either table changes).  Used when pred_clip == 0: one 16-byte
+                                          gather serves both tables, results bit-identical to the separate lookups */
 } pnr_palette_frame_args;
+/* out[i] = (a[i].x, a[i].y, b[i].x, b[i].y) for two C = 2 fp32 tables of `rows` rows with the same level layout */
+int pnr_interleave_tables(const float* a, const float* b, uint64_t rows, float* out, pnr_stream_t stream);
 uint64_t pnr_palette_frame_workspace_bytes(uint32_t N, uint32_t num_basis, uint32_t clip_dim, int pred_clip);
 int pnr_palette_render_frame(const pnr_palette_frame_args* args, pnr_stream_t stream);
 

@@ -58,6 +58,7 @@ SIGNATURES = {
     "pnr_grid_encode_backward_binned": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u64, _ptr, _u64, _ptr],
     "pnr_linear_wgrad_workspace_bytes": [_u32, _u32, _u32],
     "pnr_linear_wgrad": [_ptr, _int, _ptr, _int, _u32, _u32, _u32, _ptr, _int, _ptr, _u64, _ptr],
+    "pnr_interleave_tables": [_ptr, _ptr, _u64, _ptr, _ptr],
     "pnr_get_rays": [_ptr, _u32, _f32, _f32, _f32, _f32, _u32, _u32, _ptr, _u32, _ptr, _ptr, _ptr],
 }
 _RESTYPES = {"pnr_error_string": ctypes.c_char_p, "pnr_scan_scratch_bytes": _u64, "pnr_nerf_field_packed_bytes": _u64, "pnr_occupancy_mip_bytes": _u64, "pnr_nerf_frame_workspace_bytes": _u64, "pnr_palette_field_packed_bytes": _u64, "pnr_palette_frame_workspace_bytes": _u64,
@@ -75,7 +76,7 @@ class NerfFrameArgs(ctypes.Structure):
 class PaletteFrameArgs(ctypes.Structure):
     """Mirror of `pnr_palette_frame_args` (include/pnr.h)."""
     _fields_ = [("base", NerfFrameArgs), ("embeddings_palette", _ptr), ("embeddings_clip", _ptr), ("basis_color", _ptr), ("or_bias", _ptr),
-                ("num_basis", _u32), ("clip_dim", _u32), ("pred_clip", _int), ("offsets_weight", _f32), ("view_dep_weight", _f32), ("aux_map", _ptr)]
+                ("num_basis", _u32), ("clip_dim", _u32), ("pred_clip", _int), ("offsets_weight", _f32), ("view_dep_weight", _f32), ("aux_map", _ptr), ("embeddings_pair", _ptr)]
 
 
 class PaletteWeights(ctypes.Structure):

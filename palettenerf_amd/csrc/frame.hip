@@ -242,6 +242,76 @@ __global__ void __launch_bounds__(256) k_frame_grid(const FrameCtl* __restrict__
     }
 }
 
+// Two hash tables with one level layout (PaletteNeRF's `encoder` and `encoder_palette` are looked up at the same positions)
+// interleaved row by row -- (a.x, a.y, b.x, b.y) = 16 bytes per index: one gather fetches both tables' rows, so the lookup of
+// the pair costs the lane requests and L2->L1 line fills of ONE table.  Same corner order and fmaf chains as two separate
+// lookups: the encoder outputs are bit-identical.
+__global__ void __launch_bounds__(256) k_interleave_tables(const float2* __restrict__ a, const float2* __restrict__ b, uint64_t rows,
+                                                           float4* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < rows) { const float2 u = a[i], v = b[i]; out[i] = make_float4(u.x, u.y, v.x, v.y); }
+}
+
+__global__ void __launch_bounds__(256) k_frame_grid_pair(const FrameCtl* __restrict__ ctl, const float* __restrict__ xyzs, const float* __restrict__ deltas,
+                                                         const float4* __restrict__ table, float* __restrict__ enc_a, float* __restrict__ enc_b,
+                                                         const int32_t* __restrict__ offsets, LevelParams lp, uint32_t level_stride, float bound,
+                                                         float two_bound, uint32_t gridtype) {
+    if (ctl->done) return;
+    const uint32_t rows = (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step;
+    const uint32_t level = blockIdx.y;
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    const float4* g = table + off0;
+    const float scale = lp.scale[level];
+    const uint32_t resolution = lp.resolution[level];
+    for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < rows; b += gridDim.x * 256) {
+        if (deltas[(size_t)b * 2] == 0.0f) continue;
+        float in[3];
+        bool oob = false;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            in[d] = (xyzs[(size_t)b * 3 + d] + bound) / two_bound;
+            oob |= (in[d] < 0.0f) | (in[d] > 1.0f);
+        }
+        float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (!oob) {
+            float pos[3];
+            uint32_t pg[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                pos[d] = fmaf(in[d], scale, 0.5f);
+                const float fl = floorf(pos[d]);
+                pg[d] = (uint32_t)fl;
+                pos[d] -= (float)pg[d];
+            }
+            uint32_t idxs[8];
+            float ws[8];
+#pragma unroll
+            for (uint32_t idx = 0; idx < 8; idx++) {
+                float w = 1.0f;
+                uint32_t pl[3];
+#pragma unroll
+                for (uint32_t d = 0; d < 3; d++) {
+                    if ((idx & (1u << d)) == 0) { w *= 1.0f - pos[d]; pl[d] = pg[d]; }
+                    else { w *= pos[d]; pl[d] = pg[d] + 1; }
+                }
+                ws[idx] = w;
+                idxs[idx] = grid_index<3, 1>(gridtype, false, hashmap_size, resolution, pl);
+            }
+            float4 v[8];
+#pragma unroll
+            for (uint32_t idx = 0; idx < 8; idx++) v[idx] = g[idxs[idx]];
+#pragma unroll
+            for (uint32_t idx = 0; idx < 8; idx++) {
+                out.x = fmaf(ws[idx], v[idx].x, out.x); out.y = fmaf(ws[idx], v[idx].y, out.y);
+                out.z = fmaf(ws[idx], v[idx].z, out.z); out.w = fmaf(ws[idx], v[idx].w, out.w);
+            }
+        }
+        *reinterpret_cast<float2*>(enc_a + ((size_t)level * level_stride + b) * 2) = make_float2(out.x, out.y);
+        *reinterpret_cast<float2*>(enc_b + ((size_t)level * level_stride + b) * 2) = make_float2(out.z, out.w);
+    }
+}
+
 // the fused MFMA field of field.hip with rows from the control block, dead-slot skipping and density_scale
 constexpr int kFieldThreads = 512;
 template <int PREC>
@@ -473,6 +543,14 @@ using namespace pnr;
 
 extern "C" {
 
+int pnr_interleave_tables(const float* a, const float* b, uint64_t rows, float* out, pnr_stream_t stream) {
+    if (rows == 0) return PNR_OK;
+    if (!a || !b || !out) return PNR_ERR_INVALID;
+    hipLaunchKernelGGL(k_interleave_tables, dim3((uint32_t)((rows + 255) / 256)), dim3(256), 0, as_stream(stream), reinterpret_cast<const float2*>(a),
+                       reinterpret_cast<const float2*>(b), rows, reinterpret_cast<float4*>(out));
+    return check_launch();
+}
+
 uint64_t pnr_nerf_frame_workspace_bytes(uint32_t N) { return carve(nullptr, N).bytes; }
 uint64_t pnr_palette_frame_workspace_bytes(uint32_t N, uint32_t num_basis, uint32_t clip_dim, int pred_clip) {
     return carve(nullptr, N, pnr_palette_aux_channels(num_basis, clip_dim), pred_clip != 0).bytes;
@@ -519,6 +597,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     gs.table[1] = pal ? pal->embeddings_palette : nullptr; gs.enc[1] = w.enc_pal;
     gs.table[2] = with_clip ? pal->embeddings_clip : nullptr; gs.enc[2] = w.enc_clip;
     const uint32_t n_enc = pal ? (with_clip ? 3u : 2u) : 1u;
+    const float4* pair_table = (pal && !with_clip && pal->embeddings_pair) ? reinterpret_cast<const float4*>(pal->embeddings_pair) : nullptr;
     pnr_palette_field_args pf = {};
     if (pal) {
         pf.enc = w.enc; pf.enc_palette = w.enc_pal; pf.enc_clip = w.enc_clip; pf.level_stride = N; pf.dirs = w.dirs; pf.deltas = w.deltas;
@@ -575,8 +654,12 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             const uint32_t gx = cdiv(rows_ub, 256);
             hipEvent_t e0 = timing ? next_event() : nullptr, e1 = timing ? next_event() : nullptr;
             if (e0) (void)hipEventRecord(e0, s);
-            hipLaunchKernelGGL(k_frame_grid, dim3(gx < 1024u ? gx : 1024u, 16, n_enc), dim3(256), 0, s, cur, w.xyzs, w.deltas, gs, a->offsets, lp, N,
-                               a->bound, 2.0f * a->bound, a->gridtype);
+            if (pair_table)
+                hipLaunchKernelGGL(k_frame_grid_pair, dim3(gx < 1024u ? gx : 1024u, 16), dim3(256), 0, s, cur, w.xyzs, w.deltas, pair_table, w.enc, w.enc_pal,
+                                   a->offsets, lp, N, a->bound, 2.0f * a->bound, a->gridtype);
+            else
+                hipLaunchKernelGGL(k_frame_grid, dim3(gx < 1024u ? gx : 1024u, 16, n_enc), dim3(256), 0, s, cur, w.xyzs, w.deltas, gs, a->offsets, lp, N,
+                                   a->bound, 2.0f * a->bound, a->gridtype);
             if (e1) (void)hipEventRecord(e1, s);
             if (pal) {
                 pf.ctl = cur; pf.B = rows_ub;

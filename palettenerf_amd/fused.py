@@ -173,6 +173,7 @@ class PaletteFieldFused:
         # without a clip head the reference composites clip_dim channels of zeros (palette/renderer.py:477,510): the map is zero whatever
         # happens, so those channels are left out of the packed aux row (52 -> 36 floats per sample for 4 bases) and returned as zeros
         self.clip_dim = int(m.opt.clip_dim) if self.pred_clip else 0
+        self.interleave_tables = True   # native loop: look both hash tables up through one interleaved copy (see _pair_table)
         self.aux_channels = int(_lib.load().pnr_palette_aux_channels(self.nb, self.clip_dim))
 
     def _weights(self):
@@ -215,6 +216,20 @@ class PaletteFieldFused:
         return self._bc, self._bias
 
     @torch.no_grad()
+    def _pair_table(self):
+        """`encoder` and `encoder_palette` interleaved row by row ([rows, 4] fp32; one 16-byte gather then serves both lookups).
+        A copy of both tables (2 x 50 MB for the shipped config), rebuilt when either changes."""
+        m = self.model
+        a, b = m.encoder.embeddings.detach(), m.encoder_palette.embeddings.detach()
+        if a.dtype != torch.float32 or b.dtype != torch.float32 or a.shape != b.shape or a.shape[1] != 2:
+            return None
+        key = (a.data_ptr(), a._version, b.data_ptr(), b._version)
+        if getattr(self, "_pair_key", None) != key:
+            out = torch.empty(a.shape[0], 4, dtype=torch.float32, device=a.device)
+            call("pnr_interleave_tables", ptr(a.contiguous()), ptr(b.contiguous()), ctypes.c_uint64(a.shape[0]), ptr(out))
+            self._pair, self._pair_key = out, key
+        return self._pair
+
     def render_frame(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh):
         """One PaletteNeRF inference frame through the device-driven loop (pnr_palette_render_frame).
         Returns (weights_sum [N], depth [N], image [N,3], aux_map [N, aux_channels], stats); raw accumulations."""
@@ -265,6 +280,8 @@ class PaletteFieldFused:
         p.num_basis, p.clip_dim, p.pred_clip = self.nb, self.clip_dim, int(self.pred_clip)
         p.offsets_weight, p.view_dep_weight = float(m.offsets_weight), float(m.view_dep_weight)
         p.aux_map = aux_map.data_ptr()
+        pair = self._pair_table() if (self.interleave_tables and not self.pred_clip) else None
+        p.embeddings_pair = pair.data_ptr() if pair is not None else None
         for t, name in ((rays_o, "rays_o"), (rays_d, "rays_d"), (nears, "nears"), (fars, "fars")):
             require(t, torch.float32, name)
         rc = lib.pnr_palette_render_frame(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))

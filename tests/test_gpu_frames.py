@@ -288,3 +288,38 @@ def test_training_converges_on_a_synthetic_scene(cuda):
     spec.loader.exec_module(mod)
     log = mod.main(["--steps", "500", "--res", "96", "--views", "12", "--rays", "2048"])
     assert log[0][1] < 20.0 and log[-1][1] > 30.0 and log[-1][1] - log[0][1] > 15.0, log
+
+
+def test_palette_native_loop_pair_table_is_bit_identical(cuda):
+    """The interleaved (encoder, encoder_palette) table of the native PaletteNeRF loop must leave every output bit-identical to the two
+    separate lookups, and must follow in-place updates of either table."""
+    from palettenerf_amd.fused import PaletteFieldFused
+    m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True, density_scale=30.0, min_near=0.2)
+    scene.seed_field_(m, 9)
+    m = m.to(cuda).eval()
+    put_scene(m, cuda)
+    m.count_rendered = True
+    m.march_mode, m.fused_field = "native", True
+    m._fused = PaletteFieldFused(m)
+    pose = torch.from_numpy(scene.lookat_pose())[None]
+    ro, rd = scene.get_rays(pose, scene.intrinsics_from_fov(48, 40), 48, 40)
+    ro, rd = ro.to(cuda), rd.to(cuda)
+    kw = dict(perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4, gui_mode=False)
+
+    def both():
+        outs = []
+        for flag in (False, True):
+            m._fused.interleave_tables = flag
+            with torch.no_grad():
+                outs.append(m.render(ro, rd, **kw))
+        a, b = outs
+        assert int(a["rendered"].item()) == int(b["rendered"].item()) > 500
+        for k, v in a.items():
+            if torch.is_tensor(v) and v.dtype.is_floating_point and v.numel() > 1:
+                assert torch.equal(torch.nan_to_num(b[k], nan=-7.0), torch.nan_to_num(v, nan=-7.0)), k
+        return a
+    first = both()
+    with torch.no_grad():
+        m.encoder_palette.embeddings.mul_(0.5)      # in-place update: the interleaved copy must be rebuilt
+    second = both()
+    assert not torch.equal(first["basis_rgb"], second["basis_rgb"])
