@@ -703,7 +703,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) total += ms;
         }
         a->kernel_ms[0] = total;
-        a->kernel_ms[1] = (float)counted * (float)n_enc;  // one k_frame_grid launch covers n_enc tables: count table-launches
+        a->kernel_ms[1] = (float)counted * (pair_table ? 1.0f : (float)n_enc);  // a k_frame_grid launch covers n_enc tables (count table-launches); the pair kernel is one launch for both
     }
     if (a->stats) {
         a->stats[0] = (uint64_t)host_ctl->iterations;
