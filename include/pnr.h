@@ -272,7 +272,14 @@ typedef struct pnr_palette_field_args {
     float* sigmas;                 /* [B]   = density_scale * exp(h0) */
     float* rgbs;                   /* [B,3] */
     float* aux;                    /* [B, aux_stride] = direct_rgb 3 | view_dep 3 | omega nb | basis_rgb 3nb | unscaled 3nb | clip | 0 pad */
+    /* frame loop only (ctl != NULL), all three or none: in iterations with one sample per ray (ctl->n_step == 1) the aux row is
+     * composited straight into aux_map (aux_map[ray] += weight * row, the arithmetic of composite_rays_flex) instead of being written
+     * to `aux` and read back by the composite launch -- when the kernel can stage the tile in LDS (pnr_palette_field_stages_aux) */
+    const int32_t* rays_alive;     /* [n_alive] ray id of every slot */
+    const float* weights_sum;      /* [N] of BEFORE this iteration */
+    float* aux_map;                /* [N, aux_stride] */
 } pnr_palette_field_args;
+int pnr_palette_field_stages_aux(uint32_t aux_stride, int pred_clip);   /* 1 when the field kernel stages aux rows in LDS (then it can composite them) */
 uint64_t pnr_palette_field_packed_bytes(int pred_clip);
 uint32_t pnr_palette_aux_channels(uint32_t num_basis, uint32_t clip_dim);   /* 6 + 7 nb + clip_dim rounded up to a multiple of 4 */
 int pnr_palette_field_pack(const pnr_palette_weights* weights, void* packed, pnr_stream_t stream);

@@ -58,6 +58,7 @@ SIGNATURES = {
     "pnr_grid_encode_backward_binned": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u64, _ptr, _u64, _ptr],
     "pnr_linear_wgrad_workspace_bytes": [_u32, _u32, _u32],
     "pnr_linear_wgrad": [_ptr, _int, _ptr, _int, _u32, _u32, _u32, _ptr, _int, _ptr, _u64, _ptr],
+    "pnr_palette_field_stages_aux": [_u32, _int],
     "pnr_interleave_tables": [_ptr, _ptr, _u64, _ptr, _ptr],
     "pnr_get_rays": [_ptr, _u32, _f32, _f32, _f32, _f32, _u32, _u32, _ptr, _u32, _ptr, _ptr, _ptr],
 }
@@ -90,7 +91,7 @@ class PaletteFieldArgs(ctypes.Structure):
     _fields_ = [("ctl", _ptr), ("B", _u32), ("enc", _ptr), ("enc_palette", _ptr), ("enc_clip", _ptr), ("level_stride", _u32), ("dirs", _ptr),
                 ("deltas", _ptr), ("packed", _ptr), ("basis_color", _ptr), ("or_bias", _ptr), ("num_basis", _u32), ("clip_dim", _u32),
                 ("pred_clip", _int), ("density_scale", _f32), ("offsets_weight", _f32), ("view_dep_weight", _f32), ("aux_stride", _u32),
-                ("sigmas", _ptr), ("rgbs", _ptr), ("aux", _ptr)]
+                ("sigmas", _ptr), ("rgbs", _ptr), ("aux", _ptr), ("rays_alive", _ptr), ("weights_sum", _ptr), ("aux_map", _ptr)]
 
 
 _lib = None

@@ -353,13 +353,13 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_composite(const FrameCtl* _
                                                                const float* __restrict__ rgbs, const float* __restrict__ deltas,
                                                                float* __restrict__ weights_sum, float* __restrict__ depth, float* __restrict__ image,
                                                                int32_t* __restrict__ scratch, const float* __restrict__ aux, float* __restrict__ aux_map,
-                                                               uint32_t aux_stride) {
+                                                               uint32_t aux_stride, int aux_done_when_one_step) {
     if (ctl->done) return;
     const uint32_t n_alive = (uint32_t)ctl->n_alive, n_step = (uint32_t)ctl->n_step;
     const uint32_t nchunks = (n_alive + kRayBlock - 1) / kRayBlock;
     __shared__ int wsum[kRayBlock / PNR_WAVE];
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        if (aux) {
+        if (aux && !(aux_done_when_one_step && n_step == 1)) {   // with one sample per ray the palette field kernel has composited the row itself
             // Phase 1 (palette): the packed aux row.  aux_stride / 4 lanes per ray, one float4 of channels per lane: a ray's row is one
             // coalesced 208-byte read per sample and per map instead of a 208-byte-strided walk by a single thread.  Every
             // lane re-derives the (cheap) weights; they start from the weights_sum of BEFORE this iteration because phase 2,
@@ -597,6 +597,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     gs.table[1] = pal ? pal->embeddings_palette : nullptr; gs.enc[1] = w.enc_pal;
     gs.table[2] = with_clip ? pal->embeddings_clip : nullptr; gs.enc[2] = w.enc_clip;
     const uint32_t n_enc = pal ? (with_clip ? 3u : 2u) : 1u;
+    const int aux_fused = (pal && pnr_palette_field_stages_aux(aux_stride, pal->pred_clip)) ? 1 : 0;
     const float4* pair_table = (pal && !with_clip && pal->embeddings_pair) ? reinterpret_cast<const float4*>(pal->embeddings_pair) : nullptr;
     pnr_palette_field_args pf = {};
     if (pal) {
@@ -663,6 +664,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             if (e1) (void)hipEventRecord(e1, s);
             if (pal) {
                 pf.ctl = cur; pf.B = rows_ub;
+                if (aux_fused) { pf.rays_alive = alive_in; pf.weights_sum = out_ws; pf.aux_map = out_aux; }
                 const int rc = pnr_palette_field_forward(&pf, stream);
                 if (rc != PNR_OK) return rc;
             } else if (a->field_precision == PNR_FIELD_FP32)
@@ -672,7 +674,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
                 hipLaunchKernelGGL(k_frame_field<1>, dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas,
                                    a->packed_weights, a->density_scale, w.sigmas, w.rgbs);
             hipLaunchKernelGGL(k_frame_composite, gm, bm, 0, s, cur, a->T_thresh, alive_in, w.rays_t, w.sigmas, w.rgbs, w.deltas, out_ws, out_depth, out_image,
-                               w.scratch, (const float*)w.aux, out_aux, aux_stride);
+                               w.scratch, (const float*)w.aux, out_aux, aux_stride, aux_fused);
             hipLaunchKernelGGL(k_frame_compact, gm, bm, 0, s, cur, nxt, alive_in, alive_out, w.scratch, N, a->max_steps, w.partials, gm.x);
         }
         if (hipMemcpyAsync(host_ctl, w.ctl + (iter & 1), sizeof(FrameCtl), hipMemcpyDeviceToHost, s) != hipSuccess) return PNR_ERR_LAUNCH;

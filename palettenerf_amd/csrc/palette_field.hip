@@ -119,7 +119,9 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
                                                                    uint32_t level_stride, const float* __restrict__ dirs,
                                                                    const float* __restrict__ deltas, const unsigned char* __restrict__ packed,
                                                                    uint32_t packed_bytes, PaletteParams pp, float* __restrict__ sigmas,
-                                                                   float* __restrict__ rgbs, float* __restrict__ aux, uint32_t stage_stride) {
+                                                                   float* __restrict__ rgbs, float* __restrict__ aux, uint32_t stage_stride,
+                                                                   const int32_t* __restrict__ rays_alive, const float* __restrict__ weights_sum,
+                                                                   float* __restrict__ aux_map) {
     if (ctl && ctl->done) return;
     const uint32_t B = ctl ? (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step : B_arg;
     const uint32_t ntiles = (B + 255) / 256;
@@ -130,6 +132,7 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     const int nb = pp.nb;
+    const bool fuse_composite = stage_stride && ctl && aux_map && ctl->n_step == 1;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t n = tile * 256 + wave * 32 + (lane & 31);
         const bool valid = n < B && (!deltas || deltas[(size_t)(n < B ? n : 0) * 2] != 0.0f);
@@ -257,7 +260,14 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
 #pragma unroll
             for (int k = 0; k < 16; k++) if (k < pp.clip_dim) a[c + k] = pp.pred_clip ? clip[k] : 0.0f;
             for (c += pp.clip_dim; c < pp.aux_stride; c++) a[c] = 0.0f;
-            sigmas[n] = pp.density_scale * __expf(sigma_logit);
+            const float sigma = pp.density_scale * __expf(sigma_logit);
+            sigmas[n] = sigma;
+            if (fuse_composite) {   // one sample per ray: slot n is ray rays_alive[n]; the weight exactly as k_frame_composite forms it
+                const int index = rays_alive[n];
+                const float alpha = 1.0f - __expf(-sigma * deltas[(size_t)n * 2]);
+                a[pp.aux_stride] = alpha * (1.0f - weights_sum[index]);
+                a[pp.aux_stride + 1] = __int_as_float(index);
+            }
 #pragma unroll
             for (int k = 0; k < 3; k++) rgbs[(size_t)n * 3 + k] = rgb[k] + pp.view_dep_weight * view_dep[k];
         }
@@ -267,8 +277,18 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
             const unsigned long long live = __ballot(valid && h == 0);     // rows of dead / out-of-range slots hold stale slab data: skip them
             for (uint32_t i = (uint32_t)lane; i < 32 * nq; i += 64) {
                 const uint32_t row = i / nq, q = i - row * nq;
-                if ((live >> row) & 1ull)
-                    *reinterpret_cast<float4*>(aux + (size_t)(n0 + row) * pp.aux_stride + q * 4) = *reinterpret_cast<const float4*>(slab + row * stage_stride + q * 4);
+                if (!((live >> row) & 1ull)) continue;
+                const float4 v = *reinterpret_cast<const float4*>(slab + row * stage_stride + q * 4);
+                if (fuse_composite) {   // aux_map[ray] += weight * row (raymarching.cu:1114-1185 with n_step == 1), no round trip through `aux`
+                    const float wgt = slab[row * stage_stride + pp.aux_stride];
+                    const int index = __float_as_int(slab[row * stage_stride + pp.aux_stride + 1]);
+                    float4* dst = reinterpret_cast<float4*>(aux_map + (size_t)index * pp.aux_stride) + q;
+                    float4 acc = *dst;
+                    acc.x = fmaf(wgt, v.x, acc.x); acc.y = fmaf(wgt, v.y, acc.y); acc.z = fmaf(wgt, v.z, acc.z); acc.w = fmaf(wgt, v.w, acc.w);
+                    *dst = acc;
+                } else {
+                    *reinterpret_cast<float4*>(aux + (size_t)(n0 + row) * pp.aux_stride + q * 4) = v;
+                }
             }
         }
     }
@@ -318,6 +338,11 @@ int pnr_palette_field_pack(const pnr_palette_weights* pw, void* packed, pnr_stre
     return check_launch();
 }
 
+int pnr_palette_field_stages_aux(uint32_t aux_stride, int pred_clip) {
+    const uint32_t packed_bytes = (uint32_t)pnr_palette_field_packed_bytes(pred_clip);
+    return (aux_stride & 3u) == 0 && packed_bytes + (kPalThreads / 64) * 32 * (aux_stride + 4) * 4 <= 160 * 1024;
+}
+
 int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stream) {
     if (!a) return PNR_ERR_INVALID;
     if (a->num_basis < 1 || a->num_basis > 5 || a->clip_dim > 16) return PNR_ERR_UNSUPPORTED;
@@ -343,12 +368,13 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
         attr_set = true;
     }
     // staging slab for coalesced aux rows: 8 waves x 32 rows x (aux_stride + 4) floats, when it fits next to the weights
-    uint32_t stage_stride = a->aux_stride + 4;
-    uint32_t lds = packed_bytes + (kPalThreads / 64) * 32 * stage_stride * 4;
-    if (lds > kLdsLimit || (a->aux_stride & 3u)) { stage_stride = 0; lds = packed_bytes; }
+    uint32_t stage_stride = pnr_palette_field_stages_aux(a->aux_stride, pp.pred_clip) ? a->aux_stride + 4 : 0;
+    const uint32_t lds = packed_bytes + (kPalThreads / 64) * 32 * stage_stride * 4;
+    const bool fuse = a->ctl && a->rays_alive && a->weights_sum && a->aux_map;
     hipLaunchKernelGGL(k_palette_field_fwd, dim3(grid), dim3(kPalThreads), lds, as_stream(stream), static_cast<const FrameCtlView*>(a->ctl), a->B,
                        a->enc, a->enc_palette, a->enc_clip, a->level_stride, a->dirs, a->deltas, static_cast<const unsigned char*>(a->packed), packed_bytes, pp,
-                       a->sigmas, a->rgbs, a->aux, stage_stride);
+                       a->sigmas, a->rgbs, a->aux, stage_stride, fuse ? a->rays_alive : nullptr, fuse ? a->weights_sum : nullptr,
+                       fuse ? a->aux_map : nullptr);
     return check_launch();
 }
 
