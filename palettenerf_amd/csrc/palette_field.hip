@@ -77,8 +77,10 @@ __device__ __forceinline__ f32x16 elu16(f32x16 v) {
     for (int i = 0; i < 16; i++) v[i] = v[i] > 0.0f ? v[i] : __expf(v[i]) - 1.0f;  // F.elu, alpha 1
     return v;
 }
-__device__ __forceinline__ void load_enc_blocks(const float* __restrict__ enc, size_t level_stride, uint32_t row, bool valid, int h, h8 bh[2], h8 bl[2]) {
-    float x[2][8];
+// the 8 encoder rows of a lane (levels 4h..4h+3 and 8+4h..8+4h+3), raw: issued at the top of a tile for every table so that the
+// loads of the later networks are in flight while the earlier ones compute (the workgroup has registers to spare: LDS, not VGPRs,
+// limits it to two waves per SIMD)
+__device__ __forceinline__ void load_enc_raw(const float* __restrict__ enc, size_t level_stride, uint32_t row, bool valid, int h, float x[2][8]) {
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
 #pragma unroll
@@ -87,6 +89,10 @@ __device__ __forceinline__ void load_enc_blocks(const float* __restrict__ enc, s
             const float2 v = valid ? *reinterpret_cast<const float2*>(enc + ((size_t)level * level_stride + row) * 2) : make_float2(0.0f, 0.0f);
             x[kb][2 * q] = v.x; x[kb][2 * q + 1] = v.y;
         }
+}
+__device__ __forceinline__ void load_enc_blocks(const float* __restrict__ enc, size_t level_stride, uint32_t row, bool valid, int h, h8 bh[2], h8 bl[2]) {
+    float x[2][8];
+    load_enc_raw(enc, level_stride, row, valid, h, x);
     split8(x[0], bh[0], bl[0]);
     split8(x[1], bh[1], bl[1]);
 }
@@ -140,8 +146,16 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
         const uint32_t row = n < B ? n : (B - 1);
         h8 bh[2], bl[2];
 
+        // all global reads of the tile up front
+        float xs[2][8], xp[2][8];
+        load_enc_raw(enc, level_stride, row, valid, h, xs);
+        load_enc_raw(enc_pal, level_stride, row, valid, h, xp);
+        float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+        if (valid) { dx = dirs[(size_t)row * 3]; dy = dirs[(size_t)row * 3 + 1]; dz = dirs[(size_t)row * 3 + 2]; }
+
         // ---------------- sigma_net
-        load_enc_blocks(enc, level_stride, row, valid, h, bh, bl);
+        split8(xs[0], bh[0], bl[0]);
+        split8(xs[1], bh[1], bl[1]);
         f32x16 t0 = zero16(), t1 = zero16();
         t0 = mma3(t0, w + (PB_S0 + 0) * kF16BlockBytes, bh[0], bl[0], lane);
         t0 = mma3(t0, w + (PB_S0 + 1) * kF16BlockBytes, bh[1], bl[1], lane);
@@ -166,8 +180,6 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
         const float diffuse[3] = {sigmoidf(dif[0]), sigmoidf(dif[1]), sigmoidf(dif[2])};
 
         // ---------------- color_net (view dependent): [SH16 ; geo15] -> 64 -> 64 -> 3
-        float dx = 0.0f, dy = 0.0f, dz = 0.0f;
-        if (valid) { dx = dirs[(size_t)row * 3]; dy = dirs[(size_t)row * 3 + 1]; dz = dirs[(size_t)row * 3 + 2]; }
         {
             float sh[16], v[8];
             sh_eval<4>(dx, dy, dz, sh);
@@ -188,7 +200,8 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
         const float view_dep[3] = {sigmoidf(vdt[0]), sigmoidf(vdt[1]), sigmoidf(vdt[2])};
 
         // ---------------- basis_net: [enc_palette(32) ; diffuse(3)] -> 64 (ELU) -> 15
-        load_enc_blocks(enc_pal, level_stride, row, valid, h, bh, bl);
+        split8(xp[0], bh[0], bl[0]);
+        split8(xp[1], bh[1], bl[1]);
         h8 dh, dl;
         {
             float v[8] = {diffuse[0], diffuse[1], diffuse[2], 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // read by the lower half-wave only (zero weights elsewhere)
