@@ -45,6 +45,9 @@ typedef void* pnr_stream_t; /* hipStream_t */
 const char* pnr_error_string(int code);
 /* ABI version of this header; bumped on any signature change. */
 int pnr_abi_version(void);
+/* run-time switches that change speed only, for A/B measurements and tests: "block_skip" (exact jumps over empty blocks in the march),
+ * "aux_fusion" (PaletteNeRF frame loop: aux composite inside the field kernel); both default to 1 */
+int pnr_set_option(const char* name, int value);
 
 /* ---------------------------------------------------------------- raymarching: utils ------- */
 
@@ -274,10 +277,12 @@ typedef struct pnr_palette_field_args {
     float* aux;                    /* [B, aux_stride] = direct_rgb 3 | view_dep 3 | omega nb | basis_rgb 3nb | unscaled 3nb | clip | 0 pad */
     /* frame loop only (ctl != NULL), all three or none: in iterations with one sample per ray (ctl->n_step == 1) the aux row is
      * composited straight into aux_map (aux_map[ray] += weight * row, the arithmetic of composite_rays_flex) instead of being written
-     * to `aux` and read back by the composite launch -- when the kernel can stage the tile in LDS (pnr_palette_field_stages_aux) */
+     * to `aux` and read back by the composite launch -- when the kernel can stage the tile in LDS (pnr_palette_field_stages_aux);
+     * likewise with 2, 4 or 8 samples per ray (a ray's rows then sit in one 32-row tile) */
     const int32_t* rays_alive;     /* [n_alive] ray id of every slot */
     const float* weights_sum;      /* [N] of BEFORE this iteration */
     float* aux_map;                /* [N, aux_stride] */
+    float T_thresh;                /* early-termination threshold of the composite (frame loop only) */
 } pnr_palette_field_args;
 int pnr_palette_field_stages_aux(uint32_t aux_stride, int pred_clip);   /* 1 when the field kernel stages aux rows in LDS (then it can composite them) */
 uint64_t pnr_palette_field_packed_bytes(int pred_clip);

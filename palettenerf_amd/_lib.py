@@ -13,6 +13,7 @@ _u32, _f32, _int, _ptr, _u64 = ctypes.c_uint32, ctypes.c_float, ctypes.c_int, ct
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/pnr.h one to one
 SIGNATURES = {
     "pnr_abi_version": [],
+    "pnr_set_option": [ctypes.c_char_p, _int],
     "pnr_error_string": [_int],
     "pnr_scan_scratch_bytes": [_u32],
     "pnr_near_far_from_aabb": [_ptr, _ptr, _ptr, _u32, _f32, _ptr, _ptr, _ptr],
@@ -91,7 +92,7 @@ class PaletteFieldArgs(ctypes.Structure):
     _fields_ = [("ctl", _ptr), ("B", _u32), ("enc", _ptr), ("enc_palette", _ptr), ("enc_clip", _ptr), ("level_stride", _u32), ("dirs", _ptr),
                 ("deltas", _ptr), ("packed", _ptr), ("basis_color", _ptr), ("or_bias", _ptr), ("num_basis", _u32), ("clip_dim", _u32),
                 ("pred_clip", _int), ("density_scale", _f32), ("offsets_weight", _f32), ("view_dep_weight", _f32), ("aux_stride", _u32),
-                ("sigmas", _ptr), ("rgbs", _ptr), ("aux", _ptr), ("rays_alive", _ptr), ("weights_sum", _ptr), ("aux_map", _ptr)]
+                ("sigmas", _ptr), ("rgbs", _ptr), ("aux", _ptr), ("rays_alive", _ptr), ("weights_sum", _ptr), ("aux_map", _ptr), ("T_thresh", _f32)]
 
 
 _lib = None

@@ -16,6 +16,7 @@
 #include "grid_core.hpp"
 #include "field_core.hpp"
 #include <vector>
+#include <stdlib.h>
 
 namespace pnr {
 
@@ -359,7 +360,7 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_composite(const FrameCtl* _
     const uint32_t nchunks = (n_alive + kRayBlock - 1) / kRayBlock;
     __shared__ int wsum[kRayBlock / PNR_WAVE];
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        if (aux && !(aux_done_when_one_step && n_step == 1)) {   // with one sample per ray the palette field kernel has composited the row itself
+        if (aux && !(aux_done_when_one_step && n_step <= 8 && (32 % n_step) == 0)) {   // with 1, 2, 4 or 8 samples per ray the palette field kernel has composited the rows itself
             // Phase 1 (palette): the packed aux row.  aux_stride / 4 lanes per ray, one float4 of channels per lane: a ray's row is one
             // coalesced 208-byte read per sample and per map instead of a 208-byte-strided walk by a single thread.  Every
             // lane re-derives the (cheap) weights; they start from the weights_sum of BEFORE this iteration because phase 2,
@@ -597,7 +598,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     gs.table[1] = pal ? pal->embeddings_palette : nullptr; gs.enc[1] = w.enc_pal;
     gs.table[2] = with_clip ? pal->embeddings_clip : nullptr; gs.enc[2] = w.enc_clip;
     const uint32_t n_enc = pal ? (with_clip ? 3u : 2u) : 1u;
-    const int aux_fused = (pal && pnr_palette_field_stages_aux(aux_stride, pal->pred_clip)) ? 1 : 0;
+    const int aux_fused = (pal && g_opt_aux_fusion && pnr_palette_field_stages_aux(aux_stride, pal->pred_clip)) ? 1 : 0;
     const float4* pair_table = (pal && !with_clip && pal->embeddings_pair) ? reinterpret_cast<const float4*>(pal->embeddings_pair) : nullptr;
     pnr_palette_field_args pf = {};
     if (pal) {
@@ -664,7 +665,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             if (e1) (void)hipEventRecord(e1, s);
             if (pal) {
                 pf.ctl = cur; pf.B = rows_ub;
-                if (aux_fused) { pf.rays_alive = alive_in; pf.weights_sum = out_ws; pf.aux_map = out_aux; }
+                if (aux_fused) { pf.rays_alive = alive_in; pf.weights_sum = out_ws; pf.aux_map = out_aux; pf.T_thresh = a->T_thresh; }
                 const int rc = pnr_palette_field_forward(&pf, stream);
                 if (rc != PNR_OK) return rc;
             } else if (a->field_precision == PNR_FIELD_FP32)

@@ -57,8 +57,7 @@ static MarchParams make_march_params(float bound, float dt_gamma, uint32_t max_s
     p.dt_max = two_sqrt3 * (float)(1 << (C - 1)) / (float)H;        // :349
     p.C = C; p.H = H; p.max_steps = max_steps;
     p.mip_words = with_mip ? (uint32_t)(((uint64_t)C * H * H * H / 64 + 31) / 32) : 0;
-    static const bool no_block_skip = getenv("PNR_NO_BLOCK_SKIP") != nullptr;
-    p.block_skip = no_block_skip ? 0u : 1u;
+    p.block_skip = g_opt_block_skip ? 1u : 0u;
     return p;
 }
 static inline bool is_pow2f(float v) {

@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
                                                                    uint32_t packed_bytes, PaletteParams pp, float* __restrict__ sigmas,
                                                                    float* __restrict__ rgbs, float* __restrict__ aux, uint32_t stage_stride,
                                                                    const int32_t* __restrict__ rays_alive, const float* __restrict__ weights_sum,
-                                                                   float* __restrict__ aux_map) {
+                                                                   float* __restrict__ aux_map, float T_thresh) {
     if (ctl && ctl->done) return;
     const uint32_t B = ctl ? (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step : B_arg;
     const uint32_t ntiles = (B + 255) / 256;
@@ -138,7 +138,10 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     const int nb = pp.nb;
-    const bool fuse_composite = stage_stride && ctl && aux_map && ctl->n_step == 1;
+    // rows of a ray are consecutive; with 1, 2, 4 or 8 samples per ray they sit inside one 32-row wave tile and the aux composite
+    // can run here (fstep = samples per ray), otherwise the composite launch does it
+    const uint32_t fstep = (stage_stride && ctl && aux_map && ctl->n_step <= 8 && (32 % ctl->n_step) == 0) ? (uint32_t)ctl->n_step : 0u;
+    const bool fuse_composite = fstep != 0;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t n = tile * 256 + wave * 32 + (lane & 31);
         const bool valid = n < B && (!deltas || deltas[(size_t)(n < B ? n : 0) * 2] != 0.0f);
@@ -275,32 +278,59 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
             for (c += pp.clip_dim; c < pp.aux_stride; c++) a[c] = 0.0f;
             const float sigma = pp.density_scale * __expf(sigma_logit);
             sigmas[n] = sigma;
-            if (fuse_composite) {   // one sample per ray: slot n is ray rays_alive[n]; the weight exactly as k_frame_composite forms it
-                const int index = rays_alive[n];
-                const float alpha = 1.0f - __expf(-sigma * deltas[(size_t)n * 2]);
-                a[pp.aux_stride] = alpha * (1.0f - weights_sum[index]);
-                a[pp.aux_stride + 1] = __int_as_float(index);
-            }
+            if (fuse_composite) a[pp.aux_stride] = 1.0f - __expf(-sigma * deltas[(size_t)n * 2]);   // alpha, exactly as k_frame_composite forms it
 #pragma unroll
             for (int k = 0; k < 3; k++) rgbs[(size_t)n * 3 + k] = rgb[k] + pp.view_dep_weight * view_dep[k];
         }
         if (stage_stride) {   // same wave wrote the slab: DS operations of a wave complete in order
-            const float* slab = reinterpret_cast<const float*>(w + packed_bytes) + (size_t)wave * 32 * stage_stride;
-            const uint32_t n0 = tile * 256 + wave * 32, nq = (uint32_t)pp.aux_stride / 4;
+            float* slab = reinterpret_cast<float*>(w + packed_bytes) + (size_t)wave * 32 * stage_stride;
+            const uint32_t n0 = tile * 256 + wave * 32, nq = (uint32_t)pp.aux_stride / 4, S = (uint32_t)pp.aux_stride;
             const unsigned long long live = __ballot(valid && h == 0);     // rows of dead / out-of-range slots hold stale slab data: skip them
-            for (uint32_t i = (uint32_t)lane; i < 32 * nq; i += 64) {
-                const uint32_t row = i / nq, q = i - row * nq;
-                if (!((live >> row) & 1ull)) continue;
-                const float4 v = *reinterpret_cast<const float4*>(slab + row * stage_stride + q * 4);
-                if (fuse_composite) {   // aux_map[ray] += weight * row (raymarching.cu:1114-1185 with n_step == 1), no round trip through `aux`
-                    const float wgt = slab[row * stage_stride + pp.aux_stride];
-                    const int index = __float_as_int(slab[row * stage_stride + pp.aux_stride + 1]);
+            if (fuse_composite) {
+                // aux_map[ray] += sum_k weight_k * row_k: the recurrence of raymarching.cu:1114-1185 (weights from the weights_sum of
+                // BEFORE this iteration, stop at a dead row, stop after the sample that sees T < T_thresh), same fmaf order.
+                // Leader lane of a ray: weights of its rows, how many count, and the ray id, left in the slab's spare columns.
+                if (lane < 32 && (lane % fstep) == 0) {
+                    const uint32_t slot = (n0 + lane) / fstep;
+                    int cnt = 0, index = 0;
+                    if (slot < (uint32_t)ctl->n_alive && ((live >> lane) & 1ull)) {
+                        index = rays_alive[slot];
+                        float ws = weights_sum[index];
+                        for (uint32_t k = 0; k < fstep; k++) {
+                            if (!((live >> (lane + k)) & 1ull)) break;
+                            float* r = slab + (lane + k) * stage_stride;
+                            const float T = 1.0f - ws;
+                            const float wgt = r[S] * T;
+                            ws += wgt;
+                            r[S] = wgt;
+                            cnt++;
+                            if (T < T_thresh) break;
+                        }
+                    }
+                    slab[lane * stage_stride + S + 1] = __int_as_float(index);
+                    slab[lane * stage_stride + S + 2] = __int_as_float(cnt);
+                }
+                const uint32_t rays_in_tile = 32 / fstep;
+                for (uint32_t i = (uint32_t)lane; i < rays_in_tile * nq; i += 64) {
+                    const uint32_t ray = i / nq, q = i - ray * nq, base = ray * fstep;
+                    const int cnt = __float_as_int(slab[base * stage_stride + S + 2]);
+                    if (cnt == 0) continue;
+                    const int index = __float_as_int(slab[base * stage_stride + S + 1]);
                     float4* dst = reinterpret_cast<float4*>(aux_map + (size_t)index * pp.aux_stride) + q;
                     float4 acc = *dst;
-                    acc.x = fmaf(wgt, v.x, acc.x); acc.y = fmaf(wgt, v.y, acc.y); acc.z = fmaf(wgt, v.z, acc.z); acc.w = fmaf(wgt, v.w, acc.w);
+                    for (int k = 0; k < cnt; k++) {
+                        const float* r = slab + (base + k) * stage_stride;
+                        const float wgt = r[S];
+                        const float4 v = *reinterpret_cast<const float4*>(r + q * 4);
+                        acc.x = fmaf(wgt, v.x, acc.x); acc.y = fmaf(wgt, v.y, acc.y); acc.z = fmaf(wgt, v.z, acc.z); acc.w = fmaf(wgt, v.w, acc.w);
+                    }
                     *dst = acc;
-                } else {
-                    *reinterpret_cast<float4*>(aux + (size_t)(n0 + row) * pp.aux_stride + q * 4) = v;
+                }
+            } else {
+                for (uint32_t i = (uint32_t)lane; i < 32 * nq; i += 64) {
+                    const uint32_t row = i / nq, q = i - row * nq;
+                    if ((live >> row) & 1ull)
+                        *reinterpret_cast<float4*>(aux + (size_t)(n0 + row) * pp.aux_stride + q * 4) = *reinterpret_cast<const float4*>(slab + row * stage_stride + q * 4);
                 }
             }
         }
@@ -387,7 +417,7 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
     hipLaunchKernelGGL(k_palette_field_fwd, dim3(grid), dim3(kPalThreads), lds, as_stream(stream), static_cast<const FrameCtlView*>(a->ctl), a->B,
                        a->enc, a->enc_palette, a->enc_clip, a->level_stride, a->dirs, a->deltas, static_cast<const unsigned char*>(a->packed), packed_bytes, pp,
                        a->sigmas, a->rgbs, a->aux, stage_stride, fuse ? a->rays_alive : nullptr, fuse ? a->weights_sum : nullptr,
-                       fuse ? a->aux_map : nullptr);
+                       fuse ? a->aux_map : nullptr, a->T_thresh);
     return check_launch();
 }
 

@@ -401,11 +401,21 @@ __global__ void __launch_bounds__(kBlock) k_get_rays(const float* __restrict__ p
 // ==========================================================================================
 // C ABI
 // ==========================================================================================
+int g_opt_block_skip = getenv("PNR_NO_BLOCK_SKIP") ? 0 : 1;
+int g_opt_aux_fusion = getenv("PNR_NO_AUX_FUSION") ? 0 : 1;
+
 using namespace pnr;
 
 extern "C" {
 
 int pnr_abi_version(void) { return 1; }
+
+int pnr_set_option(const char* name, int value) {
+    if (!name) return PNR_ERR_INVALID;
+    if (!strcmp(name, "block_skip")) { g_opt_block_skip = value != 0; return PNR_OK; }
+    if (!strcmp(name, "aux_fusion")) { g_opt_aux_fusion = value != 0; return PNR_OK; }
+    return PNR_ERR_INVALID;
+}
 
 const char* pnr_error_string(int code) {
     switch (code) {
