@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--ray-order", choices=["tile8", "tile4", "tile16", "morton", "rowmajor"], default="tile8", help="initial order of the alive list in the native loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--half-tables", action="store_true", help="native loop with fp16 hash tables and the reference's half interpolation (its --fp16 tables); MLP unchanged")
     ap.add_argument("--scene", choices=["s0", "s1"], default="s0", help="s0: dense 8^3 bricks (the headline scene); s1: sparse 4^3 bricks, the occupied box ~94 %% air")
     ap.add_argument("--dt-gamma", type=float, default=0.0, help="march step growth (0 = the lego config; 1/128 = the LLFF / 360 configs)")
     ap.add_argument("--cpu-crop", type=int, default=480, help="side of the centre crop timed on the CPU oracle")
@@ -180,6 +181,7 @@ def main():
         if getattr(m, "_fused", None) is None:
             from palettenerf_amd.fused import PaletteFieldFused
             m._fused = PaletteFieldFused(m)
+        m._fused.table_half = bool(args.half_tables)
         m._fused.ray_order = tile_ray_order(idx, W, {"tile8": 8, "tile4": 4, "tile16": 16, "morton": 0}[args.ray_order]).to(device)   # idx: row-major pixel ids (of the stacked views) this rank renders
         for _ in range(2):
             frame()                                               # re-warm with the final ordering
@@ -231,6 +233,8 @@ def main():
 
     if rank == 0:
         per_sample = GRID_BYTES_PER_SAMPLE_FP16 if args.fp16 else GRID_BYTES_PER_SAMPLE_FP32
+        if args.half_tables:
+            per_sample = 12 + 16 * 8 * 2 * 2 + 32 * 4   # half rows gathered, fp32 encoder output written
         n_tables = 1 if args.model == "nerf" else 2  # palette: encoder + encoder_palette (pred_clip off in the bench config)
         launches = prof["pnr_grid_encode_forward"]
         k_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in launches)
@@ -243,7 +247,7 @@ def main():
         achieved = (k_units * per_sample) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic = None  # HBM-side bytes per launch from the committed PMC passes of this exact workload (profiles/r01_traffic.json)
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if m.march_mode == "native" and H == 800 and args.density_scale == 100.0 and not args.fp16 and world == 1 and os.path.exists(tpath):
+        if m.march_mode == "native" and H == 800 and args.density_scale == 100.0 and not args.fp16 and not args.half_tables and world == 1 and os.path.exists(tpath):
             t = json.load(open(tpath)).get(args.model)
             if t:
                 pair = args.model == "palette"   # the interleaved pair kernel is ONE launch for both tables
@@ -258,7 +262,7 @@ def main():
             "vs_baseline": None, "dtype": "f16" if args.fp16 else "f32", "data": "synthetic",
             "config": {"workload": f"configs[{1 if args.model == 'nerf' else 2}]: NeRF-synthetic lego geometry (scene {args.scene.upper()}), -m {args.model} inference, {H}x{W}, {n_views} view(s)/step",
                        "rays_per_step": n_views * H * W, "rendered_samples_per_step": total_rendered // args.steps,
-                       "evaluated_rows_per_step_rank0": rows // args.steps, "density_scale": args.density_scale, "dt_gamma": args.dt_gamma, "march_mode": m.march_mode, "fused_field": bool(getattr(m, "fused_field", False)), "field_precision": args.field_precision, "ray_order": args.ray_order,
+                       "evaluated_rows_per_step_rank0": rows // args.steps, "density_scale": args.density_scale, "dt_gamma": args.dt_gamma, "march_mode": m.march_mode, "fused_field": bool(getattr(m, "fused_field", False)), "field_precision": args.field_precision, "half_tables": bool(args.half_tables), "ray_order": args.ray_order,
                        "parallelism": f"32x32 ray tiles of {n_views} view(s) round-robin over {world} GPUs + one all_gather/step" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": n_launches,

@@ -214,6 +214,9 @@ typedef struct pnr_nerf_frame_args {
                                       (same fp32 operations, in the same order, as the reference's torch expressions) */
     float bg_color[3];             /* used when finish != 0 and bg_map == NULL (the reference's default is 1) */
     const float* bg_map;           /* optional per-ray background [N,3] (device) for finish */
+    int table_dtype;               /* PNR_DTYPE_F32 (default) or PNR_DTYPE_F16: the reference's --fp16 tables (`embeddings` then points to halves;
+                                      PaletteNeRF: embeddings_pair = both tables as interleaved halves, required, no clip head).  The lookup
+                                      then reproduces the reference's half interpolation (as pnr_grid_encode_forward with dtype 1) */
 } pnr_nerf_frame_args;
 uint64_t pnr_nerf_frame_workspace_bytes(uint32_t N);
 int pnr_nerf_render_frame(const pnr_nerf_frame_args* args, pnr_stream_t stream);

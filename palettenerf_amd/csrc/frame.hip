@@ -243,6 +243,68 @@ __global__ void __launch_bounds__(256) k_frame_grid(const FrameCtl* __restrict__
     }
 }
 
+// fp16 tables (the reference's -O / --fp16 mode: `embeddings.to(torch.half)`, gridencoder/grid.py:38): NT tables interleaved row by
+// row, a row = NT x half2 (4 or 8 bytes).  Interpolation with the reference's half accumulator -- every addend and every partial
+// sum rounded to fp16 (gridencoder.cu:142,165 with scalar_t = at::Half) -- so the encoder output equals k_grid_fwd<__half>'s bit
+// for bit; it is handed to the field kernel as fp32 (exact).
+template <int NT>
+__global__ void __launch_bounds__(256) k_frame_grid_h(const FrameCtl* __restrict__ ctl, const float* __restrict__ xyzs, const float* __restrict__ deltas,
+                                                      const __half* __restrict__ table, float* __restrict__ enc_a, float* __restrict__ enc_b,
+                                                      const int32_t* __restrict__ offsets, LevelParams lp, uint32_t level_stride, float bound,
+                                                      float two_bound, uint32_t gridtype) {
+    if (ctl->done) return;
+    const uint32_t rows = (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step;
+    const uint32_t level = blockIdx.y;
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    const __half* g = table + (size_t)off0 * 2 * NT;
+    const float scale = lp.scale[level];
+    const uint32_t resolution = lp.resolution[level];
+    for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < rows; b += gridDim.x * 256) {
+        if (deltas[(size_t)b * 2] == 0.0f) continue;
+        float in[3];
+        bool oob = false;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            in[d] = (xyzs[(size_t)b * 3 + d] + bound) / two_bound;
+            oob |= (in[d] < 0.0f) | (in[d] > 1.0f);
+        }
+        __half acc[2 * NT];
+#pragma unroll
+        for (int ch = 0; ch < 2 * NT; ch++) acc[ch] = __float2half(0.0f);
+        if (!oob) {
+            float pos[3];
+            uint32_t pg[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                pos[d] = fmaf(in[d], scale, 0.5f);
+                const float fl = floorf(pos[d]);
+                pg[d] = (uint32_t)fl;
+                pos[d] -= (float)pg[d];
+            }
+            uint32_t idxs[8];
+            float ws[8];
+#pragma unroll
+            for (uint32_t idx = 0; idx < 8; idx++) {
+                float w = 1.0f;
+                uint32_t pl[3];
+#pragma unroll
+                for (uint32_t d = 0; d < 3; d++) {
+                    if ((idx & (1u << d)) == 0) { w *= 1.0f - pos[d]; pl[d] = pg[d]; }
+                    else { w *= pos[d]; pl[d] = pg[d] + 1; }
+                }
+                ws[idx] = w;
+                idxs[idx] = grid_index<3, 1>(gridtype, false, hashmap_size, resolution, pl);
+            }
+#pragma unroll
+            for (uint32_t idx = 0; idx < 8; idx++) corner_accumulate<2 * NT>(acc, ws[idx], g + (size_t)idxs[idx] * 2 * NT);
+        }
+        *reinterpret_cast<float2*>(enc_a + ((size_t)level * level_stride + b) * 2) = make_float2(__half2float(acc[0]), __half2float(acc[1]));
+        if constexpr (NT == 2)
+            *reinterpret_cast<float2*>(enc_b + ((size_t)level * level_stride + b) * 2) = make_float2(__half2float(acc[2]), __half2float(acc[3]));
+    }
+}
+
 // Two hash tables with one level layout (PaletteNeRF's `encoder` and `encoder_palette` are looked up at the same positions)
 // interleaved row by row -- (a.x, a.y, b.x, b.y) = 16 bytes per index: one gather fetches both tables' rows, so the lookup of
 // the pair costs the lane requests and L2->L1 line fills of ONE table.  Same corner order and fmaf chains as two separate
@@ -599,7 +661,10 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     gs.table[2] = with_clip ? pal->embeddings_clip : nullptr; gs.enc[2] = w.enc_clip;
     const uint32_t n_enc = pal ? (with_clip ? 3u : 2u) : 1u;
     const int aux_fused = (pal && g_opt_aux_fusion && pnr_palette_field_stages_aux(aux_stride, pal->pred_clip)) ? 1 : 0;
-    const float4* pair_table = (pal && !with_clip && pal->embeddings_pair) ? reinterpret_cast<const float4*>(pal->embeddings_pair) : nullptr;
+    const bool half_tables = a->table_dtype == PNR_DTYPE_F16;   // fp16 tables: nerf = `embeddings` as halves; palette = embeddings_pair as interleaved halves
+    if (half_tables && pal && (with_clip || !pal->embeddings_pair)) return PNR_ERR_UNSUPPORTED;
+    if (a->table_dtype != PNR_DTYPE_F32 && a->table_dtype != PNR_DTYPE_F16) return PNR_ERR_UNSUPPORTED;
+    const float4* pair_table = (pal && !half_tables && !with_clip && pal->embeddings_pair) ? reinterpret_cast<const float4*>(pal->embeddings_pair) : nullptr;
     pnr_palette_field_args pf = {};
     if (pal) {
         pf.enc = w.enc; pf.enc_palette = w.enc_pal; pf.enc_clip = w.enc_clip; pf.level_stride = N; pf.dirs = w.dirs; pf.deltas = w.deltas;
@@ -656,7 +721,13 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             const uint32_t gx = cdiv(rows_ub, 256);
             hipEvent_t e0 = timing ? next_event() : nullptr, e1 = timing ? next_event() : nullptr;
             if (e0) (void)hipEventRecord(e0, s);
-            if (pair_table)
+            if (half_tables && pal)
+                hipLaunchKernelGGL(k_frame_grid_h<2>, dim3(gx < 1024u ? gx : 1024u, 16), dim3(256), 0, s, cur, w.xyzs, w.deltas,
+                                   reinterpret_cast<const __half*>(pal->embeddings_pair), w.enc, w.enc_pal, a->offsets, lp, N, a->bound, 2.0f * a->bound, a->gridtype);
+            else if (half_tables)
+                hipLaunchKernelGGL(k_frame_grid_h<1>, dim3(gx < 1024u ? gx : 1024u, 16), dim3(256), 0, s, cur, w.xyzs, w.deltas,
+                                   reinterpret_cast<const __half*>(a->embeddings), w.enc, (float*)nullptr, a->offsets, lp, N, a->bound, 2.0f * a->bound, a->gridtype);
+            else if (pair_table)
                 hipLaunchKernelGGL(k_frame_grid_pair, dim3(gx < 1024u ? gx : 1024u, 16), dim3(256), 0, s, cur, w.xyzs, w.deltas, pair_table, w.enc, w.enc_pal,
                                    a->offsets, lp, N, a->bound, 2.0f * a->bound, a->gridtype);
             else
@@ -706,7 +777,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) total += ms;
         }
         a->kernel_ms[0] = total;
-        a->kernel_ms[1] = (float)counted * (pair_table ? 1.0f : (float)n_enc);  // a k_frame_grid launch covers n_enc tables (count table-launches); the pair kernel is one launch for both
+        a->kernel_ms[1] = (float)counted * ((pair_table || half_tables) ? 1.0f : (float)n_enc);  // a k_frame_grid launch covers n_enc tables (count table-launches); the pair kernel is one launch for both
     }
     if (a->stats) {
         a->stats[0] = (uint64_t)host_ctl->iterations;

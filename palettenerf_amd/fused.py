@@ -38,6 +38,16 @@ def tile_ray_order(pixel_index, W, tile=8):
     return torch.argsort(key).to(torch.int32)
 
 
+def _half_copy(owner, attr, t):
+    """fp16 copy of a table, cached on `owner` until the table changes (data pointer / version)."""
+    key = (t.data_ptr(), t._version)
+    cached = getattr(owner, attr, None)
+    if cached is None or cached[0] != key:
+        cached = (key, t.to(torch.float16).contiguous())
+        setattr(owner, attr, cached)
+    return cached[1]
+
+
 def _set_finish(a, bg_color, N, mask):
     """Fill the finish / bg fields of a frame-args struct; returns True when the call will apply the epilogue."""
     a.finish, a.bg_map = 0, None
@@ -72,6 +82,7 @@ class NeRFFieldFused:
         self.versions = None
         self.precision = 1  # PNR_FIELD_F16X3 (split-fp16 matrix path, ~2^-22 relative); 0 = PNR_FIELD_FP32 (exact fmaf chains)
         self.time_grid_kernel = False  # bench.py: HIP-event timing of the grid-encode launches inside the native frame loop
+        self.table_half = False        # native loop: look the hash table up as fp16 with the reference's half interpolation (its --fp16 mode)
         m = model
         ok = (m.encoder.num_levels == 16 and m.encoder.level_dim == 2 and m.encoder.input_dim == 3 and m.hidden_dim == 64 and m.geo_feat_dim == 15
               and m.num_layers == 2 and m.num_layers_color == 3 and m.hidden_dim_color == 64 and m.encoder_dir.degree == 4)
@@ -114,8 +125,11 @@ class NeRFFieldFused:
         mip = raymarching.occupancy_mip(m.density_bitfield, m.cascade, m.grid_size, m.bound)
         enc = m.encoder
         emb = require(enc.embeddings.detach(), torch.float32, "embeddings")
+        if self.table_half:   # the reference's --fp16 tables (`embeddings.to(torch.half)` per forward, gridencoder/grid.py:38): converted once per update here
+            emb = _half_copy(self, "_emb_half", emb)
         stats = (ctypes.c_uint64 * 4)()
         a = _lib.NerfFrameArgs()
+        a.table_dtype = 1 if self.table_half else 0
         a.N = N
         a.rays_o, a.rays_d = rays_o.data_ptr(), rays_d.data_ptr()
         a.nears, a.fars = nears.data_ptr(), fars.data_ptr()
@@ -174,6 +188,7 @@ class PaletteFieldFused:
         # happens, so those channels are left out of the packed aux row (52 -> 36 floats per sample for 4 bases) and returned as zeros
         self.clip_dim = int(m.opt.clip_dim) if self.pred_clip else 0
         self.interleave_tables = True   # native loop: look both hash tables up through one interleaved copy (see _pair_table)
+        self.table_half = False         # native loop: fp16 tables with the reference's half interpolation (its --fp16 mode; no clip head)
         self.aux_channels = int(_lib.load().pnr_palette_aux_channels(self.nb, self.clip_dim))
 
     def _weights(self):
@@ -223,10 +238,13 @@ class PaletteFieldFused:
         a, b = m.encoder.embeddings.detach(), m.encoder_palette.embeddings.detach()
         if a.dtype != torch.float32 or b.dtype != torch.float32 or a.shape != b.shape or a.shape[1] != 2:
             return None
-        key = (a.data_ptr(), a._version, b.data_ptr(), b._version)
+        key = (a.data_ptr(), a._version, b.data_ptr(), b._version, bool(self.table_half))
         if getattr(self, "_pair_key", None) != key:
-            out = torch.empty(a.shape[0], 4, dtype=torch.float32, device=a.device)
-            call("pnr_interleave_tables", ptr(a.contiguous()), ptr(b.contiguous()), ctypes.c_uint64(a.shape[0]), ptr(out))
+            if self.table_half:   # rows of 4 halves: (a.x, a.y, b.x, b.y)
+                out = torch.cat([a.to(torch.float16), b.to(torch.float16)], dim=1).contiguous()
+            else:
+                out = torch.empty(a.shape[0], 4, dtype=torch.float32, device=a.device)
+                call("pnr_interleave_tables", ptr(a.contiguous()), ptr(b.contiguous()), ctypes.c_uint64(a.shape[0]), ptr(out))
             self._pair, self._pair_key = out, key
         return self._pair
 
@@ -280,8 +298,11 @@ class PaletteFieldFused:
         p.num_basis, p.clip_dim, p.pred_clip = self.nb, self.clip_dim, int(self.pred_clip)
         p.offsets_weight, p.view_dep_weight = float(m.offsets_weight), float(m.view_dep_weight)
         p.aux_map = aux_map.data_ptr()
-        pair = self._pair_table() if (self.interleave_tables and not self.pred_clip) else None
+        if self.table_half and self.pred_clip:
+            raise RuntimeError("fp16 tables in the native PaletteNeRF loop need the interleaved pair table (no clip head)")
+        pair = self._pair_table() if ((self.interleave_tables or self.table_half) and not self.pred_clip) else None
         p.embeddings_pair = pair.data_ptr() if pair is not None else None
+        a.table_dtype = 1 if self.table_half else 0
         for t, name in ((rays_o, "rays_o"), (rays_d, "rays_d"), (nears, "nears"), (fars, "fars")):
             require(t, torch.float32, name)
         rc = lib.pnr_palette_render_frame(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))

@@ -359,3 +359,35 @@ def test_palette_aux_fusion_is_bit_identical(cuda):
     finally:
         lib.pnr_set_option(b"aux_fusion", 1)
     assert lib.pnr_set_option(b"no_such_option", 1) != 0
+
+
+@pytest.mark.parametrize("model_kind", ["nerf", "palette"])
+def test_native_loop_half_tables_track_the_fp32_frame(cuda, model_kind):
+    """table_half: the native loop looks the hash tables up as fp16 with the reference's half interpolation (its --fp16 mode; the lookup
+    kernel shares corner_accumulate<__half> with pnr_grid_encode_forward, which is bit-exact against the oracle).  The frame must
+    stay within fp16 rounding of the fp32-table frame: image 4e-3, sample count 2 %."""
+    from palettenerf_amd.fused import NeRFFieldFused, PaletteFieldFused
+    if model_kind == "nerf":
+        m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=30.0, min_near=0.2)
+    else:
+        m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True, density_scale=30.0, min_near=0.2)
+    scene.seed_field_(m, 13)
+    m = m.to(cuda).eval()
+    put_scene(m, cuda)
+    m.count_rendered = True
+    m.march_mode, m.fused_field = "native", True
+    m._fused = (NeRFFieldFused if model_kind == "nerf" else PaletteFieldFused)(m)
+    pose = torch.from_numpy(scene.lookat_pose())[None]
+    ro, rd = scene.get_rays(pose, scene.intrinsics_from_fov(64, 64), 64, 64)
+    ro, rd = ro.to(cuda), rd.to(cuda)
+    kw = dict(perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+    outs = []
+    for half in (False, True):
+        m._fused.table_half = half
+        with torch.no_grad():
+            outs.append(m.render(ro, rd, **kw))
+    a, b = outs
+    na, nb_ = int(a["rendered"].item()), int(b["rendered"].item())
+    assert na > 1000 and abs(na - nb_) < 0.02 * na
+    diff = (a["image"] - b["image"]).abs()
+    assert float(diff.max()) < 2e-2 and float(diff.mean()) < 4e-3 and float(diff.max()) > 0.0, (float(diff.max()), float(diff.mean()))
