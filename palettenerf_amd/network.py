@@ -61,6 +61,19 @@ class NeRFNetwork(NeRFRenderer):
         h = _run(self.sigma_net, self.encoder(x, bound=self.bound))
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
 
+    def color(self, x, d, mask=None, geo_feat=None, **kwargs):
+        """nerf/network.py:157-184 -- colour head alone, optionally only where mask is set (other rows stay 0)."""
+        if mask is not None:
+            rgbs = torch.zeros(mask.shape[0], 3, dtype=x.dtype, device=x.device)
+            if not mask.any():
+                return rgbs
+            d, geo_feat = d[mask], geo_feat[mask]
+        h = torch.sigmoid(_run(self.color_net, torch.cat([self.encoder_dir(d), geo_feat], dim=-1)))
+        if mask is None:
+            return h
+        rgbs[mask] = h.to(rgbs.dtype)
+        return rgbs
+
     def get_params(self, lr):
         """nerf/network.py:186-206"""
         return [{"params": self.encoder.parameters(), "lr": lr}, {"params": self.sigma_net.parameters(), "lr": lr},

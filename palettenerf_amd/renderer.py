@@ -32,6 +32,29 @@ def default_opt(**kw):
     return opt
 
 
+def sample_pdf(bins, weights, n_samples, det=False):
+    """Inverse-CDF sampling of the piecewise-constant density `weights` over `bins` (nerf/renderer.py:12-45, NeRF's hierarchical sampler):
+    bins [B, T], weights [B, T-1] -> [B, n_samples].  det: stratified midpoints instead of uniform random numbers."""
+    pdf = weights + 1e-5
+    pdf = pdf / pdf.sum(-1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+    lead = list(cdf.shape[:-1])
+    if det:
+        u = torch.linspace(0.5 / n_samples, 1.0 - 0.5 / n_samples, steps=n_samples).to(weights.device).expand(lead + [n_samples])
+    else:
+        u = torch.rand(lead + [n_samples]).to(weights.device)
+    u = u.contiguous()
+    hi = torch.searchsorted(cdf, u, right=True)
+    lo = (hi - 1).clamp(min=0)
+    hi = hi.clamp(max=cdf.shape[-1] - 1)
+    cdf_lo, cdf_hi = torch.gather(cdf, -1, lo), torch.gather(cdf, -1, hi)
+    bin_lo, bin_hi = torch.gather(bins, -1, lo), torch.gather(bins, -1, hi)
+    span = cdf_hi - cdf_lo
+    span = torch.where(span < 1e-5, torch.ones_like(span), span)
+    return bin_lo + (u - cdf_lo) / span * (bin_hi - bin_lo)
+
+
 class _MarchState:
     """Per-frame state of the inference loop (nerf/renderer.py:344-350)."""
 
@@ -216,10 +239,26 @@ class _RendererBase(nn.Module):
 
     def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
         """nerf/renderer.py:564-603 / palette/renderer.py:554-573 -- never staged when cuda_ray."""
-        if not self.cuda_ray:
-            raise ValueError("Pure pytorch version is not available: the reference's non-cuda_ray path is dead code "
-                             "(nerf/renderer.py:591,601; palette/renderer.py:292-294)")
-        return self.run_cuda(rays_o, rays_d, **kwargs)
+        if self.cuda_ray:
+            return self.run_cuda(rays_o, rays_d, **kwargs)
+        if not hasattr(self, "run"):
+            raise ValueError("Pure pytorch version is not available")   # palette/renderer.py:292-294
+        # Uniform-sampling path (BASELINE configs[0]).  The reference's dispatcher crashes here by accident (nerf/renderer.py:591 reads a
+        # key run() never returns, :601 passes rays_gt into num_steps); run() itself works and is what this mirrors.  Staged rendering
+        # follows nerf/renderer.py:577-589: batches of max_ray_batch rays, B == 1.
+        if not staged or self.training:
+            return self.run(rays_o, rays_d, **kwargs)
+        B, N = rays_o.shape[:2]
+        out = {"depth": torch.empty(B, N, device=rays_o.device), "image": torch.empty(B, N, 3, device=rays_o.device),
+               "weights_sum": torch.empty(B * N, device=rays_o.device)}
+        for b in range(B):
+            for head in range(0, N, max_ray_batch):
+                tail = min(head + max_ray_batch, N)
+                r = self.run(rays_o[b:b + 1, head:tail], rays_d[b:b + 1, head:tail], **kwargs)
+                out["depth"][b:b + 1, head:tail] = r["depth"]
+                out["image"][b:b + 1, head:tail] = r["image"]
+                out["weights_sum"][b * N + head:b * N + tail] = r["weights_sum"]
+        return out
 
 
 class NeRFRenderer(_OccupancyMaintenance, _RendererBase):
@@ -235,6 +274,65 @@ class NeRFRenderer(_OccupancyMaintenance, _RendererBase):
 
     def density(self, x):
         raise NotImplementedError()
+
+    def run(self, rays_o, rays_d, num_steps=128, upsample_steps=128, bg_color=None, perturb=False, **kwargs):
+        """nerf/renderer.py:127-255 -- the path without an occupancy grid: num_steps samples spread evenly over [near, far] of the box,
+        optionally upsample_steps more drawn from the coarse weights (sample_pdf), alpha compositing in torch.  Encoders and near/far are
+        the HIP ops; depth is normalised to [0, 1] over [near, far] (unlike run_cuda's)."""
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        N, device = rays_o.shape[0], rays_o.device
+        aabb = self.aabb_train if self.training else self.aabb_infer
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
+        nears, fars = nears.unsqueeze(-1), fars.unsqueeze(-1)
+        lo, hi = aabb[:3], aabb[3:]
+
+        def points(z):  # [N, T] -> [N, T, 3], clipped to the box
+            return torch.min(torch.max(rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * z.unsqueeze(-1), lo), hi)
+
+        def query(xyzs, T):
+            return {k: v.view(N, T, -1) for k, v in self.density(xyzs.reshape(-1, 3)).items()}
+
+        def ray_weights(z, sigma):  # transmittance-weighted opacities; the last interval is one uniform step long
+            deltas = torch.cat([z[..., 1:] - z[..., :-1], sample_dist * torch.ones_like(z[..., :1])], dim=-1)
+            alphas = 1 - torch.exp(-deltas * self.density_scale * sigma)
+            trans = torch.cumprod(torch.cat([torch.ones_like(alphas[..., :1]), 1 - alphas + 1e-15], dim=-1), dim=-1)[..., :-1]
+            return deltas, alphas * trans
+
+        z_vals = nears + (fars - nears) * torch.linspace(0.0, 1.0, num_steps, device=device).unsqueeze(0).expand(N, num_steps)
+        sample_dist = (fars - nears) / num_steps
+        if perturb:
+            z_vals = z_vals + (torch.rand(z_vals.shape, device=device) - 0.5) * sample_dist
+        xyzs = points(z_vals)
+        fields = query(xyzs, num_steps)
+        if upsample_steps > 0:
+            with torch.no_grad():
+                deltas, weights = ray_weights(z_vals, fields["sigma"].squeeze(-1))
+                z_mid = z_vals[..., :-1] + 0.5 * deltas[..., :-1]
+                new_z = sample_pdf(z_mid, weights[:, 1:-1], upsample_steps, det=not self.training).detach()
+                new_xyzs = points(new_z)
+            new_fields = query(new_xyzs, upsample_steps)   # only the new points go through the field again
+            z_vals, order = torch.sort(torch.cat([z_vals, new_z], dim=1), dim=1)
+            xyzs = torch.cat([xyzs, new_xyzs], dim=1)
+            xyzs = torch.gather(xyzs, 1, order.unsqueeze(-1).expand_as(xyzs))
+            for k in fields:
+                both = torch.cat([fields[k], new_fields[k]], dim=1)
+                fields[k] = torch.gather(both, 1, order.unsqueeze(-1).expand_as(both))
+        _, weights = ray_weights(z_vals, fields["sigma"].squeeze(-1))
+        dirs = rays_d.view(-1, 1, 3).expand_as(xyzs)
+        flat = {k: v.reshape(-1, v.shape[-1]) for k, v in fields.items()}
+        mask = weights > 1e-4   # the colour head only runs where a sample matters (hard-coded in the reference too)
+        rgbs = self.color(xyzs.reshape(-1, 3), dirs.reshape(-1, 3), mask=mask.reshape(-1), **flat).view(N, -1, 3)
+        weights_sum = weights.sum(dim=-1)
+        depth = torch.sum(weights * ((z_vals - nears) / (fars - nears)).clamp(0, 1), dim=-1)
+        image = torch.sum(weights.unsqueeze(-1) * rgbs, dim=-2)
+        if self.bg_radius > 0:
+            bg_color = self.background(raymarching.sph_from_ray(rays_o, rays_d, self.bg_radius), rays_d.reshape(-1, 3))
+        elif bg_color is None:
+            bg_color = 1
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "weights_sum": weights_sum}
 
     def run_cuda(self, rays_o, rays_d, rays_gt=None, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024,
                  T_thresh=1e-4, **kwargs):

@@ -198,6 +198,29 @@ def gen_frames():
         print("palette train", name, int(p.step_counter[0, 0]), float(loss))
 
 
+# ------------------------------------------------------------------------------------------ uniform-sampling path (configs[0])
+RUN_CASES = [
+    # name, H, W, num_steps, upsample_steps, density_scale, seed
+    ("a", 20, 20, 128, 128, 1.0, 0),     # nerf/renderer.py:127 defaults
+    ("b", 16, 12, 512, 0, 0.05, 1),      # main_nerf.py:31-32 (--num_steps 512 --upsample_steps 0), translucent field
+]
+
+
+def gen_run():
+    """NeRFRenderer.run (nerf/renderer.py:127-255) of the reference as it is, cuda_ray=False, eval mode (deterministic upsampling)."""
+    ref_nerf, _, _ = import_reference()
+    for name, H, W, ns, us, dscale, seed in RUN_CASES:
+        ro, rd = frame_inputs(H, W)
+        m = ref_nerf.NeRFNetwork(bound=2, cuda_ray=False, density_scale=dscale, min_near=0.2)
+        scene.seed_field_(m, seed)
+        m.eval()
+        with torch.no_grad():
+            r = m.run(ro, rd, num_steps=ns, upsample_steps=us, bg_color=None, perturb=False)
+        np.savez_compressed(os.path.join(HERE, f"run_nerf_{name}.npz"), H=H, W=W, num_steps=ns, upsample_steps=us, density_scale=dscale, seed=seed,
+                            image=r["image"].numpy(), depth=r["depth"].numpy(), weights_sum=r["weights_sum"].numpy())
+        print("run", name, float(r["weights_sum"].mean()), float(r["image"].mean()), float(r["depth"].mean()))
+
+
 # ------------------------------------------------------------------------------------------ get_rays / checkpoint layout
 def _reference_get_rays():
     """nerf/utils.py:get_rays as it is (function body executed from the reference file; its module imports cv2, tensorboardX, ...,
@@ -255,6 +278,8 @@ def gen_state_dict_layout():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["sh", "frames"]
+    if "run" in which:
+        gen_run()
     if "rays" in which:
         gen_get_rays()
     if "layout" in which:

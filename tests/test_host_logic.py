@@ -198,3 +198,42 @@ def test_get_rays_oracle_and_index_selection_against_the_reference():
     np.testing.assert_array_equal(rays._patch_indices(H, W, 64, 4, "cpu").numpy(), g["patch_inds"][0])
     torch.manual_seed(13)
     np.testing.assert_array_equal(rays._pair_indices(H, W, 64, 3, "cpu").numpy(), g["pair_inds"][0])
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_uniform_sampling_path_reproduces_the_reference_run(facade, case):
+    """BASELINE configs[0]: NeRFRenderer.run without an occupancy grid (nerf/renderer.py:127-255) -- goldens made by the reference's own
+    run() (tests/golden/gen_golden.py run).  Both the direct call and the staged render() dispatcher (4096-ray batches in the reference,
+    small ones here) must give the frame."""
+    g = np.load(os.path.join(GOLDEN, f"run_nerf_{case}.npz"))
+    m = network.NeRFNetwork(bound=2, cuda_ray=False, density_scale=float(g["density_scale"]), min_near=0.2)
+    scene.seed_field_(m, int(g["seed"]))
+    m.eval()
+    ro, rd = rays(g)
+    kw = dict(num_steps=int(g["num_steps"]), upsample_steps=int(g["upsample_steps"]), perturb=False)
+    with torch.no_grad():
+        r = m.run(ro, rd, **kw)
+        rs = m.render(ro, rd, staged=True, max_ray_batch=100, **kw)
+    for k in ("image", "depth", "weights_sum"):
+        np.testing.assert_allclose(r[k].numpy(), g[k], rtol=0, atol=2e-6, err_msg=k)
+        np.testing.assert_allclose(rs[k].numpy(), g[k], rtol=0, atol=2e-6, err_msg="staged " + k)
+
+
+def test_sample_pdf_matches_a_direct_inverse_cdf():
+    """sample_pdf (nerf/renderer.py:12-45): deterministic mode against a NumPy float64 inverse CDF of the same piecewise-constant density."""
+    rng = np.random.default_rng(5)
+    bins = np.sort(rng.uniform(0.2, 4.0, size=(7, 33)), axis=1).astype(np.float32)
+    w = rng.uniform(0, 1, size=(7, 32)).astype(np.float32)
+    w[2] = 0.0          # an empty ray: uniform over its bins
+    w[3, 5:] = 0.0
+    got = renderer.sample_pdf(torch.from_numpy(bins), torch.from_numpy(w), 16, det=True).numpy()
+    pdf = (w.astype(np.float64) + 1e-5)
+    pdf /= pdf.sum(1, keepdims=True)
+    cdf = np.concatenate([np.zeros((7, 1)), np.cumsum(pdf, 1)], 1)
+    u = np.linspace(0.5 / 16, 1 - 0.5 / 16, 16)
+    for b in range(7):
+        want = np.interp(u, cdf[b], bins[b].astype(np.float64))   # cdf has 33 knots: bins are the abscissae
+        flat = np.diff(cdf[b]) < 1e-5                               # the reference treats a (nearly) empty bin as width 1 in cdf space
+        ok = ~flat[np.clip(np.searchsorted(cdf[b], u, side="right") - 1, 0, 31)]
+        np.testing.assert_allclose(got[b][ok], want[ok], rtol=0, atol=2e-4)
+    assert np.all(np.diff(got, axis=1) >= -1e-6)
