@@ -101,9 +101,26 @@ def cpu_baseline(args):
             r = m.render(ro, rd, perturb=False, dt_gamma=args.dt_gamma, max_steps=1024, T_thresh=1e-4, **({"gui_mode": False} if args.model == "palette" else {}))
         dt = time.perf_counter() - t0
         n = int(r["rendered"].item())
+        # BASELINE configs[0] beside it: the reference's CPU-runnable case, NeRFRenderer.run at 400x400 with --num_steps 512 --upsample_steps 0
+        # (main_nerf.py:31-32), a quarter of one max_ray_batch of 4096 rays (160 such pieces make the frame), all host cores for the torch part
+        uniform = None
+        if args.model == "nerf":
+            torch.set_num_threads(os.cpu_count() or 1)
+            mu = network.NeRFNetwork(bound=2, cuda_ray=False, density_scale=args.density_scale, min_near=0.2)
+            scene.seed_field_(mu, 0)
+            mu.eval()
+            ro0, rd0 = scene.get_rays(pose, scene.intrinsics_from_fov(400, 400), 400, 400)
+            mid = 400 * 200 - 512
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                mu.run(ro0[:, mid:mid + 1024].contiguous(), rd0[:, mid:mid + 1024].contiguous(), num_steps=512, upsample_steps=0, perturb=False)
+            du = time.perf_counter() - t0
+            uniform = {"value": 1024 * 512 / du, "unit": "evaluated samples/s", "cores": os.cpu_count(), "ms_per_400x400_frame_extrapolated": du * 160 * 1e3,
+                       "sample": f"1024 rays x 512 uniform samples (1/160) of a 400x400 frame ({du:.1f} s; C oracle encoders 1 thread + torch MLP)"}
+            torch.set_num_threads(1)
     finally:
         renderer.raymarching, pge.GridEncoder, psh.SHEncoder = saved
-    return {"value": n / dt, "unit": "samples/s", "cores": 1, "kind": "port",
+    return {"uniform_path_config0": uniform, "value": n / dt, "unit": "samples/s", "cores": 1, "kind": "port",
             "sample": f"centre {c}x{c} crop of the {H}x{W} frame ({idx.numel()} rays, {n} rendered samples, {dt:.1f} s; -m {args.model}, C oracle ops + torch CPU MLP, 1 thread; "
                       f"host has {os.cpu_count()} cores)"}
 

@@ -291,7 +291,14 @@ class NeRFRenderer(_OccupancyMaintenance, _RendererBase):
         def points(z):  # [N, T] -> [N, T, 3], clipped to the box
             return torch.min(torch.max(rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * z.unsqueeze(-1), lo), hi)
 
+        # fused_field: one fused MFMA field launch per query gives sigma and rgb of every point; rgb of the points the reference does not
+        # send through its colour head (mask below) is zeroed afterwards, which is what its masked colour query returns for them
+        fast = bool(getattr(self, "fused_field", False)) and not self.training and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
+
         def query(xyzs, T):
+            if fast:
+                sigma, rgb = self(xyzs.reshape(-1, 3), rays_d.view(-1, 1, 3).expand(N, T, 3).reshape(-1, 3))
+                return {"sigma": sigma.view(N, T, 1), "rgb": rgb.view(N, T, 3)}
             return {k: v.view(N, T, -1) for k, v in self.density(xyzs.reshape(-1, 3)).items()}
 
         def ray_weights(z, sigma):  # transmittance-weighted opacities; the last interval is one uniform step long
@@ -323,7 +330,10 @@ class NeRFRenderer(_OccupancyMaintenance, _RendererBase):
         dirs = rays_d.view(-1, 1, 3).expand_as(xyzs)
         flat = {k: v.reshape(-1, v.shape[-1]) for k, v in fields.items()}
         mask = weights > 1e-4   # the colour head only runs where a sample matters (hard-coded in the reference too)
-        rgbs = self.color(xyzs.reshape(-1, 3), dirs.reshape(-1, 3), mask=mask.reshape(-1), **flat).view(N, -1, 3)
+        if fast:
+            rgbs = fields["rgb"] * mask.unsqueeze(-1)
+        else:
+            rgbs = self.color(xyzs.reshape(-1, 3), dirs.reshape(-1, 3), mask=mask.reshape(-1), **flat).view(N, -1, 3)
         weights_sum = weights.sum(dim=-1)
         depth = torch.sum(weights * ((z_vals - nears) / (fars - nears)).clamp(0, 1), dim=-1)
         image = torch.sum(weights.unsqueeze(-1) * rgbs, dim=-2)

@@ -393,14 +393,16 @@ def test_native_loop_half_tables_track_the_fp32_frame(cuda, model_kind):
     assert float(diff.max()) < 2e-2 and float(diff.mean()) < 4e-3 and float(diff.max()) > 0.0, (float(diff.max()), float(diff.mean()))
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("case", ["a", "b"])
-def test_uniform_sampling_path_on_the_hip_ops(cuda, golden_dir, case):
+def test_uniform_sampling_path_on_the_hip_ops(cuda, golden_dir, case, fused):
     """BASELINE configs[0] on the GPU: NeRFRenderer.run (no occupancy grid) over the HIP near/far, hash-grid and SH operators against the
     frame the reference's own run() produced (tests/golden/gen_golden.py run); fp32 colour tolerance 1e-4."""
     g = load(golden_dir, f"run_nerf_{case}")
     m = network.NeRFNetwork(bound=2, cuda_ray=False, density_scale=float(g["density_scale"]), min_near=0.2)
     scene.seed_field_(m, int(g["seed"]))
     m = m.to(cuda).eval()
+    m.fused_field = fused   # True: sigma and rgb of every point from the fused MFMA field kernel, unmasked points zeroed afterwards
     ro, rd = frame_rays(g, cuda)
     kw = dict(num_steps=int(g["num_steps"]), upsample_steps=int(g["upsample_steps"]), perturb=False)
     with torch.no_grad():
