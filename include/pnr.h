@@ -323,6 +323,10 @@ int pnr_grid_encode_backward_binned(const float* grad, const float* inputs, cons
 uint64_t pnr_linear_wgrad_workspace_bytes(uint32_t B, uint32_t in_dim, uint32_t out_dim);
 int pnr_linear_wgrad(const void* x, int x_dtype, const void* dy, int dy_dtype, uint32_t B, uint32_t in_dim, uint32_t out_dim, float* dw,
                      int accumulate, void* workspace, uint64_t workspace_bytes, pnr_stream_t stream);
+/* bias gradient of a dense layer with bias (palette/network.py:111 offsets_radiance_net, the only one): db[o] = sum_b dY[b][o];
+ * workspace of pnr_linear_wgrad_workspace_bytes(B, 1, out_dim) */
+int pnr_linear_bgrad(const void* dy, int dy_dtype, uint32_t B, uint32_t out_dim, float* db, int accumulate, void* workspace, uint64_t workspace_bytes,
+                     pnr_stream_t stream);
 
 /* ---------------------------------------------------------------- ray generation ----------- */
 
@@ -337,6 +341,25 @@ int pnr_get_rays(const float* poses, uint32_t B, float fx, float fy, float cx, f
                  uint32_t N, float* rays_o, float* rays_d, pnr_stream_t stream);
 
 /* ---------------------------------------------------------------- palette ------------------ */
+
+/* Training-mode palette colour-basis composite as one launch each way (replaces the ~40 torch launches of palette/renderer.py:344-386
+ * between PaletteNetwork.forward and composite_rays_train / composite_rays_flex_train; same arithmetic):
+ *   omega [M,nb], offsets_radiance [M,3nb+1] (offsets, then radiance), view_dep [M,3], diffuse [M,3], clip_feat [M,clip_dim] or NULL (zeros),
+ *   smooth_norm [M] or NULL (zeros), basis_color [nb,3] (the unclamped parameter)
+ *   -> rgbs [M,3] = sum_b omega_b softplus(radiance) (clamp(P_b,0,1) + offsets_b) + view_dep
+ *      all_buffer [M, 13+clip_dim+nb] = omega_sparsity, view_dep_norm, offsets_norm, smooth_norm, view_dep, diffuse+view_dep, diffuse, clip_feat, omega
+ * backward: grad_rgbs [M,3], grad_all [M,13+clip_dim+nb] -> gradients of every input (view_dep gets none through rgbs: the reference detaches
+ * it there); grad_clip_feat / grad_smooth_norm / grad_basis_color may be NULL (not wanted).  grad_basis_color [nb,3] is reduced
+ * deterministically through `workspace` (pnr_palette_train_shade_workspace_bytes).  nb <= 16. */
+uint64_t pnr_palette_train_shade_workspace_bytes(uint32_t num_basis);
+int pnr_palette_train_shade_forward(uint32_t M, uint32_t num_basis, uint32_t clip_dim, const float* omega, const float* offsets_radiance,
+                                    const float* view_dep, const float* diffuse, const float* clip_feat, const float* smooth_norm,
+                                    const float* basis_color, float* rgbs, float* all_buffer, pnr_stream_t stream);
+int pnr_palette_train_shade_backward(uint32_t M, uint32_t num_basis, uint32_t clip_dim, const float* omega, const float* offsets_radiance,
+                                     const float* view_dep, const float* basis_color, const float* grad_rgbs, const float* grad_all,
+                                     float* grad_omega, float* grad_offsets_radiance, float* grad_view_dep, float* grad_diffuse,
+                                     float* grad_clip_feat, float* grad_smooth_norm, float* grad_basis_color, void* workspace,
+                                     uint64_t workspace_bytes, pnr_stream_t stream);
 
 /* replace rgb_to_hsv / hsv_to_rgb, palette/src/palette_func.h, palette.cu:135-149 */
 int pnr_rgb_to_hsv(uint32_t n, const float* input, float* output, pnr_stream_t stream);

@@ -56,11 +56,47 @@ class _LinearNoBias(torch.autograd.Function):
         return dx, dw
 
 
+def bias_grad(dy):
+    """dy [B, out] (fp32 or fp16, CUDA) -> db [out] fp32 = column sums (pnr_linear_bgrad)."""
+    B, n_out = dy.shape
+    dy = dy.contiguous()
+    out = torch.empty(n_out, dtype=torch.float32, device=dy.device)
+    nbytes = int(_lib.load().pnr_linear_wgrad_workspace_bytes(B, 1, n_out))
+    ws = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=dy.device)
+    call("pnr_linear_bgrad", ptr(dy), ctypes.c_int(_DTYPE[dy.dtype]), ctypes.c_uint32(B), ctypes.c_uint32(n_out), ptr(out), ctypes.c_int(0), ptr(ws),
+         ctypes.c_uint64(nbytes))
+    return out
+
+
+class _LinearBias(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda")
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx = dw = db = None
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if ctx.needs_input_grad[0]:
+            dx = (dy2 @ weight.to(dy2.dtype)).reshape(x.shape).to(x.dtype)
+        if ctx.needs_input_grad[1]:
+            dw = weight_grad(x.reshape(-1, x.shape[-1]), dy2).to(weight.dtype)
+        if ctx.needs_input_grad[2]:
+            db = bias_grad(dy2).to(weight.dtype)
+        return dx, dw, db
+
+
 class Linear(nn.Linear):
-    """nn.Linear(in, out, bias=False) whose weight gradient runs on the HIP kernel when it pays (CUDA, >= MIN_ROWS rows, dims <= 64)."""
+    """nn.Linear whose weight (and bias) gradient runs on the HIP kernel when it pays (CUDA, >= MIN_ROWS rows, dims <= 64)."""
 
     def forward(self, x):
-        if (self.bias is None and x.is_cuda and torch.is_grad_enabled() and self.weight.requires_grad and self.in_features <= 64
+        if (x.is_cuda and torch.is_grad_enabled() and self.weight.requires_grad and self.in_features <= 64
                 and self.out_features <= 64 and x.dtype in _DTYPE and x.numel() // x.shape[-1] >= MIN_ROWS):
-            return _LinearNoBias.apply(x, self.weight)
+            if self.bias is None:
+                return _LinearNoBias.apply(x, self.weight)
+            return _LinearBias.apply(x, self.weight, self.bias)
         return F.linear(x, self.weight, self.bias)

@@ -98,7 +98,7 @@ class PaletteNetwork(PaletteRenderer):
         self.color_net = _mlp([self.in_dim_dir + geo_feat_dim] + [hidden_dim] * (num_layers_color - 1) + [3])
         self.diff_net = _mlp([geo_feat_dim] + [hidden_dim] * (num_layers_color - 1) + [3])
         self.basis_net = _mlp([self.in_dim_palette + 3] + [hidden_dim] * (num_layers - 1) + [geo_feat_dim])
-        self.offsets_radiance_net = nn.Linear(geo_feat_dim, self.num_basis * 3 + 1)  # the only layer with a bias
+        self.offsets_radiance_net = Linear(geo_feat_dim, self.num_basis * 3 + 1)  # the only layer with a bias
         self.omega_net = nn.Sequential(Linear(geo_feat_dim, self.num_basis, bias=False), nn.Softplus())
         if opt.pred_clip:
             self.clip_net = _mlp([self.in_dim_clip] + [hidden_dim] * (num_layers - 1) + [opt.clip_dim])

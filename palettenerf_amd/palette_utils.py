@@ -4,7 +4,7 @@ import ctypes
 
 import torch
 from torch.autograd import Function
-from torch.amp import custom_fwd
+from torch.amp import custom_bwd, custom_fwd
 
 from ._torch_glue import call, ptr, require, to_cuda
 
@@ -65,3 +65,61 @@ def compute_RGB_histogram(colors_rgb, weights, bits_per_channel):
     bc = torch.empty(nb, 3, dtype=torch.float32, device=c.device)
     call("pnr_rgb_histogram", ptr(c), ptr(w), _u32(c.shape[0]), ctypes.c_int(bits_per_channel), ptr(bw), ptr(bc))
     return (bw.cpu().numpy(), bc.cpu().numpy()) if as_numpy else (bw, bc)
+
+
+class _palette_train_shade(Function):
+    """Training-mode palette colour-basis composite (palette/renderer.py:344-386) as one HIP launch each way: see
+    `pnr_palette_train_shade_forward` in include/pnr.h.  Returns (rgbs [M,3], all_buffer [M, 13 + clip_dim + nb])."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, omega, offsets_radiance, view_dep, diffuse, clip_feat, smooth_norm, basis_color, clip_dim=None):
+        M, nb = omega.shape
+        if clip_dim is None:
+            clip_dim = 0 if clip_feat is None else clip_feat.shape[-1]
+        if clip_feat is not None and clip_feat.shape != (M, clip_dim):
+            raise RuntimeError("palette_train_shade: clip_feat must be [M, clip_dim]")
+        f32 = torch.float32
+        omega, offsets_radiance = require(omega.contiguous(), f32, "omega"), require(offsets_radiance.contiguous(), f32, "offsets_radiance")
+        view_dep, diffuse = require(view_dep.contiguous(), f32, "view_dep"), require(diffuse.contiguous(), f32, "diffuse")
+        basis_color = require(basis_color.contiguous(), f32, "basis_color")
+        if offsets_radiance.shape != (M, 3 * nb + 1) or basis_color.shape != (nb, 3):
+            raise RuntimeError("palette_train_shade: offsets_radiance must be [M, 3 nb + 1] and basis_color [nb, 3]")
+        if clip_feat is not None:
+            clip_feat = require(clip_feat.contiguous(), f32, "clip_feat")
+        if smooth_norm is not None:
+            smooth_norm = require(smooth_norm.contiguous().view(-1), f32, "smooth_norm")
+        rgbs = torch.empty(M, 3, device=omega.device, dtype=f32)
+        all_buffer = torch.empty(M, 13 + clip_dim + nb, device=omega.device, dtype=f32)
+        call("pnr_palette_train_shade_forward", _u32(M), _u32(nb), _u32(clip_dim), ptr(omega), ptr(offsets_radiance), ptr(view_dep), ptr(diffuse),
+             ptr(clip_feat), ptr(smooth_norm), ptr(basis_color), ptr(rgbs), ptr(all_buffer))
+        ctx.save_for_backward(omega, offsets_radiance, view_dep, basis_color)
+        ctx.dims = (M, nb, clip_dim, clip_feat is not None, smooth_norm is not None)
+        return rgbs, all_buffer
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, g_rgbs, g_all):
+        from . import _lib
+        omega, offsets_radiance, view_dep, basis_color = ctx.saved_tensors
+        M, nb, clip_dim, has_clip, has_smooth = ctx.dims
+        dev, f32 = omega.device, torch.float32
+        g_rgbs = torch.zeros(M, 3, device=dev, dtype=f32) if g_rgbs is None else g_rgbs.contiguous().float()
+        g_all = torch.zeros(M, 13 + clip_dim + nb, device=dev, dtype=f32) if g_all is None else g_all.contiguous().float()
+        g_omega, g_or = torch.empty_like(omega), torch.empty_like(offsets_radiance)
+        g_vd, g_df = torch.empty(M, 3, device=dev, dtype=f32), torch.empty(M, 3, device=dev, dtype=f32)
+        g_clip = torch.empty(M, clip_dim, device=dev, dtype=f32) if has_clip and ctx.needs_input_grad[4] else None
+        g_smooth = torch.empty(M, 1, device=dev, dtype=f32) if has_smooth and ctx.needs_input_grad[5] else None
+        g_bc = ws = None
+        ws_bytes = 0
+        if ctx.needs_input_grad[6]:
+            g_bc = torch.empty(nb, 3, device=dev, dtype=f32)
+            ws_bytes = int(_lib.load().pnr_palette_train_shade_workspace_bytes(nb))
+            ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        call("pnr_palette_train_shade_backward", _u32(M), _u32(nb), _u32(clip_dim), ptr(omega), ptr(offsets_radiance), ptr(view_dep), ptr(basis_color),
+             ptr(g_rgbs), ptr(g_all), ptr(g_omega), ptr(g_or), ptr(g_vd), ptr(g_df), ptr(g_clip), ptr(g_smooth), ptr(g_bc), ptr(ws),
+             ctypes.c_uint64(ws_bytes))
+        return g_omega, g_or, g_vd, g_df, g_clip, g_smooth, g_bc, None
+
+
+palette_train_shade = _palette_train_shade.apply

@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import raymarching
-from .palette_utils import hsv_to_rgb, rgb_to_hsv
+from .palette_utils import hsv_to_rgb, palette_train_shade, rgb_to_hsv
 
 
 def default_opt(**kw):
@@ -546,6 +546,7 @@ class PaletteRenderer(_RendererBase):
             sigmas, clip_feat, omega, offsets_radiance, view_dep, diffuse = self(xyzs, dirs)
             offsets, radiance = offsets_radiance[..., :-1], offsets_radiance[..., -1:]
             sigmas = (self.density_scale * sigmas).detach()  # geometry is frozen (palette/renderer.py:334-335)
+            fused_shade = bool(getattr(self, "fused_train_shade", True)) and xyzs.is_cuda and nb <= 16
             radiance = radiance.reshape(M, 1, 1)
             offsets = offsets.reshape(M, nb, 3)
             omega = omega.reshape(M, nb, 1)
@@ -555,15 +556,14 @@ class PaletteRenderer(_RendererBase):
             basis_color = self.basis_color[None, :, :].clamp(0, 1)
             if self.freeze_basis_color:
                 basis_color = basis_color.detach()
-            final_color = F.softplus(radiance) * (basis_color + offsets)
-            basis_rgb = omega * final_color
-            rgbs = basis_rgb.sum(dim=-2) + view_dep.detach()
-            direct_rgb = diffuse + view_dep
-            weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
-
-            omega_sparsity = omega[..., 0].sum(dim=-1, keepdim=True) / ((omega[..., 0] ** 2).sum(dim=-1, keepdim=True) + 1e-6) - 1
-            offsets_norm = (offsets ** 2).sum(dim=-1).sum(dim=-1, keepdim=True)
-            view_dep_norm = (view_dep ** 2).sum(dim=-1, keepdim=True)
+            if not fused_shade:
+                final_color = F.softplus(radiance) * (basis_color + offsets)
+                basis_rgb = omega * final_color
+                rgbs = basis_rgb.sum(dim=-2) + view_dep.detach()
+                direct_rgb = diffuse + view_dep
+                omega_sparsity = omega[..., 0].sum(dim=-1, keepdim=True) / ((omega[..., 0] ** 2).sum(dim=-1, keepdim=True) + 1e-6) - 1
+                offsets_norm = (offsets ** 2).sum(dim=-1).sum(dim=-1, keepdim=True)
+                view_dep_norm = (view_dep ** 2).sum(dim=-1, keepdim=True)
             if self.require_smooth_loss:
                 xyzs_diff = (xyzs + torch.rand_like(xyzs) * self.bound * 0.03).clamp(-self.bound, self.bound)
                 _, clip_feat_diff, omega_diff, _, _, diffuse_diff = self(xyzs_diff, dirs)
@@ -580,11 +580,20 @@ class PaletteRenderer(_RendererBase):
                 if self.opt.pred_clip:
                     smooth_norm += ((clip_feat_diff - clip_feat) ** 2).sum(dim=-1, keepdim=True) * smooth_weight
             else:
-                smooth_norm = torch.zeros_like(omega_sparsity)
+                smooth_norm = None
 
             # 13 + clip_dim + nb channels in ONE flex composite (palette/renderer.py:384-386)
-            all_buffer = torch.cat([omega_sparsity, view_dep_norm, offsets_norm, smooth_norm, view_dep, direct_rgb, diffuse, clip_feat,
-                                    omega[..., 0]], dim=-1)
+            if fused_shade:  # the whole colour-basis composite + the 33-column row in one HIP launch each way (pnr_palette_train_shade_*)
+                # without a clip head the row keeps its clip_dim columns, zero, as the reference's torch.zeros clip_feat does
+                rgbs, all_buffer = palette_train_shade(omega.reshape(M, nb), offsets_radiance.reshape(M, 3 * nb + 1), view_dep, diffuse,
+                                                       clip_feat if self.opt.pred_clip else None, smooth_norm,
+                                                       self.basis_color.detach() if self.freeze_basis_color else self.basis_color, clip_dim)
+            else:
+                if smooth_norm is None:
+                    smooth_norm = torch.zeros_like(omega_sparsity)
+                all_buffer = torch.cat([omega_sparsity, view_dep_norm, offsets_norm, smooth_norm, view_dep, direct_rgb, diffuse, clip_feat,
+                                        omega[..., 0]], dim=-1)
+            weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
             all_map = raymarching.composite_rays_flex_train(sigmas, all_buffer, deltas, rays, T_thresh)
             image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
             depth = torch.clamp(depth - nears, min=0) / (fars - nears)

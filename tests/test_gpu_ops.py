@@ -639,6 +639,23 @@ def test_linear_module_gradients_match_nn_linear(cuda):
         linear.weight_grad(torch.zeros(4, 65, device=cuda), torch.zeros(4, 3, device=cuda))
 
 
+def test_linear_with_bias_gradients_match_float64(cuda):
+    """The one dense layer with a bias (offsets_radiance_net, palette/network.py:111): weight and bias gradient through pnr_linear_wgrad /
+    pnr_linear_bgrad against float64 sums; same state_dict entries as nn.Linear."""
+    from palettenerf_amd import linear
+    torch.manual_seed(1)
+    lay = linear.Linear(15, 13).to(cuda)
+    assert set(lay.state_dict()) == {"weight", "bias"}
+    x = torch.randn(70001, 15, device=cuda, requires_grad=True)
+    w = torch.randn(70001, 13, device=cuda)
+    (lay(x) * w).sum().backward()
+    xd, wd = x.detach().double().cpu(), w.double().cpu()
+    np.testing.assert_allclose(host(lay.bias.grad), wd.sum(0).numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(host(lay.weight.grad), (wd.t() @ xd).numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(host(x.grad), (wd @ lay.weight.detach().double().cpu()).numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(host(linear.bias_grad(w.half())), w.half().double().cpu().sum(0).numpy(), rtol=1e-5, atol=1e-3)
+
+
 @pytest.mark.parametrize("case", ["hash16", "tiled", "small_table", "clustered"])
 def test_grid_backward_binned_matches_oracle(cuda, case, monkeypatch):
     """The bucket-binned table gradient (csrc/grid_binned.hip) against the oracle's scatter loop and against the atomic kernel."""
@@ -721,3 +738,71 @@ def test_march_sparse_scene_block_jumps_bit_exact(cuda, dt_gamma):
     np.testing.assert_array_equal(host(rays), orays)
     np.testing.assert_array_equal(host(x), ox)
     np.testing.assert_array_equal(host(dl), odl)
+
+
+@pytest.mark.parametrize("nb,clip_dim,has_clip,has_smooth,frozen", [(4, 16, False, False, False), (4, 16, True, True, False), (6, 0, False, False, True),
+                                                                    (1, 3, True, False, False), (16, 2, True, True, False)])
+def test_palette_train_shade_matches_the_torch_formulas(cuda, nb, clip_dim, has_clip, has_smooth, frozen):
+    """pnr_palette_train_shade_* against the reference's own torch arithmetic (palette/renderer.py:344-386) evaluated in float64 with autograd:
+    forward 2e-6 relative, gradients 2e-5 relative to the largest gradient of each tensor.  Covers basis colours outside [0, 1] (clamp passes
+    no gradient there), radiance beyond softplus' linear threshold, no clip head (zero columns), frozen basis colours, nb = 1 and 16."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(nb * 100 + clip_dim)
+    M = 20000 + nb
+    def rnd(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g) * scale)
+    omega = (F.softplus(rnd(M, nb)) + 0.05)
+    omega = omega / omega.sum(-1, keepdim=True)
+    offrad = rnd(M, 3 * nb + 1, scale=0.5)
+    offrad[:50, -1] = torch.linspace(15.0, 30.0, 50)     # around F.softplus' threshold (20)
+    view_dep, diffuse = torch.rand(M, 3, generator=g), torch.rand(M, 3, generator=g)
+    clip_feat = rnd(M, clip_dim) if has_clip else None
+    smooth = torch.rand(M, 1, generator=g) if has_smooth else None
+    basis = torch.rand(nb, 3, generator=g) * 1.4 - 0.2   # some components outside [0, 1]
+    w_rgb, w_all = rnd(M, 3), rnd(M, 13 + clip_dim + nb)
+
+    def leafs(dtype, device):
+        ts = [omega, offrad, view_dep, diffuse, clip_feat, smooth, basis]
+        return [None if t is None else t.to(device=device, dtype=dtype).requires_grad_(True) for t in ts]
+
+    # reference arithmetic, float64 on the host
+    o, r, vd, df, cf, sm, bc = leafs(torch.float64, "cpu")
+    off, rad = r[:, :-1].reshape(M, nb, 3), r[:, -1:].reshape(M, 1, 1)
+    bcc = bc[None].clamp(0, 1)
+    if frozen:
+        bcc = bcc.detach()
+    final = F.softplus(rad) * (bcc + off)
+    rgbs = (o[..., None] * final).sum(-2) + vd.detach()
+    sparsity = o.sum(-1, keepdim=True) / ((o ** 2).sum(-1, keepdim=True) + 1e-6) - 1
+    cols = [sparsity, (vd ** 2).sum(-1, keepdim=True), (off ** 2).sum(-1).sum(-1, keepdim=True), sm if sm is not None else torch.zeros(M, 1, dtype=torch.float64),
+            vd, df + vd, df, cf if cf is not None else torch.zeros(M, clip_dim, dtype=torch.float64), o]
+    all_ref = torch.cat(cols, -1)
+    ((rgbs * w_rgb.double()).sum() + (all_ref * w_all.double()).sum()).backward()
+    ref_grads = [None if t is None else t.grad for t in (o, r, vd, df, cf, sm, bc)]
+
+    o2, r2, vd2, df2, cf2, sm2, bc2 = leafs(torch.float32, cuda)
+    rg, ab = palette_utils.palette_train_shade(o2, r2, vd2, df2, cf2, sm2, bc2.detach() if frozen else bc2, clip_dim)
+    assert ab.shape == (M, 13 + clip_dim + nb)
+    np.testing.assert_allclose(rg.detach().cpu().numpy(), rgbs.detach().numpy(), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(ab.detach().cpu().numpy(), all_ref.detach().numpy(), rtol=2e-6, atol=2e-6)
+    ((rg * w_rgb.to(cuda)).sum() + (ab * w_all.to(cuda)).sum()).backward()
+    for name, got, want in zip(("omega", "offsets_radiance", "view_dep", "diffuse", "clip_feat", "smooth_norm", "basis_color"),
+                               (o2, r2, vd2, df2, cf2, sm2, bc2), ref_grads):
+        if got is None:
+            continue
+        if name == "basis_color" and frozen:
+            assert got.grad is None
+            continue
+        scale = float(want.abs().max()) + 1e-12
+        err = float((got.grad.cpu().double() - want).abs().max())
+        assert err <= 2e-5 * scale + 1e-7, (name, err, scale)
+    if not frozen:  # the clamp passes nothing where a basis colour lies outside [0, 1]
+        outside = ((basis < 0) | (basis > 1))
+        assert outside.any() and float(bc2.grad.cpu()[outside].abs().max()) == 0.0
+    # deterministic: the basis-colour gradient is reduced in a fixed order
+    if not frozen:
+        first = bc2.grad.clone()
+        bc2.grad = None
+        rg, ab = palette_utils.palette_train_shade(o2, r2, vd2, df2, cf2, sm2, bc2, clip_dim)
+        ((rg * w_rgb.to(cuda)).sum() + (ab * w_all.to(cuda)).sum()).backward()
+        assert torch.equal(first, bc2.grad)
