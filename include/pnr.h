@@ -170,6 +170,12 @@ int pnr_nerf_field_pack(const float* w_sigma0, const float* w_sigma1, const floa
                         const float* w_color2, float* packed, int precision, pnr_stream_t stream);
 int pnr_nerf_field_forward(const float* enc, const float* dirs, const float* packed, uint32_t B, float* sigmas,
                            float* rgbs, int precision, pnr_stream_t stream);
+/* sigma_net alone (NeRFNetwork.density / the frozen-geometry half of PaletteNetwork.forward: nerf/network.py:126-143,
+ * palette/network.py:161-170): sigmas [B] = scale * exp(h0), geo_feat [B,15] = h[1:] (NULL: not wanted).  Same enc layout, packed blob
+ * and precision modes as pnr_nerf_field_forward.  No gradient: for inference, the occupancy sweep and PaletteNeRF training (whose
+ * geometry is detached). */
+int pnr_nerf_density_forward(const float* enc, const float* packed, uint32_t B, float scale, float* sigmas, float* geo_feat, int precision,
+                             pnr_stream_t stream);
 
 /* Device-driven inference frame of the NeRF path: the loop of nerf/renderer.py:344-380 (same n_step schedule,
  * same per-ray arithmetic, order-preserving compaction) with n_alive / n_step / step kept in a device control

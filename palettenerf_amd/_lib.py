@@ -42,6 +42,7 @@ SIGNATURES = {
     "pnr_nerf_field_packed_bytes": [],
     "pnr_nerf_field_pack": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _int, _ptr],
     "pnr_nerf_field_forward": [_ptr, _ptr, _ptr, _u32, _ptr, _ptr, _int, _ptr],
+    "pnr_nerf_density_forward": [_ptr, _ptr, _u32, _f32, _ptr, _ptr, _int, _ptr],
     "pnr_nerf_frame_workspace_bytes": [_u32],
     "pnr_nerf_render_frame": [_ptr, _ptr],
     "pnr_palette_field_packed_bytes": [_int],

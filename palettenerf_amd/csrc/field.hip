@@ -104,6 +104,35 @@ __global__ void __launch_bounds__(kFieldThreads) k_nerf_field_fwd(const float* _
     }
 }
 
+// sigma_net alone: sigma = exp(logit) and, optionally, the 15 geometry features per sample ([B,15] row-major, what the colour heads of
+// both models take).  Only the first 16 KiB (fp32) / 8 blocks (f16x3) of the packed blob are read.
+template <int PREC>
+__global__ void __launch_bounds__(kFieldThreads) k_nerf_density_fwd(const float* __restrict__ enc /* [16][B][2] */, const float* __restrict__ packed, uint32_t B,
+                                                                    float scale, float* __restrict__ sigmas, float* __restrict__ geo) {
+    constexpr int kFloats = PREC == 0 ? kC0 : 8 * kF16BlockBytes / 4;
+    __shared__ float w[kFloats];
+    for (int i = threadIdx.x * 4; i < kFloats; i += kFieldThreads * 4)
+        *reinterpret_cast<float4*>(&w[i]) = *reinterpret_cast<const float4*>(&packed[i]);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const uint32_t ntiles = (B + 255) / 256;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t n = tile * 256 + wave * 32 + (lane & 31);
+        const bool valid = n < B;
+        const uint32_t nc = valid ? n : (B - 1);
+        const f32x16 g = nerf_density_tile<PREC>(w, lane, valid, enc, B, nc);
+        if (!valid) continue;
+        if (h == 0) sigmas[n] = scale * expf(g[0]);   // trunc_exp forward (activation.py:9), times the caller's density_scale (1 = plain sigma)
+        if (geo) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int row = frag_row(r, 0) + 4 * h;   // 0..15
+                if (row >= 1) geo[(size_t)n * 15 + row - 1] = g[r];
+            }
+        }
+    }
+}
+
 }  // namespace pnr
 
 using namespace pnr;
@@ -137,6 +166,20 @@ int pnr_nerf_field_forward(const float* enc, const float* dirs, const float* pac
         hipLaunchKernelGGL(k_nerf_field_fwd<0>, dim3(grid), dim3(kFieldThreads), 0, as_stream(stream), enc, dirs, packed, B, sigmas, rgbs);
     else
         hipLaunchKernelGGL(k_nerf_field_fwd<1>, dim3(grid), dim3(kFieldThreads), 0, as_stream(stream), enc, dirs, packed, B, sigmas, rgbs);
+    return check_launch();
+}
+
+int pnr_nerf_density_forward(const float* enc, const float* packed, uint32_t B, float scale, float* sigmas, float* geo_feat, int precision,
+                             pnr_stream_t stream) {
+    if (precision != PNR_FIELD_FP32 && precision != PNR_FIELD_F16X3) return PNR_ERR_UNSUPPORTED;
+    if (B == 0) return PNR_OK;
+    if (!enc || !packed || !sigmas) return PNR_ERR_INVALID;
+    const uint32_t ntiles = cdiv(B, 256);
+    const uint32_t grid = ntiles < 1024u ? ntiles : 1024u;
+    if (precision == PNR_FIELD_FP32)
+        hipLaunchKernelGGL(k_nerf_density_fwd<0>, dim3(grid), dim3(kFieldThreads), 0, as_stream(stream), enc, packed, B, scale, sigmas, geo_feat);
+    else
+        hipLaunchKernelGGL(k_nerf_density_fwd<1>, dim3(grid), dim3(kFieldThreads), 0, as_stream(stream), enc, packed, B, scale, sigmas, geo_feat);
     return check_launch();
 }
 

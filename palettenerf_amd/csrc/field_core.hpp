@@ -234,6 +234,54 @@ __device__ __forceinline__ FieldOut nerf_field_tile_f32(const float* __restrict_
     return out;
 }
 
+// sigma_net alone (32 -> 64 ReLU -> 16): the 16 outputs of a sample as the lower 8 accumulator registers of its two half-wave lanes
+// (row frag_row(r, h): logit = row 0, geo feature k = row k).  Same arithmetic as the first half of the field tiles above.
+template <int PREC>
+__device__ __forceinline__ f32x16 nerf_density_tile(const float* __restrict__ wf, int lane, bool valid, const float* __restrict__ enc, size_t level_stride,
+                                                    uint32_t row) {
+    const int h = lane >> 5;
+    f32x16 h0 = zero16(), h1 = zero16(), g = zero16();
+    if constexpr (PREC == 0) {
+        float x[16];
+#pragma unroll
+        for (int s = 0; s < 16; s++) x[s] = valid ? enc[((size_t)s * level_stride + row) * 2 + h] : 0.0f;
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            h0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[kS0 + s * 64 + lane], x[s], h0, 0, 0, 0);
+            h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[kS0 + (16 + s) * 64 + lane], x[s], h1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        h0 = relu16(h0); h1 = relu16(h1);
+        g = mma_frag(g, &wf[kS1], h0, lane);
+        g = mma_frag(g, &wf[kS1 + 16 * 64], h1, lane);
+    } else {
+        const unsigned char* w = reinterpret_cast<const unsigned char*>(wf);
+        h8 bh[4], bl[4];
+        float x[2][8];
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int level = 8 * kb + 4 * h + q;
+                const float2 v = valid ? *reinterpret_cast<const float2*>(enc + ((size_t)level * level_stride + row) * 2) : make_float2(0.0f, 0.0f);
+                x[kb][2 * q] = v.x; x[kb][2 * q + 1] = v.y;
+            }
+        split8(x[0], bh[0], bl[0]);
+        split8(x[1], bh[1], bl[1]);
+        h0 = mma3(h0, w + 0 * kF16BlockBytes, bh[0], bl[0], lane);
+        h0 = mma3(h0, w + 1 * kF16BlockBytes, bh[1], bl[1], lane);
+        h1 = mma3(h1, w + 2 * kF16BlockBytes, bh[0], bl[0], lane);
+        h1 = mma3(h1, w + 3 * kF16BlockBytes, bh[1], bl[1], lane);
+        __builtin_amdgcn_sched_barrier(0);
+        h0 = relu16(h0); h1 = relu16(h1);
+        split_frag(h0, 0, bh[0], bl[0]); split_frag(h0, 1, bh[1], bl[1]);
+        split_frag(h1, 0, bh[2], bl[2]); split_frag(h1, 1, bh[3], bl[3]);
+#pragma unroll
+        for (int kb = 0; kb < 4; kb++) g = mma3(g, w + (4 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
+    }
+    return g;
+}
+
 template <int PREC>
 __device__ __forceinline__ FieldOut nerf_field_tile(const float* __restrict__ w, int lane, bool valid, const float* __restrict__ enc,
                                                     size_t level_stride, uint32_t row, float dx, float dy, float dz) {

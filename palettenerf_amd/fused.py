@@ -170,6 +170,31 @@ class NeRFFieldFused:
         return sigmas, rgbs
 
 
+class DensityFused(NeRFFieldFused):
+    """sigma_net alone through the matrix cores (pnr_nerf_density_forward): sigma and the 15 geometry features of sample batches, no
+    gradient.  Works for NeRFNetwork and PaletteNetwork (same encoder / sigma_net / color_net shapes; only the sigma_net part of the blob
+    is read).  Users: the occupancy sweep (update_extra_state), density() under no_grad, PaletteNeRF training (geometry detached)."""
+
+    @torch.no_grad()
+    def __call__(self, x, scale=1.0, want_geo=True):
+        m = self.model
+        x01 = ((x + m.bound) / (2 * m.bound)).contiguous()
+        enc = grid_encode_raw(m.encoder, x01)
+        B = x.shape[0]
+        sigmas = torch.empty(B, dtype=torch.float32, device=x.device)
+        geo = torch.empty(B, 15, dtype=torch.float32, device=x.device) if want_geo else None
+        call("pnr_nerf_density_forward", ptr(enc), ptr(self._pack()), _u32(B), ctypes.c_float(scale), ptr(sigmas), ptr(geo), _int(self.precision), units=B)
+        return sigmas, geo
+
+
+def density_fused(model):
+    """The model's cached DensityFused (built on first use)."""
+    d = getattr(model, "_density_fused", None)
+    if d is None:
+        d = model._density_fused = DensityFused(model)
+    return d
+
+
 class PaletteFieldFused:
     """Fused PaletteNeRF field + colour-basis composite (pnr_palette_field_forward).  Produces, per sample,
     sigma * density_scale, rgb and one packed aux row [direct 3 | view_dep 3 | omega nb | basis_rgb 3nb | unscaled 3nb | clip | pad]."""

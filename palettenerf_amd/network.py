@@ -27,6 +27,22 @@ def _run(net, h, act=F.relu):
     return h
 
 
+def density_fused(model):
+    from .fused import density_fused as get
+    return get(model)
+
+
+def _fused_arch_ok(m):
+    """The fused density kernel is specialised for the shipped architecture (hashgrid 16 x 2, 64-wide sigma_net, 15 geometry features)."""
+    e = m.encoder
+    return (getattr(e, "num_levels", 0) == 16 and getattr(e, "level_dim", 0) == 2 and m.hidden_dim == 64 and m.geo_feat_dim == 15 and m.num_layers == 2
+            and m.num_layers_color == 3 and m.hidden_dim_color == 64 and getattr(m.encoder_dir, "degree", 0) == 4)
+
+
+def _fused_density_ok(m, x):
+    return bool(m.fused_field) and x.is_cuda and not torch.is_grad_enabled() and not torch.is_autocast_enabled() and _fused_arch_ok(m)
+
+
 class NeRFNetwork(NeRFRenderer):
     def __init__(self, encoding="hashgrid", encoding_dir="sphere_harmonics", num_layers=2, hidden_dim=64, geo_feat_dim=15,
                  num_layers_color=3, hidden_dim_color=64, bound=1, **kwargs):
@@ -58,6 +74,9 @@ class NeRFNetwork(NeRFRenderer):
 
     def density(self, x):
         """nerf/network.py:126-143"""
+        if _fused_density_ok(self, x):
+            sigma, geo = density_fused(self)(x)
+            return {"sigma": sigma, "geo_feat": geo}
         h = _run(self.sigma_net, self.encoder(x, bound=self.bound))
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
 
@@ -106,11 +125,16 @@ class PaletteNetwork(PaletteRenderer):
         self.fused_field = False  # True: inference goes through the fused palette field + packed-aux composite (no edit / stylizer)
         self._fused = None
 
-    def forward(self, x, d):
-        """palette/network.py:156-185.  Returns sigma, clip_feat, omega, offsets_radiance, view_dep, diffuse."""
-        h = _run(self.sigma_net, self.encoder(x, bound=self.bound))
-        sigma = trunc_exp(h[..., 0])
-        geo_feat = h[..., 1:].detach()
+    def forward(self, x, d, frozen_density=False):
+        """palette/network.py:156-185.  Returns sigma, clip_feat, omega, offsets_radiance, view_dep, diffuse.
+        frozen_density: the caller detaches sigma (PaletteNeRF training, palette/renderer.py:334-335; geo_feat is detached here anyway), so
+        encoder + sigma_net may run as the fused no-gradient density kernel."""
+        if frozen_density and x.is_cuda and not torch.is_autocast_enabled() and _fused_arch_ok(self):
+            sigma, geo_feat = density_fused(self)(x)
+        else:
+            h = _run(self.sigma_net, self.encoder(x, bound=self.bound))
+            sigma = trunc_exp(h[..., 0])
+            geo_feat = h[..., 1:].detach()
         if self.opt.pred_clip:
             clip_feat = _run(self.clip_net, self.encoder_clip(x, bound=self.bound))
         else:
@@ -119,6 +143,9 @@ class PaletteNetwork(PaletteRenderer):
         return sigma, clip_feat, omega, offsets_radiance, view_dep, diffuse
 
     def density(self, x):
+        if _fused_density_ok(self, x):
+            sigma, geo = density_fused(self)(x)
+            return {"sigma": sigma, "geo_feat": geo}
         h = _run(self.sigma_net, self.encoder(x, bound=self.bound))
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
 

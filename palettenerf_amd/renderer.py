@@ -543,9 +543,10 @@ class PaletteRenderer(_RendererBase):
                                                                     self.grid_size, nears, fars, counter, self.mean_count, perturb, 128,
                                                                     force_all_rays, dt_gamma, max_steps)
             M = xyzs.shape[0]
-            sigmas, clip_feat, omega, offsets_radiance, view_dep, diffuse = self(xyzs, dirs)
+            # geometry is frozen here (sigma detached below, geo_feat inside the network): encoder + sigma_net as the fused density kernel
+            sigmas, clip_feat, omega, offsets_radiance, view_dep, diffuse = self(xyzs, dirs, frozen_density=bool(getattr(self, "fused_train_density", True)))
             offsets, radiance = offsets_radiance[..., :-1], offsets_radiance[..., -1:]
-            sigmas = (self.density_scale * sigmas).detach()  # geometry is frozen (palette/renderer.py:334-335)
+            sigmas = (self.density_scale * sigmas).detach()  # palette/renderer.py:334-335
             fused_shade = bool(getattr(self, "fused_train_shade", True)) and xyzs.is_cuda and nb <= 16
             radiance = radiance.reshape(M, 1, 1)
             offsets = offsets.reshape(M, nb, 3)
@@ -566,7 +567,7 @@ class PaletteRenderer(_RendererBase):
                 view_dep_norm = (view_dep ** 2).sum(dim=-1, keepdim=True)
             if self.require_smooth_loss:
                 xyzs_diff = (xyzs + torch.rand_like(xyzs) * self.bound * 0.03).clamp(-self.bound, self.bound)
-                _, clip_feat_diff, omega_diff, _, _, diffuse_diff = self(xyzs_diff, dirs)
+                _, clip_feat_diff, omega_diff, _, _, diffuse_diff = self(xyzs_diff, dirs, frozen_density=bool(getattr(self, "fused_train_density", True)))
                 omega_diff = omega_diff.reshape(M, nb, 1)
                 diffuse_diff = diffuse_diff.reshape(M, 3)
                 xyzs_weight = (xyzs - xyzs_diff).norm(dim=-1, keepdim=True) ** 2 / self.bound ** 2 / self.opt.smooth_sigma_xyz

@@ -19,7 +19,8 @@ def main():
             m = network.NeRFNetwork(bound=2, cuda_ray=True, min_near=0.2)
         scene.seed_field_(m, 0)
         m = m.to(dev).train()
-        for mode, start in (("full", 0), ("partial", 16)):
+        for fused, mode, start in ((False, "full", 0), (False, "partial", 16), (True, "full", 0), (True, "partial", 16)):
+            m.fused_field = fused
             for rep in range(3):
                 m.iter_density = start
                 m.update_extra_state()
@@ -30,7 +31,7 @@ def main():
                 m.iter_density = start
                 m.update_extra_state()
             torch.cuda.synchronize()
-            print(f"{kind} update_extra_state {mode}: {(time.perf_counter() - t0) / n * 1e3:.2f} ms, occupied {int((m.density_grid > 0).sum())}")
+            print(f"{kind} update_extra_state fused_density={fused} {mode}: {(time.perf_counter() - t0) / n * 1e3:.2f} ms, occupied {int((m.density_grid > 0).sum())}")
 
 
 if __name__ == "__main__":

@@ -806,3 +806,34 @@ def test_palette_train_shade_matches_the_torch_formulas(cuda, nb, clip_dim, has_
         rg, ab = palette_utils.palette_train_shade(o2, r2, vd2, df2, cf2, sm2, bc2, clip_dim)
         ((rg * w_rgb.to(cuda)).sum() + (ab * w_all.to(cuda)).sum()).backward()
         assert torch.equal(first, bc2.grad)
+
+
+@pytest.mark.parametrize("kind", ["nerf", "palette"])
+@pytest.mark.parametrize("precision", [0, 1])
+def test_fused_density_matches_the_torch_sigma_net(cuda, kind, precision):
+    """pnr_nerf_density_forward (hash-grid lookup + sigma_net on the matrix cores) against the torch modules: sigma 2e-5 relative,
+    geometry features 2e-5 absolute (fp32 GEMM order); both precision modes, both models, a batch that is not a multiple of the tile."""
+    from palettenerf_amd import network, renderer
+    from palettenerf_amd.fused import DensityFused
+    if kind == "nerf":
+        m = network.NeRFNetwork(bound=2, cuda_ray=True)
+    else:
+        m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True)
+    scene.seed_field_(m, 5)
+    m = m.to(cuda).eval()
+    g = torch.Generator().manual_seed(3)
+    x = ((torch.rand(100003, 3, generator=g) * 2 - 1) * 2).to(cuda)
+    with torch.no_grad():
+        want = m.density(x)                      # fused_field is off: torch modules over the HIP encoder
+    d = DensityFused(m)
+    d.precision = precision
+    sigma, geo = d(x)
+    np.testing.assert_allclose(host(sigma), host(want["sigma"]), rtol=2e-5, atol=1e-30)
+    np.testing.assert_allclose(host(geo), host(want["geo_feat"]), rtol=0, atol=2e-5)
+    s2, none = d(x, scale=30.0, want_geo=False)
+    assert none is None
+    np.testing.assert_allclose(host(s2), host(sigma) * np.float32(30.0), rtol=1e-6)
+    m.fused_field = True
+    with torch.no_grad():
+        got = m.density(x)                       # the module routes through the fused kernel now
+    assert torch.equal(got["sigma"], d(x)[0]) or precision == 0

@@ -92,10 +92,15 @@ def test_state_dict_names_match_reference_checkpoint_layout():
     assert id(m.basis_net[0].weight) not in names  # reference quirk 8: basis_net is not optimised
 
 
-def test_render_refuses_pure_torch_path():
-    m = network.NeRFNetwork(bound=2, cuda_ray=False)
+def test_render_without_cuda_ray():
+    """PaletteRenderer has no uniform-sampling path (palette/renderer.py:292-294 raises); NeRFRenderer dispatches to run(), whose HIP
+    operators refuse CPU tensors loudly (no CPU fallback in the product path)."""
+    p = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=False)
     with pytest.raises(ValueError):
-        m.render(torch.zeros(1, 4, 3), torch.zeros(1, 4, 3))
+        p.render(torch.zeros(1, 4, 3), torch.zeros(1, 4, 3))
+    m = network.NeRFNetwork(bound=2, cuda_ray=False)
+    with pytest.raises((RuntimeError, AssertionError)):
+        m.render(torch.zeros(1, 4, 3), torch.ones(1, 4, 3))
 
 
 # ------------------------------------------------------------------ exact lattice jump (csrc/lattice.hpp, compiled for the host)
