@@ -60,6 +60,11 @@ SIGNATURES = {
     "pnr_grid_encode_backward_binned": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _int, _u64, _ptr, _u64, _ptr],
     "pnr_linear_wgrad_workspace_bytes": [_u32, _u32, _u32],
     "pnr_linear_wgrad": [_ptr, _int, _ptr, _int, _u32, _u32, _u32, _ptr, _int, _ptr, _u64, _ptr],
+    "pnr_mlp_packed_bytes": [_ptr],
+    "pnr_mlp_pack": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "pnr_mlp_forward": [_ptr, _ptr, _ptr, _u32, _ptr, _ptr],
+    "pnr_mlp_backward_workspace_bytes": [_ptr, _u32],
+    "pnr_mlp_backward": [_ptr, _ptr, _ptr, _ptr, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _ptr],
     "pnr_linear_bgrad": [_ptr, _int, _u32, _u32, _ptr, _int, _ptr, _u64, _ptr],
     "pnr_palette_field_stages_aux": [_u32, _int],
     "pnr_interleave_tables": [_ptr, _ptr, _u64, _ptr, _ptr],
@@ -70,7 +75,12 @@ SIGNATURES = {
 }
 _RESTYPES = {"pnr_error_string": ctypes.c_char_p, "pnr_scan_scratch_bytes": _u64, "pnr_nerf_field_packed_bytes": _u64, "pnr_occupancy_mip_bytes": _u64, "pnr_nerf_frame_workspace_bytes": _u64, "pnr_palette_field_packed_bytes": _u64, "pnr_palette_frame_workspace_bytes": _u64,
              "pnr_palette_aux_channels": _u32, "pnr_linear_wgrad_workspace_bytes": _u64, "pnr_grid_backward_binned_workspace_bytes": _u64,
-             "pnr_palette_train_shade_workspace_bytes": _u64}
+             "pnr_palette_train_shade_workspace_bytes": _u64, "pnr_mlp_packed_bytes": _u64, "pnr_mlp_backward_workspace_bytes": _u64}
+
+class MlpDesc(ctypes.Structure):
+    """Mirror of `pnr_mlp_desc` (include/pnr.h)."""
+    _fields_ = [("n_layers", _u32), ("dims", _u32 * 4), ("activation", _int)]
+
 
 class NerfFrameArgs(ctypes.Structure):
     """Mirror of `pnr_nerf_frame_args` (include/pnr.h)."""

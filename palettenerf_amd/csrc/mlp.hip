@@ -1,0 +1,414 @@
+// mlp.hip -- the fields' small bias-free MLPs (2 or 3 layers, every width <= 64, ReLU or ELU between layers) as ONE launch forward
+// and ONE launch backward for training, on the gfx950 matrix cores (nerf/network.py:33-93, palette/network.py:60-153 build them as
+// nn.Linear(bias=False) stacks; autograd runs each as 3 library GEMMs + activation kernels forward and 2 GEMMs + an activation kernel per
+// layer backward, every one a round trip of a [6e5, 64] activation through HBM at ~2 TB/s).
+//
+// MI355X formulation: a wave owns a tile of 32 samples and keeps every activation of the tile feature-major in registers --
+// the D fragment of v_mfma_f32_32x32x2_f32 (register r of lane (s, h) = feature frag_row(r, h) of sample s) is exactly the B operand
+// the next layer needs, so a layer is a chain of MFMAs against weights staged once per workgroup in LDS (exact fp32 fma chains).
+// The backward recomputes the hidden activations from X (nothing but X and dY is read), propagates dY through the transposed
+// weights the same way, and forms the weight gradients dW_l = dZ_l^T A_{l-1} with the SAMPLE as the MFMA k dimension: the two operands
+// are written sample-major into a per-wave LDS tile and read back as "lane = feature, k = sample parity".  dW lives in accumulator
+// registers for the whole launch, is reduced over the 4 waves through LDS and over workgroups by a second tiny launch in a fixed
+// order (deterministic, no atomics).  HBM traffic: X and dY read once, dX written once.
+#include "field_core.hpp"
+
+namespace pnr {
+
+constexpr int kMlpThreads = 256;
+constexpr int kMlpWaves = kMlpThreads / PNR_WAVE;
+constexpr int kStage = 65;                       // floats per staged sample row (odd: conflict-free column walks)
+constexpr int kStageFloats = 32 * kStage;        // one 32-sample tile
+constexpr uint32_t kMlpMaxBlocks = 256;          // one persistent workgroup per CU
+__host__ __device__ constexpr uint32_t tiles32(uint32_t n) { return (n + 31u) / 32u; }
+
+struct MlpPlan {
+    uint32_t n_layers, act;
+    uint32_t dims[4];
+    uint32_t w_off[3], wt_off[3];    // float offsets of the packed W_l / W_l^T slots
+    uint32_t dw_off[3];              // float offsets of dW_l inside a partial row
+    uint32_t packed_floats, dw_floats;
+};
+
+// tiles of 32 features the kernels use at layer boundary d: what the width needs at the input and the output, always 2 at hidden
+// boundaries (zero padded), so that 8 kernel instances cover every stack
+__host__ __device__ inline uint32_t plan_tiles(const MlpPlan& p, uint32_t d) { return (d == 0 || d == p.n_layers) ? tiles32(p.dims[d]) : 2u; }
+
+static bool make_plan(const pnr_mlp_desc* d, MlpPlan& p) {
+    if (!d || d->n_layers < 2 || d->n_layers > 3 || (d->activation != 0 && d->activation != 1)) return false;
+    p.n_layers = d->n_layers;
+    p.act = (uint32_t)d->activation;
+    uint32_t off = 0, dw = 0;
+    for (uint32_t l = 0; l <= d->n_layers; l++) {
+        if (d->dims[l] == 0 || d->dims[l] > 64) return false;
+        p.dims[l] = d->dims[l];
+    }
+    for (uint32_t l = 0; l < d->n_layers; l++) { p.w_off[l] = off; off += plan_tiles(p, l + 1) * plan_tiles(p, l) * 1024; }
+    for (uint32_t l = 0; l < d->n_layers; l++) { p.wt_off[l] = off; off += plan_tiles(p, l + 1) * plan_tiles(p, l) * 1024; }
+    for (uint32_t l = 0; l < d->n_layers; l++) { p.dw_off[l] = dw; dw += p.dims[l + 1] * p.dims[l]; }
+    p.packed_floats = off;
+    p.dw_floats = dw;
+    return true;
+}
+
+struct MlpWeights { const float* w[3]; };
+struct MlpGrads { float* dw[3]; };
+
+// packed slot of a matrix M [rows][cols] (row-major source given by `transposed`): [row tile][k tile][r 0..15][lane] = M[rt*32 + lane%32][kt*32 + frag_row(r, lane/32)]
+__global__ void __launch_bounds__(256) k_mlp_pack(MlpPlan p, MlpWeights ws, float* __restrict__ packed) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= p.packed_floats) return;
+    for (uint32_t slot = 0; slot < 2 * p.n_layers; slot++) {
+        const bool tr = slot >= p.n_layers;
+        const uint32_t l = tr ? slot - p.n_layers : slot;
+        const uint32_t off = tr ? p.wt_off[l] : p.w_off[l];
+        const uint32_t in = p.dims[l], out = p.dims[l + 1];
+        const uint32_t rows = tr ? in : out, cols = tr ? out : in;
+        const uint32_t nkt = plan_tiles(p, tr ? l + 1 : l), size = plan_tiles(p, tr ? l : l + 1) * nkt * 1024;
+        if (e < off || e >= off + size) continue;
+        const uint32_t q = e - off, lane = q & 63, r = (q >> 6) & 15, t = q >> 10, kt = t % nkt, rt = t / nkt;
+        const uint32_t row = rt * 32 + (lane & 31), col = kt * 32 + (uint32_t)frag_row((int)r, (int)(lane >> 5));
+        float v = 0.0f;
+        if (row < rows && col < cols) v = tr ? ws.w[l][(size_t)col * in + row] : ws.w[l][(size_t)row * in + col];
+        packed[e] = v;
+        return;
+    }
+}
+
+// out[rt] = sum_kt W[rt][kt] . a[kt]  (feature-major fragments; NRT x NKT tiles of 32)
+template <int NRT, int NKT>
+__device__ __forceinline__ void mlp_layer(const float* __restrict__ wp, const f32x16 (&a)[2], f32x16 (&out)[2], int lane) {
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++) {
+        out[rt] = zero16();
+#pragma unroll
+        for (int kt = 0; kt < NKT; kt++) {
+            const float* w = wp + (size_t)((rt * NKT + kt) * 16) * 64;
+#pragma unroll
+            for (int r = 0; r < 16; r++) out[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r * 64 + lane], a[kt][r], out[rt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+__device__ __forceinline__ float act_fwd(float z, uint32_t act) { return act == 0 ? fmaxf(z, 0.0f) : (z > 0.0f ? z : expm1f(z)); }
+// derivative from the activation's OUTPUT (ReLU: h > 0; ELU, alpha 1: h > 0 ? 1 : h + 1)
+__device__ __forceinline__ float act_grad(float h, uint32_t act) { return h > 0.0f ? 1.0f : (act == 0 ? 0.0f : h + 1.0f); }
+
+template <int NT>
+__device__ __forceinline__ void apply_act(f32x16 (&v)[2], uint32_t act) {
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[t][r] = act_fwd(v[t][r], act);
+}
+template <int NT>
+__device__ __forceinline__ void mul_act_grad(f32x16 (&g)[2], const f32x16 (&h)[2], uint32_t act) {
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) g[t][r] *= act_grad(h[t][r], act);
+}
+
+// sample-major staging tile of one wave: buf[sample 0..31][feature 0..63] (row stride kStage)
+__device__ __forceinline__ void stage_from_global(float* __restrict__ buf, const float* __restrict__ g, uint32_t row0, uint32_t B, uint32_t width, int lane) {
+    for (uint32_t f = (uint32_t)lane; f < 32 * width; f += PNR_WAVE) {
+        const uint32_t r = f / width, c = f - r * width;
+        buf[r * kStage + c] = (row0 + r < B) ? g[(size_t)row0 * width + f] : 0.0f;
+    }
+    for (uint32_t f = (uint32_t)lane; f < 32 * (64 - width); f += PNR_WAVE) {   // zero the padding columns: they are MFMA operands too
+        const uint32_t r = f / (64 - width), c = f - r * (64 - width);
+        buf[r * kStage + width + c] = 0.0f;
+    }
+}
+__device__ __forceinline__ void stage_to_global(const float* __restrict__ buf, float* __restrict__ g, uint32_t row0, uint32_t B, uint32_t width, int lane) {
+    for (uint32_t f = (uint32_t)lane; f < 32 * width; f += PNR_WAVE) {
+        const uint32_t r = f / width, c = f - r * width;
+        if (row0 + r < B) g[(size_t)row0 * width + f] = buf[r * kStage + c];
+    }
+}
+template <int NT>
+__device__ __forceinline__ void frag_from_stage(const float* __restrict__ buf, int lane, f32x16 (&a)[2]) {
+    const int s = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) a[t][r] = buf[s * kStage + t * 32 + frag_row(r, h)];
+}
+template <int NT>
+__device__ __forceinline__ void frag_to_stage(float* __restrict__ buf, int lane, const f32x16 (&a)[2]) {
+    const int s = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) buf[s * kStage + t * 32 + frag_row(r, h)] = t < NT ? a[t][r] : 0.0f;   // absent tiles: zero operands
+}
+
+// acc[rt][ct] += sum over the tile's 32 samples of G[s][rt*32 + i] * A[s][ct*32 + j]   (G, A: staged sample-major tiles)
+template <int NRT, int NCT>
+__device__ __forceinline__ void wgrad_accumulate(f32x16 (&acc)[2][2], const float* __restrict__ G, const float* __restrict__ A, int lane) {
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ct++) {
+#pragma unroll
+            for (int p = 0; p < 16; p++)
+                acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(G[(2 * p + h) * kStage + rt * 32 + c], A[(2 * p + h) * kStage + ct * 32 + c], acc[rt][ct], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// tiles of 32 features at layer boundary d (0 = input ... NL = output); hidden widths always take 2 tiles (<= 64, zero padded)
+template <int NL, int TI, int TO>
+__host__ __device__ constexpr int tiles_at(int d) { return d == 0 ? TI : (d == NL ? TO : 2); }
+
+template <int NL, int TI, int TO>
+__global__ void __launch_bounds__(kMlpThreads) k_mlp_fwd(MlpPlan p, const float* __restrict__ packed, const float* __restrict__ x, uint32_t B, float* __restrict__ y) {
+    extern __shared__ float lds[];
+    float* w = lds;
+    const uint32_t wfloats = p.wt_off[0];   // forward slots only
+    for (uint32_t i = threadIdx.x * 4; i < wfloats; i += kMlpThreads * 4) *reinterpret_cast<float4*>(&w[i]) = *reinterpret_cast<const float4*>(&packed[i]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* stage = lds + wfloats + wave * kStageFloats;
+    __syncthreads();
+    const uint32_t nblock_tiles = (B + 32 * kMlpWaves - 1) / (32 * kMlpWaves);
+    for (uint32_t bt = blockIdx.x; bt < nblock_tiles; bt += gridDim.x) {
+        const uint32_t row0 = (bt * kMlpWaves + wave) * 32;
+        stage_from_global(stage, x, row0, B, p.dims[0], lane);
+        __syncthreads();
+        f32x16 a[2], o[2];
+        frag_from_stage<TI>(stage, lane, a);
+        mlp_layer<2, TI>(w + p.w_off[0], a, o, lane);
+        apply_act<2>(o, p.act);
+        if constexpr (NL == 3) {
+            mlp_layer<2, 2>(w + p.w_off[1], o, a, lane);
+            apply_act<2>(a, p.act);
+            mlp_layer<TO, 2>(w + p.w_off[2], a, o, lane);
+        } else {
+            mlp_layer<TO, 2>(w + p.w_off[1], o, a, lane);
+            o[0] = a[0];
+            if constexpr (TO == 2) o[1] = a[1];
+        }
+        __syncthreads();
+        frag_to_stage<TO>(stage, lane, o);
+        __syncthreads();
+        stage_to_global(stage, y, row0, B, p.dims[NL], lane);
+        __syncthreads();
+    }
+}
+
+template <int NL, int TI, int TO>
+__global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd(MlpPlan p, const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ dy,
+                                                         uint32_t B, float* __restrict__ dx, float* __restrict__ partial /* [gridDim.x][dw_floats] */) {
+    extern __shared__ float lds[];
+    float* w = lds;
+    for (uint32_t i = threadIdx.x * 4; i < p.packed_floats; i += kMlpThreads * 4) *reinterpret_cast<float4*>(&w[i]) = *reinterpret_cast<const float4*>(&packed[i]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* GA = lds + p.packed_floats + wave * 2 * kStageFloats;   // gradient side of the weight-gradient products
+    float* GB = GA + kStageFloats;                                 // activation side
+    __syncthreads();
+    f32x16 dw0[2][2], dw1[2][2], dw2[2][2];   // only the tiles a layer has are touched (the others are never materialised)
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) { dw0[i][j] = zero16(); dw1[i][j] = zero16(); dw2[i][j] = zero16(); }
+    const uint32_t nblock_tiles = (B + 32 * kMlpWaves - 1) / (32 * kMlpWaves);
+    for (uint32_t bt = blockIdx.x; bt < nblock_tiles; bt += gridDim.x) {
+        const uint32_t row0 = (bt * kMlpWaves + wave) * 32;
+        stage_from_global(GB, x, row0, B, p.dims[0], lane);
+        stage_from_global(GA, dy, row0, B, p.dims[NL], lane);
+        __syncthreads();
+        // recompute the hidden activations h1 (after layer 0) and h2 (after layer 1, NL == 3)
+        f32x16 xin[2], h1[2], h2[2], g[2], t[2];
+        frag_from_stage<TI>(GB, lane, xin);
+        frag_from_stage<TO>(GA, lane, g);
+        mlp_layer<2, TI>(w + p.w_off[0], xin, h1, lane);
+        apply_act<2>(h1, p.act);
+        if constexpr (NL == 3) {
+            mlp_layer<2, 2>(w + p.w_off[1], h1, h2, lane);
+            apply_act<2>(h2, p.act);
+            // layer 2: GA = dY, GB <- h2
+            __syncthreads();
+            frag_to_stage<2>(GB, lane, h2);
+            __syncthreads();
+            wgrad_accumulate<TO, 2>(dw2, GA, GB, lane);
+            mlp_layer<2, TO>(w + p.wt_off[2], g, t, lane);          // dH2 = W2^T dY
+            mul_act_grad<2>(t, h2, p.act);
+            g[0] = t[0]; g[1] = t[1];
+            // layer 1: GA <- dZ2, GB <- h1
+            __syncthreads();
+            frag_to_stage<2>(GA, lane, g);
+            frag_to_stage<2>(GB, lane, h1);
+            __syncthreads();
+            wgrad_accumulate<2, 2>(dw1, GA, GB, lane);
+            mlp_layer<2, 2>(w + p.wt_off[1], g, t, lane);           // dH1 = W1^T dZ2
+            mul_act_grad<2>(t, h1, p.act);
+            g[0] = t[0]; g[1] = t[1];
+        } else {
+            // layer 1 (the last): GA = dY, GB <- h1
+            __syncthreads();
+            frag_to_stage<2>(GB, lane, h1);
+            __syncthreads();
+            wgrad_accumulate<TO, 2>(dw1, GA, GB, lane);
+            mlp_layer<2, TO>(w + p.wt_off[1], g, t, lane);          // dH1 = W1^T dY
+            mul_act_grad<2>(t, h1, p.act);
+            g[0] = t[0]; g[1] = t[1];
+        }
+        // layer 0: GA <- dZ1, GB <- X
+        __syncthreads();
+        frag_to_stage<2>(GA, lane, g);
+        stage_from_global(GB, x, row0, B, p.dims[0], lane);
+        __syncthreads();
+        wgrad_accumulate<2, TI>(dw0, GA, GB, lane);
+        if (dx) {
+            mlp_layer<TI, 2>(w + p.wt_off[0], g, t, lane);          // dX = W0^T dZ1
+            __syncthreads();
+            frag_to_stage<TI>(GA, lane, t);
+            __syncthreads();
+            stage_to_global(GA, dx, row0, B, p.dims[0], lane);
+        }
+        __syncthreads();
+    }
+    // reduce the 4 waves' dW through LDS (the staging area: 8 tiles of 2080 floats >= 64 x 64 x 3), then one partial row per workgroup
+    float* red = lds + p.packed_floats;
+    __syncthreads();
+    float* out = partial + (size_t)blockIdx.x * p.dw_floats;
+    const int c = lane & 31, hh = lane >> 5;
+    for (int wv = 0; wv < kMlpWaves; wv++) {
+        if (wave == wv) {
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                const uint32_t in = p.dims[l], outd = p.dims[l + 1];
+#pragma unroll
+                for (int rt = 0; rt < tiles_at<NL, TI, TO>(l + 1); rt++)
+#pragma unroll
+                    for (int ct = 0; ct < tiles_at<NL, TI, TO>(l); ct++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const uint32_t row = rt * 32 + frag_row(r, hh), col = ct * 32 + c;
+                            if (row < outd && col < in) {
+                                float* q = red + p.dw_off[l] + row * in + col;
+                                const float v = l == 0 ? dw0[rt][ct][r] : (l == 1 ? dw1[rt][ct][r] : dw2[rt][ct][r]);
+                                *q = (wv == 0 ? 0.0f : *q) + v;
+                            }
+                        }
+            }
+        }
+        __syncthreads();
+    }
+    for (uint32_t e = threadIdx.x; e < p.dw_floats; e += kMlpThreads) out[e] = red[e];
+}
+
+// dw[e] = sum over the workgroup partials in a fixed order (8 groups of 32 columns per workgroup)
+__global__ void __launch_bounds__(256) k_mlp_dw_reduce(const float* __restrict__ partial, uint32_t nparts, MlpPlan p, MlpGrads gr) {
+    __shared__ float red[8][32];
+    const uint32_t c = threadIdx.x & 31u, g = threadIdx.x >> 5;
+    const uint32_t e = blockIdx.x * 32 + c;
+    float s = 0.0f;
+    if (e < p.dw_floats)
+        for (uint32_t q = g; q < nparts; q += 8) s += partial[(size_t)q * p.dw_floats + e];
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0 && e < p.dw_floats) {
+        float t = red[0][c];
+#pragma unroll
+        for (int k = 1; k < 8; k++) t += red[k][c];
+        for (uint32_t l = 0; l < p.n_layers; l++) {
+            const uint32_t n = p.dims[l] * p.dims[l + 1];
+            if (e >= p.dw_off[l] && e < p.dw_off[l] + n && gr.dw[l]) gr.dw[l][e - p.dw_off[l]] = t;
+        }
+    }
+}
+
+static uint32_t mlp_blocks(uint32_t B) {
+    const uint32_t t = cdiv(B, 32 * kMlpWaves);
+    return t < kMlpMaxBlocks ? (t ? t : 1) : kMlpMaxBlocks;
+}
+
+}  // namespace pnr
+
+using namespace pnr;
+
+extern "C" {
+
+uint64_t pnr_mlp_packed_bytes(const pnr_mlp_desc* desc) {
+    MlpPlan p;
+    return make_plan(desc, p) ? (uint64_t)p.packed_floats * 4 : 0;
+}
+
+int pnr_mlp_pack(const pnr_mlp_desc* desc, const float* w0, const float* w1, const float* w2, float* packed, pnr_stream_t stream) {
+    MlpPlan p;
+    if (!make_plan(desc, p)) return PNR_ERR_UNSUPPORTED;
+    if (!w0 || !w1 || (p.n_layers == 3 && !w2) || !packed) return PNR_ERR_INVALID;
+    MlpWeights ws{{w0, w1, w2}};
+    hipLaunchKernelGGL(k_mlp_pack, dim3(cdiv(p.packed_floats, 256)), dim3(256), 0, as_stream(stream), p, ws, packed);
+    return check_launch();
+}
+
+#define PNR_MLP_DISPATCH(KERNEL, NLV, TIV, TOV, ...)                                                                                           \
+    do {                                                                                                                                       \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL<NLV, TIV, TOV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=  \
+            hipSuccess)                                                                                                                        \
+            return PNR_ERR_LAUNCH;                                                                                                             \
+        hipLaunchKernelGGL((KERNEL<NLV, TIV, TOV>), dim3(grid), dim3(kMlpThreads), lds, s, __VA_ARGS__);                                       \
+    } while (0)
+#define PNR_MLP_SWITCH(KERNEL, ...)                                                                   \
+    do {                                                                                              \
+        const int ti = (int)tiles32(p.dims[0]), to = (int)tiles32(p.dims[p.n_layers]);                \
+        if (p.n_layers == 2) {                                                                        \
+            if (ti == 1 && to == 1) PNR_MLP_DISPATCH(KERNEL, 2, 1, 1, __VA_ARGS__);                   \
+            else if (ti == 1) PNR_MLP_DISPATCH(KERNEL, 2, 1, 2, __VA_ARGS__);                         \
+            else if (to == 1) PNR_MLP_DISPATCH(KERNEL, 2, 2, 1, __VA_ARGS__);                         \
+            else PNR_MLP_DISPATCH(KERNEL, 2, 2, 2, __VA_ARGS__);                                      \
+        } else {                                                                                      \
+            if (ti == 1 && to == 1) PNR_MLP_DISPATCH(KERNEL, 3, 1, 1, __VA_ARGS__);                   \
+            else if (ti == 1) PNR_MLP_DISPATCH(KERNEL, 3, 1, 2, __VA_ARGS__);                         \
+            else if (to == 1) PNR_MLP_DISPATCH(KERNEL, 3, 2, 1, __VA_ARGS__);                         \
+            else PNR_MLP_DISPATCH(KERNEL, 3, 2, 2, __VA_ARGS__);                                      \
+        }                                                                                             \
+    } while (0)
+
+int pnr_mlp_forward(const pnr_mlp_desc* desc, const float* packed, const float* x, uint32_t B, float* y, pnr_stream_t stream) {
+    MlpPlan p;
+    if (!make_plan(desc, p)) return PNR_ERR_UNSUPPORTED;
+    if (B == 0) return PNR_OK;
+    if (!packed || !x || !y) return PNR_ERR_INVALID;
+    const size_t lds = ((size_t)p.wt_off[0] + kMlpWaves * kStageFloats) * 4;
+    if (lds > 160 * 1024) return PNR_ERR_UNSUPPORTED;
+    hipStream_t s = as_stream(stream);
+    const uint32_t tiles = cdiv(B, 32 * kMlpWaves), grid = tiles < 2 * kMlpMaxBlocks ? tiles : 2 * kMlpMaxBlocks;   // two workgroups per CU
+    PNR_MLP_SWITCH(k_mlp_fwd, p, packed, x, B, y);
+    return check_launch();
+}
+
+uint64_t pnr_mlp_backward_workspace_bytes(const pnr_mlp_desc* desc, uint32_t B) {
+    MlpPlan p;
+    if (!make_plan(desc, p)) return 0;
+    return (uint64_t)mlp_blocks(B) * p.dw_floats * 4;
+}
+
+int pnr_mlp_backward(const pnr_mlp_desc* desc, const float* packed, const float* x, const float* dy, uint32_t B, float* dx, float* dw0, float* dw1,
+                     float* dw2, void* workspace, uint64_t workspace_bytes, pnr_stream_t stream) {
+    MlpPlan p;
+    if (!make_plan(desc, p)) return PNR_ERR_UNSUPPORTED;
+    hipStream_t s = as_stream(stream);
+    MlpGrads gr{{dw0, dw1, dw2}};
+    if (B == 0) {
+        for (uint32_t l = 0; l < p.n_layers; l++)
+            if (gr.dw[l] && hipMemsetAsync(gr.dw[l], 0, (size_t)p.dims[l] * p.dims[l + 1] * 4, s) != hipSuccess) return PNR_ERR_LAUNCH;
+        return PNR_OK;
+    }
+    if (!packed || !x || !dy || !workspace) return PNR_ERR_INVALID;
+    if (workspace_bytes < pnr_mlp_backward_workspace_bytes(desc, B)) return PNR_ERR_INVALID;
+    const size_t lds = ((size_t)p.packed_floats + kMlpWaves * 2 * kStageFloats) * 4;
+    if (lds > 160 * 1024 || p.dw_floats > (uint32_t)(kMlpWaves * 2 * kStageFloats)) return PNR_ERR_UNSUPPORTED;
+    const uint32_t blocks = mlp_blocks(B), grid = blocks;
+    float* partial = static_cast<float*>(workspace);
+    PNR_MLP_SWITCH(k_mlp_bwd, p, packed, x, dy, B, dx, partial);
+    hipLaunchKernelGGL(k_mlp_dw_reduce, dim3(cdiv(p.dw_floats, 32)), dim3(256), 0, s, partial, blocks, p, gr);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -11,6 +11,7 @@ import torch.nn.functional as F
 from .activation import trunc_exp
 from .encoding import get_encoder
 from .linear import Linear
+from .mlp import run_mlp
 from .renderer import NeRFRenderer, PaletteRenderer
 
 
@@ -20,11 +21,8 @@ def _mlp(dims):
 
 
 def _run(net, h, act=F.relu):
-    for i, layer in enumerate(net):
-        h = layer(h)
-        if i != len(net) - 1:
-            h = act(h, inplace=True)
-    return h
+    """The reference's layer loop; on the GPU under autograd the whole stack is one fused launch each way (mlp.run_mlp)."""
+    return run_mlp(net, h, act)
 
 
 def density_fused(model):

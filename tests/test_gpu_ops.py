@@ -837,3 +837,61 @@ def test_fused_density_matches_the_torch_sigma_net(cuda, kind, precision):
     with torch.no_grad():
         got = m.density(x)                       # the module routes through the fused kernel now
     assert torch.equal(got["sigma"], d(x)[0]) or precision == 0
+
+
+@pytest.mark.parametrize("dims,act", [((31, 64, 64, 3), "relu"), ((15, 64, 64, 3), "relu"), ((35, 64, 15), "elu"), ((32, 64, 16), "relu"),
+                                      ((7, 20, 40), "elu"), ((64, 33, 64, 16), "relu")])
+def test_fused_mlp_forward_backward_match_float64(cuda, dims, act):
+    """pnr_mlp_forward / pnr_mlp_backward (csrc/mlp.hip) against the layer loop in float64: output 2e-6 relative to the largest output,
+    dX and every dW 2e-5 relative to that gradient's largest entry (fp32 accumulation over 5e4 samples).  Shapes of every net of both
+    fields plus odd widths and a batch that is not a multiple of the 128-sample workgroup tile; dW is deterministic."""
+    import torch.nn.functional as F
+    from palettenerf_amd import mlp
+    torch.manual_seed(sum(dims))
+    B = 50000 + 77
+    net = torch.nn.ModuleList([torch.nn.Linear(dims[i], dims[i + 1], bias=False) for i in range(len(dims) - 1)]).to(cuda)
+    for l in net:
+        torch.nn.init.normal_(l.weight, std=1.0 / l.in_features ** 0.5)
+    fact = F.relu if act == "relu" else F.elu
+    x = torch.randn(B, dims[0], device=cuda, requires_grad=True)
+    wy = torch.randn(B, dims[-1], device=cuda)
+    # a hidden unit whose pre-activation is within rounding of 0 may sit on either side of the kink in fp32 and float64: such samples
+    # (a handful in 5e4 x 128 units) get no output gradient, so that the derivative choice cannot matter
+    with torch.no_grad():
+        hd, zmin = x.detach().double().cpu(), torch.full((B,), 1e9, dtype=torch.float64)
+        for i, l in enumerate(net[:-1]):
+            z = hd @ l.weight.detach().double().cpu().t()
+            zmin = torch.minimum(zmin, z.abs().min(dim=1).values)
+            hd = fact(z)
+        ambiguous = zmin < 2e-6
+        assert int(ambiguous.sum()) < 200
+        wy[ambiguous.to(cuda)] = 0.0
+    assert mlp.fusable(net, x, fact)
+    y = mlp.run_mlp(net, x, fact)
+    (y * wy).sum().backward()
+    got = [x.grad.clone()] + [l.weight.grad.clone() for l in net]
+    # float64 reference on the host
+    xd = x.detach().double().cpu().requires_grad_(True)
+    wd = [l.weight.detach().double().cpu().requires_grad_(True) for l in net]
+    h = xd
+    for i, w in enumerate(wd):
+        h = h @ w.t()
+        if i != len(wd) - 1:
+            h = fact(h)
+    (h * wy.double().cpu()).sum().backward()
+    want = [xd.grad] + [w.grad for w in wd]
+    scale = float(h.abs().max())
+    assert float((y.detach().double().cpu() - h.detach()).abs().max()) <= 2e-6 * scale
+    for name, a, b in zip(["dx"] + [f"dw{i}" for i in range(len(wd))], got, want):
+        err, ref = float((a.double().cpu() - b).abs().max()), float(b.abs().max())
+        assert err <= 2e-5 * ref, (name, err, ref)
+    for l in net:
+        l.weight.grad = None
+    x.grad = None
+    (mlp.run_mlp(net, x, fact) * wy).sum().backward()
+    assert all(torch.equal(l.weight.grad, g) for l, g in zip(net, got[1:]))
+    # no input gradient wanted: same dW
+    for l in net:
+        l.weight.grad = None
+    (mlp.run_mlp(net, x.detach(), fact) * wy).sum().backward()
+    assert all(torch.equal(l.weight.grad, g) for l, g in zip(net, got[1:]))
