@@ -18,7 +18,7 @@ namespace pnr {
 constexpr int kMlpThreads = 256;
 constexpr int kMlpWaves = kMlpThreads / PNR_WAVE;
 constexpr int kStage = 65;                       // floats per staged sample row (odd: conflict-free column walks)
-constexpr int kStageFloats = 32 * kStage;        // one 32-sample tile
+constexpr int kStageFloats = 33 * kStage;        // one 32-sample tile + a row that swallows the lanes beyond the tile
 constexpr uint32_t kMlpMaxBlocks = 256;          // one persistent workgroup per CU
 __host__ __device__ constexpr uint32_t tiles32(uint32_t n) { return (n + 31u) / 32u; }
 
@@ -28,6 +28,7 @@ struct MlpPlan {
     uint32_t w_off[3], wt_off[3];    // float offsets of the packed W_l / W_l^T slots
     uint32_t dw_off[3];              // float offsets of dW_l inside a partial row
     uint32_t packed_floats, dw_floats;
+    uint32_t magic[4];               // floor(2^32 / dims[d]) + 1: f / dims[d] = umulhi(f, magic[d]) exactly for f < 2^16
 };
 
 // tiles of 32 features the kernels use at layer boundary d: what the width needs at the input and the output, always 2 at hidden
@@ -42,6 +43,7 @@ static bool make_plan(const pnr_mlp_desc* d, MlpPlan& p) {
     for (uint32_t l = 0; l <= d->n_layers; l++) {
         if (d->dims[l] == 0 || d->dims[l] > 64) return false;
         p.dims[l] = d->dims[l];
+        p.magic[l] = (uint32_t)((1ull << 32) / d->dims[l]) + 1u;
     }
     for (uint32_t l = 0; l < d->n_layers; l++) { p.w_off[l] = off; off += plan_tiles(p, l + 1) * plan_tiles(p, l) * 1024; }
     for (uint32_t l = 0; l < d->n_layers; l++) { p.wt_off[l] = off; off += plan_tiles(p, l + 1) * plan_tiles(p, l) * 1024; }
@@ -91,42 +93,87 @@ __device__ __forceinline__ void mlp_layer(const float* __restrict__ wp, const f3
     }
 }
 
-__device__ __forceinline__ float act_fwd(float z, uint32_t act) { return act == 0 ? fmaxf(z, 0.0f) : (z > 0.0f ? z : expm1f(z)); }
+// ELU without a divergent call: exp(min(z, 0)) - 1 is within 6e-8 absolute of expm1 (the activations are O(1)); selected by sign
+__device__ __forceinline__ float act_fwd(float z, int act) {
+    if (act == 0) return fmaxf(z, 0.0f);
+    const float e = expf(fminf(z, 0.0f)) - 1.0f;
+    return z > 0.0f ? z : e;
+}
 // derivative from the activation's OUTPUT (ReLU: h > 0; ELU, alpha 1: h > 0 ? 1 : h + 1)
-__device__ __forceinline__ float act_grad(float h, uint32_t act) { return h > 0.0f ? 1.0f : (act == 0 ? 0.0f : h + 1.0f); }
+__device__ __forceinline__ float act_grad(float h, int act) { return h > 0.0f ? 1.0f : (act == 0 ? 0.0f : h + 1.0f); }
 
 template <int NT>
-__device__ __forceinline__ void apply_act(f32x16 (&v)[2], uint32_t act) {
+__device__ __forceinline__ void apply_act(f32x16 (&v)[2], int act) {
 #pragma unroll
     for (int t = 0; t < NT; t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) v[t][r] = act_fwd(v[t][r], act);
 }
 template <int NT>
-__device__ __forceinline__ void mul_act_grad(f32x16 (&g)[2], const f32x16 (&h)[2], uint32_t act) {
+__device__ __forceinline__ void mul_act_grad(f32x16 (&g)[2], const f32x16 (&h)[2], int act) {
 #pragma unroll
     for (int t = 0; t < NT; t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) g[t][r] *= act_grad(h[t][r], act);
 }
 
-// sample-major staging tile of one wave: buf[sample 0..31][feature 0..63] (row stride kStage)
-__device__ __forceinline__ void stage_from_global(float* __restrict__ buf, const float* __restrict__ g, uint32_t row0, uint32_t B, uint32_t width, int lane) {
-    for (uint32_t f = (uint32_t)lane; f < 32 * width; f += PNR_WAVE) {
-        const uint32_t r = f / width, c = f - r * width;
-        buf[r * kStage + c] = (row0 + r < B) ? g[(size_t)row0 * width + f] : 0.0f;
-    }
-    for (uint32_t f = (uint32_t)lane; f < 32 * (64 - width); f += PNR_WAVE) {   // zero the padding columns: they are MFMA operands too
-        const uint32_t r = f / (64 - width), c = f - r * (64 - width);
-        buf[r * kStage + width + c] = 0.0f;
+// The staging tiles are private to a wave: its LDS instructions execute in issue order, so a later read sees an earlier write of any
+// lane of the same wave; all that is needed is that the compiler keeps the program order (no workgroup barrier, waves run independently).
+// A fence or __syncthreads() here would also drain vmcnt, i.e. wait for the next tile's prefetch right away.
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+
+// sample-major staging tile of one wave: buf[sample 0..31][feature 0..63] (row stride kStage), row 32 = trash.
+// A wave's 32 x width tile is held raw in registers (element f = lane + 64 k of the row-major tile): the NEXT tile's global loads are
+// issued before the current tile's matrix work and land while it runs (one wave per SIMD: nothing else would hide them).  Everything is
+// branch-free: loads clamp their index and select 0 past the end of the array, lanes beyond the tile write the trash row.
+template <int NT>
+__device__ __forceinline__ void raw_load(float (&v)[16 * NT], const float* __restrict__ g, uint32_t row0, uint32_t B, uint32_t width, int lane) {
+    const uint32_t total = B * width, base = row0 * width;
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++)
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) {
+        const int k = kt * 16 + kk;
+        // nothing but the load here: any use of the value (even a select) would make the compiler wait for it on the spot and
+        // serialise the tile's loads; elements past the end of the array are zeroed when the tile is staged (raw_to_stage)
+        // (registers that lie wholly beyond the tile re-read a few lines of the following tiles: cheaper than 16 uniform branches, which
+        // also derail the register allocator)
+        const uint32_t e = base + (uint32_t)lane + 64u * k;
+        v[k] = g[e < total ? e : total - 1u];
     }
 }
-__device__ __forceinline__ void stage_to_global(const float* __restrict__ buf, float* __restrict__ g, uint32_t row0, uint32_t B, uint32_t width, int lane) {
-    for (uint32_t f = (uint32_t)lane; f < 32 * width; f += PNR_WAVE) {
-        const uint32_t r = f / width, c = f - r * width;
-        if (row0 + r < B) g[(size_t)row0 * width + f] = buf[r * kStage + c];
+template <int NT>
+__device__ __forceinline__ void raw_to_stage(float* __restrict__ buf, const float (&v)[16 * NT], uint32_t row0, uint32_t B, uint32_t width, uint32_t magic,
+                                             int lane) {
+    const uint32_t total = B * width, base = row0 * width;
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++)
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) {
+        const int k = kt * 16 + kk;
+        const uint32_t f = (uint32_t)lane + 64u * k;
+        uint32_t r = __umulhi(f, magic);
+        const uint32_t c = f - r * width;
+        r = r < 32u ? r : 32u;
+        buf[r * kStage + c] = base + f < total ? v[k] : 0.0f;
+    }
+    // zero the padding columns (they are MFMA operands too): lane = (row, parity), columns width + parity, width + parity + 2, ...
+    for (uint32_t c = width + ((uint32_t)lane >> 5); c < 32u * NT; c += 2) buf[((uint32_t)lane & 31u) * kStage + c] = 0.0f;
+}
+template <int NT>
+__device__ __forceinline__ void stage_to_global(const float* __restrict__ buf, float* __restrict__ g, uint32_t row0, uint32_t B, uint32_t width, uint32_t magic, int lane) {
+    const uint32_t total = B * width, base = row0 * width;
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++)
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) {
+        const int k = kt * 16 + kk;
+        const uint32_t f = (uint32_t)lane + 64u * k;
+        const uint32_t r = __umulhi(f, magic), c = f - r * width;
+        if (r < 32u && base + f < total) g[base + f] = buf[r * kStage + c];
     }
 }
+
 template <int NT>
 __device__ __forceinline__ void frag_from_stage(const float* __restrict__ buf, int lane, f32x16 (&a)[2]) {
     const int s = lane & 31, h = lane >> 5;
@@ -164,7 +211,7 @@ __device__ __forceinline__ void wgrad_accumulate(f32x16 (&acc)[2][2], const floa
 template <int NL, int TI, int TO>
 __host__ __device__ constexpr int tiles_at(int d) { return d == 0 ? TI : (d == NL ? TO : 2); }
 
-template <int NL, int TI, int TO>
+template <int NL, int TI, int TO, int ACT>
 __global__ void __launch_bounds__(kMlpThreads) k_mlp_fwd(MlpPlan p, const float* __restrict__ packed, const float* __restrict__ x, uint32_t B, float* __restrict__ y) {
     extern __shared__ float lds[];
     float* w = lds;
@@ -174,32 +221,35 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_fwd(MlpPlan p, const float*
     float* stage = lds + wfloats + wave * kStageFloats;
     __syncthreads();
     const uint32_t nblock_tiles = (B + 32 * kMlpWaves - 1) / (32 * kMlpWaves);
+    float xr[16 * TI];
+    raw_load<TI>(xr, x, (blockIdx.x * kMlpWaves + wave) * 32, B, p.dims[0], lane);
     for (uint32_t bt = blockIdx.x; bt < nblock_tiles; bt += gridDim.x) {
         const uint32_t row0 = (bt * kMlpWaves + wave) * 32;
-        stage_from_global(stage, x, row0, B, p.dims[0], lane);
-        __syncthreads();
+        raw_to_stage<TI>(stage, xr, row0, B, p.dims[0], p.magic[0], lane);
+        wave_sync();
+        raw_load<TI>(xr, x, ((bt + gridDim.x) * kMlpWaves + wave) * 32, B, p.dims[0], lane);   // the next tile's loads fly during this one's matrix work
         f32x16 a[2], o[2];
         frag_from_stage<TI>(stage, lane, a);
         mlp_layer<2, TI>(w + p.w_off[0], a, o, lane);
-        apply_act<2>(o, p.act);
+        apply_act<2>(o, ACT);
         if constexpr (NL == 3) {
             mlp_layer<2, 2>(w + p.w_off[1], o, a, lane);
-            apply_act<2>(a, p.act);
+            apply_act<2>(a, ACT);
             mlp_layer<TO, 2>(w + p.w_off[2], a, o, lane);
         } else {
             mlp_layer<TO, 2>(w + p.w_off[1], o, a, lane);
             o[0] = a[0];
             if constexpr (TO == 2) o[1] = a[1];
         }
-        __syncthreads();
+        wave_sync();
         frag_to_stage<TO>(stage, lane, o);
-        __syncthreads();
-        stage_to_global(stage, y, row0, B, p.dims[NL], lane);
-        __syncthreads();
+        wave_sync();
+        stage_to_global<TO>(stage, y, row0, B, p.dims[NL], p.magic[NL], lane);
+        wave_sync();
     }
 }
 
-template <int NL, int TI, int TO>
+template <int NL, int TI, int TO, int ACT>
 __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd(MlpPlan p, const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ dy,
                                                          uint32_t B, float* __restrict__ dx, float* __restrict__ partial /* [gridDim.x][dw_floats] */) {
     extern __shared__ float lds[];
@@ -215,61 +265,67 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd(MlpPlan p, const float*
 #pragma unroll
         for (int j = 0; j < 2; j++) { dw0[i][j] = zero16(); dw1[i][j] = zero16(); dw2[i][j] = zero16(); }
     const uint32_t nblock_tiles = (B + 32 * kMlpWaves - 1) / (32 * kMlpWaves);
+    float xr[16 * TI], yn[16 * TO];
+    raw_load<TI>(xr, x, (blockIdx.x * kMlpWaves + wave) * 32, B, p.dims[0], lane);
+    raw_load<TO>(yn, dy, (blockIdx.x * kMlpWaves + wave) * 32, B, p.dims[NL], lane);
     for (uint32_t bt = blockIdx.x; bt < nblock_tiles; bt += gridDim.x) {
         const uint32_t row0 = (bt * kMlpWaves + wave) * 32;
-        stage_from_global(GB, x, row0, B, p.dims[0], lane);
-        stage_from_global(GA, dy, row0, B, p.dims[NL], lane);
-        __syncthreads();
+        raw_to_stage<TI>(GB, xr, row0, B, p.dims[0], p.magic[0], lane);
+        raw_to_stage<TO>(GA, yn, row0, B, p.dims[NL], p.magic[NL], lane);
+        wave_sync();
+        const uint32_t next0 = ((bt + gridDim.x) * kMlpWaves + wave) * 32;
+        raw_load<TO>(yn, dy, next0, B, p.dims[NL], lane);          // the next tile's dY flies during this tile's matrix work
         // recompute the hidden activations h1 (after layer 0) and h2 (after layer 1, NL == 3)
         f32x16 xin[2], h1[2], h2[2], g[2], t[2];
         frag_from_stage<TI>(GB, lane, xin);
         frag_from_stage<TO>(GA, lane, g);
         mlp_layer<2, TI>(w + p.w_off[0], xin, h1, lane);
-        apply_act<2>(h1, p.act);
+        apply_act<2>(h1, ACT);
         if constexpr (NL == 3) {
             mlp_layer<2, 2>(w + p.w_off[1], h1, h2, lane);
-            apply_act<2>(h2, p.act);
+            apply_act<2>(h2, ACT);
             // layer 2: GA = dY, GB <- h2
-            __syncthreads();
+            wave_sync();
             frag_to_stage<2>(GB, lane, h2);
-            __syncthreads();
+            wave_sync();
             wgrad_accumulate<TO, 2>(dw2, GA, GB, lane);
             mlp_layer<2, TO>(w + p.wt_off[2], g, t, lane);          // dH2 = W2^T dY
-            mul_act_grad<2>(t, h2, p.act);
+            mul_act_grad<2>(t, h2, ACT);
             g[0] = t[0]; g[1] = t[1];
             // layer 1: GA <- dZ2, GB <- h1
-            __syncthreads();
+            wave_sync();
             frag_to_stage<2>(GA, lane, g);
             frag_to_stage<2>(GB, lane, h1);
-            __syncthreads();
+            wave_sync();
             wgrad_accumulate<2, 2>(dw1, GA, GB, lane);
             mlp_layer<2, 2>(w + p.wt_off[1], g, t, lane);           // dH1 = W1^T dZ2
-            mul_act_grad<2>(t, h1, p.act);
+            mul_act_grad<2>(t, h1, ACT);
             g[0] = t[0]; g[1] = t[1];
         } else {
             // layer 1 (the last): GA = dY, GB <- h1
-            __syncthreads();
+            wave_sync();
             frag_to_stage<2>(GB, lane, h1);
-            __syncthreads();
+            wave_sync();
             wgrad_accumulate<TO, 2>(dw1, GA, GB, lane);
             mlp_layer<2, TO>(w + p.wt_off[1], g, t, lane);          // dH1 = W1^T dY
-            mul_act_grad<2>(t, h1, p.act);
+            mul_act_grad<2>(t, h1, ACT);
             g[0] = t[0]; g[1] = t[1];
         }
         // layer 0: GA <- dZ1, GB <- X
-        __syncthreads();
+        wave_sync();
         frag_to_stage<2>(GA, lane, g);
-        stage_from_global(GB, x, row0, B, p.dims[0], lane);
-        __syncthreads();
+        raw_to_stage<TI>(GB, xr, row0, B, p.dims[0], p.magic[0], lane);
+        wave_sync();
+        raw_load<TI>(xr, x, next0, B, p.dims[0], lane);            // X is needed twice per tile: its prefetch starts after the second use
         wgrad_accumulate<2, TI>(dw0, GA, GB, lane);
         if (dx) {
             mlp_layer<TI, 2>(w + p.wt_off[0], g, t, lane);          // dX = W0^T dZ1
-            __syncthreads();
+            wave_sync();
             frag_to_stage<TI>(GA, lane, t);
-            __syncthreads();
-            stage_to_global(GA, dx, row0, B, p.dims[0], lane);
+            wave_sync();
+            stage_to_global<TI>(GA, dx, row0, B, p.dims[0], p.magic[0], lane);
         }
-        __syncthreads();
+        wave_sync();
     }
     // reduce the 4 waves' dW through LDS (the staging area: 8 tiles of 2080 floats >= 64 x 64 x 3), then one partial row per workgroup
     float* red = lds + p.packed_floats;
@@ -349,10 +405,17 @@ int pnr_mlp_pack(const pnr_mlp_desc* desc, const float* w0, const float* w1, con
 
 #define PNR_MLP_DISPATCH(KERNEL, NLV, TIV, TOV, ...)                                                                                           \
     do {                                                                                                                                       \
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL<NLV, TIV, TOV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=  \
-            hipSuccess)                                                                                                                        \
-            return PNR_ERR_LAUNCH;                                                                                                             \
-        hipLaunchKernelGGL((KERNEL<NLV, TIV, TOV>), dim3(grid), dim3(kMlpThreads), lds, s, __VA_ARGS__);                                       \
+        if (p.act == 0) {                                                                                                                      \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL<NLV, TIV, TOV, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                    (int)lds) != hipSuccess)                                                                                   \
+                return PNR_ERR_LAUNCH;                                                                                                         \
+            hipLaunchKernelGGL((KERNEL<NLV, TIV, TOV, 0>), dim3(grid), dim3(kMlpThreads), lds, s, __VA_ARGS__);                                \
+        } else {                                                                                                                               \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL<NLV, TIV, TOV, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                    (int)lds) != hipSuccess)                                                                                   \
+                return PNR_ERR_LAUNCH;                                                                                                         \
+            hipLaunchKernelGGL((KERNEL<NLV, TIV, TOV, 1>), dim3(grid), dim3(kMlpThreads), lds, s, __VA_ARGS__);                                \
+        }                                                                                                                                      \
     } while (0)
 #define PNR_MLP_SWITCH(KERNEL, ...)                                                                   \
     do {                                                                                              \
