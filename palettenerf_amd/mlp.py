@@ -3,7 +3,8 @@
 `run_mlp(net, h, act)` is what `network._run` calls: the reference's layer loop (nerf/network.py:101-106, 113-118; palette/network.py:164-168,
 240-262) `for l: h = net[l](h); if l != last: h = act(h)`.  On CUDA fp32 batches of at least MIN_ROWS rows with gradients enabled, 2 or 3
 bias-free layers of width <= 64 and ReLU / ELU between them, it runs `pnr_mlp_forward` / `pnr_mlp_backward` (hidden activations recomputed
-in the backward, weight gradients reduced deterministically); otherwise the plain torch loop.
+in the backward, weight gradients reduced deterministically); otherwise the plain torch loop.  Under fp16 autocast the fused path still
+computes in fp32 (inputs cast up, fp32 out): faster than the half GEMM chain here and at least as accurate.
 """
 import ctypes
 
@@ -29,6 +30,7 @@ def _desc(dims, act):
 
 class _FusedMLP(torch.autograd.Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)   # under autocast: fp32 in, fp32 out (at least the accuracy of the half GEMMs)
     def forward(ctx, x, act, *weights):
         dims = [weights[0].shape[1]] + [w.shape[0] for w in weights]
         desc = _desc(dims, act)
@@ -46,6 +48,7 @@ class _FusedMLP(torch.autograd.Function):
         return y.reshape(*x.shape[:-1], dims[-1])
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy):
         x2, packed = ctx.saved_tensors
         dims, act = ctx.dims, ctx.act
@@ -65,7 +68,9 @@ class _FusedMLP(torch.autograd.Function):
 
 
 def fusable(net, h, act):
-    if not (enabled and h.is_cuda and h.dtype == torch.float32 and torch.is_grad_enabled() and not torch.is_autocast_enabled()):
+    if not (enabled and h.is_cuda and h.dtype in (torch.float32, torch.float16) and torch.is_grad_enabled()):
+        return False
+    if h.dtype == torch.float16 and not torch.is_autocast_enabled():
         return False
     if act not in _ACT or len(net) not in (2, 3) or h.numel() // h.shape[-1] < MIN_ROWS:
         return False
