@@ -125,7 +125,7 @@ class PaletteNetwork(PaletteRenderer):
 
     def forward(self, x, d, frozen_density=False):
         """palette/network.py:156-185.  Returns sigma, clip_feat, omega, offsets_radiance, view_dep, diffuse.
-        frozen_density: the caller detaches sigma (PaletteNeRF training, palette/renderer.py:334-335; geo_feat is detached here anyway), so
+        frozen_density: the caller detaches sigma (PaletteNeRF training, palette/renderer.py:333-334; geo_feat is detached here anyway), so
         encoder + sigma_net may run as the fused no-gradient density kernel."""
         if frozen_density and x.is_cuda and _fused_arch_ok(self):   # also under autocast: fp32 tables and MFMA chains, no gradient needed
             sigma, geo_feat = density_fused(self)(x)

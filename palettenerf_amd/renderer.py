@@ -546,7 +546,7 @@ class PaletteRenderer(_RendererBase):
             # geometry is frozen here (sigma detached below, geo_feat inside the network): encoder + sigma_net as the fused density kernel
             sigmas, clip_feat, omega, offsets_radiance, view_dep, diffuse = self(xyzs, dirs, frozen_density=bool(getattr(self, "fused_train_density", True)))
             offsets, radiance = offsets_radiance[..., :-1], offsets_radiance[..., -1:]
-            sigmas = (self.density_scale * sigmas).detach()  # palette/renderer.py:334-335
+            sigmas = (self.density_scale * sigmas).detach()  # palette/renderer.py:333-334
             fused_shade = bool(getattr(self, "fused_train_shade", True)) and xyzs.is_cuda and nb <= 16
             radiance = radiance.reshape(M, 1, 1)
             offsets = offsets.reshape(M, nb, 3)
