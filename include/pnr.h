@@ -349,6 +349,17 @@ uint64_t pnr_mlp_backward_workspace_bytes(const pnr_mlp_desc* desc, uint32_t B);
 int pnr_mlp_backward(const pnr_mlp_desc* desc, const float* packed, const float* x, const float* dy, uint32_t B, float* dx, float* dw0, float* dw1,
                      float* dw2, void* workspace, uint64_t workspace_bytes, pnr_stream_t stream);
 
+/* The same with the first 32 input columns taken straight from a hash-grid encoder output in its native level-major layout
+ * enc [16][B][2] (pnr_grid_encode_forward's `outputs`) and the remaining dims[0] - 32 columns from a row-major x_tail [B, dims[0]-32]
+ * (NULL when dims[0] == 32): replaces `torch.cat([encoder(x), tail])` + the [L,B,C] -> [B,L*C] copy of gridencoder/grid.py:57-58 in
+ * front of sigma_net (nerf/network.py:99-101) and basis_net (palette/network.py:257-260).  The backward returns the encoder part of dX in
+ * level-major layout too (what pnr_grid_encode_backward[_binned] takes as `grad`); the tail gets no gradient (the reference detaches it). */
+int pnr_mlp_forward_lm(const pnr_mlp_desc* desc, const float* packed, const float* enc_level_major, uint32_t levels, const float* x_tail, uint32_t B, float* y,
+                       pnr_stream_t stream);
+int pnr_mlp_backward_lm(const pnr_mlp_desc* desc, const float* packed, const float* enc_level_major, uint32_t levels, const float* x_tail, const float* dy,
+                        uint32_t B, float* denc_level_major, float* dw0, float* dw1, float* dw2, void* workspace, uint64_t workspace_bytes,
+                        pnr_stream_t stream);
+
 /* bias gradient of a dense layer with bias (palette/network.py:111 offsets_radiance_net, the only one): db[o] = sum_b dY[b][o];
  * workspace of pnr_linear_wgrad_workspace_bytes(B, 1, out_dim) */
 int pnr_linear_bgrad(const void* dy, int dy_dtype, uint32_t B, uint32_t out_dim, float* db, int accumulate, void* workspace, uint64_t workspace_bytes,

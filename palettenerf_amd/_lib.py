@@ -65,6 +65,8 @@ SIGNATURES = {
     "pnr_mlp_forward": [_ptr, _ptr, _ptr, _u32, _ptr, _ptr],
     "pnr_mlp_backward_workspace_bytes": [_ptr, _u32],
     "pnr_mlp_backward": [_ptr, _ptr, _ptr, _ptr, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _ptr],
+    "pnr_mlp_forward_lm": [_ptr, _ptr, _ptr, _u32, _ptr, _u32, _ptr, _ptr],
+    "pnr_mlp_backward_lm": [_ptr, _ptr, _ptr, _u32, _ptr, _ptr, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _ptr],
     "pnr_linear_bgrad": [_ptr, _int, _u32, _u32, _ptr, _int, _ptr, _u64, _ptr],
     "pnr_palette_field_stages_aux": [_u32, _int],
     "pnr_interleave_tables": [_ptr, _ptr, _u64, _ptr, _ptr],

@@ -29,6 +29,7 @@ struct MlpPlan {
     uint32_t dw_off[3];              // float offsets of dW_l inside a partial row
     uint32_t packed_floats, dw_floats;
     uint32_t magic[4];               // floor(2^32 / dims[d]) + 1: f / dims[d] = umulhi(f, magic[d]) exactly for f < 2^16
+    uint32_t lm, tail, tail_magic;   // lm = 1: the first 32 input columns come from a level-major encoder output [16][B][2], `tail` more from a row-major [B][tail]
 };
 
 // tiles of 32 features the kernels use at layer boundary d: what the width needs at the input and the output, always 2 at hidden
@@ -50,6 +51,8 @@ static bool make_plan(const pnr_mlp_desc* d, MlpPlan& p) {
     for (uint32_t l = 0; l < d->n_layers; l++) { p.dw_off[l] = dw; dw += p.dims[l + 1] * p.dims[l]; }
     p.packed_floats = off;
     p.dw_floats = dw;
+    p.lm = p.tail = 0;
+    p.tail_magic = 1;
     return true;
 }
 
@@ -174,6 +177,53 @@ __device__ __forceinline__ void stage_to_global(const float* __restrict__ buf, f
     }
 }
 
+// X whose first 32 columns are a hash-grid encoder output in its native level-major layout enc [16][B][2] (no [B,32] copy is ever made) and
+// whose remaining `tail` columns (NT == 2) are a row-major [B][tail] tensor.  A level's 32 samples x 2 channels of a tile are 64
+// contiguous floats: one coalesced load per level, register k = level k; registers 16.. hold the tail like raw_load.
+template <int NT>
+__device__ __forceinline__ void raw_load_lm(float (&v)[16 * NT], const float* __restrict__ enc, const float* __restrict__ tail_src, uint32_t wt, uint32_t row0,
+                                            uint32_t B, int lane) {
+    const uint32_t total = B * 2u, e = row0 * 2u + (uint32_t)lane, ec = e < total ? e : total - 1u;
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = enc[(size_t)k * total + ec];
+    if constexpr (NT == 2) {
+        const uint32_t ttotal = B * wt, tbase = row0 * wt;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t t = tbase + (uint32_t)lane + 64u * k;
+            v[16 + k] = ttotal ? tail_src[t < ttotal ? t : ttotal - 1u] : 0.0f;
+        }
+    }
+}
+template <int NT>
+__device__ __forceinline__ void raw_to_stage_lm(float* __restrict__ buf, const float (&v)[16 * NT], uint32_t wt, uint32_t tail_magic, uint32_t row0, uint32_t B,
+                                                int lane) {
+    const uint32_t r0 = (uint32_t)lane >> 1, ch = (uint32_t)lane & 1u;
+    const bool live = row0 + r0 < B;
+#pragma unroll
+    for (int k = 0; k < 16; k++) buf[r0 * kStage + 2 * k + ch] = live ? v[k] : 0.0f;
+    if constexpr (NT == 2) {
+        const uint32_t ttotal = B * wt, tbase = row0 * wt;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t f = (uint32_t)lane + 64u * k;
+            uint32_t r = __umulhi(f, tail_magic);
+            const uint32_t c = f - r * wt;
+            r = r < 32u ? r : 32u;
+            buf[r * kStage + 32 + c] = tbase + f < ttotal ? v[16 + k] : 0.0f;
+        }
+        for (uint32_t c = 32u + wt + ((uint32_t)lane >> 5); c < 64u; c += 2) buf[((uint32_t)lane & 31u) * kStage + c] = 0.0f;
+    }
+}
+// dX of the level-major columns back in level-major layout [16][B][2] (what the table-gradient kernels take)
+__device__ __forceinline__ void stage_to_global_lm(const float* __restrict__ buf, float* __restrict__ denc, uint32_t row0, uint32_t B, int lane) {
+    const uint32_t r0 = (uint32_t)lane >> 1, ch = (uint32_t)lane & 1u;
+    if (row0 + r0 < B) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) denc[((size_t)k * B + row0) * 2u + (uint32_t)lane] = buf[r0 * kStage + 2 * k + ch];
+    }
+}
+
 template <int NT>
 __device__ __forceinline__ void frag_from_stage(const float* __restrict__ buf, int lane, f32x16 (&a)[2]) {
     const int s = lane & 31, h = lane >> 5;
@@ -212,7 +262,8 @@ template <int NL, int TI, int TO>
 __host__ __device__ constexpr int tiles_at(int d) { return d == 0 ? TI : (d == NL ? TO : 2); }
 
 template <int NL, int TI, int TO, int ACT>
-__global__ void __launch_bounds__(kMlpThreads) k_mlp_fwd(MlpPlan p, const float* __restrict__ packed, const float* __restrict__ x, uint32_t B, float* __restrict__ y) {
+__global__ void __launch_bounds__(kMlpThreads) k_mlp_fwd(MlpPlan p, const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ x_tail, uint32_t B,
+                                                         float* __restrict__ y) {
     extern __shared__ float lds[];
     float* w = lds;
     const uint32_t wfloats = p.wt_off[0];   // forward slots only
@@ -222,12 +273,15 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_fwd(MlpPlan p, const float*
     __syncthreads();
     const uint32_t nblock_tiles = (B + 32 * kMlpWaves - 1) / (32 * kMlpWaves);
     float xr[16 * TI];
-    raw_load<TI>(xr, x, (blockIdx.x * kMlpWaves + wave) * 32, B, p.dims[0], lane);
+    if (p.lm) raw_load_lm<TI>(xr, x, x_tail, p.tail, (blockIdx.x * kMlpWaves + wave) * 32, B, lane);
+    else raw_load<TI>(xr, x, (blockIdx.x * kMlpWaves + wave) * 32, B, p.dims[0], lane);
     for (uint32_t bt = blockIdx.x; bt < nblock_tiles; bt += gridDim.x) {
         const uint32_t row0 = (bt * kMlpWaves + wave) * 32;
-        raw_to_stage<TI>(stage, xr, row0, B, p.dims[0], p.magic[0], lane);
+        if (p.lm) raw_to_stage_lm<TI>(stage, xr, p.tail, p.tail_magic, row0, B, lane);
+        else raw_to_stage<TI>(stage, xr, row0, B, p.dims[0], p.magic[0], lane);
         wave_sync();
-        raw_load<TI>(xr, x, ((bt + gridDim.x) * kMlpWaves + wave) * 32, B, p.dims[0], lane);   // the next tile's loads fly during this one's matrix work
+        if (p.lm) raw_load_lm<TI>(xr, x, x_tail, p.tail, ((bt + gridDim.x) * kMlpWaves + wave) * 32, B, lane);   // the next tile's loads fly during this one's matrix work
+        else raw_load<TI>(xr, x, ((bt + gridDim.x) * kMlpWaves + wave) * 32, B, p.dims[0], lane);
         f32x16 a[2], o[2];
         frag_from_stage<TI>(stage, lane, a);
         mlp_layer<2, TI>(w + p.w_off[0], a, o, lane);
@@ -250,7 +304,7 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_fwd(MlpPlan p, const float*
 }
 
 template <int NL, int TI, int TO, int ACT>
-__global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd(MlpPlan p, const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ dy,
+__global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd(MlpPlan p, const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ x_tail, const float* __restrict__ dy,
                                                          uint32_t B, float* __restrict__ dx, float* __restrict__ partial /* [gridDim.x][dw_floats] */) {
     extern __shared__ float lds[];
     float* w = lds;
@@ -266,11 +320,13 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd(MlpPlan p, const float*
         for (int j = 0; j < 2; j++) { dw0[i][j] = zero16(); dw1[i][j] = zero16(); dw2[i][j] = zero16(); }
     const uint32_t nblock_tiles = (B + 32 * kMlpWaves - 1) / (32 * kMlpWaves);
     float xr[16 * TI], yn[16 * TO];
-    raw_load<TI>(xr, x, (blockIdx.x * kMlpWaves + wave) * 32, B, p.dims[0], lane);
+    if (p.lm) raw_load_lm<TI>(xr, x, x_tail, p.tail, (blockIdx.x * kMlpWaves + wave) * 32, B, lane);
+    else raw_load<TI>(xr, x, (blockIdx.x * kMlpWaves + wave) * 32, B, p.dims[0], lane);
     raw_load<TO>(yn, dy, (blockIdx.x * kMlpWaves + wave) * 32, B, p.dims[NL], lane);
     for (uint32_t bt = blockIdx.x; bt < nblock_tiles; bt += gridDim.x) {
         const uint32_t row0 = (bt * kMlpWaves + wave) * 32;
-        raw_to_stage<TI>(GB, xr, row0, B, p.dims[0], p.magic[0], lane);
+        if (p.lm) raw_to_stage_lm<TI>(GB, xr, p.tail, p.tail_magic, row0, B, lane);
+        else raw_to_stage<TI>(GB, xr, row0, B, p.dims[0], p.magic[0], lane);
         raw_to_stage<TO>(GA, yn, row0, B, p.dims[NL], p.magic[NL], lane);
         wave_sync();
         const uint32_t next0 = ((bt + gridDim.x) * kMlpWaves + wave) * 32;
@@ -314,16 +370,19 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd(MlpPlan p, const float*
         // layer 0: GA <- dZ1, GB <- X
         wave_sync();
         frag_to_stage<2>(GA, lane, g);
-        raw_to_stage<TI>(GB, xr, row0, B, p.dims[0], p.magic[0], lane);
+        if (p.lm) raw_to_stage_lm<TI>(GB, xr, p.tail, p.tail_magic, row0, B, lane);
+        else raw_to_stage<TI>(GB, xr, row0, B, p.dims[0], p.magic[0], lane);
         wave_sync();
-        raw_load<TI>(xr, x, next0, B, p.dims[0], lane);            // X is needed twice per tile: its prefetch starts after the second use
+        if (p.lm) raw_load_lm<TI>(xr, x, x_tail, p.tail, next0, B, lane);   // X is needed twice per tile: its prefetch starts after the second use
+        else raw_load<TI>(xr, x, next0, B, p.dims[0], lane);
         wgrad_accumulate<2, TI>(dw0, GA, GB, lane);
         if (dx) {
             mlp_layer<TI, 2>(w + p.wt_off[0], g, t, lane);          // dX = W0^T dZ1
             wave_sync();
             frag_to_stage<TI>(GA, lane, t);
             wave_sync();
-            stage_to_global<TI>(GA, dx, row0, B, p.dims[0], p.magic[0], lane);
+            if (p.lm) stage_to_global_lm(GA, dx, row0, B, lane);
+            else stage_to_global<TI>(GA, dx, row0, B, p.dims[0], p.magic[0], lane);
         }
         wave_sync();
     }
@@ -433,17 +492,38 @@ int pnr_mlp_pack(const pnr_mlp_desc* desc, const float* w0, const float* w1, con
         }                                                                                             \
     } while (0)
 
-int pnr_mlp_forward(const pnr_mlp_desc* desc, const float* packed, const float* x, uint32_t B, float* y, pnr_stream_t stream) {
+// lm_levels: 0 = x is row-major [B, dims[0]]; 16 = x is a level-major encoder output [16][B][2] followed by x_tail [B, dims[0] - 32]
+static int plan_sources(MlpPlan& p, uint32_t lm_levels, const float* x_tail) {
+    if (lm_levels == 0) return PNR_OK;
+    if (lm_levels != 16 || p.dims[0] < 32) return PNR_ERR_UNSUPPORTED;
+    p.lm = 1;
+    p.tail = p.dims[0] - 32;
+    if (p.tail && !x_tail) return PNR_ERR_INVALID;
+    p.tail_magic = p.tail ? (uint32_t)((1ull << 32) / p.tail) + 1u : 1u;
+    return PNR_OK;
+}
+
+static int mlp_forward_impl(const pnr_mlp_desc* desc, const float* packed, const float* x, uint32_t lm_levels, const float* x_tail, uint32_t B, float* y,
+                            pnr_stream_t stream) {
     MlpPlan p;
     if (!make_plan(desc, p)) return PNR_ERR_UNSUPPORTED;
     if (B == 0) return PNR_OK;
     if (!packed || !x || !y) return PNR_ERR_INVALID;
+    if (int rc = plan_sources(p, lm_levels, x_tail)) return rc;
     const size_t lds = ((size_t)p.wt_off[0] + kMlpWaves * kStageFloats) * 4;
     if (lds > 160 * 1024) return PNR_ERR_UNSUPPORTED;
     hipStream_t s = as_stream(stream);
     const uint32_t tiles = cdiv(B, 32 * kMlpWaves), grid = tiles < 2 * kMlpMaxBlocks ? tiles : 2 * kMlpMaxBlocks;   // two workgroups per CU
-    PNR_MLP_SWITCH(k_mlp_fwd, p, packed, x, B, y);
+    PNR_MLP_SWITCH(k_mlp_fwd, p, packed, x, x_tail, B, y);
     return check_launch();
+}
+
+int pnr_mlp_forward(const pnr_mlp_desc* desc, const float* packed, const float* x, uint32_t B, float* y, pnr_stream_t stream) {
+    return mlp_forward_impl(desc, packed, x, 0, nullptr, B, y, stream);
+}
+int pnr_mlp_forward_lm(const pnr_mlp_desc* desc, const float* packed, const float* enc_level_major, uint32_t levels, const float* x_tail, uint32_t B, float* y,
+                       pnr_stream_t stream) {
+    return mlp_forward_impl(desc, packed, enc_level_major, levels, x_tail, B, y, stream);
 }
 
 uint64_t pnr_mlp_backward_workspace_bytes(const pnr_mlp_desc* desc, uint32_t B) {
@@ -452,10 +532,11 @@ uint64_t pnr_mlp_backward_workspace_bytes(const pnr_mlp_desc* desc, uint32_t B) 
     return (uint64_t)mlp_blocks(B) * p.dw_floats * 4;
 }
 
-int pnr_mlp_backward(const pnr_mlp_desc* desc, const float* packed, const float* x, const float* dy, uint32_t B, float* dx, float* dw0, float* dw1,
-                     float* dw2, void* workspace, uint64_t workspace_bytes, pnr_stream_t stream) {
+static int mlp_backward_impl(const pnr_mlp_desc* desc, const float* packed, const float* x, uint32_t lm_levels, const float* x_tail, const float* dy,
+                             uint32_t B, float* dx, float* dw0, float* dw1, float* dw2, void* workspace, uint64_t workspace_bytes, pnr_stream_t stream) {
     MlpPlan p;
     if (!make_plan(desc, p)) return PNR_ERR_UNSUPPORTED;
+    if (int rc = plan_sources(p, lm_levels, x_tail)) return rc;
     hipStream_t s = as_stream(stream);
     MlpGrads gr{{dw0, dw1, dw2}};
     if (B == 0) {
@@ -469,9 +550,19 @@ int pnr_mlp_backward(const pnr_mlp_desc* desc, const float* packed, const float*
     if (lds > 160 * 1024 || p.dw_floats > (uint32_t)(kMlpWaves * 2 * kStageFloats)) return PNR_ERR_UNSUPPORTED;
     const uint32_t blocks = mlp_blocks(B), grid = blocks;
     float* partial = static_cast<float*>(workspace);
-    PNR_MLP_SWITCH(k_mlp_bwd, p, packed, x, dy, B, dx, partial);
+    PNR_MLP_SWITCH(k_mlp_bwd, p, packed, x, x_tail, dy, B, dx, partial);
     hipLaunchKernelGGL(k_mlp_dw_reduce, dim3(cdiv(p.dw_floats, 32)), dim3(256), 0, s, partial, blocks, p, gr);
     return check_launch();
+}
+
+int pnr_mlp_backward(const pnr_mlp_desc* desc, const float* packed, const float* x, const float* dy, uint32_t B, float* dx, float* dw0, float* dw1,
+                     float* dw2, void* workspace, uint64_t workspace_bytes, pnr_stream_t stream) {
+    return mlp_backward_impl(desc, packed, x, 0, nullptr, dy, B, dx, dw0, dw1, dw2, workspace, workspace_bytes, stream);
+}
+int pnr_mlp_backward_lm(const pnr_mlp_desc* desc, const float* packed, const float* enc_level_major, uint32_t levels, const float* x_tail, const float* dy,
+                        uint32_t B, float* denc_level_major, float* dw0, float* dw1, float* dw2, void* workspace, uint64_t workspace_bytes,
+                        pnr_stream_t stream) {
+    return mlp_backward_impl(desc, packed, enc_level_major, levels, x_tail, dy, B, denc_level_major, dw0, dw1, dw2, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

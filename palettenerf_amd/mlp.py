@@ -92,3 +92,99 @@ def run_mlp(net, h, act=F.relu):
         if i != len(net) - 1:
             h = act(h, inplace=True)
     return h
+
+
+class _EncodeMLP(torch.autograd.Function):
+    """hash-grid lookup -> (optional tail columns) -> bias-free MLP with the encoder output kept level-major end to end
+    (pnr_grid_encode_forward -> pnr_mlp_forward_lm; backward pnr_mlp_backward_lm -> pnr_grid_encode_backward_binned): no [L,B,C] <-> [B,L*C]
+    copies, no torch.cat.  x01 [B,3] in [0,1] (no gradient), tail [B,t] or None (no gradient)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x01, embeddings, offsets, meta, tail, act, *weights):
+        from .gridencoder import _u32, _f32, _int     # ctypes aliases
+        S, H, gridtype, align_corners = meta
+        x01 = x01.contiguous()
+        B = x01.shape[0]
+        L = offsets.shape[0] - 1
+        dev = x01.device
+        emb = embeddings.detach().contiguous()
+        enc = torch.empty(L, B, 2, device=dev, dtype=torch.float32)
+        call("pnr_grid_encode_forward", ptr(x01), ptr(emb), ptr(offsets), ptr(enc), _u32(B), _u32(3), _u32(2), _u32(L), _f32(S), _u32(H), None, _u32(gridtype),
+             _int(int(align_corners)), _int(0), units=B)
+        t = 0 if tail is None else tail.shape[1]
+        dims = [L * 2 + t] + [w.shape[0] for w in weights]
+        desc = _desc(dims, act)
+        lib = _lib.load()
+        packed = torch.empty(int(lib.pnr_mlp_packed_bytes(ctypes.byref(desc))) // 4, dtype=torch.float32, device=dev)
+        ws = [w.detach().contiguous() for w in weights]
+        call("pnr_mlp_pack", ctypes.byref(desc), ptr(ws[0]), ptr(ws[1]), ptr(ws[2]) if len(ws) == 3 else None, ptr(packed))
+        tail_c = None if tail is None else tail.detach().contiguous()
+        y = torch.empty(B, dims[-1], dtype=torch.float32, device=dev)
+        call("pnr_mlp_forward_lm", ctypes.byref(desc), ptr(packed), ptr(enc), ctypes.c_uint32(L), ptr(tail_c), ctypes.c_uint32(B), ptr(y))
+        ctx.save_for_backward(x01, offsets, enc, tail_c, packed)
+        ctx.dims, ctx.act, ctx.meta, ctx.rows = dims, act, meta, emb.shape[0]
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        from .gridencoder import _u32, _f32, _int
+        x01, offsets, enc, tail_c, packed = ctx.saved_tensors
+        dims, act = ctx.dims, ctx.act
+        S, H, gridtype, align_corners = ctx.meta
+        desc = _desc(dims, act)
+        lib = _lib.load()
+        dev = x01.device
+        B, L = x01.shape[0], offsets.shape[0] - 1
+        dy2 = dy.reshape(-1, dims[-1]).contiguous().float()
+        want_emb = ctx.needs_input_grad[1]
+        denc = torch.empty(L, B, 2, device=dev, dtype=torch.float32) if want_emb else None
+        n = len(dims) - 1
+        dws = [torch.empty(dims[l + 1], dims[l], dtype=torch.float32, device=dev) if ctx.needs_input_grad[6 + l] else None for l in range(n)]
+        nbytes = int(lib.pnr_mlp_backward_workspace_bytes(ctypes.byref(desc), B))
+        ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
+        call("pnr_mlp_backward_lm", ctypes.byref(desc), ptr(packed), ptr(enc), ctypes.c_uint32(L), ptr(tail_c), ptr(dy2), ctypes.c_uint32(B), ptr(denc),
+             ptr(dws[0]), ptr(dws[1]), ptr(dws[2]) if n == 3 else None, ptr(ws), ctypes.c_uint64(nbytes))
+        grad_emb = None
+        if want_emb:
+            grad_emb = torch.zeros(ctx.rows, 2, device=dev, dtype=torch.float32)
+            gb = int(lib.pnr_grid_backward_binned_workspace_bytes(B, L, ctx.rows))
+            gws = torch.empty(gb // 4 + 1, dtype=torch.int32, device=dev)
+            call("pnr_grid_encode_backward_binned", ptr(denc), ptr(x01), ptr(offsets), ptr(grad_emb), _u32(B), _u32(3), _u32(2), _u32(L), _f32(S), _u32(H),
+                 _u32(gridtype), _int(int(align_corners)), ctypes.c_uint64(ctx.rows), ptr(gws), ctypes.c_uint64(gb))
+        return (None, grad_emb, None, None, None, None, *dws)
+
+
+def encode_mlp(encoder, x, bound, tail, net, act=F.relu):
+    """`_run(net, cat([encoder(x, bound), tail]), act)` -- fused end to end when it can be (CUDA fp32 hash grid with 16 levels x 2 features,
+    a large batch, no gradient wanted for x or tail), the plain composition otherwise."""
+    from .gridencoder import BINNED_MIN_ROWS
+    import numpy as np
+    ok = (enabled and x.is_cuda and torch.is_grad_enabled() and not x.requires_grad and (tail is None or not tail.requires_grad)
+          and getattr(encoder, "num_levels", 0) == 16 and getattr(encoder, "level_dim", 0) == 2 and getattr(encoder, "input_dim", 0) == 3
+          and hasattr(encoder, "embeddings") and encoder.embeddings.dtype == torch.float32 and x.numel() // 3 >= max(MIN_ROWS, BINNED_MIN_ROWS)
+          and x.numel() // 3 * 16 * 8 < 2 ** 32)
+    if ok:
+        ok = net[0].in_features == 32 + (0 if tail is None else tail.shape[-1]) and fusable(net, _Rows(x.numel() // 3, net[0].in_features, x), act)
+    if not ok:
+        h = encoder(x, bound=bound)
+        if tail is not None:
+            h = torch.cat([h, tail], dim=-1)
+        return run_mlp(net, h, act)
+    x01 = ((x + bound) / (2 * bound)).reshape(-1, 3)   # same two roundings as GridEncoder.forward (gridencoder/grid.py:142)
+    meta = (float(np.log2(encoder.per_level_scale)), int(encoder.base_resolution), int(encoder.gridtype_id), bool(encoder.align_corners))
+    t2 = None if tail is None else tail.reshape(-1, tail.shape[-1])
+    y = _EncodeMLP.apply(x01, encoder.embeddings, encoder.offsets, meta, t2, _ACT[act], *[l.weight for l in net])
+    return y.reshape(*x.shape[:-1], y.shape[-1])
+
+
+class _Rows:
+    """Stand-in with the attributes `fusable` looks at (the [rows, in] input is never materialised on the fused path)."""
+
+    def __init__(self, rows, width, like):
+        self.is_cuda, self.dtype, self.shape, self.requires_grad = like.is_cuda, torch.float32, (rows, width), False
+        self._n = rows * width
+
+    def numel(self):
+        return self._n

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 from .activation import trunc_exp
 from .encoding import get_encoder
 from .linear import Linear
-from .mlp import run_mlp
+from .mlp import encode_mlp, run_mlp
 from .renderer import NeRFRenderer, PaletteRenderer
 
 
@@ -64,7 +64,7 @@ class NeRFNetwork(NeRFRenderer):
                 from .fused import NeRFFieldFused
                 self._fused = NeRFFieldFused(self)
             return self._fused(x, d)
-        h = _run(self.sigma_net, self.encoder(x, bound=self.bound))
+        h = encode_mlp(self.encoder, x, self.bound, None, self.sigma_net)
         sigma = trunc_exp(h[..., 0])
         geo_feat = h[..., 1:]
         h = _run(self.color_net, torch.cat([self.encoder_dir(d), geo_feat], dim=-1))
@@ -75,7 +75,7 @@ class NeRFNetwork(NeRFRenderer):
         if _fused_density_ok(self, x):
             sigma, geo = density_fused(self)(x)
             return {"sigma": sigma, "geo_feat": geo}
-        h = _run(self.sigma_net, self.encoder(x, bound=self.bound))
+        h = encode_mlp(self.encoder, x, self.bound, None, self.sigma_net)
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
 
     def color(self, x, d, mask=None, geo_feat=None, **kwargs):
@@ -130,11 +130,11 @@ class PaletteNetwork(PaletteRenderer):
         if frozen_density and x.is_cuda and _fused_arch_ok(self):   # also under autocast: fp32 tables and MFMA chains, no gradient needed
             sigma, geo_feat = density_fused(self)(x)
         else:
-            h = _run(self.sigma_net, self.encoder(x, bound=self.bound))
+            h = encode_mlp(self.encoder, x, self.bound, None, self.sigma_net)
             sigma = trunc_exp(h[..., 0])
             geo_feat = h[..., 1:].detach()
         if self.opt.pred_clip:
-            clip_feat = _run(self.clip_net, self.encoder_clip(x, bound=self.bound))
+            clip_feat = encode_mlp(self.encoder_clip, x, self.bound, None, self.clip_net)
         else:
             clip_feat = torch.zeros_like(sigma[..., None].repeat(1, self.opt.clip_dim))
         omega, offsets_radiance, view_dep, diffuse = self.color(x, d, geo_feat=geo_feat)
@@ -144,7 +144,7 @@ class PaletteNetwork(PaletteRenderer):
         if _fused_density_ok(self, x):
             sigma, geo = density_fused(self)(x)
             return {"sigma": sigma, "geo_feat": geo}
-        h = _run(self.sigma_net, self.encoder(x, bound=self.bound))
+        h = encode_mlp(self.encoder, x, self.bound, None, self.sigma_net)
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
 
     def color(self, x, d, mask=None, geo_feat=None, **kwargs):
@@ -154,8 +154,7 @@ class PaletteNetwork(PaletteRenderer):
         g = geo_feat.detach()
         diffuse = torch.sigmoid(_run(self.diff_net, g))
         view_dep = torch.sigmoid(_run(self.color_net, torch.cat([self.encoder_dir(d), g], dim=-1)))
-        h = torch.cat([self.encoder_palette(x, bound=self.bound), diffuse.detach()], dim=-1)
-        h = _run(self.basis_net, h, act=F.elu)
+        h = encode_mlp(self.encoder_palette, x, self.bound, diffuse.detach(), self.basis_net, act=F.elu)   # cat([encoder_palette(x), diffuse]) -> basis_net
         offsets_radiance = self.offsets_radiance_net(h)
         omega = self.omega_net(h) + 0.05
         omega = omega / omega.sum(dim=-1, keepdim=True)

@@ -895,3 +895,40 @@ def test_fused_mlp_forward_backward_match_float64(cuda, dims, act):
         l.weight.grad = None
     (mlp.run_mlp(net, x.detach(), fact) * wy).sum().backward()
     assert all(torch.equal(l.weight.grad, g) for l, g in zip(net, got[1:]))
+
+
+@pytest.mark.parametrize("tail_w,dims,act", [(0, (32, 64, 16), "relu"), (3, (35, 64, 15), "elu"), (0, (32, 64, 64, 3), "relu")])
+def test_encode_mlp_keeps_the_encoder_output_level_major(cuda, tail_w, dims, act):
+    """mlp.encode_mlp (grid lookup -> [tail] -> MLP with the encoder output level-major end to end, pnr_mlp_*_lm + the binned table gradient)
+    against the plain composition GridEncoder -> torch.cat -> layer loop: output 2e-6 of its scale, weight gradients 2e-5 and the table
+    gradient 1e-4 of their largest entries (the table gradient sums ~1e5 addends per coarse row in a different order)."""
+    import torch.nn.functional as F
+    from palettenerf_amd import mlp
+    torch.manual_seed(5 + tail_w)
+    B = 40000 + 13
+    enc = gridencoder.GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=4096).to(cuda)
+    enc.embeddings.data.uniform_(-0.5, 0.5)
+    net = torch.nn.ModuleList([torch.nn.Linear(dims[i], dims[i + 1], bias=False) for i in range(len(dims) - 1)]).to(cuda)
+    fact = F.relu if act == "relu" else F.elu
+    x = (torch.rand(B, 3, device=cuda) * 2 - 1) * 2
+    tail = torch.rand(B, tail_w, device=cuda) if tail_w else None
+    wy = torch.randn(B, dims[-1], device=cuda)
+    y = mlp.encode_mlp(enc, x, 2, tail, net, fact)
+    chain = [type(y.grad_fn).__name__] + [type(f[0]).__name__ for f in y.grad_fn.next_functions if f[0] is not None]
+    assert any("EncodeMLP" in n for n in chain), chain      # the fused path ran
+    (y * wy).sum().backward()
+    got = [enc.embeddings.grad.clone()] + [l.weight.grad.clone() for l in net]
+    enc.embeddings.grad = None
+    for l in net:
+        l.weight.grad = None
+    mlp.enabled = False
+    try:
+        y2 = mlp.encode_mlp(enc, x, 2, tail, net, fact)      # plain composition (torch layer loop, library GEMMs)
+        (y2 * wy).sum().backward()
+    finally:
+        mlp.enabled = True
+    want = [enc.embeddings.grad] + [l.weight.grad for l in net]
+    assert float((y - y2).abs().max()) <= 3e-6 * float(y2.abs().max())
+    for name, a, b, tol in zip(["table"] + [f"dw{i}" for i in range(len(net))], got, want, [1e-4] + [3e-5] * len(net)):
+        err, ref = float((a - b).abs().max()), float(b.abs().max())
+        assert err <= tol * ref, (name, err, ref)
