@@ -351,7 +351,7 @@ int pnr_mlp_backward(const pnr_mlp_desc* desc, const float* packed, const float*
 
 /* The same with the first 32 input columns taken straight from a hash-grid encoder output in its native level-major layout
  * enc [16][B][2] (pnr_grid_encode_forward's `outputs`) and the remaining dims[0] - 32 columns from a row-major x_tail [B, dims[0]-32]
- * (NULL when dims[0] == 32): replaces `torch.cat([encoder(x), tail])` + the [L,B,C] -> [B,L*C] copy of gridencoder/grid.py:57-58 in
+ * (NULL when dims[0] == 32): replaces `torch.cat([encoder(x), tail])` + the [L,B,C] -> [B,L*C] copy of gridencoder/grid.py:51-52 in
  * front of sigma_net (nerf/network.py:99-101) and basis_net (palette/network.py:257-260).  The backward returns the encoder part of dX in
  * level-major layout too (what pnr_grid_encode_backward[_binned] takes as `grad`); the tail gets no gradient (the reference detaches it). */
 int pnr_mlp_forward_lm(const pnr_mlp_desc* desc, const float* packed, const float* enc_level_major, uint32_t levels, const float* x_tail, uint32_t B, float* y,
