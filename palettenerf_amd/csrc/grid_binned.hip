@@ -253,10 +253,12 @@ __global__ void __launch_bounds__(kBinThreads) k_bin_scatter(const float* __rest
 __global__ void __launch_bounds__(1024) k_bin_gather(const BinJob* __restrict__ jobs, const uint32_t* __restrict__ n_jobs,
                                                      const uint16_t* __restrict__ rec_row, const float2* __restrict__ rec_val,
                                                      float* __restrict__ grad_grid) {
-    extern __shared__ float acc[];   // [kBinRows][2]
+    // fp64 accumulators: on gfx950 ds_add_f64 runs at 1.3 T lane-atomics/s where ds_add_f32 manages 0.2 T/s (profiles/micro/lds_atomics.hip),
+    // and the bucket sums come out order-independent to fp32 precision as a bonus; 128 KiB of the CU's 160 KiB LDS
+    extern __shared__ double acc[];   // [kBinRows][2]
     for (uint32_t job = blockIdx.x; job < *n_jobs; job += gridDim.x) {
         const BinJob jb = jobs[job];
-        for (uint32_t i = threadIdx.x; i < jb.nrows * 2; i += 1024) acc[i] = 0.0f;
+        for (uint32_t i = threadIdx.x; i < jb.nrows * 2; i += 1024) acc[i] = 0.0;
         __syncthreads();
         constexpr uint32_t U = 8;   // records in flight per thread: the loop is a latency chain otherwise (~76 HBM round trips per job)
         uint32_t r = jb.rec_begin + threadIdx.x;
@@ -266,21 +268,21 @@ __global__ void __launch_bounds__(1024) k_bin_gather(const BinJob* __restrict__ 
 #pragma unroll
             for (uint32_t u = 0; u < U; u++) { row[u] = rec_row[r + u * 1024]; v[u] = rec_val[r + u * 1024]; }
 #pragma unroll
-            for (uint32_t u = 0; u < U; u++) { atomicAdd(&acc[row[u] * 2], v[u].x); atomicAdd(&acc[row[u] * 2 + 1], v[u].y); }
+            for (uint32_t u = 0; u < U; u++) { atomicAdd(&acc[row[u] * 2], (double)v[u].x); atomicAdd(&acc[row[u] * 2 + 1], (double)v[u].y); }
         }
         for (; r < jb.rec_end; r += 1024) {
             const uint32_t row = rec_row[r];
             const float2 v = rec_val[r];
-            atomicAdd(&acc[row * 2], v.x);
-            atomicAdd(&acc[row * 2 + 1], v.y);
+            atomicAdd(&acc[row * 2], (double)v.x);
+            atomicAdd(&acc[row * 2 + 1], (double)v.y);
         }
         __syncthreads();
         float* dst = grad_grid + (size_t)jb.row_base * 2;
         if (jb.exclusive) {
-            for (uint32_t i = threadIdx.x; i < jb.nrows * 2; i += 1024) dst[i] += acc[i];
+            for (uint32_t i = threadIdx.x; i < jb.nrows * 2; i += 1024) dst[i] += (float)acc[i];
         } else {
             for (uint32_t i = threadIdx.x; i < jb.nrows * 2; i += 1024)
-                if (acc[i] != 0.0f) unsafeAtomicAdd(dst + i, acc[i]);
+                if (acc[i] != 0.0) unsafeAtomicAdd(dst + i, (float)acc[i]);
         }
         __syncthreads();
     }
@@ -347,12 +349,12 @@ int pnr_grid_encode_backward_binned(const float* grad, const float* inputs, cons
                                    cursor, rec_row, rec_val, nc);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_gather), hipFuncAttributeMaxDynamicSharedMemorySize, kBinRows * 2 * 4) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_gather), hipFuncAttributeMaxDynamicSharedMemorySize, kBinRows * 2 * 8) != hipSuccess)
             return PNR_ERR_LAUNCH;
         attr_set = true;
     }
     const uint32_t gather_blocks = lay.job_bound < 1024u ? lay.job_bound : 1024u;
-    hipLaunchKernelGGL(k_bin_gather, dim3(gather_blocks), dim3(1024), kBinRows * 2 * 4, s, jobs, n_jobs, rec_row, rec_val, grad_embeddings);
+    hipLaunchKernelGGL(k_bin_gather, dim3(gather_blocks), dim3(1024), kBinRows * 2 * 8, s, jobs, n_jobs, rec_row, rec_val, grad_embeddings);
     return check_launch();
 }
 
