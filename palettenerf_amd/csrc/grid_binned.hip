@@ -336,7 +336,8 @@ int pnr_grid_encode_backward_binned(const float* grad, const float* inputs, cons
     const LevelParams lp = make_level_params(L, S, H);
     if (hipMemsetAsync(counts, 0, (size_t)lay.bucket_bound * 4, s) != hipSuccess) return PNR_ERR_LAUNCH;
     uint32_t nc = 0;   // levels whose cells are wide compared with the sample spacing: run-combined records (as k_grid_bwd<COMBINE>)
-    while (nc < L && lp.scale[nc] <= 384.0f) nc++;
+    // (with fp64 LDS accumulation only the two coarsest levels still gain from merging runs: 3.47 -> 3.29 ms/step against the former bound of 384)
+    while (nc < L && lp.scale[nc] <= 24.0f) nc++;
     const uint32_t gx = cdiv(B, kBinThreads * kBinSamples);
     const uint32_t hist_bytes = lay.bucket_bound * 4;
     const bool ac = align_corners != 0;
