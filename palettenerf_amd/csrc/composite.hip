@@ -11,6 +11,7 @@ namespace pnr {
 
 constexpr uint32_t kBlock = 256;
 constexpr int kChunk = 16;
+constexpr int kAhead = 8;   // samples fetched ahead of the serial recurrence in the one-thread-per-ray training kernels
 
 // alpha of one sample; __expf == v_exp_f32(x * log2e), the gfx950 counterpart of CUDA's __expf
 __device__ __forceinline__ float alpha_of(float sigma, float delta) { return 1.0f - __expf(-sigma * delta); }
@@ -31,17 +32,30 @@ __global__ void __launch_bounds__(kBlock) k_composite_train_fwd(const float* __r
     const float* s = sigmas + offset;
     const float* c = rgbs + (size_t)offset * 3;
     const float* dl = deltas + (size_t)offset * 2;
+    // A training batch has a few thousand rays of ~150 samples: with one thread per ray the walk is a chain of dependent memory round trips
+    // (64 waves on the whole chip).  kAhead samples are fetched before the serial recurrence consumes them -- same operations, same order.
     float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, t = 0, d = 0;
-    for (uint32_t step = 0; step < num_steps; step++) {
-        const float alpha = alpha_of(s[0], dl[0]);
-        const float w = alpha * T;
-        r = fmaf(w, c[0], r); g = fmaf(w, c[1], g); b = fmaf(w, c[2], b);
-        t += dl[1];
-        d = fmaf(w, t, d);
-        ws += w;
-        T *= 1.0f - alpha;
-        if (T < T_thresh) break;
-        s++; c += 3; dl += 2;
+    bool stop = false;
+    for (uint32_t base = 0; base < num_steps && !stop; base += kAhead) {
+        float sg[kAhead], d0[kAhead], d1[kAhead], cr[kAhead], cg[kAhead], cb[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; u++) {
+            const uint32_t k = base + u < num_steps ? base + u : num_steps - 1;   // clamped: stays inside the ray's rows
+            sg[u] = s[k]; d0[u] = dl[(size_t)k * 2]; d1[u] = dl[(size_t)k * 2 + 1];
+            cr[u] = c[(size_t)k * 3]; cg[u] = c[(size_t)k * 3 + 1]; cb[u] = c[(size_t)k * 3 + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < kAhead; u++) {
+            if (stop || base + u >= num_steps) break;
+            const float alpha = alpha_of(sg[u], d0[u]);
+            const float w = alpha * T;
+            r = fmaf(w, cr[u], r); g = fmaf(w, cg[u], g); b = fmaf(w, cb[u], b);
+            t += d1[u];
+            d = fmaf(w, t, d);
+            ws += w;
+            T *= 1.0f - alpha;
+            if (T < T_thresh) stop = true;
+        }
     }
     weights_sum[index] = ws; depth[index] = d;
     image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
@@ -89,6 +103,7 @@ __global__ void __launch_bounds__(kBlock) k_composite_flex_train_fwd(const float
 // bytes per load; four samples are fetched ahead of the serial recurrence.
 constexpr uint32_t kLanesPerRay = 16;
 constexpr int kCoopCh = 4;   // channels per lane and pass
+constexpr uint32_t kCoopMinSamples = 1u << 16;   // below this the exact sample-order kernels are used (small batches, the oracle-parity tests)
 __global__ void __launch_bounds__(kBlock) k_composite_flex_train_fwd_coop(const float* __restrict__ sigmas, const float* __restrict__ input,
                                                                           const float* __restrict__ deltas, const int32_t* __restrict__ rays,
                                                                           uint32_t M, uint32_t N, uint32_t n_channel, float T_thresh,
@@ -128,6 +143,113 @@ __global__ void __launch_bounds__(kBlock) k_composite_flex_train_fwd_coop(const 
         }
 #pragma unroll
         for (int j = 0; j < kCoopCh; j++) if (c0 + j * kLanesPerRay < n_channel) output[(size_t)index * n_channel + c0 + j * kLanesPerRay] = acc[j];
+    }
+}
+
+// rgb / depth / weights variant with 16 lanes per ray, one SAMPLE per lane: the transmittance of a group of 16 consecutive samples is an
+// exclusive prefix product over the lanes (4 shuffle steps), T in front of the group is carried along.  A 600-sample ray takes 38 group
+// steps instead of 600 serial ones (the longest ray of a wave sets the pace of the one-thread-per-ray kernel: 140-200 us per launch on
+// a 4096-ray batch).  Same terms as raymarching.cu:504-580, summed in scan / tree order instead of sample order (~1e-7 relative).
+__device__ __forceinline__ float group_excl_product(float v, int q, float& total) {   // over the 16 lanes of a ray; total = product of all 16
+    float inc = v;
+#pragma unroll
+    for (int off = 1; off < (int)kLanesPerRay; off <<= 1) {
+        const float up = __shfl_up(inc, off, kLanesPerRay);
+        if (q >= off) inc *= up;
+    }
+    total = __shfl(inc, kLanesPerRay - 1, kLanesPerRay);
+    const float ex = __shfl_up(inc, 1, kLanesPerRay);
+    return q == 0 ? 1.0f : ex;
+}
+__device__ __forceinline__ float group_incl_sum(float v, int q, float& total) {
+    float inc = v;
+#pragma unroll
+    for (int off = 1; off < (int)kLanesPerRay; off <<= 1) {
+        const float up = __shfl_up(inc, off, kLanesPerRay);
+        if (q >= off) inc += up;
+    }
+    total = __shfl(inc, kLanesPerRay - 1, kLanesPerRay);
+    return inc;
+}
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int off = kLanesPerRay / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, kLanesPerRay);
+    return v;
+}
+
+__global__ void __launch_bounds__(kBlock) k_composite_train_fwd_coop(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                                     const float* __restrict__ deltas, const int32_t* __restrict__ rays, uint32_t M,
+                                                                     uint32_t N, float T_thresh, float* __restrict__ weights_sum,
+                                                                     float* __restrict__ depth, float* __restrict__ image) {
+    const uint32_t n = (blockIdx.x * kBlock + threadIdx.x) / kLanesPerRay;
+    const int q = (int)(threadIdx.x % kLanesPerRay);
+    if (n >= N) return;   // whole 16-lane groups leave together
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    float r = 0, g = 0, b = 0, ws = 0, d = 0;
+    if (num_steps != 0 && offset + num_steps <= M) {
+        float T = 1.0f, t = 0.0f;   // transmittance / ray parameter in front of the current group
+        for (uint32_t base = 0; base < num_steps && !(T < T_thresh); base += kLanesPerRay) {
+            const uint32_t k = base + (uint32_t)q;
+            const bool in = k < num_steps;
+            const size_t row = (size_t)offset + (in ? k : num_steps - 1);
+            const float alpha = in ? alpha_of(sigmas[row], deltas[row * 2]) : 0.0f;
+            float keep, tsum;
+            const float Tq = T * group_excl_product(1.0f - alpha, q, keep);          // transmittance in front of this lane's sample
+            const float tq = t + group_incl_sum(in ? deltas[row * 2 + 1] : 0.0f, q, tsum);
+            const float w = (in && !(Tq < T_thresh)) ? alpha * Tq : 0.0f;            // the reference stops after the sample that drops T below the threshold
+            r = fmaf(w, rgbs[row * 3], r); g = fmaf(w, rgbs[row * 3 + 1], g); b = fmaf(w, rgbs[row * 3 + 2], b);
+            d = fmaf(w, tq, d);
+            ws += w;
+            T *= keep;
+            t += tsum;
+        }
+    }
+    r = group_sum(r); g = group_sum(g); b = group_sum(b); ws = group_sum(ws); d = group_sum(d);
+    if (q == 0) {
+        weights_sum[index] = ws; depth[index] = d;
+        image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+    }
+}
+
+// raymarching.cu:681-761 with the same lane layout: the running colour of the reference (r, g, b after sample k) is an inclusive prefix sum
+__global__ void __launch_bounds__(kBlock) k_composite_train_bwd_coop(const float* __restrict__ grad_weights_sum, const float* __restrict__ grad_image,
+                                                                     const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                                     const float* __restrict__ deltas, const int32_t* __restrict__ rays,
+                                                                     const float* __restrict__ weights_sum, const float* __restrict__ image, uint32_t M,
+                                                                     uint32_t N, float T_thresh, float* __restrict__ grad_sigmas,
+                                                                     float* __restrict__ grad_rgbs) {
+    const uint32_t n = (blockIdx.x * kBlock + threadIdx.x) / kLanesPerRay;
+    const int q = (int)(threadIdx.x % kLanesPerRay);
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    if (num_steps == 0 || offset + num_steps > M) return;
+    const float gws = grad_weights_sum[index];
+    const float g0 = grad_image[index * 3], g1 = grad_image[index * 3 + 1], g2 = grad_image[index * 3 + 2];
+    const float r_final = image[index * 3], g_final = image[index * 3 + 1], b_final = image[index * 3 + 2], ws_final = weights_sum[index];
+    float T = 1.0f, r = 0, g = 0, b = 0;   // state in front of the current group
+    for (uint32_t base = 0; base < num_steps && !(T < T_thresh); base += kLanesPerRay) {
+        const uint32_t k = base + (uint32_t)q;
+        const bool in = k < num_steps;
+        const size_t row = (size_t)offset + (in ? k : num_steps - 1);
+        const float dl0 = deltas[row * 2];
+        const float alpha = in ? alpha_of(sigmas[row], dl0) : 0.0f;
+        const float c0 = rgbs[row * 3], c1 = rgbs[row * 3 + 1], c2 = rgbs[row * 3 + 2];
+        float keep, sr, sg, sb;
+        const float Tq = T * group_excl_product(1.0f - alpha, q, keep);
+        const bool live = in && !(Tq < T_thresh);
+        const float w = live ? alpha * Tq : 0.0f;
+        const float rq = r + group_incl_sum(w * c0, q, sr), gq = g + group_incl_sum(w * c1, q, sg), bq = b + group_incl_sum(w * c2, q, sb);
+        if (live) {
+            const float Ta = Tq * (1.0f - alpha);   // transmittance after this sample
+            grad_rgbs[row * 3] = g0 * w; grad_rgbs[row * 3 + 1] = g1 * w; grad_rgbs[row * 3 + 2] = g2 * w;
+            float acc = g0 * fmaf(Ta, c0, -(r_final - rq));
+            acc = fmaf(g1, fmaf(Ta, c1, -(g_final - gq)), acc);
+            acc = fmaf(g2, fmaf(Ta, c2, -(b_final - bq)), acc);
+            acc = fmaf(gws, 1.0f - ws_final, acc);
+            grad_sigmas[row] = dl0 * acc;
+        }
+        T *= keep;
+        r += sr; g += sg; b += sb;
     }
 }
 
@@ -191,19 +313,31 @@ __global__ void __launch_bounds__(kBlock) k_composite_train_bwd(const float* __r
     float* gs = grad_sigmas + offset;
     float* gc = grad_rgbs + (size_t)offset * 3;
     float T = 1.0f, r = 0, g = 0, b = 0;
-    for (uint32_t step = 0; step < num_steps; step++) {
-        const float alpha = alpha_of(s[0], dl[0]);
-        const float w = alpha * T;
-        r = fmaf(w, c[0], r); g = fmaf(w, c[1], g); b = fmaf(w, c[2], b);
-        T *= 1.0f - alpha;
-        gc[0] = g0 * w; gc[1] = g1 * w; gc[2] = g2 * w;
-        float acc = g0 * fmaf(T, c[0], -(r_final - r));
-        acc = fmaf(g1, fmaf(T, c[1], -(g_final - g)), acc);
-        acc = fmaf(g2, fmaf(T, c[2], -(b_final - b)), acc);
-        acc = fmaf(gws, 1.0f - ws_final, acc);
-        gs[0] = dl[0] * acc;
-        if (T < T_thresh) break;
-        s++; c += 3; dl += 2; gs++; gc += 3;
+    bool stop = false;
+    for (uint32_t base = 0; base < num_steps && !stop; base += kAhead) {   // kAhead samples fetched ahead, as in the forward
+        float sg[kAhead], d0[kAhead], cr[kAhead], cg[kAhead], cb[kAhead];
+#pragma unroll
+        for (int u = 0; u < kAhead; u++) {
+            const uint32_t k = base + u < num_steps ? base + u : num_steps - 1;
+            sg[u] = s[k]; d0[u] = dl[(size_t)k * 2];
+            cr[u] = c[(size_t)k * 3]; cg[u] = c[(size_t)k * 3 + 1]; cb[u] = c[(size_t)k * 3 + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < kAhead; u++) {
+            if (stop || base + u >= num_steps) break;
+            const uint32_t k = base + u;
+            const float alpha = alpha_of(sg[u], d0[u]);
+            const float w = alpha * T;
+            r = fmaf(w, cr[u], r); g = fmaf(w, cg[u], g); b = fmaf(w, cb[u], b);
+            T *= 1.0f - alpha;
+            gc[(size_t)k * 3] = g0 * w; gc[(size_t)k * 3 + 1] = g1 * w; gc[(size_t)k * 3 + 2] = g2 * w;
+            float acc = g0 * fmaf(T, cr[u], -(r_final - r));
+            acc = fmaf(g1, fmaf(T, cg[u], -(g_final - g)), acc);
+            acc = fmaf(g2, fmaf(T, cb[u], -(b_final - b)), acc);
+            acc = fmaf(gws, 1.0f - ws_final, acc);
+            gs[k] = d0[u] * acc;
+            if (T < T_thresh) stop = true;
+        }
     }
 }
 
@@ -309,8 +443,12 @@ int pnr_composite_rays_train_forward(const float* sigmas, const float* rgbs, con
     if (N == 0) return PNR_OK;
     if (!rays || !weights_sum || !depth || !image) return PNR_ERR_INVALID;
     if (M > 0 && (!sigmas || !rgbs || !deltas)) return PNR_ERR_INVALID;
-    hipLaunchKernelGGL(k_composite_train_fwd, dim3(cdiv(N, kBlock)), dim3(kBlock), 0, as_stream(stream), sigmas, rgbs, deltas, rays, M, N,
-                       T_thresh, weights_sum, depth, image);
+    if (M >= kCoopMinSamples)   // training batches: 16 lanes per ray
+        hipLaunchKernelGGL(k_composite_train_fwd_coop, dim3(cdiv(N * kLanesPerRay, kBlock)), dim3(kBlock), 0, as_stream(stream), sigmas, rgbs, deltas,
+                           rays, M, N, T_thresh, weights_sum, depth, image);
+    else
+        hipLaunchKernelGGL(k_composite_train_fwd, dim3(cdiv(N, kBlock)), dim3(kBlock), 0, as_stream(stream), sigmas, rgbs, deltas, rays, M, N,
+                           T_thresh, weights_sum, depth, image);
     return check_launch();
 }
 
@@ -320,8 +458,12 @@ int pnr_composite_rays_train_backward(const float* grad_weights_sum, const float
     if (N == 0 || M == 0) return PNR_OK;
     if (!grad_weights_sum || !grad_image || !sigmas || !rgbs || !deltas || !rays || !weights_sum || !image || !grad_sigmas || !grad_rgbs)
         return PNR_ERR_INVALID;
-    hipLaunchKernelGGL(k_composite_train_bwd, dim3(cdiv(N, kBlock)), dim3(kBlock), 0, as_stream(stream), grad_weights_sum, grad_image, sigmas,
-                       rgbs, deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs);
+    if (M >= kCoopMinSamples)
+        hipLaunchKernelGGL(k_composite_train_bwd_coop, dim3(cdiv(N * kLanesPerRay, kBlock)), dim3(kBlock), 0, as_stream(stream), grad_weights_sum,
+                           grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs);
+    else
+        hipLaunchKernelGGL(k_composite_train_bwd, dim3(cdiv(N, kBlock)), dim3(kBlock), 0, as_stream(stream), grad_weights_sum, grad_image, sigmas,
+                           rgbs, deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs);
     return check_launch();
 }
 

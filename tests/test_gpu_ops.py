@@ -263,10 +263,14 @@ def _train_case(rng, N, max_len, nc):
     return rays, sig, rgb, feat, dl, M
 
 
-def test_composite_train_forward_backward(cuda):
+@pytest.mark.parametrize("N,sigma_scale", [(300, 1.0), (3000, 1.0), (3000, 0.03)])
+def test_composite_train_forward_backward(cuda, N, sigma_scale):
+    """N = 300: the sample-order kernels (M < 65536); N = 3000: the 16-lanes-per-ray scan kernels, with opaque rays that stop at T_thresh
+    after ~30 samples and with translucent ones that run their full length."""
     rng = np.random.default_rng(6)
-    N = 3000
     rays, sig, rgb, feat, dl, M = _train_case(rng, N, 200, 33)
+    sig = (sig * sigma_scale).astype(np.float32)
+    assert (M >= 65536) == (N == 3000)
     ts, tc = dev(sig, cuda).requires_grad_(True), dev(rgb, cuda).requires_grad_(True)
     ws, dep, img = raymarching.composite_rays_train(ts, tc, dev(dl, cuda), dev(rays, cuda), 1e-4)
     ows, odep, oimg = oracle.composite_rays_train_forward(sig, rgb, dl, rays, 1e-4)
