@@ -102,10 +102,11 @@ def cpu_baseline(args):
         dt = time.perf_counter() - t0
         n = int(r["rendered"].item())
         # BASELINE configs[0] beside it: the reference's CPU-runnable case, NeRFRenderer.run at 400x400 with --num_steps 512 --upsample_steps 0
-        # (main_nerf.py:31-32), a quarter of one max_ray_batch of 4096 rays (160 such pieces make the frame), all host cores for the torch part
+        # (main_nerf.py:31-32), a quarter of one max_ray_batch of 4096 rays (160 such pieces make the frame), 8 threads for the torch part as the reference's scripts set
         uniform = None
         if args.model == "nerf":
-            torch.set_num_threads(os.cpu_count() or 1)
+            n_thr = min(8, os.cpu_count() or 1)       # the reference's scripts pin OMP_NUM_THREADS=8 (scripts/run_blender.sh:48)
+            torch.set_num_threads(n_thr)
             mu = network.NeRFNetwork(bound=2, cuda_ray=False, density_scale=args.density_scale, min_near=0.2)
             scene.seed_field_(mu, 0)
             mu.eval()
@@ -115,7 +116,7 @@ def cpu_baseline(args):
             with torch.no_grad():
                 mu.run(ro0[:, mid:mid + 1024].contiguous(), rd0[:, mid:mid + 1024].contiguous(), num_steps=512, upsample_steps=0, perturb=False)
             du = time.perf_counter() - t0
-            uniform = {"value": 1024 * 512 / du, "unit": "evaluated samples/s", "cores": os.cpu_count(), "ms_per_400x400_frame_extrapolated": du * 160 * 1e3,
+            uniform = {"value": 1024 * 512 / du, "unit": "evaluated samples/s", "cores": n_thr, "ms_per_400x400_frame_extrapolated": du * 160 * 1e3,
                        "sample": f"1024 rays x 512 uniform samples (1/160) of a 400x400 frame ({du:.1f} s; C oracle encoders 1 thread + torch MLP)"}
             torch.set_num_threads(1)
     finally:

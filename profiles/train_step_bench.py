@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--model", choices=["palette", "nerf"], default="palette")
     ap.add_argument("--fp16", action="store_true")
+    ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True): one launch per parameter group instead of seven")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     if args.model == "palette":
@@ -43,7 +44,7 @@ def main():
     intr = scene.intrinsics_from_fov(H, W, 0.9)
     ro_all, rd_all = scene.get_rays(torch.from_numpy(np.stack(poses)), intr, H, W)
     ro_all, rd_all = ro_all.to(dev), rd_all.to(dev)
-    opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=args.fused_adam)
     scaler = torch.amp.GradScaler("cuda", enabled=args.fp16)
     target = torch.rand(args.rays, 3, device=dev)
 
