@@ -105,7 +105,7 @@ def cpu_baseline(args):
         # (main_nerf.py:31-32), a quarter of one max_ray_batch of 4096 rays (160 such pieces make the frame), 8 threads for the torch part as the reference's scripts set
         uniform = None
         if args.model == "nerf":
-            n_thr = min(8, os.cpu_count() or 1)       # the reference's scripts pin OMP_NUM_THREADS=8 (scripts/run_blender.sh:48)
+            n_thr = min(8, os.cpu_count() or 1)       # the reference's scripts pin OMP_NUM_THREADS=8 (scripts/run_blender.sh:47)
             torch.set_num_threads(n_thr)
             mu = network.NeRFNetwork(bound=2, cuda_ray=False, density_scale=args.density_scale, min_near=0.2)
             scene.seed_field_(mu, 0)
