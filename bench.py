@@ -117,7 +117,7 @@ def cpu_baseline(args):
                 mu.run(ro0[:, mid:mid + 1024].contiguous(), rd0[:, mid:mid + 1024].contiguous(), num_steps=512, upsample_steps=0, perturb=False)
             du = time.perf_counter() - t0
             uniform = {"value": 1024 * 512 / du, "unit": "evaluated samples/s", "cores": n_thr, "ms_per_400x400_frame_extrapolated": du * 160 * 1e3,
-                       "sample": f"1024 rays x 512 uniform samples (1/160) of a 400x400 frame ({du:.1f} s; C oracle encoders 1 thread + torch MLP)"}
+                       "sample": f"1024 rays x 512 uniform samples (1/160) of a 400x400 frame ({du:.1f} s; C oracle encoders 1 thread + torch MLP on {n_thr} threads; host has {os.cpu_count()} cores -- all of them made this piece slower)"}
             torch.set_num_threads(1)
     finally:
         renderer.raymarching, pge.GridEncoder, psh.SHEncoder = saved
