@@ -46,7 +46,8 @@ const char* pnr_error_string(int code);
 /* ABI version of this header; bumped on any signature change. */
 int pnr_abi_version(void);
 /* run-time switches that change speed only, for A/B measurements and tests: "block_skip" (exact jumps over empty blocks in the march),
- * "aux_fusion" (PaletteNeRF frame loop: aux composite inside the field kernel); both default to 1 */
+ * "aux_fusion" (PaletteNeRF frame loop: aux composite inside the field kernel), "composite_fusion" (NeRF frame loop: iterations with one
+ * sample per ray composited inside the field kernel); all default to 1 */
 int pnr_set_option(const char* name, int value);
 
 /* ---------------------------------------------------------------- raymarching: utils ------- */

@@ -377,33 +377,80 @@ __global__ void __launch_bounds__(256) k_frame_grid_pair(const FrameCtl* __restr
 
 // the fused MFMA field of field.hip with rows from the control block, dead-slot skipping and density_scale
 constexpr int kFieldThreads = 512;
+// With one sample per ray (n_step == 1: 27 of the 29 iterations of the benchmark frame) the compositing step of the iteration is done
+// right here by the lanes that hold the sample's sigma and rgb (`fuse`): same operations in the same order as k_frame_composite's
+// phase 2 on the same values (what it would re-read from sigmas / rgbs), including the per-chunk survivor counts of the compaction --
+// a 256-sample tile IS chunk `tile` of the alive list.  k_frame_composite returns at once on such iterations.
 template <int PREC>
 __global__ void __launch_bounds__(kFieldThreads) k_frame_field(const FrameCtl* __restrict__ ctl, const float* __restrict__ enc, uint32_t level_stride,
                                                                const float* __restrict__ dirs, const float* __restrict__ deltas,
                                                                const float* __restrict__ packed, float density_scale, float* __restrict__ sigmas,
-                                                               float* __restrict__ rgbs) {
+                                                               float* __restrict__ rgbs, int fuse_one_step, float T_thresh, int32_t* __restrict__ rays_alive,
+                                                               float* __restrict__ rays_t, float* __restrict__ weights_sum, float* __restrict__ depth,
+                                                               float* __restrict__ image, int32_t* __restrict__ scratch) {
     if (ctl->done) return;
     const uint32_t B = (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step;
+    const bool fuse = fuse_one_step && ctl->n_step == 1;
     const uint32_t ntiles = (B + 255) / 256;
     if (blockIdx.x >= ntiles) return;
     __shared__ float w[kPackedFloats];
+    __shared__ int wsum[kFieldThreads / PNR_WAVE];
     for (int i = threadIdx.x * 4; i < kPackedFloats; i += kFieldThreads * 4)
         *reinterpret_cast<float4*>(&w[i]) = *reinterpret_cast<const float4*>(&packed[i]);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t n = tile * 256 + wave * 32 + (lane & 31);
-        const bool valid = n < B && deltas[(size_t)(n < B ? n : 0) * 2] != 0.0f;
-        if (!__any(valid)) continue;  // wave-uniform: all 32 slots of this wave are dead or out of range
-        const uint32_t nc = n < B ? n : (B - 1);
-        float dx = 0.0f, dy = 0.0f, dz = 0.0f;
-        if (valid) { dx = dirs[(size_t)nc * 3]; dy = dirs[(size_t)nc * 3 + 1]; dz = dirs[(size_t)nc * 3 + 2]; }
-        const FieldOut o = nerf_field_tile<PREC>(w, lane, valid, enc, level_stride, nc, dx, dy, dz);
+        const float dl0 = n < B ? deltas[(size_t)n * 2] : 0.0f;
+        const bool valid = n < B && dl0 != 0.0f;
+        FieldOut o = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (__any(valid)) {   // wave-uniform: otherwise all 32 slots of this wave are dead or out of range
+            const uint32_t nc = n < B ? n : (B - 1);
+            float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+            if (valid) { dx = dirs[(size_t)nc * 3]; dy = dirs[(size_t)nc * 3 + 1]; dz = dirs[(size_t)nc * 3 + 2]; }
+            o = nerf_field_tile<PREC>(w, lane, valid, enc, level_stride, nc, dx, dy, dz);
+        }
+        float sigma = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
         if (valid && h == 0) {
-            sigmas[n] = density_scale * __expf(o.sigma_logit);   // nerf/renderer.py:372; hardware exp / rcp: ~1e-7 on these arguments
-            rgbs[(size_t)n * 3] = __frcp_rn(1.0f + __expf(-o.o0));
-            rgbs[(size_t)n * 3 + 1] = __frcp_rn(1.0f + __expf(-o.o1));
-            rgbs[(size_t)n * 3 + 2] = __frcp_rn(1.0f + __expf(-o.o2));
+            sigma = density_scale * __expf(o.sigma_logit);   // nerf/renderer.py:372; hardware exp / rcp: ~1e-7 on these arguments
+            cr = __frcp_rn(1.0f + __expf(-o.o0));
+            cg = __frcp_rn(1.0f + __expf(-o.o1));
+            cb = __frcp_rn(1.0f + __expf(-o.o2));
+            if (!fuse) {
+                sigmas[n] = sigma;
+                rgbs[(size_t)n * 3] = cr; rgbs[(size_t)n * 3 + 1] = cg; rgbs[(size_t)n * 3 + 2] = cb;
+            }
+        }
+        if (fuse) {   // block-uniform
+            int keep = 0;
+            if (h == 0 && n < B) {   // slot n of the alive list: k_frame_composite phase 2 with n_step == 1
+                const int index = rays_alive[n];
+                float ws = weights_sum[index], t = rays_t[index], d = depth[index];
+                float r = image[index * 3], g = image[index * 3 + 1], b = image[index * 3 + 2];
+                bool stepped = false;
+                if (dl0 != 0.0f) {
+                    const float alpha = 1.0f - __expf(-sigma * dl0);
+                    const float T = 1.0f - ws;
+                    const float wgt = alpha * T;
+                    ws += wgt;
+                    t += deltas[(size_t)n * 2 + 1];
+                    d = fmaf(wgt, t, d);
+                    r = fmaf(wgt, cr, r); g = fmaf(wgt, cg, g); b = fmaf(wgt, cb, b);
+                    stepped = !(T < T_thresh);
+                }
+                if (!stepped) rays_alive[n] = -1; else { rays_t[index] = t; keep = 1; }
+                weights_sum[index] = ws; depth[index] = d;
+                image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+            }
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) wsum[wave] = __popcll(m);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int tot = 0;
+                for (int wv = 0; wv < kFieldThreads / (int)PNR_WAVE; wv++) tot += wsum[wv];
+                scratch[kHdr + tile] = tot;
+            }
+            __syncthreads();
         }
     }
 }
@@ -416,9 +463,10 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_composite(const FrameCtl* _
                                                                const float* __restrict__ rgbs, const float* __restrict__ deltas,
                                                                float* __restrict__ weights_sum, float* __restrict__ depth, float* __restrict__ image,
                                                                int32_t* __restrict__ scratch, const float* __restrict__ aux, float* __restrict__ aux_map,
-                                                               uint32_t aux_stride, int aux_done_when_one_step) {
+                                                               uint32_t aux_stride, int aux_done_when_one_step, int all_done_when_one_step) {
     if (ctl->done) return;
     const uint32_t n_alive = (uint32_t)ctl->n_alive, n_step = (uint32_t)ctl->n_step;
+    if (all_done_when_one_step && n_step == 1) return;   // k_frame_field has composited this iteration and counted the survivors
     const uint32_t nchunks = (n_alive + kRayBlock - 1) / kRayBlock;
     __shared__ int wsum[kRayBlock / PNR_WAVE];
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
@@ -661,6 +709,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     gs.table[2] = with_clip ? pal->embeddings_clip : nullptr; gs.enc[2] = w.enc_clip;
     const uint32_t n_enc = pal ? (with_clip ? 3u : 2u) : 1u;
     const int aux_fused = (pal && g_opt_aux_fusion && pnr_palette_field_stages_aux(aux_stride, pal->pred_clip)) ? 1 : 0;
+    const int composite_fused = (!pal && g_opt_composite_fusion) ? 1 : 0;   // NeRF: one-sample-per-ray iterations are composited inside the field kernel
     const bool half_tables = a->table_dtype == PNR_DTYPE_F16;   // fp16 tables: nerf = `embeddings` as halves; palette = embeddings_pair as interleaved halves
     if (half_tables && pal && (with_clip || !pal->embeddings_pair)) return PNR_ERR_UNSUPPORTED;
     if (a->table_dtype != PNR_DTYPE_F32 && a->table_dtype != PNR_DTYPE_F16) return PNR_ERR_UNSUPPORTED;
@@ -741,12 +790,14 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
                 if (rc != PNR_OK) return rc;
             } else if (a->field_precision == PNR_FIELD_FP32)
                 hipLaunchKernelGGL(k_frame_field<0>, dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas,
-                                   a->packed_weights, a->density_scale, w.sigmas, w.rgbs);
+                                   a->packed_weights, a->density_scale, w.sigmas, w.rgbs, composite_fused, a->T_thresh, alive_in, w.rays_t, out_ws, out_depth,
+                                   out_image, w.scratch);
             else
                 hipLaunchKernelGGL(k_frame_field<1>, dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas,
-                                   a->packed_weights, a->density_scale, w.sigmas, w.rgbs);
+                                   a->packed_weights, a->density_scale, w.sigmas, w.rgbs, composite_fused, a->T_thresh, alive_in, w.rays_t, out_ws, out_depth,
+                                   out_image, w.scratch);
             hipLaunchKernelGGL(k_frame_composite, gm, bm, 0, s, cur, a->T_thresh, alive_in, w.rays_t, w.sigmas, w.rgbs, w.deltas, out_ws, out_depth, out_image,
-                               w.scratch, (const float*)w.aux, out_aux, aux_stride, aux_fused);
+                               w.scratch, (const float*)w.aux, out_aux, aux_stride, aux_fused, composite_fused);
             hipLaunchKernelGGL(k_frame_compact, gm, bm, 0, s, cur, nxt, alive_in, alive_out, w.scratch, N, a->max_steps, w.partials, gm.x);
         }
         if (hipMemcpyAsync(host_ctl, w.ctl + (iter & 1), sizeof(FrameCtl), hipMemcpyDeviceToHost, s) != hipSuccess) return PNR_ERR_LAUNCH;

@@ -403,6 +403,7 @@ __global__ void __launch_bounds__(kBlock) k_get_rays(const float* __restrict__ p
 // ==========================================================================================
 int g_opt_block_skip = getenv("PNR_NO_BLOCK_SKIP") ? 0 : 1;
 int g_opt_aux_fusion = getenv("PNR_NO_AUX_FUSION") ? 0 : 1;
+int g_opt_composite_fusion = getenv("PNR_NO_COMPOSITE_FUSION") ? 0 : 1;
 
 using namespace pnr;
 
@@ -414,6 +415,7 @@ int pnr_set_option(const char* name, int value) {
     if (!name) return PNR_ERR_INVALID;
     if (!strcmp(name, "block_skip")) { g_opt_block_skip = value != 0; return PNR_OK; }
     if (!strcmp(name, "aux_fusion")) { g_opt_aux_fusion = value != 0; return PNR_OK; }
+    if (!strcmp(name, "composite_fusion")) { g_opt_composite_fusion = value != 0; return PNR_OK; }
     return PNR_ERR_INVALID;
 }
 
