@@ -38,7 +38,7 @@ __device__ __forceinline__ int schedule_n_step(int N, int n_alive) {  // nerf/re
 
 __global__ void __launch_bounds__(kRayBlock) k_frame_init(uint32_t N, const float* __restrict__ nears, int32_t* __restrict__ alive,
                                                           float* __restrict__ rays_t, float* __restrict__ weights_sum, float* __restrict__ depth,
-                                                          float* __restrict__ image, FrameCtl* __restrict__ ctl) {
+                                                          float* __restrict__ image, FrameCtl* __restrict__ ctl, int32_t* __restrict__ counts) {
     const uint32_t i = blockIdx.x * kRayBlock + threadIdx.x;
     if (i < N) {
         alive[i] = (int32_t)i;   // the reference's arange (nerf/renderer.py:352)
@@ -46,9 +46,12 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_init(uint32_t N, const floa
         weights_sum[i] = 0.0f; depth[i] = 0.0f;
         image[i * 3] = 0.0f; image[i * 3 + 1] = 0.0f; image[i * 3 + 2] = 0.0f;
     }
+    // The state "in front of iteration 0" as k_frame_march expects it from a previous iteration: a full alive list whose chunks all
+    // survive (identity compaction), nothing marched yet.
+    if (threadIdx.x == 0 && blockIdx.x * kRayBlock < N) counts[blockIdx.x] = (int32_t)(N - blockIdx.x * kRayBlock < kRayBlock ? N - blockIdx.x * kRayBlock : kRayBlock);
     if (i == 0) {
         FrameCtl c = {};
-        c.n_alive = (int32_t)N; c.n_step = schedule_n_step((int)N, (int)N); c.done = N == 0;
+        c.n_alive = (int32_t)N; c.n_step = 0; c.iterations = -1; c.done = N == 0;
         ctl[0] = c; ctl[1] = c;
     }
 }
@@ -106,20 +109,80 @@ __device__ unsigned long long g_march_stats[8];
 __device__ unsigned int g_march_max[64];   // per iteration: max probes of any ray
 __device__ unsigned int g_march_kinds[64][8];   // per iteration: probe kinds of (one of) the slowest rays  // probes, empty probes, (unused), ray-launches
 #endif
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long* sh /* [kRayBlock / 64] */) {
+    for (int off = PNR_WAVE / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, PNR_WAVE);
+    __syncthreads();
+    if ((threadIdx.x & (PNR_WAVE - 1)) == 0) sh[threadIdx.x / PNR_WAVE] = v;
+    __syncthreads();
+    unsigned long long t = 0;
+    for (int wv = 0; wv < (int)(kRayBlock / PNR_WAVE); wv++) t += sh[wv];
+    return t;
+}
+
+
+// One launch per iteration does the stable compaction of the previous iteration's alive list, the schedule of this iteration and the
+// march itself.  Every workgroup totals the per-chunk survivor counts (k_frame_composite / k_frame_field wrote them; a few coalesced
+// loads per thread out of L2) -- that gives n_alive and n_step of this iteration without a separate launch -- and derives the output
+// offset of its chunk by summing the counts in front of it; a surviving ray is written to its compacted slot and marched from there.
+// Workgroup 0 also adds the previous march's sample partials and writes this iteration's control block for the kernels that follow.
 template <bool MIP, bool POW2>
-__global__ void __launch_bounds__(kRayBlock) k_frame_march(FrameCtl* __restrict__ ctl, const int32_t* __restrict__ rays_alive,
+__global__ void __launch_bounds__(kRayBlock) k_frame_march(const FrameCtl* __restrict__ prev, FrameCtl* __restrict__ cur, const int32_t* __restrict__ alive_prev,
+                                                           int32_t* __restrict__ rays_alive, const int32_t* __restrict__ scratch, uint32_t N, uint32_t max_steps,
+                                                           const int32_t* __restrict__ partials_prev, uint32_t n_partials_prev,
                                                            const float* __restrict__ rays_t, const float* __restrict__ rays_o,
                                                            const float* __restrict__ rays_d, MarchParams p, const uint8_t* __restrict__ grid,
                                                            const float* __restrict__ fars, float* __restrict__ xyzs, float* __restrict__ dirs,
                                                            float* __restrict__ deltas, const uint32_t* __restrict__ mip,
                                                            int32_t* __restrict__ emitted_partials /* [gridDim.x] */) {
-    if (ctl->done) return;
-    const uint32_t n_alive = (uint32_t)ctl->n_alive, n_step = (uint32_t)ctl->n_step;
-    if (blockIdx.x * kRayBlock >= n_alive) { if (threadIdx.x == 0) emitted_partials[blockIdx.x] = 0; return; }
+    __shared__ int csum[kRayBlock / PNR_WAVE];
+    __shared__ unsigned long long red[kRayBlock / PNR_WAVE];
+    if (prev->done) { if (blockIdx.x == 0 && threadIdx.x == 0) *cur = *prev; return; }
+    const uint32_t n_prev = (uint32_t)prev->n_alive, nchunks = (n_prev + kRayBlock - 1) / kRayBlock;
+    const int32_t* counts = scratch + kHdr;
+    unsigned long long part = 0;
+    for (uint32_t j = threadIdx.x; j < nchunks; j += kRayBlock) part += (unsigned long long)counts[j];
+    const uint32_t n_alive = (uint32_t)block_sum_u64(part, red);
+    const uint32_t n_step = (uint32_t)schedule_n_step((int)N, (int)n_alive);
+    const int step_now = prev->step + prev->n_step;
+    const bool done = n_alive == 0 || (uint32_t)step_now >= max_steps;
+    if (blockIdx.x == 0) {
+        unsigned long long e = 0;
+        for (uint32_t j = threadIdx.x; j < n_partials_prev; j += kRayBlock) e += (unsigned long long)partials_prev[j];
+        const unsigned long long emitted_prev = block_sum_u64(e, red);
+        if (threadIdx.x == 0) {
+            FrameCtl c = *prev;
+            c.rendered += emitted_prev;
+            c.rows += (unsigned long long)n_prev * (unsigned long long)prev->n_step;
+            c.step = step_now;
+            c.iterations += 1;
+            c.n_alive = (int32_t)n_alive;
+            c.n_step = (int32_t)n_step;
+            c.done = done;
+            *cur = c;
+        }
+    }
+    if (done || blockIdx.x >= nchunks) { if (threadIdx.x == 0) emitted_partials[blockIdx.x] = 0; return; }
+    const int lane = threadIdx.x & (PNR_WAVE - 1), wave = threadIdx.x / PNR_WAVE;
     const uint32_t* mip_lds = stage_mip(mip, MIP ? p.mip_words : 0);
     uint32_t emitted = 0;
-    for (uint32_t n = blockIdx.x * kRayBlock + threadIdx.x; n < n_alive; n += gridDim.x * kRayBlock) {
-        const int index = rays_alive[n];
+    uint32_t base = 0, summed_to = 0;   // base = sum of counts[0 .. summed_to)
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        unsigned long long pre = 0;
+        for (uint32_t j = summed_to + threadIdx.x; j < chunk; j += kRayBlock) pre += (unsigned long long)counts[j];
+        base += (uint32_t)block_sum_u64(pre, red);
+        summed_to = chunk;
+        const uint32_t slot = chunk * kRayBlock + threadIdx.x;
+        const int index = slot < n_prev ? alive_prev[slot] : -1;
+        const int keep = index >= 0 ? 1 : 0;
+        const unsigned long long alive_mask = __ballot(keep);
+        if (lane == 0) csum[wave] = __popcll(alive_mask);
+        __syncthreads();
+        int woff = 0;
+        for (int wv = 0; wv < wave; wv++) woff += csum[wv];
+        __syncthreads();
+        if (!keep) continue;
+        const uint32_t n = base + (uint32_t)woff + (uint32_t)__popcll(alive_mask & ((1ull << lane) - 1ull));
+        rays_alive[n] = index;
         RayCtx c;
         ctx_init(c, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, p, grid, mip_lds);
         float* px = xyzs + (size_t)n * n_step * 3;
@@ -158,9 +221,9 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_march(FrameCtl* __restrict_
 #endif
         }
 #ifdef PNR_MARCH_STATS
-        const int so = ctl->iterations == 0 ? 0 : 4;
-        if (atomicMax(&g_march_max[ctl->iterations & 63], (unsigned int)probes) < (unsigned int)probes)
-            for (int kk = 0; kk < 8; kk++) g_march_kinds[ctl->iterations & 63][kk] = kinds[kk];
+        const int so = prev->iterations + 1 == 0 ? 0 : 4;
+        if (atomicMax(&g_march_max[(prev->iterations + 1) & 63], (unsigned int)probes) < (unsigned int)probes)
+            for (int kk = 0; kk < 8; kk++) g_march_kinds[(prev->iterations + 1) & 63][kk] = kinds[kk];
         atomicAdd(&g_march_stats[so + 0], probes); atomicAdd(&g_march_stats[so + 1], empties); atomicAdd(&g_march_stats[so + 3], 1ull);
         {   // wave-level: max probes over the wave (what the wave actually executes)
             unsigned long long mx = probes;
@@ -542,68 +605,6 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_composite(const FrameCtl* _
     }
 }
 
-// Stable compaction of the alive list + the schedule of the NEXT iteration, one launch.  Every workgroup derives the output
-// offset of its chunk itself by summing the per-chunk survivor counts in front of it (k_frame_composite wrote them; a few
-// coalesced loads per thread from L2) -- no separate scan launch.  Workgroup 0 also totals the counts and the march's
-// sample partials and writes the next control block.
-__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long* sh /* [kRayBlock / 64] */) {
-    for (int off = PNR_WAVE / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, PNR_WAVE);
-    __syncthreads();
-    if ((threadIdx.x & (PNR_WAVE - 1)) == 0) sh[threadIdx.x / PNR_WAVE] = v;
-    __syncthreads();
-    unsigned long long t = 0;
-    for (int wv = 0; wv < (int)(kRayBlock / PNR_WAVE); wv++) t += sh[wv];
-    return t;
-}
-
-__global__ void __launch_bounds__(kRayBlock) k_frame_compact(const FrameCtl* __restrict__ cur, FrameCtl* __restrict__ nxt, const int32_t* __restrict__ alive_in,
-                                                             int32_t* __restrict__ alive_out, const int32_t* __restrict__ scratch, uint32_t N,
-                                                             uint32_t max_steps, const int32_t* __restrict__ emitted_partials, uint32_t n_partials) {
-    if (cur->done) { if (blockIdx.x == 0 && threadIdx.x == 0) *nxt = *cur; return; }
-    const uint32_t n_alive = (uint32_t)cur->n_alive;
-    const uint32_t nchunks = (n_alive + kRayBlock - 1) / kRayBlock;
-    const int32_t* counts = scratch + kHdr;
-    __shared__ int wsum[kRayBlock / PNR_WAVE];
-    __shared__ unsigned long long red[kRayBlock / PNR_WAVE];
-    const int lane = threadIdx.x & (PNR_WAVE - 1), wave = threadIdx.x / PNR_WAVE;
-    uint32_t base = 0, summed_to = 0;   // base = sum of counts[0 .. summed_to)
-    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        unsigned long long part = 0;
-        for (uint32_t j = summed_to + threadIdx.x; j < chunk; j += kRayBlock) part += (unsigned long long)counts[j];
-        base += (uint32_t)block_sum_u64(part, red);
-        summed_to = chunk;
-        const uint32_t i = chunk * kRayBlock + threadIdx.x;
-        const int id = i < n_alive ? alive_in[i] : -1;
-        const int keep = id >= 0 ? 1 : 0;
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) wsum[wave] = __popcll(m);
-        __syncthreads();
-        int woff = 0;
-        for (int wv = 0; wv < wave; wv++) woff += wsum[wv];
-        const int rank = __popcll(m & ((1ull << lane) - 1ull));
-        if (keep) alive_out[base + woff + rank] = id;
-        __syncthreads();
-    }
-    if (blockIdx.x == 0) {
-        unsigned long long part = 0, e = 0;
-        for (uint32_t j = threadIdx.x; j < nchunks; j += kRayBlock) part += (unsigned long long)counts[j];
-        for (uint32_t j = threadIdx.x; j < n_partials; j += kRayBlock) e += (unsigned long long)emitted_partials[j];
-        const unsigned long long total = block_sum_u64(part, red);
-        const unsigned long long emitted = block_sum_u64(e, red);
-        if (threadIdx.x == 0) {
-            FrameCtl c = *cur;
-            c.rendered += emitted;
-            c.rows += (unsigned long long)c.n_alive * (unsigned long long)c.n_step;
-            c.step += c.n_step;
-            c.iterations += 1;
-            c.n_alive = (int32_t)total;
-            c.n_step = schedule_n_step((int)N, c.n_alive);
-            c.done = (c.n_alive <= 0) || ((uint32_t)c.step >= max_steps);
-            *nxt = c;
-        }
-    }
-}
-
 static inline uint64_t align256(uint64_t v) { return (v + 255) & ~uint64_t(255); }
 
 struct FrameWorkspace {
@@ -613,7 +614,7 @@ struct FrameWorkspace {
     float *enc_pal, *enc_clip, *aux;  // palette model only
     float *s_o, *s_d, *s_near, *s_far, *s_ws, *s_depth, *s_image, *s_aux;  // ray_order: inputs / outputs in processing order
     int32_t* scratch;
-    int32_t* partials;
+    int32_t* partials[2];   // the march's per-workgroup sample counts: written by iteration i, summed by iteration i + 1
     uint64_t bytes;
 };
 static FrameWorkspace carve(void* base, uint32_t N, uint32_t aux_stride = 0, bool with_clip = false) {
@@ -632,7 +633,8 @@ static FrameWorkspace carve(void* base, uint32_t N, uint32_t aux_stride = 0, boo
     w.sigmas = reinterpret_cast<float*>(take(n * 4));
     w.rgbs = reinterpret_cast<float*>(take(n * 12));
     w.scratch = reinterpret_cast<int32_t*>(take((kHdr + n / kRayBlock + 2) * 4));
-    w.partials = reinterpret_cast<int32_t*>(take(2048 * 4));
+    w.partials[0] = reinterpret_cast<int32_t*>(take(2048 * 4));
+    w.partials[1] = reinterpret_cast<int32_t*>(take(2048 * 4));
     w.enc_pal = w.enc_clip = w.aux = nullptr;
     if (aux_stride) {
         w.enc_pal = reinterpret_cast<float*>(take(n * 16 * 2 * 4));
@@ -732,8 +734,8 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     const LevelParams lp = make_level_params(16, a->S, a->base_resolution);
     const uint32_t* mip = static_cast<const uint32_t*>(a->mip);
 
-    hipLaunchKernelGGL(k_frame_init, dim3(cdiv(N, kRayBlock)), dim3(kRayBlock), 0, s, N, in_near, w.alive[0], w.rays_t, out_ws, out_depth, out_image,
-                       w.ctl);
+    hipLaunchKernelGGL(k_frame_init, dim3(cdiv(N, kRayBlock)), dim3(kRayBlock), 0, s, N, in_near, w.alive[1], w.rays_t, out_ws, out_depth, out_image,
+                       w.ctl, w.scratch + kHdr);
     // optional live timing of the roofline kernel: HIP events on the launch stream around every k_frame_grid launch
     static thread_local std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
@@ -747,26 +749,32 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     // number of iterations, so the first chunk is the previous frame's count (one look per frame when the guess holds; launches
     // past the end are no-ops that cost a few microseconds each); after that, short chunks that grow for long, translucent marches.
     static thread_local uint32_t predicted_iterations = 0;
-    uint32_t chunk = predicted_iterations ? (predicted_iterations < 1024u ? predicted_iterations : 1024u) : 8u;
+    // (+1: the launch that finds no ray left is the one that reports it)
+    uint32_t chunk = predicted_iterations ? (predicted_iterations < 1024u ? predicted_iterations + 1u : 1024u) : 8u;
     uint32_t looks = 0;
+    uint32_t prev_partials = 0;   // workgroups of the previous march launch (= sample partials to add up)
     int iter = 0;
     for (;;) {
         for (uint32_t k = 0; k < chunk; k++, iter++) {
-            FrameCtl* cur = w.ctl + (iter & 1);
-            FrameCtl* nxt = w.ctl + ((iter + 1) & 1);
-            int32_t* alive_in = w.alive[iter & 1];
-            int32_t* alive_out = w.alive[(iter + 1) & 1];
+            FrameCtl* cur = w.ctl + (iter & 1);                 // this iteration's control block, written by its march launch
+            const FrameCtl* prev = w.ctl + ((iter + 1) & 1);    // the previous iteration's (k_frame_init's in front of iteration 0)
+            int32_t* alive_in = w.alive[iter & 1];              // this iteration's compacted list (the march writes it, the composite punches holes)
+            const int32_t* alive_prev = w.alive[(iter + 1) & 1];
             const uint32_t ray_blocks = cdiv(alive_ub, kRayBlock);
             const uint32_t rows_ub = (uint64_t)alive_ub * 8 < N ? alive_ub * 8 : N;
             const dim3 gm(ray_blocks < 2048u ? ray_blocks : 2048u), bm(kRayBlock);
             if (use_mip && pow2)
-                hipLaunchKernelGGL((k_frame_march<true, true>), gm, bm, march_lds, s, cur, alive_in, w.rays_t, in_o, in_d, mp, a->bitfield, in_far, w.xyzs, w.dirs, w.deltas, mip, w.partials);
+                hipLaunchKernelGGL((k_frame_march<true, true>), gm, bm, march_lds, s, prev, cur, alive_prev, alive_in, w.scratch, N, a->max_steps, w.partials[(iter + 1) & 1], prev_partials,
+                                   w.rays_t, in_o, in_d, mp, a->bitfield, in_far, w.xyzs, w.dirs, w.deltas, mip, w.partials[iter & 1]);
             else if (use_mip)
-                hipLaunchKernelGGL((k_frame_march<true, false>), gm, bm, march_lds, s, cur, alive_in, w.rays_t, in_o, in_d, mp, a->bitfield, in_far, w.xyzs, w.dirs, w.deltas, mip, w.partials);
+                hipLaunchKernelGGL((k_frame_march<true, false>), gm, bm, march_lds, s, prev, cur, alive_prev, alive_in, w.scratch, N, a->max_steps, w.partials[(iter + 1) & 1], prev_partials,
+                                   w.rays_t, in_o, in_d, mp, a->bitfield, in_far, w.xyzs, w.dirs, w.deltas, mip, w.partials[iter & 1]);
             else if (pow2)
-                hipLaunchKernelGGL((k_frame_march<false, true>), gm, bm, march_lds, s, cur, alive_in, w.rays_t, in_o, in_d, mp, a->bitfield, in_far, w.xyzs, w.dirs, w.deltas, mip, w.partials);
+                hipLaunchKernelGGL((k_frame_march<false, true>), gm, bm, march_lds, s, prev, cur, alive_prev, alive_in, w.scratch, N, a->max_steps, w.partials[(iter + 1) & 1], prev_partials,
+                                   w.rays_t, in_o, in_d, mp, a->bitfield, in_far, w.xyzs, w.dirs, w.deltas, mip, w.partials[iter & 1]);
             else
-                hipLaunchKernelGGL((k_frame_march<false, false>), gm, bm, march_lds, s, cur, alive_in, w.rays_t, in_o, in_d, mp, a->bitfield, in_far, w.xyzs, w.dirs, w.deltas, mip, w.partials);
+                hipLaunchKernelGGL((k_frame_march<false, false>), gm, bm, march_lds, s, prev, cur, alive_prev, alive_in, w.scratch, N, a->max_steps, w.partials[(iter + 1) & 1], prev_partials,
+                                   w.rays_t, in_o, in_d, mp, a->bitfield, in_far, w.xyzs, w.dirs, w.deltas, mip, w.partials[iter & 1]);
             const uint32_t gx = cdiv(rows_ub, 256);
             hipEvent_t e0 = timing ? next_event() : nullptr, e1 = timing ? next_event() : nullptr;
             if (e0) (void)hipEventRecord(e0, s);
@@ -798,9 +806,9 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
                                    out_image, w.scratch);
             hipLaunchKernelGGL(k_frame_composite, gm, bm, 0, s, cur, a->T_thresh, alive_in, w.rays_t, w.sigmas, w.rgbs, w.deltas, out_ws, out_depth, out_image,
                                w.scratch, (const float*)w.aux, out_aux, aux_stride, aux_fused, composite_fused);
-            hipLaunchKernelGGL(k_frame_compact, gm, bm, 0, s, cur, nxt, alive_in, alive_out, w.scratch, N, a->max_steps, w.partials, gm.x);
+            prev_partials = gm.x;
         }
-        if (hipMemcpyAsync(host_ctl, w.ctl + (iter & 1), sizeof(FrameCtl), hipMemcpyDeviceToHost, s) != hipSuccess) return PNR_ERR_LAUNCH;
+        if (hipMemcpyAsync(host_ctl, w.ctl + ((iter - 1) & 1), sizeof(FrameCtl), hipMemcpyDeviceToHost, s) != hipSuccess) return PNR_ERR_LAUNCH;   // the last launched iteration's
         if (hipStreamSynchronize(s) != hipSuccess) return PNR_ERR_LAUNCH;
         if (host_ctl->done) break;
         alive_ub = (uint32_t)host_ctl->n_alive;
