@@ -9,8 +9,8 @@
 //   * no staging buffers are zero-filled: the march writes the delta == 0 sentinel itself, padding
 //     rows do not exist, dead slots are skipped by the grid and field kernels;
 //   * world -> [0,1] normalisation, density_scale and the sample counter are folded into kernels.
-// Per iteration: march, grid (level-major, L2-resident tables), field (fp32 MFMA), composite(+count),
-// compact(+schedule) = 5 launches, no host round trip.
+// Per iteration: march (+ compaction of the previous alive list + this iteration's schedule), grid (level-major, L2-resident
+// tables), field (MFMA; + the composite when a ray has one sample), composite(+count) = 4 launches, no host round trip.
 #include "pnr_common.hpp"
 #include "march_core.hpp"
 #include "grid_core.hpp"
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_march(const FrameCtl* __res
         emitted += step;
         for (; step < n_step; step++) { pl[0] = 0.0f; pl[1] = 0.0f; pl += 2; }
     }
-    // one partial per workgroup, summed by k_frame_compact: thousands of same-address atomics would serialise in L2
+    // one partial per workgroup, summed by workgroup 0 of the next iteration's march: thousands of same-address atomics would serialise in L2
     __shared__ uint32_t wsum[kRayBlock / PNR_WAVE];
     for (int off = PNR_WAVE / 2; off > 0; off >>= 1) emitted += __shfl_xor(emitted, off, PNR_WAVE);
     if ((threadIdx.x & (PNR_WAVE - 1)) == 0) wsum[threadIdx.x / PNR_WAVE] = emitted;
