@@ -509,6 +509,7 @@ static int mlp_forward_impl(const pnr_mlp_desc* desc, const float* packed, const
     if (!make_plan(desc, p)) return PNR_ERR_UNSUPPORTED;
     if (B == 0) return PNR_OK;
     if (!packed || !x || !y) return PNR_ERR_INVALID;
+    if ((uint64_t)B * 64 >= (1ull << 32)) return PNR_ERR_UNSUPPORTED;   // element indices are 32-bit
     if (int rc = plan_sources(p, lm_levels, x_tail)) return rc;
     const size_t lds = ((size_t)p.wt_off[0] + kMlpWaves * kStageFloats) * 4;
     if (lds > 160 * 1024) return PNR_ERR_UNSUPPORTED;
@@ -545,6 +546,7 @@ static int mlp_backward_impl(const pnr_mlp_desc* desc, const float* packed, cons
         return PNR_OK;
     }
     if (!packed || !x || !dy || !workspace) return PNR_ERR_INVALID;
+    if ((uint64_t)B * 64 >= (1ull << 32)) return PNR_ERR_UNSUPPORTED;   // element indices are 32-bit
     if (workspace_bytes < pnr_mlp_backward_workspace_bytes(desc, B)) return PNR_ERR_INVALID;
     const size_t lds = ((size_t)p.packed_floats + kMlpWaves * 2 * kStageFloats) * 4;
     if (lds > 160 * 1024 || p.dw_floats > (uint32_t)(kMlpWaves * 2 * kStageFloats)) return PNR_ERR_UNSUPPORTED;

@@ -72,7 +72,7 @@ def fusable(net, h, act):
         return False
     if h.dtype == torch.float16 and not torch.is_autocast_enabled():
         return False
-    if act not in _ACT or len(net) not in (2, 3) or h.numel() // h.shape[-1] < MIN_ROWS:
+    if act not in _ACT or len(net) not in (2, 3) or not MIN_ROWS <= h.numel() // h.shape[-1] < 2 ** 26:
         return False
     dims = [net[0].in_features] + [l.out_features for l in net]
     if max(dims) > 64 or any(l.bias is not None or l.weight.dtype != torch.float32 for l in net):
