@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--model", choices=["palette", "nerf"], default="palette")
     ap.add_argument("--fp16", action="store_true")
+    ap.add_argument("--sync-each-step", action="store_true", help="loss.item() every step, as the reference's trainer does")
     ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True): one launch per parameter group instead of seven")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -60,6 +61,8 @@ def main():
         scaler.scale(loss).backward()
         scaler.step(opt)
         scaler.update()
+        if args.sync_each_step:
+            loss.item()      # the reference's trainer reads the loss every step (nerf/utils.py train_one_epoch): host and GPU cannot overlap across steps
         return int(m.step_counter[(m.local_step - 1) % 16, 0])
 
     for i in range(args.warmup):

@@ -77,3 +77,36 @@ def test_ops_fail_loudly_without_library(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
         _lib.load()
+
+
+def test_training_entry_points_validate_without_gpu():
+    """The training-side entries added in round 1 (fused MLP, palette train shade, density, bias gradient) size and validate on the host."""
+    from palettenerf_amd import _lib
+    lib = _lib.load()
+    u32, f32, i32, u64 = ctypes.c_uint32, ctypes.c_float, ctypes.c_int, ctypes.c_uint64
+
+    def desc(dims, act=0):
+        d = _lib.MlpDesc()
+        d.n_layers = len(dims) - 1
+        for i, v in enumerate(dims):
+            d.dims[i] = v
+        d.activation = act
+        return d
+
+    colour = desc([31, 64, 64, 3])
+    # W and W^T slots: (2x1 + 2x2 + 1x2) tiles each way, 4 KiB per tile
+    assert lib.pnr_mlp_packed_bytes(ctypes.byref(colour)) == 2 * (2 + 4 + 2) * 4096
+    assert lib.pnr_mlp_backward_workspace_bytes(ctypes.byref(colour), u32(627000)) == 256 * (31 * 64 + 64 * 64 + 64 * 3) * 4
+    assert lib.pnr_mlp_packed_bytes(ctypes.byref(desc([31, 65, 3]))) == 0            # a width above 64
+    bad = desc([31, 64, 3], act=2)
+    assert lib.pnr_mlp_forward(ctypes.byref(bad), None, None, u32(8), None, None) == -2
+    assert lib.pnr_mlp_forward(ctypes.byref(colour), None, None, u32(8), None, None) == -1      # null pointers
+    assert lib.pnr_mlp_forward(ctypes.byref(colour), None, None, u32(0), None, None) == 0       # empty batch
+    assert lib.pnr_mlp_forward_lm(ctypes.byref(colour), ctypes.c_void_p(8), ctypes.c_void_p(8), u32(16), None, u32(8), ctypes.c_void_p(8), None) == -2  # 31 < 32 columns
+    assert lib.pnr_palette_train_shade_workspace_bytes(u32(4)) == 512 * 4 * 3 * 4
+    assert lib.pnr_palette_train_shade_forward(u32(8), u32(17), u32(0), None, None, None, None, None, None, None, None, None, None) == -2   # nb > 16
+    assert lib.pnr_palette_train_shade_forward(u32(0), u32(4), u32(16), None, None, None, None, None, None, None, None, None, None) == 0
+    assert lib.pnr_nerf_density_forward(None, None, u32(8), f32(1.0), None, None, i32(7), None) == -2                                      # precision
+    assert lib.pnr_nerf_density_forward(None, None, u32(8), f32(1.0), None, None, i32(1), None) == -1
+    assert lib.pnr_linear_bgrad(None, i32(0), u32(0), u32(13), None, i32(1), None, u64(0), None) == -1                                      # no output
+    assert lib.pnr_set_option(b"composite_fusion", 1) == 0
