@@ -143,14 +143,14 @@ def main():
 
     from palettenerf_amd import _torch_glue, dist as pdist, scene
     m = build_model(args, device)
-    mode = args.mode or ("fused" if args.fp16 else "native")
+    mode = args.mode or "native"     # --fp16: the native loop under autocast looks the tables up as fp16 (the reference's -O tables), the field stays fp32-accurate
     m.march_mode = "device" if mode == "fused" else mode
-    if mode in ("fused", "native") and args.model == "nerf" and not args.fp16:
+    if mode in ("fused", "native") and args.model == "nerf" and (not args.fp16 or mode == "native"):
         from palettenerf_amd.fused import NeRFFieldFused
         m.fused_field = True
         m._fused = NeRFFieldFused(m)
         m._fused.precision = 0 if args.field_precision == "fp32" else 1
-    if mode in ("fused", "native") and args.model == "palette" and not args.fp16:
+    if mode in ("fused", "native") and args.model == "palette" and (not args.fp16 or mode == "native"):
         m.fused_field = True
     H = W = args.res
     n_views = world if args.scaling == "weak" else 1
@@ -251,7 +251,7 @@ def main():
 
     if rank == 0:
         per_sample = GRID_BYTES_PER_SAMPLE_FP16 if args.fp16 else GRID_BYTES_PER_SAMPLE_FP32
-        if args.half_tables:
+        if args.half_tables or (args.fp16 and m.march_mode == "native"):
             per_sample = 12 + 16 * 8 * 2 * 2 + 32 * 4   # half rows gathered, fp32 encoder output written
         n_tables = 1 if args.model == "nerf" else 2  # palette: encoder + encoder_palette (pred_clip off in the bench config)
         launches = prof["pnr_grid_encode_forward"]
@@ -280,7 +280,7 @@ def main():
             "vs_baseline": None, "dtype": "f16" if args.fp16 else "f32", "data": "synthetic",
             "config": {"workload": f"configs[{1 if args.model == 'nerf' else 2}]: NeRF-synthetic lego geometry (scene {args.scene.upper()}), -m {args.model} inference, {H}x{W}, {n_views} view(s)/step",
                        "rays_per_step": n_views * H * W, "rendered_samples_per_step": total_rendered // args.steps,
-                       "evaluated_rows_per_step_rank0": rows // args.steps, "density_scale": args.density_scale, "dt_gamma": args.dt_gamma, "march_mode": m.march_mode, "fused_field": bool(getattr(m, "fused_field", False)), "field_precision": args.field_precision, "half_tables": bool(args.half_tables), "ray_order": args.ray_order,
+                       "evaluated_rows_per_step_rank0": rows // args.steps, "density_scale": args.density_scale, "dt_gamma": args.dt_gamma, "march_mode": m.march_mode, "fused_field": bool(getattr(m, "fused_field", False)), "field_precision": args.field_precision, "half_tables": bool(args.half_tables or (args.fp16 and m.march_mode == "native")), "ray_order": args.ray_order,
                        "parallelism": f"32x32 ray tiles of {n_views} view(s) round-robin over {world} GPUs + one all_gather/step" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": n_launches,

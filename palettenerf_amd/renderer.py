@@ -388,9 +388,16 @@ class NeRFRenderer(_OccupancyMaintenance, _RendererBase):
             if getattr(self, "_fused", None) is None:
                 from .fused import NeRFFieldFused
                 self._fused = NeRFFieldFused(self)
-            if perturb or torch.is_autocast_enabled():
-                raise RuntimeError("march_mode='native' covers fp32 inference without perturbation")
-            weights_sum, depth_acc, image_acc, stats = self._fused.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color=bg_color)
+            if perturb:
+                raise RuntimeError("march_mode='native' covers inference without perturbation")
+            # under fp16 autocast (the reference's -O mode) the loop looks the hash table up as fp16 with the reference's half interpolation
+            # (gridencoder/grid.py:36-39), the field stays on its fp32-accurate matrix path; outputs are fp32 as the reference's are
+            was_half = self._fused.table_half
+            self._fused.table_half = was_half or torch.is_autocast_enabled()
+            try:
+                weights_sum, depth_acc, image_acc, stats = self._fused.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color=bg_color)
+            finally:
+                self._fused.table_half = was_half
             if stats["finished"]:   # the frame call applied the epilogue below itself (same fp32 operations, one launch less each)
                 image, depth = image_acc, depth_acc
             else:
@@ -620,7 +627,9 @@ class PaletteRenderer(_RendererBase):
         basis_acc_map = torch.zeros(N, nb, **f32)
         clip_feat_map = torch.zeros(N, clip_dim, **f32)
 
-        use_fused = bool(getattr(self, "fused_field", False)) and self.edit is None and self.stylizer is None and not torch.is_autocast_enabled()
+        # under fp16 autocast only the native loop takes the fused path (fp16 tables, fp32-accurate field); it has no clip-head variant there
+        autocast_ok = not torch.is_autocast_enabled() or (self.march_mode == "native" and not perturb and not self.opt.pred_clip)
+        use_fused = bool(getattr(self, "fused_field", False)) and self.edit is None and self.stylizer is None and autocast_ok
         if use_fused:
             if getattr(self, "_fused", None) is None:
                 from .fused import PaletteFieldFused
@@ -674,7 +683,12 @@ class PaletteRenderer(_RendererBase):
 
         native = use_fused and self.march_mode == "native" and not perturb
         if native:  # device-driven loop: same schedule and arithmetic, no per-iteration host sync (pnr_palette_render_frame)
-            ws_n, depth_n, image_n, aux_map, stats = self._fused.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh)
+            was_half = self._fused.table_half
+            self._fused.table_half = was_half or torch.is_autocast_enabled()     # -O mode: fp16 tables with the reference's half interpolation
+            try:
+                ws_n, depth_n, image_n, aux_map, stats = self._fused.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh)
+            finally:
+                self._fused.table_half = was_half
             st = _MarchState.__new__(_MarchState)
             st.weights_sum, st.depth, st.image, st.n_samples = ws_n, depth_n, image_n, stats["rows"]
             st.rendered = torch.tensor([stats["rendered"]], dtype=torch.int64)   # host tensor: the count came back with the control block

@@ -474,3 +474,33 @@ def test_update_extra_state_with_the_fused_density_kernel(cuda):
     thresh = min(mean, 0.01)
     near = int(((a - thresh).abs() <= 2e-5 * a.abs()).sum())
     assert diff_bits <= near
+
+
+@pytest.mark.parametrize("model_kind", ["nerf", "palette"])
+def test_native_loop_under_fp16_autocast_uses_half_tables(cuda, model_kind):
+    """The reference's -O mode (fp16 autocast): the native loop then looks the tables up as fp16 with the reference's half interpolation and keeps
+    the field on its fp32-accurate path.  Same frame, bit for bit, as table_half=True outside autocast; fp32 outputs."""
+    from palettenerf_amd.fused import NeRFFieldFused, PaletteFieldFused
+    if model_kind == "nerf":
+        m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=30.0, min_near=0.2)
+    else:
+        m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True, density_scale=30.0, min_near=0.2)
+    scene.seed_field_(m, 17)
+    m = m.to(cuda).eval()
+    put_scene(m, cuda)
+    m.count_rendered = True
+    m.march_mode, m.fused_field = "native", True
+    m._fused = (NeRFFieldFused if model_kind == "nerf" else PaletteFieldFused)(m)
+    pose = torch.from_numpy(scene.lookat_pose())[None]
+    ro, rd = scene.get_rays(pose, scene.intrinsics_from_fov(48, 48), 48, 48)
+    ro, rd = ro.to(cuda), rd.to(cuda)
+    kw = dict(perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        a = m.render(ro, rd, **kw)
+    assert m._fused.table_half is False          # restored
+    m._fused.table_half = True
+    with torch.no_grad():
+        b = m.render(ro, rd, **kw)
+    assert a["image"].dtype == torch.float32 and int(a["rendered"].item()) == int(b["rendered"].item()) > 500
+    for k in ("image", "depth", "weights_sum"):
+        assert torch.equal(torch.nan_to_num(a[k], nan=-7.0), torch.nan_to_num(b[k], nan=-7.0)), k
