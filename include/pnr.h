@@ -378,6 +378,12 @@ int pnr_linear_bgrad(const void* dy, int dy_dtype, uint32_t B, uint32_t out_dim,
 int pnr_get_rays(const float* poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, const int64_t* inds,
                  uint32_t N, float* rays_o, float* rays_d, pnr_stream_t stream);
 
+/* The frame's last step on the way to the video / PNG writer (nerf/utils.py:719-723, 1013-1017: `(pred * 255).astype(np.uint8)` on the
+ * host, after `linear_to_srgb` when the scene is in linear colour, utils.py:43-44, 1010-1011): fp32 values -> uint8 on the device, so that
+ * a frame leaves the GPU as 3 bytes per pixel.  u8 = (uint8)(v * 255) (truncation, as numpy's astype for in-range values);
+ * linear_to_srgb != 0: v = v < 0.0031308 ? 12.92 v : 1.055 v^0.41666 - 0.055 first. */
+int pnr_image_to_uint8(const float* src, uint64_t n, int linear_to_srgb, uint8_t* dst, pnr_stream_t stream);
+
 /* ---------------------------------------------------------------- palette ------------------ */
 
 /* Training-mode palette colour-basis composite as one launch each way (replaces the ~40 torch launches of palette/renderer.py:344-386

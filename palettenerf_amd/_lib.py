@@ -73,6 +73,7 @@ SIGNATURES = {
     "pnr_palette_train_shade_workspace_bytes": [_u32],
     "pnr_palette_train_shade_forward": [_u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "pnr_palette_train_shade_backward": [_u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _ptr],
+    "pnr_image_to_uint8": [_ptr, _u64, _int, _ptr, _ptr],
     "pnr_get_rays": [_ptr, _u32, _f32, _f32, _f32, _f32, _u32, _u32, _ptr, _u32, _ptr, _ptr, _ptr],
 }
 _RESTYPES = {"pnr_error_string": ctypes.c_char_p, "pnr_scan_scratch_bytes": _u64, "pnr_nerf_field_packed_bytes": _u64, "pnr_occupancy_mip_bytes": _u64, "pnr_nerf_frame_workspace_bytes": _u64, "pnr_palette_field_packed_bytes": _u64, "pnr_palette_frame_workspace_bytes": _u64,

@@ -376,6 +376,30 @@ __global__ void __launch_bounds__(1024) k_mip_bounds(uint32_t* __restrict__ mip,
 }
 
 // nerf/utils.py:53-149, deterministic core (pixel ids -> rays)
+// four values per thread: one 16-byte load, one 4-byte store
+__global__ void __launch_bounds__(kBlock) k_image_to_uint8(const float* __restrict__ src, uint64_t n, int to_srgb, uint8_t* __restrict__ dst) {
+    const uint64_t i0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (i0 + 3 < n && (reinterpret_cast<uintptr_t>(src + i0) & 15u) == 0) {
+        const float4 q = *reinterpret_cast<const float4*>(src + i0);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+        for (int k = 0; k < 4; k++) if (i0 + k < n) v[k] = src[i0 + k];
+    }
+    uint8_t b[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float x = v[k];
+        if (to_srgb) x = x < 0.0031308f ? 12.92f * x : 1.055f * powf(x, 0.41666f) - 0.055f;
+        b[k] = (uint8_t)(int)(x * 255.0f);
+    }
+    if (i0 + 3 < n && (reinterpret_cast<uintptr_t>(dst + i0) & 3u) == 0)
+        *reinterpret_cast<uchar4*>(dst + i0) = make_uchar4(b[0], b[1], b[2], b[3]);
+    else
+        for (int k = 0; k < 4; k++) if (i0 + k < n) dst[i0 + k] = b[k];
+}
+
 __global__ void __launch_bounds__(kBlock) k_get_rays(const float* __restrict__ poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t W,
                                                      const long long* __restrict__ inds, uint32_t N, float* __restrict__ rays_o,
                                                      float* __restrict__ rays_d) {
@@ -436,6 +460,15 @@ int pnr_get_rays(const float* poses, uint32_t B, float fx, float fy, float cx, f
     if (!inds && N != H * W) return PNR_ERR_INVALID;
     hipLaunchKernelGGL(k_get_rays, dim3(cdiv(N, kBlock), B), dim3(kBlock), 0, as_stream(stream), poses, B, fx, fy, cx, cy, W,
                        reinterpret_cast<const long long*>(inds), N, rays_o, rays_d);
+    return check_launch();
+}
+
+int pnr_image_to_uint8(const float* src, uint64_t n, int linear_to_srgb, uint8_t* dst, pnr_stream_t stream) {
+    if (n == 0) return PNR_OK;
+    if (!src || !dst) return PNR_ERR_INVALID;
+    const uint64_t blocks = (n + kBlock * 4 - 1) / (kBlock * 4);
+    if (blocks > 0x7fffffffull) return PNR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_image_to_uint8, dim3((uint32_t)blocks), dim3(kBlock), 0, as_stream(stream), src, n, linear_to_srgb, dst);
     return check_launch();
 }
 

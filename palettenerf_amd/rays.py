@@ -79,3 +79,12 @@ def get_rays(poses, intrinsics, H, W, N=-1, error_map=None, patch_size=1, random
     out["rays_o"] = rays_o
     out["rays_d"] = rays_d
     return out
+
+
+def image_to_uint8(image, linear_to_srgb=False):
+    """What the reference does on the host before writing a frame (nerf/utils.py:719-723, 1010-1017): `(pred * 255).astype(np.uint8)`, after
+    `linear_to_srgb` for scenes in linear colour -- here on the device (pnr_image_to_uint8), so a frame crosses PCIe as bytes."""
+    src = require(image.contiguous(), torch.float32, "image")
+    out = torch.empty(src.shape, dtype=torch.uint8, device=src.device)
+    call("pnr_image_to_uint8", ptr(src), ctypes.c_uint64(src.numel()), ctypes.c_int(int(bool(linear_to_srgb))), ptr(out))
+    return out

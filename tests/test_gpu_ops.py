@@ -936,3 +936,27 @@ def test_encode_mlp_keeps_the_encoder_output_level_major(cuda, tail_w, dims, act
     for name, a, b, tol in zip(["table"] + [f"dw{i}" for i in range(len(net))], got, want, [1e-4] + [3e-5] * len(net)):
         err, ref = float((a - b).abs().max()), float(b.abs().max())
         assert err <= tol * ref, (name, err, ref)
+
+
+def test_image_to_uint8_matches_the_host_conversion(cuda):
+    """pnr_image_to_uint8 against what the reference does on the host before writing a frame, `(pred * 255).astype(np.uint8)`
+    (nerf/utils.py:716-723): bit-exact, incl. exact 0 and 1, every byte boundary k/255 and its float neighbours, an odd element count and an
+    unaligned view.  With linear_to_srgb (utils.py:43-44) the device powf may differ from torch's by an ulp: at most one level apart, < 0.01 %."""
+    from palettenerf_amd import rays
+    rng = np.random.default_rng(9)
+    edges = np.arange(256, dtype=np.float32) / np.float32(255)
+    x = np.concatenate([rng.random(300001).astype(np.float32), [0.0, 1.0], edges, np.nextafter(edges, 2, dtype=np.float32), np.nextafter(edges, -1, dtype=np.float32).clip(0)])
+    x = x.astype(np.float32)
+    t = dev(x, cuda)
+    got = host(rays.image_to_uint8(t))
+    np.testing.assert_array_equal(got, (x * np.float32(255)).astype(np.uint8))
+    view = t[1:-2]                                # not 16-byte aligned, odd length
+    np.testing.assert_array_equal(host(rays.image_to_uint8(view)), (x[1:-2] * np.float32(255)).astype(np.uint8))
+    img = t[:300000].reshape(100, 1000, 3)
+    assert rays.image_to_uint8(img).shape == (100, 1000, 3)
+    xt = torch.from_numpy(x)
+    srgb = torch.where(xt < 0.0031308, 12.92 * xt, 1.055 * xt ** 0.41666 - 0.055).numpy()
+    want = (srgb * np.float32(255)).astype(np.uint8)
+    got = host(rays.image_to_uint8(t, linear_to_srgb=True))
+    diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert diff.max() <= 1 and (diff != 0).mean() < 1e-4
