@@ -123,3 +123,15 @@ class _palette_train_shade(Function):
 
 
 palette_train_shade = _palette_train_shade.apply
+
+
+def get_palette_weight_with_hist(rgb, hist_weights):
+    """palette/utils.py:117-124: per-pixel palette weights read from the extraction's 3-D colour LUT `hist_weights` [1, nb, R, G, B]
+    (PaletteRenderer.initialize_palette keeps it in that layout) by trilinear interpolation at the pixel's colour; zero outside [0, 1]^3.
+    rgb [..., 3] in [0, 1] -> [..., nb].  A torch op in the reference as well (grid_sample; its x axis is the LUT's last one, i.e. blue)."""
+    if hist_weights.ndim != 5:
+        raise AssertionError("hist_weights must be [1, nb, R, G, B]")
+    lead = rgb.shape[:-1]
+    grid = rgb.reshape(1, 1, 1, -1, 3).flip(-1) * 2 - 1
+    w = torch.nn.functional.grid_sample(hist_weights, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+    return w.reshape(hist_weights.shape[1], -1).permute(1, 0).reshape(*lead, -1)

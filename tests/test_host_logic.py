@@ -242,3 +242,30 @@ def test_sample_pdf_matches_a_direct_inverse_cdf():
         ok = ~flat[np.clip(np.searchsorted(cdf[b], u, side="right") - 1, 0, 31)]
         np.testing.assert_allclose(got[b][ok], want[ok], rtol=0, atol=2e-4)
     assert np.all(np.diff(got, axis=1) >= -1e-6)
+
+
+def test_palette_weight_lut_is_a_trilinear_lookup():
+    """get_palette_weight_with_hist (palette/utils.py:117-124) against a direct NumPy trilinear interpolation of the [R, G, B] LUT, and against the
+    reference's own expression (grid_sample over rgb[..., [2, 1, 0]] * 2 - 1)."""
+    from palettenerf_amd import palette_utils
+    rng = np.random.default_rng(3)
+    nb, R = 4, 8
+    lut = rng.random((nb, R, R, R)).astype(np.float32)
+    rgb = rng.random((5, 7, 3)).astype(np.float32)
+    rgb[0, 0] = [0.0, 1.0, 0.5]
+    hw = torch.from_numpy(lut)[None]
+    got = palette_utils.get_palette_weight_with_hist(torch.from_numpy(rgb), hw).numpy()
+    assert got.shape == (5, 7, nb)
+    p = rgb.reshape(-1, 3).astype(np.float64) * (R - 1)
+    i0 = np.clip(np.floor(p).astype(int), 0, R - 2)
+    f = p - i0
+    want = np.zeros((p.shape[0], nb))
+    for dr in (0, 1):
+        for dg in (0, 1):
+            for db in (0, 1):
+                wgt = np.where(dr, f[:, 0], 1 - f[:, 0]) * np.where(dg, f[:, 1], 1 - f[:, 1]) * np.where(db, f[:, 2], 1 - f[:, 2])
+                want += wgt[:, None] * lut[:, i0[:, 0] + dr, i0[:, 1] + dg, i0[:, 2] + db].T
+    np.testing.assert_allclose(got.reshape(-1, nb), want, rtol=0, atol=2e-6)
+    t = torch.from_numpy(rgb).reshape(-1, 3)
+    ref = torch.nn.functional.grid_sample(hw, t[None, None, None, :, [2, 1, 0]] * 2 - 1, mode="bilinear", padding_mode="zeros", align_corners=True)
+    np.testing.assert_array_equal(got.reshape(-1, nb), ref.squeeze().permute(1, 0).numpy())
