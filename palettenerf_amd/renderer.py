@@ -488,6 +488,34 @@ class RegionEdit(nn.Module):
         return torch.lerp(rgbs, rgb_new, weight[..., None])
 
 
+class Stylizer(nn.Module):
+    """User-guided photorealistic style transfer head (palette/renderer.py:150-183): per-basis intensity shift dI, palette shift dP and a
+    3x3 transform of the offsets per basis (kept near a rotation by ARAP_loss), optimised by the GUI and then used by run_cuda in place of
+    the plain colour-basis composite.  Same parameter names and shapes as the reference's."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        nb = opt.num_basis
+        self.dI = nn.Parameter(torch.zeros(nb, dtype=torch.float32))
+        self.dP = nn.Parameter(torch.zeros(1, nb, 3, dtype=torch.float32))
+        self.ddelta = nn.Parameter(torch.eye(3, dtype=torch.float32)[None].repeat(nb, 1, 1))
+
+    def ARAP_loss(self):
+        eye = torch.eye(3, dtype=torch.float32, device=self.ddelta.device)[None]
+        return ((torch.bmm(self.ddelta, self.ddelta.transpose(1, 2)) - eye) ** 2).sum()
+
+    def forward(self, radiance, omega, palette, offsets, view_dep=None):
+        nb = self.opt.num_basis
+        lead = offsets.shape[:-2]
+        intensity = (F.softplus(radiance.reshape(-1, 1, 1)).repeat(1, nb, 1) + self.dI[None, :, None]).clamp(0)
+        colour = palette.reshape(-1, nb, 3) + self.dP + torch.einsum("npi,pij->npj", offsets.reshape(-1, nb, 3), self.ddelta)
+        rgbs = (omega.reshape(-1, nb, 1) * (intensity * colour).clamp(0, 1)).sum(dim=-2)
+        if view_dep is not None:
+            rgbs = rgbs + view_dep.detach()
+        return rgbs.reshape(*lead, 3)
+
+
 class PaletteRenderer(_RendererBase):
     """palette/renderer.py:186-245"""
 

@@ -269,3 +269,26 @@ def test_palette_weight_lut_is_a_trilinear_lookup():
     t = torch.from_numpy(rgb).reshape(-1, 3)
     ref = torch.nn.functional.grid_sample(hw, t[None, None, None, :, [2, 1, 0]] * 2 - 1, mode="bilinear", padding_mode="zeros", align_corners=True)
     np.testing.assert_array_equal(got.reshape(-1, nb), ref.squeeze().permute(1, 0).numpy())
+
+
+def test_stylizer_matches_its_formula_and_starts_as_the_plain_composite():
+    """Stylizer (palette/renderer.py:150-183): with its initial parameters it is the plain colour-basis composite with clamping
+    sum_b omega_b clamp(softplus(radiance) (P_b + offsets_b), 0, 1) + view_dep; with perturbed parameters it follows the reference's expression."""
+    import torch.nn.functional as F
+    opt = renderer.default_opt()
+    st = renderer.Stylizer(opt)
+    assert {k: tuple(v.shape) for k, v in st.state_dict().items()} == {"dI": (4,), "dP": (1, 4, 3), "ddelta": (4, 3, 3)}
+    g = torch.Generator().manual_seed(4)
+    M, nb = 50, opt.num_basis
+    radiance, omega = torch.randn(M, 1, 1, generator=g), torch.rand(M, nb, 1, generator=g)
+    palette, offsets, vd = torch.rand(1, nb, 3, generator=g), torch.randn(M, nb, 3, generator=g) * 0.1, torch.rand(M, 3, generator=g)
+    plain = (omega * (F.softplus(radiance) * (palette + offsets)).clamp(0, 1)).sum(-2) + vd
+    torch.testing.assert_close(st(radiance, omega, palette.expand(M, nb, 3), offsets, vd), plain)
+    assert float(st.ARAP_loss()) == 0.0
+    with torch.no_grad():
+        st.dI.copy_(torch.tensor([0.1, -0.2, 0.0, 0.3])); st.dP.normal_(0, 0.05, generator=g); st.ddelta.add_(torch.randn(nb, 3, 3, generator=g) * 0.1)
+    want = ((F.softplus(radiance).repeat(1, nb, 1) + st.dI[None, :, None]).clamp(0)
+            * ((palette.expand(M, nb, 3) + st.dP) + torch.einsum("npi,pij->npj", offsets, st.ddelta))).clamp(0, 1)
+    want = (omega * want).sum(-2)
+    torch.testing.assert_close(st(radiance, omega, palette.expand(M, nb, 3), offsets), want)
+    assert float(st.ARAP_loss()) > 0.0
