@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--ray-order", choices=["tile8", "tile4", "tile16", "morton", "rowmajor"], default="tile8", help="initial order of the alive list in the native loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-interleave", action="store_true", help="-m palette: separate hash-table lookups instead of the interleaved copy (A/B)")
+    ap.add_argument("--pred-clip", action="store_true", help="-m palette with the clip-feature head (main_palette.py --pred_clip): third hash table + clip_net")
     ap.add_argument("--half-tables", action="store_true", help="native loop with fp16 hash tables and the reference's half interpolation (its --fp16 tables); MLP unchanged")
     ap.add_argument("--scene", choices=["s0", "s1"], default="s0", help="s0: dense 8^3 bricks (the headline scene); s1: sparse 4^3 bricks, the occupied box ~94 %% air")
     ap.add_argument("--dt-gamma", type=float, default=0.0, help="march step growth (0 = the lego config; 1/128 = the LLFF / 360 configs)")
@@ -57,7 +59,7 @@ def build_model(args, device):
     if args.model == "nerf":
         m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=args.density_scale, min_near=0.2)
     else:
-        m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True, density_scale=args.density_scale, min_near=0.2)
+        m = network.PaletteNetwork(renderer.default_opt(pred_clip=bool(getattr(args, "pred_clip", False))), bound=2, cuda_ray=True, density_scale=args.density_scale, min_near=0.2)
     scene.seed_field_(m, 0)
     m = m.to(device).eval()
     m.density_grid.copy_(torch.from_numpy(scene.brick_density_grid() if args.scene == "s0" else scene.sparse_density_grid()).to(device))
@@ -82,7 +84,7 @@ def cpu_baseline(args):
         if args.model == "nerf":
             m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=args.density_scale, min_near=0.2)
         else:
-            m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True, density_scale=args.density_scale, min_near=0.2)
+            m = network.PaletteNetwork(renderer.default_opt(pred_clip=bool(getattr(args, "pred_clip", False))), bound=2, cuda_ray=True, density_scale=args.density_scale, min_near=0.2)
         scene.seed_field_(m, 0)
         grid = scene.brick_density_grid() if args.scene == "s0" else scene.sparse_density_grid()
         m.density_grid.copy_(torch.from_numpy(grid))
@@ -152,6 +154,10 @@ def main():
         m._fused.precision = 0 if args.field_precision == "fp32" else 1
     if mode in ("fused", "native") and args.model == "palette" and (not args.fp16 or mode == "native"):
         m.fused_field = True
+        if args.no_interleave:
+            from palettenerf_amd.fused import PaletteFieldFused
+            m._fused = PaletteFieldFused(m)
+            m._fused.interleave_tables = False
     H = W = args.res
     n_views = world if args.scaling == "weak" else 1
     import numpy as np
@@ -253,7 +259,7 @@ def main():
         per_sample = GRID_BYTES_PER_SAMPLE_FP16 if args.fp16 else GRID_BYTES_PER_SAMPLE_FP32
         if args.half_tables or (args.fp16 and m.march_mode == "native"):
             per_sample = 12 + 16 * 8 * 2 * 2 + 32 * 4   # half rows gathered, fp32 encoder output written
-        n_tables = 1 if args.model == "nerf" else 2  # palette: encoder + encoder_palette (pred_clip off in the bench config)
+        n_tables = 1 if args.model == "nerf" else (3 if args.pred_clip else 2)  # palette: encoder + encoder_palette (+ encoder_clip with --pred-clip)
         launches = prof["pnr_grid_encode_forward"]
         k_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in launches)
         k_units = sum(u for _, _, u in launches)

@@ -246,9 +246,13 @@ typedef struct pnr_palette_frame_args {
     const float* embeddings_pair;      /* optional: `encoder` and `encoder_palette` interleaved row by row ([rows][4] floats, built by
                                           pnr_interleave_tables; rebuild when either table changes).  Used when pred_clip == 0: one 16-byte
                                           gather serves both tables, results bit-identical to the separate lookups */
+    const float* embeddings_triple;    /* optional, pred_clip != 0: all three tables interleaved ([rows][8] floats: encoder, encoder_palette,
+                                          encoder_clip, 2 pad; pnr_interleave_tables3): one 32-byte row per corner, bit-identical results */
 } pnr_palette_frame_args;
 /* out[i] = (a[i].x, a[i].y, b[i].x, b[i].y) for two C = 2 fp32 tables of `rows` rows with the same level layout */
 int pnr_interleave_tables(const float* a, const float* b, uint64_t rows, float* out, pnr_stream_t stream);
+/* a, b, c: [rows][2] fp32 -> out [rows][8] = (a.x, a.y, b.x, b.y, c.x, c.y, 0, 0): the --pred_clip model's three lookups from one 32-byte row */
+int pnr_interleave_tables3(const float* a, const float* b, const float* c, uint64_t rows, float* out, pnr_stream_t stream);
 uint64_t pnr_palette_frame_workspace_bytes(uint32_t N, uint32_t num_basis, uint32_t clip_dim, int pred_clip);
 int pnr_palette_render_frame(const pnr_palette_frame_args* args, pnr_stream_t stream);
 

@@ -70,6 +70,7 @@ SIGNATURES = {
     "pnr_linear_bgrad": [_ptr, _int, _u32, _u32, _ptr, _int, _ptr, _u64, _ptr],
     "pnr_palette_field_stages_aux": [_u32, _int],
     "pnr_interleave_tables": [_ptr, _ptr, _u64, _ptr, _ptr],
+    "pnr_interleave_tables3": [_ptr, _ptr, _ptr, _u64, _ptr, _ptr],
     "pnr_palette_train_shade_workspace_bytes": [_u32],
     "pnr_palette_train_shade_forward": [_u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "pnr_palette_train_shade_backward": [_u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _ptr],
@@ -97,7 +98,7 @@ class NerfFrameArgs(ctypes.Structure):
 class PaletteFrameArgs(ctypes.Structure):
     """Mirror of `pnr_palette_frame_args` (include/pnr.h)."""
     _fields_ = [("base", NerfFrameArgs), ("embeddings_palette", _ptr), ("embeddings_clip", _ptr), ("basis_color", _ptr), ("or_bias", _ptr),
-                ("num_basis", _u32), ("clip_dim", _u32), ("pred_clip", _int), ("offsets_weight", _f32), ("view_dep_weight", _f32), ("aux_map", _ptr), ("embeddings_pair", _ptr)]
+                ("num_basis", _u32), ("clip_dim", _u32), ("pred_clip", _int), ("offsets_weight", _f32), ("view_dep_weight", _f32), ("aux_map", _ptr), ("embeddings_pair", _ptr), ("embeddings_triple", _ptr)]
 
 
 class PaletteWeights(ctypes.Structure):

@@ -438,6 +438,85 @@ __global__ void __launch_bounds__(256) k_frame_grid_pair(const FrameCtl* __restr
     }
 }
 
+// --pred_clip: `encoder`, `encoder_palette` and `encoder_clip` in one copy, 32 bytes per row (two 16-byte loads from the same sector
+// per corner instead of three scattered 8-byte ones); same corner order and fmaf chains: bit-identical encoder outputs
+__global__ void __launch_bounds__(256) k_interleave_tables3(const float2* __restrict__ a, const float2* __restrict__ b, const float2* __restrict__ c,
+                                                            uint64_t rows, float4* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < rows) {
+        const float2 u = a[i], v = b[i], t = c[i];
+        out[2 * i] = make_float4(u.x, u.y, v.x, v.y);
+        out[2 * i + 1] = make_float4(t.x, t.y, 0.0f, 0.0f);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_frame_grid_triple(const FrameCtl* __restrict__ ctl, const float* __restrict__ xyzs, const float* __restrict__ deltas,
+                                                           const float4* __restrict__ table, float* __restrict__ enc_a, float* __restrict__ enc_b,
+                                                           float* __restrict__ enc_c, const int32_t* __restrict__ offsets, LevelParams lp,
+                                                           uint32_t level_stride, float bound, float two_bound, uint32_t gridtype) {
+    if (ctl->done) return;
+    const uint32_t rows = (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step;
+    const uint32_t level = blockIdx.y;
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    const float4* g = table + (size_t)off0 * 2;
+    const float scale = lp.scale[level];
+    const uint32_t resolution = lp.resolution[level];
+    for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < rows; b += gridDim.x * 256) {
+        if (deltas[(size_t)b * 2] == 0.0f) continue;
+        float in[3];
+        bool oob = false;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            in[d] = (xyzs[(size_t)b * 3 + d] + bound) / two_bound;
+            oob |= (in[d] < 0.0f) | (in[d] > 1.0f);
+        }
+        float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float2 outc = make_float2(0.0f, 0.0f);
+        if (!oob) {
+            float pos[3];
+            uint32_t pg[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                pos[d] = fmaf(in[d], scale, 0.5f);
+                const float fl = floorf(pos[d]);
+                pg[d] = (uint32_t)fl;
+                pos[d] -= (float)pg[d];
+            }
+            uint32_t idxs[8];
+            float ws[8];
+#pragma unroll
+            for (uint32_t idx = 0; idx < 8; idx++) {
+                float w = 1.0f;
+                uint32_t pl[3];
+#pragma unroll
+                for (uint32_t d = 0; d < 3; d++) {
+                    if ((idx & (1u << d)) == 0) { w *= 1.0f - pos[d]; pl[d] = pg[d]; }
+                    else { w *= pos[d]; pl[d] = pg[d] + 1; }
+                }
+                ws[idx] = w;
+                idxs[idx] = grid_index<3, 1>(gridtype, false, hashmap_size, resolution, pl);
+            }
+            float4 v[8];
+            float2 vc[8];
+#pragma unroll
+            for (uint32_t idx = 0; idx < 8; idx++) {
+                v[idx] = g[(size_t)idxs[idx] * 2];
+                vc[idx] = *reinterpret_cast<const float2*>(&g[(size_t)idxs[idx] * 2 + 1]);
+            }
+#pragma unroll
+            for (uint32_t idx = 0; idx < 8; idx++) {
+                out.x = fmaf(ws[idx], v[idx].x, out.x); out.y = fmaf(ws[idx], v[idx].y, out.y);
+                out.z = fmaf(ws[idx], v[idx].z, out.z); out.w = fmaf(ws[idx], v[idx].w, out.w);
+                outc.x = fmaf(ws[idx], vc[idx].x, outc.x); outc.y = fmaf(ws[idx], vc[idx].y, outc.y);
+            }
+        }
+        *reinterpret_cast<float2*>(enc_a + ((size_t)level * level_stride + b) * 2) = make_float2(out.x, out.y);
+        *reinterpret_cast<float2*>(enc_b + ((size_t)level * level_stride + b) * 2) = make_float2(out.z, out.w);
+        *reinterpret_cast<float2*>(enc_c + ((size_t)level * level_stride + b) * 2) = outc;
+    }
+}
+
 // the fused MFMA field of field.hip with rows from the control block, dead-slot skipping and density_scale
 constexpr int kFieldThreads = 512;
 // With one sample per ray (n_step == 1: 27 of the 29 iterations of the benchmark frame) the compositing step of the iteration is done
@@ -664,6 +743,14 @@ int pnr_interleave_tables(const float* a, const float* b, uint64_t rows, float* 
     return check_launch();
 }
 
+int pnr_interleave_tables3(const float* a, const float* b, const float* c, uint64_t rows, float* out, pnr_stream_t stream) {
+    if (rows == 0) return PNR_OK;
+    if (!a || !b || !c || !out) return PNR_ERR_INVALID;
+    hipLaunchKernelGGL(k_interleave_tables3, dim3((uint32_t)((rows + 255) / 256)), dim3(256), 0, as_stream(stream), reinterpret_cast<const float2*>(a),
+                       reinterpret_cast<const float2*>(b), reinterpret_cast<const float2*>(c), rows, reinterpret_cast<float4*>(out));
+    return check_launch();
+}
+
 uint64_t pnr_nerf_frame_workspace_bytes(uint32_t N) { return carve(nullptr, N).bytes; }
 uint64_t pnr_palette_frame_workspace_bytes(uint32_t N, uint32_t num_basis, uint32_t clip_dim, int pred_clip) {
     return carve(nullptr, N, pnr_palette_aux_channels(num_basis, clip_dim), pred_clip != 0).bytes;
@@ -716,6 +803,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     if (half_tables && pal && (with_clip || !pal->embeddings_pair)) return PNR_ERR_UNSUPPORTED;
     if (a->table_dtype != PNR_DTYPE_F32 && a->table_dtype != PNR_DTYPE_F16) return PNR_ERR_UNSUPPORTED;
     const float4* pair_table = (pal && !half_tables && !with_clip && pal->embeddings_pair) ? reinterpret_cast<const float4*>(pal->embeddings_pair) : nullptr;
+    const float4* triple_table = (pal && !half_tables && with_clip && pal->embeddings_triple) ? reinterpret_cast<const float4*>(pal->embeddings_triple) : nullptr;
     pnr_palette_field_args pf = {};
     if (pal) {
         pf.enc = w.enc; pf.enc_palette = w.enc_pal; pf.enc_clip = w.enc_clip; pf.level_stride = N; pf.dirs = w.dirs; pf.deltas = w.deltas;
@@ -784,6 +872,9 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             else if (half_tables)
                 hipLaunchKernelGGL(k_frame_grid_h<1>, dim3(gx < 1024u ? gx : 1024u, 16), dim3(256), 0, s, cur, w.xyzs, w.deltas,
                                    reinterpret_cast<const __half*>(a->embeddings), w.enc, (float*)nullptr, a->offsets, lp, N, a->bound, 2.0f * a->bound, a->gridtype);
+            else if (triple_table)
+                hipLaunchKernelGGL(k_frame_grid_triple, dim3(gx < 1024u ? gx : 1024u, 16), dim3(256), 0, s, cur, w.xyzs, w.deltas, triple_table, w.enc, w.enc_pal,
+                                   w.enc_clip, a->offsets, lp, N, a->bound, 2.0f * a->bound, a->gridtype);
             else if (pair_table)
                 hipLaunchKernelGGL(k_frame_grid_pair, dim3(gx < 1024u ? gx : 1024u, 16), dim3(256), 0, s, cur, w.xyzs, w.deltas, pair_table, w.enc, w.enc_pal,
                                    a->offsets, lp, N, a->bound, 2.0f * a->bound, a->gridtype);
@@ -836,7 +927,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) total += ms;
         }
         a->kernel_ms[0] = total;
-        a->kernel_ms[1] = (float)counted * ((pair_table || half_tables) ? 1.0f : (float)n_enc);  // a k_frame_grid launch covers n_enc tables (count table-launches); the pair kernel is one launch for both
+        a->kernel_ms[1] = (float)counted * ((pair_table || triple_table || half_tables) ? 1.0f : (float)n_enc);  // a k_frame_grid launch covers n_enc tables (count table-launches); the pair kernel is one launch for both
     }
     if (a->stats) {
         a->stats[0] = (uint64_t)host_ctl->iterations;

@@ -273,6 +273,21 @@ class PaletteFieldFused:
             self._pair, self._pair_key = out, key
         return self._pair
 
+    @torch.no_grad()
+    def _triple_table(self):
+        """--pred_clip: the three tables interleaved row by row ([rows, 8] fp32 = encoder, encoder_palette, encoder_clip, 2 pad): one 32-byte
+        row per corner serves all three lookups.  Rebuilt when any table changes."""
+        m = self.model
+        ts = [e.embeddings.detach() for e in (m.encoder, m.encoder_palette, m.encoder_clip)]
+        if any(t.dtype != torch.float32 or t.shape != ts[0].shape or t.shape[1] != 2 for t in ts):
+            return None
+        key = tuple((t.data_ptr(), t._version) for t in ts)
+        if getattr(self, "_triple_key", None) != key:
+            out = torch.empty(ts[0].shape[0], 8, dtype=torch.float32, device=ts[0].device)
+            call("pnr_interleave_tables3", *[ptr(t.contiguous()) for t in ts], ctypes.c_uint64(ts[0].shape[0]), ptr(out))
+            self._triple, self._triple_key = out, key
+        return self._triple
+
     def render_frame(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh):
         """One PaletteNeRF inference frame through the device-driven loop (pnr_palette_render_frame).
         Returns (weights_sum [N], depth [N], image [N,3], aux_map [N, aux_channels], stats); raw accumulations."""
@@ -327,6 +342,8 @@ class PaletteFieldFused:
             raise RuntimeError("fp16 tables in the native PaletteNeRF loop need the interleaved pair table (no clip head)")
         pair = self._pair_table() if ((self.interleave_tables or self.table_half) and not self.pred_clip) else None
         p.embeddings_pair = pair.data_ptr() if pair is not None else None
+        triple = self._triple_table() if (self.interleave_tables and self.pred_clip and not self.table_half) else None
+        p.embeddings_triple = triple.data_ptr() if triple is not None else None
         a.table_dtype = 1 if self.table_half else 0
         for t, name in ((rays_o, "rays_o"), (rays_d, "rays_d"), (nears, "nears"), (fars, "fars")):
             require(t, torch.float32, name)

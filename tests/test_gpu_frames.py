@@ -290,11 +290,12 @@ def test_training_converges_on_a_synthetic_scene(cuda):
     assert log[0][1] < 20.0 and log[-1][1] > 30.0 and log[-1][1] - log[0][1] > 15.0, log
 
 
-def test_palette_native_loop_pair_table_is_bit_identical(cuda):
-    """The interleaved (encoder, encoder_palette) table of the native PaletteNeRF loop must leave every output bit-identical to the two
-    separate lookups, and must follow in-place updates of either table."""
+@pytest.mark.parametrize("pred_clip", [False, True])
+def test_palette_native_loop_pair_table_is_bit_identical(cuda, pred_clip):
+    """The interleaved (encoder, encoder_palette) table of the native PaletteNeRF loop -- with a clip head the three-table copy with 32-byte
+    rows -- must leave every output bit-identical to the separate lookups, and must follow in-place updates of a table."""
     from palettenerf_amd.fused import PaletteFieldFused
-    m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True, density_scale=30.0, min_near=0.2)
+    m = network.PaletteNetwork(renderer.default_opt(pred_clip=pred_clip), bound=2, cuda_ray=True, density_scale=30.0, min_near=0.2)
     scene.seed_field_(m, 9)
     m = m.to(cuda).eval()
     put_scene(m, cuda)
@@ -319,10 +320,15 @@ def test_palette_native_loop_pair_table_is_bit_identical(cuda):
                 assert torch.equal(torch.nan_to_num(b[k], nan=-7.0), torch.nan_to_num(v, nan=-7.0)), k
         return a
     first = both()
+    assert (getattr(m._fused, "_triple", None) is not None) == pred_clip
     with torch.no_grad():
         m.encoder_palette.embeddings.mul_(0.5)      # in-place update: the interleaved copy must be rebuilt
+        if pred_clip:
+            m.encoder_clip.embeddings.mul_(0.5)
     second = both()
     assert not torch.equal(first["basis_rgb"], second["basis_rgb"])
+    if pred_clip:
+        assert float(first["clip_feat"].abs().max()) > 0 and not torch.equal(first["clip_feat"], second["clip_feat"])
 
 
 @pytest.mark.parametrize("precision", [0, 1])
