@@ -134,6 +134,8 @@ int pnr_march_rays_train_mip(const float* rays_o, const float* rays_d, const uin
                              float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                              const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
                              int32_t* rays, int32_t* counter, const float* noises, void* scratch, const void* mip,
+                             float* t_store /* optional [N * max_steps] floats: the counting pass keeps every sample's ray parameter there and the
+                                               rows are then written 16 lanes per ray without a second walk; same outputs */,
                              pnr_stream_t stream);
 
 /* Stable compaction replacing the host-side `rays_alive[rays_alive >= 0]` boolean mask

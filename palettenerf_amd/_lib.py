@@ -35,7 +35,7 @@ SIGNATURES = {
     "pnr_build_occupancy_mip": [_ptr, _u32, _u32, _f32, _ptr, _ptr],
     "pnr_march_rays_mip": [_u32, _u32, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "pnr_march_rays_train_mip": [_ptr, _ptr, _ptr, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
-                                 _ptr, _ptr, _ptr, _ptr],
+                                 _ptr, _ptr, _ptr, _ptr, _ptr],
     "pnr_compact_alive": [_u32, _ptr, _ptr, _ptr, _ptr, _ptr],
     "pnr_grid_encode_forward": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _u32, _ptr, _u32, _int, _int, _ptr],
     "pnr_grid_encode_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _u32, _ptr, _ptr, _u32, _int, _int, _ptr],

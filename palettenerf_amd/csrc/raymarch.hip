@@ -171,7 +171,7 @@ template <bool MIP, bool POW2>
 __global__ void __launch_bounds__(kBlock) k_march_train_count(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid, MarchParams p, uint32_t N,
     const float* __restrict__ nears, const float* __restrict__ fars, const float* __restrict__ noises, int32_t* __restrict__ scratch,
-    const uint32_t* __restrict__ mip) {
+    const uint32_t* __restrict__ mip, float* __restrict__ t_store /* [N][max_steps] or null: the sample parameters, for k_march_train_emit */) {
     const uint32_t* mip_lds = stage_mip(mip, MIP ? p.mip_words : 0);
     const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t max_steps = p.max_steps;
@@ -186,7 +186,10 @@ __global__ void __launch_bounds__(kBlock) k_march_train_count(
         t = skip_to_box<MIP && POW2>(c, bh, t);
         float x, y, z, dt;
         while (t < far && (uint32_t)num_steps < max_steps) {
-            if (march_probe<MIP, POW2>(c, t, x, y, z, dt)) { num_steps++; t += dt; }
+            if (march_probe<MIP, POW2>(c, t, x, y, z, dt)) {
+                if (t_store) t_store[(size_t)n * max_steps + (uint32_t)num_steps] = t;
+                num_steps++; t += dt;
+            }
         }
         scratch[kScanHdr + gridDim.x + n] = num_steps;  // per-ray counts live behind the block sums
     }
@@ -240,6 +243,61 @@ __global__ void __launch_bounds__(kBlock) k_march_train_write(
             pl[0] = dt; pl[1] = t - last_t;
             last_t = t;
             px += 3; pd += 3; pl += 2; step++;
+        }
+    }
+}
+
+// Second pass when the count pass kept every sample's ray parameter (t_store): no second walk through the occupancy grid -- a sample's
+// position, step and deltas are functions of its t alone (march_probe's first four lines; t_after = t + dt as the walk does), so 16
+// lanes per ray write the rows side by side.  The serial pass is paced by each wave's longest ray (~105 us on a 4096-ray batch); this
+// one is a streaming write.  Same values bit for bit as k_march_train_write.
+__global__ void __launch_bounds__(kBlock) k_march_train_emit(const float* __restrict__ rays_o, const float* __restrict__ rays_d, MarchParams p, uint32_t N,
+                                                             uint32_t M, const float* __restrict__ nears, const float* __restrict__ noises,
+                                                             const float* __restrict__ t_store, float* __restrict__ xyzs, float* __restrict__ dirs,
+                                                             float* __restrict__ deltas, int32_t* __restrict__ rays, const int32_t* __restrict__ scratch) {
+    __shared__ uint32_t s_point[kBlock];
+    __shared__ int s_steps[kBlock];
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    const int num_steps = n < N ? scratch[kScanHdr + gridDim.x + n] : 0;
+    int total;
+    const int excl = block_exclusive_scan(num_steps, &total);
+    const uint32_t point_index = (uint32_t)(scratch[0] + scratch[kScanHdr + blockIdx.x] + excl);
+    const uint32_t ray_index = (uint32_t)scratch[1] + n;
+    if (blockIdx.y == 0 && n < N && ray_index < N) {
+        rays[ray_index * 3] = (int32_t)n;
+        rays[ray_index * 3 + 1] = (int32_t)point_index;
+        rays[ray_index * 3 + 2] = num_steps;
+    }
+    s_point[threadIdx.x] = point_index;
+    s_steps[threadIdx.x] = (n < N && point_index + (uint32_t)num_steps <= M) ? num_steps : 0;   // a ray whose rows would not fit is dropped (raymarching.cu:419)
+    __syncthreads();
+    // 16 workgroups (blockIdx.y) share a 256-ray chunk: each repeats the cheap offset scan above and writes the rows of 16 of its rays
+    const uint32_t q = threadIdx.x & 15u;
+    {
+        const uint32_t r = blockIdx.y * (kBlock / 16) + (threadIdx.x >> 4);
+        const uint32_t ray = blockIdx.x * kBlock + r;
+        const int steps = s_steps[r];
+        if (ray >= N || steps == 0) return;
+        const float ox = rays_o[(size_t)ray * 3], oy = rays_o[(size_t)ray * 3 + 1], oz = rays_o[(size_t)ray * 3 + 2];
+        const float dx = rays_d[(size_t)ray * 3], dy = rays_d[(size_t)ray * 3 + 1], dz = rays_d[(size_t)ray * 3 + 2];
+        float t_first = nears[ray];
+        t_first = fmaf(clampf(t_first * p.dt_gamma, p.dt_min, p.dt_max), noises[ray], t_first);   // where the walk started: delta[1] of sample 0 spans the skipped space
+        const float* ts = t_store + (size_t)ray * p.max_steps;
+        const size_t row0 = s_point[r];
+        for (uint32_t k = q; k < (uint32_t)steps; k += 16) {
+            const float t0 = ts[k];
+            const float dt = clampf(t0 * p.dt_gamma, p.dt_min, p.dt_max);
+            float last_t = t_first;
+            if (k > 0) { const float tp = ts[k - 1]; last_t = tp + clampf(tp * p.dt_gamma, p.dt_min, p.dt_max); }
+            const float t_after = t0 + dt;
+            float* px = xyzs + (row0 + k) * 3;
+            float* pd = dirs + (row0 + k) * 3;
+            float* pl = deltas + (row0 + k) * 2;
+            px[0] = clampf(fmaf(t0, dx, ox), -p.bound, p.bound);
+            px[1] = clampf(fmaf(t0, dy, oy), -p.bound, p.bound);
+            px[2] = clampf(fmaf(t0, dz, oz), -p.bound, p.bound);
+            pd[0] = dx; pd[1] = dy; pd[2] = dz;
+            pl[0] = dt; pl[1] = t_after - last_t;
         }
     }
 }
@@ -534,7 +592,7 @@ static bool mip_usable(const void* mip, uint32_t C, uint32_t H) {
 int pnr_march_rays_train_mip(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma, uint32_t max_steps,
                              uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears, const float* fars, float* xyzs, float* dirs,
                              float* deltas, int32_t* rays, int32_t* counter, const float* noises, void* scratch, const void* mip,
-                             pnr_stream_t stream) {
+                             float* t_store, pnr_stream_t stream) {
     if (N == 0) return PNR_OK;
     if (!rays_o || !rays_d || !grid || !nears || !fars || !rays || !counter || !noises || !scratch) return PNR_ERR_INVALID;
     if (M > 0 && (!xyzs || !dirs || !deltas)) return PNR_ERR_INVALID;
@@ -548,10 +606,15 @@ int pnr_march_rays_train_mip(const float* rays_o, const float* rays_d, const uin
     const uint32_t lds = mip_lds_bytes(p);
     const uint32_t* m = static_cast<const uint32_t*>(mip);
 #define PNR_LAUNCH_TRAIN(MIPV, P2V)                                                                                                           \
-    hipLaunchKernelGGL((k_march_train_count<MIPV, P2V>), dim3(nb), dim3(kBlock), lds, s, rays_o, rays_d, grid, p, N, nears, fars, noises, sc, m); \
+    hipLaunchKernelGGL((k_march_train_count<MIPV, P2V>), dim3(nb), dim3(kBlock), lds, s, rays_o, rays_d, grid, p, N, nears, fars, noises, sc, m, \
+                       t_store);                                                                                                               \
     hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, sc, nb, counter, N, (int32_t*)nullptr);                                    \
-    hipLaunchKernelGGL((k_march_train_write<MIPV, P2V>), dim3(nb), dim3(kBlock), lds, s, rays_o, rays_d, grid, p, N, M, nears, fars, noises,     \
-                       xyzs, dirs, deltas, rays, sc, m)
+    if (t_store)                                                                                                                               \
+        hipLaunchKernelGGL(k_march_train_emit, dim3(nb, 16), dim3(kBlock), 0, s, rays_o, rays_d, p, N, M, nears, noises, t_store, xyzs, dirs, deltas, \
+                           rays, sc);                                                                                                          \
+    else                                                                                                                                       \
+        hipLaunchKernelGGL((k_march_train_write<MIPV, P2V>), dim3(nb), dim3(kBlock), lds, s, rays_o, rays_d, grid, p, N, M, nears, fars, noises, \
+                           xyzs, dirs, deltas, rays, sc, m)
     if (use_mip && pow2) { PNR_LAUNCH_TRAIN(true, true); }
     else if (use_mip) { PNR_LAUNCH_TRAIN(true, false); }
     else if (pow2) { PNR_LAUNCH_TRAIN(false, true); }
@@ -565,7 +628,7 @@ int pnr_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t
                          float* dirs, float* deltas, int32_t* rays, int32_t* counter, const float* noises, void* scratch,
                          pnr_stream_t stream) {
     return pnr_march_rays_train_mip(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, counter,
-                                    noises, scratch, nullptr, stream);
+                                    noises, scratch, nullptr, nullptr, stream);
 }
 
 int pnr_spread_ray_to_sample(const float* input, const int32_t* rays, uint32_t M, uint32_t N, uint32_t n_channel, float* output,

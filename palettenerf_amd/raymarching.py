@@ -140,6 +140,9 @@ packbits = _packbits.apply
 
 
 # ---------------------------------------------------------------------------- training
+T_STORE_MAX = 1 << 26   # floats (256 MB): beyond that the training march walks twice as the reference does
+
+
 class _march_rays_train(Function):
     """raymarching/raymarching.py:161-235.  Same outputs; sample offsets and the row order of `rays`
     are deterministic (prefix sum: row n == ray n) instead of atomics-ordered."""
@@ -170,11 +173,13 @@ class _march_rays_train(Function):
             noises = torch.zeros(N, dtype=rays_o.dtype, device=dev)
         scratch = _scratch(N, dev)
         mip = occupancy_mip(density_bitfield, C, H, bound)
+        # the counting pass keeps every sample's ray parameter (N * max_steps floats): the rows are then written without a second walk
+        t_store = torch.empty(N * max_steps, dtype=torch.float32, device=dev) if N * max_steps <= T_STORE_MAX else None
         call("pnr_march_rays_train_mip", ptr(require(rays_o, torch.float32, "rays_o")), ptr(require(rays_d, torch.float32, "rays_d")),
              ptr(require(density_bitfield, torch.uint8, "density_bitfield")), _f32(bound), _f32(dt_gamma), _u32(max_steps), _u32(N),
              _u32(C), _u32(H), _u32(M), ptr(require(nears, torch.float32, "nears")), ptr(require(fars, torch.float32, "fars")),
              ptr(xyzs), ptr(dirs), ptr(deltas), ptr(rays), ptr(require(step_counter, torch.int32, "step_counter")), ptr(noises),
-             ptr(scratch), ptr(mip))
+             ptr(scratch), ptr(mip), ptr(t_store))
         if force_all_rays or mean_count <= 0:
             m = step_counter[0].item()
             if align > 0:

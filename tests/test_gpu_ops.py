@@ -117,7 +117,11 @@ def test_occupancy_mip_matches_numpy(cuda, s0):
 
 
 @pytest.mark.parametrize("dt_gamma,min_near,bound", [(0.0, 0.2, 2.0), (1.0 / 128, 0.02, 2.0), (1.0 / 256, 0.05, 1.5)])
-def test_march_rays_train_bit_exact(cuda, s0, mip_mode, dt_gamma, min_near, bound):
+def test_march_rays_train_bit_exact(cuda, s0, mip_mode, dt_gamma, min_near, bound, monkeypatch):
+    """Both second passes: the rows written from the stored sample parameters (default) and the second walk (t_store off, when
+    mip_mode is the plain one) must equal the oracle bit for bit."""
+    if not mip_mode:
+        monkeypatch.setattr(raymarching, "T_STORE_MAX", 0)
     grid, bf = s0
     ro, rd = rays_of(64, 48)
     N = ro.shape[0]
