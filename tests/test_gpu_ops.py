@@ -147,6 +147,19 @@ def test_march_rays_train_perturbed_and_mean_count_overflow(cuda, s0):
     N = ro.shape[0]
     aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
     on, of = oracle.near_far_from_aabb(ro, rd, aabb, 0.2)
+    # a counter that does not start at zero: rows are offset by it, the rows in front and the alignment tail are zero (the outputs are
+    # allocated uninitialised on this path, the kernel / the wrapper clear exactly those rows)
+    cnt = np.array([300, 0], np.int32)
+    ox, od, odl, orays = oracle.march_rays_train(ro, rd, 2.0, bf, 2, 128, on, of, cnt, align=128, force_all_rays=True)
+    counter = torch.tensor([300, 0], dtype=torch.int32, device=cuda)
+    torch.empty(N * 1024 * 3, device=cuda).fill_(7.0)            # dirty the allocator's blocks
+    x, d, dl, rays = raymarching.march_rays_train(dev(ro, cuda), dev(rd, cuda), 2.0, dev(bf, cuda), 2, 128, dev(on, cuda), dev(of, cuda), counter,
+                                                  -1, False, 128, True, 0.0, 1024)
+    np.testing.assert_array_equal(host(counter), cnt)
+    np.testing.assert_array_equal(host(rays), orays)
+    np.testing.assert_array_equal(host(x), ox)
+    np.testing.assert_array_equal(host(d), od)
+    np.testing.assert_array_equal(host(dl), odl)
     # overflow path: M = mean_count rounded up, rays that do not fit are dropped (raymarching.cu:419)
     cnt = np.zeros(2, np.int32)
     ox, od, odl, orays = oracle.march_rays_train(ro, rd, 2.0, bf, 2, 128, on, of, cnt, mean_count=5000, align=128)
