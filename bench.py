@@ -1,20 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py -- the hot path's headline benchmark (BASELINE.json: rendered samples/sec + ms/frame @800x800).
+"""bench.py -- the hot path's headline benchmark (BASELINE.json: rendered samples/sec + ms/frame @800x800; PSNR vs reference).
 
-A "step" is one inference frame of the occupancy-march path over a batch of synthetic rays:
-configs[1] = NeRF-synthetic-lego geometry, `-m nerf` inference, 800x800, scene S0 (SURVEY.md 8d /
-Appendix B), seeded random-init field, inputs resident in HBM when the timed region starts.
+A "step" is one inference frame of the occupancy-march path over a batch of synthetic rays, inputs resident in HBM when the
+timed region starts.  Step i renders pose i of a camera path (the camera MOVES: 3 degrees of azimuth per step on the lego orbit,
+one pose of the 120-pose ellipse per step on the garden path), so the frame loop's iteration prediction, the occupancy mip and
+the tile-ordered alive list all face changing frames.
 
-N > 1: rays are sharded over ranks in interleaved 32x32 pixel tiles (no collective on the march data path); every step ends
-with ONE all_gather_into_tensor (RCCL) of the packed per-ray (rgb, depth, alpha) rows, after which every rank holds the full
-output.  --scaling weak (default): a step renders N views of the scene (800x800 each, azimuths spread over the orbit), i.e.
-per-GPU work is fixed -- each rank gets 1/N of the tiles of EVERY view, which also balances the load.  --scaling strong: a step
-is ONE 800x800 frame split N ways (latency-bound below ~2.5 ms/frame: see DESIGN.md section 4).
+Workloads (--workload):
+  lego          configs[1]: NeRF-synthetic-lego geometry (scene S0), `-m nerf` inference, 800x800, dt_gamma 0        (default)
+  lego_palette  configs[2]: the same frame through the PaletteNeRF model (`-m palette`)
+  garden        configs[4]: Mip-360-garden-like scene S2, `-m palette` video render, 1297x840, dt_gamma 1/128, the 120-pose
+                ellipse path of scripts/llff2nerf.py:104-106
+N > 1 (`--gpus N`): one process per GPU.  Started under torch.distributed.run (the driver's way) the ranks come from the
+environment; started plainly, this script spawns `python -m torch.distributed.run --nproc-per-node N bench.py ...` itself --
+before anything touches the GPU -- and relays its output.  Rays are sharded over ranks in interleaved 32x32 pixel tiles (no
+collective on the march data path); every step ends with ONE all_gather_into_tensor (RCCL) of the packed per-ray rows the
+reference's video writer consumes (rgb, depth, alpha; + view-dependent colour, basis images and basis weights for the palette
+model).  --scaling weak (default): a step renders N views, per-GPU work fixed; --scaling strong: ONE frame split N ways.
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -22,96 +30,231 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 GRID_BYTES_PER_SAMPLE_FP32 = 12 + 16 * 8 * 2 * 4 + 32 * 4  # 1164 B: xyz + 16 levels x 8 corners x 2 x fp32 + 32 outputs
 GRID_BYTES_PER_SAMPLE_FP16 = 12 + 16 * 8 * 2 * 2 + 32 * 2  # 588 B
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
+WORKLOADS = {
+    "lego": dict(config=1, model="nerf", scene="s0", dt_gamma=0.0, poses=120,
+                 label="configs[1]: NeRF-synthetic lego geometry (scene S0), -m nerf inference"),
+    "lego_palette": dict(config=2, model="palette", scene="s0", dt_gamma=0.0, poses=120,
+                         label="configs[2]: NeRF-synthetic lego geometry (scene S0), -m palette inference"),
+    "garden": dict(config=4, model="palette", scene="s2", dt_gamma=1.0 / 128, poses=120,
+                   label="configs[4]: Mip-360 garden-like scene S2, -m palette video render (120-pose ellipse path)"),
+}
 
-def parse():
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--res", type=int, default=800)
-    ap.add_argument("--model", choices=["nerf", "palette"], default="nerf")
-    ap.add_argument("--density-scale", type=float, default=100.0, help="S0-opaque (trained-scene-like early termination); ~0 = translucent")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None)
+    ap.add_argument("--res", type=int, default=800, help="lego workloads: frame side")
+    ap.add_argument("--model", choices=["nerf", "palette"], default=None, help="shorthand: --model palette == --workload lego_palette")
+    ap.add_argument("--density-scale", type=float, default=100.0, help="opaque, trained-scene-like early termination; ~0 = translucent")
     ap.add_argument("--fp16", action="store_true", help="the reference's -O mode: autocast, half hash tables")
     ap.add_argument("--mode", choices=["compat", "device", "fused", "native"], default=None)
     ap.add_argument("--field-precision", choices=["f16x3", "fp32"], default="f16x3",
                     help="matrix path of the fused field: split-fp16 (3 MFMAs per product, ~2^-22 relative) or exact fp32 MFMA")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--ray-order", choices=["tile8", "tile4", "tile16", "morton", "rowmajor"], default="tile8", help="initial order of the alive list in the native loop")
+    ap.add_argument("--static-pose", action="store_true", help="every step renders pose 0 (round-1 behaviour; A/B against the moving camera)")
+    ap.add_argument("--pose-step-deg", type=float, default=3.0, help="lego orbit: degrees of azimuth per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra driver-observed legs (exact-fp32 field, palette model)")
+    ap.add_argument("--extra-steps", type=int, default=20)
+    ap.add_argument("--shard-emulation", type=int, default=0, metavar="S",
+                    help="1 GPU: also render each of the S tile shards of pose 0 on its own and report max / mean shard ms (load balance of the S-GPU split)")
     ap.add_argument("--no-interleave", action="store_true", help="-m palette: separate hash-table lookups instead of the interleaved copy (A/B)")
     ap.add_argument("--pred-clip", action="store_true", help="-m palette with the clip-feature head (main_palette.py --pred_clip): third hash table + clip_net")
+    ap.add_argument("--num-basis", type=int, default=4)
     ap.add_argument("--half-tables", action="store_true", help="native loop with fp16 hash tables and the reference's half interpolation (its --fp16 tables); MLP unchanged")
-    ap.add_argument("--scene", choices=["s0", "s1"], default="s0", help="s0: dense 8^3 bricks (the headline scene); s1: sparse 4^3 bricks, the occupied box ~94 %% air")
-    ap.add_argument("--dt-gamma", type=float, default=0.0, help="march step growth (0 = the lego config; 1/128 = the LLFF / 360 configs)")
-    ap.add_argument("--cpu-crop", type=int, default=480, help="side of the centre crop timed on the CPU oracle")
-    return ap.parse_args()
-
-
-def build_model(args, device):
-    from palettenerf_amd import network, raymarching, renderer, scene
-    if args.model == "nerf":
-        m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=args.density_scale, min_near=0.2)
+    ap.add_argument("--scene", choices=["s0", "s1", "s2"], default=None, help="override the workload's scene (s1: sparse 4^3 bricks, the occupied box ~94 %% air)")
+    ap.add_argument("--dt-gamma", type=float, default=None, help="override the workload's march step growth")
+    ap.add_argument("--cpu-crop", type=int, default=400, help="side of the centre crop rendered by the CPU oracle (baseline + PSNR)")
+    args = ap.parse_args(argv)
+    if args.workload is None:
+        args.workload = "lego_palette" if args.model == "palette" else "lego"
+    wl = dict(WORKLOADS[args.workload])
+    if args.scene is not None:
+        wl["scene"] = args.scene
+    if args.dt_gamma is not None:
+        wl["dt_gamma"] = args.dt_gamma
+    if args.workload == "garden":
+        from palettenerf_amd import scene as _scene
+        wl["H"], wl["W"] = _scene.GARDEN_H, _scene.GARDEN_W
     else:
-        m = network.PaletteNetwork(renderer.default_opt(pred_clip=bool(getattr(args, "pred_clip", False))), bound=2, cuda_ray=True, density_scale=args.density_scale, min_near=0.2)
+        wl["H"] = wl["W"] = args.res
+    args.wl = wl
+    args.model = wl["model"]
+    return args
+
+
+def spawn_ranks(args, argv, script=None):
+    """`bench.py --gpus N` without a launcher: start N ranks under torch.distributed.run as a CHILD process (this process has not
+    touched the GPU and never will), relay its output, exit with its code.  `script`: what the ranks run (tests; default this file)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def world_from_env(args, argv):
+    """(world, rank, local_rank), or SystemExit after having run the ranks as children."""
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            import torch   # device_count() does not initialise the GPU
+            if torch.cuda.device_count() < args.gpus:
+                raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
+            raise SystemExit(spawn_ranks(args, argv))
+        return 1, 0, 0
+    world = int(os.environ["WORLD_SIZE"])
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
+    return world, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+# ------------------------------------------------------------------------------------------------ scene / model / rays
+def density_grid_of(name):
+    from palettenerf_amd import scene
+    return {"s0": scene.brick_density_grid, "s1": scene.sparse_density_grid, "s2": scene.garden_density_grid}[name]()
+
+
+def make_model(args, model_kind, cuda_ray=True):
+    from palettenerf_amd import network, renderer
+    if model_kind == "nerf":
+        return network.NeRFNetwork(bound=2, cuda_ray=cuda_ray, density_scale=args.density_scale, min_near=0.2)
+    opt = renderer.default_opt(pred_clip=bool(args.pred_clip), num_basis=int(args.num_basis))
+    return network.PaletteNetwork(opt, bound=2, cuda_ray=cuda_ray, density_scale=args.density_scale, min_near=0.2)
+
+
+def build_model(args, device, model_kind=None, field_precision=None):
+    import torch
+    from palettenerf_amd import raymarching, scene
+    model_kind = model_kind or args.model
+    m = make_model(args, model_kind)
     scene.seed_field_(m, 0)
     m = m.to(device).eval()
-    m.density_grid.copy_(torch.from_numpy(scene.brick_density_grid() if args.scene == "s0" else scene.sparse_density_grid()).to(device))
+    m.density_grid.copy_(torch.from_numpy(density_grid_of(args.wl["scene"])).to(device))
     raymarching.packbits(m.density_grid, 0.5, m.density_bitfield)
     m.count_rendered = True
+    mode = args.mode or "native"     # --fp16: the native loop under autocast looks the tables up as fp16 (the reference's -O tables), the field stays fp32-accurate
+    m.march_mode = "device" if mode == "fused" else mode
+    prec = field_precision or args.field_precision
+    if mode in ("fused", "native") and (not args.fp16 or mode == "native"):
+        from palettenerf_amd.fused import NeRFFieldFused, PaletteFieldFused
+        m.fused_field = True
+        m._fused = NeRFFieldFused(m) if model_kind == "nerf" else PaletteFieldFused(m)
+        m._fused.precision = 0 if prec == "fp32" else 1
+        m._fused.table_half = bool(args.half_tables)
+        if model_kind == "palette" and args.no_interleave:
+            m._fused.interleave_tables = False
     return m
 
 
-def cpu_baseline(args):
-    """The oracle ("port") timed on this host, 1 thread, on a bounded centre crop of the same frame."""
-    import numpy as np
+def pose_of(args, step, view=0, n_views=1):
+    from palettenerf_amd import scene
+    if args.static_pose:
+        step = 0
+    if args.workload == "garden":
+        return scene.garden_orbit_pose(step + (view * scene.GARDEN_POSES) // n_views)
+    return scene.lookat_pose(azimuth_deg=45.0 + args.pose_step_deg * step + 360.0 * view / n_views)
+
+
+def intrinsics_of(args):
+    from palettenerf_amd import scene
+    wl = args.wl
+    return scene.garden_intrinsics(wl["H"], wl["W"]) if args.workload == "garden" else scene.intrinsics_from_fov(wl["H"], wl["W"])
+
+
+class RayBank:
+    """This rank's rays of every distinct step of the camera path, generated on the device (pnr_get_rays) BEFORE the timed
+    region: the benchmark's inputs are resident in HBM, as the brief asks.  Views of a step are stacked vertically into one
+    (n_views * H) x W image whose 32x32 tiles are dealt round-robin to the ranks."""
+
+    def __init__(self, args, n_views, idx, device):
+        self.args, self.n_views, self.device = args, n_views, device
+        self.idx = idx.to(device)
+        self.n_steps = 1 if args.static_pose else args.wl["poses"]
+        self.cache = {}
+
+    def get(self, step):
+        import numpy as np
+        import torch
+        from palettenerf_amd import rays
+        k = step % self.n_steps
+        if k not in self.cache:
+            H, W = self.args.wl["H"], self.args.wl["W"]
+            poses = torch.from_numpy(np.stack([pose_of(self.args, k, v, self.n_views) for v in range(self.n_views)])).to(self.device)
+            ro, rd = rays.rays_from_indices(poses, intrinsics_of(self.args), H, W, None)        # [n_views, H*W, 3]
+            ro = ro.reshape(1, -1, 3)[:, self.idx].contiguous()
+            rd = rd.reshape(1, -1, 3)[:, self.idx].contiguous()
+            self.cache[k] = (ro, rd)
+        return self.cache[k]
+
+
+# ------------------------------------------------------------------------------------------------ CPU legs (oracle = checker + baseline)
+def cpu_baseline(args, crop_rays):
+    """The oracle ("port": C restatement of the kernels + torch CPU MLPs under this repo's mirror of the reference's renderer) on a
+    bounded centre crop of pose 0 of the same workload: once on 1 thread, once on all cores (OpenMP over rays / samples in the C ops,
+    torch threads for the MLPs).  Returns the baseline record and the crop's oracle image / weights (the PSNR reference)."""
+    import torch
     import oracle
+    from oracle import orc
     from oracle.facade import make_oracle_modules
-    from palettenerf_amd import network, renderer, scene
+    from palettenerf_amd import renderer, scene
     import palettenerf_amd.gridencoder as pge
     import palettenerf_amd.shencoder as psh
-    torch.set_num_threads(1)
+    ro, rd = crop_rays
     rm, ge, sh, pu = make_oracle_modules()
     saved = (renderer.raymarching, pge.GridEncoder, psh.SHEncoder)
     renderer.raymarching, pge.GridEncoder, psh.SHEncoder = rm, ge.GridEncoder, sh.SHEncoder
+    cores = os.cpu_count() or 1
+    legs = {}
     try:
-        if args.model == "nerf":
-            m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=args.density_scale, min_near=0.2)
-        else:
-            m = network.PaletteNetwork(renderer.default_opt(pred_clip=bool(getattr(args, "pred_clip", False))), bound=2, cuda_ray=True, density_scale=args.density_scale, min_near=0.2)
+        m = make_model(args, args.model)
         scene.seed_field_(m, 0)
-        grid = scene.brick_density_grid() if args.scene == "s0" else scene.sparse_density_grid()
+        grid = density_grid_of(args.wl["scene"])
         m.density_grid.copy_(torch.from_numpy(grid))
         m.density_bitfield.copy_(torch.from_numpy(oracle.packbits(grid, 0.5)))
         m.eval()
         m.count_rendered = True
-        H = W = args.res
-        pose = torch.from_numpy(scene.lookat_pose())[None]
-        ro, rd = scene.get_rays(pose, scene.intrinsics_from_fov(H, W), H, W)
-        c = args.cpu_crop
-        ys = torch.arange(H // 2 - c // 2, H // 2 + c // 2)
-        idx = (ys[:, None] * W + ys[None, :]).reshape(-1)
-        ro, rd = ro[:, idx].contiguous(), rd[:, idx].contiguous()
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            r = m.render(ro, rd, perturb=False, dt_gamma=args.dt_gamma, max_steps=1024, T_thresh=1e-4, **({"gui_mode": False} if args.model == "palette" else {}))
-        dt = time.perf_counter() - t0
-        n = int(r["rendered"].item())
+        kw = dict(perturb=False, dt_gamma=args.wl["dt_gamma"], max_steps=1024, T_thresh=1e-4)
+        if args.model == "palette":
+            kw["gui_mode"] = False
+        ref = None
+        for name, variant, threads in (("1_thread", "", 1), ("all_cores", "omp", cores)):
+            prev = orc.use_variant(variant)
+            orc.set_threads(threads)
+            torch.set_num_threads(threads)
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                r = m.render(ro, rd, **kw)
+            dt = time.perf_counter() - t0
+            orc.use_variant(prev)
+            n = int(r["rendered"].item())
+            legs[name] = {"value": n / dt, "unit": "samples/s", "cores": threads, "seconds": dt}
+            if ref is None:
+                ref = r
+            else:   # same arithmetic on more threads: the images must be the same bits
+                legs[name]["identical_to_1_thread"] = bool(torch.equal(r["image"], ref["image"]))
         # BASELINE configs[0] beside it: the reference's CPU-runnable case, NeRFRenderer.run at 400x400 with --num_steps 512 --upsample_steps 0
-        # (main_nerf.py:31-32), a quarter of one max_ray_batch of 4096 rays (160 such pieces make the frame), 8 threads for the torch part as the reference's scripts set
+        # (main_nerf.py:31-32): 1024 rays of one max_ray_batch of 4096 (160 such pieces make the frame), OMP_NUM_THREADS=8 as scripts/run_blender.sh:47 sets
         uniform = None
         if args.model == "nerf":
-            n_thr = min(8, os.cpu_count() or 1)       # the reference's scripts pin OMP_NUM_THREADS=8 (scripts/run_blender.sh:47)
+            n_thr = min(8, cores)
             torch.set_num_threads(n_thr)
-            mu = network.NeRFNetwork(bound=2, cuda_ray=False, density_scale=args.density_scale, min_near=0.2)
+            mu = make_model(args, "nerf", cuda_ray=False)
             scene.seed_field_(mu, 0)
             mu.eval()
+            pose = torch.from_numpy(scene.lookat_pose())[None]
             ro0, rd0 = scene.get_rays(pose, scene.intrinsics_from_fov(400, 400), 400, 400)
             mid = 400 * 200 - 512
             t0 = time.perf_counter()
@@ -119,20 +262,60 @@ def cpu_baseline(args):
                 mu.run(ro0[:, mid:mid + 1024].contiguous(), rd0[:, mid:mid + 1024].contiguous(), num_steps=512, upsample_steps=0, perturb=False)
             du = time.perf_counter() - t0
             uniform = {"value": 1024 * 512 / du, "unit": "evaluated samples/s", "cores": n_thr, "ms_per_400x400_frame_extrapolated": du * 160 * 1e3,
-                       "sample": f"1024 rays x 512 uniform samples (1/160) of a 400x400 frame ({du:.1f} s; C oracle encoders 1 thread + torch MLP on {n_thr} threads; host has {os.cpu_count()} cores -- all of them made this piece slower)"}
-            torch.set_num_threads(1)
+                       "sample": f"1024 rays x 512 uniform samples (1/160) of a 400x400 frame ({du:.1f} s; C oracle encoders 1 thread + torch MLP on {n_thr} threads)"}
+        torch.set_num_threads(1)
     finally:
         renderer.raymarching, pge.GridEncoder, psh.SHEncoder = saved
-    return {"uniform_path_config0": uniform, "value": n / dt, "unit": "samples/s", "cores": 1, "kind": "port",
-            "sample": f"centre {c}x{c} crop of the {H}x{W} frame ({idx.numel()} rays, {n} rendered samples, {dt:.1f} s; -m {args.model}, C oracle ops + torch CPU MLP, 1 thread; "
-                      f"host has {os.cpu_count()} cores)"}
+    one = legs["1_thread"]
+    n = int(ref["rendered"].item())
+    rec = {"value": one["value"], "unit": "samples/s", "cores": 1, "kind": "port",
+           "sample": f"centre {args.cpu_crop}x{args.cpu_crop} crop of pose 0 of the {args.wl['H']}x{args.wl['W']} frame ({ro.shape[1]} rays, {n} rendered samples, "
+                     f"{one['seconds']:.1f} s; -m {args.model}, C oracle ops + torch CPU MLP, 1 thread; host has {cores} cores)",
+           "all_cores": legs["all_cores"], "uniform_path_config0": uniform}
+    return rec, ref
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+def crop_indices(H, W, c):
+    import torch
+    c = min(c, H, W)
+    ys = torch.arange(H // 2 - c // 2, H // 2 - c // 2 + c)
+    xs = torch.arange(W // 2 - c // 2, W // 2 - c // 2 + c)
+    return (ys[:, None] * W + xs[None, :]).reshape(-1)
+
+
+# ------------------------------------------------------------------------------------------------ the GPU side
+def gather_parts(args, r, nb):
+    """Per-ray rows the reference's video writer consumes (nerf/utils.py:716-740; palette/utils.py:993-1078): rgb, depth, alpha
+    (+ view_dep_rgb, basis_rgb, basis_acc for the palette model)."""
+    parts = [r["image"][0], r["depth"][0][:, None], r["weights_sum"][:, None]]
+    if args.model == "palette":
+        parts += [r["view_dep_rgb"][0], r["basis_rgb"][0], r["basis_acc"][0]]
+    return parts
+
+
+def timed_frames(m, bank, kw, steps, fp16, first_step=0):
+    """`steps` frames back to back on one model without gather; returns (ms per step, rendered per step)."""
+    import torch
+    rendered = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ro, rd = bank.get(first_step + i)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=fp16):
+            r = m.render(ro, rd, **kw)
+        rendered += int(r["rendered"].sum())
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3, rendered // steps
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    world, rank, local_rank = world_from_env(args, argv)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     use_dist = world > 1 or os.environ.get("PNR_BENCH_FORCE_DIST") == "1"  # the latter exercises the RCCL path on a 1-GPU box
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -144,85 +327,57 @@ def main():
     device = torch.device("cuda", local_rank)
 
     from palettenerf_amd import _torch_glue, dist as pdist, scene
+    from palettenerf_amd.fused import tile_ray_order
+    wl = args.wl
+    H, W = wl["H"], wl["W"]
     m = build_model(args, device)
-    mode = args.mode or "native"     # --fp16: the native loop under autocast looks the tables up as fp16 (the reference's -O tables), the field stays fp32-accurate
-    m.march_mode = "device" if mode == "fused" else mode
-    if mode in ("fused", "native") and args.model == "nerf" and (not args.fp16 or mode == "native"):
-        from palettenerf_amd.fused import NeRFFieldFused
-        m.fused_field = True
-        m._fused = NeRFFieldFused(m)
-        m._fused.precision = 0 if args.field_precision == "fp32" else 1
-    if mode in ("fused", "native") and args.model == "palette" and (not args.fp16 or mode == "native"):
-        m.fused_field = True
-        if args.no_interleave:
-            from palettenerf_amd.fused import PaletteFieldFused
-            m._fused = PaletteFieldFused(m)
-            m._fused.interleave_tables = False
-    H = W = args.res
+    nb = int(getattr(m, "num_basis", 0))
     n_views = world if args.scaling == "weak" else 1
-    import numpy as np
-    poses = torch.from_numpy(np.stack([scene.lookat_pose(azimuth_deg=45.0 + 360.0 * v / n_views) for v in range(n_views)]))
-    ro, rd = scene.get_rays(poses, scene.intrinsics_from_fov(H, W), H, W)          # [n_views, H*W, 3]
-    ro, rd = ro.reshape(1, n_views * H * W, 3), rd.reshape(1, n_views * H * W, 3)  # the views stacked vertically: one (n_views*H) x W image
-    VH = n_views * H
+    VH = n_views * H   # the views stacked vertically: one (n_views * H) x W image
     idx, n_max = pdist.shard_indices(VH, W, rank, world)
-    ro, rd = ro[:, idx].contiguous().to(device), rd[:, idx].contiguous().to(device)
-    kw = dict(perturb=False, dt_gamma=args.dt_gamma, max_steps=1024, T_thresh=1e-4)
+    bank = RayBank(args, n_views, idx, device)
+    kw = dict(perturb=False, dt_gamma=wl["dt_gamma"], max_steps=1024, T_thresh=1e-4)
     if args.model == "palette":
         kw["gui_mode"] = False
+    native = m.march_mode == "native"
+    if native and args.ray_order != "rowmajor":
+        m._fused.ray_order = tile_ray_order(idx, W, {"tile8": 8, "tile4": 4, "tile16": 16, "morton": 0}[args.ray_order]).to(device)   # idx: row-major pixel ids (of the stacked views) this rank renders
 
-    gatherer = pdist.FrameGatherer(VH, W, 5, device) if use_dist else None
+    K = 5 if args.model == "nerf" else 8 + 4 * nb
+    gatherer = pdist.FrameGatherer(VH, W, K, device) if use_dist else None
     pending = []   # all-gather of the previous frame, still in flight
 
-    def frame():
+    def frame(i):
+        ro, rd = bank.get(i)
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=args.fp16):
             r = m.render(ro, rd, **kw)
-        if use_dist:  # one all-gather of the packed (rgb, depth, alpha) rows; every rank ends up with the full frame.  It is started here
-            # and completed after the NEXT frame has been rendered (or at the end of the timed region): communication overlaps compute
-            handle = gatherer.start([r["image"][0], r["depth"][0][:, None], r["weights_sum"][:, None]])
+        if use_dist:  # one all-gather of the packed rows; every rank ends up with the full frame.  It is started here and completed
+            # after the NEXT frame has been rendered (or at the end of the timed region): communication overlaps compute
+            handle = gatherer.start(gather_parts(args, r, nb))
             full = gatherer.finish(pending.pop()) if pending else None
             pending.append(handle)
             return r, full
         return r, None
 
-    for _ in range(args.warmup):
-        frame()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    prof = _torch_glue.profile_kernels(["pnr_grid_encode_forward"]) if rank == 0 else None
-    rendered = torch.zeros(1, dtype=torch.int64, device=device)
-    rendered_host = 0
-    rows = 0
-    native_ms, native_launches = 0.0, 0
-    native_rows = 0
-    timed_native = m.march_mode == "native" and rank == 0
-    if timed_native and getattr(m, "_fused", None) is None:
-        from palettenerf_amd.fused import PaletteFieldFused
-        m._fused = PaletteFieldFused(m)
-    if m.march_mode == "native" and args.ray_order != "rowmajor":
-        from palettenerf_amd.fused import tile_ray_order
-        if getattr(m, "_fused", None) is None:
-            from palettenerf_amd.fused import PaletteFieldFused
-            m._fused = PaletteFieldFused(m)
-        m._fused.table_half = bool(args.half_tables)
-        m._fused.ray_order = tile_ray_order(idx, W, {"tile8": 8, "tile4": 4, "tile16": 16, "morton": 0}[args.ray_order]).to(device)   # idx: row-major pixel ids (of the stacked views) this rank renders
-        for _ in range(2):
-            frame()                                               # re-warm with the final ordering
-        torch.cuda.synchronize()
-    if m.march_mode == "native":   # untimed, on every rank (a frame holds a collective): one frame with the in-library HIP-event timing on,
-        fused = getattr(m, "_fused", None)   # so that the events exist before the timed region
-        if fused is not None:
-            fused.time_grid_kernel = True
-        frame()
-        if fused is not None:
-            fused.time_grid_kernel = False
-        torch.cuda.synchronize()
+    n_frames = args.warmup + args.steps
+    for i in range(min(n_frames, bank.n_steps)):   # rays of every pose of the run: resident before the timed region
+        bank.get(i)
+    for i in range(args.warmup):
+        frame(i)
+    if native:   # untimed, on every rank (a frame holds a collective): one frame with the in-library HIP-event timing on, so that the events exist
+        m._fused.time_grid_kernel = True
+        frame(args.warmup)
+        m._fused.time_grid_kernel = False
     if use_dist:
         if pending:
             gatherer.finish(pending.pop())
         dist.barrier()
-        torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    prof = _torch_glue.profile_kernels(["pnr_grid_encode_forward"]) if rank == 0 else None
+    rendered = torch.zeros(1, dtype=torch.int64, device=device)
+    rendered_host, rows, looks, iterations = 0, 0, 0, 0
+    native_ms, native_launches, native_live = 0.0, 0, 0
+    timed_native = native and rank == 0
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # diagnostics only (no sync inside the loop)
     t0 = time.perf_counter()
     step_ev[0].record()
@@ -231,14 +386,16 @@ def main():
         # FIRST timed step only, so the measurement lives inside the timed region without distorting it
         if timed_native:
             m._fused.time_grid_kernel = i == 0
-        r, _full = frame()
+        r, _full = frame(args.warmup + i)
         if r["rendered"].is_cuda:
             rendered += r["rendered"]
         else:
             rendered_host += int(r["rendered"])   # native loop: the count is already on the host (it came back with the control block)
         rows += r["n_samples"]
+        looks += int(r.get("host_looks", 0))
+        iterations += int(r.get("iterations", 0))
         if timed_native and i == 0:
-            native_ms, native_launches, native_rows = r.get("grid_ms", 0.0), r.get("grid_launches", 0), r["n_samples"]
+            native_ms, native_launches, native_live = r.get("grid_ms", 0.0), r.get("grid_launches", 0), int(r["rendered"])
         step_ev[i + 1].record()
     if pending:
         _full = gatherer.finish(pending.pop())   # the last frame's all-gather completes inside the timed region
@@ -255,9 +412,11 @@ def main():
     elapsed = float(t.item())
     total_rendered = int(rendered.item())
 
+    out = None
     if rank == 0:
+        half_rows = args.half_tables or (args.fp16 and native)
         per_sample = GRID_BYTES_PER_SAMPLE_FP16 if args.fp16 else GRID_BYTES_PER_SAMPLE_FP32
-        if args.half_tables or (args.fp16 and m.march_mode == "native"):
+        if half_rows:
             per_sample = 12 + 16 * 8 * 2 * 2 + 32 * 4   # half rows gathered, fp32 encoder output written
         n_tables = 1 if args.model == "nerf" else (3 if args.pred_clip else 2)  # palette: encoder + encoder_palette (+ encoder_clip with --pred-clip)
         launches = prof["pnr_grid_encode_forward"]
@@ -265,17 +424,16 @@ def main():
         k_units = sum(u for _, _, u in launches)
         n_launches = len(launches)
         kernel_name = "k_grid_fwd (pnr_grid_encode_forward)"
-        if m.march_mode == "native":  # events recorded inside pnr_nerf_render_frame around every k_frame_grid launch
-            k_ms, k_units, n_launches = native_ms, native_rows * n_tables, native_launches
-            kernel_name = "k_frame_grid (device-driven frame loop)" if args.model == "nerf" else "k_frame_grid_pair (device-driven frame loop, encoder + encoder_palette interleaved)"
+        if native:  # events recorded inside pnr_*_render_frame around every grid launch of the first timed step; LIVE samples (delta > 0), dead slots are skipped by the kernel
+            k_ms, k_units, n_launches = native_ms, native_live * n_tables, native_launches
+            kernel_name = "k_frame_grid (device-driven frame loop)" if args.model == "nerf" else "k_frame_grid_pair/_triple (device-driven frame loop, tables interleaved)"
         achieved = (k_units * per_sample) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic = None  # HBM-side bytes per launch from the committed PMC passes of this exact workload (profiles/r01_traffic.json)
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if m.march_mode == "native" and H == 800 and args.density_scale == 100.0 and not args.fp16 and not args.half_tables and world == 1 and os.path.exists(tpath):
-            t = json.load(open(tpath)).get(args.model)
-            if t:
-                pair = args.model == "palette"   # the interleaved pair kernel is ONE launch for both tables
-                traffic = t["traffic_bytes_per_launch"] / (1 if pair else n_tables)
+        traffic = None  # HBM-side bytes per launch from the committed PMC passes of this workload (profiles/r02_traffic.json; regenerate with profiles/pmc_pass.sh)
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        if native and args.density_scale == 100.0 and not args.fp16 and not args.half_tables and world == 1 and os.path.exists(tpath):
+            tr = json.load(open(tpath)).get(args.workload if args.res == 800 else "")
+            if tr:
+                traffic = tr["traffic_bytes_per_launch"]
         raw_steps = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
         slowest = max(range(args.steps), key=lambda i: raw_steps[i])
         per_step = sorted(raw_steps)
@@ -284,21 +442,81 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "step_ms": {"min": per_step[0], "median": per_step[len(per_step) // 2], "max": per_step[-1], "slowest_step": slowest}, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f16" if args.fp16 else "f32", "data": "synthetic",
-            "config": {"workload": f"configs[{1 if args.model == 'nerf' else 2}]: NeRF-synthetic lego geometry (scene {args.scene.upper()}), -m {args.model} inference, {H}x{W}, {n_views} view(s)/step",
+            "config": {"workload": f"{wl['label']}, {H}x{W}, {n_views} view(s)/step, camera moving ({'static pose' if args.static_pose else 'one pose of the path per step'})",
                        "rays_per_step": n_views * H * W, "rendered_samples_per_step": total_rendered // args.steps,
-                       "evaluated_rows_per_step_rank0": rows // args.steps, "density_scale": args.density_scale, "dt_gamma": args.dt_gamma, "march_mode": m.march_mode, "fused_field": bool(getattr(m, "fused_field", False)), "field_precision": args.field_precision, "half_tables": bool(args.half_tables or (args.fp16 and m.march_mode == "native")), "ray_order": args.ray_order,
+                       "evaluated_rows_per_step_rank0": rows // args.steps, "density_scale": args.density_scale, "dt_gamma": wl["dt_gamma"], "march_mode": m.march_mode,
+                       "fused_field": bool(getattr(m, "fused_field", False)), "field_precision": args.field_precision, "half_tables": bool(half_rows), "ray_order": args.ray_order,
+                       "iterations_per_frame_rank0": iterations / max(1, args.steps), "host_looks_per_frame": looks / max(1, args.steps),
+                       "gathered_floats_per_ray": K if use_dist else 0, "rccl_ranks": dist.get_world_size() if use_dist else 1,
                        "parallelism": f"32x32 ray tiles of {n_views} view(s) round-robin over {world} GPUs + one all_gather/step" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": n_launches,
-                         "avg_launch_ms": k_ms / max(1, n_launches), "avg_rows_per_launch": k_units / max(1, n_launches),
-                         "algorithmic_bytes_per_row": per_sample,
+                         "avg_launch_ms": k_ms / max(1, n_launches), "avg_live_samples_per_launch": k_units / max(1, n_launches) / (n_tables if native else 1),
+                         "algorithmic_bytes_per_sample": per_sample * (n_tables if native else 1),
                          "algorithmic_bytes_per_launch": per_sample * k_units / max(1, n_launches)},
         }
         if achieved > HBM_PEAK_GBS:
             out["roofline"]["note"] = ("algorithmic bytes per second exceed the HBM peak: table rows are re-used out of L2 / Infinity Cache "
                                        "(the HBM-side bytes per launch are in `traffic`)")
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+    if use_dist:
+        dist.barrier()
+    extra = {}
+    if rank == 0 and world == 1:
+        # --- PSNR / max-abs against the oracle + the CPU baseline, on a centre crop of pose 0 (same device-generated rays for both sides)
+        if not args.no_cpu_baseline:
+            from palettenerf_amd import rays as prays
+            cidx = crop_indices(H, W, args.cpu_crop).to(device)
+            pose0 = torch.from_numpy(pose_of(args, 0)[None]).to(device)
+            cro, crd = prays.rays_from_indices(pose0, intrinsics_of(args), H, W, cidx[None])
+            saved_order = getattr(m._fused, "ray_order", None) if native else None
+            if native:
+                m._fused.ray_order = None
+            with torch.no_grad():
+                g = m.render(cro, crd, **kw)
+            if native:
+                m._fused.ray_order = saved_order
+            rec, ref = cpu_baseline(args, (cro.cpu(), crd.cpu()))
+            out["cpu_baseline"] = rec
+            gi, ri = g["image"].cpu(), ref["image"]
+            out["parity"] = {"psnr_vs_oracle_db": scene.psnr(gi, ri), "max_abs_rgb": float((gi - ri).abs().max()),
+                             "max_abs_alpha": float((g["weights_sum"].cpu() - ref["weights_sum"]).abs().max()),
+                             "rendered_samples_equal": int(g["rendered"].sum()) == int(ref["rendered"].sum()),
+                             "sample": rec["sample"].split(" (")[0], "tolerance": "1e-4 abs (north_star)"}
+        # --- extra driver-observed legs on the same box: the exact-fp32 field and the PaletteNeRF model (configs[2]) on the same camera path
+        if not args.no_extras and native and args.workload == "lego" and not args.fp16:
+            n = max(1, args.extra_steps)
+            for name, kind, prec in (("fp32_field", "nerf", "fp32"), ("palette", "palette", "f16x3"), ("palette_fp32_field", "palette", "fp32")):
+                try:
+                    mm = build_model(args, device, kind, prec)
+                    mm._fused.ray_order = m._fused.ray_order
+                    kk = dict(kw)
+                    if kind == "palette":
+                        kk["gui_mode"] = False
+                    timed_frames(mm, bank, kk, 3, False)
+                    ms, rend = timed_frames(mm, bank, kk, n, False, first_step=args.warmup)
+                    extra[f"{name}_ms_per_step"] = ms
+                    extra[f"{name}_rendered_per_step"] = rend
+                    del mm
+                except RuntimeError as e:   # reported, never hidden
+                    extra[f"{name}_error"] = str(e)
+            extra["extra_steps"] = n
+        if args.shard_emulation > 1 and native:
+            S = args.shard_emulation
+            times, samples = [], []
+            for s in range(S):
+                sidx, _ = pdist.shard_indices(H, W, s, S)
+                sargs = argparse.Namespace(**vars(args))
+                sargs.static_pose = True
+                sbank = RayBank(sargs, 1, sidx, device)
+                m._fused.ray_order = tile_ray_order(sidx, W, 8).to(device)
+                timed_frames(m, sbank, kw, 2, args.fp16)
+                ms, rend = timed_frames(m, sbank, kw, 5, args.fp16)
+                times.append(ms)
+                samples.append(rend)
+            extra["shard_emulation"] = {"shards": S, "ms": times, "max_ms": max(times), "mean_ms": sum(times) / S, "samples": samples,
+                                        "imbalance_max_over_mean": max(times) / (sum(times) / S)}
+        if extra:
+            out["extra"] = extra
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:

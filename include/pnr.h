@@ -212,7 +212,8 @@ typedef struct pnr_nerf_frame_args {
     float* image;                  /* [N,3] out */
     void* workspace;
     uint64_t workspace_bytes;
-    uint64_t* stats;               /* HOST, optional: [iterations, rendered samples, evaluated rows, enqueued iterations] */
+    uint64_t* stats;               /* HOST, optional, 5 entries: [iterations, rendered samples, evaluated rows, enqueued iterations,
+                                      host looks at the control block (= stream synchronisations of this frame)] */
     float* kernel_ms;              /* HOST, optional: [0] = summed HIP-event time (ms) of the grid-encode launches that did work,
                                       [1] = their number; events are recorded on `stream` around each launch */
     const int32_t* ray_order;      /* optional permutation of 0..N-1 (device): processing order of the rays, e.g. 8x8 pixel tiles per

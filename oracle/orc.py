@@ -12,24 +12,41 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "liborc.so")
+_VARIANTS = {"": "liborc.so", "omp": "liborc_omp.so", "nofma": "liborc_nofma.so"}   # see the header of pnr_oracle.c
 
 
 def build(force=False):
     src = os.path.join(_HERE, "pnr_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    sos = [os.path.join(_HERE, "_build", f) for f in _VARIANTS.values()]
+    if force or any(not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src) for so in sos):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
 
-_lib = None
+_libs = {}
+_variant = ""
+
+
+def use_variant(name=""):
+    """Select the build every wrapper below calls: "" canonical (single thread, explicit fmaf), "omp" (same arithmetic, all cores),
+    "nofma" (no contraction anywhere: the reference's kernel bodies as g++ compiles them).  Returns the previous selection."""
+    global _variant
+    if name not in _VARIANTS:
+        raise ValueError(name)
+    prev, _variant = _variant, name
+    return prev
+
+
+def set_threads(n):
+    """Thread count of the "omp" variant (no-op for the others)."""
+    lib().orc_set_threads(ctypes.c_int(int(n)))
 
 
 def lib():
-    global _lib
-    if _lib is None:
+    if _variant not in _libs:
         build()
-        _lib = ctypes.CDLL(_SO)
-    return _lib
+        _libs[_variant] = ctypes.CDLL(os.path.join(_HERE, "_build", _VARIANTS[_variant]))
+    return _libs[_variant]
 
 
 def _p(a):

@@ -1,7 +1,7 @@
 /*
  * pnr_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY, never shipped, never on the product path).
  *
- * A plain-C, single-threaded, one-loop-per-"thread" restatement of the reference's hot-path
+ * A plain-C, one-loop-per-"thread" restatement (single-threaded in its canonical build; see the build variants below) of the reference's hot-path
  * algorithms (zfkuang/PaletteNeRF: raymarching/, gridencoder/, shencoder/, palette/src).
  * Every function cites the reference file:line it follows.  Only tests/, __graft_entry__.smoke()
  * and bench.py's cpu_baseline leg may load this library.
@@ -35,6 +35,31 @@
 #include <float.h>
 
 #define ORC_API __attribute__((visibility("default")))
+
+/* Build variants of this one source (oracle/Makefile):
+ *   liborc.so        the canonical oracle: single-threaded, explicit fmaf() where nvcc contracts (above).
+ *   liborc_omp.so    -fopenmp -DORC_OMP: the same arithmetic with the independent per-ray / per-sample loops spread over the host's
+ *                    cores (bench.py's all-cores CPU baseline leg; results are identical, every iteration writes its own outputs).
+ *   liborc_nofma.so  -DORC_NO_FMA: every ORC_FMA(a,b,c) is a rounded product followed by a rounded sum, i.e. the reference's kernel
+ *                    bodies compiled WITHOUT contraction (g++ -ffp-contract=off) -- the build SURVEY.md Appendix B measured the
+ *                    reference's own kernel_march_rays_train with (63 001 827 / 15 750 694 samples on scene S0 at 800^2 / 400^2).
+ *                    tests/test_oracle.py pins this variant to those two reference-measured counts. */
+#ifdef ORC_NO_FMA
+static inline float orc_mul_add(float a, float b, float c) { volatile float p = a * b; return p + c; }
+#define ORC_FMA(a, b, c) orc_mul_add((a), (b), (c))
+#else
+#define ORC_FMA(a, b, c) fmaf((a), (b), (c))
+#endif
+#ifdef ORC_OMP
+#include <omp.h>
+#define ORC_PAR_FOR _Pragma("omp parallel for schedule(dynamic, 64)")
+ORC_API void orc_set_threads(int n) { omp_set_num_threads(n); }
+ORC_API int orc_max_threads(void) { return omp_get_max_threads(); }
+#else
+#define ORC_PAR_FOR
+ORC_API void orc_set_threads(int n) { (void)n; }
+ORC_API int orc_max_threads(void) { return 1; }
+#endif
 
 /* ------------------------------------------------------------------------------------------ */
 /* helpers                                                                                     */
@@ -113,6 +138,7 @@ static inline uint16_t orc_f2h(float f) {
 /* raymarching.cu:95-148  kernel_near_far_from_aabb */
 ORC_API void orc_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb,
                                     uint32_t N, float min_near, float* nears, float* fars) {
+    ORC_PAR_FOR
     for (uint32_t n = 0; n < N; n++) {
         const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
         const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
@@ -203,9 +229,9 @@ static inline void orc_ctx_init(orc_ray_ctx* c, const float* o, const float* d, 
  * (caller then does t += dt); returns 0 after having advanced *t past the empty cell. */
 static inline int orc_march_probe(const orc_ray_ctx* c, float* t, float* px, float* py, float* pz, float* pdt) {
     const float tt0 = *t;
-    const float x = orc_clampf(fmaf(tt0, c->dx, c->ox), -c->bound, c->bound);
-    const float y = orc_clampf(fmaf(tt0, c->dy, c->oy), -c->bound, c->bound);
-    const float z = orc_clampf(fmaf(tt0, c->dz, c->oz), -c->bound, c->bound);
+    const float x = orc_clampf(ORC_FMA(tt0, c->dx, c->ox), -c->bound, c->bound);
+    const float y = orc_clampf(ORC_FMA(tt0, c->dy, c->oy), -c->bound, c->bound);
+    const float z = orc_clampf(ORC_FMA(tt0, c->dz, c->oz), -c->bound, c->bound);
     const float dt = orc_clampf(tt0 * c->dt_gamma, c->dt_min, c->dt_max);
     const int lp = orc_mip_from_pos(x, y, z, c->fC), ld = orc_mip_from_dt(dt, c->fH, c->fC);
     const int level = lp > ld ? lp : ld;
@@ -213,16 +239,16 @@ static inline int orc_march_probe(const orc_ray_ctx* c, float* t, float* px, flo
     const float mip_rbound = 1.0f / mip_bound;
     const float hi = (float)(c->H - 1);
     /* :377-379  double intermediate, narrowed to float by clamp(float,...), truncated to int */
-    const int nx = (int)orc_clampf((float)(0.5 * (double)fmaf(x, mip_rbound, 1.0f) * (double)c->H), 0.0f, hi);
-    const int ny = (int)orc_clampf((float)(0.5 * (double)fmaf(y, mip_rbound, 1.0f) * (double)c->H), 0.0f, hi);
-    const int nz = (int)orc_clampf((float)(0.5 * (double)fmaf(z, mip_rbound, 1.0f) * (double)c->H), 0.0f, hi);
+    const int nx = (int)orc_clampf((float)(0.5 * (double)ORC_FMA(x, mip_rbound, 1.0f) * (double)c->H), 0.0f, hi);
+    const int ny = (int)orc_clampf((float)(0.5 * (double)ORC_FMA(y, mip_rbound, 1.0f) * (double)c->H), 0.0f, hi);
+    const int nz = (int)orc_clampf((float)(0.5 * (double)ORC_FMA(z, mip_rbound, 1.0f) * (double)c->H), 0.0f, hi);
     const uint32_t index = (uint32_t)level * c->H3 + orc_morton((uint32_t)nx, (uint32_t)ny, (uint32_t)nz); /* :381 (integer form, A3) */
     const int occ = c->grid[index / 8] & (1 << (index % 8));
     if (occ) { *px = x; *py = y; *pz = z; *pdt = dt; return 1; }
     /* :393-401 distance to the next voxel boundary */
-    const float tx = fmaf(fmaf(fmaf(0.5f, orc_signf(c->dx), (float)nx + 0.5f) * c->rH, 2.0f, -1.0f), mip_bound, -x) * c->rdx;
-    const float ty = fmaf(fmaf(fmaf(0.5f, orc_signf(c->dy), (float)ny + 0.5f) * c->rH, 2.0f, -1.0f), mip_bound, -y) * c->rdy;
-    const float tz = fmaf(fmaf(fmaf(0.5f, orc_signf(c->dz), (float)nz + 0.5f) * c->rH, 2.0f, -1.0f), mip_bound, -z) * c->rdz;
+    const float tx = ORC_FMA(ORC_FMA(ORC_FMA(0.5f, orc_signf(c->dx), (float)nx + 0.5f) * c->rH, 2.0f, -1.0f), mip_bound, -x) * c->rdx;
+    const float ty = ORC_FMA(ORC_FMA(ORC_FMA(0.5f, orc_signf(c->dy), (float)ny + 0.5f) * c->rH, 2.0f, -1.0f), mip_bound, -y) * c->rdy;
+    const float tz = ORC_FMA(ORC_FMA(ORC_FMA(0.5f, orc_signf(c->dz), (float)nz + 0.5f) * c->rH, 2.0f, -1.0f), mip_bound, -z) * c->rdz;
     const float tt = tt0 + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
     float tc = tt0;
     do { tc += orc_clampf(tc * c->dt_gamma, c->dt_min, c->dt_max); } while (tc < tt);
@@ -242,7 +268,7 @@ ORC_API void orc_march_rays_train(const float* rays_o, const float* rays_d, cons
         orc_ray_ctx c; orc_ctx_init(&c, rays_o + n * 3, rays_d + n * 3, bound, dt_gamma, max_steps, C, H, grid);
         const float far = fars[n];
         float t0 = nears[n];
-        t0 = fmaf(orc_clampf(t0 * dt_gamma, c.dt_min, c.dt_max), noises[n], t0);   /* :354 */
+        t0 = ORC_FMA(orc_clampf(t0 * dt_gamma, c.dt_min, c.dt_max), noises[n], t0);   /* :354 */
         float t = t0, x, y, z, dt; uint32_t num_steps = 0;
         while (t < far && num_steps < max_steps) {                                   /* :362 */
             if (orc_march_probe(&c, &t, &x, &y, &z, &dt)) { num_steps++; t += dt; }
@@ -270,12 +296,13 @@ ORC_API void orc_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* ra
                             uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
                             float* xyzs, float* dirs, float* deltas, const float* noises) {
     (void)nears;
+    ORC_PAR_FOR
     for (uint32_t n = 0; n < n_alive; n++) {
         const int index = rays_alive[n];
         orc_ray_ctx c; orc_ctx_init(&c, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid);
         float* px = xyzs + (size_t)n * n_step * 3; float* pd = dirs + (size_t)n * n_step * 3; float* pl = deltas + (size_t)n * n_step * 2;
         float t = rays_t[index]; const float far = fars[index];
-        t = fmaf(orc_clampf(t * dt_gamma, c.dt_min, c.dt_max), noises[n], t);      /* :952, noise indexed by slot (quirk 5) */
+        t = ORC_FMA(orc_clampf(t * dt_gamma, c.dt_min, c.dt_max), noises[n], t);      /* :952, noise indexed by slot (quirk 5) */
         float last_t = t, x, y, z, dt; uint32_t step = 0;
         while (t < far && step < n_step) {
             if (orc_march_probe(&c, &t, &x, &y, &z, &dt)) {
@@ -402,6 +429,7 @@ ORC_API void orc_spread_ray_to_sample(const float* input, const int32_t* rays, u
 /* raymarching.cu:1025-1111 */
 ORC_API void orc_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
                                 const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum, float* depth, float* image) {
+    ORC_PAR_FOR
     for (uint32_t n = 0; n < n_alive; n++) {
         const int index = rays_alive[n];
         const float* s = sigmas + (size_t)n * n_step; const float* c = rgbs + (size_t)n * n_step * 3; const float* dl = deltas + (size_t)n * n_step * 2;
@@ -428,9 +456,10 @@ ORC_API void orc_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thres
 ORC_API void orc_composite_rays_flex(uint32_t n_alive, uint32_t n_step, uint32_t n_channel, float T_thresh, const int32_t* rays_alive,
                                      const float* rays_t, const float* sigmas, const float* input, const float* deltas,
                                      const float* weights_sum, float* output) {
-    float temp[128];
     (void)rays_t;
+    ORC_PAR_FOR
     for (uint32_t n = 0; n < n_alive; n++) {
+        float temp[128];
         const int index = rays_alive[n];
         const float* s = sigmas + (size_t)n * n_step; const float* in = input + (size_t)n * n_step * n_channel; const float* dl = deltas + (size_t)n * n_step * 2;
         float* out = output + (size_t)index * n_channel;
@@ -484,6 +513,7 @@ ORC_API void orc_grid_encode_forward(const float* inputs, const float* grid, con
     for (uint32_t level = 0; level < L; level++) {
         const float* g = grid + (size_t)(uint32_t)offsets[level] * C;
         const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+        ORC_PAR_FOR
         for (uint32_t b = 0; b < B; b++) {
             const float* in = inputs + (size_t)b * D;
             float* out = outputs + ((size_t)level * B + b) * C;
@@ -639,6 +669,7 @@ static double orc_fact(int n) { double r = 1; for (int i = 2; i <= n; i++) r *= 
 ORC_API void orc_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t degree, float* dy_dx) {
     const uint32_t C2 = degree * degree;
     const double PI = 3.14159265358979323846;
+    ORC_PAR_FOR
     for (uint32_t b = 0; b < B; b++) {
         const double x = inputs[(size_t)b * D], y = inputs[(size_t)b * D + 1], z = inputs[(size_t)b * D + 2];
         double re[9], im[9]; re[0] = 1; im[0] = 0;

@@ -812,8 +812,13 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
         pf.view_dep_weight = pal->view_dep_weight; pf.aux_stride = aux_stride; pf.sigmas = w.sigmas; pf.rgbs = w.rgbs; pf.aux = w.aux;
     }
 
-    static thread_local FrameCtl* host_ctl = nullptr;  // pinned read-back slot (one in-flight frame per host thread)
-    if (!host_ctl && hipHostMalloc(reinterpret_cast<void**>(&host_ctl), sizeof(FrameCtl), hipHostMallocDefault) != hipSuccess) return PNR_ERR_LAUNCH;
+    // per host thread AND per device (a process may drive several GPUs): the pinned read-back slot, the timing events and the iteration
+    // prediction of the previous frame rendered there
+    struct PerDevice { FrameCtl* host_ctl = nullptr; std::vector<hipEvent_t> ev; uint32_t predicted_iterations = 0; };
+    static thread_local PerDevice per_device[kMaxDevices];
+    PerDevice& dev_state = per_device[current_device()];
+    FrameCtl*& host_ctl = dev_state.host_ctl;  // one in-flight frame per host thread and device
+    if (!host_ctl && hipHostMalloc(reinterpret_cast<void**>(&host_ctl), sizeof(FrameCtl), hipHostMallocPortable) != hipSuccess) return PNR_ERR_LAUNCH;
 
     const bool use_mip = a->mip && (a->H % 4) == 0 && pnr_occupancy_mip_bytes(a->C, a->H) <= 64 * 1024;
     const bool pow2 = is_pow2f(a->bound) && (a->H & (a->H - 1)) == 0;
@@ -825,7 +830,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     hipLaunchKernelGGL(k_frame_init, dim3(cdiv(N, kRayBlock)), dim3(kRayBlock), 0, s, N, in_near, w.alive[1], w.rays_t, out_ws, out_depth, out_image,
                        w.ctl, w.scratch + kHdr);
     // optional live timing of the roofline kernel: HIP events on the launch stream around every k_frame_grid launch
-    static thread_local std::vector<hipEvent_t> ev;
+    std::vector<hipEvent_t>& ev = dev_state.ev;
     size_t ev_used = 0;
     auto next_event = [&]() -> hipEvent_t {
         if (ev_used == ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; ev.push_back(e); }
@@ -836,7 +841,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     // Iterations enqueued between two looks at the control block.  Consecutive frames of a camera path need nearly the same
     // number of iterations, so the first chunk is the previous frame's count (one look per frame when the guess holds; launches
     // past the end are no-ops that cost a few microseconds each); after that, short chunks that grow for long, translucent marches.
-    static thread_local uint32_t predicted_iterations = 0;
+    uint32_t& predicted_iterations = dev_state.predicted_iterations;
     // (+1: the launch that finds no ray left is the one that reports it)
     uint32_t chunk = predicted_iterations ? (predicted_iterations < 1024u ? predicted_iterations + 1u : 1024u) : 8u;
     uint32_t looks = 0;
@@ -934,6 +939,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
         a->stats[1] = host_ctl->rendered;
         a->stats[2] = host_ctl->rows;
         a->stats[3] = (uint64_t)iter;  // iterations enqueued (>= executed)
+        a->stats[4] = (uint64_t)looks + 1;  // host looks at the control block (stream synchronisations) this frame took
     }
     return check_launch();
 }

@@ -348,12 +348,8 @@ int pnr_grid_encode_backward_binned(const float* grad, const float* inputs, cons
                                rec_row, rec_val, 0u);
     if (nc < L) hipLaunchKernelGGL(k_bin_scatter<false>, dim3(gx, L - nc), dim3(kBinThreads), 2 * hist_bytes, s, grad, inputs, offsets, B, lp, gridtype, ac,
                                    cursor, rec_row, rec_val, nc);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_gather), hipFuncAttributeMaxDynamicSharedMemorySize, kBinRows * 2 * 8) != hipSuccess)
-            return PNR_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static bool attr_set[kMaxDevices] = {};
+    if (!ensure_dynamic_lds(k_bin_gather, kBinRows * 2 * 8, attr_set)) return PNR_ERR_LAUNCH;
     const uint32_t gather_blocks = lay.job_bound < 1024u ? lay.job_bound : 1024u;
     hipLaunchKernelGGL(k_bin_gather, dim3(gather_blocks), dim3(1024), kBinRows * 2 * 8, s, jobs, n_jobs, rec_row, rec_val, grad_embeddings);
     return check_launch();

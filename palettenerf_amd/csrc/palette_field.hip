@@ -404,12 +404,8 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
     const uint32_t ntiles = cdiv(rows_ub ? rows_ub : 1, 256);
     const uint32_t grid = ntiles < 256u ? ntiles : 256u;  // one persistent 512-thread workgroup per CU (100-116 KiB of LDS)
     constexpr uint32_t kLdsLimit = 160 * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_palette_field_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit) != hipSuccess)
-            return PNR_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static bool attr_set[kMaxDevices] = {};
+    if (!ensure_dynamic_lds(k_palette_field_fwd, kLdsLimit, attr_set)) return PNR_ERR_LAUNCH;
     // staging slab for coalesced aux rows: 8 waves x 32 rows x (aux_stride + 4) floats, when it fits next to the weights
     uint32_t stage_stride = pnr_palette_field_stages_aux(a->aux_stride, pp.pred_clip) ? a->aux_stride + 4 : 0;
     const uint32_t lds = packed_bytes + (kPalThreads / 64) * 32 * stage_stride * 4;

@@ -20,6 +20,19 @@ inline int check_launch() {
 inline hipStream_t as_stream(pnr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
+// One process may drive several GPUs: function attributes and events belong to a device, so one-time set-up is tracked per device id.
+constexpr int kMaxDevices = 64;
+inline int current_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0; return d; }
+// raise a kernel's dynamic-LDS limit once per device; false = the runtime refused
+template <typename K>
+inline bool ensure_dynamic_lds(K kernel, uint32_t bytes, bool* done /* [kMaxDevices] */) {
+    const int d = current_device();
+    if (done[d]) return true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+    done[d] = true;
+    return true;
+}
+
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
 __device__ __forceinline__ float signf(float x) { return copysignf(1.0f, x); }
 

@@ -1,6 +1,7 @@
 """MI355X-first fused evaluation of the fields (no reference counterpart as one call): level-major
 hash-grid lookup feeding the MFMA tiny-MLP kernel directly, no permute/copy, no per-layer launches."""
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -38,11 +39,31 @@ def tile_ray_order(pixel_index, W, tile=8):
     return torch.argsort(key).to(torch.int32)
 
 
+PARANOID = os.environ.get("PNR_PARANOID_CACHE") == "1"   # rebuild every derived blob on every use (debugging aid for code that writes through `.data`)
+
+
+def _pkey(p):
+    """Identity of a parameter's CURRENT value as far as torch can tell: the Parameter object, its storage and its version counter.
+    In-place torch ops, optimizer steps and load_state_dict bump the version; replacing the Parameter changes the identity.  Writes through
+    `p.data` (torch_ema's copy_to / restore, `p.data.uniform_()`) change neither: call invalidate_fused_caches(model) after those."""
+    return (id(p), p.data_ptr(), p._version)
+
+
+def invalidate_fused_caches(model):
+    """Forget every blob derived from the model's parameters (packed MFMA weights, interleaved / half tables, host-side parameter copies).
+    Called by load_state_dict and initialize_palette; call it yourself after writing parameters through `.data` (EMA swap-in / restore:
+    nerf/utils.py:829-839, 959-961)."""
+    for attr in ("_fused", "_density_fused"):
+        f = getattr(model, attr, None)
+        if f is not None:
+            f.invalidate_caches()
+
+
 def _half_copy(owner, attr, t):
-    """fp16 copy of a table, cached on `owner` until the table changes (data pointer / version)."""
-    key = (t.data_ptr(), t._version)
+    """fp16 copy of a table, cached on `owner` until the table changes (identity / data pointer / version)."""
+    key = _pkey(t)
     cached = getattr(owner, attr, None)
-    if cached is None or cached[0] != key:
+    if cached is None or cached[0] != key or PARANOID:
         cached = (key, t.to(torch.float16).contiguous())
         setattr(owner, attr, cached)
     return cached[1]
@@ -93,10 +114,14 @@ class NeRFFieldFused:
         m = self.model
         return [m.sigma_net[0].weight, m.sigma_net[1].weight, m.color_net[0].weight, m.color_net[1].weight, m.color_net[2].weight]
 
+    def invalidate_caches(self):
+        self.versions = None
+        self._emb_half = None
+
     def _pack(self):
         ws = self._weights()
-        versions = tuple((w.data_ptr(), w._version) for w in ws) + (self.precision,)
-        if self.packed is None or versions != self.versions:
+        versions = tuple(_pkey(w) for w in ws) + (self.precision,)
+        if self.packed is None or versions != self.versions or PARANOID:
             dev = ws[0].device
             if self.packed is None or self.packed.device != dev:
                 self.packed = torch.empty(int(_lib.load().pnr_nerf_field_packed_bytes()) // 4, dtype=torch.float32, device=dev)
@@ -126,8 +151,8 @@ class NeRFFieldFused:
         enc = m.encoder
         emb = require(enc.embeddings.detach(), torch.float32, "embeddings")
         if self.table_half:   # the reference's --fp16 tables (`embeddings.to(torch.half)` per forward, gridencoder/grid.py:38): converted once per update here
-            emb = _half_copy(self, "_emb_half", emb)
-        stats = (ctypes.c_uint64 * 4)()
+            emb = _half_copy(self, "_emb_half", enc.embeddings)
+        stats = (ctypes.c_uint64 * 5)()
         a = _lib.NerfFrameArgs()
         a.table_dtype = 1 if self.table_half else 0
         a.N = N
@@ -154,7 +179,7 @@ class NeRFFieldFused:
             require(t, torch.float32, name)
         rc = lib.pnr_nerf_render_frame(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         _lib.check(rc, "pnr_nerf_render_frame")
-        return ws, depth, image, {"iterations": int(stats[0]), "rendered": int(stats[1]), "rows": int(stats[2]), "enqueued": int(stats[3]),
+        return ws, depth, image, {"iterations": int(stats[0]), "rendered": int(stats[1]), "rows": int(stats[2]), "enqueued": int(stats[3]), "looks": int(stats[4]),
                                   "grid_ms": float(kms[0]), "grid_launches": int(kms[1]), "finished": finished}
 
     @torch.no_grad()
@@ -212,6 +237,7 @@ class PaletteFieldFused:
         # without a clip head the reference composites clip_dim channels of zeros (palette/renderer.py:477,510): the map is zero whatever
         # happens, so those channels are left out of the packed aux row (52 -> 36 floats per sample for 4 bases) and returned as zeros
         self.clip_dim = int(m.opt.clip_dim) if self.pred_clip else 0
+        self.precision = 1              # PNR_FIELD_F16X3; 0 = PNR_FIELD_FP32 (exact fmaf chains, pnr_palette_*'s fp32 matrix path)
         self.interleave_tables = True   # native loop: look both hash tables up through one interleaved copy (see _pair_table)
         self.table_half = False         # native loop: fp16 tables with the reference's half interpolation (its --fp16 mode; no clip head)
         self.aux_channels = int(_lib.load().pnr_palette_aux_channels(self.nb, self.clip_dim))
@@ -225,10 +251,14 @@ class PaletteFieldFused:
             ws += [m.clip_net[0].weight, m.clip_net[1].weight]
         return ws
 
+    def invalidate_caches(self):
+        self.versions = None
+        self._pair_key = self._triple_key = self._hp_key = None
+
     def _pack(self):
         ws = self._weights()
-        versions = tuple((w.data_ptr(), w._version) for w in ws)
-        if self.packed is None or versions != self.versions:
+        versions = tuple(_pkey(w) for w in ws) + (self.precision,)
+        if self.packed is None or versions != self.versions or PARANOID:
             dev = ws[0].device
             lib = _lib.load()
             self.packed = torch.empty(int(lib.pnr_palette_field_packed_bytes(int(self.pred_clip))), dtype=torch.uint8, device=dev)
@@ -248,8 +278,8 @@ class PaletteFieldFused:
 
     def _host_params(self):
         m = self.model
-        key = (m.basis_color._version, m.offsets_radiance_net.bias._version)
-        if getattr(self, "_hp_key", None) != key:  # two tiny D2H copies, only when the parameters change
+        key = (_pkey(m.basis_color), _pkey(m.offsets_radiance_net.bias))
+        if getattr(self, "_hp_key", None) != key or PARANOID:  # two tiny D2H copies, only when the parameters change
             self._bc = (ctypes.c_float * (3 * self.nb))(*m.basis_color.detach().float().cpu().reshape(-1).tolist())
             self._bias = (ctypes.c_float * (3 * self.nb + 1))(*m.offsets_radiance_net.bias.detach().float().cpu().tolist())
             self._hp_key = key
@@ -260,11 +290,11 @@ class PaletteFieldFused:
         """`encoder` and `encoder_palette` interleaved row by row ([rows, 4] fp32; one 16-byte gather then serves both lookups).
         A copy of both tables (2 x 50 MB for the shipped config), rebuilt when either changes."""
         m = self.model
+        key = (_pkey(m.encoder.embeddings), _pkey(m.encoder_palette.embeddings), bool(self.table_half))
         a, b = m.encoder.embeddings.detach(), m.encoder_palette.embeddings.detach()
         if a.dtype != torch.float32 or b.dtype != torch.float32 or a.shape != b.shape or a.shape[1] != 2:
             return None
-        key = (a.data_ptr(), a._version, b.data_ptr(), b._version, bool(self.table_half))
-        if getattr(self, "_pair_key", None) != key:
+        if getattr(self, "_pair_key", None) != key or PARANOID:
             if self.table_half:   # rows of 4 halves: (a.x, a.y, b.x, b.y)
                 out = torch.cat([a.to(torch.float16), b.to(torch.float16)], dim=1).contiguous()
             else:
@@ -278,11 +308,11 @@ class PaletteFieldFused:
         """--pred_clip: the three tables interleaved row by row ([rows, 8] fp32 = encoder, encoder_palette, encoder_clip, 2 pad): one 32-byte
         row per corner serves all three lookups.  Rebuilt when any table changes."""
         m = self.model
+        key = tuple(_pkey(e.embeddings) for e in (m.encoder, m.encoder_palette, m.encoder_clip))
         ts = [e.embeddings.detach() for e in (m.encoder, m.encoder_palette, m.encoder_clip)]
         if any(t.dtype != torch.float32 or t.shape != ts[0].shape or t.shape[1] != 2 for t in ts):
             return None
-        key = tuple((t.data_ptr(), t._version) for t in ts)
-        if getattr(self, "_triple_key", None) != key:
+        if getattr(self, "_triple_key", None) != key or PARANOID:
             out = torch.empty(ts[0].shape[0], 8, dtype=torch.float32, device=ts[0].device)
             call("pnr_interleave_tables3", *[ptr(t.contiguous()) for t in ts], ctypes.c_uint64(ts[0].shape[0]), ptr(out))
             self._triple, self._triple_key = out, key
@@ -308,7 +338,7 @@ class PaletteFieldFused:
         for other in (m.encoder_palette, m.encoder_clip):
             if not torch.equal(other.offsets, enc.offsets) or other.per_level_scale != enc.per_level_scale:
                 raise RuntimeError("the three hash grids must share one level layout")
-        stats = (ctypes.c_uint64 * 4)()
+        stats = (ctypes.c_uint64 * 5)()
         kms = (ctypes.c_float * 2)()
         bc, bias = self._host_params()
         p = _lib.PaletteFrameArgs()
@@ -349,7 +379,7 @@ class PaletteFieldFused:
             require(t, torch.float32, name)
         rc = lib.pnr_palette_render_frame(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         _lib.check(rc, "pnr_palette_render_frame")
-        return ws, depth, image, aux_map, {"iterations": int(stats[0]), "rendered": int(stats[1]), "rows": int(stats[2]), "enqueued": int(stats[3]),
+        return ws, depth, image, aux_map, {"iterations": int(stats[0]), "rendered": int(stats[1]), "rows": int(stats[2]), "enqueued": int(stats[3]), "looks": int(stats[4]),
                                            "grid_ms": float(kms[0]), "grid_launches": int(kms[1])}
 
     @torch.no_grad()

@@ -104,7 +104,8 @@ class GridEncoder(nn.Module):
         self.reset_parameters()
 
     def reset_parameters(self):
-        self.embeddings.data.uniform_(-1e-4, 1e-4)
+        with torch.no_grad():   # in place on the Parameter itself (not `.data`): bumps its version, so blobs derived from the table are rebuilt
+            self.embeddings.uniform_(-1e-4, 1e-4)
 
     def __repr__(self):
         finest = int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))

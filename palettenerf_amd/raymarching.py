@@ -18,32 +18,35 @@ _bwd = custom_bwd(device_type="cuda")
 
 
 USE_MIP = True  # stage the any/all occupancy mip in LDS for the march kernels (bit-identical results, far fewer global probes)
-_mip_cache = {}  # bitfield.data_ptr() -> (key, mip tensor)
+_MIP_ATTR = "_pnr_occupancy_mip"
 
 
 def occupancy_mip(bitfield, C, H, bound):
-    """Cached any/all brick mip of a density bitfield (pnr_build_occupancy_mip).  The cache is keyed on the tensor's
-    storage pointer and version counter: torch in-place ops and this module's packbits() bump the version; code that
-    rewrites the bitfield behind torch's back must call invalidate_occupancy_mip()."""
+    """Cached any/all brick mip of a density bitfield (pnr_build_occupancy_mip).  The cache entry lives ON the bitfield tensor object
+    (an attribute), so it dies with the tensor: a later tensor that happens to get the same address from the caching allocator is a
+    different object and starts without a mip.  The entry is keyed on the tensor's version counter (torch in-place ops, load_state_dict
+    and this module's packbits() bump it), storage pointer and geometry; code that rewrites the bitfield behind torch's back (through
+    `.data` or a raw pointer) must call invalidate_occupancy_mip(bitfield)."""
     if not USE_MIP or H % 4 != 0 or bitfield.data_ptr() % 8 != 0:
         return None
     nbytes = int(_lib.load().pnr_occupancy_mip_bytes(int(C), int(H)))
     if nbytes > 64 * 1024:
         return None
-    key = (bitfield._version, int(C), int(H), float(bound), bitfield.numel())
-    ent = _mip_cache.get(bitfield.data_ptr())
-    if ent is not None and ent[0] == key and ent[1].device == bitfield.device:
+    key = (bitfield._version, bitfield.data_ptr(), str(bitfield.device), int(C), int(H), float(bound), bitfield.numel())
+    ent = getattr(bitfield, _MIP_ATTR, None)
+    if ent is not None and ent[0] == key:
         return ent[1]
     mip = torch.empty(nbytes // 4, dtype=torch.int32, device=bitfield.device)
     call("pnr_build_occupancy_mip", ptr(require(bitfield, torch.uint8, "density_bitfield")), _u32(C), _u32(H), _f32(bound), ptr(mip))
-    if len(_mip_cache) > 64:
-        _mip_cache.clear()
-    _mip_cache[bitfield.data_ptr()] = (key, mip)
+    setattr(bitfield, _MIP_ATTR, (key, mip))
     return mip
 
 
-def invalidate_occupancy_mip():
-    _mip_cache.clear()
+def invalidate_occupancy_mip(bitfield=None):
+    """Drop the cached mip of `bitfield` (only needed after writes that bypass torch's version counter).  Without an argument this is a
+    no-op kept for callers of the former process-wide cache."""
+    if bitfield is not None and hasattr(bitfield, _MIP_ATTR):
+        delattr(bitfield, _MIP_ATTR)
 
 
 def _scratch(n, device):

@@ -190,6 +190,17 @@ class _RendererBase(nn.Module):
             self.mean_count = 0
             self.local_step = 0
 
+    def invalidate_fused_caches(self):
+        """Forget the blobs the fused kernels derive from the parameters (fused.invalidate_fused_caches).  load_state_dict and
+        initialize_palette call it; call it after writing parameters through `.data` (an EMA swap, nerf/utils.py:829-839)."""
+        from .fused import invalidate_fused_caches
+        invalidate_fused_caches(self)
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_fused_caches()
+        return out
+
     def reset_extra_state(self):
         if not self.cuda_ray:
             return
@@ -408,7 +419,7 @@ class NeRFRenderer(_OccupancyMaintenance, _RendererBase):
             rgb_norm_map = torch.zeros_like(image[..., 0])
             results["n_samples"] = stats["rows"]
             results["rendered"] = torch.tensor([stats["rendered"]], dtype=torch.int64)   # host tensor: the count came back with the control block
-            results["iterations"] = stats["iterations"]
+            results["iterations"], results["host_looks"] = stats["iterations"], stats["looks"]
             results["grid_ms"], results["grid_launches"] = stats["grid_ms"], stats["grid_launches"]
         else:
             def shade(st, n_alive, n_step, xyzs, dirs, deltas):
@@ -537,14 +548,19 @@ class PaletteRenderer(_RendererBase):
             self.basis_color = None
 
     def initialize_palette(self, color_list=None, hist_weights=None):
-        """palette/renderer.py:247-268 (sRGB colour space only; srgb_to_linear is a harness utility)."""
+        """palette/renderer.py:247-268; with --color_space linear the extracted (sRGB) palette is moved to linear colour first (:256-259,
+        srgb_to_linear of nerf/utils.py:39-40)."""
         if color_list is None:
             if self.basis_color is None:
                 self.basis_color = nn.Parameter(torch.zeros([self.num_basis, 3]) + 0.5, requires_grad=True)
         else:
             dev = self.aabb_train.device
-            self.basis_color = nn.Parameter(torch.as_tensor(color_list, dtype=torch.float32, device=dev).reshape(self.num_basis, 3).clone(),
-                                            requires_grad=True)
+            colors = torch.as_tensor(color_list, dtype=torch.float32, device=dev).reshape(self.num_basis, 3).clone()
+            space = getattr(self.opt, "color_space", "srgb")
+            if space == "linear":
+                colors = torch.where(colors < 0.04045, colors / 12.92, ((colors + 0.055) / 1.055) ** 2.4)
+            self.basis_color = nn.Parameter(colors, requires_grad=True)
+        self.invalidate_fused_caches()
         self.basis_color_origin = nn.Parameter(self.basis_color.data.clone(), requires_grad=False)
         if hist_weights is not None:
             hw = torch.as_tensor(hist_weights).float().permute(3, 0, 1, 2).unsqueeze(0)
@@ -721,6 +737,7 @@ class PaletteRenderer(_RendererBase):
             st.weights_sum, st.depth, st.image, st.n_samples = ws_n, depth_n, image_n, stats["rows"]
             st.rendered = torch.tensor([stats["rendered"]], dtype=torch.int64)   # host tensor: the count came back with the control block
             results["iterations"], results["grid_ms"], results["grid_launches"] = stats["iterations"], stats["grid_ms"], stats["grid_launches"]
+            results["host_looks"] = stats["looks"]
         else:
             st = self._infer_loop(rays_o, rays_d, nears, fars, perturb, dt_gamma, max_steps, shade_fused if use_fused else shade)
         if use_fused:  # unpack the composited aux row into the reference's maps

@@ -87,6 +87,74 @@ def slab_density_grid(H=128, half_thickness=0.8, bound=2):
     return grid
 
 
+# ---------------------------------------------------------------------------------------------- scene S2 ("garden-like")
+# Mip-NeRF-360 garden, images_4: 1297 x 840 pixels, focal ~ 961 px (dataset facts, not in the reference tree).
+GARDEN_W, GARDEN_H, GARDEN_FL = 1297, 840, 961.0
+GARDEN_POSES = 120        # scripts/llff2nerf.py:106: gen_renderposes(poses, bounds, 120)
+
+
+def garden_density_grid(H=128, seed=0, bound=2):
+    """Scene S2: an unbounded-360-style layout inside bound = 2 (the mip360 configs: bound 2, scale 0.12-0.16, so the cameras orbit at
+    ~0.5 from the origin): a bricked centre object (max|p| < 0.3, 4^3-cell bricks, 3 of 4 present), a thin ground slab through the whole
+    box, scattered "hedge" bricks around the object and a sparse far shell that only the coarse cascade resolves.  Morton order, 1 = occupied;
+    cascade 1 = every cell that contains the centre of an occupied cascade-0 cell, plus the ground and the far shell outside |p| < 1."""
+    cascade = 1 + math.ceil(math.log2(bound))
+    assert cascade == 2, "S2 is defined for bound = 2"
+    idx = np.arange(H, dtype=np.uint32)
+    i, j, k = np.meshgrid(idx, idx, idx, indexing="ij")
+    c = (idx.astype(np.float64) + 0.5) / H * 2 - 1
+    px, py, pz = np.meshgrid(c, c, c, indexing="ij")
+
+    def bhash(a, b, cc, salt):
+        h = (a * np.uint32(73856093)) ^ (b * np.uint32(19349663)) ^ (cc * np.uint32(83492791)) ^ np.uint32((seed * 2654435761 + salt) & 0xFFFFFFFF)
+        return (h ^ (h >> np.uint32(13))) * np.uint32(0x5bd1e995)
+
+    m = np.maximum(np.maximum(np.abs(px), np.abs(py)), np.abs(pz))
+    obj = (m < 0.3) & ((bhash(i >> 2, j >> 2, k >> 2, 1) >> np.uint32(8)) % np.uint32(4) != 0)
+    ground = (py > -0.42) & (py < -0.34)
+    hedge = (np.maximum(np.abs(px), np.abs(pz)) > 0.55) & (py >= -0.34) & (py < 0.25) & ((bhash(i >> 3, j >> 3, k >> 3, 2) >> np.uint32(8)) % np.uint32(12) == 0)
+    occ0 = obj | ground | hedge
+    grid = np.zeros((cascade, H ** 3), dtype=np.float32)
+    grid[0, morton3d_np(i[occ0], j[occ0], k[occ0])] = 1.0
+    s = 2.0
+    qi = np.floor((px[occ0] / s + 1) / 2 * H).astype(np.uint32)
+    qj = np.floor((py[occ0] / s + 1) / 2 * H).astype(np.uint32)
+    qk = np.floor((pz[occ0] / s + 1) / 2 * H).astype(np.uint32)
+    grid[1, morton3d_np(qi, qj, qk)] = 1.0
+    qx, qy, qz = px * s, py * s, pz * s          # cascade-1 cell centres
+    outside = np.maximum(np.maximum(np.abs(qx), np.abs(qy)), np.abs(qz)) >= 1.0
+    far_ground = outside & (qy > -0.44) & (qy < -0.32)
+    far_shell = outside & (qy >= -0.32) & (qy < 0.9) & ((bhash(i >> 3, j >> 3, k >> 3, 3) >> np.uint32(8)) % np.uint32(8) == 0)
+    occ1 = far_ground | far_shell
+    grid[1, morton3d_np(i[occ1], j[occ1], k[occ1])] = 1.0
+    return grid
+
+
+def lookat_pose_from(eye, target=(0.0, 0.0, 0.0)):
+    """4x4 camera-to-world at `eye` looking at `target`; world up +y; columns (right, down, forward) as lookat_pose."""
+    eye = np.asarray(eye, np.float64)
+    fwd = np.asarray(target, np.float64) - eye
+    fwd /= np.linalg.norm(fwd)
+    right = np.cross(fwd, np.array([0.0, 1.0, 0.0]))
+    right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    pose = np.eye(4, dtype=np.float32)
+    pose[:3, 0], pose[:3, 1], pose[:3, 2], pose[:3, 3] = right, down, fwd, eye
+    return pose
+
+
+def garden_orbit_pose(i, n=GARDEN_POSES, radius=0.52, height=0.22):
+    """Pose i of the n-pose ellipse path of the video render (the role of nerf_360_v2.gen_renderposes, scripts/llff2nerf.py:104-106):
+    an ellipse of semi-axes radius x 0.8 radius around the object at `height`, looking slightly below the origin."""
+    a = 2.0 * math.pi * (i % n) / n
+    return lookat_pose_from((radius * math.sin(a), height, 0.8 * radius * math.cos(a)), (0.0, -0.1, 0.0))
+
+
+def garden_intrinsics(H=GARDEN_H, W=GARDEN_W):
+    fl = GARDEN_FL * W / GARDEN_W
+    return np.array([fl, fl, W / 2, H / 2], dtype=np.float32)
+
+
 def packbits_np(grid, thresh):
     """NumPy statement of packbits (bit i of byte n <-> cell 8n+i, strict '>')."""
     return np.packbits((np.asarray(grid, np.float32).reshape(-1) > np.float32(thresh)), bitorder="little")

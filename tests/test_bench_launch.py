@@ -1,0 +1,65 @@
+"""bench.py's launcher logic on CPU: `--gpus N` without a launcher spawns N ranks under torch.distributed.run (as a child process, before
+anything touches a GPU), and a rank count that disagrees with --gpus is refused."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_workloads_name_every_gpu_config_of_baseline_json():
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    named = sorted(w["config"] for w in bench.WORKLOADS.values())
+    assert named == [1, 2, 4]                      # configs[0] is the CPU plumbing case (cpu_baseline.uniform_path_config0), configs[3] the training run
+    assert len(base["configs"]) == 5
+    a = bench.parse(["--workload", "garden"])
+    assert (a.wl["H"], a.wl["W"], a.wl["model"]) == (840, 1297, "palette") and abs(a.wl["dt_gamma"] - 1 / 128) < 1e-12
+    a = bench.parse([])
+    assert (a.wl["H"], a.wl["W"], a.wl["model"], a.wl["dt_gamma"], a.gpus) == (800, 800, "nerf", 0.0, 1)
+    assert bench.parse(["--model", "palette"]).workload == "lego_palette"
+
+
+def test_gpus_flag_spawns_that_many_ranks(tmp_path, monkeypatch):
+    """The spawn path really produces WORLD_SIZE == --gpus ranks (a stand-in script records what each rank sees)."""
+    probe = tmp_path / "probe.py"
+    probe.write_text("import os, sys\n"
+                     "open(os.path.join(sys.argv[-1], 'rank' + os.environ['RANK']), 'w').write(os.environ['WORLD_SIZE'] + ' ' + os.environ['LOCAL_RANK'] + ' ' + ' '.join(sys.argv[1:-1]))\n")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    args = bench.parse(["--gpus", "2", "--steps", "3"])
+    rc = bench.spawn_ranks(args, ["--gpus", "2", "--steps", "3", str(tmp_path)], script=str(probe))
+    assert rc == 0
+    seen = sorted(f for f in os.listdir(tmp_path) if f.startswith("rank"))
+    assert seen == ["rank0", "rank1"]
+    for r, f in enumerate(seen):
+        world, local, *argv = (tmp_path / f).read_text().split()
+        assert (world, local) == ("2", str(r)) and argv == ["--gpus", "2", "--steps", "3"]   # the ranks get the same flags
+
+
+def test_world_from_env(monkeypatch):
+    import torch
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert bench.world_from_env(bench.parse([]), []) == (1, 0, 0)
+    # --gpus 2, no launcher, 2 devices visible: the parent spawns and exits with the children's code; it never initialises a GPU itself
+    calls = []
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    monkeypatch.setattr(bench, "spawn_ranks", lambda a, argv, script=None: calls.append((a.gpus, list(argv))) or 7)
+    with pytest.raises(SystemExit) as e:
+        bench.world_from_env(bench.parse(["--gpus", "2"]), ["--gpus", "2"])
+    assert e.value.code == 7 and calls == [(2, ["--gpus", "2"])]
+    # fewer devices than ranks: refused loudly
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit, match="only 1 GPU"):
+        bench.world_from_env(bench.parse(["--gpus", "2"]), ["--gpus", "2"])
+    # under a launcher: ranks from the environment, and they must agree with --gpus
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("RANK", "3")
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    assert bench.world_from_env(bench.parse(["--gpus", "4"]), []) == (4, 3, 3)
+    with pytest.raises(SystemExit, match="must agree"):
+        bench.world_from_env(bench.parse(["--gpus", "8"]), [])
+    with pytest.raises(SystemExit, match="must agree"):
+        bench.world_from_env(bench.parse([]), [])

@@ -510,3 +510,58 @@ def test_native_loop_under_fp16_autocast_uses_half_tables(cuda, model_kind):
     assert a["image"].dtype == torch.float32 and int(a["rendered"].item()) == int(b["rendered"].item()) > 500
     for k in ("image", "depth", "weights_sum"):
         assert torch.equal(torch.nan_to_num(a[k], nan=-7.0), torch.nan_to_num(b[k], nan=-7.0)), k
+
+
+def test_fused_blobs_follow_parameter_updates(cuda, golden_dir):
+    """The packed MFMA weights, interleaved tables and host-side parameter copies are caches of the parameters: optimizer-style in-place
+    updates, load_state_dict and initialize_palette must all show up in the next native frame; writes through `.data` (an EMA swap,
+    nerf/utils.py:829-839) need invalidate_fused_caches() and then show up too."""
+    g = load(golden_dir, "frame_palette_a")
+    opt = renderer.default_opt()
+    m = network.PaletteNetwork(opt, bound=2, cuda_ray=True, density_scale=float(g["density_scale"]), min_near=0.2)
+    scene.seed_field_(m, int(g["seed"]))
+    m = m.to(cuda).eval()
+    put_scene(m, cuda)
+    m.march_mode, m.fused_field = "native", True
+    ro, rd = frame_rays(g, cuda)
+    kw = dict(dt_gamma=float(g["dt_gamma"]), perturb=False, max_steps=1024, T_thresh=1e-4, gui_mode=False)
+
+    def both():
+        with torch.no_grad():
+            n = m.render(ro, rd, **kw)["image"]
+            m.march_mode, m.fused_field = "compat", False
+            c = m.render(ro, rd, **kw)["image"]
+            m.march_mode, m.fused_field = "native", True
+        return n, c
+
+    n0, c0 = both()
+    close(n0, g["image"], what="before")
+    # 1. in-place update of weights, a table, the bias and the palette (what an optimizer step does)
+    with torch.no_grad():
+        m.color_net[2].weight.mul_(0.5)
+        m.encoder_palette.embeddings.mul_(-1.0)
+        m.offsets_radiance_net.bias.add_(0.3)
+        m.basis_color.mul_(0.5)
+    n1, c1 = both()
+    assert float((n1 - n0).abs().max()) > 1e-2 and float((n1 - c1).abs().max()) < COLOUR_TOL
+    # 2. a write through .data does not bump the version: stale until invalidated, correct afterwards
+    m.diff_net[2].weight.data.mul_(-1.0)
+    m.invalidate_fused_caches()
+    n2, c2 = both()
+    assert float((n2 - n1).abs().max()) > 1e-3 and float((n2 - c2).abs().max()) < COLOUR_TOL
+    # 3. load_state_dict (same Parameter objects, new values) and a second initialize_palette (a NEW Parameter object at version 0)
+    fresh = network.PaletteNetwork(opt, bound=2, cuda_ray=True, density_scale=float(g["density_scale"]), min_near=0.2)
+    scene.seed_field_(fresh, int(g["seed"]))
+    sd = {k: v for k, v in fresh.state_dict().items() if not k.startswith("density_")}
+    m.load_state_dict(sd, strict=False)
+    n3, c3 = both()
+    close(n3, g["image"], what="after load_state_dict")
+    m.initialize_palette([[0.9, 0.1, 0.1], [0.1, 0.9, 0.1], [0.1, 0.1, 0.9], [0.5, 0.5, 0.5]])
+    n4, c4 = both()
+    assert float((n4 - n3).abs().max()) > 1e-2 and float((n4 - c4).abs().max()) < COLOUR_TOL
+    m.opt.color_space = "linear"   # main_palette.py --color_space linear: the extracted sRGB palette is linearised (palette/renderer.py:256-259)
+    m.initialize_palette([[0.9, 0.1, 0.1], [0.1, 0.9, 0.1], [0.1, 0.1, 0.9], [0.5, 0.5, 0.5]])
+    want = torch.tensor([0.9, 0.1, 0.5])
+    want = torch.where(want < 0.04045, want / 12.92, ((want + 0.055) / 1.055) ** 2.4)
+    assert torch.allclose(m.basis_color.detach().cpu()[[0, 0, 3], [0, 1, 0]], want, atol=1e-7)
+    assert torch.equal(m.basis_color_origin, m.basis_color.detach())
