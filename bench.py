@@ -217,6 +217,9 @@ def cpu_baseline(args, crop_rays):
     saved = (renderer.raymarching, pge.GridEncoder, psh.SHEncoder)
     renderer.raymarching, pge.GridEncoder, psh.SHEncoder = rm, ge.GridEncoder, sh.SHEncoder
     cores = os.cpu_count() or 1
+    # "all cores": OpenMP threads over rays / samples in the C ops; the torch MLP batches (<= 160 k rows x 64) stop scaling long before a 256-core
+    # host is full (oversubscribed GEMM threads made this leg 15x SLOWER than one thread), so torch gets at most 32 threads
+    omp_threads, torch_threads = min(cores, 64), min(cores, 32)
     legs = {}
     try:
         m = make_model(args, args.model)
@@ -230,21 +233,21 @@ def cpu_baseline(args, crop_rays):
         if args.model == "palette":
             kw["gui_mode"] = False
         ref = None
-        for name, variant, threads in (("1_thread", "", 1), ("all_cores", "omp", cores)):
+        for name, variant, threads, tthreads in (("1_thread", "", 1, 1), ("all_cores", "omp", omp_threads, torch_threads)):
             prev = orc.use_variant(variant)
             orc.set_threads(threads)
-            torch.set_num_threads(threads)
+            torch.set_num_threads(tthreads)
             t0 = time.perf_counter()
             with torch.no_grad():
                 r = m.render(ro, rd, **kw)
             dt = time.perf_counter() - t0
             orc.use_variant(prev)
             n = int(r["rendered"].item())
-            legs[name] = {"value": n / dt, "unit": "samples/s", "cores": threads, "seconds": dt}
+            legs[name] = {"value": n / dt, "unit": "samples/s", "cores": threads, "torch_threads": tthreads, "host_cores": cores, "seconds": dt}
             if ref is None:
                 ref = r
-            else:   # same arithmetic on more threads: the images must be the same bits
-                legs[name]["identical_to_1_thread"] = bool(torch.equal(r["image"], ref["image"]))
+            else:   # the C ops are bit-identical on any thread count (tests/test_oracle.py); torch's CPU GEMMs block differently per thread count
+                legs[name]["max_abs_rgb_vs_1_thread"] = float((r["image"] - ref["image"]).abs().max())
         # BASELINE configs[0] beside it: the reference's CPU-runnable case, NeRFRenderer.run at 400x400 with --num_steps 512 --upsample_steps 0
         # (main_nerf.py:31-32): 1024 rays of one max_ray_batch of 4096 (160 such pieces make the frame), OMP_NUM_THREADS=8 as scripts/run_blender.sh:47 sets
         uniform = None
@@ -480,7 +483,7 @@ def main(argv=None):
             gi, ri = g["image"].cpu(), ref["image"]
             out["parity"] = {"psnr_vs_oracle_db": scene.psnr(gi, ri), "max_abs_rgb": float((gi - ri).abs().max()),
                              "max_abs_alpha": float((g["weights_sum"].cpu() - ref["weights_sum"]).abs().max()),
-                             "rendered_samples_equal": int(g["rendered"].sum()) == int(ref["rendered"].sum()),
+                             "rendered_samples_gpu": int(g["rendered"].sum()), "rendered_samples_oracle": int(ref["rendered"].sum()),
                              "sample": rec["sample"].split(" (")[0], "tolerance": "1e-4 abs (north_star)"}
         # --- extra driver-observed legs on the same box: the exact-fp32 field and the PaletteNeRF model (configs[2]) on the same camera path
         if not args.no_extras and native and args.workload == "lego" and not args.fp16:

@@ -172,13 +172,17 @@ uint64_t pnr_nerf_field_packed_bytes(void);
 int pnr_nerf_field_pack(const float* w_sigma0, const float* w_sigma1, const float* w_color0, const float* w_color1,
                         const float* w_color2, float* packed, int precision, pnr_stream_t stream);
 int pnr_nerf_field_forward(const float* enc, const float* dirs, const float* packed, uint32_t B, float* sigmas,
-                           float* rgbs, int precision, pnr_stream_t stream);
+                           float* rgbs, int precision, float enc_scale, pnr_stream_t stream);
+/* enc_scale (here, in pnr_nerf_density_forward and in the frame / palette argument structs): a power of two the encoder features are
+ * multiplied by before the split-fp16 matrix path splits them, undone exactly after the first (bias-free, positively homogeneous) stack;
+ * 1 (or 0) = none.  For hash tables whose entries are tiny (the reference initialises them U(-1e-4, 1e-4), gridencoder/grid.py:107) it keeps
+ * the low halves out of fp16's subnormal range.  Ignored by PNR_FIELD_FP32. */
 /* sigma_net alone (NeRFNetwork.density / the frozen-geometry half of PaletteNetwork.forward: nerf/network.py:126-143,
  * palette/network.py:161-170): sigmas [B] = scale * exp(h0), geo_feat [B,15] = h[1:] (NULL: not wanted).  Same enc layout, packed blob
  * and precision modes as pnr_nerf_field_forward.  No gradient: for inference, the occupancy sweep and PaletteNeRF training (whose
  * geometry is detached). */
 int pnr_nerf_density_forward(const float* enc, const float* packed, uint32_t B, float scale, float* sigmas, float* geo_feat, int precision,
-                             pnr_stream_t stream);
+                             float enc_scale, pnr_stream_t stream);
 
 /* Device-driven inference frame of the NeRF path: the loop of nerf/renderer.py:344-380 (same n_step schedule,
  * same per-ray arithmetic, order-preserving compaction) with n_alive / n_step / step kept in a device control
@@ -227,13 +231,34 @@ typedef struct pnr_nerf_frame_args {
     int table_dtype;               /* PNR_DTYPE_F32 (default) or PNR_DTYPE_F16: the reference's --fp16 tables (`embeddings` then points to halves;
                                       PaletteNeRF: embeddings_pair = both tables as interleaved halves, required, no clip head).  The lookup
                                       then reproduces the reference's half interpolation (as pnr_grid_encode_forward with dtype 1) */
+    float enc_scale[3];            /* power-of-two prescale of the features of `embeddings` (PaletteNeRF: + embeddings_palette, embeddings_clip) in the
+                                      split-fp16 field, see pnr_nerf_field_forward; 0 or 1 = none */
 } pnr_nerf_frame_args;
 uint64_t pnr_nerf_frame_workspace_bytes(uint32_t N);
 int pnr_nerf_render_frame(const pnr_nerf_frame_args* args, pnr_stream_t stream);
 
-/* The same device-driven loop for the PaletteNeRF model (palette/renderer.py:430-550 without RegionEdit / Stylizer):
- * `base.embeddings` is the `encoder` table, `base.packed_weights` the pnr_palette_field_pack blob, base.field_precision must be
- * PNR_FIELD_F16X3.  aux_map [N, pnr_palette_aux_channels(nb, clip_dim)] receives the composited packed row
+/* Appearance editing heads of the PaletteNeRF inference loop, evaluated inside the fused field kernel's epilogue (HOST struct).
+ *   mode 1  RegionEdit.forward (palette/renderer.py:121-147): per basis, final colour -> HSV (pnr_rgb_to_hsv's arithmetic), hue += delta_hsv[b][0]
+ *           (+360, fmod 360), saturation / value *= delta_hsv[b][1..2] (clipped at 0), -> RGB, then lerp(original, edited, weight) with
+ *           weight = exp(-|xyz - mean_xyz|^2 / std_xyz) * exp(-|clip_feat - mean_clip|^2 / std_clip) (each factor only when its mean is set);
+ *           weight_mode != 0 returns the weight itself in every channel (the GUI's region preview).
+ *   mode 2  Stylizer.forward (palette/renderer.py:166-183): rgb = sum_b omega_b clamp(max(softplus(r) + dI_b, 0) (P_b + dP_b + offsets_b . ddelta_b), 0, 1)
+ *           + view_dep  (offsets_weight / view_dep_weight do not apply, as in the reference). */
+#define PNR_MAX_BASIS 10
+#define PNR_MAX_CLIP 32
+typedef struct pnr_palette_edit {
+    int mode;                                /* 0 none, 1 RegionEdit, 2 Stylizer */
+    float delta_hsv[PNR_MAX_BASIS][3];
+    int has_mean_xyz;  float mean_xyz[3];  float std_xyz;
+    int has_mean_clip; float mean_clip[PNR_MAX_CLIP]; float std_clip;   /* has_mean_clip = number of entries (the model's clip_dim), 0 = not set */
+    int weight_mode;
+    float dI[PNR_MAX_BASIS]; float dP[PNR_MAX_BASIS][3]; float ddelta[PNR_MAX_BASIS][3][3];
+} pnr_palette_edit;
+
+/* The same device-driven loop for the PaletteNeRF model (palette/renderer.py:430-550, RegionEdit / Stylizer included through `edit`):
+ * `base.embeddings` is the `encoder` table, `base.packed_weights` the pnr_palette_field_pack blob (packed with base.field_precision:
+ * PNR_FIELD_F16X3 or the exact PNR_FIELD_FP32).  num_basis <= PNR_MAX_BASIS, clip_dim <= PNR_MAX_CLIP.
+ * aux_map [N, pnr_palette_aux_channels(nb, clip_dim)] receives the composited packed row
  * direct_rgb 3 | view_dep 3 | basis_acc nb | basis_rgb 3nb | unscaled_basis_rgb 3nb | clip_feat clip_dim | pad
  * (raw accumulations: the background mix of direct_rgb is the caller's, palette/renderer.py:541). */
 typedef struct pnr_palette_frame_args {
@@ -251,6 +276,7 @@ typedef struct pnr_palette_frame_args {
                                           gather serves both tables, results bit-identical to the separate lookups */
     const float* embeddings_triple;    /* optional, pred_clip != 0: all three tables interleaved ([rows][8] floats: encoder, encoder_palette,
                                           encoder_clip, 2 pad; pnr_interleave_tables3): one 32-byte row per corner, bit-identical results */
+    const pnr_palette_edit* edit;      /* HOST, optional: RegionEdit / Stylizer applied to every sample (NULL or mode 0: none) */
 } pnr_palette_frame_args;
 /* out[i] = (a[i].x, a[i].y, b[i].x, b[i].y) for two C = 2 fp32 tables of `rows` rows with the same level layout */
 int pnr_interleave_tables(const float* a, const float* b, uint64_t rows, float* out, pnr_stream_t stream);
@@ -259,8 +285,8 @@ int pnr_interleave_tables3(const float* a, const float* b, const float* c, uint6
 uint64_t pnr_palette_frame_workspace_bytes(uint32_t N, uint32_t num_basis, uint32_t clip_dim, int pred_clip);
 int pnr_palette_render_frame(const pnr_palette_frame_args* args, pnr_stream_t stream);
 
-/* Fused PaletteNeRF field + palette colour-basis composite (palette/network.py:156-280, palette/renderer.py:470-500,
- * inference branch without RegionEdit / Stylizer).  Split-fp16 matrix path.  All weights are row-major [out][in]
+/* Fused PaletteNeRF field + palette colour-basis composite (palette/network.py:156-280, palette/renderer.py:470-500, RegionEdit /
+ * Stylizer included).  Split-fp16 or exact-fp32 matrix path (`precision`).  All weights are row-major [out][in]
  * device fp32 pointers of the bias-free nn.Linear layers; offsets_radiance has a bias (passed to the forward call). */
 typedef struct pnr_palette_weights {
     const float *sigma0, *sigma1;              /* [64,32], [16,64]            */
@@ -270,8 +296,9 @@ typedef struct pnr_palette_weights {
     const float *offsets_radiance;             /* [3 nb + 1, 15]              */
     const float *omega;                        /* [nb, 15]                    */
     const float *clip0, *clip1;                /* [64,32], [clip_dim,64] (pred_clip only) */
-    uint32_t num_basis, clip_dim;              /* nb <= 5, clip_dim <= 16     */
+    uint32_t num_basis, clip_dim;              /* nb <= PNR_MAX_BASIS, clip_dim <= PNR_MAX_CLIP */
     int pred_clip;
+    int precision;                             /* PNR_FIELD_F16X3 or PNR_FIELD_FP32: number format of the packed blob */
 } pnr_palette_weights;
 typedef struct pnr_palette_field_args {
     const void* ctl;               /* NULL for the stand-alone op (rows = B); internal frame control block otherwise */
@@ -300,9 +327,14 @@ typedef struct pnr_palette_field_args {
     const float* weights_sum;      /* [N] of BEFORE this iteration */
     float* aux_map;                /* [N, aux_stride] */
     float T_thresh;                /* early-termination threshold of the composite (frame loop only) */
+    int precision;                 /* PNR_FIELD_F16X3 / PNR_FIELD_FP32, as the blob was packed */
+    const pnr_palette_edit* edit;  /* HOST, optional */
+    const float* xyzs;             /* [B,3] world positions of the samples: needed by RegionEdit's spatial window (edit->has_mean_xyz) */
+    const void* edit_device;       /* internal (frame loop): the edit parameters already on the device; NULL for callers */
+    float enc_scale[3];            /* power-of-two prescales of enc / enc_palette / enc_clip in the split-fp16 path (0 or 1 = none) */
 } pnr_palette_field_args;
-int pnr_palette_field_stages_aux(uint32_t aux_stride, int pred_clip);   /* 1 when the field kernel stages aux rows in LDS (then it can composite them) */
-uint64_t pnr_palette_field_packed_bytes(int pred_clip);
+int pnr_palette_field_stages_aux(uint32_t num_basis, uint32_t clip_dim, int pred_clip);   /* 1 when the field kernel stages aux rows in LDS (then it can composite them) */
+uint64_t pnr_palette_field_packed_bytes(uint32_t num_basis, uint32_t clip_dim, int pred_clip);
 uint32_t pnr_palette_aux_channels(uint32_t num_basis, uint32_t clip_dim);   /* 6 + 7 nb + clip_dim rounded up to a multiple of 4 */
 int pnr_palette_field_pack(const pnr_palette_weights* weights, void* packed, pnr_stream_t stream);
 int pnr_palette_field_forward(const pnr_palette_field_args* args, pnr_stream_t stream);

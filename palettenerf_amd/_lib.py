@@ -41,11 +41,11 @@ SIGNATURES = {
     "pnr_grid_encode_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _u32, _ptr, _ptr, _u32, _int, _int, _ptr],
     "pnr_nerf_field_packed_bytes": [],
     "pnr_nerf_field_pack": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _int, _ptr],
-    "pnr_nerf_field_forward": [_ptr, _ptr, _ptr, _u32, _ptr, _ptr, _int, _ptr],
-    "pnr_nerf_density_forward": [_ptr, _ptr, _u32, _f32, _ptr, _ptr, _int, _ptr],
+    "pnr_nerf_field_forward": [_ptr, _ptr, _ptr, _u32, _ptr, _ptr, _int, _f32, _ptr],
+    "pnr_nerf_density_forward": [_ptr, _ptr, _u32, _f32, _ptr, _ptr, _int, _f32, _ptr],
     "pnr_nerf_frame_workspace_bytes": [_u32],
     "pnr_nerf_render_frame": [_ptr, _ptr],
-    "pnr_palette_field_packed_bytes": [_int],
+    "pnr_palette_field_packed_bytes": [_u32, _u32, _int],
     "pnr_palette_aux_channels": [_u32, _u32],
     "pnr_palette_field_pack": [_ptr, _ptr, _ptr],
     "pnr_palette_field_forward": [_ptr, _ptr],
@@ -68,7 +68,7 @@ SIGNATURES = {
     "pnr_mlp_forward_lm": [_ptr, _ptr, _ptr, _u32, _ptr, _u32, _ptr, _ptr],
     "pnr_mlp_backward_lm": [_ptr, _ptr, _ptr, _u32, _ptr, _ptr, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _ptr],
     "pnr_linear_bgrad": [_ptr, _int, _u32, _u32, _ptr, _int, _ptr, _u64, _ptr],
-    "pnr_palette_field_stages_aux": [_u32, _int],
+    "pnr_palette_field_stages_aux": [_u32, _u32, _int],
     "pnr_interleave_tables": [_ptr, _ptr, _u64, _ptr, _ptr],
     "pnr_interleave_tables3": [_ptr, _ptr, _ptr, _u64, _ptr, _ptr],
     "pnr_palette_train_shade_workspace_bytes": [_u32],
@@ -92,19 +92,30 @@ class NerfFrameArgs(ctypes.Structure):
                 ("C", _u32), ("H", _u32), ("dt_gamma", _f32), ("max_steps", _u32), ("T_thresh", _f32), ("embeddings", _ptr), ("offsets", _ptr),
                 ("num_levels", _u32), ("S", _f32), ("base_resolution", _u32), ("gridtype", _u32), ("packed_weights", _ptr), ("field_precision", _int), ("density_scale", _f32),
                 ("weights_sum", _ptr), ("depth", _ptr), ("image", _ptr), ("workspace", _ptr), ("workspace_bytes", _u64), ("stats", _ptr), ("kernel_ms", _ptr), ("ray_order", _ptr),
-                ("finish", _int), ("bg_color", _f32 * 3), ("bg_map", _ptr), ("table_dtype", _int)]
+                ("finish", _int), ("bg_color", _f32 * 3), ("bg_map", _ptr), ("table_dtype", _int), ("enc_scale", _f32 * 3)]
+
+
+MAX_BASIS, MAX_CLIP = 10, 32   # PNR_MAX_BASIS, PNR_MAX_CLIP
+
+
+class PaletteEdit(ctypes.Structure):
+    """Mirror of `pnr_palette_edit` (include/pnr.h)."""
+    _fields_ = [("mode", _int), ("delta_hsv", (_f32 * 3) * MAX_BASIS), ("has_mean_xyz", _int), ("mean_xyz", _f32 * 3), ("std_xyz", _f32),
+                ("has_mean_clip", _int), ("mean_clip", _f32 * MAX_CLIP), ("std_clip", _f32), ("weight_mode", _int),
+                ("dI", _f32 * MAX_BASIS), ("dP", (_f32 * 3) * MAX_BASIS), ("ddelta", ((_f32 * 3) * 3) * MAX_BASIS)]
 
 
 class PaletteFrameArgs(ctypes.Structure):
     """Mirror of `pnr_palette_frame_args` (include/pnr.h)."""
     _fields_ = [("base", NerfFrameArgs), ("embeddings_palette", _ptr), ("embeddings_clip", _ptr), ("basis_color", _ptr), ("or_bias", _ptr),
-                ("num_basis", _u32), ("clip_dim", _u32), ("pred_clip", _int), ("offsets_weight", _f32), ("view_dep_weight", _f32), ("aux_map", _ptr), ("embeddings_pair", _ptr), ("embeddings_triple", _ptr)]
+                ("num_basis", _u32), ("clip_dim", _u32), ("pred_clip", _int), ("offsets_weight", _f32), ("view_dep_weight", _f32), ("aux_map", _ptr), ("embeddings_pair", _ptr), ("embeddings_triple", _ptr),
+                ("edit", _ptr)]
 
 
 class PaletteWeights(ctypes.Structure):
     """Mirror of `pnr_palette_weights` (include/pnr.h)."""
     _fields_ = [(n, _ptr) for n in ("sigma0", "sigma1", "diff0", "diff1", "diff2", "color0", "color1", "color2", "basis0", "basis1",
-                                    "offsets_radiance", "omega", "clip0", "clip1")] + [("num_basis", _u32), ("clip_dim", _u32), ("pred_clip", _int)]
+                                    "offsets_radiance", "omega", "clip0", "clip1")] + [("num_basis", _u32), ("clip_dim", _u32), ("pred_clip", _int), ("precision", _int)]
 
 
 class PaletteFieldArgs(ctypes.Structure):
@@ -112,7 +123,8 @@ class PaletteFieldArgs(ctypes.Structure):
     _fields_ = [("ctl", _ptr), ("B", _u32), ("enc", _ptr), ("enc_palette", _ptr), ("enc_clip", _ptr), ("level_stride", _u32), ("dirs", _ptr),
                 ("deltas", _ptr), ("packed", _ptr), ("basis_color", _ptr), ("or_bias", _ptr), ("num_basis", _u32), ("clip_dim", _u32),
                 ("pred_clip", _int), ("density_scale", _f32), ("offsets_weight", _f32), ("view_dep_weight", _f32), ("aux_stride", _u32),
-                ("sigmas", _ptr), ("rgbs", _ptr), ("aux", _ptr), ("rays_alive", _ptr), ("weights_sum", _ptr), ("aux_map", _ptr), ("T_thresh", _f32)]
+                ("sigmas", _ptr), ("rgbs", _ptr), ("aux", _ptr), ("rays_alive", _ptr), ("weights_sum", _ptr), ("aux_map", _ptr), ("T_thresh", _f32),
+                ("precision", _int), ("edit", _ptr), ("xyzs", _ptr), ("edit_device", _ptr), ("enc_scale", _f32 * 3)]
 
 
 _lib = None

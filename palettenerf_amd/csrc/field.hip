@@ -82,7 +82,7 @@ constexpr int kFieldThreads = 512;  // 8 waves x 32 samples = 256 samples per wo
 template <int PREC>
 __global__ void __launch_bounds__(kFieldThreads) k_nerf_field_fwd(const float* __restrict__ enc /* [16][B][2] */, const float* __restrict__ dirs /* [B][3] */,
                                                                   const float* __restrict__ packed, uint32_t B, float* __restrict__ sigmas,
-                                                                  float* __restrict__ rgbs) {
+                                                                  float* __restrict__ rgbs, float enc_scale) {
     __shared__ float w[kPackedFloats];
     for (int i = threadIdx.x * 4; i < kPackedFloats; i += kFieldThreads * 4)
         *reinterpret_cast<float4*>(&w[i]) = *reinterpret_cast<const float4*>(&packed[i]);
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(kFieldThreads) k_nerf_field_fwd(const float* _
         const bool valid = n < B;
         const uint32_t nc = valid ? n : (B - 1);
         const float dx = dirs[(size_t)nc * 3], dy = dirs[(size_t)nc * 3 + 1], dz = dirs[(size_t)nc * 3 + 2];
-        const FieldOut o = nerf_field_tile<PREC>(w, lane, valid, enc, B, nc, dx, dy, dz);
+        const FieldOut o = nerf_field_tile<PREC>(w, lane, valid, enc, B, nc, dx, dy, dz, enc_scale);
         if (valid && h == 0) {
             sigmas[n] = expf(o.sigma_logit);                      // trunc_exp forward (activation.py:9)
             rgbs[(size_t)n * 3] = 1.0f / (1.0f + expf(-o.o0));    // sigmoid (nerf/network.py:122)
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(kFieldThreads) k_nerf_field_fwd(const float* _
 // both models take).  Only the first 16 KiB (fp32) / 8 blocks (f16x3) of the packed blob are read.
 template <int PREC>
 __global__ void __launch_bounds__(kFieldThreads) k_nerf_density_fwd(const float* __restrict__ enc /* [16][B][2] */, const float* __restrict__ packed, uint32_t B,
-                                                                    float scale, float* __restrict__ sigmas, float* __restrict__ geo) {
+                                                                    float scale, float* __restrict__ sigmas, float* __restrict__ geo, float enc_scale) {
     constexpr int kFloats = PREC == 0 ? kC0 : 8 * kF16BlockBytes / 4;
     __shared__ float w[kFloats];
     for (int i = threadIdx.x * 4; i < kFloats; i += kFieldThreads * 4)
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(kFieldThreads) k_nerf_density_fwd(const float*
         const uint32_t n = tile * 256 + wave * 32 + (lane & 31);
         const bool valid = n < B;
         const uint32_t nc = valid ? n : (B - 1);
-        const f32x16 g = nerf_density_tile<PREC>(w, lane, valid, enc, B, nc);
+        const f32x16 g = nerf_density_tile<PREC>(w, lane, valid, enc, B, nc, enc_scale);
         if (!valid) continue;
         if (h == 0) sigmas[n] = scale * expf(g[0]);   // trunc_exp forward (activation.py:9), times the caller's density_scale (1 = plain sigma)
         if (geo) {
@@ -156,30 +156,32 @@ int pnr_nerf_field_pack(const float* w_sigma0, const float* w_sigma1, const floa
 }
 
 int pnr_nerf_field_forward(const float* enc, const float* dirs, const float* packed, uint32_t B, float* sigmas, float* rgbs, int precision,
-                           pnr_stream_t stream) {
+                           float enc_scale, pnr_stream_t stream) {
+    if (!(enc_scale > 0.0f)) enc_scale = 1.0f;
     if (precision != PNR_FIELD_FP32 && precision != PNR_FIELD_F16X3) return PNR_ERR_UNSUPPORTED;
     if (B == 0) return PNR_OK;
     if (!enc || !dirs || !packed || !sigmas || !rgbs) return PNR_ERR_INVALID;
     const uint32_t ntiles = cdiv(B, 256);
     const uint32_t grid = ntiles < 512u ? ntiles : 512u;  // 2 persistent workgroups per CU
     if (precision == PNR_FIELD_FP32)
-        hipLaunchKernelGGL(k_nerf_field_fwd<0>, dim3(grid), dim3(kFieldThreads), 0, as_stream(stream), enc, dirs, packed, B, sigmas, rgbs);
+        hipLaunchKernelGGL(k_nerf_field_fwd<0>, dim3(grid), dim3(kFieldThreads), 0, as_stream(stream), enc, dirs, packed, B, sigmas, rgbs, enc_scale);
     else
-        hipLaunchKernelGGL(k_nerf_field_fwd<1>, dim3(grid), dim3(kFieldThreads), 0, as_stream(stream), enc, dirs, packed, B, sigmas, rgbs);
+        hipLaunchKernelGGL(k_nerf_field_fwd<1>, dim3(grid), dim3(kFieldThreads), 0, as_stream(stream), enc, dirs, packed, B, sigmas, rgbs, enc_scale);
     return check_launch();
 }
 
 int pnr_nerf_density_forward(const float* enc, const float* packed, uint32_t B, float scale, float* sigmas, float* geo_feat, int precision,
-                             pnr_stream_t stream) {
+                             float enc_scale, pnr_stream_t stream) {
+    if (!(enc_scale > 0.0f)) enc_scale = 1.0f;
     if (precision != PNR_FIELD_FP32 && precision != PNR_FIELD_F16X3) return PNR_ERR_UNSUPPORTED;
     if (B == 0) return PNR_OK;
     if (!enc || !packed || !sigmas) return PNR_ERR_INVALID;
     const uint32_t ntiles = cdiv(B, 256);
     const uint32_t grid = ntiles < 1024u ? ntiles : 1024u;
     if (precision == PNR_FIELD_FP32)
-        hipLaunchKernelGGL(k_nerf_density_fwd<0>, dim3(grid), dim3(kFieldThreads), 0, as_stream(stream), enc, packed, B, scale, sigmas, geo_feat);
+        hipLaunchKernelGGL(k_nerf_density_fwd<0>, dim3(grid), dim3(kFieldThreads), 0, as_stream(stream), enc, packed, B, scale, sigmas, geo_feat, enc_scale);
     else
-        hipLaunchKernelGGL(k_nerf_density_fwd<1>, dim3(grid), dim3(kFieldThreads), 0, as_stream(stream), enc, packed, B, scale, sigmas, geo_feat);
+        hipLaunchKernelGGL(k_nerf_density_fwd<1>, dim3(grid), dim3(kFieldThreads), 0, as_stream(stream), enc, packed, B, scale, sigmas, geo_feat, enc_scale);
     return check_launch();
 }
 

@@ -102,11 +102,49 @@ __device__ __forceinline__ f32x16 mma3(f32x16 acc, const unsigned char* __restri
     return acc;
 }
 
+// ------------------------------------------------------------------------------------------
+// One K = 16 weight block against one group of 8 activations per lane-half, in either arithmetic -- the PaletteNeRF field is written
+// once over this interface.  A block is 2 KiB in both layouts: split-fp16 [hi: 64 lanes x 8 halfs][lo: same], or fp32 [8 steps][64 lanes]
+// where step j multiplies the activation v[j] of the lane-half: the same (row, column) pairs meet in both, only the number format of
+// the products differs (fp32 here: v_mfma_f32_32x32x2_f32, exact fp32 products and sums).
+// ------------------------------------------------------------------------------------------
+template <int PREC> struct BOp;
+template <> struct BOp<1> { h8 hi, lo; };
+template <> struct BOp<0> { float v[8]; };
+
+template <int PREC> __device__ __forceinline__ BOp<PREC> make_op(const float v[8]) {
+    BOp<PREC> o;
+    if constexpr (PREC == 1) split8(v, o.hi, o.lo);
+    else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) o.v[j] = v[j];
+    }
+    return o;
+}
+template <int PREC> __device__ __forceinline__ BOp<PREC> frag_op(const f32x16& a, int half_idx) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = a[half_idx * 8 + j];
+    return make_op<PREC>(v);
+}
+template <int PREC> __device__ __forceinline__ f32x16 mma_blk(f32x16 acc, const unsigned char* __restrict__ wblock, const BOp<PREC>& b, int lane) {
+    if constexpr (PREC == 1) return mma3(acc, wblock, b.hi, b.lo, lane);
+    else {
+        const float* w = reinterpret_cast<const float*>(wblock);
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j * 64 + lane], b.v[j], acc, 0, 0, 0);
+        return acc;
+    }
+}
+
 struct FieldOut { float sigma_logit, o0, o1, o2; };
 
 // One wave-tile (32 samples) of the NeRF field, split-fp16 matrix path.  w: the 48 KiB blob in LDS.
+// enc_scale: a power of two (1 = none) the encoder features are multiplied by before they are split into fp16 pairs, and sigma_net's 16
+// outputs divided by afterwards -- exact, since the bias-free ReLU stack is positively homogeneous.  It keeps the `lo` halves of very small
+// features (hash tables at the reference's initialisation scale U(-1e-4, 1e-4), gridencoder/grid.py:107) out of the fp16 subnormal range.
 __device__ __forceinline__ FieldOut nerf_field_tile_f16x3(const unsigned char* __restrict__ w, int lane, bool valid, const float* __restrict__ enc,
-                                                          size_t level_stride, uint32_t row, float dx, float dy, float dz) {
+                                                          size_t level_stride, uint32_t row, float dx, float dy, float dz, float enc_scale) {
     const int h = lane >> 5;
     h8 bh[4], bl[4];
     {   // sigma_net[0] inputs: k-block kb, element j  <-  encoder feature 16 kb + 8 h + j  = (level 8 kb + 4 h + j/2, channel j&1)
@@ -119,6 +157,10 @@ __device__ __forceinline__ FieldOut nerf_field_tile_f16x3(const unsigned char* _
                 const float2 v = valid ? *reinterpret_cast<const float2*>(enc + ((size_t)level * level_stride + row) * 2) : make_float2(0.0f, 0.0f);
                 x[kb][2 * q] = v.x; x[kb][2 * q + 1] = v.y;
             }
+        if (enc_scale != 1.0f) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) { x[0][j] *= enc_scale; x[1][j] *= enc_scale; }
+        }
         split8(x[0], bh[0], bl[0]);
         split8(x[1], bh[1], bl[1]);
     }
@@ -137,6 +179,11 @@ __device__ __forceinline__ FieldOut nerf_field_tile_f16x3(const unsigned char* _
 #pragma unroll
     for (int kb = 0; kb < 4; kb++) g = mma3(g, w + (4 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
     __builtin_amdgcn_sched_barrier(0);
+    if (enc_scale != 1.0f) {
+        const float inv = 1.0f / enc_scale;
+#pragma unroll
+        for (int r = 0; r < 8; r++) g[r] *= inv;   // rows 0..15 live in registers 0..7 of both half-waves
+    }
     FieldOut out;
     out.sigma_logit = g[0];
 
@@ -238,7 +285,7 @@ __device__ __forceinline__ FieldOut nerf_field_tile_f32(const float* __restrict_
 // (row frag_row(r, h): logit = row 0, geo feature k = row k).  Same arithmetic as the first half of the field tiles above.
 template <int PREC>
 __device__ __forceinline__ f32x16 nerf_density_tile(const float* __restrict__ wf, int lane, bool valid, const float* __restrict__ enc, size_t level_stride,
-                                                    uint32_t row) {
+                                                    uint32_t row, float enc_scale = 1.0f) {
     const int h = lane >> 5;
     f32x16 h0 = zero16(), h1 = zero16(), g = zero16();
     if constexpr (PREC == 0) {
@@ -266,6 +313,10 @@ __device__ __forceinline__ f32x16 nerf_density_tile(const float* __restrict__ wf
                 const float2 v = valid ? *reinterpret_cast<const float2*>(enc + ((size_t)level * level_stride + row) * 2) : make_float2(0.0f, 0.0f);
                 x[kb][2 * q] = v.x; x[kb][2 * q + 1] = v.y;
             }
+        if (enc_scale != 1.0f) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) { x[0][j] *= enc_scale; x[1][j] *= enc_scale; }
+        }
         split8(x[0], bh[0], bl[0]);
         split8(x[1], bh[1], bl[1]);
         h0 = mma3(h0, w + 0 * kF16BlockBytes, bh[0], bl[0], lane);
@@ -278,15 +329,20 @@ __device__ __forceinline__ f32x16 nerf_density_tile(const float* __restrict__ wf
         split_frag(h1, 0, bh[2], bl[2]); split_frag(h1, 1, bh[3], bl[3]);
 #pragma unroll
         for (int kb = 0; kb < 4; kb++) g = mma3(g, w + (4 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
+        if (enc_scale != 1.0f) {
+            const float inv = 1.0f / enc_scale;
+#pragma unroll
+            for (int r = 0; r < 8; r++) g[r] *= inv;
+        }
     }
     return g;
 }
 
 template <int PREC>
 __device__ __forceinline__ FieldOut nerf_field_tile(const float* __restrict__ w, int lane, bool valid, const float* __restrict__ enc,
-                                                    size_t level_stride, uint32_t row, float dx, float dy, float dz) {
-    if constexpr (PREC == 0) return nerf_field_tile_f32(w, lane, valid, enc, level_stride, row, dx, dy, dz);
-    else return nerf_field_tile_f16x3(reinterpret_cast<const unsigned char*>(w), lane, valid, enc, level_stride, row, dx, dy, dz);
+                                                    size_t level_stride, uint32_t row, float dx, float dy, float dz, float enc_scale = 1.0f) {
+    if constexpr (PREC == 0) return nerf_field_tile_f32(w, lane, valid, enc, level_stride, row, dx, dy, dz);   // exact fp32: no scaling needed
+    else return nerf_field_tile_f16x3(reinterpret_cast<const unsigned char*>(w), lane, valid, enc, level_stride, row, dx, dy, dz, enc_scale);
 }
 
 }  // namespace pnr

@@ -18,6 +18,10 @@
 #include <vector>
 #include <stdlib.h>
 
+// palette_field.hip (internal): device image of the edit parameters
+uint64_t pnr_internal_edit_device_bytes();
+int pnr_internal_edit_upload(const pnr_palette_edit* edit, void* dst, hipStream_t s);
+
 namespace pnr {
 
 struct FrameCtl {  // 64 bytes, two copies ping-ponged by iteration parity
@@ -83,7 +87,7 @@ __device__ __forceinline__ float finish_depth(const FrameFinish& f, float d, uin
     return fmaxf(d - f.nears[ray], 0.0f) / (f.fars[ray] - f.nears[ray]);
 }
 
-template <uint32_t LANES>   // lanes per ray: 16 with an aux row to move (float4 each), 4 without
+template <uint32_t LANES>   // lanes per ray: 16 (32 for rows of more than 64 floats) with an aux row to move (float4 each), 4 without
 __global__ void __launch_bounds__(kRayBlock) k_frame_unsort_outputs(uint32_t N, const int32_t* __restrict__ order, const float* __restrict__ sws,
                                                                     const float* __restrict__ sdepth, const float* __restrict__ simage,
                                                                     const float* __restrict__ saux, uint32_t aux_stride, float* __restrict__ ws,
@@ -526,7 +530,7 @@ constexpr int kFieldThreads = 512;
 template <int PREC>
 __global__ void __launch_bounds__(kFieldThreads) k_frame_field(const FrameCtl* __restrict__ ctl, const float* __restrict__ enc, uint32_t level_stride,
                                                                const float* __restrict__ dirs, const float* __restrict__ deltas,
-                                                               const float* __restrict__ packed, float density_scale, float* __restrict__ sigmas,
+                                                               const float* __restrict__ packed, float density_scale, float enc_scale, float* __restrict__ sigmas,
                                                                float* __restrict__ rgbs, int fuse_one_step, float T_thresh, int32_t* __restrict__ rays_alive,
                                                                float* __restrict__ rays_t, float* __restrict__ weights_sum, float* __restrict__ depth,
                                                                float* __restrict__ image, int32_t* __restrict__ scratch) {
@@ -550,7 +554,7 @@ __global__ void __launch_bounds__(kFieldThreads) k_frame_field(const FrameCtl* _
             const uint32_t nc = n < B ? n : (B - 1);
             float dx = 0.0f, dy = 0.0f, dz = 0.0f;
             if (valid) { dx = dirs[(size_t)nc * 3]; dy = dirs[(size_t)nc * 3 + 1]; dz = dirs[(size_t)nc * 3 + 2]; }
-            o = nerf_field_tile<PREC>(w, lane, valid, enc, level_stride, nc, dx, dy, dz);
+            o = nerf_field_tile<PREC>(w, lane, valid, enc, level_stride, nc, dx, dy, dz, enc_scale);
         }
         float sigma = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
         if (valid && h == 0) {
@@ -691,6 +695,7 @@ struct FrameWorkspace {
     int32_t* alive[2];
     float *rays_t, *xyzs, *dirs, *deltas, *enc, *sigmas, *rgbs;
     float *enc_pal, *enc_clip, *aux;  // palette model only
+    void* edit;                       // palette model only: device image of the edit parameters
     float *s_o, *s_d, *s_near, *s_far, *s_ws, *s_depth, *s_image, *s_aux;  // ray_order: inputs / outputs in processing order
     int32_t* scratch;
     int32_t* partials[2];   // the march's per-workgroup sample counts: written by iteration i, summed by iteration i + 1
@@ -715,7 +720,9 @@ static FrameWorkspace carve(void* base, uint32_t N, uint32_t aux_stride = 0, boo
     w.partials[0] = reinterpret_cast<int32_t*>(take(2048 * 4));
     w.partials[1] = reinterpret_cast<int32_t*>(take(2048 * 4));
     w.enc_pal = w.enc_clip = w.aux = nullptr;
+    w.edit = nullptr;
     if (aux_stride) {
+        w.edit = take(pnr_internal_edit_device_bytes());
         w.enc_pal = reinterpret_cast<float*>(take(n * 16 * 2 * 4));
         if (with_clip) w.enc_clip = reinterpret_cast<float*>(take(n * 16 * 2 * 4));
         w.aux = reinterpret_cast<float*>(take(n * aux_stride * 4));
@@ -762,7 +769,8 @@ int pnr_nerf_render_frame(const pnr_nerf_frame_args* a, pnr_stream_t stream) { r
 
 int pnr_palette_render_frame(const pnr_palette_frame_args* p, pnr_stream_t stream) {
     if (!p) return PNR_ERR_INVALID;
-    if (p->num_basis < 1 || p->num_basis > 5 || p->clip_dim > 16) return PNR_ERR_UNSUPPORTED;
+    if (p->num_basis < 1 || p->num_basis > PNR_MAX_BASIS || p->clip_dim > PNR_MAX_CLIP) return PNR_ERR_UNSUPPORTED;
+    if (p->edit && (p->edit->mode < 0 || p->edit->mode > 2)) return PNR_ERR_UNSUPPORTED;
     if (p->base.N && (!p->embeddings_palette || !p->basis_color || !p->or_bias || !p->aux_map || (p->pred_clip && !p->embeddings_clip))) return PNR_ERR_INVALID;
     return render_frame_impl(&p->base, p, stream);
 }
@@ -775,7 +783,6 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
         return PNR_ERR_INVALID;
     if (a->C == 0 || a->C > 16 || a->H == 0 || a->max_steps == 0 || a->num_levels != 16) return PNR_ERR_UNSUPPORTED;
     if (a->field_precision != PNR_FIELD_FP32 && a->field_precision != PNR_FIELD_F16X3) return PNR_ERR_UNSUPPORTED;
-    if (pal && a->field_precision != PNR_FIELD_F16X3) return PNR_ERR_UNSUPPORTED;
     const uint32_t aux_stride = pal ? pnr_palette_aux_channels(pal->num_basis, pal->clip_dim) : 0;
     const bool with_clip = pal && pal->pred_clip;
     hipStream_t s = as_stream(stream);
@@ -797,7 +804,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     gs.table[1] = pal ? pal->embeddings_palette : nullptr; gs.enc[1] = w.enc_pal;
     gs.table[2] = with_clip ? pal->embeddings_clip : nullptr; gs.enc[2] = w.enc_clip;
     const uint32_t n_enc = pal ? (with_clip ? 3u : 2u) : 1u;
-    const int aux_fused = (pal && g_opt_aux_fusion && pnr_palette_field_stages_aux(aux_stride, pal->pred_clip)) ? 1 : 0;
+    const int aux_fused = (pal && g_opt_aux_fusion && pnr_palette_field_stages_aux(pal->num_basis, pal->clip_dim, pal->pred_clip)) ? 1 : 0;
     const int composite_fused = (!pal && g_opt_composite_fusion) ? 1 : 0;   // NeRF: one-sample-per-ray iterations are composited inside the field kernel
     const bool half_tables = a->table_dtype == PNR_DTYPE_F16;   // fp16 tables: nerf = `embeddings` as halves; palette = embeddings_pair as interleaved halves
     if (half_tables && pal && (with_clip || !pal->embeddings_pair)) return PNR_ERR_UNSUPPORTED;
@@ -810,6 +817,13 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
         pf.packed = a->packed_weights; pf.basis_color = pal->basis_color; pf.or_bias = pal->or_bias; pf.num_basis = pal->num_basis;
         pf.clip_dim = pal->clip_dim; pf.pred_clip = pal->pred_clip; pf.density_scale = a->density_scale; pf.offsets_weight = pal->offsets_weight;
         pf.view_dep_weight = pal->view_dep_weight; pf.aux_stride = aux_stride; pf.sigmas = w.sigmas; pf.rgbs = w.rgbs; pf.aux = w.aux;
+        pf.precision = a->field_precision; pf.xyzs = w.xyzs;
+        for (int k = 0; k < 3; k++) pf.enc_scale[k] = a->enc_scale[k];
+        if (pal->edit && pal->edit->mode != 0) {   // RegionEdit / Stylizer: parameters uploaded once for the whole frame
+            const int rc = pnr_internal_edit_upload(pal->edit, w.edit, s);
+            if (rc != PNR_OK) return rc;
+            pf.edit = pal->edit; pf.edit_device = w.edit;
+        }
     }
 
     // per host thread AND per device (a process may drive several GPUs): the pinned read-back slot, the timing events and the iteration
@@ -820,6 +834,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     FrameCtl*& host_ctl = dev_state.host_ctl;  // one in-flight frame per host thread and device
     if (!host_ctl && hipHostMalloc(reinterpret_cast<void**>(&host_ctl), sizeof(FrameCtl), hipHostMallocPortable) != hipSuccess) return PNR_ERR_LAUNCH;
 
+    const float enc_scale = a->enc_scale[0] > 0.0f ? a->enc_scale[0] : 1.0f;
     const bool use_mip = a->mip && (a->H % 4) == 0 && pnr_occupancy_mip_bytes(a->C, a->H) <= 64 * 1024;
     const bool pow2 = is_pow2f(a->bound) && (a->H & (a->H - 1)) == 0;
     const MarchParams mp = make_march_params(a->bound, a->dt_gamma, a->max_steps, a->C, a->H, use_mip);
@@ -894,11 +909,11 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
                 if (rc != PNR_OK) return rc;
             } else if (a->field_precision == PNR_FIELD_FP32)
                 hipLaunchKernelGGL(k_frame_field<0>, dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas,
-                                   a->packed_weights, a->density_scale, w.sigmas, w.rgbs, composite_fused, a->T_thresh, alive_in, w.rays_t, out_ws, out_depth,
+                                   a->packed_weights, a->density_scale, enc_scale, w.sigmas, w.rgbs, composite_fused, a->T_thresh, alive_in, w.rays_t, out_ws, out_depth,
                                    out_image, w.scratch);
             else
                 hipLaunchKernelGGL(k_frame_field<1>, dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas,
-                                   a->packed_weights, a->density_scale, w.sigmas, w.rgbs, composite_fused, a->T_thresh, alive_in, w.rays_t, out_ws, out_depth,
+                                   a->packed_weights, a->density_scale, enc_scale, w.sigmas, w.rgbs, composite_fused, a->T_thresh, alive_in, w.rays_t, out_ws, out_depth,
                                    out_image, w.scratch);
             hipLaunchKernelGGL(k_frame_composite, gm, bm, 0, s, cur, a->T_thresh, alive_in, w.rays_t, w.sigmas, w.rgbs, w.deltas, out_ws, out_depth, out_image,
                                w.scratch, (const float*)w.aux, out_aux, aux_stride, aux_fused, composite_fused);
@@ -915,7 +930,10 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     FrameFinish fin;
     fin.on = a->finish; fin.bg[0] = a->bg_color[0]; fin.bg[1] = a->bg_color[1]; fin.bg[2] = a->bg_color[2];
     fin.bg_map = a->bg_map; fin.nears = a->nears; fin.fars = a->fars;   // indexed by ray id
-    if (sorted && pal)
+    if (sorted && pal && aux_stride > 64)
+        hipLaunchKernelGGL(k_frame_unsort_outputs<32>, dim3(cdiv(N, kRayBlock / 32)), dim3(kRayBlock), 0, s, N, a->ray_order, w.s_ws, w.s_depth, w.s_image,
+                           w.s_aux, aux_stride, a->weights_sum, a->depth, a->image, pal->aux_map, fin);
+    else if (sorted && pal)
         hipLaunchKernelGGL(k_frame_unsort_outputs<16>, dim3(cdiv(N * 16, kRayBlock)), dim3(kRayBlock), 0, s, N, a->ray_order, w.s_ws, w.s_depth, w.s_image,
                            w.s_aux, aux_stride, a->weights_sum, a->depth, a->image, pal->aux_map, fin);
     else if (sorted)

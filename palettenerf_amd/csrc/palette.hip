@@ -2,38 +2,24 @@
 // Follows the reference's palette extension (palette/src/palette.cu:45-133): H in [0,360),
 // S and V in percent, equality test |a-b| < 1e-9, branch order r, g, b.
 #include "pnr_common.hpp"
+#include "hsv_core.hpp"
 
 namespace pnr {
 
 __global__ void __launch_bounds__(256) k_rgb_to_hsv(uint32_t n, const float* __restrict__ input, float* __restrict__ output) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float r = input[i * 3], g = input[i * 3 + 1], b = input[i * 3 + 2];
-    const float c_max = fmaxf(fmaxf(r, g), b), c_min = fminf(fminf(r, g), b), diff = c_max - c_min;
-    float h, s;
-    if ((double)fabsf(diff) < 1e-9) h = 0.0f;
-    else if ((double)fabsf(c_max - r) < 1e-9) h = (float)fmod((double)(60.0f * ((g - b) / diff) + 360.0f), 360.0);
-    else if ((double)fabsf(c_max - g) < 1e-9) h = (float)fmod((double)(60.0f * ((b - r) / diff) + 120.0f), 360.0);
-    else h = (float)fmod((double)(60.0f * ((r - g) / diff) + 240.0f), 360.0);
-    if ((double)fabsf(c_max) < 1e-9) s = 0.0f; else s = (diff / c_max) * 100.0f;
-    output[i * 3] = h; output[i * 3 + 1] = s; output[i * 3 + 2] = c_max * 100.0f;
+    float h, s, v;
+    rgb_to_hsv_px(input[i * 3], input[i * 3 + 1], input[i * 3 + 2], h, s, v);
+    output[i * 3] = h; output[i * 3 + 1] = s; output[i * 3 + 2] = v;
 }
 
 __global__ void __launch_bounds__(256) k_hsv_to_rgb(uint32_t n, const float* __restrict__ input, float* __restrict__ output) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float h = input[i * 3], s = input[i * 3 + 1], v = input[i * 3 + 2];
-    const float c = s / 100.0f * v / 100.0f;
-    const float x = c * (1.0f - fabsf((float)fmod((double)(h / 60.0f), 2.0) - 1.0f));
-    const float m = v / 100.0f - c;
-    float r = 0.0f, g = 0.0f, b = 0.0f;
-    if (h >= 0.0f && h < 60.0f) { r = c; g = x; }
-    else if (h >= 60.0f && h < 120.0f) { r = x; g = c; }
-    else if (h >= 120.0f && h < 180.0f) { g = c; b = x; }
-    else if (h >= 180.0f && h < 240.0f) { g = x; b = c; }
-    else if (h >= 240.0f && h < 300.0f) { r = x; b = c; }
-    else { r = c; b = x; }
-    output[i * 3] = r + m; output[i * 3 + 1] = g + m; output[i * 3 + 2] = b + m;
+    float r, g, b;
+    hsv_to_rgb_px(input[i * 3], input[i * 3 + 1], input[i * 3 + 2], r, g, b);
+    output[i * 3] = r; output[i * 3 + 1] = g; output[i * 3 + 2] = b;
 }
 
 // weighted RGB histogram (reference: CPU C++ compute_RGB_histogram, palette/src/bindings.cpp:40-91).

@@ -9,29 +9,37 @@
 //   p      = basis_net([enc_palette ; diff])      35 -> 64 (ELU) -> 15
 //   o_r    = offsets_radiance_net(p)              15 -> 3 nb + 1 (with bias)
 //   omega  = normalise(softplus(omega_net(p)) + 0.05)                  15 -> nb
-//   final_b = softplus(radiance) * (clamp(P_b,0,1) + k_off * offset_b) ; basis_rgb_b = omega_b * final_b
-//   rgb    = sum_b basis_rgb_b + k_vd * vd
+//   final_b = softplus(radiance) * (clamp(P_b,0,1) + k_off * offset_b) ; [RegionEdit] ; basis_rgb_b = omega_b * final_b
+//   rgb    = sum_b basis_rgb_b + k_vd * vd                              (or the Stylizer's closed form)
 // Outputs: sigma * density_scale, rgb, and ONE packed auxiliary row
 //   aux = [direct_rgb 3 | view_dep 3 | omega nb | basis_rgb 3nb | unscaled_basis_rgb 3nb | clip clip_dim | 0-pad to x4]
 // so that the reference's six composite_rays_flex launches collapse into a single one over the packed row.
 //
-// Matrix path: split-fp16 (field_core.hpp), activations chained through the register file exactly as in the NeRF
-// kernel: 50 (58 with clip) K=16 blocks of 2 KiB in LDS, 3 MFMAs each.  Layers whose outputs feed scalar math
-// (rgb heads, offsets/radiance, omega, clip) place their rows in the lower half-wave so no cross-lane traffic is needed.
+// Matrix path: written once over field_core.hpp's block interface, instantiated for split-fp16 (3 MFMAs per K = 16 block) and exact
+// fp32 (8 v_mfma_f32_32x32x2_f32 per block); activations are chained through the register file exactly as in the NeRF kernel.
+// 50 blocks of 2 KiB in LDS for up to 5 palette bases without a clip head; +1 block for 6..10 bases (offsets_radiance then has up to
+// 31 outputs: a second tile), +8 with the clip head (+4 more for clip_dim > 16).  Layers whose outputs feed scalar math (rgb heads,
+// offsets/radiance, omega, clip) place their rows in the lower half-wave so no cross-lane traffic is needed.
 #include "pnr_common.hpp"
 #include "field_core.hpp"
+#include "hsv_core.hpp"
+#include <string.h>
 
 namespace pnr {
 
 // ---- block table -------------------------------------------------------------------------------------------------
 enum { COL_LINEAR = 0, COL_FRAG = 1, COL_SH_GEO = 2, COL_GEO = 3, COL_ENC_DIFF = 4, COL_FRAG15 = 5 };
-enum { ROW_ID = 0, ROW_HALF0 = 1 };
+enum { ROW_ID = 0, ROW_HALF0 = 1, ROW_HALF0_B = 2 };   // HALF0_B: output rows 16..31 in the lower half-wave's 16 slots (a second tile)
 // first block of every layer
 enum {
     PB_S0 = 0, PB_S1 = 4, PB_D0 = 8, PB_D1 = 10, PB_D2 = 18, PB_C0 = 22, PB_C1 = 26, PB_C2 = 34, PB_B0 = 38, PB_B1 = 44, PB_OR = 48, PB_OM = 49,
-    PB_CL0 = 50, PB_CL1 = 54, PB_END_NOCLIP = 50, PB_END_CLIP = 58
+    PB_OR2 = 50, PB_CL0 = 51, PB_CL1 = 55, PB_CL1B = 59, PB_END = 63
 };
-constexpr int kPalMaxBlocks = 58;
+constexpr int kPalMaxBlocks = PB_END;
+// blocks a model shape needs (= what is packed and staged in LDS)
+__host__ __device__ constexpr int pal_blocks(int nb, int clip_dim, int pred_clip) {
+    return pred_clip ? (clip_dim > 16 ? PB_END : PB_CL1B) : (nb > 5 ? PB_CL0 : PB_OR2);
+}
 
 struct PackBlock { const float* W; int ld, nrows, rt, colkind, kb, rowkind; };
 struct PackTable { PackBlock b[kPalMaxBlocks]; int n; };
@@ -50,20 +58,28 @@ __device__ __forceinline__ int pack_col(int kind, int kb, int h, int j) {
     }
 }
 
-__global__ void __launch_bounds__(256) k_pack_blocks_f16x3(PackTable t, unsigned char* __restrict__ packed) {
+// PREC 1: block = [hi: 64 lanes x 8 halfs][lo: same]; PREC 0: block = [8 steps][64 lanes] fp32 (field_core.hpp: mma_blk)
+template <int PREC>
+__global__ void __launch_bounds__(256) k_pack_blocks(PackTable t, unsigned char* __restrict__ packed) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= t.n * 512) return;
     const int q = e / 512, lane = (e / 8) & 63, j = e & 7, i = lane & 31, h = lane >> 5;
     const PackBlock b = t.b[q];
-    const int row = b.rowkind == ROW_ID ? b.rt * 32 + i : half0_slot(i);
+    int row = b.rt * 32 + i;
+    if (b.rowkind == ROW_HALF0) row = half0_slot(i);
+    else if (b.rowkind == ROW_HALF0_B) row = half0_slot(i) < 0 ? -1 : 16 + half0_slot(i);
     const int col = pack_col(b.colkind, b.kb, h, j);
     float v = 0.0f;
-    if (row >= 0 && row < b.nrows && col >= 0 && col < b.ld) v = b.W[(size_t)row * b.ld + col];
-    const _Float16 hi = (_Float16)v;
-    const _Float16 lo = (_Float16)(v - (float)hi);
-    _Float16* blk = reinterpret_cast<_Float16*>(packed + (size_t)q * kF16BlockBytes);
-    blk[lane * 8 + j] = hi;
-    blk[512 + lane * 8 + j] = lo;
+    if (b.W && row >= 0 && row < b.nrows && col >= 0 && col < b.ld) v = b.W[(size_t)row * b.ld + col];   // W == NULL: block unused by this shape (zeros)
+    if constexpr (PREC == 1) {
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        _Float16* blk = reinterpret_cast<_Float16*>(packed + (size_t)q * kF16BlockBytes);
+        blk[lane * 8 + j] = hi;
+        blk[512 + lane * 8 + j] = lo;
+    } else {
+        reinterpret_cast<float*>(packed + (size_t)q * kF16BlockBytes)[j * 64 + lane] = v;
+    }
 }
 
 // ---- device helpers ----------------------------------------------------------------------------------------------
@@ -90,28 +106,42 @@ __device__ __forceinline__ void load_enc_raw(const float* __restrict__ enc, size
             x[kb][2 * q] = v.x; x[kb][2 * q + 1] = v.y;
         }
 }
-__device__ __forceinline__ void load_enc_blocks(const float* __restrict__ enc, size_t level_stride, uint32_t row, bool valid, int h, h8 bh[2], h8 bl[2]) {
-    float x[2][8];
-    load_enc_raw(enc, level_stride, row, valid, h, x);
-    split8(x[0], bh[0], bl[0]);
-    split8(x[1], bh[1], bl[1]);
-}
 // 64 -> N layer from two activation tiles: 4 k-blocks starting at block q0
+template <int PREC>
 __device__ __forceinline__ f32x16 dense64(f32x16 acc, const unsigned char* __restrict__ w, int q0, const f32x16& a0, const f32x16& a1, int lane) {
-    h8 bh, bl;
-    split_frag(a0, 0, bh, bl); acc = mma3(acc, w + (q0 + 0) * kF16BlockBytes, bh, bl, lane);
-    split_frag(a0, 1, bh, bl); acc = mma3(acc, w + (q0 + 1) * kF16BlockBytes, bh, bl, lane);
-    split_frag(a1, 0, bh, bl); acc = mma3(acc, w + (q0 + 2) * kF16BlockBytes, bh, bl, lane);
-    split_frag(a1, 1, bh, bl); acc = mma3(acc, w + (q0 + 3) * kF16BlockBytes, bh, bl, lane);
+    acc = mma_blk<PREC>(acc, w + (q0 + 0) * kF16BlockBytes, frag_op<PREC>(a0, 0), lane);
+    acc = mma_blk<PREC>(acc, w + (q0 + 1) * kF16BlockBytes, frag_op<PREC>(a0, 1), lane);
+    acc = mma_blk<PREC>(acc, w + (q0 + 2) * kF16BlockBytes, frag_op<PREC>(a1, 0), lane);
+    acc = mma_blk<PREC>(acc, w + (q0 + 3) * kF16BlockBytes, frag_op<PREC>(a1, 1), lane);
     __builtin_amdgcn_sched_barrier(0);
     return acc;
 }
 
+__device__ __forceinline__ void scale8x2(float x[2][8], float s) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) { x[0][j] *= s; x[1][j] *= s; }
+}
+__device__ __forceinline__ f32x16 scale16(f32x16 v, float s) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] *= s;
+    return v;
+}
+
+constexpr int kMaxNb = PNR_MAX_BASIS;
 struct PaletteParams {
-    float basis_color[5][3];   // already clamped to [0,1]
-    float or_bias[16];         // offsets_radiance_net.bias (3 nb + 1 entries)
+    float basis_color[kMaxNb][3];   // already clamped to [0,1]
+    float or_bias[32];              // offsets_radiance_net.bias (3 nb + 1 entries)
     float density_scale, offsets_weight, view_dep_weight;
     int nb, clip_dim, pred_clip, aux_stride;
+    float enc_scale[3];             // power-of-two prescales of enc / enc_palette / enc_clip (split-fp16 path only; 1 = none)
+};
+// RegionEdit / Stylizer parameters (pnr_palette_edit) as the kernel reads them from device memory
+struct EditParams {
+    float delta_hsv[kMaxNb][3];
+    float mean_xyz[3], std_xyz;
+    float mean_clip[PNR_MAX_CLIP], std_clip;
+    int has_mean_xyz, has_mean_clip, weight_mode;
+    float dI[kMaxNb], dP[kMaxNb][3], ddelta[kMaxNb][3][3];
 };
 
 constexpr int kPalThreads = 512;
@@ -120,6 +150,12 @@ constexpr int kPalThreads = 512;
 // dead slots (delta == 0) are skipped.
 struct FrameCtlView { int32_t n_alive, n_step, step, done; };
 
+// torch.lerp(start, end, weight) for fp32 (ATen/native/Lerp.h): the branch keeps both ends exact
+__device__ __forceinline__ float torch_lerp(float a, float b, float w) { const float d = b - a; return w < 0.5f ? a + w * d : b - d * (1.0f - w); }
+
+// EDIT: 0 plain composite, 1 RegionEdit, 2 Stylizer (pnr_palette_edit.mode); separate instantiations keep the HSV / double-fmod code
+// and the extra parameters out of the plain kernel
+template <int PREC, int EDIT>
 __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCtlView* __restrict__ ctl, uint32_t B_arg, const float* __restrict__ enc,
                                                                    const float* __restrict__ enc_pal, const float* __restrict__ enc_clip,
                                                                    uint32_t level_stride, const float* __restrict__ dirs,
@@ -127,7 +163,8 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
                                                                    uint32_t packed_bytes, PaletteParams pp, float* __restrict__ sigmas,
                                                                    float* __restrict__ rgbs, float* __restrict__ aux, uint32_t stage_stride,
                                                                    const int32_t* __restrict__ rays_alive, const float* __restrict__ weights_sum,
-                                                                   float* __restrict__ aux_map, float T_thresh) {
+                                                                   float* __restrict__ aux_map, float T_thresh, const float* __restrict__ xyzs,
+                                                                   const EditParams* __restrict__ ep) {
     if (ctl && ctl->done) return;
     const uint32_t B = ctl ? (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step : B_arg;
     const uint32_t ntiles = (B + 255) / 256;
@@ -147,7 +184,6 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
         const bool valid = n < B && (!deltas || deltas[(size_t)(n < B ? n : 0) * 2] != 0.0f);
         if (!__any(valid)) continue;
         const uint32_t row = n < B ? n : (B - 1);
-        h8 bh[2], bl[2];
 
         // all global reads of the tile up front
         float xs[2][8], xp[2][8];
@@ -156,30 +192,33 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
         float dx = 0.0f, dy = 0.0f, dz = 0.0f;
         if (valid) { dx = dirs[(size_t)row * 3]; dy = dirs[(size_t)row * 3 + 1]; dz = dirs[(size_t)row * 3 + 2]; }
 
-        // ---------------- sigma_net
-        split8(xs[0], bh[0], bl[0]);
-        split8(xs[1], bh[1], bl[1]);
+        // ---------------- sigma_net (prescaled by a power of two when the table's entries are tiny: undone exactly on its 16 outputs)
+        const bool pre_s = PREC == 1 && pp.enc_scale[0] != 1.0f, pre_p = PREC == 1 && pp.enc_scale[1] != 1.0f, pre_c = PREC == 1 && pp.enc_scale[2] != 1.0f;
+        if (pre_s) scale8x2(xs, pp.enc_scale[0]);
         f32x16 t0 = zero16(), t1 = zero16();
-        t0 = mma3(t0, w + (PB_S0 + 0) * kF16BlockBytes, bh[0], bl[0], lane);
-        t0 = mma3(t0, w + (PB_S0 + 1) * kF16BlockBytes, bh[1], bl[1], lane);
-        t1 = mma3(t1, w + (PB_S0 + 2) * kF16BlockBytes, bh[0], bl[0], lane);
-        t1 = mma3(t1, w + (PB_S0 + 3) * kF16BlockBytes, bh[1], bl[1], lane);
+        {
+            const BOp<PREC> b0 = make_op<PREC>(xs[0]), b1 = make_op<PREC>(xs[1]);
+            t0 = mma_blk<PREC>(t0, w + (PB_S0 + 0) * kF16BlockBytes, b0, lane);
+            t0 = mma_blk<PREC>(t0, w + (PB_S0 + 1) * kF16BlockBytes, b1, lane);
+            t1 = mma_blk<PREC>(t1, w + (PB_S0 + 2) * kF16BlockBytes, b0, lane);
+            t1 = mma_blk<PREC>(t1, w + (PB_S0 + 3) * kF16BlockBytes, b1, lane);
+        }
         __builtin_amdgcn_sched_barrier(0);
         t0 = relu16(t0); t1 = relu16(t1);
-        const f32x16 g = dense64(zero16(), w, PB_S1, t0, t1, lane);   // rows 0..15: sigma logit, geo_feat 1..15
+        f32x16 g = dense64<PREC>(zero16(), w, PB_S1, t0, t1, lane);   // rows 0..15: sigma logit, geo_feat 1..15
+        if (pre_s) g = scale16(g, 1.0f / pp.enc_scale[0]);
         const float sigma_logit = g[0];
-        h8 gh, gl;
-        split_frag(g, 0, gh, gl);                                      // the geo k-block, shared by diff_net and color_net
+        const BOp<PREC> geo = frag_op<PREC>(g, 0);                           // the geo k-block, shared by diff_net and color_net
 
         // ---------------- diff_net: 15 -> 64 -> 64 -> 3
-        t0 = mma3(zero16(), w + (PB_D0 + 0) * kF16BlockBytes, gh, gl, lane);
-        t1 = mma3(zero16(), w + (PB_D0 + 1) * kF16BlockBytes, gh, gl, lane);
+        t0 = mma_blk<PREC>(zero16(), w + (PB_D0 + 0) * kF16BlockBytes, geo, lane);
+        t1 = mma_blk<PREC>(zero16(), w + (PB_D0 + 1) * kF16BlockBytes, geo, lane);
         __builtin_amdgcn_sched_barrier(0);
         t0 = relu16(t0); t1 = relu16(t1);
-        f32x16 u0 = dense64(zero16(), w, PB_D1, t0, t1, lane);
-        f32x16 u1 = dense64(zero16(), w, PB_D1 + 4, t0, t1, lane);
+        f32x16 u0 = dense64<PREC>(zero16(), w, PB_D1, t0, t1, lane);
+        f32x16 u1 = dense64<PREC>(zero16(), w, PB_D1 + 4, t0, t1, lane);
         u0 = relu16(u0); u1 = relu16(u1);
-        f32x16 dif = dense64(zero16(), w, PB_D2, u0, u1, lane);        // rows 0..2
+        const f32x16 dif = dense64<PREC>(zero16(), w, PB_D2, u0, u1, lane);  // rows 0..2
         const float diffuse[3] = {sigmoidf(dif[0]), sigmoidf(dif[1]), sigmoidf(dif[2])};
 
         // ---------------- color_net (view dependent): [SH16 ; geo15] -> 64 -> 64 -> 3
@@ -188,69 +227,80 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
             sh_eval<4>(dx, dy, dz, sh);
 #pragma unroll
             for (int j = 0; j < 8; j++) v[j] = select_half(h, sh[j], sh[8 + j]);
-            split8(v, bh[0], bl[0]);
+            const BOp<PREC> shb = make_op<PREC>(v);
+            t0 = mma_blk<PREC>(zero16(), w + (PB_C0 + 0) * kF16BlockBytes, shb, lane);
+            t0 = mma_blk<PREC>(t0, w + (PB_C0 + 1) * kF16BlockBytes, geo, lane);
+            t1 = mma_blk<PREC>(zero16(), w + (PB_C0 + 2) * kF16BlockBytes, shb, lane);
+            t1 = mma_blk<PREC>(t1, w + (PB_C0 + 3) * kF16BlockBytes, geo, lane);
         }
-        t0 = mma3(zero16(), w + (PB_C0 + 0) * kF16BlockBytes, bh[0], bl[0], lane);
-        t0 = mma3(t0, w + (PB_C0 + 1) * kF16BlockBytes, gh, gl, lane);
-        t1 = mma3(zero16(), w + (PB_C0 + 2) * kF16BlockBytes, bh[0], bl[0], lane);
-        t1 = mma3(t1, w + (PB_C0 + 3) * kF16BlockBytes, gh, gl, lane);
         __builtin_amdgcn_sched_barrier(0);
         t0 = relu16(t0); t1 = relu16(t1);
-        u0 = dense64(zero16(), w, PB_C1, t0, t1, lane);
-        u1 = dense64(zero16(), w, PB_C1 + 4, t0, t1, lane);
+        u0 = dense64<PREC>(zero16(), w, PB_C1, t0, t1, lane);
+        u1 = dense64<PREC>(zero16(), w, PB_C1 + 4, t0, t1, lane);
         u0 = relu16(u0); u1 = relu16(u1);
-        const f32x16 vdt = dense64(zero16(), w, PB_C2, u0, u1, lane);
+        const f32x16 vdt = dense64<PREC>(zero16(), w, PB_C2, u0, u1, lane);
         const float view_dep[3] = {sigmoidf(vdt[0]), sigmoidf(vdt[1]), sigmoidf(vdt[2])};
 
         // ---------------- basis_net: [enc_palette(32) ; diffuse(3)] -> 64 (ELU) -> 15
-        split8(xp[0], bh[0], bl[0]);
-        split8(xp[1], bh[1], bl[1]);
-        h8 dh, dl;
         {
-            float v[8] = {diffuse[0], diffuse[1], diffuse[2], 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // read by the lower half-wave only (zero weights elsewhere)
-            split8(v, dh, dl);
+            const float ps = pre_p ? pp.enc_scale[1] : 1.0f;   // the whole 35-wide input row is scaled; the ELU needs the true pre-activations back
+            if (pre_p) scale8x2(xp, ps);
+            const BOp<PREC> b0 = make_op<PREC>(xp[0]), b1 = make_op<PREC>(xp[1]);
+            const float v[8] = {diffuse[0] * ps, diffuse[1] * ps, diffuse[2] * ps, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // read by the lower half-wave only (zero weights elsewhere)
+            const BOp<PREC> db = make_op<PREC>(v);
+            t0 = mma_blk<PREC>(zero16(), w + (PB_B0 + 0) * kF16BlockBytes, b0, lane);
+            t0 = mma_blk<PREC>(t0, w + (PB_B0 + 1) * kF16BlockBytes, b1, lane);
+            t0 = mma_blk<PREC>(t0, w + (PB_B0 + 2) * kF16BlockBytes, db, lane);
+            t1 = mma_blk<PREC>(zero16(), w + (PB_B0 + 3) * kF16BlockBytes, b0, lane);
+            t1 = mma_blk<PREC>(t1, w + (PB_B0 + 4) * kF16BlockBytes, b1, lane);
+            t1 = mma_blk<PREC>(t1, w + (PB_B0 + 5) * kF16BlockBytes, db, lane);
         }
-        t0 = mma3(zero16(), w + (PB_B0 + 0) * kF16BlockBytes, bh[0], bl[0], lane);
-        t0 = mma3(t0, w + (PB_B0 + 1) * kF16BlockBytes, bh[1], bl[1], lane);
-        t0 = mma3(t0, w + (PB_B0 + 2) * kF16BlockBytes, dh, dl, lane);
-        t1 = mma3(zero16(), w + (PB_B0 + 3) * kF16BlockBytes, bh[0], bl[0], lane);
-        t1 = mma3(t1, w + (PB_B0 + 4) * kF16BlockBytes, bh[1], bl[1], lane);
-        t1 = mma3(t1, w + (PB_B0 + 5) * kF16BlockBytes, dh, dl, lane);
         __builtin_amdgcn_sched_barrier(0);
+        if (pre_p) { t0 = scale16(t0, 1.0f / pp.enc_scale[1]); t1 = scale16(t1, 1.0f / pp.enc_scale[1]); }
         t0 = elu16(t0); t1 = elu16(t1);
-        const f32x16 p = dense64(zero16(), w, PB_B1, t0, t1, lane);   // rows 0..14
+        const f32x16 p = dense64<PREC>(zero16(), w, PB_B1, t0, t1, lane);   // rows 0..14
 
-        // ---------------- offsets_radiance_net (bias) and omega_net, rows placed in the lower half-wave
-        h8 ph, pl;
-        split_frag(p, 0, ph, pl);
-        f32x16 orr = zero16();
+        // ---------------- offsets_radiance_net (bias) and omega_net, rows placed in the lower half-wave (outputs 16.. in a second tile)
+        const BOp<PREC> pb = frag_op<PREC>(p, 0);
+        f32x16 orr = zero16(), orr2 = zero16();
         if (h == 0) {
 #pragma unroll
-            for (int j = 0; j < 16; j++) orr[j] = pp.or_bias[j];
+            for (int j = 0; j < 16; j++) { orr[j] = pp.or_bias[j]; orr2[j] = pp.or_bias[16 + j]; }
         }
-        orr = mma3(orr, w + PB_OR * kF16BlockBytes, ph, pl, lane);
-        const f32x16 om = mma3(zero16(), w + PB_OM * kF16BlockBytes, ph, pl, lane);
+        orr = mma_blk<PREC>(orr, w + PB_OR * kF16BlockBytes, pb, lane);
+        if (nb > 5) orr2 = mma_blk<PREC>(orr2, w + PB_OR2 * kF16BlockBytes, pb, lane);
+        const f32x16 om = mma_blk<PREC>(zero16(), w + PB_OM * kF16BlockBytes, pb, lane);
         __builtin_amdgcn_sched_barrier(0);
 
         // ---------------- clip_net (optional): 32 -> 64 -> clip_dim, output rows in the lower half-wave
-        f32x16 clip = zero16();
+        f32x16 clip = zero16(), clip2 = zero16();
         if (pp.pred_clip) {
-            load_enc_blocks(enc_clip, level_stride, row, valid, h, bh, bl);
-            t0 = mma3(zero16(), w + (PB_CL0 + 0) * kF16BlockBytes, bh[0], bl[0], lane);
-            t0 = mma3(t0, w + (PB_CL0 + 1) * kF16BlockBytes, bh[1], bl[1], lane);
-            t1 = mma3(zero16(), w + (PB_CL0 + 2) * kF16BlockBytes, bh[0], bl[0], lane);
-            t1 = mma3(t1, w + (PB_CL0 + 3) * kF16BlockBytes, bh[1], bl[1], lane);
+            float xc[2][8];
+            load_enc_raw(enc_clip, level_stride, row, valid, h, xc);
+            if (pre_c) scale8x2(xc, pp.enc_scale[2]);
+            const BOp<PREC> b0 = make_op<PREC>(xc[0]), b1 = make_op<PREC>(xc[1]);
+            t0 = mma_blk<PREC>(zero16(), w + (PB_CL0 + 0) * kF16BlockBytes, b0, lane);
+            t0 = mma_blk<PREC>(t0, w + (PB_CL0 + 1) * kF16BlockBytes, b1, lane);
+            t1 = mma_blk<PREC>(zero16(), w + (PB_CL0 + 2) * kF16BlockBytes, b0, lane);
+            t1 = mma_blk<PREC>(t1, w + (PB_CL0 + 3) * kF16BlockBytes, b1, lane);
             __builtin_amdgcn_sched_barrier(0);
             t0 = relu16(t0); t1 = relu16(t1);
-            clip = dense64(zero16(), w, PB_CL1, t0, t1, lane);
+            clip = dense64<PREC>(zero16(), w, PB_CL1, t0, t1, lane);
+            if (pp.clip_dim > 16) clip2 = dense64<PREC>(zero16(), w, PB_CL1B, t0, t1, lane);
+            if (pre_c) { clip = scale16(clip, 1.0f / pp.enc_scale[2]); clip2 = scale16(clip2, 1.0f / pp.enc_scale[2]); }
         }
 
         // ---------------- scalar epilogue on the lower half-wave: the palette colour-basis composite
         if (valid && h == 0) {
-            float omega[5], osum = 0.0f;
+            float omega[kMaxNb], osum = 0.0f;
 #pragma unroll
-            for (int b = 0; b < 5; b++) if (b < nb) { omega[b] = softplusf(om[b]) + 0.05f; osum += omega[b]; }
-            const float sp = softplusf(orr[3 * nb]);  // radiance is the LAST of the 3 nb + 1 outputs (palette/renderer.py:471)
+            for (int b = 0; b < kMaxNb; b++) if (b < nb) { omega[b] = softplusf(om[b]) + 0.05f; osum += omega[b]; }
+            // offsets_radiance outputs by index (compile-time after unrolling); radiance is the LAST of the 3 nb + 1 outputs (palette/renderer.py:471)
+            auto orv = [&](int idx) -> float { return idx < 16 ? orr[idx & 15] : orr2[idx & 15]; };
+            float radiance = 0.0f;
+#pragma unroll
+            for (int b = 1; b <= kMaxNb; b++) if (nb == b) radiance = orv(3 * b);
+            const float sp = softplusf(radiance);
             float rgb[3] = {0.0f, 0.0f, 0.0f};
             // aux row: straight to global (one 4-byte store per channel and lane, rows aux_stride apart), or -- when the LDS has room --
             // into this wave's staging slab, from where the whole 32-row tile (contiguous in memory) goes out as 16-byte stores
@@ -259,28 +309,74 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
 #pragma unroll
             for (int k = 0; k < 3; k++) { a[k] = diffuse[k] + view_dep[k]; a[3 + k] = view_dep[k]; }   // direct_rgb, view_dep_rgb
 #pragma unroll
-            for (int b = 0; b < 5; b++) if (b < nb) { omega[b] = omega[b] / osum; a[6 + b] = omega[b]; }
+            for (int b = 0; b < kMaxNb; b++) if (b < nb) { omega[b] = omega[b] / osum; a[6 + b] = omega[b]; }
+            float edit_w = 1.0f;
+            if constexpr (EDIT == 1) {   // RegionEdit's window (palette/renderer.py:126-134)
+                if (ep->has_mean_xyz) {
+                    float d2 = 0.0f;
 #pragma unroll
-            for (int b = 0; b < 5; b++) if (b < nb) {
+                    for (int k = 0; k < 3; k++) { const float d = xyzs[(size_t)n * 3 + k] - ep->mean_xyz[k]; d2 += d * d; }
+                    edit_w *= expf(-d2 / ep->std_xyz);
+                }
+                if (ep->has_mean_clip) {
+                    float d2 = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < PNR_MAX_CLIP; k++) if (k < ep->has_mean_clip) {   // without a clip head clip_feat is zeros (palette/network.py:179)
+                        const float c = (pp.pred_clip && k < pp.clip_dim) ? (k < 16 ? clip[k & 15] : clip2[k & 15]) : 0.0f;
+                        const float d = c - ep->mean_clip[k];
+                        d2 += d * d;
+                    }
+                    edit_w *= expf(-d2 / ep->std_clip);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < kMaxNb; b++) if (b < nb) {
+                float fin[3], off[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) off[k] = orv(3 * b + k);
+                if constexpr (EDIT == 2) {   // Stylizer.forward (palette/renderer.py:166-183)
+                    const float inten = fmaxf(sp + ep->dI[b], 0.0f);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        float o2 = 0.0f;
+#pragma unroll
+                        for (int i = 0; i < 3; i++) o2 = fmaf(off[i], ep->ddelta[b][i][k], o2);
+                        fin[k] = fminf(fmaxf(inten * ((pp.basis_color[b][k] + ep->dP[b][k]) + o2), 0.0f), 1.0f);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) fin[k] = sp * (pp.basis_color[b][k] + pp.offsets_weight * off[k]);
+                }
+                if constexpr (EDIT == 1) {   // RegionEdit.forward (palette/renderer.py:121-147)
+                    if (ep->weight_mode) { fin[0] = fin[1] = fin[2] = edit_w; }
+                    else {
+                        float hh, ss, vv, er, eg, eb;
+                        rgb_to_hsv_px(fin[0], fin[1], fin[2], hh, ss, vv);
+                        hh = fmodf((hh + ep->delta_hsv[b][0]) + 360.0f, 360.0f);
+                        ss = fmaxf(ss * ep->delta_hsv[b][1], 0.0f);
+                        vv = fmaxf(vv * ep->delta_hsv[b][2], 0.0f);
+                        hsv_to_rgb_px(hh, ss, vv, er, eg, eb);
+                        fin[0] = torch_lerp(fin[0], er, edit_w); fin[1] = torch_lerp(fin[1], eg, edit_w); fin[2] = torch_lerp(fin[2], eb, edit_w);
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
-                    const float off = orr[3 * b + k];
-                    const float fin = sp * (pp.basis_color[b][k] + pp.offsets_weight * off);
-                    const float brgb = omega[b] * fin;
+                    const float brgb = omega[b] * fin[k];
                     rgb[k] += brgb;
                     a[6 + nb + 3 * b + k] = brgb;                                    // basis_rgb
-                    a[6 + 4 * nb + 3 * b + k] = pp.basis_color[b][k] + off;          // unscaled_basis_rgb
+                    a[6 + 4 * nb + 3 * b + k] = pp.basis_color[b][k] + off[k];       // unscaled_basis_rgb
                 }
             }
             int c = 6 + 7 * nb;
 #pragma unroll
-            for (int k = 0; k < 16; k++) if (k < pp.clip_dim) a[c + k] = pp.pred_clip ? clip[k] : 0.0f;
+            for (int k = 0; k < PNR_MAX_CLIP; k++) if (k < pp.clip_dim) a[c + k] = pp.pred_clip ? (k < 16 ? clip[k & 15] : clip2[k & 15]) : 0.0f;
             for (c += pp.clip_dim; c < pp.aux_stride; c++) a[c] = 0.0f;
             const float sigma = pp.density_scale * __expf(sigma_logit);
             sigmas[n] = sigma;
             if (fuse_composite) a[pp.aux_stride] = 1.0f - __expf(-sigma * deltas[(size_t)n * 2]);   // alpha, exactly as k_frame_composite forms it
+            const float kvd = EDIT == 2 ? 1.0f : pp.view_dep_weight;   // the Stylizer adds view_dep unscaled (palette/renderer.py:181)
 #pragma unroll
-            for (int k = 0; k < 3; k++) rgbs[(size_t)n * 3 + k] = rgb[k] + pp.view_dep_weight * view_dep[k];
+            for (int k = 0; k < 3; k++) rgbs[(size_t)n * 3 + k] = rgb[k] + kvd * view_dep[k];
         }
         if (stage_stride) {   // same wave wrote the slab: DS operations of a wave complete in order
             float* slab = reinterpret_cast<float*>(w + packed_bytes) + (size_t)wave * 32 * stage_stride;
@@ -341,19 +437,50 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
 
 using namespace pnr;
 
+namespace {
+// device copy of the edit parameters: a small ring of slots per device, so that launches in flight keep their own
+constexpr int kEditSlots = 64;
+struct EditRing { EditParams* dev = nullptr; EditParams* host = nullptr; int next = 0; };
+EditRing g_edit_ring[kMaxDevices];
+
+bool shape_ok(uint32_t nb, uint32_t clip_dim) { return nb >= 1 && nb <= PNR_MAX_BASIS && clip_dim <= PNR_MAX_CLIP; }
+
+void fill_edit(EditParams& e, const pnr_palette_edit& src) {
+    memset(&e, 0, sizeof(e));
+    memcpy(e.delta_hsv, src.delta_hsv, sizeof(e.delta_hsv));
+    memcpy(e.mean_xyz, src.mean_xyz, sizeof(e.mean_xyz));
+    memcpy(e.mean_clip, src.mean_clip, sizeof(e.mean_clip));
+    e.std_xyz = src.std_xyz; e.std_clip = src.std_clip;
+    e.has_mean_xyz = src.has_mean_xyz; e.has_mean_clip = src.has_mean_clip; e.weight_mode = src.weight_mode;
+    memcpy(e.dI, src.dI, sizeof(e.dI)); memcpy(e.dP, src.dP, sizeof(e.dP)); memcpy(e.ddelta, src.ddelta, sizeof(e.ddelta));
+}
+}  // namespace
+
+// internal (frame.hip): the device image of a pnr_palette_edit, uploaded once per frame into the frame workspace
+uint64_t pnr_internal_edit_device_bytes() { return sizeof(EditParams); }
+int pnr_internal_edit_upload(const pnr_palette_edit* edit, void* dst, hipStream_t s) {
+    EditParams e;
+    fill_edit(e, *edit);
+    return hipMemcpyAsync(dst, &e, sizeof(e), hipMemcpyHostToDevice, s) == hipSuccess ? PNR_OK : PNR_ERR_LAUNCH;   // pageable source: staged before the call returns
+}
+
 extern "C" {
 
-uint64_t pnr_palette_field_packed_bytes(int pred_clip) { return (uint64_t)(pred_clip ? PB_END_CLIP : PB_END_NOCLIP) * kF16BlockBytes; }
+uint64_t pnr_palette_field_packed_bytes(uint32_t num_basis, uint32_t clip_dim, int pred_clip) {
+    return (uint64_t)pal_blocks((int)num_basis, (int)clip_dim, pred_clip ? 1 : 0) * kF16BlockBytes;
+}
 uint32_t pnr_palette_aux_channels(uint32_t num_basis, uint32_t clip_dim) { return (6 + 7 * num_basis + clip_dim + 3) & ~3u; }
 
 int pnr_palette_field_pack(const pnr_palette_weights* pw, void* packed, pnr_stream_t stream) {
     if (!pw || !packed) return PNR_ERR_INVALID;
-    if (pw->num_basis < 1 || pw->num_basis > 5 || pw->clip_dim > 16) return PNR_ERR_UNSUPPORTED;
+    if (!shape_ok(pw->num_basis, pw->clip_dim)) return PNR_ERR_UNSUPPORTED;
+    if (pw->precision != PNR_FIELD_FP32 && pw->precision != PNR_FIELD_F16X3) return PNR_ERR_UNSUPPORTED;
     if (!pw->sigma0 || !pw->sigma1 || !pw->diff0 || !pw->diff1 || !pw->diff2 || !pw->color0 || !pw->color1 || !pw->color2 || !pw->basis0 || !pw->basis1 ||
         !pw->offsets_radiance || !pw->omega)
         return PNR_ERR_INVALID;
     if (pw->pred_clip && (!pw->clip0 || !pw->clip1)) return PNR_ERR_INVALID;
     PackTable t;
+    for (int i = 0; i < kPalMaxBlocks; i++) t.b[i] = PackBlock{nullptr, 0, 0, 0, 0, 0, 0};
     int q = 0;
     auto add = [&](const float* W, int ld, int nrows, int nrt, int nkb, int colkind, int rowkind) {
         for (int rt = 0; rt < nrt; rt++)
@@ -372,48 +499,87 @@ int pnr_palette_field_pack(const pnr_palette_weights* pw, void* packed, pnr_stre
     add(pw->basis1, 64, 15, 1, 4, COL_FRAG, ROW_ID);          // PB_B1
     add(pw->offsets_radiance, 15, 3 * nb + 1, 1, 1, COL_FRAG15, ROW_HALF0);  // PB_OR
     add(pw->omega, 15, nb, 1, 1, COL_FRAG15, ROW_HALF0);      // PB_OM
+    add(nb > 5 ? pw->offsets_radiance : nullptr, 15, 3 * nb + 1, 1, 1, COL_FRAG15, ROW_HALF0_B);   // PB_OR2: outputs 16..31 (zeros when unused)
     if (pw->pred_clip) {
         add(pw->clip0, 32, 64, 2, 2, COL_LINEAR, ROW_ID);     // PB_CL0
         add(pw->clip1, 64, (int)pw->clip_dim, 1, 4, COL_FRAG, ROW_HALF0);  // PB_CL1
+        if (pw->clip_dim > 16) add(pw->clip1, 64, (int)pw->clip_dim, 1, 4, COL_FRAG, ROW_HALF0_B);  // PB_CL1B
     }
-    t.n = q;
-    hipLaunchKernelGGL(k_pack_blocks_f16x3, dim3(cdiv((uint32_t)q * 512, 256)), dim3(256), 0, as_stream(stream), t, static_cast<unsigned char*>(packed));
+    t.n = pal_blocks(nb, (int)pw->clip_dim, pw->pred_clip ? 1 : 0);
+    if (q < t.n) return PNR_ERR_INVALID;
+    const dim3 grid(cdiv((uint32_t)t.n * 512, 256));
+    if (pw->precision == PNR_FIELD_F16X3) hipLaunchKernelGGL(k_pack_blocks<1>, grid, dim3(256), 0, as_stream(stream), t, static_cast<unsigned char*>(packed));
+    else hipLaunchKernelGGL(k_pack_blocks<0>, grid, dim3(256), 0, as_stream(stream), t, static_cast<unsigned char*>(packed));
     return check_launch();
 }
 
-int pnr_palette_field_stages_aux(uint32_t aux_stride, int pred_clip) {
-    const uint32_t packed_bytes = (uint32_t)pnr_palette_field_packed_bytes(pred_clip);
-    return (aux_stride & 3u) == 0 && packed_bytes + (kPalThreads / 64) * 32 * (aux_stride + 4) * 4 <= 160 * 1024;
+int pnr_palette_field_stages_aux(uint32_t num_basis, uint32_t clip_dim, int pred_clip) {
+    const uint32_t aux_stride = pnr_palette_aux_channels(num_basis, clip_dim);
+    const uint32_t packed_bytes = (uint32_t)pnr_palette_field_packed_bytes(num_basis, clip_dim, pred_clip);
+    return packed_bytes + (kPalThreads / 64) * 32 * (aux_stride + 4) * 4 <= 160 * 1024;
 }
 
 int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stream) {
     if (!a) return PNR_ERR_INVALID;
-    if (a->num_basis < 1 || a->num_basis > 5 || a->clip_dim > 16) return PNR_ERR_UNSUPPORTED;
-    if (a->aux_stride < 6 + 7 * a->num_basis + a->clip_dim || a->aux_stride > 64) return PNR_ERR_INVALID;
+    if (!shape_ok(a->num_basis, a->clip_dim)) return PNR_ERR_UNSUPPORTED;
+    if (a->precision != PNR_FIELD_FP32 && a->precision != PNR_FIELD_F16X3) return PNR_ERR_UNSUPPORTED;
+    if (a->aux_stride < 6 + 7 * a->num_basis + a->clip_dim || a->aux_stride > PNR_CHANNEL_MAXIMUM || (a->aux_stride & 3u)) return PNR_ERR_INVALID;
     if (a->B == 0 && !a->ctl) return PNR_OK;
     if (!a->enc || !a->enc_palette || !a->dirs || !a->packed || !a->sigmas || !a->rgbs || !a->aux || !a->basis_color || !a->or_bias) return PNR_ERR_INVALID;
     if (a->pred_clip && !a->enc_clip) return PNR_ERR_INVALID;
+    const int edit_mode = a->edit ? a->edit->mode : 0;
+    if (edit_mode < 0 || edit_mode > 2) return PNR_ERR_UNSUPPORTED;
+    if (edit_mode == 1 && a->edit->has_mean_xyz && !a->xyzs) return PNR_ERR_INVALID;
     PaletteParams pp;
-    for (int b = 0; b < 5; b++)
+    for (int b = 0; b < kMaxNb; b++)
         for (int k = 0; k < 3; k++) pp.basis_color[b][k] = b < (int)a->num_basis ? fminf(1.0f, fmaxf(0.0f, a->basis_color[b * 3 + k])) : 0.0f;
-    for (int j = 0; j < 16; j++) pp.or_bias[j] = j < (int)(3 * a->num_basis + 1) ? a->or_bias[j] : 0.0f;
+    for (int j = 0; j < 32; j++) pp.or_bias[j] = j < (int)(3 * a->num_basis + 1) ? a->or_bias[j] : 0.0f;
     pp.density_scale = a->density_scale; pp.offsets_weight = a->offsets_weight; pp.view_dep_weight = a->view_dep_weight;
     pp.nb = (int)a->num_basis; pp.clip_dim = (int)a->clip_dim; pp.pred_clip = a->pred_clip ? 1 : 0; pp.aux_stride = (int)a->aux_stride;
-    const uint32_t packed_bytes = (uint32_t)pnr_palette_field_packed_bytes(pp.pred_clip);
+    for (int k = 0; k < 3; k++) pp.enc_scale[k] = a->enc_scale[k] > 0.0f ? a->enc_scale[k] : 1.0f;
+    const uint32_t packed_bytes = (uint32_t)pnr_palette_field_packed_bytes(a->num_basis, a->clip_dim, pp.pred_clip);
     const uint32_t rows_ub = a->B;
     const uint32_t ntiles = cdiv(rows_ub ? rows_ub : 1, 256);
-    const uint32_t grid = ntiles < 256u ? ntiles : 256u;  // one persistent 512-thread workgroup per CU (100-116 KiB of LDS)
+    const uint32_t grid = ntiles < 256u ? ntiles : 256u;  // one persistent 512-thread workgroup per CU (100-126 KiB of LDS)
     constexpr uint32_t kLdsLimit = 160 * 1024;
-    static bool attr_set[kMaxDevices] = {};
-    if (!ensure_dynamic_lds(k_palette_field_fwd, kLdsLimit, attr_set)) return PNR_ERR_LAUNCH;
     // staging slab for coalesced aux rows: 8 waves x 32 rows x (aux_stride + 4) floats, when it fits next to the weights
-    uint32_t stage_stride = pnr_palette_field_stages_aux(a->aux_stride, pp.pred_clip) ? a->aux_stride + 4 : 0;
+    const bool stages = a->aux_stride == pnr_palette_aux_channels(a->num_basis, a->clip_dim) && pnr_palette_field_stages_aux(a->num_basis, a->clip_dim, pp.pred_clip);
+    const uint32_t stage_stride = stages ? a->aux_stride + 4 : 0;
     const uint32_t lds = packed_bytes + (kPalThreads / 64) * 32 * stage_stride * 4;
     const bool fuse = a->ctl && a->rays_alive && a->weights_sum && a->aux_map;
-    hipLaunchKernelGGL(k_palette_field_fwd, dim3(grid), dim3(kPalThreads), lds, as_stream(stream), static_cast<const FrameCtlView*>(a->ctl), a->B,
-                       a->enc, a->enc_palette, a->enc_clip, a->level_stride, a->dirs, a->deltas, static_cast<const unsigned char*>(a->packed), packed_bytes, pp,
-                       a->sigmas, a->rgbs, a->aux, stage_stride, fuse ? a->rays_alive : nullptr, fuse ? a->weights_sum : nullptr,
-                       fuse ? a->aux_map : nullptr, a->T_thresh);
+    hipStream_t s = as_stream(stream);
+    const EditParams* ep_dev = nullptr;
+    if (edit_mode && a->edit_device) ep_dev = static_cast<const EditParams*>(a->edit_device);   // frame loop: uploaded once per frame
+    else if (edit_mode) {   // this call's parameters go into the next slot of the device's ring (pinned staging copy, async copy on the launch stream)
+        EditRing& ring = g_edit_ring[current_device()];
+        if (!ring.dev) {
+            if (hipMalloc(reinterpret_cast<void**>(&ring.dev), sizeof(EditParams) * kEditSlots) != hipSuccess) return PNR_ERR_LAUNCH;
+            if (hipHostMalloc(reinterpret_cast<void**>(&ring.host), sizeof(EditParams) * kEditSlots, hipHostMallocPortable) != hipSuccess) return PNR_ERR_LAUNCH;
+        }
+        const int slot = ring.next;
+        ring.next = (ring.next + 1) % kEditSlots;
+        EditParams& e = ring.host[slot];
+        const pnr_palette_edit& src = *a->edit;
+        fill_edit(e, src);
+        if (hipMemcpyAsync(ring.dev + slot, &e, sizeof(EditParams), hipMemcpyHostToDevice, s) != hipSuccess) return PNR_ERR_LAUNCH;
+        ep_dev = ring.dev + slot;
+    }
+    static bool attr_set[2][3][kMaxDevices] = {};
+#define PNR_LAUNCH_PAL(PREC, EDIT)                                                                                                             \
+    do {                                                                                                                                       \
+        if (!ensure_dynamic_lds(k_palette_field_fwd<PREC, EDIT>, kLdsLimit, attr_set[PREC][EDIT])) return PNR_ERR_LAUNCH;                      \
+        hipLaunchKernelGGL((k_palette_field_fwd<PREC, EDIT>), dim3(grid), dim3(kPalThreads), lds, s, static_cast<const FrameCtlView*>(a->ctl), \
+                           a->B, a->enc, a->enc_palette, a->enc_clip, a->level_stride, a->dirs, a->deltas,                                     \
+                           static_cast<const unsigned char*>(a->packed), packed_bytes, pp, a->sigmas, a->rgbs, a->aux, stage_stride,           \
+                           fuse ? a->rays_alive : nullptr, fuse ? a->weights_sum : nullptr, fuse ? a->aux_map : nullptr, a->T_thresh, a->xyzs, \
+                           ep_dev);                                                                                                            \
+    } while (0)
+    if (a->precision == PNR_FIELD_F16X3) {
+        if (edit_mode == 0) PNR_LAUNCH_PAL(1, 0); else if (edit_mode == 1) PNR_LAUNCH_PAL(1, 1); else PNR_LAUNCH_PAL(1, 2);
+    } else {
+        if (edit_mode == 0) PNR_LAUNCH_PAL(0, 0); else if (edit_mode == 1) PNR_LAUNCH_PAL(0, 1); else PNR_LAUNCH_PAL(0, 2);
+    }
+#undef PNR_LAUNCH_PAL
     return check_launch();
 }
 

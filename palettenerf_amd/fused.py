@@ -1,6 +1,7 @@
 """MI355X-first fused evaluation of the fields (no reference counterpart as one call): level-major
 hash-grid lookup feeding the MFMA tiny-MLP kernel directly, no permute/copy, no per-layer launches."""
 import ctypes
+import math
 import os
 
 import numpy as np
@@ -69,6 +70,66 @@ def _half_copy(owner, attr, t):
     return cached[1]
 
 
+
+F16X3_SAFE_ACTIVATION = 3.0e4   # fp16 overflows at 65 504: above this bound on any split operand the field runs on the exact fp32 path
+
+
+def _l1(w):
+    """max_j sum_i |W[j][i]|: the factor by which a dense layer can grow the largest |activation|."""
+    return w.detach().abs().sum(dim=1).max()
+
+
+def _prescale_of(table_max):
+    """Power of two that lifts a table's largest |entry| into [0.5, 1) when it is below 1/8 (else 1): below that the `lo` halves of the
+    split features start to fall into fp16's subnormal range (the reference initialises its tables U(-1e-4, 1e-4), gridencoder/grid.py:107)."""
+    if not math.isfinite(table_max) or table_max <= 0.0 or table_max >= 0.125:
+        return 1.0
+    return float(2.0 ** min(14, math.floor(-math.log2(table_max))))
+
+
+class _PrecisionGuard:
+    """What the split-fp16 matrix path needs to be safe for ANY weights: operands are split into two fp16 halves, so
+    (a) very small encoder features lose their low half to the subnormal range -> they are pre-multiplied by a power of two inside the kernel
+        (enc_scale, exact: the first stack is bias-free and positively homogeneous; undone on its outputs);
+    (b) an activation beyond fp16's range becomes inf -> a static bound on every split operand (largest table entry times the layers' L1 row
+        norms) is computed when the blob is (re)packed; if it can exceed F16X3_SAFE_ACTIVATION the call runs on the exact fp32 path instead.
+    `precision` is what the caller asked for; `effective_precision()` is what runs.  A handful of tiny device reductions and ONE host read per
+    repack (never per frame)."""
+
+    def _guard_tables(self):
+        raise NotImplementedError
+
+    def _guard_bound(self, tmax, scales):
+        raise NotImplementedError
+
+    def _guard(self):
+        tables = self._guard_tables()
+        key = tuple(_pkey(w) for w in self._weights()) + tuple(_pkey(t) for t in tables)
+        if getattr(self, "_guard_key", None) != key or PARANOID:
+            tmax = [float(v) for v in torch.stack([t.detach().abs().max().float() for t in tables]).cpu().tolist()]
+            scales = [_prescale_of(v) for v in tmax]
+            bound = float(self._guard_bound(tmax, scales))
+            self._guard_state = (scales + [1.0] * (3 - len(scales)), bound)
+            self._guard_key = key
+        return self._guard_state
+
+    def enc_scales(self):
+        """[s_encoder, s_encoder_palette, s_encoder_clip] for the split-fp16 path (all 1.0 on the fp32 path)."""
+        return self._guard()[0] if self.effective_precision() == 1 else [1.0, 1.0, 1.0]
+
+    def effective_precision(self):
+        if int(self.precision) == 0:
+            return 0
+        bound = self._guard()[1]
+        if not (bound < F16X3_SAFE_ACTIVATION):
+            if not getattr(self, "_warned_fp32", False):
+                self._warned_fp32 = True
+                import warnings
+                warnings.warn(f"fused field: activations may reach {bound:.3g} (> fp16 range): running the exact fp32 matrix path instead of split-fp16")
+            return 0
+        return 1
+
+
 def _set_finish(a, bg_color, N, mask):
     """Fill the finish / bg fields of a frame-args struct; returns True when the call will apply the epilogue."""
     a.finish, a.bg_map = 0, None
@@ -94,7 +155,7 @@ def _set_finish(a, bg_color, N, mask):
     return True
 
 
-class NeRFFieldFused:
+class NeRFFieldFused(_PrecisionGuard):
     """Caches the MFMA-ordered weight blob of a NeRFNetwork and evaluates (sigma, rgb) for sample batches."""
 
     def __init__(self, model):
@@ -117,16 +178,31 @@ class NeRFFieldFused:
     def invalidate_caches(self):
         self.versions = None
         self._emb_half = None
+        self._guard_key = None
+
+    def _guard_tables(self):
+        return [self.model.encoder.embeddings]
+
+    def _guard_bound(self, tmax, scales):
+        ws = self._weights()
+        l1 = [float(v) for v in torch.stack([_l1(w).float() for w in ws]).cpu().tolist()]
+        enc = tmax[0] * scales[0]
+        h1 = l1[0] * enc                                   # sigma_net hidden (in prescaled units)
+        geo = l1[1] * h1 / scales[0]                       # its 16 outputs, descaled
+        c0 = l1[2] * max(1.6, geo)                         # colour net input = [SH (|Y| < 1.6 up to degree 4) ; geo]
+        c1 = l1[3] * c0
+        return max(enc, h1, geo, c0, c1)
 
     def _pack(self):
         ws = self._weights()
-        versions = tuple(_pkey(w) for w in ws) + (self.precision,)
+        prec = self.effective_precision()
+        versions = tuple(_pkey(w) for w in ws) + (prec,)
         if self.packed is None or versions != self.versions or PARANOID:
             dev = ws[0].device
             if self.packed is None or self.packed.device != dev:
                 self.packed = torch.empty(int(_lib.load().pnr_nerf_field_packed_bytes()) // 4, dtype=torch.float32, device=dev)
             ws = [require(w.detach().contiguous(), torch.float32, "weight") for w in ws]
-            call("pnr_nerf_field_pack", *[ptr(w) for w in ws], ptr(self.packed), _int(self.precision))
+            call("pnr_nerf_field_pack", *[ptr(w) for w in ws], ptr(self.packed), _int(prec))
             self.versions = versions
         return self.packed
 
@@ -165,7 +241,9 @@ class NeRFFieldFused:
         a.embeddings, a.offsets = emb.data_ptr(), enc.offsets.data_ptr()
         a.num_levels, a.S, a.base_resolution, a.gridtype = enc.num_levels, float(np.log2(enc.per_level_scale)), enc.base_resolution, enc.gridtype_id
         a.packed_weights = self._pack().data_ptr()
-        a.field_precision = int(self.precision)
+        a.field_precision = int(self.effective_precision())
+        for k, v in enumerate(self.enc_scales()):
+            a.enc_scale[k] = v
         a.density_scale = float(m.density_scale)
         a.weights_sum, a.depth, a.image = ws.data_ptr(), depth.data_ptr(), image.data_ptr()
         a.workspace, a.workspace_bytes = self._ws.data_ptr(), nbytes
@@ -191,7 +269,7 @@ class NeRFFieldFused:
         sigmas = torch.empty(B, dtype=torch.float32, device=x.device)
         rgbs = torch.empty(B, 3, dtype=torch.float32, device=x.device)
         call("pnr_nerf_field_forward", ptr(enc), ptr(require(d.contiguous(), torch.float32, "dirs")), ptr(self._pack()), _u32(B), ptr(sigmas),
-             ptr(rgbs), _int(self.precision), units=B)
+             ptr(rgbs), _int(self.effective_precision()), _f32(self.enc_scales()[0]), units=B)
         return sigmas, rgbs
 
 
@@ -208,7 +286,7 @@ class DensityFused(NeRFFieldFused):
         B = x.shape[0]
         sigmas = torch.empty(B, dtype=torch.float32, device=x.device)
         geo = torch.empty(B, 15, dtype=torch.float32, device=x.device) if want_geo else None
-        call("pnr_nerf_density_forward", ptr(enc), ptr(self._pack()), _u32(B), ctypes.c_float(scale), ptr(sigmas), ptr(geo), _int(self.precision), units=B)
+        call("pnr_nerf_density_forward", ptr(enc), ptr(self._pack()), _u32(B), ctypes.c_float(scale), ptr(sigmas), ptr(geo), _int(self.effective_precision()), _f32(self.enc_scales()[0]), units=B)
         return sigmas, geo
 
 
@@ -220,7 +298,7 @@ def density_fused(model):
     return d
 
 
-class PaletteFieldFused:
+class PaletteFieldFused(_PrecisionGuard):
     """Fused PaletteNeRF field + colour-basis composite (pnr_palette_field_forward).  Produces, per sample,
     sigma * density_scale, rgb and one packed aux row [direct 3 | view_dep 3 | omega nb | basis_rgb 3nb | unscaled 3nb | clip | pad]."""
 
@@ -230,7 +308,7 @@ class PaletteFieldFused:
         self.versions = None
         m = model
         ok = (m.encoder.num_levels == 16 and m.encoder.level_dim == 2 and m.hidden_dim == 64 and m.geo_feat_dim == 15 and m.num_layers == 2
-              and m.num_layers_color == 3 and m.encoder_dir.degree == 4 and 1 <= m.num_basis <= 5 and m.opt.clip_dim <= 16)
+              and m.num_layers_color == 3 and m.encoder_dir.degree == 4 and 1 <= m.num_basis <= _lib.MAX_BASIS and m.opt.clip_dim <= _lib.MAX_CLIP)
         if not ok:
             raise RuntimeError("fused palette field kernel is specialised for the shipped architecture")
         self.nb, self.pred_clip = int(m.num_basis), bool(m.opt.pred_clip)
@@ -253,15 +331,39 @@ class PaletteFieldFused:
 
     def invalidate_caches(self):
         self.versions = None
-        self._pair_key = self._triple_key = self._hp_key = None
+        self._pair_key = self._triple_key = self._hp_key = self._guard_key = None
+
+    def _guard_tables(self):
+        m = self.model
+        return [m.encoder.embeddings, m.encoder_palette.embeddings] + ([m.encoder_clip.embeddings] if self.pred_clip else [])
+
+    def _guard_bound(self, tmax, scales):
+        l1 = [float(v) for v in torch.stack([_l1(w).float() for w in self._weights()]).cpu().tolist()]
+        s0, s1, d0, d1, d2, c0, c1, c2, b0, b1 = l1[:10]
+        enc = tmax[0] * scales[0]
+        h1 = s0 * enc
+        geo = s1 * h1 / scales[0]
+        dd0 = d0 * geo
+        dd1 = d1 * dd0
+        cc0 = c0 * max(1.6, geo)
+        cc1 = c1 * cc0
+        bin_ = max(tmax[1], 1.0) * scales[1]               # [enc_palette ; diffuse in (0,1)], prescaled together
+        bb0 = b0 * bin_ / scales[1]                        # ELU output <= its input bound
+        p = b1 * max(bb0, 1.0)
+        sites = [enc, h1, geo, dd0, dd1, cc0, cc1, bin_, bb0, p]
+        if self.pred_clip:
+            ce = tmax[2] * scales[2]
+            sites += [ce, l1[12] * ce]
+        return max(sites)
 
     def _pack(self):
         ws = self._weights()
-        versions = tuple(_pkey(w) for w in ws) + (self.precision,)
+        prec = self.effective_precision()
+        versions = tuple(_pkey(w) for w in ws) + (prec,)
         if self.packed is None or versions != self.versions or PARANOID:
             dev = ws[0].device
             lib = _lib.load()
-            self.packed = torch.empty(int(lib.pnr_palette_field_packed_bytes(int(self.pred_clip))), dtype=torch.uint8, device=dev)
+            self.packed = torch.empty(int(lib.pnr_palette_field_packed_bytes(self.nb, self.clip_dim, int(self.pred_clip))), dtype=torch.uint8, device=dev)
             self._keep = [require(w.detach().contiguous(), torch.float32, "weight") for w in ws]
             pw = _lib.PaletteWeights()
             names = ["sigma0", "sigma1", "diff0", "diff1", "diff2", "color0", "color1", "color2", "basis0", "basis1", "offsets_radiance", "omega"]
@@ -269,18 +371,64 @@ class PaletteFieldFused:
                 names += ["clip0", "clip1"]
             for name, w in zip(names, self._keep):
                 setattr(pw, name, w.data_ptr())
-            pw.num_basis, pw.clip_dim, pw.pred_clip = self.nb, self.clip_dim, int(self.pred_clip)
+            pw.num_basis, pw.clip_dim, pw.pred_clip, pw.precision = self.nb, self.clip_dim, int(self.pred_clip), int(prec)
             rc = lib.pnr_palette_field_pack(ctypes.byref(pw), ctypes.c_void_p(self.packed.data_ptr()),
                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
             _lib.check(rc, "pnr_palette_field_pack")
             self.versions = versions
         return self.packed
 
+    def _edit_struct(self):
+        """The model's RegionEdit / Stylizer state as a pnr_palette_edit (None when neither is set).  Rebuilt when the controllers' tensors
+        change (object identity / version): a few small D2H copies per change, none per frame."""
+        m = self.model
+        edit, sty = getattr(m, "edit", None), getattr(m, "stylizer", None)
+        if edit is None and sty is None:
+            return None
+        if sty is not None:
+            key = ("s", id(sty), _pkey(sty.dI), _pkey(sty.dP), _pkey(sty.ddelta))
+        else:
+            tkey = lambda t: None if t is None or not torch.is_tensor(t) else (id(t), t.data_ptr(), t._version)
+            key = ("e", id(edit), tkey(edit.delta_hsv), tkey(edit.mean_xyz), tkey(edit.mean_clip), float(edit.std_xyz), float(edit.std_clip), bool(edit.weight_mode))
+        if getattr(self, "_edit_key", None) == key and not PARANOID:
+            return self._edit
+        e = _lib.PaletteEdit()
+        nb = self.nb
+        if sty is not None:    # palette/renderer.py:150-183
+            e.mode = 2
+            dI, dP, dd = sty.dI.detach().float().cpu(), sty.dP.detach().float().cpu().reshape(nb, 3), sty.ddelta.detach().float().cpu()
+            for b in range(nb):
+                e.dI[b] = float(dI[b])
+                for k in range(3):
+                    e.dP[b][k] = float(dP[b, k])
+                    for j in range(3):
+                        e.ddelta[b][k][j] = float(dd[b, k, j])
+        else:                  # palette/renderer.py:84-147
+            e.mode = 1
+            dh = edit.delta_hsv.detach().float().cpu()
+            for b in range(nb):
+                for k in range(3):
+                    e.delta_hsv[b][k] = float(dh[b, k])
+            if edit.mean_xyz is not None:
+                e.has_mean_xyz = 1
+                for k, v in enumerate(edit.mean_xyz.detach().float().cpu().reshape(-1)[:3].tolist()):
+                    e.mean_xyz[k] = v
+            if edit.mean_clip is not None:
+                mc = edit.mean_clip.detach().float().cpu().reshape(-1).tolist()
+                if len(mc) != int(m.opt.clip_dim):
+                    raise RuntimeError("RegionEdit.mean_clip must have clip_dim entries")
+                e.has_mean_clip = len(mc)
+                for k, v in enumerate(mc):
+                    e.mean_clip[k] = v
+            e.std_xyz, e.std_clip, e.weight_mode = float(edit.std_xyz), float(edit.std_clip), int(bool(edit.weight_mode))
+        self._edit, self._edit_key = e, key
+        return e
+
     def _host_params(self):
         m = self.model
         key = (_pkey(m.basis_color), _pkey(m.offsets_radiance_net.bias))
         if getattr(self, "_hp_key", None) != key or PARANOID:  # two tiny D2H copies, only when the parameters change
-            self._bc = (ctypes.c_float * (3 * self.nb))(*m.basis_color.detach().float().cpu().reshape(-1).tolist())
+            self._bc = (ctypes.c_float * (3 * self.nb))(*m.basis_color.detach().float().cpu().reshape(-1).tolist())   # clamped to [0,1] by the callee
             self._bias = (ctypes.c_float * (3 * self.nb + 1))(*m.offsets_radiance_net.bias.detach().float().cpu().tolist())
             self._hp_key = key
         return self._bc, self._bias
@@ -354,7 +502,9 @@ class PaletteFieldFused:
         a.offsets = enc.offsets.data_ptr()
         a.num_levels, a.S, a.base_resolution, a.gridtype = enc.num_levels, float(np.log2(enc.per_level_scale)), enc.base_resolution, enc.gridtype_id
         a.packed_weights = self._pack().data_ptr()
-        a.field_precision = 1
+        a.field_precision = int(self.effective_precision())
+        for k, v in enumerate(self.enc_scales()):
+            a.enc_scale[k] = v
         a.density_scale = float(m.density_scale)
         a.weights_sum, a.depth, a.image = ws.data_ptr(), depth.data_ptr(), image.data_ptr()
         a.workspace, a.workspace_bytes = self._ws.data_ptr(), nbytes
@@ -368,6 +518,8 @@ class PaletteFieldFused:
         p.num_basis, p.clip_dim, p.pred_clip = self.nb, self.clip_dim, int(self.pred_clip)
         p.offsets_weight, p.view_dep_weight = float(m.offsets_weight), float(m.view_dep_weight)
         p.aux_map = aux_map.data_ptr()
+        edit = self._edit_struct()
+        p.edit = ctypes.cast(ctypes.pointer(edit), ctypes.c_void_p) if edit is not None else None
         if self.table_half and self.pred_clip:
             raise RuntimeError("fp16 tables in the native PaletteNeRF loop need the interleaved pair table (no clip head)")
         pair = self._pair_table() if ((self.interleave_tables or self.table_half) and not self.pred_clip) else None
@@ -410,6 +562,13 @@ class PaletteFieldFused:
         a.density_scale, a.offsets_weight, a.view_dep_weight = float(m.density_scale), float(m.offsets_weight), float(m.view_dep_weight)
         a.aux_stride = self.aux_channels
         a.sigmas, a.rgbs, a.aux = sigmas.data_ptr(), rgbs.data_ptr(), aux.data_ptr()
+        a.precision = int(self.effective_precision())
+        for k, v in enumerate(self.enc_scales()):
+            a.enc_scale[k] = v
+        edit = self._edit_struct()
+        a.edit = ctypes.cast(ctypes.pointer(edit), ctypes.c_void_p) if edit is not None else None
+        xw = require(x.contiguous(), torch.float32, "xyzs")
+        a.xyzs = xw.data_ptr()
         rc = lib.pnr_palette_field_forward(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         _lib.check(rc, "pnr_palette_field_forward")
         return sigmas, rgbs, aux

@@ -673,7 +673,10 @@ class PaletteRenderer(_RendererBase):
 
         # under fp16 autocast only the native loop takes the fused path (fp16 tables, fp32-accurate field); it has no clip-head variant there
         autocast_ok = not torch.is_autocast_enabled() or (self.march_mode == "native" and not perturb and not self.opt.pred_clip)
-        use_fused = bool(getattr(self, "fused_field", False)) and self.edit is None and self.stylizer is None and autocast_ok
+        # RegionEdit and the Stylizer run inside the fused field kernel's epilogue (pnr_palette_edit): editing costs no extra launch
+        use_fused = bool(getattr(self, "fused_field", False)) and autocast_ok
+        if use_fused and self.stylizer is not None and not gui_mode:
+            raise RuntimeError("the Stylizer renders in gui_mode only (palette/renderer.py:481-488 defines no basis maps for it)")
         if use_fused:
             if getattr(self, "_fused", None) is None:
                 from .fused import PaletteFieldFused

@@ -223,6 +223,14 @@ def seed_field_(model, seed=0, table_range=0.5):
     return model
 
 
+def stylizer_state(nb, seed):
+    """Seeded, clearly non-trivial Stylizer parameters {dI [nb], dP [1,nb,3], ddelta [nb,3,3]} (palette/renderer.py:150-165 initialises them to
+    zero / identity; the GUI's optimiser moves them).  Used by the fixtures (tests/golden/gen_golden.py) and the tests that replay them."""
+    g = torch.Generator().manual_seed(seed)
+    return {"dI": (torch.rand(nb, generator=g) - 0.5) * 0.6, "dP": (torch.rand(1, nb, 3, generator=g) - 0.5) * 0.4,
+            "ddelta": torch.eye(3)[None].repeat(nb, 1, 1) + (torch.rand(nb, 3, 3, generator=g) - 0.5) * 0.5}
+
+
 def psnr(a, b):
     """-10 log10(mean((a-b)^2)) (nerf/utils.py:242)."""
     mse = float(torch.mean((a.double() - b.double()) ** 2))

@@ -198,6 +198,57 @@ def gen_frames():
         print("palette train", name, int(p.step_counter[0, 0]), float(loss))
 
 
+# ------------------------------------------------------------------------------------------ palette extras: Stylizer, edit windows, more bases
+EXTRA_CASES = [
+    # name, H, W, dt_gamma, density_scale, seed, num_basis, pred_clip
+    ("style_a", 40, 40, 0.0, 1.0, 100, 4, False),
+    ("style_b", 36, 28, 1.0 / 128, 0.02, 101, 4, True),
+    ("nb6", 32, 32, 0.0, 1.0, 102, 6, False),
+    ("nb8", 30, 26, 1.0 / 128, 0.05, 103, 8, True),
+]
+
+
+def gen_palette_extra():
+    """The reference's PaletteRenderer.run_cuda with its own Stylizer / RegionEdit classes (palette/renderer.py:84-183) and with more than
+    5 palette bases (main_palette.py:141: num_basis = rows of the extracted palette), the oracle injected as the kernel layer."""
+    ref_nerf, ref_pal, ref_pal_r = import_reference()
+    grid = scene.brick_density_grid()
+    for name, H, W, dt_gamma, dscale, seed, nb, pred_clip in EXTRA_CASES:
+        ro, rd = frame_inputs(H, W)
+        opt = types.SimpleNamespace(num_basis=nb, clip_dim=16, pred_clip=pred_clip, use_initialization_from_rgbxy=False, test=True,
+                                    color_space="srgb", smooth_sigma_xyz=0.005, smooth_sigma_color=0.2, smooth_sigma_clip=0.0)
+        p = ref_pal.PaletteNetwork(opt, bound=2, cuda_ray=True, density_scale=dscale, min_near=0.2)
+        scene.seed_field_(p, seed)
+        setup_model(p, grid)
+        p.eval()
+        kw = dict(dt_gamma=dt_gamma, perturb=False, max_steps=1024, T_thresh=1e-4)
+        out = dict(H=H, W=W, dt_gamma=dt_gamma, density_scale=dscale, seed=seed, num_basis=nb, pred_clip=pred_clip)
+        with torch.no_grad():
+            r = p.run_cuda(ro, rd, gui_mode=False, **kw)
+            for k in ("image", "depth", "weights_sum", "clip_feat", "direct_rgb", "view_dep_rgb", "basis_rgb", "unscaled_basis_rgb", "basis_acc"):
+                out[k] = r[k].numpy()
+            # Stylizer (gui_mode only: the reference defines no basis maps on that branch)
+            p.stylizer = ref_pal_r.Stylizer(opt)
+            st = scene.stylizer_state(nb, seed)
+            for k, v in st.items():
+                getattr(p.stylizer, k).data.copy_(v)
+            out["style_image"] = p.run_cuda(ro, rd, gui_mode=True, **kw)["image"].numpy()
+            p.stylizer = None
+            # RegionEdit with a spatial AND a semantic window; then its weight-preview mode
+            p.edit = ref_pal_r.RegionEdit(opt)
+            p.edit.update_cent(mean_xyz=torch.tensor([0.1, 0.0, -0.2]), mean_clip=torch.linspace(-0.3, 0.3, 16))
+            p.edit.update_std(std_xyz=0.5, std_clip=2.0)
+            p.edit.update_delta_hsv(p.basis_color.data.clamp(0, 1), (p.basis_color.data * 0.6 + 0.2).flip(0).clamp(0, 1))
+            e1 = p.run_cuda(ro, rd, gui_mode=False, **kw)
+            out["edit_image"], out["edit_basis_rgb"] = e1["image"].numpy(), e1["basis_rgb"].numpy()
+            p.edit.weight_mode = True
+            out["edit_weight_image"] = p.run_cuda(ro, rd, gui_mode=True, **kw)["image"].numpy()
+            p.edit = None
+        np.savez_compressed(os.path.join(HERE, f"frame_palette_{name}.npz"), **out)
+        print("palette extra", name, float(r["weights_sum"].mean()), float(np.abs(out["style_image"] - out["image"]).max()),
+              float(np.abs(out["edit_image"] - out["image"]).max()), float(out["edit_weight_image"].mean()))
+
+
 # ------------------------------------------------------------------------------------------ uniform-sampling path (configs[0])
 RUN_CASES = [
     # name, H, W, num_steps, upsample_steps, density_scale, seed
@@ -276,8 +327,33 @@ def gen_state_dict_layout():
     print("state_dict layout", len(layout["nerf"]), len(layout["palette"]))
 
 
+# ------------------------------------------------------------------------------------------ RGB histogram (the reference's own compiled C++)
+def gen_hist():
+    """compute_RGB_histogram of the reference itself: palette/src/bindings.cpp compiled unmodified from /root/reference (oracle/ref_build.py),
+    called the way palette/utils.py:129-146 calls it (flattened float32 arrays).  Inputs include the clamp edges (< 0, exactly 0.999, >= 1)."""
+    sys.path.insert(0, ROOT)
+    from oracle import ref_build
+    assert ref_build.build() is not None, "the reference sources are needed to generate this fixture"
+    mod = ref_build.load()
+    rng = np.random.default_rng(2024)
+    rgb = rng.uniform(-0.05, 1.05, size=(4096, 3)).astype(np.float32)
+    rgb[:8] = np.array([[0, 0, 0], [1, 1, 1], [0.999, 0.999, 0.999], [0.9990001, 0.5, 0.25], [-1, 2, 0.5], [0.124999, 0.125, 0.125001],
+                        [0.5, 0.5, 0.5], [0.998, 0.0009765625, 0.99899995]], np.float32)
+    w = rng.uniform(0.0, 3.0, size=4096).astype(np.float32)
+    out = {"colors_rgb": rgb, "weights": w}
+    for bpc in (1, 2, 3, 5):
+        bw, bc = mod.compute_RGB_histogram(rgb.flatten(), w.flatten(), bpc)
+        out[f"bin_weights_{bpc}"], out[f"bin_centers_{bpc}"] = np.asarray(bw), np.asarray(bc)
+    np.savez_compressed(os.path.join(HERE, "hist.npz"), **out)
+    print("hist", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["sh", "frames"]
+    if "hist" in which:
+        gen_hist()
+    if "palette_extra" in which:
+        gen_palette_extra()
     if "run" in which:
         gen_run()
     if "rays" in which:

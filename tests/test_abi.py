@@ -34,7 +34,7 @@ def test_python_binding_table_matches_header():
     from palettenerf_amd import _lib
     assert sorted(_lib.SIGNATURES) == header_symbols()
     lib = _lib.load()
-    assert lib.pnr_abi_version() >= 1
+    assert lib.pnr_abi_version() >= 2
     assert lib.pnr_error_string(0) == b"ok"
     assert b"unsupported" in lib.pnr_error_string(-2)
     assert lib.pnr_scan_scratch_bytes(1000) >= 4 * 1000
@@ -59,6 +59,29 @@ def test_argument_validation_without_gpu():
     # empty inputs are a no-op
     assert lib.pnr_morton3d(None, u32(0), None, None) == 0
     assert lib.pnr_march_rays(u32(0), u32(4), *([None] * 4), f32(2), f32(0), u32(1024), u32(2), u32(128), *([None] * 8)) == 0
+
+
+def test_palette_field_sizes_and_limits_without_gpu():
+    """Shapes the fused PaletteNeRF field accepts (1..10 bases, clip heads up to 32 wide) and the sizes it reports, on the host."""
+    from palettenerf_amd import _lib
+    lib = _lib.load()
+    u32, i32 = ctypes.c_uint32, ctypes.c_int
+    assert lib.pnr_palette_field_packed_bytes(u32(4), u32(0), i32(0)) == 50 * 2048        # 50 K = 16 blocks
+    assert lib.pnr_palette_field_packed_bytes(u32(8), u32(0), i32(0)) == 51 * 2048        # + the second offsets_radiance tile
+    assert lib.pnr_palette_field_packed_bytes(u32(4), u32(16), i32(1)) == 59 * 2048       # + clip_net
+    assert lib.pnr_palette_field_packed_bytes(u32(4), u32(32), i32(1)) == 63 * 2048       # + its second output tile
+    assert lib.pnr_palette_aux_channels(u32(4), u32(16)) == 52 and lib.pnr_palette_aux_channels(u32(8), u32(16)) == 80
+    assert lib.pnr_palette_field_stages_aux(u32(4), u32(0), i32(0)) == 1 and lib.pnr_palette_field_stages_aux(u32(10), u32(32), i32(1)) == 0
+    a = _lib.PaletteFieldArgs()
+    a.num_basis, a.clip_dim, a.precision, a.aux_stride = 11, 16, 1, 100
+    assert lib.pnr_palette_field_forward(ctypes.byref(a), None) == -2                     # more than PNR_MAX_BASIS bases
+    a.num_basis, a.precision = 4, 5
+    assert lib.pnr_palette_field_forward(ctypes.byref(a), None) == -2                     # unknown precision
+    a.precision, a.aux_stride = 0, 50
+    assert lib.pnr_palette_field_forward(ctypes.byref(a), None) == -1                     # aux_stride not a multiple of 4
+    p = _lib.PaletteFrameArgs()
+    p.num_basis = 11
+    assert lib.pnr_palette_render_frame(ctypes.byref(p), None) == -2
 
 
 def test_product_path_never_imports_the_oracle():
@@ -106,7 +129,7 @@ def test_training_entry_points_validate_without_gpu():
     assert lib.pnr_palette_train_shade_workspace_bytes(u32(4)) == 512 * 4 * 3 * 4
     assert lib.pnr_palette_train_shade_forward(u32(8), u32(17), u32(0), None, None, None, None, None, None, None, None, None, None) == -2   # nb > 16
     assert lib.pnr_palette_train_shade_forward(u32(0), u32(4), u32(16), None, None, None, None, None, None, None, None, None, None) == 0
-    assert lib.pnr_nerf_density_forward(None, None, u32(8), f32(1.0), None, None, i32(7), None) == -2                                      # precision
-    assert lib.pnr_nerf_density_forward(None, None, u32(8), f32(1.0), None, None, i32(1), None) == -1
+    assert lib.pnr_nerf_density_forward(None, None, u32(8), f32(1.0), None, None, i32(7), f32(1.0), None) == -2                                      # precision
+    assert lib.pnr_nerf_density_forward(None, None, u32(8), f32(1.0), None, None, i32(1), f32(1.0), None) == -1
     assert lib.pnr_linear_bgrad(None, i32(0), u32(0), u32(13), None, i32(1), None, u64(0), None) == -1                                      # no output
     assert lib.pnr_set_option(b"composite_fusion", 1) == 0

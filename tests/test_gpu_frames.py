@@ -112,7 +112,7 @@ def test_palette_inference_frame_all_maps_and_edit(cuda, golden_dir, case):
             close(r[k], g[k], what=f"{mode}:{k}")
         close(r["depth"], g["depth"], tol=2e-4, what="depth")
         close(r["depth_origin"], g["depth_origin"], tol=5e-4, what="depth_origin")
-    # regional edit: RGB->HSV->RGB inside the loop (the fused field steps aside when an edit is active)
+    # regional edit: RGB->HSV->RGB inside the fused field epilogue of the device-driven loop (the last mode set above)
     m.edit = renderer.RegionEdit(opt)
     m.edit.update_cent(mean_xyz=torch.tensor([0.1, 0.0, -0.2], device=cuda))
     m.edit.update_std(std_xyz=0.5)
@@ -545,7 +545,7 @@ def test_fused_blobs_follow_parameter_updates(cuda, golden_dir):
     n1, c1 = both()
     assert float((n1 - n0).abs().max()) > 1e-2 and float((n1 - c1).abs().max()) < COLOUR_TOL
     # 2. a write through .data does not bump the version: stale until invalidated, correct afterwards
-    m.diff_net[2].weight.data.mul_(-1.0)
+    m.color_net[1].weight.data.mul_(-1.0)
     m.invalidate_fused_caches()
     n2, c2 = both()
     assert float((n2 - n1).abs().max()) > 1e-3 and float((n2 - c2).abs().max()) < COLOUR_TOL
@@ -565,3 +565,115 @@ def test_fused_blobs_follow_parameter_updates(cuda, golden_dir):
     want = torch.where(want < 0.04045, want / 12.92, ((want + 0.055) / 1.055) ** 2.4)
     assert torch.allclose(m.basis_color.detach().cpu()[[0, 0, 3], [0, 1, 0]], want, atol=1e-7)
     assert torch.equal(m.basis_color_origin, m.basis_color.detach())
+
+
+@pytest.mark.parametrize("case", ["style_a", "style_b", "nb6", "nb8"])
+def test_palette_stylizer_edit_and_many_basis_frames_in_every_mode(cuda, golden_dir, case):
+    """Fixtures from the reference's own Stylizer / RegionEdit classes and PaletteNetwork with 4, 6 and 8 palette bases
+    (tests/golden/gen_golden.py:gen_palette_extra).  Both editing heads run inside the fused field kernel's epilogue, in the host-driven
+    loop (fused) and in the device-driven loop (native), in the split-fp16 and the exact-fp32 matrix path."""
+    from tests.test_host_logic import _extra_model, set_extra_edit, set_extra_stylizer
+    from palettenerf_amd.fused import PaletteFieldFused
+    g = load(golden_dir, f"frame_palette_{case}")
+    opt, m = _extra_model(g)
+    m = m.to(cuda).eval()
+    put_scene(m, cuda)
+    ro, rd = frame_rays(g, cuda)
+    kw = dict(dt_gamma=float(g["dt_gamma"]), perturb=False, max_steps=1024, T_thresh=1e-4)
+    maps = ("image", "weights_sum", "clip_feat", "direct_rgb", "view_dep_rgb", "basis_rgb", "unscaled_basis_rgb", "basis_acc")
+    for mode in ("compat", "fused", "native", "native_fp32"):
+        m.march_mode = {"fused": "device", "native_fp32": "native"}.get(mode, mode)
+        m.fused_field = mode != "compat"
+        if m.fused_field:
+            m._fused = PaletteFieldFused(m)
+            m._fused.precision = 0 if mode == "native_fp32" else 1
+        with torch.no_grad():
+            r = m.render(ro, rd, gui_mode=False, **kw)
+            for k in maps:
+                close(r[k], g[k], what=f"{mode}:{k}")
+            close(r["depth"], g["depth"], tol=2e-4, what=f"{mode}:depth")
+            set_extra_stylizer(m, opt, g, cuda)
+            close(m.render(ro, rd, gui_mode=True, **kw)["image"], g["style_image"], what=f"{mode}:style_image")
+            if m.fused_field:
+                with pytest.raises(RuntimeError, match="gui_mode"):
+                    m.render(ro, rd, gui_mode=False, **kw)
+            m.stylizer = None
+            set_extra_edit(m, opt, cuda)
+            e = m.render(ro, rd, gui_mode=False, **kw)
+            close(e["image"], g["edit_image"], tol=3e-4, what=f"{mode}:edit_image")          # HSV hue wrap amplifies rounding a little
+            close(e["basis_rgb"], g["edit_basis_rgb"], tol=3e-4, what=f"{mode}:edit_basis_rgb")
+            m.edit.weight_mode = True
+            close(m.render(ro, rd, gui_mode=True, **kw)["image"], g["edit_weight_image"], what=f"{mode}:edit_weight_image")
+            m.edit = None
+
+
+def test_native_loop_renders_the_round1_edit_fixture(cuda, golden_dir):
+    """frame_palette_{a,b}.npz: edit_image (RegionEdit with a spatial window only, gui_mode) now also through the device-driven loop."""
+    for case in ("a", "b"):
+        g = load(golden_dir, f"frame_palette_{case}")
+        opt = renderer.default_opt(pred_clip=bool(g["pred_clip"]))
+        m = network.PaletteNetwork(opt, bound=2, cuda_ray=True, density_scale=float(g["density_scale"]), min_near=0.2)
+        scene.seed_field_(m, int(g["seed"]))
+        m = m.to(cuda).eval()
+        put_scene(m, cuda)
+        ro, rd = frame_rays(g, cuda)
+        m.march_mode, m.fused_field = "native", True
+        m.edit = renderer.RegionEdit(opt)
+        m.edit.update_cent(mean_xyz=torch.tensor([0.1, 0.0, -0.2], device=cuda))
+        m.edit.update_std(std_xyz=0.5)
+        m.edit.update_delta_hsv(m.basis_color.data.clamp(0, 1), (m.basis_color.data * 0.6 + 0.2).flip(0).clamp(0, 1))
+        with torch.no_grad():
+            r = m.render(ro, rd, dt_gamma=float(g["dt_gamma"]), perturb=False, max_steps=1024, T_thresh=1e-4, gui_mode=True)
+        close(r["image"], g["edit_image"], tol=3e-4, what=f"edit_image {case}")
+        assert "iterations" in r                                                         # it really took the device-driven loop
+
+
+@pytest.mark.parametrize("kind,case", [("nerf", "a"), ("nerf", "b"), ("palette", "a"), ("palette", "b")])
+def test_checkpoint_file_to_native_render(cuda, golden_dir, tmp_path, kind, case):
+    """f3: a `.pth` in the reference trainer's layout (nerf/utils.py:1083-1143) -> a FRESH model -> the device-driven loop.  The fused
+    kernels' blobs (MFMA weight blob, interleaved pair / triple table, host-side palette and bias) are all derived from what the checkpoint
+    loaded; the frame must be the fixture the reference's own renderer produced for those weights."""
+    from palettenerf_amd import checkpoint
+    g = load(golden_dir, f"frame_{kind}_{case}")
+
+    def build():
+        if kind == "nerf":
+            return network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=float(g["density_scale"]), min_near=0.2)
+        return network.PaletteNetwork(renderer.default_opt(pred_clip=bool(g["pred_clip"])), bound=2, cuda_ray=True, density_scale=float(g["density_scale"]), min_near=0.2)
+
+    src = build()
+    scene.seed_field_(src, int(g["seed"]))
+    src = src.to(cuda)
+    put_scene(src, cuda)
+    src.mean_count, src.mean_density = 1234, 0.5
+    path = checkpoint.save_model(src, str(tmp_path / "ngp_ep0007.pth"), epoch=7, global_step=700)
+    del src
+
+    m = build().to(cuda).eval()                     # default initialisation: tables U(-1e-4, 1e-4), empty occupancy
+    m.march_mode, m.fused_field = "native", True
+    ro, rd = frame_rays(g, cuda)
+    kw = dict(dt_gamma=float(g["dt_gamma"]), perturb=False, max_steps=1024, T_thresh=1e-4)
+    if kind == "palette":
+        kw["gui_mode"] = False
+    with torch.no_grad():
+        before = m.render(ro, rd, **kw)             # packs the blobs of the UNTRAINED weights (and finds nothing to march: empty bitfield)
+    assert float(before["weights_sum"].abs().max()) == 0.0
+    fused = m._fused
+    blob_before = fused.packed.clone()
+    info = checkpoint.load_model(m, path, map_location="cpu")
+    assert info["missing"] == [] and info["unexpected"] == [] and info["epoch"] == 7 and m.mean_count == 1234
+    with torch.no_grad():
+        r = m.render(ro, rd, **kw)
+    assert m._fused is fused and not torch.equal(fused.packed, blob_before)            # same object, blob rebuilt from the loaded weights
+    close(r["image"], g["image"], what="image")
+    close(r["weights_sum"], g["weights_sum"], what="weights_sum")
+    close(r["depth"], g["depth"], tol=2e-4, what="depth")
+    if kind == "palette":
+        for k in ("clip_feat", "direct_rgb", "view_dep_rgb", "basis_rgb", "unscaled_basis_rgb", "basis_acc"):
+            close(r[k], g[k], what=k)
+        table = fused._triple if fused.pred_clip else fused._pair                      # the interleaved copy holds the LOADED tables
+        assert torch.equal(table[:, 0:2], m.encoder.embeddings.detach()) and torch.equal(table[:, 2:4], m.encoder_palette.embeddings.detach())
+    # a 'best' checkpoint (no density_grid, utils.py:1135) loads non-strictly and leaves the occupancy alone
+    best = checkpoint.save_model(m, str(tmp_path / "ngp.pth"), best=True)
+    info = checkpoint.load_model(build().to(cuda), best)
+    assert info["missing"] == ["density_grid"]

@@ -583,6 +583,142 @@ def test_fused_palette_field_matches_torch_module(cuda, pred_clip):
         assert float(aux[:, used:].abs().sum()) == 0.0 and float(want_aux[:, used:].abs().sum()) == 0.0
 
 
+
+def _palette_reference_rows(m, x, d, nb):
+    """The torch statement of palette/renderer.py:470-500 (no edit): sigma, rgbs and the packed aux row of the unfused module."""
+    import torch.nn.functional as F
+    B = x.shape[0]
+    sigma, clip_feat, omega, offsets_radiance, view_dep, diffuse = m(x, d)
+    offsets, radiance = offsets_radiance[..., :-1].reshape(B, nb, 3), offsets_radiance[..., -1:].reshape(B, 1, 1)
+    basis_color = m.basis_color[None].clamp(0, 1)
+    final = F.softplus(radiance) * (basis_color + m.offsets_weight * offsets)
+    basis_rgb = omega.reshape(B, nb, 1) * final
+    rgbs = basis_rgb.sum(-2) + m.view_dep_weight * view_dep
+    aux = torch.cat([diffuse + view_dep, view_dep, omega, basis_rgb.reshape(B, -1), (basis_color + offsets).reshape(B, -1), clip_feat], dim=1)
+    return sigma, rgbs, aux
+
+
+@pytest.mark.parametrize("nb,clip_dim,pred_clip,precision", [(6, 16, False, 1), (8, 16, True, 1), (10, 32, True, 1), (4, 16, True, 0), (8, 16, False, 0), (1, 16, False, 1)])
+def test_fused_palette_field_more_bases_wider_clip_and_exact_fp32(cuda, nb, clip_dim, pred_clip, precision):
+    """num_basis is the number of rows of the extracted palette (main_palette.py:141), not a constant: 1..10 bases (offsets_radiance_net then
+    has up to 31 outputs: a second output tile), clip heads up to 32 wide, and the exact-fp32 matrix path of the same kernel."""
+    from palettenerf_amd import network, renderer
+    from palettenerf_amd.fused import PaletteFieldFused
+    rng = np.random.default_rng(61)
+    opt = renderer.default_opt(pred_clip=pred_clip, num_basis=nb, clip_dim=clip_dim)
+    m = network.PaletteNetwork(opt, bound=2, cuda_ray=True, density_scale=3.0)
+    scene.seed_field_(m, 7 + nb)
+    m = m.to(cuda).eval()
+    m.offsets_weight, m.view_dep_weight = 0.7, 1.3
+    fused = PaletteFieldFused(m)
+    fused.precision = precision
+    for B in (33, 4097):
+        x = dev(rng.random((B, 3)).astype(np.float32) * 4 - 2, cuda)
+        d = rng.standard_normal((B, 3)).astype(np.float32)
+        d = dev(d / np.linalg.norm(d, axis=1, keepdims=True), cuda)
+        with torch.no_grad():
+            sigma, rgbs, want_aux = _palette_reference_rows(m, x, d, nb)
+            s, c, aux = fused(x, d)
+        used = 6 + 7 * nb + (clip_dim if pred_clip else 0)
+        assert aux.shape == (B, (used + 3) // 4 * 4) and fused.effective_precision() == precision
+        np.testing.assert_allclose(host(s), host(sigma) * 3.0, rtol=3e-5, atol=1e-7)
+        np.testing.assert_allclose(host(c), host(rgbs), rtol=0, atol=5e-6)
+        np.testing.assert_allclose(host(aux[:, :used]), host(want_aux)[:, :used], rtol=0, atol=5e-6)
+        assert float(aux[:, used:].abs().sum()) == 0.0
+    with pytest.raises(RuntimeError):
+        PaletteFieldFused(network.PaletteNetwork(renderer.default_opt(num_basis=11), bound=2, cuda_ray=True).to(cuda))
+
+
+@pytest.mark.parametrize("model_kind", ["nerf", "palette"])
+def test_split_fp16_field_with_tables_at_the_reference_init_scale(cuda, model_kind):
+    """Hash tables as the reference initialises them, U(-1e-4, 1e-4) (gridencoder/grid.py:107): encoder features of ~1e-5, whose low fp16 halves
+    would be subnormal.  The kernel prescales them by a power of two (enc_scale), so sigma_net's outputs keep fp32-class RELATIVE accuracy."""
+    from palettenerf_amd import network, renderer
+    from palettenerf_amd.fused import NeRFFieldFused, PaletteFieldFused, density_fused
+    rng = np.random.default_rng(62)
+    if model_kind == "nerf":
+        m = network.NeRFNetwork(bound=2, cuda_ray=True)
+    else:
+        m = network.PaletteNetwork(renderer.default_opt(pred_clip=True), bound=2, cuda_ray=True)
+    scene.seed_field_(m, 9, table_range=1e-4)
+    m = m.to(cuda).eval()
+    B = 20000
+    x = dev(rng.random((B, 3)).astype(np.float32) * 4 - 2, cuda)
+    d = rng.standard_normal((B, 3)).astype(np.float32)
+    d = dev(d / np.linalg.norm(d, axis=1, keepdims=True), cuda)
+    with torch.no_grad():
+        m.fused_field = False
+        ref = m.density(x)
+        m.fused_field = True
+        got = m.density(x)                         # the fused density kernel (split-fp16)
+    df = density_fused(m)
+    assert df.effective_precision() == 1 and df.enc_scales()[0] == 8192.0
+    g_ref, g_got = host(ref["geo_feat"]), host(got["geo_feat"])
+    assert np.abs(g_ref).max() < 1e-3             # the features really are tiny
+    assert np.abs(g_got - g_ref).max() <= 1e-5 * np.abs(g_ref).max()      # relative to the layer's scale: fp32-class (2e-4 without the prescale)
+    np.testing.assert_allclose(host(got["sigma"]), host(ref["sigma"]), rtol=1e-6)
+    with torch.no_grad():
+        if model_kind == "nerf":
+            m.fused_field = False
+            s_ref, c_ref = m(x, d)
+            m._fused = NeRFFieldFused(m)
+            m.fused_field = True
+            s, c = m(x, d)
+            np.testing.assert_allclose(host(s), host(s_ref), rtol=1e-6)
+            np.testing.assert_allclose(host(c), host(c_ref), atol=1e-6)
+        else:
+            fused = PaletteFieldFused(m)
+            assert fused.enc_scales() == [8192.0, 8192.0, 8192.0]
+            sigma, rgbs, want_aux = _palette_reference_rows(m, x, d, 4)
+            s, c, aux = fused(x, d)
+            np.testing.assert_allclose(host(s), host(sigma), rtol=1e-6)
+            np.testing.assert_allclose(host(c), host(rgbs), atol=2e-6)
+            np.testing.assert_allclose(host(aux[:, :50]), host(want_aux)[:, :50], atol=2e-6)
+            clip_ref = host(want_aux[:, 34:50])
+            assert np.abs(host(aux[:, 34:50]) - clip_ref).max() <= 1e-5 * np.abs(clip_ref).max()   # clip_net is prescaled too
+
+
+@pytest.mark.parametrize("model_kind", ["nerf", "palette"])
+def test_split_fp16_field_steps_aside_when_activations_can_leave_the_fp16_range(cuda, model_kind):
+    """One weight row scaled so that hidden activations exceed 65 504 (fp16's largest value): the split operands would become inf.  The static
+    activation bound computed at pack time sends such weights to the exact-fp32 matrix path; frames in every mode agree with the torch loop."""
+    import warnings
+    from palettenerf_amd import network, renderer
+    if model_kind == "nerf":
+        m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=100.0, min_near=0.2)
+    else:
+        m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True, density_scale=100.0, min_near=0.2)
+    scene.seed_field_(m, 11)
+    with torch.no_grad():
+        m.color_net[0].weight[5].mul_(4.0e5)       # hidden unit 5 of the view-dependent head: activations up to ~1e6
+        m.color_net[1].weight[:, 5].mul_(1.0e-5)   # its consumers scaled back so that the colours stay meaningful
+    m = m.to(cuda).eval()
+    m.density_grid.copy_(torch.from_numpy(scene.brick_density_grid()).to(cuda))
+    raymarching.packbits(m.density_grid, 0.5, m.density_bitfield)
+    ro, rd = rays_of(48, 48)
+    ro, rd = dev(ro, cuda)[None], dev(rd, cuda)[None]
+    kw = dict(perturb=False, dt_gamma=0.0, max_steps=1024, T_thresh=1e-4)
+    if model_kind == "palette":
+        kw["gui_mode"] = False
+    out = {}
+    with torch.no_grad(), warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        for mode in ("compat", "fused", "native"):
+            m.march_mode = "device" if mode == "fused" else mode
+            m.fused_field = mode != "compat"
+            out[mode] = m.render(ro, rd, **kw)
+    assert m._fused.precision == 1 and m._fused.effective_precision() == 0          # asked for split-fp16, ran exact fp32
+    assert any("fp16 range" in str(w.message) for w in caught)
+    x = dev(np.random.default_rng(1).random((4096, 3)).astype(np.float32) * 1.2 - 0.6, cuda)
+    with torch.no_grad():
+        h = torch.relu(torch.cat([m.encoder_dir(rd[0, :4096]), m.density(x)["geo_feat"]], dim=-1) @ m.color_net[0].weight.t())
+    assert float(h.max()) > 65504.0                                                   # the premise: fp16 could not hold this activation
+    for mode in ("fused", "native"):
+        for k in ("image", "weights_sum"):
+            assert torch.isfinite(out[mode][k]).all()
+            assert float((out[mode][k] - out["compat"][k]).abs().max()) < 1e-4, (mode, k)
+
+
 def test_rgb_histogram_matches_oracle(cuda):
     rng = np.random.default_rng(70)
     rgb = (rng.random((200003, 3)) * 1.2 - 0.1).astype(np.float32)   # includes values below 0 and above 0.999 (clamped)
@@ -596,6 +732,33 @@ def test_rgb_histogram_matches_oracle(cuda):
         assert abs(bw.sum() - w.astype(np.float64).sum()) < 1e-6
     bw, bc = palette_utils.compute_RGB_histogram(np.zeros((0, 3), np.float32), np.zeros(0, np.float32), 2)
     assert bw.sum() == 0 and bc.shape == (64, 3)
+
+
+def test_rgb_histogram_and_hsv_against_the_reference_build(cuda, golden_dir):
+    """pnr_rgb_histogram against the fixture the reference's own compiled compute_RGB_histogram produced (tests/golden/hist.npz), and -- when
+    oracle/_ref holds the built module -- the reference's `_palette_func` pybind layer (palette/src/bindings.cpp, unmodified) driving this
+    repo's HIP HSV kernels through the C ABI (csrc/shim/palette_func_hip.cpp): the drop-in at the native boundary."""
+    g = np.load(f"{golden_dir}/hist.npz")
+    for bpc in (1, 2, 3, 5):
+        bw, bc = palette_utils.compute_RGB_histogram(g["colors_rgb"], g["weights"], bpc)
+        np.testing.assert_array_equal(bc, g[f"bin_centers_{bpc}"])
+        np.testing.assert_allclose(bw, g[f"bin_weights_{bpc}"], rtol=1e-13, atol=0)   # fp64 atomics: the order of the additions differs
+    from oracle import ref_build
+    if not ref_build.available():
+        pytest.skip("oracle/_ref not built (it is built where /root/reference exists and travels with the snapshot)")
+    mod = ref_build.load()
+    rng = np.random.default_rng(71)
+    rgb = rng.random((4099, 3)).astype(np.float32)
+    t = dev(rgb, cuda)
+    hsv = torch.empty_like(t)
+    mod.rgb_to_hsv(rgb.shape[0], t, hsv)
+    back = torch.empty_like(t)
+    mod.hsv_to_rgb(rgb.shape[0], hsv, back)
+    np.testing.assert_allclose(host(hsv), oracle.rgb_to_hsv(rgb), rtol=2e-6, atol=2e-4)
+    np.testing.assert_allclose(host(back), rgb, atol=2e-6)
+    assert torch.equal(hsv, palette_utils.rgb_to_hsv(t))                              # same kernel as the Python operator
+    with pytest.raises(RuntimeError):
+        mod.rgb_to_hsv(4, torch.zeros(4, 3), torch.zeros(4, 3))                        # CPU tensors are refused (TORCH_CHECK -> RuntimeError)
 
 
 # ------------------------------------------------------------------------------------------ ray generation (f2)

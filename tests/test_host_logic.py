@@ -78,6 +78,52 @@ def test_palette_mirror_reproduces_reference_frames(facade):
     np.testing.assert_allclose(r2["image"].numpy(), g["edit_image"], atol=1e-6)
 
 
+def _extra_model(g):
+    opt = renderer.default_opt(pred_clip=bool(g["pred_clip"]), num_basis=int(g["num_basis"]))
+    m = network.PaletteNetwork(opt, bound=2, cuda_ray=True, density_scale=float(g["density_scale"]), min_near=0.2)
+    scene.seed_field_(m, int(g["seed"]))
+    return opt, m
+
+
+def set_extra_edit(m, opt, device="cpu"):
+    """The RegionEdit state of the `frame_palette_{style,nb}*` fixtures (tests/golden/gen_golden.py:gen_palette_extra)."""
+    m.edit = renderer.RegionEdit(opt)
+    m.edit.update_cent(mean_xyz=torch.tensor([0.1, 0.0, -0.2], device=device), mean_clip=torch.linspace(-0.3, 0.3, 16).to(device))
+    m.edit.update_std(std_xyz=0.5, std_clip=2.0)
+    m.edit.update_delta_hsv(m.basis_color.data.clamp(0, 1), (m.basis_color.data * 0.6 + 0.2).flip(0).clamp(0, 1))
+
+
+def set_extra_stylizer(m, opt, g, device="cpu"):
+    m.stylizer = renderer.Stylizer(opt).to(device)
+    with torch.no_grad():
+        for k, v in scene.stylizer_state(int(g["num_basis"]), int(g["seed"])).items():
+            getattr(m.stylizer, k).copy_(v)
+
+
+@pytest.mark.parametrize("case", ["style_a", "style_b", "nb6", "nb8"])
+def test_palette_mirror_reproduces_stylizer_edit_and_many_basis_frames(facade, case):
+    """Fixtures from the reference's own Stylizer / RegionEdit classes and PaletteNetwork with 4, 6 and 8 bases (gen_palette_extra)."""
+    g = np.load(os.path.join(GOLDEN, f"frame_palette_{case}.npz"))
+    opt, m = _extra_model(g)
+    put_scene(m)
+    m.eval()
+    ro, rd = rays(g)
+    kw = dict(dt_gamma=float(g["dt_gamma"]), perturb=False, max_steps=1024, T_thresh=1e-4)
+    with torch.no_grad():
+        r = m.render(ro, rd, gui_mode=False, **kw)
+        for k in ("image", "depth", "weights_sum", "clip_feat", "direct_rgb", "view_dep_rgb", "basis_rgb", "unscaled_basis_rgb", "basis_acc"):
+            np.testing.assert_allclose(r[k].numpy(), g[k], rtol=0, atol=1e-6, err_msg=k)
+        set_extra_stylizer(m, opt, g)
+        np.testing.assert_allclose(m.render(ro, rd, gui_mode=True, **kw)["image"].numpy(), g["style_image"], atol=1e-6)
+        m.stylizer = None
+        set_extra_edit(m, opt)
+        e = m.render(ro, rd, gui_mode=False, **kw)
+        np.testing.assert_allclose(e["image"].numpy(), g["edit_image"], atol=1e-6)
+        np.testing.assert_allclose(e["basis_rgb"].numpy(), g["edit_basis_rgb"], atol=1e-6)
+        m.edit.weight_mode = True
+        np.testing.assert_allclose(m.render(ro, rd, gui_mode=True, **kw)["image"].numpy(), g["edit_weight_image"], atol=1e-6)
+
+
 def test_state_dict_names_match_reference_checkpoint_layout():
     m = network.PaletteNetwork(renderer.default_opt(pred_clip=True), bound=2, cuda_ray=True)
     keys = set(m.state_dict())

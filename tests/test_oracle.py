@@ -413,3 +413,193 @@ def test_march_train_drops_rays_that_overflow_M(s0):
     assert np.all(deltas[rays[first_over, 1]:M] == 0)  # nothing written for the overflowing ray
     ws, dep, img = oracle.composite_rays_train_forward(np.ones(M, np.float32), np.ones((M, 3), np.float32), deltas, rays)
     assert np.all(ws[rays[over, 0]] == 0)
+
+
+# ------------------------------------------------------------------------------------------ independent formulation of the march
+def _fma32(a, b, c):
+    """Correctly rounded float32 fma in NumPy: the product of two float32 is exact in float64; the float64 sum is corrected with its exact
+    rounding error (TwoSum) when it lands on a float32 rounding midpoint, so that rounding to float32 happens once."""
+    a, b, c = (np.asarray(v, np.float32).astype(np.float64) for v in (a, b, c))
+    p = a * b
+    s = p + c
+    bb = s - p
+    err = (p - (s - bb)) + (c - bb)
+    bits = s.view(np.uint64) if s.ndim else np.array(s).view(np.uint64)
+    mid = (bits & np.uint64(0x1FFFFFFF)) == np.uint64(0x10000000)
+    nudge = mid & (err != 0) & np.isfinite(s)
+    s = np.where(nudge, np.nextafter(s, np.where(err > 0, np.inf, -np.inf)), s)
+    with np.errstate(over="ignore"):
+        return s.astype(np.float32)
+
+
+def _numpy_march(ro, rd, bf, nears, fars, bound, C, H, dt_gamma, max_steps):
+    """All rays advance together, one probe per loop turn (masks instead of per-thread control flow); array arithmetic in float32 with the
+    canonical contractions spelled out through _fma32.  Written from raymarching.cu:340-403 alone: shares no code with oracle/pnr_oracle.c
+    or the HIP kernels.  Returns per-ray counts and the emitted samples (ray, x, y, z, dt, t_after) in per-ray order."""
+    f32 = np.float32
+    o, d = ro.astype(f32), rd.astype(f32)
+    with np.errstate(divide="ignore"):
+        rdir = (f32(1) / d).astype(f32)
+    sgn = np.copysign(f32(1), d).astype(f32)
+    N = o.shape[0]
+    sqrt3 = f32(1.7320508075688772)
+    dt_min = f32(f32(2) * sqrt3 / f32(max_steps))
+    dt_max = f32(f32(f32(2) * sqrt3 * f32(1 << (C - 1))) / f32(H))
+    rH = f32(1) / f32(H)
+    clamp = lambda x, lo, hi: np.fmin(f32(hi), np.fmax(f32(lo), x)).astype(f32)   # fminf / fmaxf drop NaNs exactly like np.fmin / np.fmax
+    t = nears.astype(f32).copy()
+    t = _fma32(clamp(t * f32(dt_gamma), dt_min, dt_max), np.zeros(N, f32), t)   # perturb with noise 0 (kept: it turns -0 / NaN cases the same way)
+    far = fars.astype(f32)
+    count = np.zeros(N, np.int64)
+    out = []
+    with np.errstate(invalid="ignore", over="ignore"):
+        while True:
+            act = np.nonzero((t < far) & (count < max_steps))[0]
+            if act.size == 0:
+                break
+            ta = t[act]
+            p = clamp(_fma32(ta[:, None], d[act], o[act]), -bound, bound)
+            dt = clamp(ta * f32(dt_gamma), dt_min, dt_max)
+            e_pos = np.frexp(np.abs(p).max(1))[1]
+            e_dt = np.frexp((dt * f32(H)).astype(f32) * f32(0.5))[1]
+            level = np.clip(np.maximum(e_pos, e_dt), 0, C - 1).astype(np.int64)
+            mip_bound = np.fmin(np.ldexp(f32(1), level).astype(f32), f32(bound)).astype(f32)
+            mip_rbound = (f32(1) / mip_bound).astype(f32)
+            cell_f = (0.5 * _fma32(p, mip_rbound[:, None], f32(1)).astype(np.float64) * float(H)).astype(f32)     # double intermediate, then float
+            cell = clamp(cell_f, 0.0, float(H - 1)).astype(np.int64)                                                # truncation
+            index = level * H ** 3 + scene.morton3d_np(cell[:, 0], cell[:, 1], cell[:, 2]).astype(np.int64)
+            occ = ((bf[index // 8] >> (index % 8)) & 1).astype(bool)
+            hit = act[occ]
+            t_after = (ta[occ] + dt[occ]).astype(f32)
+            out.append(np.column_stack([hit.astype(np.float64), p[occ].astype(np.float64), dt[occ].astype(np.float64), t_after.astype(np.float64)]))
+            count[hit] += 1
+            t[hit] = t_after
+            miss = ~occ
+            if miss.any():
+                am = act[miss]
+                inner = _fma32(f32(0.5), sgn[am], (cell[miss].astype(f32) + f32(0.5)).astype(f32))
+                inner = (inner * rH).astype(f32)
+                plane = _fma32(_fma32(inner, f32(2), f32(-1)), mip_bound[miss][:, None], -p[miss])
+                txyz = (plane * rdir[am]).astype(f32)
+                tt = (ta[miss] + np.fmax(f32(0), np.fmin(txyz[:, 0], np.fmin(txyz[:, 1], txyz[:, 2])))).astype(f32)
+                tc = ta[miss].copy()
+                go = np.ones(tc.shape, bool)
+                while go.any():   # do { t += clamp(t * dt_gamma, dt_min, dt_max); } while (t < tt);
+                    tc[go] = (tc[go] + clamp(tc[go] * f32(dt_gamma), dt_min, dt_max)).astype(f32)
+                    go &= tc < tt
+                t[am] = tc
+    rows = np.concatenate(out) if out else np.zeros((0, 6))
+    rows = rows[np.argsort(rows[:, 0], kind="stable")]
+    return count, rows
+
+
+@pytest.mark.parametrize("dt_gamma,min_near,HW", [(0.0, 0.2, (40, 30)), (1.0 / 128, 0.02, (32, 24)), (1.0 / 32, 0.2, (20, 20))])
+def test_march_against_an_independent_numpy_formulation(s0, dt_gamma, min_near, HW):
+    """The oracle's march (and with it the HIP kernels, which equal the oracle bit for bit) against a second, array-style statement of
+    raymarching.cu:340-403 that shares no code with it: per-ray counts, positions, step sizes and parameters must be the same bits."""
+    grid, bf = s0
+    ro, rd = _rays(*HW)
+    nears, fars = oracle.near_far_from_aabb(ro, rd, [-2, -2, -2, 2, 2, 2], min_near)
+    cnt = np.zeros(2, np.int32)
+    xyzs, dirs, deltas, rays = oracle.march_rays_train(ro, rd, 2.0, bf, 2, 128, nears, fars, cnt, force_all_rays=True, dt_gamma=dt_gamma)
+    count, rows = _numpy_march(ro, rd, bf, nears, fars, 2.0, 2, 128, dt_gamma, 1024)
+    m = int(cnt[0])
+    assert m > 2000
+    np.testing.assert_array_equal(count, rays[:, 2])                              # per-ray counts: bit-exact
+    assert rows.shape[0] == m
+    np.testing.assert_array_equal(rows[:, 1:4].astype(np.float32), xyzs[:m])      # sample positions
+    np.testing.assert_array_equal(rows[:, 4].astype(np.float32), deltas[:m, 0])   # step sizes
+    np.testing.assert_array_equal(rows[:, 0].astype(np.int64), np.repeat(np.arange(ro.shape[0]), rays[:, 2]))
+
+
+def test_fma32_helper_is_a_correctly_rounded_fma():
+    rng = np.random.default_rng(9)
+    a = rng.standard_normal(200000).astype(np.float32)
+    b = rng.standard_normal(200000).astype(np.float32)
+    c = (-(a.astype(np.float64) * b.astype(np.float64))).astype(np.float32) * np.float32(1 + 2.0 ** -12)   # heavy cancellation
+    want = np.array([np.float32(np.longdouble(x) * np.longdouble(y) + np.longdouble(z)) for x, y, z in zip(a[:20000], b[:20000], c[:20000])])
+    np.testing.assert_array_equal(_fma32(a[:20000], b[:20000], c[:20000]), want)
+    # a constructed double-rounding trap: a*b + c lies just above a float32 midpoint, the float64 sum lands exactly on it
+    a1, b1 = np.float32(1 + 2.0 ** -12), np.float32(1 + 2.0 ** -12)          # product = 1 + 2^-11 + 2^-24 exactly
+    c1 = np.float32(2.0 ** -60)
+    assert _fma32(a1, b1, c1) == np.float32(1 + 2.0 ** -11 + 2.0 ** -23)     # round up (true value is above the midpoint), not to even
+
+
+# ------------------------------------------------------------------------------------------ build variants of the oracle
+def test_oracle_openmp_variant_is_bit_identical(s0):
+    from oracle import orc
+    grid, bf = s0
+    ro, rd = _rays(48, 48)
+    nears, fars = oracle.near_far_from_aabb(ro, rd, [-2, -2, -2, 2, 2, 2], 0.2)
+    N = ro.shape[0]
+    alive = np.arange(N, dtype=np.int32)
+    rng = np.random.default_rng(3)
+    pls = float(np.exp2(np.log2(4096 / 16) / 15))
+    offsets = oracle.grid_offsets(3, 16, pls, 16, 19)
+    emb = (rng.random((int(offsets[-1]), 2)) - 0.5).astype(np.float32)
+
+    def run():
+        x, d, dl = oracle.march_rays(N, 4, alive, nears.copy(), ro, rd, 2.0, bf, 2, 128, nears, fars, align=128)
+        enc = oracle.grid_encode_forward((x + 2) / 4, emb, offsets, pls, 16)
+        sh = oracle.sh_encode_forward(d, 4)
+        ws, dep, img, al, rt = np.zeros(N, np.float32), np.zeros(N, np.float32), np.zeros((N, 3), np.float32), alive.copy(), nears.copy()
+        oracle.composite_rays(N, 4, al, rt, np.abs(enc[:, 0]) * 50, np.abs(enc[:, 1:4]), dl, ws, dep, img, 1e-4)
+        return x, dl, enc, sh, ws, dep, img, al, rt
+
+    a = run()
+    prev = orc.use_variant("omp")
+    try:
+        orc.set_threads(4)
+        b = run()
+    finally:
+        orc.use_variant(prev)
+    for u, v in zip(a, b):
+        np.testing.assert_array_equal(u, v)
+
+
+def test_oracle_without_contraction_reproduces_the_reference_measured_counts(s0):
+    """SURVEY.md Appendix B ran the reference's own kernel_march_rays_train as host code (g++ -ffp-contract=off, i.e. NO fused multiply-adds)
+    on scene S0 at 400 x 400: 88 725 rays with samples, at most 508 per ray, 15 750 694 samples.  The no-FMA build of the oracle is that
+    arithmetic: hitting rays and the per-ray maximum are equal; the total agrees to 3 samples in 15.75 M (the survey's ray generator is not
+    recorded: three fp32 ray generators tried here -- float64 + one rounding, the reference's torch get_rays, the device kernel -- differ in
+    last bits of the directions and move the total by +-5).  The canonical build (explicit fmaf where nvcc contracts) differs from the
+    no-FMA build by 7 samples at this size: that is the whole effect of the contraction choice."""
+    from oracle import orc
+    grid, bf = s0
+    ro, rd = _rays(400, 400)
+    nears, fars = oracle.near_far_from_aabb(ro, rd, [-2, -2, -2, 2, 2, 2], 0.2)
+    res = {}
+    for variant in ("nofma", ""):
+        prev = orc.use_variant(variant)
+        try:
+            cnt = np.zeros(2, np.int32)
+            rays = oracle.march_rays_train(ro, rd, 2.0, bf, 2, 128, nears, fars, cnt, mean_count=1, align=128)[3]   # M tiny: counting pass only
+        finally:
+            orc.use_variant(prev)
+        res[variant] = (int(cnt[0]), int((rays[:, 2] > 0).sum()), int(rays[:, 2].max()))
+    assert res["nofma"][1:] == (88725, 508) and res[""][1:] == (88725, 508)          # Appendix B, exact
+    assert abs(res["nofma"][0] - 15750694) <= 8                                       # Appendix B's total, to the ray generator's last bits
+    assert res["nofma"][0] == 15750697 and res[""][0] == 15750690                     # pinned: the two builds on this repo's deterministic rays
+
+
+# ------------------------------------------------------------------------------------------ RGB histogram: the reference's own compiled code
+def test_rgb_histogram_against_the_reference_build(golden_dir):
+    """tests/golden/hist.npz was produced by palette/src/bindings.cpp:40-91 itself (compiled unmodified, oracle/ref_build.py); when the built
+    module is present it is also called directly.  Integer bin indices and double accumulation in input order: bit-exact."""
+    g = np.load(os.path.join(golden_dir, "hist.npz"))
+    rgb, w = g["colors_rgb"], g["weights"]
+    for bpc in (1, 2, 3, 5):
+        bw, bc = oracle.compute_RGB_histogram(rgb, w, bpc)
+        np.testing.assert_array_equal(bw, g[f"bin_weights_{bpc}"])
+        np.testing.assert_array_equal(bc, g[f"bin_centers_{bpc}"])
+    from oracle import ref_build
+    if ref_build.available():
+        mod = ref_build.load()
+        rng = np.random.default_rng(8)
+        rgb2 = rng.uniform(-0.2, 1.2, (20001, 3)).astype(np.float32)
+        w2 = rng.uniform(0, 1, 20001).astype(np.float32)
+        for bpc in (1, 4, 6):
+            rbw, rbc = mod.compute_RGB_histogram(rgb2.flatten(), w2.flatten(), bpc)
+            bw, bc = oracle.compute_RGB_histogram(rgb2, w2, bpc)
+            np.testing.assert_array_equal(bw, np.asarray(rbw))
+            np.testing.assert_array_equal(bc, np.asarray(rbc))
