@@ -47,7 +47,8 @@ const char* pnr_error_string(int code);
 int pnr_abi_version(void);
 /* run-time switches that change speed only, for A/B measurements and tests: "block_skip" (exact jumps over empty blocks in the march),
  * "aux_fusion" (PaletteNeRF frame loop: aux composite inside the field kernel), "composite_fusion" (NeRF frame loop: iterations with one
- * sample per ray composited inside the field kernel); all default to 1 */
+ * sample per ray composited inside the field kernel); all default to 1.  "adam_variant" (0..7, default 0): which multiply-adds of pnr_adam_step
+ * are left uncontracted (kept for re-deriving the bit-exact form against a new torch build) */
 int pnr_set_option(const char* name, int value);
 
 /* ---------------------------------------------------------------- raymarching: utils ------- */
@@ -404,6 +405,20 @@ int pnr_mlp_backward_lm(const pnr_mlp_desc* desc, const float* packed, const flo
  * workspace of pnr_linear_wgrad_workspace_bytes(B, 1, out_dim) */
 int pnr_linear_bgrad(const void* dy, int dy_dtype, uint32_t B, uint32_t out_dim, float* db, int accumulate, void* workspace, uint64_t workspace_bytes,
                      pnr_stream_t stream);
+
+/* ---------------------------------------------------------------- training: optimiser step -- */
+
+/* torch.optim.Adam (the reference's optimiser: main_nerf.py:113, main_palette.py:223 -- lr 1e-2, betas (0.9, 0.99), eps 1e-15, no weight decay,
+ * no amsgrad) for up to pnr_adam_max_tensors() fp32 tensors in ONE launch: read p, g, m, v -- write p, m, v, once.  Bit-identical to torch's
+ * seven elementwise kernels per tensor (same operations, roundings and contractions; torch/optim/adam.py:_single_tensor_adam).  The scalars are
+ * the ones torch forms on the host, narrowed to fp32 where its kernels narrow them:
+ *   one_minus_beta1 = (float)(1 - beta1), one_minus_beta2 = (float)(1 - beta2), neg_step_size = (float)(-(lr / (1 - beta1^step))),
+ *   inv_bias_correction2_sqrt = 1.0f / (float)((1 - beta2^step) ** 0.5)   (a division by a host scalar is a multiplication by its fp32 reciprocal),
+ *   inv_grad_scale: 1, or 1 / GradScaler's scale to fold `unscale_` into the same pass. */
+typedef struct pnr_adam_tensor { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; uint64_t n; } pnr_adam_tensor;   /* HOST array of device pointers */
+typedef struct pnr_adam_scalars { float one_minus_beta1, beta2, one_minus_beta2, inv_bias_correction2_sqrt, eps, neg_step_size, inv_grad_scale; } pnr_adam_scalars;
+uint32_t pnr_adam_max_tensors(void);
+int pnr_adam_step(const pnr_adam_tensor* tensors, uint32_t count, const pnr_adam_scalars* scalars, pnr_stream_t stream);
 
 /* ---------------------------------------------------------------- ray generation ----------- */
 

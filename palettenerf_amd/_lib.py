@@ -75,11 +75,23 @@ SIGNATURES = {
     "pnr_palette_train_shade_forward": [_u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "pnr_palette_train_shade_backward": [_u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _ptr],
     "pnr_image_to_uint8": [_ptr, _u64, _int, _ptr, _ptr],
+    "pnr_adam_max_tensors": [],
+    "pnr_adam_step": [_ptr, _u32, _ptr, _ptr],
     "pnr_get_rays": [_ptr, _u32, _f32, _f32, _f32, _f32, _u32, _u32, _ptr, _u32, _ptr, _ptr, _ptr],
 }
-_RESTYPES = {"pnr_error_string": ctypes.c_char_p, "pnr_scan_scratch_bytes": _u64, "pnr_nerf_field_packed_bytes": _u64, "pnr_occupancy_mip_bytes": _u64, "pnr_nerf_frame_workspace_bytes": _u64, "pnr_palette_field_packed_bytes": _u64, "pnr_palette_frame_workspace_bytes": _u64,
+_RESTYPES = {"pnr_adam_max_tensors": _u32, "pnr_error_string": ctypes.c_char_p, "pnr_scan_scratch_bytes": _u64, "pnr_nerf_field_packed_bytes": _u64, "pnr_occupancy_mip_bytes": _u64, "pnr_nerf_frame_workspace_bytes": _u64, "pnr_palette_field_packed_bytes": _u64, "pnr_palette_frame_workspace_bytes": _u64,
              "pnr_palette_aux_channels": _u32, "pnr_linear_wgrad_workspace_bytes": _u64, "pnr_grid_backward_binned_workspace_bytes": _u64,
              "pnr_palette_train_shade_workspace_bytes": _u64, "pnr_mlp_packed_bytes": _u64, "pnr_mlp_backward_workspace_bytes": _u64}
+
+class AdamTensor(ctypes.Structure):
+    """Mirror of `pnr_adam_tensor` (include/pnr.h)."""
+    _fields_ = [("param", _ptr), ("grad", _ptr), ("exp_avg", _ptr), ("exp_avg_sq", _ptr), ("n", _u64)]
+
+
+class AdamScalars(ctypes.Structure):
+    """Mirror of `pnr_adam_scalars` (include/pnr.h)."""
+    _fields_ = [(n, _f32) for n in ("one_minus_beta1", "beta2", "one_minus_beta2", "inv_bias_correction2_sqrt", "eps", "neg_step_size", "inv_grad_scale")]
+
 
 class MlpDesc(ctypes.Structure):
     """Mirror of `pnr_mlp_desc` (include/pnr.h)."""

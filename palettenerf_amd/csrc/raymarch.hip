@@ -486,6 +486,7 @@ __global__ void __launch_bounds__(kBlock) k_get_rays(const float* __restrict__ p
 int g_opt_block_skip = getenv("PNR_NO_BLOCK_SKIP") ? 0 : 1;
 int g_opt_aux_fusion = getenv("PNR_NO_AUX_FUSION") ? 0 : 1;
 int g_opt_composite_fusion = getenv("PNR_NO_COMPOSITE_FUSION") ? 0 : 1;
+int g_opt_adam_variant = 0;   // experiment switch of adam.hip (which multiply-adds are contracted); 0 = torch's kernels on this platform
 
 using namespace pnr;
 
@@ -498,6 +499,7 @@ int pnr_set_option(const char* name, int value) {
     if (!strcmp(name, "block_skip")) { g_opt_block_skip = value != 0; return PNR_OK; }
     if (!strcmp(name, "aux_fusion")) { g_opt_aux_fusion = value != 0; return PNR_OK; }
     if (!strcmp(name, "composite_fusion")) { g_opt_composite_fusion = value != 0; return PNR_OK; }
+    if (!strcmp(name, "adam_variant")) { g_opt_adam_variant = value & 7; return PNR_OK; }
     return PNR_ERR_INVALID;
 }
 

@@ -131,7 +131,10 @@ def test_garden_video_frame_native_equals_reference_style_loop(cuda):
         with torch.no_grad():
             out[mode] = m.render(ro, rd, **kw)
     a, b = out["compat"], out["native"]
-    assert int(a["rendered"].sum()) == int(b["rendered"].sum()) > 5_000_000      # same schedule, same compaction, same samples
+    na, nb_ = int(a["rendered"].sum()), int(b["rendered"].sum())
+    # same schedule and compaction; the two loops evaluate sigma with different roundings (rocBLAS fp32 GEMMs vs the fused split-fp16 field),
+    # so a handful of the 31 M samples fall on the other side of the T < 1e-4 termination test
+    assert na > 5_000_000 and abs(na - nb_) <= 1e-5 * na, (na, nb_)
     for k in ("image", "weights_sum", "direct_rgb", "view_dep_rgb", "basis_rgb", "unscaled_basis_rgb", "basis_acc"):
         assert float((a[k] - b[k]).abs().max()) < 1e-4, k
     assert scene.psnr(a["image"], b["image"]) > 80.0
