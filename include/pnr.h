@@ -413,10 +413,11 @@ int pnr_linear_bgrad(const void* dy, int dy_dtype, uint32_t B, uint32_t out_dim,
  * seven elementwise kernels per tensor (same operations, roundings and contractions; torch/optim/adam.py:_single_tensor_adam).  The scalars are
  * the ones torch forms on the host, narrowed to fp32 where its kernels narrow them:
  *   one_minus_beta1 = (float)(1 - beta1), one_minus_beta2 = (float)(1 - beta2), neg_step_size = (float)(-(lr / (1 - beta1^step))),
- *   inv_bias_correction2_sqrt = 1.0f / (float)((1 - beta2^step) ** 0.5)   (a division by a host scalar is a multiplication by its fp32 reciprocal),
+ *   bias_correction2_sqrt = (float)((1 - beta2^step) ** 0.5)   (torch's default foreach implementation divides by it; option "adam_variant" bit 0
+ *   multiplies by its fp32 reciprocal instead, as torch's single-tensor kernels do for a division by a host scalar),
  *   inv_grad_scale: 1, or 1 / GradScaler's scale to fold `unscale_` into the same pass. */
 typedef struct pnr_adam_tensor { float* param; const float* grad; float* exp_avg; float* exp_avg_sq; uint64_t n; } pnr_adam_tensor;   /* HOST array of device pointers */
-typedef struct pnr_adam_scalars { float one_minus_beta1, beta2, one_minus_beta2, inv_bias_correction2_sqrt, eps, neg_step_size, inv_grad_scale; } pnr_adam_scalars;
+typedef struct pnr_adam_scalars { float one_minus_beta1, beta2, one_minus_beta2, bias_correction2_sqrt, eps, neg_step_size, inv_grad_scale; } pnr_adam_scalars;
 uint32_t pnr_adam_max_tensors(void);
 int pnr_adam_step(const pnr_adam_tensor* tensors, uint32_t count, const pnr_adam_scalars* scalars, pnr_stream_t stream);
 

@@ -90,7 +90,7 @@ class AdamTensor(ctypes.Structure):
 
 class AdamScalars(ctypes.Structure):
     """Mirror of `pnr_adam_scalars` (include/pnr.h)."""
-    _fields_ = [(n, _f32) for n in ("one_minus_beta1", "beta2", "one_minus_beta2", "inv_bias_correction2_sqrt", "eps", "neg_step_size", "inv_grad_scale")]
+    _fields_ = [(n, _f32) for n in ("one_minus_beta1", "beta2", "one_minus_beta2", "bias_correction2_sqrt", "eps", "neg_step_size", "inv_grad_scale")]
 
 
 class MlpDesc(ctypes.Structure):

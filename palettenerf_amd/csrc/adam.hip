@@ -3,9 +3,10 @@
 // The reference trains with torch.optim.Adam(lr, betas=(0.9, 0.99), eps=1e-15) (main_nerf.py:113, main_palette.py:223); torch runs it as
 // seven elementwise kernels per parameter tensor (lerp, mul, addcmul, sqrt, mul, add, addcdiv): ~75 launches and seven passes over the
 // 50 MB hash tables per step.  Here every element of every tensor makes one trip: read p, g, m, v -- write p, m, v.
-// The arithmetic is torch's, operation for operation and rounding for rounding (torch/optim/adam.py:_single_tensor_adam with the scalar
-// conventions of its CUDA kernels: division by a host scalar is a multiplication by its fp32 reciprocal, lerp / addcmul / addcdiv contract
-// their last multiply-add), so that a training run is bit-identical to one driven by torch.optim.Adam (tests/test_gpu_ops.py).
+// The arithmetic is torch's, operation for operation and rounding for rounding (torch/optim/adam.py:_multi_tensor_adam, what
+// torch.optim.Adam runs by default on the GPU; the forms its kernels use on this build were measured with profiles/micro/adam_probe.py:
+// lerp = fma(w, g - m, m); addcmul = fma(alpha, g * g, v); division by the fp32 scalar; addcdiv = fma(alpha, m / denom, p)), so that a
+// training run is bit-identical to one driven by torch.optim.Adam (tests/test_gpu_ops.py).
 #include "pnr_common.hpp"
 
 namespace pnr {
@@ -19,7 +20,7 @@ struct AdamTable {
     uint32_t first_chunk[kAdamMaxTensors + 1];   // chunk index at which every tensor starts (prefix sum of ceil(n / kAdamChunk))
     int count;
 };
-struct AdamScalars { float w1, beta2, c2, inv_bc2_sqrt, eps, neg_step_size; float inv_grad_scale; int variant; };
+struct AdamScalars { float w1, beta2, c2, bc2_sqrt, inv_bc2_sqrt, eps, neg_step_size; float inv_grad_scale; int variant; };
 
 __global__ void __launch_bounds__(kAdamThreads) k_adam(AdamTable tab, AdamScalars s) {
     int ti = 0;
@@ -34,12 +35,14 @@ __global__ void __launch_bounds__(kAdamThreads) k_adam(AdamTable tab, AdamScalar
         if (s.inv_grad_scale != 1.0f) g *= s.inv_grad_scale;        // GradScaler.unscale_ folded in (a separate torch kernel otherwise)
         float m = t.m[i], v = t.v[i];
         // exp_avg.lerp_(grad, 1 - beta1): |weight| < 0.5 -> self + weight * (end - self)           (ATen/native/Lerp.h)
-        m = (s.variant & 1) ? m + s.w1 * (g - m) : fmaf(s.w1, g - m, m);
-        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2): a + alpha * b * c          (PointwiseOpsKernel.cu)
+        m = fmaf(s.w1, g - m, m);
+        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2): a + alpha * (b * c), the product b * c rounded first
+        // (PointwiseOpsKernel.cu; which of the candidate forms torch's build uses was measured: profiles/micro/adam_probe.py)
         v = v * s.beta2;
-        v = (s.variant & 2) ? v + (s.c2 * g) * g : fmaf(s.c2 * g, g, v);
-        // denom = (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps): the division by a host scalar multiplies by its reciprocal
-        const float denom = sqrtf(v) * s.inv_bc2_sqrt + s.eps;
+        v = (s.variant & 2) ? fmaf(s.c2 * g, g, v) : fmaf(s.c2, g * g, v);
+        // denom = (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps).  torch's default (foreach) implementation divides by the fp32 scalar;
+        // its single-tensor kernels turn a division by a host scalar into a multiplication by the fp32 reciprocal -- variant bit 0
+        const float denom = ((s.variant & 1) ? sqrtf(v) * s.inv_bc2_sqrt : sqrtf(v) / s.bc2_sqrt) + s.eps;
         // param.addcdiv_(exp_avg, denom, value = -step_size): a + alpha * (b / c)
         const float q = m / denom;
         t.p[i] = (s.variant & 4) ? t.p[i] + s.neg_step_size * q : fmaf(s.neg_step_size, q, t.p[i]);
@@ -77,7 +80,7 @@ int pnr_adam_step(const pnr_adam_tensor* tensors, uint32_t count, const pnr_adam
     tab.first_chunk[used] = (uint32_t)chunks;
     tab.count = used;
     AdamScalars s;
-    s.w1 = sc->one_minus_beta1; s.beta2 = sc->beta2; s.c2 = sc->one_minus_beta2; s.inv_bc2_sqrt = sc->inv_bias_correction2_sqrt; s.eps = sc->eps;
+    s.w1 = sc->one_minus_beta1; s.beta2 = sc->beta2; s.c2 = sc->one_minus_beta2; s.bc2_sqrt = sc->bias_correction2_sqrt; s.inv_bc2_sqrt = 1.0f / sc->bias_correction2_sqrt; s.eps = sc->eps;
     s.neg_step_size = sc->neg_step_size;
     s.inv_grad_scale = sc->inv_grad_scale > 0.0f ? sc->inv_grad_scale : 1.0f;
     s.variant = g_opt_adam_variant;

@@ -55,7 +55,7 @@ class Adam(torch.optim.Optimizer):
                 bias_correction2_sqrt = bias_correction2 ** 0.5
                 sc = _lib.AdamScalars()
                 sc.one_minus_beta1, sc.beta2, sc.one_minus_beta2 = 1 - beta1, beta2, 1 - beta2
-                sc.inv_bias_correction2_sqrt = float(f32(1.0) / f32(bias_correction2_sqrt))
+                sc.bias_correction2_sqrt = bias_correction2_sqrt
                 sc.eps, sc.neg_step_size = group["eps"], -step_size
                 sc.inv_grad_scale = 1.0 if not self.grad_scale else float(f32(1.0) / f32(self.grad_scale))
                 for i in range(0, len(items), cap):

@@ -690,8 +690,8 @@ def test_split_fp16_field_steps_aside_when_activations_can_leave_the_fp16_range(
         m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True, density_scale=100.0, min_near=0.2)
     scene.seed_field_(m, 11)
     with torch.no_grad():
-        m.color_net[0].weight[5].mul_(4.0e5)       # hidden unit 5 of the view-dependent head: activations up to ~1e6
-        m.color_net[1].weight[:, 5].mul_(1.0e-5)   # its consumers scaled back so that the colours stay meaningful
+        m.color_net[0].weight[5].mul_(4.0e6)       # hidden unit 5 of the view-dependent head: activations of several 1e5
+        m.color_net[1].weight[:, 5].mul_(1.0e-6)   # its consumers scaled back so that the colours stay meaningful
     m = m.to(cuda).eval()
     m.density_grid.copy_(torch.from_numpy(scene.brick_density_grid()).to(cuda))
     raymarching.packbits(m.density_grid, 0.5, m.density_bitfield)
@@ -1187,7 +1187,7 @@ def test_fused_adam_is_bit_identical_to_torch_adam(cuda):
             out.append([p.detach().clone() for p in ps] + [opt.state[p][k].clone() for p in ps if len(opt.state[p]) for k in ("exp_avg", "exp_avg_sq")])
         return out, opt
 
-    want, ref_opt = run(torch.optim.Adam)
+    want, ref_opt = run(torch.optim.Adam)            # torch's default on the GPU: the foreach implementation
     matching = []
     for variant in range(8):
         got, my_opt = run(optim.Adam, variant)
