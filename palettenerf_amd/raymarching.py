@@ -164,9 +164,15 @@ class _march_rays_train(Function):
             if align > 0:
                 mean_count += align - mean_count % align
             M = mean_count
-        xyzs = torch.zeros(M, 3, dtype=rays_o.dtype, device=dev)
-        dirs = torch.zeros(M, 3, dtype=rays_o.dtype, device=dev)
-        deltas = torch.zeros(M, 2, dtype=rays_o.dtype, device=dev)
+        sliced = force_all_rays or mean_count <= 0
+        # The reference zero-fills all M = N * max_steps rows (134 MB for 4096 rays) and then keeps the first counter[0] of them
+        # (raymarching.py:205-207, 223-229).  Only rows the caller can see need to be defined: with the slice, the rows in front of the
+        # samples (a counter that did not start at zero) and the alignment tail are cleared below, everything else is written by the kernel;
+        # without the slice (mean_count > 0) all M rows are returned, so they are zero-filled as in the reference.
+        alloc = torch.empty if sliced else torch.zeros
+        xyzs = alloc(M, 3, dtype=rays_o.dtype, device=dev)
+        dirs = alloc(M, 3, dtype=rays_o.dtype, device=dev)
+        deltas = alloc(M, 2, dtype=rays_o.dtype, device=dev)
         rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
         if step_counter is None:
             step_counter = torch.zeros(2, dtype=torch.int32, device=dev)
@@ -176,18 +182,33 @@ class _march_rays_train(Function):
             noises = torch.zeros(N, dtype=rays_o.dtype, device=dev)
         scratch = _scratch(N, dev)
         mip = occupancy_mip(density_bitfield, C, H, bound)
+        start = step_counter[:1].clone() if sliced else None   # where this call's rows begin (read back together with the new counter)
         # the counting pass keeps every sample's ray parameter (N * max_steps floats): the rows are then written without a second walk
         t_store = torch.empty(N * max_steps, dtype=torch.float32, device=dev) if N * max_steps <= T_STORE_MAX else None
-        call("pnr_march_rays_train_mip", ptr(require(rays_o, torch.float32, "rays_o")), ptr(require(rays_d, torch.float32, "rays_d")),
-             ptr(require(density_bitfield, torch.uint8, "density_bitfield")), _f32(bound), _f32(dt_gamma), _u32(max_steps), _u32(N),
-             _u32(C), _u32(H), _u32(M), ptr(require(nears, torch.float32, "nears")), ptr(require(fars, torch.float32, "fars")),
-             ptr(xyzs), ptr(dirs), ptr(deltas), ptr(rays), ptr(require(step_counter, torch.int32, "step_counter")), ptr(noises),
-             ptr(scratch), ptr(mip), ptr(t_store))
-        if force_all_rays or mean_count <= 0:
-            m = step_counter[0].item()
-            if align > 0:
-                m += align - m % align
-            xyzs, dirs, deltas = xyzs[:m], dirs[:m], deltas[:m]
+
+        def launch():
+            call("pnr_march_rays_train_mip", ptr(require(rays_o, torch.float32, "rays_o")), ptr(require(rays_d, torch.float32, "rays_d")),
+                 ptr(require(density_bitfield, torch.uint8, "density_bitfield")), _f32(bound), _f32(dt_gamma), _u32(max_steps), _u32(N),
+                 _u32(C), _u32(H), _u32(M), ptr(require(nears, torch.float32, "nears")), ptr(require(fars, torch.float32, "fars")),
+                 ptr(xyzs), ptr(dirs), ptr(deltas), ptr(rays), ptr(require(step_counter, torch.int32, "step_counter")), ptr(noises),
+                 ptr(scratch), ptr(mip), ptr(t_store))
+
+        launch()
+        if sliced:
+            first, m = torch.cat([start, step_counter[:1]]).tolist()     # ONE host read (the reference's `.item()`, raymarching.py:224)
+            if m > M:   # rays were dropped for lack of room (only possible when the counter did not start at zero): their rows must read as zeros
+                step_counter[0] = first
+                step_counter[1] -= N
+                for buf in (xyzs, dirs, deltas):
+                    buf.zero_()
+                launch()
+            m_al = m + (align - m % align) if align > 0 else m
+            for buf in (xyzs, dirs, deltas):
+                if first > 0:
+                    buf[:min(first, M)].zero_()
+                if m_al > m:
+                    buf[min(m, M):min(m_al, M)].zero_()
+            xyzs, dirs, deltas = xyzs[:m_al], dirs[:m_al], deltas[:m_al]
         return xyzs, dirs, deltas, rays
 
 

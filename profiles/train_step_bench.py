@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--fp16", action="store_true")
     ap.add_argument("--sync-each-step", action="store_true", help="loss.item() every step, as the reference's trainer does")
     ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True): one launch per parameter group instead of seven")
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of palettenerf_amd.optim.Adam (pnr_adam_step: one launch for all tensors, same bits)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     if args.model == "palette":
@@ -45,7 +46,11 @@ def main():
     intr = scene.intrinsics_from_fov(H, W, 0.9)
     ro_all, rd_all = scene.get_rays(torch.from_numpy(np.stack(poses)), intr, H, W)
     ro_all, rd_all = ro_all.to(dev), rd_all.to(dev)
-    opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=args.fused_adam)
+    if args.torch_adam or args.fused_adam or args.fp16:
+        opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=args.fused_adam)
+    else:
+        from palettenerf_amd import optim
+        opt = optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
     scaler = torch.amp.GradScaler("cuda", enabled=args.fp16)
     target = torch.rand(args.rays, 3, device=dev)
 
