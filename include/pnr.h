@@ -217,8 +217,9 @@ typedef struct pnr_nerf_frame_args {
     float* image;                  /* [N,3] out */
     void* workspace;
     uint64_t workspace_bytes;
-    uint64_t* stats;               /* HOST, optional, 5 entries: [iterations, rendered samples, evaluated rows, enqueued iterations,
-                                      host looks at the control block (= stream synchronisations of this frame)] */
+    uint64_t* stats;               /* HOST, optional, 6 entries: [iterations, rendered samples, evaluated rows, enqueued iterations,
+                                      host looks at the control block (= stream synchronisations of this frame),
+                                      1 if watch_overflow saw an operand beyond fp16's range (the frame is then invalid: render it with PNR_FIELD_FP32)] */
     float* kernel_ms;              /* HOST, optional: [0] = summed HIP-event time (ms) of the grid-encode launches that did work,
                                       [1] = their number; events are recorded on `stream` around each launch */
     const int32_t* ray_order;      /* optional permutation of 0..N-1 (device): processing order of the rays, e.g. 8x8 pixel tiles per
@@ -234,6 +235,8 @@ typedef struct pnr_nerf_frame_args {
                                       then reproduces the reference's half interpolation (as pnr_grid_encode_forward with dtype 1) */
     float enc_scale[3];            /* power-of-two prescale of the features of `embeddings` (PaletteNeRF: + embeddings_palette, embeddings_clip) in the
                                       split-fp16 field, see pnr_nerf_field_forward; 0 or 1 = none */
+    int watch_overflow;            /* PNR_FIELD_F16X3 only: the field kernels watch the operands they split for magnitudes beyond fp16's range
+                                      (65 504) and report through stats[5]; for weights whose activations the caller cannot bound (~1 VALU per operand) */
 } pnr_nerf_frame_args;
 uint64_t pnr_nerf_frame_workspace_bytes(uint32_t N);
 int pnr_nerf_render_frame(const pnr_nerf_frame_args* args, pnr_stream_t stream);
@@ -333,6 +336,7 @@ typedef struct pnr_palette_field_args {
     const float* xyzs;             /* [B,3] world positions of the samples: needed by RegionEdit's spatial window (edit->has_mean_xyz) */
     const void* edit_device;       /* internal (frame loop): the edit parameters already on the device; NULL for callers */
     float enc_scale[3];            /* power-of-two prescales of enc / enc_palette / enc_clip in the split-fp16 path (0 or 1 = none) */
+    int32_t* overflow_flag;        /* optional (device): set to 1 when a split-fp16 operand exceeds fp16's range (the kernel then watches its operands) */
 } pnr_palette_field_args;
 int pnr_palette_field_stages_aux(uint32_t num_basis, uint32_t clip_dim, int pred_clip);   /* 1 when the field kernel stages aux rows in LDS (then it can composite them) */
 uint64_t pnr_palette_field_packed_bytes(uint32_t num_basis, uint32_t clip_dim, int pred_clip);

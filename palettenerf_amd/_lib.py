@@ -104,7 +104,7 @@ class NerfFrameArgs(ctypes.Structure):
                 ("C", _u32), ("H", _u32), ("dt_gamma", _f32), ("max_steps", _u32), ("T_thresh", _f32), ("embeddings", _ptr), ("offsets", _ptr),
                 ("num_levels", _u32), ("S", _f32), ("base_resolution", _u32), ("gridtype", _u32), ("packed_weights", _ptr), ("field_precision", _int), ("density_scale", _f32),
                 ("weights_sum", _ptr), ("depth", _ptr), ("image", _ptr), ("workspace", _ptr), ("workspace_bytes", _u64), ("stats", _ptr), ("kernel_ms", _ptr), ("ray_order", _ptr),
-                ("finish", _int), ("bg_color", _f32 * 3), ("bg_map", _ptr), ("table_dtype", _int), ("enc_scale", _f32 * 3)]
+                ("finish", _int), ("bg_color", _f32 * 3), ("bg_map", _ptr), ("table_dtype", _int), ("enc_scale", _f32 * 3), ("watch_overflow", _int)]
 
 
 MAX_BASIS, MAX_CLIP = 10, 32   # PNR_MAX_BASIS, PNR_MAX_CLIP
@@ -136,7 +136,7 @@ class PaletteFieldArgs(ctypes.Structure):
                 ("deltas", _ptr), ("packed", _ptr), ("basis_color", _ptr), ("or_bias", _ptr), ("num_basis", _u32), ("clip_dim", _u32),
                 ("pred_clip", _int), ("density_scale", _f32), ("offsets_weight", _f32), ("view_dep_weight", _f32), ("aux_stride", _u32),
                 ("sigmas", _ptr), ("rgbs", _ptr), ("aux", _ptr), ("rays_alive", _ptr), ("weights_sum", _ptr), ("aux_map", _ptr), ("T_thresh", _f32),
-                ("precision", _int), ("edit", _ptr), ("xyzs", _ptr), ("edit_device", _ptr), ("enc_scale", _f32 * 3)]
+                ("precision", _int), ("edit", _ptr), ("xyzs", _ptr), ("edit_device", _ptr), ("enc_scale", _f32 * 3), ("overflow_flag", _ptr)]
 
 
 _lib = None

@@ -93,6 +93,33 @@ __device__ __forceinline__ void split_frag(const f32x16& a, int half_idx, h8& hi
     for (int j = 0; j < 8; j++) v[j] = a[half_idx * 8 + j];
     split8(v, hi, lo);
 }
+// Overflow watch of the split-fp16 path: fp16 holds magnitudes up to 65 504, a larger operand would be split into (inf, nan).  When the
+// host cannot rule that out from the weights (fused.py: static activation bound), the CHECK = true instantiations remember the largest
+// |operand| they split (integer max on the bit patterns, ~1 VALU per operand) and raise a flag; the frame is then rendered again on the
+// exact fp32 path.  CHECK = false compiles to nothing.
+constexpr int kF16MaxBits = 0x477FE000;   // 65504.0f
+template <bool CHECK> struct SplitWatch;
+template <> struct SplitWatch<false> {
+    __device__ __forceinline__ void see(const float*) {}
+    __device__ __forceinline__ bool overflowed() const { return false; }
+};
+template <> struct SplitWatch<true> {
+    int mx = 0;
+    __device__ __forceinline__ void see(const float v[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) mx = max(max(mx, __float_as_int(v[j]) & 0x7fffffff), __float_as_int(v[j + 1]) & 0x7fffffff);   // NaN patterns are larger still
+    }
+    __device__ __forceinline__ bool overflowed() const { return mx > kF16MaxBits; }
+};
+template <bool CHECK>
+__device__ __forceinline__ void split_frag_w(SplitWatch<CHECK>& sw, const f32x16& a, int half_idx, h8& hi, h8& lo) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = a[half_idx * 8 + j];
+    sw.see(v);
+    split8(v, hi, lo);
+}
+
 __device__ __forceinline__ f32x16 mma3(f32x16 acc, const unsigned char* __restrict__ wblock, const h8& bhi, const h8& blo, int lane) {
     const h8 ahi = *reinterpret_cast<const h8*>(wblock + lane * 16);
     const h8 alo = *reinterpret_cast<const h8*>(wblock + 1024 + lane * 16);
@@ -112,20 +139,20 @@ template <int PREC> struct BOp;
 template <> struct BOp<1> { h8 hi, lo; };
 template <> struct BOp<0> { float v[8]; };
 
-template <int PREC> __device__ __forceinline__ BOp<PREC> make_op(const float v[8]) {
+template <int PREC, bool CHECK = false> __device__ __forceinline__ BOp<PREC> make_op(const float v[8], SplitWatch<CHECK>* sw = nullptr) {
     BOp<PREC> o;
-    if constexpr (PREC == 1) split8(v, o.hi, o.lo);
+    if constexpr (PREC == 1) { if constexpr (CHECK) sw->see(v); split8(v, o.hi, o.lo); }
     else {
 #pragma unroll
         for (int j = 0; j < 8; j++) o.v[j] = v[j];
     }
     return o;
 }
-template <int PREC> __device__ __forceinline__ BOp<PREC> frag_op(const f32x16& a, int half_idx) {
+template <int PREC, bool CHECK = false> __device__ __forceinline__ BOp<PREC> frag_op(const f32x16& a, int half_idx, SplitWatch<CHECK>* sw = nullptr) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) v[j] = a[half_idx * 8 + j];
-    return make_op<PREC>(v);
+    return make_op<PREC, CHECK>(v, sw);
 }
 template <int PREC> __device__ __forceinline__ f32x16 mma_blk(f32x16 acc, const unsigned char* __restrict__ wblock, const BOp<PREC>& b, int lane) {
     if constexpr (PREC == 1) return mma3(acc, wblock, b.hi, b.lo, lane);
@@ -143,8 +170,10 @@ struct FieldOut { float sigma_logit, o0, o1, o2; };
 // enc_scale: a power of two (1 = none) the encoder features are multiplied by before they are split into fp16 pairs, and sigma_net's 16
 // outputs divided by afterwards -- exact, since the bias-free ReLU stack is positively homogeneous.  It keeps the `lo` halves of very small
 // features (hash tables at the reference's initialisation scale U(-1e-4, 1e-4), gridencoder/grid.py:107) out of the fp16 subnormal range.
+template <bool CHECK>
 __device__ __forceinline__ FieldOut nerf_field_tile_f16x3(const unsigned char* __restrict__ w, int lane, bool valid, const float* __restrict__ enc,
-                                                          size_t level_stride, uint32_t row, float dx, float dy, float dz, float enc_scale) {
+                                                          size_t level_stride, uint32_t row, float dx, float dy, float dz, float enc_scale,
+                                                          SplitWatch<CHECK>& sw) {
     const int h = lane >> 5;
     h8 bh[4], bl[4];
     {   // sigma_net[0] inputs: k-block kb, element j  <-  encoder feature 16 kb + 8 h + j  = (level 8 kb + 4 h + j/2, channel j&1)
@@ -161,6 +190,7 @@ __device__ __forceinline__ FieldOut nerf_field_tile_f16x3(const unsigned char* _
 #pragma unroll
             for (int j = 0; j < 8; j++) { x[0][j] *= enc_scale; x[1][j] *= enc_scale; }
         }
+        sw.see(x[0]); sw.see(x[1]);
         split8(x[0], bh[0], bl[0]);
         split8(x[1], bh[1], bl[1]);
     }
@@ -173,8 +203,8 @@ __device__ __forceinline__ FieldOut nerf_field_tile_f16x3(const unsigned char* _
     h0 = relu16(h0); h1 = relu16(h1);
 
     // sigma_net[1]: 64 -> 16
-    split_frag(h0, 0, bh[0], bl[0]); split_frag(h0, 1, bh[1], bl[1]);
-    split_frag(h1, 0, bh[2], bl[2]); split_frag(h1, 1, bh[3], bl[3]);
+    split_frag_w(sw, h0, 0, bh[0], bl[0]); split_frag_w(sw, h0, 1, bh[1], bl[1]);
+    split_frag_w(sw, h1, 0, bh[2], bl[2]); split_frag_w(sw, h1, 1, bh[3], bl[3]);
     f32x16 g = zero16();
 #pragma unroll
     for (int kb = 0; kb < 4; kb++) g = mma3(g, w + (4 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
@@ -196,7 +226,7 @@ __device__ __forceinline__ FieldOut nerf_field_tile_f16x3(const unsigned char* _
         for (int j = 0; j < 8; j++) v[j] = select_half(h, sh[j], sh[8 + j]);
         split8(v, bh[0], bl[0]);
     }
-    split_frag(g, 0, bh[1], bl[1]);
+    split_frag_w(sw, g, 0, bh[1], bl[1]);
     f32x16 c0 = zero16(), c1 = zero16();
     c0 = mma3(c0, w + 8 * kF16BlockBytes, bh[0], bl[0], lane);
     c0 = mma3(c0, w + 9 * kF16BlockBytes, bh[1], bl[1], lane);
@@ -206,8 +236,8 @@ __device__ __forceinline__ FieldOut nerf_field_tile_f16x3(const unsigned char* _
     c0 = relu16(c0); c1 = relu16(c1);
 
     // color_net[1]: 64 -> 64
-    split_frag(c0, 0, bh[0], bl[0]); split_frag(c0, 1, bh[1], bl[1]);
-    split_frag(c1, 0, bh[2], bl[2]); split_frag(c1, 1, bh[3], bl[3]);
+    split_frag_w(sw, c0, 0, bh[0], bl[0]); split_frag_w(sw, c0, 1, bh[1], bl[1]);
+    split_frag_w(sw, c1, 0, bh[2], bl[2]); split_frag_w(sw, c1, 1, bh[3], bl[3]);
     f32x16 d0 = zero16(), d1 = zero16();
 #pragma unroll
     for (int kb = 0; kb < 4; kb++) d0 = mma3(d0, w + (12 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
@@ -217,8 +247,8 @@ __device__ __forceinline__ FieldOut nerf_field_tile_f16x3(const unsigned char* _
     d0 = relu16(d0); d1 = relu16(d1);
 
     // color_net[2]: 64 -> 3
-    split_frag(d0, 0, bh[0], bl[0]); split_frag(d0, 1, bh[1], bl[1]);
-    split_frag(d1, 0, bh[2], bl[2]); split_frag(d1, 1, bh[3], bl[3]);
+    split_frag_w(sw, d0, 0, bh[0], bl[0]); split_frag_w(sw, d0, 1, bh[1], bl[1]);
+    split_frag_w(sw, d1, 0, bh[2], bl[2]); split_frag_w(sw, d1, 1, bh[3], bl[3]);
     f32x16 o = zero16();
 #pragma unroll
     for (int kb = 0; kb < 4; kb++) o = mma3(o, w + (20 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
@@ -338,11 +368,17 @@ __device__ __forceinline__ f32x16 nerf_density_tile(const float* __restrict__ wf
     return g;
 }
 
+template <int PREC, bool CHECK = false>
+__device__ __forceinline__ FieldOut nerf_field_tile(const float* __restrict__ w, int lane, bool valid, const float* __restrict__ enc,
+                                                    size_t level_stride, uint32_t row, float dx, float dy, float dz, float enc_scale, SplitWatch<CHECK>& sw) {
+    if constexpr (PREC == 0) return nerf_field_tile_f32(w, lane, valid, enc, level_stride, row, dx, dy, dz);   // exact fp32: no scaling needed
+    else return nerf_field_tile_f16x3<CHECK>(reinterpret_cast<const unsigned char*>(w), lane, valid, enc, level_stride, row, dx, dy, dz, enc_scale, sw);
+}
 template <int PREC>
 __device__ __forceinline__ FieldOut nerf_field_tile(const float* __restrict__ w, int lane, bool valid, const float* __restrict__ enc,
                                                     size_t level_stride, uint32_t row, float dx, float dy, float dz, float enc_scale = 1.0f) {
-    if constexpr (PREC == 0) return nerf_field_tile_f32(w, lane, valid, enc, level_stride, row, dx, dy, dz);   // exact fp32: no scaling needed
-    else return nerf_field_tile_f16x3(reinterpret_cast<const unsigned char*>(w), lane, valid, enc, level_stride, row, dx, dy, dz, enc_scale);
+    SplitWatch<false> sw;
+    return nerf_field_tile<PREC, false>(w, lane, valid, enc, level_stride, row, dx, dy, dz, enc_scale, sw);
 }
 
 }  // namespace pnr

@@ -57,6 +57,7 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_init(uint32_t N, const floa
         FrameCtl c = {};
         c.n_alive = (int32_t)N; c.n_step = 0; c.iterations = -1; c.done = N == 0;
         ctl[0] = c; ctl[1] = c;
+        counts[1 - (int)kHdr] = 0;   // scratch[1]: the fp16-range overflow flag of this frame
     }
 }
 
@@ -162,6 +163,7 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_march(const FrameCtl* __res
             c.n_alive = (int32_t)n_alive;
             c.n_step = (int32_t)n_step;
             c.done = done;
+            c.pad0 = scratch[1];   // fp16-range overflow flag raised by a field launch of an earlier iteration (0 = none)
             *cur = c;
         }
     }
@@ -527,7 +529,8 @@ constexpr int kFieldThreads = 512;
 // right here by the lanes that hold the sample's sigma and rgb (`fuse`): same operations in the same order as k_frame_composite's
 // phase 2 on the same values (what it would re-read from sigmas / rgbs), including the per-chunk survivor counts of the compaction --
 // a 256-sample tile IS chunk `tile` of the alive list.  k_frame_composite returns at once on such iterations.
-template <int PREC>
+// CHECK (split-fp16 only): watch the split operands for magnitudes beyond fp16's range and raise scratch[1] (SplitWatch, field_core.hpp)
+template <int PREC, bool CHECK>
 __global__ void __launch_bounds__(kFieldThreads) k_frame_field(const FrameCtl* __restrict__ ctl, const float* __restrict__ enc, uint32_t level_stride,
                                                                const float* __restrict__ dirs, const float* __restrict__ deltas,
                                                                const float* __restrict__ packed, float density_scale, float enc_scale, float* __restrict__ sigmas,
@@ -554,7 +557,9 @@ __global__ void __launch_bounds__(kFieldThreads) k_frame_field(const FrameCtl* _
             const uint32_t nc = n < B ? n : (B - 1);
             float dx = 0.0f, dy = 0.0f, dz = 0.0f;
             if (valid) { dx = dirs[(size_t)nc * 3]; dy = dirs[(size_t)nc * 3 + 1]; dz = dirs[(size_t)nc * 3 + 2]; }
-            o = nerf_field_tile<PREC>(w, lane, valid, enc, level_stride, nc, dx, dy, dz, enc_scale);
+            SplitWatch<CHECK> sw;
+            o = nerf_field_tile<PREC, CHECK>(w, lane, valid, enc, level_stride, nc, dx, dy, dz, enc_scale, sw);
+            if constexpr (CHECK) { if (sw.overflowed()) scratch[1] = 1; }
         }
         float sigma = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
         if (valid && h == 0) {
@@ -819,6 +824,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
         pf.view_dep_weight = pal->view_dep_weight; pf.aux_stride = aux_stride; pf.sigmas = w.sigmas; pf.rgbs = w.rgbs; pf.aux = w.aux;
         pf.precision = a->field_precision; pf.xyzs = w.xyzs;
         for (int k = 0; k < 3; k++) pf.enc_scale[k] = a->enc_scale[k];
+        pf.overflow_flag = a->watch_overflow ? w.scratch + 1 : nullptr;
         if (pal->edit && pal->edit->mode != 0) {   // RegionEdit / Stylizer: parameters uploaded once for the whole frame
             const int rc = pnr_internal_edit_upload(pal->edit, w.edit, s);
             if (rc != PNR_OK) return rc;
@@ -908,11 +914,15 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
                 const int rc = pnr_palette_field_forward(&pf, stream);
                 if (rc != PNR_OK) return rc;
             } else if (a->field_precision == PNR_FIELD_FP32)
-                hipLaunchKernelGGL(k_frame_field<0>, dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas,
+                hipLaunchKernelGGL((k_frame_field<0, false>), dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas,
+                                   a->packed_weights, a->density_scale, enc_scale, w.sigmas, w.rgbs, composite_fused, a->T_thresh, alive_in, w.rays_t, out_ws, out_depth,
+                                   out_image, w.scratch);
+            else if (a->watch_overflow)
+                hipLaunchKernelGGL((k_frame_field<1, true>), dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas,
                                    a->packed_weights, a->density_scale, enc_scale, w.sigmas, w.rgbs, composite_fused, a->T_thresh, alive_in, w.rays_t, out_ws, out_depth,
                                    out_image, w.scratch);
             else
-                hipLaunchKernelGGL(k_frame_field<1>, dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas,
+                hipLaunchKernelGGL((k_frame_field<1, false>), dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas,
                                    a->packed_weights, a->density_scale, enc_scale, w.sigmas, w.rgbs, composite_fused, a->T_thresh, alive_in, w.rays_t, out_ws, out_depth,
                                    out_image, w.scratch);
             hipLaunchKernelGGL(k_frame_composite, gm, bm, 0, s, cur, a->T_thresh, alive_in, w.rays_t, w.sigmas, w.rgbs, w.deltas, out_ws, out_depth, out_image,
@@ -958,6 +968,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
         a->stats[2] = host_ctl->rows;
         a->stats[3] = (uint64_t)iter;  // iterations enqueued (>= executed)
         a->stats[4] = (uint64_t)looks + 1;  // host looks at the control block (stream synchronisations) this frame took
+        a->stats[5] = (uint64_t)(host_ctl->pad0 != 0);  // an operand of the split-fp16 field left fp16's range (watch_overflow): render again in fp32
     }
     return check_launch();
 }

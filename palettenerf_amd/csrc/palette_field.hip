@@ -107,12 +107,12 @@ __device__ __forceinline__ void load_enc_raw(const float* __restrict__ enc, size
         }
 }
 // 64 -> N layer from two activation tiles: 4 k-blocks starting at block q0
-template <int PREC>
-__device__ __forceinline__ f32x16 dense64(f32x16 acc, const unsigned char* __restrict__ w, int q0, const f32x16& a0, const f32x16& a1, int lane) {
-    acc = mma_blk<PREC>(acc, w + (q0 + 0) * kF16BlockBytes, frag_op<PREC>(a0, 0), lane);
-    acc = mma_blk<PREC>(acc, w + (q0 + 1) * kF16BlockBytes, frag_op<PREC>(a0, 1), lane);
-    acc = mma_blk<PREC>(acc, w + (q0 + 2) * kF16BlockBytes, frag_op<PREC>(a1, 0), lane);
-    acc = mma_blk<PREC>(acc, w + (q0 + 3) * kF16BlockBytes, frag_op<PREC>(a1, 1), lane);
+template <int PREC, bool CHECK>
+__device__ __forceinline__ f32x16 dense64(f32x16 acc, const unsigned char* __restrict__ w, int q0, const f32x16& a0, const f32x16& a1, int lane, SplitWatch<CHECK>* sw) {
+    acc = mma_blk<PREC>(acc, w + (q0 + 0) * kF16BlockBytes, frag_op<PREC, CHECK>(a0, 0, sw), lane);
+    acc = mma_blk<PREC>(acc, w + (q0 + 1) * kF16BlockBytes, frag_op<PREC, CHECK>(a0, 1, sw), lane);
+    acc = mma_blk<PREC>(acc, w + (q0 + 2) * kF16BlockBytes, frag_op<PREC, CHECK>(a1, 0, sw), lane);
+    acc = mma_blk<PREC>(acc, w + (q0 + 3) * kF16BlockBytes, frag_op<PREC, CHECK>(a1, 1, sw), lane);
     __builtin_amdgcn_sched_barrier(0);
     return acc;
 }
@@ -154,8 +154,8 @@ struct FrameCtlView { int32_t n_alive, n_step, step, done; };
 __device__ __forceinline__ float torch_lerp(float a, float b, float w) { const float d = b - a; return w < 0.5f ? a + w * d : b - d * (1.0f - w); }
 
 // EDIT: 0 plain composite, 1 RegionEdit, 2 Stylizer (pnr_palette_edit.mode); separate instantiations keep the HSV / double-fmod code
-// and the extra parameters out of the plain kernel
-template <int PREC, int EDIT>
+// and the extra parameters out of the plain kernel.  CHECK: watch the split operands for magnitudes beyond fp16's range (SplitWatch)
+template <int PREC, int EDIT, bool CHECK>
 __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCtlView* __restrict__ ctl, uint32_t B_arg, const float* __restrict__ enc,
                                                                    const float* __restrict__ enc_pal, const float* __restrict__ enc_clip,
                                                                    uint32_t level_stride, const float* __restrict__ dirs,
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
                                                                    float* __restrict__ rgbs, float* __restrict__ aux, uint32_t stage_stride,
                                                                    const int32_t* __restrict__ rays_alive, const float* __restrict__ weights_sum,
                                                                    float* __restrict__ aux_map, float T_thresh, const float* __restrict__ xyzs,
-                                                                   const EditParams* __restrict__ ep) {
+                                                                   const EditParams* __restrict__ ep, int32_t* __restrict__ overflow_flag) {
     if (ctl && ctl->done) return;
     const uint32_t B = ctl ? (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step : B_arg;
     const uint32_t ntiles = (B + 255) / 256;
@@ -185,6 +185,7 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
         if (!__any(valid)) continue;
         const uint32_t row = n < B ? n : (B - 1);
 
+        SplitWatch<CHECK> sw_, *sw = &sw_;
         // all global reads of the tile up front
         float xs[2][8], xp[2][8];
         load_enc_raw(enc, level_stride, row, valid, h, xs);
@@ -197,7 +198,7 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
         if (pre_s) scale8x2(xs, pp.enc_scale[0]);
         f32x16 t0 = zero16(), t1 = zero16();
         {
-            const BOp<PREC> b0 = make_op<PREC>(xs[0]), b1 = make_op<PREC>(xs[1]);
+            const BOp<PREC> b0 = make_op<PREC, CHECK>(xs[0], sw), b1 = make_op<PREC, CHECK>(xs[1], sw);
             t0 = mma_blk<PREC>(t0, w + (PB_S0 + 0) * kF16BlockBytes, b0, lane);
             t0 = mma_blk<PREC>(t0, w + (PB_S0 + 1) * kF16BlockBytes, b1, lane);
             t1 = mma_blk<PREC>(t1, w + (PB_S0 + 2) * kF16BlockBytes, b0, lane);
@@ -205,20 +206,20 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
         }
         __builtin_amdgcn_sched_barrier(0);
         t0 = relu16(t0); t1 = relu16(t1);
-        f32x16 g = dense64<PREC>(zero16(), w, PB_S1, t0, t1, lane);   // rows 0..15: sigma logit, geo_feat 1..15
+        f32x16 g = dense64<PREC, CHECK>(zero16(), w, PB_S1, t0, t1, lane, sw);   // rows 0..15: sigma logit, geo_feat 1..15
         if (pre_s) g = scale16(g, 1.0f / pp.enc_scale[0]);
         const float sigma_logit = g[0];
-        const BOp<PREC> geo = frag_op<PREC>(g, 0);                           // the geo k-block, shared by diff_net and color_net
+        const BOp<PREC> geo = frag_op<PREC, CHECK>(g, 0, sw);                           // the geo k-block, shared by diff_net and color_net
 
         // ---------------- diff_net: 15 -> 64 -> 64 -> 3
         t0 = mma_blk<PREC>(zero16(), w + (PB_D0 + 0) * kF16BlockBytes, geo, lane);
         t1 = mma_blk<PREC>(zero16(), w + (PB_D0 + 1) * kF16BlockBytes, geo, lane);
         __builtin_amdgcn_sched_barrier(0);
         t0 = relu16(t0); t1 = relu16(t1);
-        f32x16 u0 = dense64<PREC>(zero16(), w, PB_D1, t0, t1, lane);
-        f32x16 u1 = dense64<PREC>(zero16(), w, PB_D1 + 4, t0, t1, lane);
+        f32x16 u0 = dense64<PREC, CHECK>(zero16(), w, PB_D1, t0, t1, lane, sw);
+        f32x16 u1 = dense64<PREC, CHECK>(zero16(), w, PB_D1 + 4, t0, t1, lane, sw);
         u0 = relu16(u0); u1 = relu16(u1);
-        const f32x16 dif = dense64<PREC>(zero16(), w, PB_D2, u0, u1, lane);  // rows 0..2
+        const f32x16 dif = dense64<PREC, CHECK>(zero16(), w, PB_D2, u0, u1, lane, sw);  // rows 0..2
         const float diffuse[3] = {sigmoidf(dif[0]), sigmoidf(dif[1]), sigmoidf(dif[2])};
 
         // ---------------- color_net (view dependent): [SH16 ; geo15] -> 64 -> 64 -> 3
@@ -227,7 +228,7 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
             sh_eval<4>(dx, dy, dz, sh);
 #pragma unroll
             for (int j = 0; j < 8; j++) v[j] = select_half(h, sh[j], sh[8 + j]);
-            const BOp<PREC> shb = make_op<PREC>(v);
+            const BOp<PREC> shb = make_op<PREC, CHECK>(v, sw);
             t0 = mma_blk<PREC>(zero16(), w + (PB_C0 + 0) * kF16BlockBytes, shb, lane);
             t0 = mma_blk<PREC>(t0, w + (PB_C0 + 1) * kF16BlockBytes, geo, lane);
             t1 = mma_blk<PREC>(zero16(), w + (PB_C0 + 2) * kF16BlockBytes, shb, lane);
@@ -235,19 +236,19 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
         }
         __builtin_amdgcn_sched_barrier(0);
         t0 = relu16(t0); t1 = relu16(t1);
-        u0 = dense64<PREC>(zero16(), w, PB_C1, t0, t1, lane);
-        u1 = dense64<PREC>(zero16(), w, PB_C1 + 4, t0, t1, lane);
+        u0 = dense64<PREC, CHECK>(zero16(), w, PB_C1, t0, t1, lane, sw);
+        u1 = dense64<PREC, CHECK>(zero16(), w, PB_C1 + 4, t0, t1, lane, sw);
         u0 = relu16(u0); u1 = relu16(u1);
-        const f32x16 vdt = dense64<PREC>(zero16(), w, PB_C2, u0, u1, lane);
+        const f32x16 vdt = dense64<PREC, CHECK>(zero16(), w, PB_C2, u0, u1, lane, sw);
         const float view_dep[3] = {sigmoidf(vdt[0]), sigmoidf(vdt[1]), sigmoidf(vdt[2])};
 
         // ---------------- basis_net: [enc_palette(32) ; diffuse(3)] -> 64 (ELU) -> 15
         {
             const float ps = pre_p ? pp.enc_scale[1] : 1.0f;   // the whole 35-wide input row is scaled; the ELU needs the true pre-activations back
             if (pre_p) scale8x2(xp, ps);
-            const BOp<PREC> b0 = make_op<PREC>(xp[0]), b1 = make_op<PREC>(xp[1]);
+            const BOp<PREC> b0 = make_op<PREC, CHECK>(xp[0], sw), b1 = make_op<PREC, CHECK>(xp[1], sw);
             const float v[8] = {diffuse[0] * ps, diffuse[1] * ps, diffuse[2] * ps, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // read by the lower half-wave only (zero weights elsewhere)
-            const BOp<PREC> db = make_op<PREC>(v);
+            const BOp<PREC> db = make_op<PREC, CHECK>(v, sw);
             t0 = mma_blk<PREC>(zero16(), w + (PB_B0 + 0) * kF16BlockBytes, b0, lane);
             t0 = mma_blk<PREC>(t0, w + (PB_B0 + 1) * kF16BlockBytes, b1, lane);
             t0 = mma_blk<PREC>(t0, w + (PB_B0 + 2) * kF16BlockBytes, db, lane);
@@ -258,10 +259,10 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
         __builtin_amdgcn_sched_barrier(0);
         if (pre_p) { t0 = scale16(t0, 1.0f / pp.enc_scale[1]); t1 = scale16(t1, 1.0f / pp.enc_scale[1]); }
         t0 = elu16(t0); t1 = elu16(t1);
-        const f32x16 p = dense64<PREC>(zero16(), w, PB_B1, t0, t1, lane);   // rows 0..14
+        const f32x16 p = dense64<PREC, CHECK>(zero16(), w, PB_B1, t0, t1, lane, sw);   // rows 0..14
 
         // ---------------- offsets_radiance_net (bias) and omega_net, rows placed in the lower half-wave (outputs 16.. in a second tile)
-        const BOp<PREC> pb = frag_op<PREC>(p, 0);
+        const BOp<PREC> pb = frag_op<PREC, CHECK>(p, 0, sw);
         f32x16 orr = zero16(), orr2 = zero16();
         if (h == 0) {
 #pragma unroll
@@ -278,15 +279,15 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
             float xc[2][8];
             load_enc_raw(enc_clip, level_stride, row, valid, h, xc);
             if (pre_c) scale8x2(xc, pp.enc_scale[2]);
-            const BOp<PREC> b0 = make_op<PREC>(xc[0]), b1 = make_op<PREC>(xc[1]);
+            const BOp<PREC> b0 = make_op<PREC, CHECK>(xc[0], sw), b1 = make_op<PREC, CHECK>(xc[1], sw);
             t0 = mma_blk<PREC>(zero16(), w + (PB_CL0 + 0) * kF16BlockBytes, b0, lane);
             t0 = mma_blk<PREC>(t0, w + (PB_CL0 + 1) * kF16BlockBytes, b1, lane);
             t1 = mma_blk<PREC>(zero16(), w + (PB_CL0 + 2) * kF16BlockBytes, b0, lane);
             t1 = mma_blk<PREC>(t1, w + (PB_CL0 + 3) * kF16BlockBytes, b1, lane);
             __builtin_amdgcn_sched_barrier(0);
             t0 = relu16(t0); t1 = relu16(t1);
-            clip = dense64<PREC>(zero16(), w, PB_CL1, t0, t1, lane);
-            if (pp.clip_dim > 16) clip2 = dense64<PREC>(zero16(), w, PB_CL1B, t0, t1, lane);
+            clip = dense64<PREC, CHECK>(zero16(), w, PB_CL1, t0, t1, lane, sw);
+            if (pp.clip_dim > 16) clip2 = dense64<PREC, CHECK>(zero16(), w, PB_CL1B, t0, t1, lane, sw);
             if (pre_c) { clip = scale16(clip, 1.0f / pp.enc_scale[2]); clip2 = scale16(clip2, 1.0f / pp.enc_scale[2]); }
         }
 
@@ -378,6 +379,7 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
 #pragma unroll
             for (int k = 0; k < 3; k++) rgbs[(size_t)n * 3 + k] = rgb[k] + kvd * view_dep[k];
         }
+        if constexpr (CHECK) { if (overflow_flag && sw_.overflowed()) *overflow_flag = 1; }
         if (stage_stride) {   // same wave wrote the slab: DS operations of a wave complete in order
             float* slab = reinterpret_cast<float*>(w + packed_bytes) + (size_t)wave * 32 * stage_stride;
             const uint32_t n0 = tile * 256 + wave * 32, nq = (uint32_t)pp.aux_stride / 4, S = (uint32_t)pp.aux_stride;
@@ -564,20 +566,22 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
         if (hipMemcpyAsync(ring.dev + slot, &e, sizeof(EditParams), hipMemcpyHostToDevice, s) != hipSuccess) return PNR_ERR_LAUNCH;
         ep_dev = ring.dev + slot;
     }
-    static bool attr_set[2][3][kMaxDevices] = {};
-#define PNR_LAUNCH_PAL(PREC, EDIT)                                                                                                             \
+    static bool attr_set[4][3][kMaxDevices] = {};   // [PREC + 2 * CHECK][EDIT]
+#define PNR_LAUNCH_PAL(PREC, EDIT, CHECK)                                                                                                      \
     do {                                                                                                                                       \
-        if (!ensure_dynamic_lds(k_palette_field_fwd<PREC, EDIT>, kLdsLimit, attr_set[PREC][EDIT])) return PNR_ERR_LAUNCH;                      \
-        hipLaunchKernelGGL((k_palette_field_fwd<PREC, EDIT>), dim3(grid), dim3(kPalThreads), lds, s, static_cast<const FrameCtlView*>(a->ctl), \
-                           a->B, a->enc, a->enc_palette, a->enc_clip, a->level_stride, a->dirs, a->deltas,                                     \
-                           static_cast<const unsigned char*>(a->packed), packed_bytes, pp, a->sigmas, a->rgbs, a->aux, stage_stride,           \
-                           fuse ? a->rays_alive : nullptr, fuse ? a->weights_sum : nullptr, fuse ? a->aux_map : nullptr, a->T_thresh, a->xyzs, \
-                           ep_dev);                                                                                                            \
+        if (!ensure_dynamic_lds(k_palette_field_fwd<PREC, EDIT, CHECK>, kLdsLimit, attr_set[PREC + (CHECK ? 2 : 0)][EDIT])) return PNR_ERR_LAUNCH; \
+        hipLaunchKernelGGL((k_palette_field_fwd<PREC, EDIT, CHECK>), dim3(grid), dim3(kPalThreads), lds, s,                                    \
+                           static_cast<const FrameCtlView*>(a->ctl), a->B, a->enc, a->enc_palette, a->enc_clip, a->level_stride, a->dirs,      \
+                           a->deltas, static_cast<const unsigned char*>(a->packed), packed_bytes, pp, a->sigmas, a->rgbs, a->aux,              \
+                           stage_stride, fuse ? a->rays_alive : nullptr, fuse ? a->weights_sum : nullptr, fuse ? a->aux_map : nullptr,         \
+                           a->T_thresh, a->xyzs, ep_dev, a->overflow_flag);                                                                    \
     } while (0)
-    if (a->precision == PNR_FIELD_F16X3) {
-        if (edit_mode == 0) PNR_LAUNCH_PAL(1, 0); else if (edit_mode == 1) PNR_LAUNCH_PAL(1, 1); else PNR_LAUNCH_PAL(1, 2);
+    if (a->precision == PNR_FIELD_F16X3 && a->overflow_flag) {   // the instantiation that watches its split operands
+        if (edit_mode == 0) PNR_LAUNCH_PAL(1, 0, true); else if (edit_mode == 1) PNR_LAUNCH_PAL(1, 1, true); else PNR_LAUNCH_PAL(1, 2, true);
+    } else if (a->precision == PNR_FIELD_F16X3) {
+        if (edit_mode == 0) PNR_LAUNCH_PAL(1, 0, false); else if (edit_mode == 1) PNR_LAUNCH_PAL(1, 1, false); else PNR_LAUNCH_PAL(1, 2, false);
     } else {
-        if (edit_mode == 0) PNR_LAUNCH_PAL(0, 0); else if (edit_mode == 1) PNR_LAUNCH_PAL(0, 1); else PNR_LAUNCH_PAL(0, 2);
+        if (edit_mode == 0) PNR_LAUNCH_PAL(0, 0, false); else if (edit_mode == 1) PNR_LAUNCH_PAL(0, 1, false); else PNR_LAUNCH_PAL(0, 2, false);
     }
 #undef PNR_LAUNCH_PAL
     return check_launch();

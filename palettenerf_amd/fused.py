@@ -99,12 +99,15 @@ class _PrecisionGuard:
     def _guard_tables(self):
         raise NotImplementedError
 
+    def _guard_weights(self):
+        return self._weights()
+
     def _guard_bound(self, tmax, scales):
         raise NotImplementedError
 
     def _guard(self):
         tables = self._guard_tables()
-        key = tuple(_pkey(w) for w in self._weights()) + tuple(_pkey(t) for t in tables)
+        key = tuple(_pkey(w) for w in self._guard_weights()) + tuple(_pkey(t) for t in tables)
         if getattr(self, "_guard_key", None) != key or PARANOID:
             tmax = [float(v) for v in torch.stack([t.detach().abs().max().float() for t in tables]).cpu().tolist()]
             scales = [_prescale_of(v) for v in tmax]
@@ -113,21 +116,35 @@ class _PrecisionGuard:
             self._guard_key = key
         return self._guard_state
 
-    def enc_scales(self):
+    def enc_scales(self, prec=None):
         """[s_encoder, s_encoder_palette, s_encoder_clip] for the split-fp16 path (all 1.0 on the fp32 path)."""
-        return self._guard()[0] if self.effective_precision() == 1 else [1.0, 1.0, 1.0]
+        prec = self.effective_precision() if prec is None else prec
+        return self._guard()[0] if prec == 1 else [1.0, 1.0, 1.0]
 
     def effective_precision(self):
+        """Matrix path of the stand-alone ops: split-fp16 only when the static bound rules an fp16 overflow out."""
         if int(self.precision) == 0:
             return 0
-        bound = self._guard()[1]
-        if not (bound < F16X3_SAFE_ACTIVATION):
-            if not getattr(self, "_warned_fp32", False):
-                self._warned_fp32 = True
-                import warnings
-                warnings.warn(f"fused field: activations may reach {bound:.3g} (> fp16 range): running the exact fp32 matrix path instead of split-fp16")
-            return 0
-        return 1
+        return 1 if self._guard()[1] < F16X3_SAFE_ACTIVATION else 0
+
+    def frame_precision(self):
+        """(precision, watch) for the device-driven frame loops.  The static bound is a guarantee but pessimistic (products of L1 norms): trained
+        weights often fail it without ever coming near fp16's range.  The frame loops therefore keep split-fp16 in that case and let the
+        kernels WATCH the operands they split (watch = True, ~1 VALU per operand); a frame that reports an overflow is rendered again in exact
+        fp32, and these weights stay on fp32 from then on (render_frame)."""
+        if int(self.precision) == 0:
+            return 0, False
+        if self._guard()[1] < F16X3_SAFE_ACTIVATION:
+            return 1, False
+        if getattr(self, "_overflowed_key", None) == self._guard_key:
+            return 0, False
+        return 1, True
+
+    def _note_overflow(self):
+        import warnings
+        self._overflowed_key = self._guard_key
+        warnings.warn("fused field: an activation left fp16's range (> 65504) in the split-fp16 matrix path: the frame is rendered again on the exact "
+                      "fp32 path, which these weights keep from now on")
 
 
 def _set_finish(a, bg_color, N, mask):
@@ -193,9 +210,9 @@ class NeRFFieldFused(_PrecisionGuard):
         c1 = l1[3] * c0
         return max(enc, h1, geo, c0, c1)
 
-    def _pack(self):
+    def _pack(self, prec=None):
         ws = self._weights()
-        prec = self.effective_precision()
+        prec = self.effective_precision() if prec is None else prec
         versions = tuple(_pkey(w) for w in ws) + (prec,)
         if self.packed is None or versions != self.versions or PARANOID:
             dev = ws[0].device
@@ -228,7 +245,8 @@ class NeRFFieldFused(_PrecisionGuard):
         emb = require(enc.embeddings.detach(), torch.float32, "embeddings")
         if self.table_half:   # the reference's --fp16 tables (`embeddings.to(torch.half)` per forward, gridencoder/grid.py:38): converted once per update here
             emb = _half_copy(self, "_emb_half", enc.embeddings)
-        stats = (ctypes.c_uint64 * 5)()
+        stats = (ctypes.c_uint64 * 6)()
+        prec, watch = self.frame_precision()
         a = _lib.NerfFrameArgs()
         a.table_dtype = 1 if self.table_half else 0
         a.N = N
@@ -240,9 +258,9 @@ class NeRFFieldFused(_PrecisionGuard):
         a.dt_gamma, a.max_steps, a.T_thresh = float(dt_gamma), int(max_steps), float(T_thresh)
         a.embeddings, a.offsets = emb.data_ptr(), enc.offsets.data_ptr()
         a.num_levels, a.S, a.base_resolution, a.gridtype = enc.num_levels, float(np.log2(enc.per_level_scale)), enc.base_resolution, enc.gridtype_id
-        a.packed_weights = self._pack().data_ptr()
-        a.field_precision = int(self.effective_precision())
-        for k, v in enumerate(self.enc_scales()):
+        a.packed_weights = self._pack(prec).data_ptr()
+        a.field_precision, a.watch_overflow = int(prec), int(watch)
+        for k, v in enumerate(self.enc_scales(prec)):
             a.enc_scale[k] = v
         a.density_scale = float(m.density_scale)
         a.weights_sum, a.depth, a.image = ws.data_ptr(), depth.data_ptr(), image.data_ptr()
@@ -257,6 +275,9 @@ class NeRFFieldFused(_PrecisionGuard):
             require(t, torch.float32, name)
         rc = lib.pnr_nerf_render_frame(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         _lib.check(rc, "pnr_nerf_render_frame")
+        if watch and stats[5]:
+            self._note_overflow()
+            return self.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color=bg_color)
         return ws, depth, image, {"iterations": int(stats[0]), "rendered": int(stats[1]), "rows": int(stats[2]), "enqueued": int(stats[3]), "looks": int(stats[4]),
                                   "grid_ms": float(kms[0]), "grid_launches": int(kms[1]), "finished": finished}
 
@@ -277,6 +298,24 @@ class DensityFused(NeRFFieldFused):
     """sigma_net alone through the matrix cores (pnr_nerf_density_forward): sigma and the 15 geometry features of sample batches, no
     gradient.  Works for NeRFNetwork and PaletteNetwork (same encoder / sigma_net / color_net shapes; only the sigma_net part of the blob
     is read).  Users: the occupancy sweep (update_extra_state), density() under no_grad, PaletteNeRF training (geometry detached)."""
+
+    def _guard_weights(self):   # only sigma_net runs here: colour-head updates (every training step) must not touch the guard or the blob
+        m = self.model
+        return [m.sigma_net[0].weight, m.sigma_net[1].weight]
+
+    def _guard_bound(self, tmax, scales):
+        l1 = [float(v) for v in torch.stack([_l1(w).float() for w in self._guard_weights()]).cpu().tolist()]
+        enc = tmax[0] * scales[0]
+        return max(enc, l1[0] * enc)
+
+    def _pack(self, prec=None):
+        prec = self.effective_precision() if prec is None else prec
+        versions = tuple(_pkey(w) for w in self._guard_weights()) + (prec,)
+        if self.packed is None or versions != self.versions or PARANOID:
+            self.versions = None
+            super()._pack(prec)
+            self.versions = versions
+        return self.packed
 
     @torch.no_grad()
     def __call__(self, x, scale=1.0, want_geo=True):
@@ -356,9 +395,9 @@ class PaletteFieldFused(_PrecisionGuard):
             sites += [ce, l1[12] * ce]
         return max(sites)
 
-    def _pack(self):
+    def _pack(self, prec=None):
         ws = self._weights()
-        prec = self.effective_precision()
+        prec = self.effective_precision() if prec is None else prec
         versions = tuple(_pkey(w) for w in ws) + (prec,)
         if self.packed is None or versions != self.versions or PARANOID:
             dev = ws[0].device
@@ -486,8 +525,9 @@ class PaletteFieldFused(_PrecisionGuard):
         for other in (m.encoder_palette, m.encoder_clip):
             if not torch.equal(other.offsets, enc.offsets) or other.per_level_scale != enc.per_level_scale:
                 raise RuntimeError("the three hash grids must share one level layout")
-        stats = (ctypes.c_uint64 * 5)()
+        stats = (ctypes.c_uint64 * 6)()
         kms = (ctypes.c_float * 2)()
+        prec, watch = self.frame_precision()
         bc, bias = self._host_params()
         p = _lib.PaletteFrameArgs()
         a = p.base
@@ -501,9 +541,9 @@ class PaletteFieldFused(_PrecisionGuard):
         a.embeddings = require(enc.embeddings.detach(), torch.float32, "embeddings").data_ptr()
         a.offsets = enc.offsets.data_ptr()
         a.num_levels, a.S, a.base_resolution, a.gridtype = enc.num_levels, float(np.log2(enc.per_level_scale)), enc.base_resolution, enc.gridtype_id
-        a.packed_weights = self._pack().data_ptr()
-        a.field_precision = int(self.effective_precision())
-        for k, v in enumerate(self.enc_scales()):
+        a.packed_weights = self._pack(prec).data_ptr()
+        a.field_precision, a.watch_overflow = int(prec), int(watch)
+        for k, v in enumerate(self.enc_scales(prec)):
             a.enc_scale[k] = v
         a.density_scale = float(m.density_scale)
         a.weights_sum, a.depth, a.image = ws.data_ptr(), depth.data_ptr(), image.data_ptr()
@@ -531,6 +571,9 @@ class PaletteFieldFused(_PrecisionGuard):
             require(t, torch.float32, name)
         rc = lib.pnr_palette_render_frame(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         _lib.check(rc, "pnr_palette_render_frame")
+        if watch and stats[5]:
+            self._note_overflow()
+            return self.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh)
         return ws, depth, image, aux_map, {"iterations": int(stats[0]), "rendered": int(stats[1]), "rows": int(stats[2]), "enqueued": int(stats[3]), "looks": int(stats[4]),
                                            "grid_ms": float(kms[0]), "grid_launches": int(kms[1])}
 

@@ -679,9 +679,13 @@ def test_split_fp16_field_with_tables_at_the_reference_init_scale(cuda, model_ki
 
 
 @pytest.mark.parametrize("model_kind", ["nerf", "palette"])
-def test_split_fp16_field_steps_aside_when_activations_can_leave_the_fp16_range(cuda, model_kind):
-    """One weight row scaled so that hidden activations exceed 65 504 (fp16's largest value): the split operands would become inf.  The static
-    activation bound computed at pack time sends such weights to the exact-fp32 matrix path; frames in every mode agree with the torch loop."""
+@pytest.mark.parametrize("row_scale,overflows", [(4.0e6, True), (1.0e4, False)])
+def test_split_fp16_field_when_activations_can_leave_the_fp16_range(cuda, model_kind, row_scale, overflows):
+    """One weight row scaled so that a hidden activation is huge.  fp16 holds magnitudes up to 65 504; beyond that a split operand is (inf, nan).
+      * the static bound (largest table entry times the layers' L1 row norms) fails for both scales -> the stand-alone ops run exact fp32;
+      * the device-driven loop keeps split-fp16 and WATCHES its operands: at 4e6 an activation really overflows -> the frame reports it, is
+        rendered again in fp32 and the weights stay on fp32; at 1e4 nothing overflows (the bound is merely pessimistic) -> split-fp16 stays.
+    Frames in every mode agree with the torch loop."""
     import warnings
     from palettenerf_amd import network, renderer
     if model_kind == "nerf":
@@ -690,8 +694,8 @@ def test_split_fp16_field_steps_aside_when_activations_can_leave_the_fp16_range(
         m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True, density_scale=100.0, min_near=0.2)
     scene.seed_field_(m, 11)
     with torch.no_grad():
-        m.color_net[0].weight[5].mul_(4.0e6)       # hidden unit 5 of the view-dependent head: activations of several 1e5
-        m.color_net[1].weight[:, 5].mul_(1.0e-6)   # its consumers scaled back so that the colours stay meaningful
+        m.color_net[0].weight[5].mul_(row_scale)          # hidden unit 5 of the view-dependent head
+        m.color_net[1].weight[:, 5].mul_(1.0 / row_scale)  # its consumers scaled back so that the colours stay meaningful
     m = m.to(cuda).eval()
     m.density_grid.copy_(torch.from_numpy(scene.brick_density_grid()).to(cuda))
     raymarching.packbits(m.density_grid, 0.5, m.density_bitfield)
@@ -706,13 +710,20 @@ def test_split_fp16_field_steps_aside_when_activations_can_leave_the_fp16_range(
         for mode in ("compat", "fused", "native"):
             m.march_mode = "device" if mode == "fused" else mode
             m.fused_field = mode != "compat"
+            if mode == "native":
+                assert m._fused.frame_precision() == (1, True)                        # split-fp16, watching
             out[mode] = m.render(ro, rd, **kw)
-    assert m._fused.precision == 1 and m._fused.effective_precision() == 0          # asked for split-fp16, ran exact fp32
-    assert any("fp16 range" in str(w.message) for w in caught)
+    assert m._fused.precision == 1 and m._fused.effective_precision() == 0            # stand-alone ops: the static bound sends them to fp32
     x = dev(np.random.default_rng(1).random((2304, 3)).astype(np.float32) * 1.2 - 0.6, cuda)
     with torch.no_grad():
         h = torch.relu(torch.cat([m.encoder_dir(rd[0]), m.density(x)["geo_feat"]], dim=-1) @ m.color_net[0].weight.t())
-    assert float(h.max()) > 65504.0                                                   # the premise: fp16 could not hold this activation
+    if overflows:
+        assert float(h.max()) > 65504.0                                               # the premise: fp16 cannot hold this activation
+        assert m._fused.frame_precision() == (0, False)                               # latched after the frame reported the overflow
+        assert any("fp16's range" in str(w.message) for w in caught)
+    else:
+        assert 1000.0 < float(h.max()) < 65504.0
+        assert m._fused.frame_precision() == (1, True) and not caught                 # nothing overflowed: split-fp16 stays, silently
     for mode in ("fused", "native"):
         for k in ("image", "weights_sum"):
             assert torch.isfinite(out[mode][k]).all()
