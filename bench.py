@@ -382,6 +382,9 @@ def main(argv=None):
     native_ms, native_launches, native_live = 0.0, 0, 0
     timed_native = native and rank == 0
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # diagnostics only (no sync inside the loop)
+    import gc
+    gc.collect()
+    gc.disable()   # as timeit does: a generation-2 collection of the interpreter's heap (tens of ms with torch imported) is not part of a frame
     t0 = time.perf_counter()
     step_ev[0].record()
     for i in range(args.steps):
@@ -406,6 +409,7 @@ def main(argv=None):
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     rendered += rendered_host
     _torch_glue.profile_kernels(None)
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)

@@ -112,7 +112,8 @@ class _PrecisionGuard:
             tmax = [float(v) for v in torch.stack([t.detach().abs().max().float() for t in tables]).cpu().tolist()]
             scales = [_prescale_of(v) for v in tmax]
             bound = float(self._guard_bound(tmax, scales))
-            self._guard_state = (scales + [1.0] * (3 - len(scales)), bound)
+            wmax = float(torch.stack([w.detach().abs().max().float() for w in self._guard_weights()]).max())   # the weights are split into fp16 halves too
+            self._guard_state = (scales + [1.0] * (3 - len(scales)), bound, wmax)
             self._guard_key = key
         return self._guard_state
 
@@ -125,14 +126,14 @@ class _PrecisionGuard:
         """Matrix path of the stand-alone ops: split-fp16 only when the static bound rules an fp16 overflow out."""
         if int(self.precision) == 0:
             return 0
-        return 1 if self._guard()[1] < F16X3_SAFE_ACTIVATION else 0
+        return 1 if self._guard()[1] < F16X3_SAFE_ACTIVATION and self._guard()[2] < F16X3_SAFE_ACTIVATION else 0
 
     def frame_precision(self):
         """(precision, watch) for the device-driven frame loops.  The static bound is a guarantee but pessimistic (products of L1 norms): trained
         weights often fail it without ever coming near fp16's range.  The frame loops therefore keep split-fp16 in that case and let the
         kernels WATCH the operands they split (watch = True, ~1 VALU per operand); a frame that reports an overflow is rendered again in exact
         fp32, and these weights stay on fp32 from then on (render_frame)."""
-        if int(self.precision) == 0:
+        if int(self.precision) == 0 or not self._guard()[2] < F16X3_SAFE_ACTIVATION:   # a weight itself beyond fp16's range: nothing to watch for
             return 0, False
         if self._guard()[1] < F16X3_SAFE_ACTIVATION:
             return 1, False
