@@ -72,6 +72,7 @@ def _half_copy(owner, attr, t):
 
 
 F16X3_SAFE_ACTIVATION = 3.0e4   # fp16 overflows at 65 504: above this bound on any split operand the field runs on the exact fp32 path
+F16X3_MAX_WEIGHT = 6.0e4        # the weights are split into fp16 halves at pack time: one beyond this cannot be represented at all
 
 
 def _l1(w):
@@ -126,14 +127,14 @@ class _PrecisionGuard:
         """Matrix path of the stand-alone ops: split-fp16 only when the static bound rules an fp16 overflow out."""
         if int(self.precision) == 0:
             return 0
-        return 1 if self._guard()[1] < F16X3_SAFE_ACTIVATION and self._guard()[2] < F16X3_SAFE_ACTIVATION else 0
+        return 1 if self._guard()[1] < F16X3_SAFE_ACTIVATION and self._guard()[2] < F16X3_MAX_WEIGHT else 0
 
     def frame_precision(self):
         """(precision, watch) for the device-driven frame loops.  The static bound is a guarantee but pessimistic (products of L1 norms): trained
         weights often fail it without ever coming near fp16's range.  The frame loops therefore keep split-fp16 in that case and let the
         kernels WATCH the operands they split (watch = True, ~1 VALU per operand); a frame that reports an overflow is rendered again in exact
         fp32, and these weights stay on fp32 from then on (render_frame)."""
-        if int(self.precision) == 0 or not self._guard()[2] < F16X3_SAFE_ACTIVATION:   # a weight itself beyond fp16's range: nothing to watch for
+        if int(self.precision) == 0 or not self._guard()[2] < F16X3_MAX_WEIGHT:   # a weight itself beyond fp16's range: nothing to watch for
             return 0, False
         if self._guard()[1] < F16X3_SAFE_ACTIVATION:
             return 1, False
