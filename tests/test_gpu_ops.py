@@ -679,12 +679,12 @@ def test_split_fp16_field_with_tables_at_the_reference_init_scale(cuda, model_ki
 
 
 @pytest.mark.parametrize("model_kind", ["nerf", "palette"])
-@pytest.mark.parametrize("row_scale,overflows", [(3.0e5, True), (1.0e4, False), (4.0e6, None)])
+@pytest.mark.parametrize("row_scale,overflows", [(1.0e4, True), (3.0e2, False), (4.0e6, None)])
 def test_split_fp16_field_when_activations_can_leave_the_fp16_range(cuda, model_kind, row_scale, overflows):
     """One weight row scaled so that a hidden activation is huge.  fp16 holds magnitudes up to 65 504; beyond that a split operand is (inf, nan).
       * the static bound (largest table entry times the layers' L1 row norms) fails for both scales -> the stand-alone ops run exact fp32;
-      * the device-driven loop keeps split-fp16 and WATCHES its operands: at 3e5 an activation really overflows -> the frame reports it, is
-        rendered again in fp32 and the weights stay on fp32; at 1e4 nothing overflows (the bound is merely pessimistic) -> split-fp16 stays;
+      * the device-driven loop keeps split-fp16 and WATCHES its operands: at 1e4 an activation really overflows -> the frame reports it, is
+        rendered again in fp32 and the weights stay on fp32; at 3e2 nothing overflows (the bound is merely pessimistic) -> split-fp16 stays;
       * at 4e6 the WEIGHTS of that row are beyond fp16's range themselves (they are split into fp16 halves at pack time): exact fp32 at once.
     Frames in every mode agree with the torch loop."""
     import warnings
@@ -695,8 +695,13 @@ def test_split_fp16_field_when_activations_can_leave_the_fp16_range(cuda, model_
         m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True, density_scale=100.0, min_near=0.2)
     scene.seed_field_(m, 11)
     with torch.no_grad():
-        m.color_net[0].weight[5].mul_(row_scale)          # hidden unit 5 of the view-dependent head
-        m.color_net[1].weight[:, 5].mul_(1.0 / row_scale)  # its consumers scaled back so that the colours stay meaningful
+        m.sigma_net[1].weight[1:].mul_(64.0)               # geometry features 64 x larger ...
+        m.color_net[0].weight[:, 16:].mul_(1.0 / 64.0)     # ... which their consumers undo,
+        if model_kind == "palette":
+            m.diff_net[0].weight.mul_(1.0 / 64.0)
+        m.color_net[0].weight[5, 16:].mul_(64.0)           # except hidden unit 5 of the view-dependent head,
+        m.color_net[0].weight[5].mul_(row_scale)           # whose row is scaled up on top
+        m.color_net[1].weight[:, 5].mul_(1.0 / row_scale)  # (its consumers scaled back so that the colours stay meaningful)
     m = m.to(cuda).eval()
     m.density_grid.copy_(torch.from_numpy(scene.brick_density_grid()).to(cuda))
     raymarching.packbits(m.density_grid, 0.5, m.density_bitfield)
