@@ -74,18 +74,23 @@ __host__ __device__ constexpr int f16_col_C0(int kb, int h, int j) {
 
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split8(const float v[8], h8& hi, h8& lo) {
-    // hi = fp16(v) (round to nearest even, two per v_cvt_pk_f16_f32); lo = fp16(v - hi) with the exact difference formed by
-    // v_fma_mix_f32 straight from the packed halves (its f16 source converts in the instruction): 4 VALU per pair instead of 5
+    // hi = fp16(v) (round to nearest even, two per v_cvt_pk_f16_f32); lo = fp16(v - hi): v - hi is exact in fp32 (hi keeps v's leading 11 bits),
+    // so v_fma_mixlo_f16 / v_fma_mixhi_f16 -- fma with the f16 source converted inside the instruction, result rounded ONCE to f16 and
+    // written to the low / high half of the destination -- give the packed lo pair in two instructions: 3 VALU per pair of values
+    // (it was 4 with v_fma_mix_f32 + a second v_cvt_pk_f16_f32)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 hw, lw;
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
         const h2v hp = {(_Float16)v[j], (_Float16)v[j + 1]};
         const uint32_t hb = __builtin_bit_cast(uint32_t, hp);
-        float l0, l1;
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hb), "v"(v[j]));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hb), "v"(v[j + 1]));
-        hi[j] = hp[0]; hi[j + 1] = hp[1];
-        lo[j] = (_Float16)l0; lo[j + 1] = (_Float16)l1;
+        uint32_t lb;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hb), "v"(v[j]));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lb) : "v"(hb), "v"(v[j + 1]));
+        hw[j / 2] = hb; lw[j / 2] = lb;
     }
+    hi = __builtin_bit_cast(h8, hw);
+    lo = __builtin_bit_cast(h8, lw);
 }
 __device__ __forceinline__ void split_frag(const f32x16& a, int half_idx, h8& hi, h8& lo) {
     float v[8];
