@@ -269,8 +269,6 @@ typedef struct pnr_palette_frame_args {
     pnr_nerf_frame_args base;
     const float* embeddings_palette;   /* `encoder_palette` table (same offsets / level parameters as `encoder`) */
     const float* embeddings_clip;      /* `encoder_clip` table (pred_clip only) */
-    const float* basis_color;          /* HOST [nb,3] */
-    const float* or_bias;              /* HOST [3 nb + 1] */
     uint32_t num_basis, clip_dim;
     int pred_clip;
     float offsets_weight, view_dep_weight;
@@ -291,7 +289,7 @@ int pnr_palette_render_frame(const pnr_palette_frame_args* args, pnr_stream_t st
 
 /* Fused PaletteNeRF field + palette colour-basis composite (palette/network.py:156-280, palette/renderer.py:470-500, RegionEdit /
  * Stylizer included).  Split-fp16 or exact-fp32 matrix path (`precision`).  All weights are row-major [out][in]
- * device fp32 pointers of the bias-free nn.Linear layers; offsets_radiance has a bias (passed to the forward call). */
+ * device fp32 pointers of the bias-free nn.Linear layers; offsets_radiance has a bias; the palette (basis_color) and that bias are packed too. */
 typedef struct pnr_palette_weights {
     const float *sigma0, *sigma1;              /* [64,32], [16,64]            */
     const float *diff0, *diff1, *diff2;        /* [64,15], [64,64], [3,64]    */
@@ -300,6 +298,8 @@ typedef struct pnr_palette_weights {
     const float *offsets_radiance;             /* [3 nb + 1, 15]              */
     const float *omega;                        /* [nb, 15]                    */
     const float *clip0, *clip1;                /* [64,32], [clip_dim,64] (pred_clip only) */
+    const float *basis_color;                  /* [nb,3] the palette (device; clamped to [0,1] at pack time, palette/renderer.py:480) */
+    const float *or_bias;                      /* [3 nb + 1] offsets_radiance_net.bias (device) */
     uint32_t num_basis, clip_dim;              /* nb <= PNR_MAX_BASIS, clip_dim <= PNR_MAX_CLIP */
     int pred_clip;
     int precision;                             /* PNR_FIELD_F16X3 or PNR_FIELD_FP32: number format of the packed blob */
@@ -313,9 +313,7 @@ typedef struct pnr_palette_field_args {
     uint32_t level_stride;
     const float* dirs;             /* [B,3] */
     const float* deltas;           /* [B,2] or NULL; rows with deltas[:,0] == 0 are skipped */
-    const void* packed;            /* pnr_palette_field_pack output */
-    const float* basis_color;      /* HOST [nb,3] (clamped to [0,1] by the callee) */
-    const float* or_bias;          /* HOST [3 nb + 1] offsets_radiance_net.bias */
+    const void* packed;            /* pnr_palette_field_pack output (weights, palette and bias) */
     uint32_t num_basis, clip_dim;
     int pred_clip;
     float density_scale, offsets_weight, view_dep_weight;

@@ -119,7 +119,7 @@ class PaletteEdit(ctypes.Structure):
 
 class PaletteFrameArgs(ctypes.Structure):
     """Mirror of `pnr_palette_frame_args` (include/pnr.h)."""
-    _fields_ = [("base", NerfFrameArgs), ("embeddings_palette", _ptr), ("embeddings_clip", _ptr), ("basis_color", _ptr), ("or_bias", _ptr),
+    _fields_ = [("base", NerfFrameArgs), ("embeddings_palette", _ptr), ("embeddings_clip", _ptr),
                 ("num_basis", _u32), ("clip_dim", _u32), ("pred_clip", _int), ("offsets_weight", _f32), ("view_dep_weight", _f32), ("aux_map", _ptr), ("embeddings_pair", _ptr), ("embeddings_triple", _ptr),
                 ("edit", _ptr)]
 
@@ -127,13 +127,13 @@ class PaletteFrameArgs(ctypes.Structure):
 class PaletteWeights(ctypes.Structure):
     """Mirror of `pnr_palette_weights` (include/pnr.h)."""
     _fields_ = [(n, _ptr) for n in ("sigma0", "sigma1", "diff0", "diff1", "diff2", "color0", "color1", "color2", "basis0", "basis1",
-                                    "offsets_radiance", "omega", "clip0", "clip1")] + [("num_basis", _u32), ("clip_dim", _u32), ("pred_clip", _int), ("precision", _int)]
+                                    "offsets_radiance", "omega", "clip0", "clip1", "basis_color", "or_bias")] + [("num_basis", _u32), ("clip_dim", _u32), ("pred_clip", _int), ("precision", _int)]
 
 
 class PaletteFieldArgs(ctypes.Structure):
     """Mirror of `pnr_palette_field_args` (include/pnr.h)."""
     _fields_ = [("ctl", _ptr), ("B", _u32), ("enc", _ptr), ("enc_palette", _ptr), ("enc_clip", _ptr), ("level_stride", _u32), ("dirs", _ptr),
-                ("deltas", _ptr), ("packed", _ptr), ("basis_color", _ptr), ("or_bias", _ptr), ("num_basis", _u32), ("clip_dim", _u32),
+                ("deltas", _ptr), ("packed", _ptr), ("num_basis", _u32), ("clip_dim", _u32),
                 ("pred_clip", _int), ("density_scale", _f32), ("offsets_weight", _f32), ("view_dep_weight", _f32), ("aux_stride", _u32),
                 ("sigmas", _ptr), ("rgbs", _ptr), ("aux", _ptr), ("rays_alive", _ptr), ("weights_sum", _ptr), ("aux_map", _ptr), ("T_thresh", _f32),
                 ("precision", _int), ("edit", _ptr), ("xyzs", _ptr), ("edit_device", _ptr), ("enc_scale", _f32 * 3), ("overflow_flag", _ptr)]

@@ -776,7 +776,7 @@ int pnr_palette_render_frame(const pnr_palette_frame_args* p, pnr_stream_t strea
     if (!p) return PNR_ERR_INVALID;
     if (p->num_basis < 1 || p->num_basis > PNR_MAX_BASIS || p->clip_dim > PNR_MAX_CLIP) return PNR_ERR_UNSUPPORTED;
     if (p->edit && (p->edit->mode < 0 || p->edit->mode > 2)) return PNR_ERR_UNSUPPORTED;
-    if (p->base.N && (!p->embeddings_palette || !p->basis_color || !p->or_bias || !p->aux_map || (p->pred_clip && !p->embeddings_clip))) return PNR_ERR_INVALID;
+    if (p->base.N && (!p->embeddings_palette || !p->aux_map || (p->pred_clip && !p->embeddings_clip))) return PNR_ERR_INVALID;
     return render_frame_impl(&p->base, p, stream);
 }
 
@@ -819,7 +819,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     pnr_palette_field_args pf = {};
     if (pal) {
         pf.enc = w.enc; pf.enc_palette = w.enc_pal; pf.enc_clip = w.enc_clip; pf.level_stride = N; pf.dirs = w.dirs; pf.deltas = w.deltas;
-        pf.packed = a->packed_weights; pf.basis_color = pal->basis_color; pf.or_bias = pal->or_bias; pf.num_basis = pal->num_basis;
+        pf.packed = a->packed_weights; pf.num_basis = pal->num_basis;
         pf.clip_dim = pal->clip_dim; pf.pred_clip = pal->pred_clip; pf.density_scale = a->density_scale; pf.offsets_weight = pal->offsets_weight;
         pf.view_dep_weight = pal->view_dep_weight; pf.aux_stride = aux_stride; pf.sigmas = w.sigmas; pf.rgbs = w.rgbs; pf.aux = w.aux;
         pf.precision = a->field_precision; pf.xyzs = w.xyzs;

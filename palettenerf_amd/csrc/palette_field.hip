@@ -82,6 +82,14 @@ __global__ void __launch_bounds__(256) k_pack_blocks(PackTable t, unsigned char*
     }
 }
 
+__global__ void k_pack_tables(const float* __restrict__ basis_color, const float* __restrict__ or_bias, int nb, float* __restrict__ out /* 64 floats */) {
+    const int i = threadIdx.x;
+    float v = 0.0f;
+    if (i < 30) { if (i < 3 * nb) v = fminf(1.0f, fmaxf(0.0f, basis_color[i])); }
+    else if (i < 62) { if (i - 30 < 3 * nb + 1) v = or_bias[i - 30]; }
+    out[i] = v;
+}
+
 // ---- device helpers ----------------------------------------------------------------------------------------------
 // Epilogue transcendentals on the hardware units (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1e-7 absolute on these bounded arguments)
 // instead of the libm-accurate expansions (15-30 VALU each, ~80 calls per sample row with the ELU layer): the field's outputs
@@ -128,9 +136,17 @@ __device__ __forceinline__ f32x16 scale16(f32x16 v, float s) {
 }
 
 constexpr int kMaxNb = PNR_MAX_BASIS;
+// per-model constants the epilogue reads.  They live at the end of the packed blob (written by pnr_palette_field_pack from the model's
+// device parameters) and are staged into LDS with the weights: as kernel arguments these 62 values sat in scalar registers for the whole
+// tile loop, were spilled to vector-register lanes and read back with v_readlane in the hot loop
+struct PaletteTables {
+    float basis_color[kMaxNb][3];   // clamped to [0,1] (palette/renderer.py:480)
+    float or_bias[32];              // offsets_radiance_net.bias (3 nb + 1 entries, zero padded)
+    float pad[2];
+};
+static_assert(sizeof(PaletteTables) == 64 * 4, "PaletteTables is 64 floats");
+constexpr uint32_t kTablesBytes = sizeof(PaletteTables);
 struct PaletteParams {
-    float basis_color[kMaxNb][3];   // already clamped to [0,1]
-    float or_bias[32];              // offsets_radiance_net.bias (3 nb + 1 entries)
     float density_scale, offsets_weight, view_dep_weight;
     int nb, clip_dim, pred_clip, aux_stride;
     float enc_scale[3];             // power-of-two prescales of enc / enc_palette / enc_clip (split-fp16 path only; 1 = none)
@@ -170,7 +186,7 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
     const uint32_t ntiles = (B + 255) / 256;
     if (blockIdx.x >= ntiles) return;
     extern __shared__ unsigned char w[];
-    for (uint32_t i = threadIdx.x * 16; i < packed_bytes; i += kPalThreads * 16)
+    for (uint32_t i = threadIdx.x * 16; i < packed_bytes; i += kPalThreads * 16)   // weights + the PaletteTables behind them
         *reinterpret_cast<uint4*>(&w[i]) = *reinterpret_cast<const uint4*>(&packed[i]);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
@@ -264,9 +280,14 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
         // ---------------- offsets_radiance_net (bias) and omega_net, rows placed in the lower half-wave (outputs 16.. in a second tile)
         const BOp<PREC> pb = frag_op<PREC, CHECK>(p, 0, sw);
         f32x16 orr = zero16(), orr2 = zero16();
+        // the tables are read from LDS where they are used: the offset goes through an opaque asm so that the 62 loads are not hoisted out of
+        // the tile loop (where they would occupy 62 vector registers for the whole kernel)
+        uint32_t toff = packed_bytes - kTablesBytes;
+        asm volatile("" : "+s"(toff));
+        const PaletteTables& T = *reinterpret_cast<const PaletteTables*>(w + toff);
         if (h == 0) {
 #pragma unroll
-            for (int j = 0; j < 16; j++) { orr[j] = pp.or_bias[j]; orr2[j] = pp.or_bias[16 + j]; }
+            for (int j = 0; j < 16; j++) { orr[j] = T.or_bias[j]; orr2[j] = T.or_bias[16 + j]; }
         }
         orr = mma_blk<PREC>(orr, w + PB_OR * kF16BlockBytes, pb, lane);
         if (nb > 5) orr2 = mma_blk<PREC>(orr2, w + PB_OR2 * kF16BlockBytes, pb, lane);
@@ -292,7 +313,9 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
         }
 
         // ---------------- scalar epilogue on the lower half-wave: the palette colour-basis composite
+        asm volatile("" : "+s"(toff));
         if (valid && h == 0) {
+            const PaletteTables& T = *reinterpret_cast<const PaletteTables*>(w + toff);
             float omega[kMaxNb], osum = 0.0f;
 #pragma unroll
             for (int b = 0; b < kMaxNb; b++) if (b < nb) { omega[b] = softplusf(om[b]) + 0.05f; osum += omega[b]; }
@@ -342,11 +365,11 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
                         float o2 = 0.0f;
 #pragma unroll
                         for (int i = 0; i < 3; i++) o2 = fmaf(off[i], ep->ddelta[b][i][k], o2);
-                        fin[k] = fminf(fmaxf(inten * ((pp.basis_color[b][k] + ep->dP[b][k]) + o2), 0.0f), 1.0f);
+                        fin[k] = fminf(fmaxf(inten * ((T.basis_color[b][k] + ep->dP[b][k]) + o2), 0.0f), 1.0f);
                     }
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 3; k++) fin[k] = sp * (pp.basis_color[b][k] + pp.offsets_weight * off[k]);
+                    for (int k = 0; k < 3; k++) fin[k] = sp * (T.basis_color[b][k] + pp.offsets_weight * off[k]);
                 }
                 if constexpr (EDIT == 1) {   // RegionEdit.forward (palette/renderer.py:121-147)
                     if (ep->weight_mode) { fin[0] = fin[1] = fin[2] = edit_w; }
@@ -365,7 +388,7 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
                     const float brgb = omega[b] * fin[k];
                     rgb[k] += brgb;
                     a[6 + nb + 3 * b + k] = brgb;                                    // basis_rgb
-                    a[6 + 4 * nb + 3 * b + k] = pp.basis_color[b][k] + off[k];       // unscaled_basis_rgb
+                    a[6 + 4 * nb + 3 * b + k] = T.basis_color[b][k] + off[k];       // unscaled_basis_rgb
                 }
             }
             int c = 6 + 7 * nb;
@@ -469,7 +492,7 @@ int pnr_internal_edit_upload(const pnr_palette_edit* edit, void* dst, hipStream_
 extern "C" {
 
 uint64_t pnr_palette_field_packed_bytes(uint32_t num_basis, uint32_t clip_dim, int pred_clip) {
-    return (uint64_t)pal_blocks((int)num_basis, (int)clip_dim, pred_clip ? 1 : 0) * kF16BlockBytes;
+    return (uint64_t)pal_blocks((int)num_basis, (int)clip_dim, pred_clip ? 1 : 0) * kF16BlockBytes + kTablesBytes;
 }
 uint32_t pnr_palette_aux_channels(uint32_t num_basis, uint32_t clip_dim) { return (6 + 7 * num_basis + clip_dim + 3) & ~3u; }
 
@@ -478,7 +501,7 @@ int pnr_palette_field_pack(const pnr_palette_weights* pw, void* packed, pnr_stre
     if (!shape_ok(pw->num_basis, pw->clip_dim)) return PNR_ERR_UNSUPPORTED;
     if (pw->precision != PNR_FIELD_FP32 && pw->precision != PNR_FIELD_F16X3) return PNR_ERR_UNSUPPORTED;
     if (!pw->sigma0 || !pw->sigma1 || !pw->diff0 || !pw->diff1 || !pw->diff2 || !pw->color0 || !pw->color1 || !pw->color2 || !pw->basis0 || !pw->basis1 ||
-        !pw->offsets_radiance || !pw->omega)
+        !pw->offsets_radiance || !pw->omega || !pw->basis_color || !pw->or_bias)
         return PNR_ERR_INVALID;
     if (pw->pred_clip && (!pw->clip0 || !pw->clip1)) return PNR_ERR_INVALID;
     PackTable t;
@@ -512,6 +535,8 @@ int pnr_palette_field_pack(const pnr_palette_weights* pw, void* packed, pnr_stre
     const dim3 grid(cdiv((uint32_t)t.n * 512, 256));
     if (pw->precision == PNR_FIELD_F16X3) hipLaunchKernelGGL(k_pack_blocks<1>, grid, dim3(256), 0, as_stream(stream), t, static_cast<unsigned char*>(packed));
     else hipLaunchKernelGGL(k_pack_blocks<0>, grid, dim3(256), 0, as_stream(stream), t, static_cast<unsigned char*>(packed));
+    hipLaunchKernelGGL(k_pack_tables, dim3(1), dim3(64), 0, as_stream(stream), pw->basis_color, pw->or_bias, nb,
+                       reinterpret_cast<float*>(static_cast<unsigned char*>(packed) + (size_t)t.n * kF16BlockBytes));
     return check_launch();
 }
 
@@ -527,15 +552,12 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
     if (a->precision != PNR_FIELD_FP32 && a->precision != PNR_FIELD_F16X3) return PNR_ERR_UNSUPPORTED;
     if (a->aux_stride < 6 + 7 * a->num_basis + a->clip_dim || a->aux_stride > PNR_CHANNEL_MAXIMUM || (a->aux_stride & 3u)) return PNR_ERR_INVALID;
     if (a->B == 0 && !a->ctl) return PNR_OK;
-    if (!a->enc || !a->enc_palette || !a->dirs || !a->packed || !a->sigmas || !a->rgbs || !a->aux || !a->basis_color || !a->or_bias) return PNR_ERR_INVALID;
+    if (!a->enc || !a->enc_palette || !a->dirs || !a->packed || !a->sigmas || !a->rgbs || !a->aux) return PNR_ERR_INVALID;
     if (a->pred_clip && !a->enc_clip) return PNR_ERR_INVALID;
     const int edit_mode = a->edit ? a->edit->mode : 0;
     if (edit_mode < 0 || edit_mode > 2) return PNR_ERR_UNSUPPORTED;
     if (edit_mode == 1 && a->edit->has_mean_xyz && !a->xyzs) return PNR_ERR_INVALID;
     PaletteParams pp;
-    for (int b = 0; b < kMaxNb; b++)
-        for (int k = 0; k < 3; k++) pp.basis_color[b][k] = b < (int)a->num_basis ? fminf(1.0f, fmaxf(0.0f, a->basis_color[b * 3 + k])) : 0.0f;
-    for (int j = 0; j < 32; j++) pp.or_bias[j] = j < (int)(3 * a->num_basis + 1) ? a->or_bias[j] : 0.0f;
     pp.density_scale = a->density_scale; pp.offsets_weight = a->offsets_weight; pp.view_dep_weight = a->view_dep_weight;
     pp.nb = (int)a->num_basis; pp.clip_dim = (int)a->clip_dim; pp.pred_clip = a->pred_clip ? 1 : 0; pp.aux_stride = (int)a->aux_stride;
     for (int k = 0; k < 3; k++) pp.enc_scale[k] = a->enc_scale[k] > 0.0f ? a->enc_scale[k] : 1.0f;

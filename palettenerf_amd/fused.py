@@ -370,9 +370,14 @@ class PaletteFieldFused(_PrecisionGuard):
             ws += [m.clip_net[0].weight, m.clip_net[1].weight]
         return ws
 
+    def _tables(self):
+        """The palette and the bias of offsets_radiance_net: packed into the blob next to the weights (the kernels read them from LDS)."""
+        m = self.model
+        return [m.basis_color, m.offsets_radiance_net.bias]
+
     def invalidate_caches(self):
         self.versions = None
-        self._pair_key = self._triple_key = self._hp_key = self._guard_key = None
+        self._pair_key = self._triple_key = self._guard_key = None
 
     def _guard_tables(self):
         m = self.model
@@ -400,7 +405,7 @@ class PaletteFieldFused(_PrecisionGuard):
     def _pack(self, prec=None):
         ws = self._weights()
         prec = self.effective_precision() if prec is None else prec
-        versions = tuple(_pkey(w) for w in ws) + (prec,)
+        versions = tuple(_pkey(w) for w in ws + self._tables()) + (prec,)
         if self.packed is None or versions != self.versions or PARANOID:
             dev = ws[0].device
             lib = _lib.load()
@@ -412,6 +417,8 @@ class PaletteFieldFused(_PrecisionGuard):
                 names += ["clip0", "clip1"]
             for name, w in zip(names, self._keep):
                 setattr(pw, name, w.data_ptr())
+            self._keep_tables = [require(t.detach().float().contiguous(), torch.float32, "palette / bias") for t in self._tables()]
+            pw.basis_color, pw.or_bias = self._keep_tables[0].data_ptr(), self._keep_tables[1].data_ptr()
             pw.num_basis, pw.clip_dim, pw.pred_clip, pw.precision = self.nb, self.clip_dim, int(self.pred_clip), int(prec)
             rc = lib.pnr_palette_field_pack(ctypes.byref(pw), ctypes.c_void_p(self.packed.data_ptr()),
                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
@@ -464,15 +471,6 @@ class PaletteFieldFused(_PrecisionGuard):
             e.std_xyz, e.std_clip, e.weight_mode = float(edit.std_xyz), float(edit.std_clip), int(bool(edit.weight_mode))
         self._edit, self._edit_key = e, key
         return e
-
-    def _host_params(self):
-        m = self.model
-        key = (_pkey(m.basis_color), _pkey(m.offsets_radiance_net.bias))
-        if getattr(self, "_hp_key", None) != key or PARANOID:  # two tiny D2H copies, only when the parameters change
-            self._bc = (ctypes.c_float * (3 * self.nb))(*m.basis_color.detach().float().cpu().reshape(-1).tolist())   # clamped to [0,1] by the callee
-            self._bias = (ctypes.c_float * (3 * self.nb + 1))(*m.offsets_radiance_net.bias.detach().float().cpu().tolist())
-            self._hp_key = key
-        return self._bc, self._bias
 
     @torch.no_grad()
     def _pair_table(self):
@@ -530,7 +528,6 @@ class PaletteFieldFused(_PrecisionGuard):
         stats = (ctypes.c_uint64 * 6)()
         kms = (ctypes.c_float * 2)()
         prec, watch = self.frame_precision()
-        bc, bias = self._host_params()
         p = _lib.PaletteFrameArgs()
         a = p.base
         a.N = N
@@ -556,7 +553,6 @@ class PaletteFieldFused(_PrecisionGuard):
         a.ray_order = order.data_ptr() if order is not None and order.numel() == N else None
         p.embeddings_palette = require(m.encoder_palette.embeddings.detach(), torch.float32, "embeddings").data_ptr()
         p.embeddings_clip = require(m.encoder_clip.embeddings.detach(), torch.float32, "embeddings").data_ptr() if self.pred_clip else None
-        p.basis_color, p.or_bias = ctypes.cast(bc, ctypes.c_void_p), ctypes.cast(bias, ctypes.c_void_p)
         p.num_basis, p.clip_dim, p.pred_clip = self.nb, self.clip_dim, int(self.pred_clip)
         p.offsets_weight, p.view_dep_weight = float(m.offsets_weight), float(m.view_dep_weight)
         p.aux_map = aux_map.data_ptr()
@@ -593,7 +589,6 @@ class PaletteFieldFused(_PrecisionGuard):
         sigmas = torch.empty(B, dtype=torch.float32, device=dev)
         rgbs = torch.empty(B, 3, dtype=torch.float32, device=dev)
         aux = torch.empty(B, self.aux_channels, dtype=torch.float32, device=dev)
-        bc, bias = self._host_params()
         a = _lib.PaletteFieldArgs()
         a.ctl, a.B = None, B
         a.enc, a.enc_palette = enc.data_ptr(), enc_pal.data_ptr()
@@ -602,7 +597,6 @@ class PaletteFieldFused(_PrecisionGuard):
         a.dirs = require(d.contiguous(), torch.float32, "dirs").data_ptr()
         a.deltas = deltas.data_ptr() if deltas is not None else None
         a.packed = self._pack().data_ptr()
-        a.basis_color, a.or_bias = ctypes.cast(bc, ctypes.c_void_p), ctypes.cast(bias, ctypes.c_void_p)
         a.num_basis, a.clip_dim, a.pred_clip = self.nb, self.clip_dim, int(self.pred_clip)
         a.density_scale, a.offsets_weight, a.view_dep_weight = float(m.density_scale), float(m.offsets_weight), float(m.view_dep_weight)
         a.aux_stride = self.aux_channels
