@@ -48,7 +48,8 @@ int pnr_abi_version(void);
 /* run-time switches that change speed only, for A/B measurements and tests: "block_skip" (exact jumps over empty blocks in the march),
  * "aux_fusion" (PaletteNeRF frame loop: aux composite inside the field kernel), "composite_fusion" (NeRF frame loop: iterations with one
  * sample per ray composited inside the field kernel); all default to 1.  "adam_variant" (0..7, default 0): which multiply-adds of pnr_adam_step
- * are left uncontracted (kept for re-deriving the bit-exact form against a new torch build) */
+ * are left uncontracted (kept for re-deriving the bit-exact form against a new torch build); "iteration_margin" (default 0): spare iterations
+ * the frame loops enqueue beyond the previous frame's count before their first look at the control block */
 int pnr_set_option(const char* name, int value);
 
 /* ---------------------------------------------------------------- raymarching: utils ------- */

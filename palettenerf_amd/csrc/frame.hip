@@ -863,8 +863,11 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     // number of iterations, so the first chunk is the previous frame's count (one look per frame when the guess holds; launches
     // past the end are no-ops that cost a few microseconds each); after that, short chunks that grow for long, translucent marches.
     uint32_t& predicted_iterations = dev_state.predicted_iterations;
-    // (+1: the launch that finds no ray left is the one that reports it)
-    uint32_t chunk = predicted_iterations ? (predicted_iterations < 1024u ? predicted_iterations + 1u : 1024u) : 8u;
+    // (+1: the launch that finds no ray left is the one that reports it; + g_opt_iteration_margin spare iterations.  Along a camera path the
+    // count drifts by one or two from frame to frame; a spare iteration is four early-exit launches (~19 us), a wrong guess one host round
+    // trip.  Measured on the moving-camera benchmark the round trip is the cheaper of the two: the margin defaults to 0)
+    const uint32_t want = predicted_iterations + 1u + (uint32_t)g_opt_iteration_margin;
+    uint32_t chunk = predicted_iterations ? (want < 1024u ? want : 1024u) : 8u;
     uint32_t looks = 0;
     uint32_t prev_partials = 0;   // workgroups of the previous march launch (= sample partials to add up)
     int iter = 0;
