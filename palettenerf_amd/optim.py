@@ -29,10 +29,11 @@ class Adam(torch.optim.Optimizer):
         cap = int(lib.pnr_adam_max_tensors())
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         f32 = np.float32
+        # ONE launch for every tensor that shares its hyperparameters and step count (the reference's get_params makes ten param groups with the
+        # same lr / betas / eps: torch runs them group by group); tensors that joined later have their own bias corrections and go separately
+        batches = {}
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
-            # one launch per (group, step count): tensors that joined later have their own bias corrections
-            batches = {}
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -46,25 +47,26 @@ class Adam(torch.optim.Optimizer):
                 st["step"] += 1
                 if not (p.is_contiguous() and p.grad.is_contiguous()):
                     raise RuntimeError("palettenerf_amd.optim.Adam: parameters and gradients must be contiguous")
-                batches.setdefault(int(st["step"].item()), []).append((p, st))
-            for step, items in batches.items():
-                # the host scalars exactly as torch/optim/adam.py forms them (Python floats), narrowed where its CUDA kernels narrow them
-                bias_correction1 = 1 - beta1 ** step
-                bias_correction2 = 1 - beta2 ** step
-                step_size = group["lr"] / bias_correction1
-                bias_correction2_sqrt = bias_correction2 ** 0.5
-                sc = _lib.AdamScalars()
-                sc.one_minus_beta1, sc.beta2, sc.one_minus_beta2 = 1 - beta1, beta2, 1 - beta2
-                sc.bias_correction2_sqrt = bias_correction2_sqrt
-                sc.eps, sc.neg_step_size = group["eps"], -step_size
-                sc.inv_grad_scale = 1.0 if not self.grad_scale else float(f32(1.0) / f32(self.grad_scale))
-                for i in range(0, len(items), cap):
-                    chunk = items[i:i + cap]
-                    arr = (_lib.AdamTensor * len(chunk))()
-                    for k, (p, st) in enumerate(chunk):
-                        arr[k].param, arr[k].grad = p.data_ptr(), p.grad.data_ptr()
-                        arr[k].exp_avg, arr[k].exp_avg_sq, arr[k].n = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
-                    _lib.check(lib.pnr_adam_step(arr, ctypes.c_uint32(len(chunk)), ctypes.byref(sc), stream), "pnr_adam_step")
-                for p, _ in items:
-                    torch.autograd.graph.increment_version(p)   # written by a raw kernel: caches keyed on the version (packed blobs, pair tables) must see it
+                key = (float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), int(st["step"].item()), p.device.index)
+                batches.setdefault(key, []).append((p, st))
+        for (lr, beta1, beta2, eps, step, _dev), items in batches.items():
+            # the host scalars exactly as torch/optim/adam.py forms them (Python floats), narrowed where its CUDA kernels narrow them
+            bias_correction1 = 1 - beta1 ** step
+            bias_correction2 = 1 - beta2 ** step
+            step_size = lr / bias_correction1
+            bias_correction2_sqrt = bias_correction2 ** 0.5
+            sc = _lib.AdamScalars()
+            sc.one_minus_beta1, sc.beta2, sc.one_minus_beta2 = 1 - beta1, beta2, 1 - beta2
+            sc.bias_correction2_sqrt = bias_correction2_sqrt
+            sc.eps, sc.neg_step_size = eps, -step_size
+            sc.inv_grad_scale = 1.0 if not self.grad_scale else float(f32(1.0) / f32(self.grad_scale))
+            for i in range(0, len(items), cap):
+                chunk = items[i:i + cap]
+                arr = (_lib.AdamTensor * len(chunk))()
+                for k, (p, st) in enumerate(chunk):
+                    arr[k].param, arr[k].grad = p.data_ptr(), p.grad.data_ptr()
+                    arr[k].exp_avg, arr[k].exp_avg_sq, arr[k].n = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+                _lib.check(lib.pnr_adam_step(arr, ctypes.c_uint32(len(chunk)), ctypes.byref(sc), stream), "pnr_adam_step")
+            for p, _ in items:
+                torch.autograd.graph.increment_version(p)   # written by a raw kernel: caches keyed on the version (packed blobs, pair tables) must see it
         return loss
