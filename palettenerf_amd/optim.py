@@ -27,7 +27,6 @@ class Adam(torch.optim.Optimizer):
                 loss = closure()
         lib = _lib.load()
         cap = int(lib.pnr_adam_max_tensors())
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         f32 = np.float32
         # ONE launch for every tensor that shares its hyperparameters and step count (the reference's get_params makes ten param groups with the
         # same lr / betas / eps: torch runs them group by group); tensors that joined later have their own bias corrections and go separately
@@ -66,7 +65,9 @@ class Adam(torch.optim.Optimizer):
                 for k, (p, st) in enumerate(chunk):
                     arr[k].param, arr[k].grad = p.data_ptr(), p.grad.data_ptr()
                     arr[k].exp_avg, arr[k].exp_avg_sq, arr[k].n = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
-                _lib.check(lib.pnr_adam_step(arr, ctypes.c_uint32(len(chunk)), ctypes.byref(sc), stream), "pnr_adam_step")
+                with torch.cuda.device(_dev):   # the launch goes to the tensors' device, on torch's current stream there
+                    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+                    _lib.check(lib.pnr_adam_step(arr, ctypes.c_uint32(len(chunk)), ctypes.byref(sc), stream), "pnr_adam_step")
             for p, _ in items:
                 torch.autograd.graph.increment_version(p)   # written by a raw kernel: caches keyed on the version (packed blobs, pair tables) must see it
         return loss
