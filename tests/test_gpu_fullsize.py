@@ -158,3 +158,105 @@ def test_garden_video_frame_native_equals_reference_style_loop(cuda):
     # (march-emitted samples depend on the n_step schedule, which follows each launch's own N / n_alive: samples marched for a ray after it
     # terminated inside a group are counted but never composited -- the pixels above are what must agree)
     assert abs(n_total - int(b["rendered"].sum())) < 0.01 * n_total
+
+
+def test_palette_frame_800_native_equals_reference_style_loop(cuda, frame800):
+    """BASELINE configs[2] at full size: the 800x800 PaletteNeRF frame (all seven composited maps) through the device-driven loop against the
+    host-driven loop with torch MLPs and the reference's seven composites; then the same with a RegionEdit active (inside the fused epilogue)."""
+    from palettenerf_amd import renderer
+    grid, bitfield, ro, rd = frame800
+    opt = renderer.default_opt()
+    m = network.PaletteNetwork(opt, bound=2, cuda_ray=True, density_scale=100.0, min_near=0.2)
+    scene.seed_field_(m, 0)
+    m = m.to(cuda).eval()
+    m.density_grid.copy_(grid)
+    raymarching.packbits(m.density_grid, 0.5, m.density_bitfield)
+    m.count_rendered = True
+    kw = dict(perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4, gui_mode=False)
+
+    def both():
+        out = {}
+        for mode in ("compat", "native"):
+            m.march_mode, m.fused_field = mode, mode == "native"
+            with torch.no_grad():
+                out[mode] = m.render(ro[None], rd[None], **kw)
+        return out["compat"], out["native"]
+
+    a, b = both()
+    na, nb_ = int(a["rendered"].sum()), int(b["rendered"].sum())
+    assert 9_000_000 < nb_ < 10_500_000 and abs(na - nb_) <= 1e-5 * na
+    for k in ("image", "weights_sum", "direct_rgb", "view_dep_rgb", "basis_rgb", "unscaled_basis_rgb", "basis_acc"):
+        assert float((a[k] - b[k]).abs().max()) < 1e-4, k
+    assert scene.psnr(a["image"], b["image"]) > 85.0
+    m.edit = renderer.RegionEdit(opt)
+    m.edit.update_cent(mean_xyz=torch.tensor([0.2, 0.1, -0.1], device=cuda))
+    m.edit.update_std(std_xyz=0.3)
+    m.edit.update_delta_hsv(m.basis_color.data.clamp(0, 1), (m.basis_color.data * 0.5 + 0.3).flip(0).clamp(0, 1))
+    c, d = both()
+    assert float((c["image"] - d["image"]).abs().max()) < 3e-4 and float((c["image"] - a["image"]).abs().max()) > 1e-2   # the edit is visible, and identical
+    assert d["iterations"] == b["iterations"]                     # the edited frame takes the same device-driven loop, launch for launch
+
+
+def test_palette_training_step_at_config3_size(cuda):
+    """BASELINE configs[3] shape: one PaletteNeRF training step on 4096 rays of the forward-facing slab scene (dt_gamma 1/128, ~0.6 M samples) --
+    the fused training path (one-launch MLP stacks, level-major encoder hand-off, fused colour-basis shade, frozen-density kernel, binned table
+    gradient) against the same step on plain torch modules + the drop-in operators; then the one-launch Adam against torch.optim.Adam on those
+    gradients."""
+    import copy
+    from palettenerf_amd import mlp, optim, renderer
+    torch.manual_seed(0)
+    m = network.PaletteNetwork(renderer.default_opt(test=False), bound=2, cuda_ray=True, min_near=0.02)
+    scene.seed_field_(m, 0)
+    m = m.to(cuda).train()
+    m.density_grid.copy_(torch.from_numpy(scene.slab_density_grid()).to(cuda))
+    raymarching.packbits(m.density_grid, 0.5, m.density_bitfield)
+    H, W = 756, 1008
+    pose = np.eye(4, dtype=np.float32)
+    pose[:3, 0], pose[:3, 1], pose[:3, 2], pose[:3, 3] = [1, 0, 0], [0, -1, 0], [0, 0, -1], [0.3, 0.0, 1.5]
+    ro, rd = scene.get_rays(torch.from_numpy(pose)[None], scene.intrinsics_from_fov(H, W, 0.9), H, W)
+    inds = torch.randint(0, H * W, [4096])
+    ro, rd = ro[:, inds].to(cuda), rd[:, inds].to(cuda)
+    target = torch.rand(4096, 3, device=cuda)
+
+    def step(fused):
+        mlp.enabled = fused
+        m.fused_train_shade = m.fused_train_density = fused
+        for p in m.parameters():
+            p.grad = None
+        r = m.run_cuda(ro, rd, dt_gamma=1 / 128, perturb=False, force_all_rays=True, max_steps=1024, T_thresh=1e-4)
+        loss = ((r["image"][0] - target) ** 2).mean() + 1e-3 * r["omega_sparsity"].mean() + 1e-2 * r["offsets_norm"].mean() + ((r["direct_rgb"][0] - target) ** 2).mean()
+        loss.backward()
+        return float(loss), int(m.step_counter[(m.local_step - 1) % 16, 0]), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    try:
+        l_ref, n_ref, g_ref = step(False)
+        l_fus, n_fus, g_fus = step(True)
+    finally:
+        mlp.enabled = True
+    assert n_ref == n_fus > 400_000                      # the march does not depend on the field path
+    assert abs(l_ref - l_fus) < 2e-5 * max(1.0, abs(l_ref))
+    assert set(g_ref) == set(g_fus) and "encoder.embeddings" not in g_fus and "encoder_palette.embeddings" in g_fus    # geometry frozen (sigma detached)
+    for name in g_ref:
+        scale = float(g_ref[name].abs().max())
+        assert float((g_ref[name] - g_fus[name]).abs().max()) <= 3e-3 * scale + 1e-9, name
+    # optimiser: same gradients, two identical models, one step each
+    m2 = copy.deepcopy(m)
+    for (n, p), (_, q) in zip(m.named_parameters(), m2.named_parameters()):
+        q.grad = None if p.grad is None else p.grad.clone()
+    torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15).step()
+    optim.Adam(m2.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15).step()
+    for (n, p), (_, q) in zip(m.named_parameters(), m2.named_parameters()):
+        assert torch.equal(p, q), n
+
+
+def test_palette_two_stage_training_converges(cuda):
+    """A short version of profiles/train_palette.py (configs[3]'s recipe: NeRF stage -> checkpoint -> PaletteNetwork + palette -> PaletteTrainer's loss):
+    the PaletteNeRF stage must lift the held-out PSNR from its initial ~8 dB to above 28 dB within 400 steps."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "train_palette.py")
+    spec = importlib.util.spec_from_file_location("train_palette", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    log = mod.main(["--steps", "400", "--nerf-steps", "400", "--log-every", "200", "--res", "0.125"])
+    assert log[0][1] < 15.0 and log[-1][1] > 28.0, log
