@@ -89,6 +89,10 @@ __device__ __forceinline__ void split8(const float v[8], h8& hi, h8& lo) {
         asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lb) : "v"(hb), "v"(v[j + 1]));
         hw[j / 2] = hb; lw[j / 2] = lb;
     }
+    // The low halves come out of inline asm: the compiler's hazard recogniser does not see a VALU write there, and the next instruction may be
+    // the MFMA that reads these registers as its B operand (VALU-write -> MFMA-read needs wait states on gfx9).  Four wait states behind the last write (s_nop 1 already made the 12-wave kernel, where this was first seen as run-to-run differences of 1e-6, bit-reproducible)
+    // covers all four registers (the first three are at least two instructions old by then).
+    asm volatile("s_nop 3" : "+v"(lw));
     hi = __builtin_bit_cast(h8, hw);
     lo = __builtin_bit_cast(h8, lw);
 }

@@ -24,6 +24,7 @@
 #include "field_core.hpp"
 #include "hsv_core.hpp"
 #include <string.h>
+#include <stdlib.h>
 
 namespace pnr {
 
@@ -171,8 +172,11 @@ __device__ __forceinline__ float torch_lerp(float a, float b, float w) { const f
 
 // EDIT: 0 plain composite, 1 RegionEdit, 2 Stylizer (pnr_palette_edit.mode); separate instantiations keep the HSV / double-fmod code
 // and the extra parameters out of the plain kernel.  CHECK: watch the split operands for magnitudes beyond fp16's range (SplitWatch)
-template <int PREC, int EDIT, bool CHECK>
-__global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCtlView* __restrict__ ctl, uint32_t B_arg, const float* __restrict__ enc,
+// NB: 0 = any number of bases (loops predicated up to PNR_MAX_BASIS), otherwise exactly NB bases (the shipped default 4: no predication,
+// no second offsets_radiance tile)
+// WAVES: waves per workgroup (8, or 12 = three per SIMD where registers and LDS allow it); a workgroup tile is WAVES x 32 samples
+template <int PREC, int EDIT, bool CHECK, int NB, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtlView* __restrict__ ctl, uint32_t B_arg, const float* __restrict__ enc,
                                                                    const float* __restrict__ enc_pal, const float* __restrict__ enc_clip,
                                                                    uint32_t level_stride, const float* __restrict__ dirs,
                                                                    const float* __restrict__ deltas, const unsigned char* __restrict__ packed,
@@ -183,29 +187,32 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
                                                                    const EditParams* __restrict__ ep, int32_t* __restrict__ overflow_flag) {
     if (ctl && ctl->done) return;
     const uint32_t B = ctl ? (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step : B_arg;
-    const uint32_t ntiles = (B + 255) / 256;
+    constexpr uint32_t kTile = WAVES * 32;
+    const uint32_t ntiles = (B + kTile - 1) / kTile;
     if (blockIdx.x >= ntiles) return;
     extern __shared__ unsigned char w[];
-    for (uint32_t i = threadIdx.x * 16; i < packed_bytes; i += kPalThreads * 16)   // weights + the PaletteTables behind them
+    for (uint32_t i = threadIdx.x * 16; i < packed_bytes; i += WAVES * 64 * 16)   // weights + the PaletteTables behind them
         *reinterpret_cast<uint4*>(&w[i]) = *reinterpret_cast<const uint4*>(&packed[i]);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
-    const int nb = pp.nb;
+    const int nb = NB ? NB : pp.nb;
+    constexpr int kLoopNb = NB ? NB : kMaxNb;
     // rows of a ray are consecutive; with 1, 2, 4 or 8 samples per ray they sit inside one 32-row wave tile and the aux composite
     // can run here (fstep = samples per ray), otherwise the composite launch does it
     const uint32_t fstep = (stage_stride && ctl && aux_map && ctl->n_step <= 8 && (32 % ctl->n_step) == 0) ? (uint32_t)ctl->n_step : 0u;
     const bool fuse_composite = fstep != 0;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint32_t n = tile * 256 + wave * 32 + (lane & 31);
+        const uint32_t n = tile * kTile + wave * 32 + (lane & 31);
         const bool valid = n < B && (!deltas || deltas[(size_t)(n < B ? n : 0) * 2] != 0.0f);
         if (!__any(valid)) continue;
         const uint32_t row = n < B ? n : (B - 1);
 
         SplitWatch<CHECK> sw_, *sw = &sw_;
         // all global reads of the tile up front
+        // (the 12-wave variant has three waves per SIMD to hide a load behind and 168 registers: it fetches the second table's features where they are used)
         float xs[2][8], xp[2][8];
         load_enc_raw(enc, level_stride, row, valid, h, xs);
-        load_enc_raw(enc_pal, level_stride, row, valid, h, xp);
+        if constexpr (WAVES == 8) load_enc_raw(enc_pal, level_stride, row, valid, h, xp);
         float dx = 0.0f, dy = 0.0f, dz = 0.0f;
         if (valid) { dx = dirs[(size_t)row * 3]; dy = dirs[(size_t)row * 3 + 1]; dz = dirs[(size_t)row * 3 + 2]; }
 
@@ -260,6 +267,7 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
 
         // ---------------- basis_net: [enc_palette(32) ; diffuse(3)] -> 64 (ELU) -> 15
         {
+            if constexpr (WAVES != 8) load_enc_raw(enc_pal, level_stride, row, valid, h, xp);
             const float ps = pre_p ? pp.enc_scale[1] : 1.0f;   // the whole 35-wide input row is scaled; the ELU needs the true pre-activations back
             if (pre_p) scale8x2(xp, ps);
             const BOp<PREC> b0 = make_op<PREC, CHECK>(xp[0], sw), b1 = make_op<PREC, CHECK>(xp[1], sw);
@@ -290,7 +298,7 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
             for (int j = 0; j < 16; j++) { orr[j] = T.or_bias[j]; orr2[j] = T.or_bias[16 + j]; }
         }
         orr = mma_blk<PREC>(orr, w + PB_OR * kF16BlockBytes, pb, lane);
-        if (nb > 5) orr2 = mma_blk<PREC>(orr2, w + PB_OR2 * kF16BlockBytes, pb, lane);
+        if (NB ? NB > 5 : nb > 5) orr2 = mma_blk<PREC>(orr2, w + PB_OR2 * kF16BlockBytes, pb, lane);
         const f32x16 om = mma_blk<PREC>(zero16(), w + PB_OM * kF16BlockBytes, pb, lane);
         __builtin_amdgcn_sched_barrier(0);
 
@@ -318,22 +326,28 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
             const PaletteTables& T = *reinterpret_cast<const PaletteTables*>(w + toff);
             float omega[kMaxNb], osum = 0.0f;
 #pragma unroll
-            for (int b = 0; b < kMaxNb; b++) if (b < nb) { omega[b] = softplusf(om[b]) + 0.05f; osum += omega[b]; }
+            for (int b = 0; b < kLoopNb; b++) if (NB || b < nb) { omega[b] = softplusf(om[b]) + 0.05f; osum += omega[b]; }
             // offsets_radiance outputs by index (compile-time after unrolling); radiance is the LAST of the 3 nb + 1 outputs (palette/renderer.py:471)
             auto orv = [&](int idx) -> float { return idx < 16 ? orr[idx & 15] : orr2[idx & 15]; };
             float radiance = 0.0f;
+            if constexpr (NB != 0) radiance = orv(3 * NB);
+            else {
 #pragma unroll
-            for (int b = 1; b <= kMaxNb; b++) if (nb == b) radiance = orv(3 * b);
+                for (int b = 1; b <= kMaxNb; b++) if (nb == b) radiance = orv(3 * b);
+            }
             const float sp = softplusf(radiance);
             float rgb[3] = {0.0f, 0.0f, 0.0f};
             // aux row: straight to global (one 4-byte store per channel and lane, rows aux_stride apart), or -- when the LDS has room --
             // into this wave's staging slab, from where the whole 32-row tile (contiguous in memory) goes out as 16-byte stores
+            // staging layout behind the weights: WAVES slabs of 32 rows x stage_stride floats, then WAVES x 32 x 3 spare floats (per row: the
+            // compositing weight; per ray leader: ray id and number of rows that count)
             float* a = stage_stride ? reinterpret_cast<float*>(w + packed_bytes) + ((size_t)wave * 32 + (lane & 31)) * stage_stride
                                     : aux + (size_t)n * pp.aux_stride;
+            float* ex = reinterpret_cast<float*>(w + packed_bytes) + (size_t)WAVES * 32 * stage_stride + (size_t)wave * 96;
 #pragma unroll
             for (int k = 0; k < 3; k++) { a[k] = diffuse[k] + view_dep[k]; a[3 + k] = view_dep[k]; }   // direct_rgb, view_dep_rgb
 #pragma unroll
-            for (int b = 0; b < kMaxNb; b++) if (b < nb) { omega[b] = omega[b] / osum; a[6 + b] = omega[b]; }
+            for (int b = 0; b < kLoopNb; b++) if (NB || b < nb) { omega[b] = omega[b] / osum; a[6 + b] = omega[b]; }
             float edit_w = 1.0f;
             if constexpr (EDIT == 1) {   // RegionEdit's window (palette/renderer.py:126-134)
                 if (ep->has_mean_xyz) {
@@ -354,7 +368,7 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
                 }
             }
 #pragma unroll
-            for (int b = 0; b < kMaxNb; b++) if (b < nb) {
+            for (int b = 0; b < kLoopNb; b++) if (NB || b < nb) {
                 float fin[3], off[3];
 #pragma unroll
                 for (int k = 0; k < 3; k++) off[k] = orv(3 * b + k);
@@ -397,7 +411,7 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
             for (c += pp.clip_dim; c < pp.aux_stride; c++) a[c] = 0.0f;
             const float sigma = pp.density_scale * __expf(sigma_logit);
             sigmas[n] = sigma;
-            if (fuse_composite) a[pp.aux_stride] = 1.0f - __expf(-sigma * deltas[(size_t)n * 2]);   // alpha, exactly as k_frame_composite forms it
+            if (fuse_composite) ex[(lane & 31) * 3] = 1.0f - __expf(-sigma * deltas[(size_t)n * 2]);   // alpha, exactly as k_frame_composite forms it
             const float kvd = EDIT == 2 ? 1.0f : pp.view_dep_weight;   // the Stylizer adds view_dep unscaled (palette/renderer.py:181)
 #pragma unroll
             for (int k = 0; k < 3; k++) rgbs[(size_t)n * 3 + k] = rgb[k] + kvd * view_dep[k];
@@ -405,7 +419,8 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
         if constexpr (CHECK) { if (overflow_flag && sw_.overflowed()) *overflow_flag = 1; }
         if (stage_stride) {   // same wave wrote the slab: DS operations of a wave complete in order
             float* slab = reinterpret_cast<float*>(w + packed_bytes) + (size_t)wave * 32 * stage_stride;
-            const uint32_t n0 = tile * 256 + wave * 32, nq = (uint32_t)pp.aux_stride / 4, S = (uint32_t)pp.aux_stride;
+            float* ex = reinterpret_cast<float*>(w + packed_bytes) + (size_t)WAVES * 32 * stage_stride + (size_t)wave * 96;
+            const uint32_t n0 = tile * kTile + wave * 32, nq = (uint32_t)pp.aux_stride / 4;
             const unsigned long long live = __ballot(valid && h == 0);     // rows of dead / out-of-range slots hold stale slab data: skip them
             if (fuse_composite) {
                 // aux_map[ray] += sum_k weight_k * row_k: the recurrence of raymarching.cu:1114-1185 (weights from the weights_sum of
@@ -419,29 +434,28 @@ __global__ void __launch_bounds__(kPalThreads) k_palette_field_fwd(const FrameCt
                         float ws = weights_sum[index];
                         for (uint32_t k = 0; k < fstep; k++) {
                             if (!((live >> (lane + k)) & 1ull)) break;
-                            float* r = slab + (lane + k) * stage_stride;
                             const float T = 1.0f - ws;
-                            const float wgt = r[S] * T;
+                            const float wgt = ex[(lane + k) * 3] * T;
                             ws += wgt;
-                            r[S] = wgt;
+                            ex[(lane + k) * 3] = wgt;
                             cnt++;
                             if (T < T_thresh) break;
                         }
                     }
-                    slab[lane * stage_stride + S + 1] = __int_as_float(index);
-                    slab[lane * stage_stride + S + 2] = __int_as_float(cnt);
+                    ex[lane * 3 + 1] = __int_as_float(index);
+                    ex[lane * 3 + 2] = __int_as_float(cnt);
                 }
                 const uint32_t rays_in_tile = 32 / fstep;
                 for (uint32_t i = (uint32_t)lane; i < rays_in_tile * nq; i += 64) {
                     const uint32_t ray = i / nq, q = i - ray * nq, base = ray * fstep;
-                    const int cnt = __float_as_int(slab[base * stage_stride + S + 2]);
+                    const int cnt = __float_as_int(ex[base * 3 + 2]);
                     if (cnt == 0) continue;
-                    const int index = __float_as_int(slab[base * stage_stride + S + 1]);
+                    const int index = __float_as_int(ex[base * 3 + 1]);
                     float4* dst = reinterpret_cast<float4*>(aux_map + (size_t)index * pp.aux_stride) + q;
                     float4 acc = *dst;
                     for (int k = 0; k < cnt; k++) {
                         const float* r = slab + (base + k) * stage_stride;
-                        const float wgt = r[S];
+                        const float wgt = ex[(base + k) * 3];
                         const float4 v = *reinterpret_cast<const float4*>(r + q * 4);
                         acc.x = fmaf(wgt, v.x, acc.x); acc.y = fmaf(wgt, v.y, acc.y); acc.z = fmaf(wgt, v.z, acc.z); acc.w = fmaf(wgt, v.w, acc.w);
                     }
@@ -488,6 +502,8 @@ int pnr_internal_edit_upload(const pnr_palette_edit* edit, void* dst, hipStream_
     fill_edit(e, *edit);
     return hipMemcpyAsync(dst, &e, sizeof(e), hipMemcpyHostToDevice, s) == hipSuccess ? PNR_OK : PNR_ERR_LAUNCH;   // pageable source: staged before the call returns
 }
+
+extern int g_opt_palette_waves12;
 
 extern "C" {
 
@@ -543,7 +559,7 @@ int pnr_palette_field_pack(const pnr_palette_weights* pw, void* packed, pnr_stre
 int pnr_palette_field_stages_aux(uint32_t num_basis, uint32_t clip_dim, int pred_clip) {
     const uint32_t aux_stride = pnr_palette_aux_channels(num_basis, clip_dim);
     const uint32_t packed_bytes = (uint32_t)pnr_palette_field_packed_bytes(num_basis, clip_dim, pred_clip);
-    return packed_bytes + (kPalThreads / 64) * 32 * (aux_stride + 4) * 4 <= 160 * 1024;
+    return packed_bytes + (kPalThreads / 64) * 32 * (aux_stride + 3) * 4 <= 160 * 1024;
 }
 
 int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stream) {
@@ -563,13 +579,18 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
     for (int k = 0; k < 3; k++) pp.enc_scale[k] = a->enc_scale[k] > 0.0f ? a->enc_scale[k] : 1.0f;
     const uint32_t packed_bytes = (uint32_t)pnr_palette_field_packed_bytes(a->num_basis, a->clip_dim, pp.pred_clip);
     const uint32_t rows_ub = a->B;
-    const uint32_t ntiles = cdiv(rows_ub ? rows_ub : 1, 256);
-    const uint32_t grid = ntiles < 256u ? ntiles : 256u;  // one persistent 512-thread workgroup per CU (100-126 KiB of LDS)
+    // one persistent workgroup per CU (100-126 KiB of LDS): 8 waves, or 12 for the specialised 4-basis kernel when its staging fits (three waves per SIMD
+    // at <= 168 registers: the dependent layer chain of a wave leaves the SIMD idle too often with two)
+    const bool nb4 = a->precision == PNR_FIELD_F16X3 && edit_mode == 0 && a->num_basis == 4 && !a->overflow_flag;
+    const bool wide = nb4 && g_opt_palette_waves12 && packed_bytes + 12u * 32u * (a->aux_stride + 3u) * 4u <= 160u * 1024u;
+    const uint32_t waves = wide ? 12u : 8u;
+    const uint32_t ntiles = cdiv(rows_ub ? rows_ub : 1, waves * 32);
+    const uint32_t grid = ntiles < 256u ? ntiles : 256u;
     constexpr uint32_t kLdsLimit = 160 * 1024;
     // staging slab for coalesced aux rows: 8 waves x 32 rows x (aux_stride + 4) floats, when it fits next to the weights
     const bool stages = a->aux_stride == pnr_palette_aux_channels(a->num_basis, a->clip_dim) && pnr_palette_field_stages_aux(a->num_basis, a->clip_dim, pp.pred_clip);
-    const uint32_t stage_stride = stages ? a->aux_stride + 4 : 0;
-    const uint32_t lds = packed_bytes + (kPalThreads / 64) * 32 * stage_stride * 4;
+    const uint32_t stage_stride = stages ? a->aux_stride : 0;
+    const uint32_t lds = packed_bytes + (stages ? waves * 32 * (stage_stride + 3) * 4 : 0);
     const bool fuse = a->ctl && a->rays_alive && a->weights_sum && a->aux_map;
     hipStream_t s = as_stream(stream);
     const EditParams* ep_dev = nullptr;
@@ -589,10 +610,11 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
         ep_dev = ring.dev + slot;
     }
     static bool attr_set[4][3][kMaxDevices] = {};   // [PREC + 2 * CHECK][EDIT]
-#define PNR_LAUNCH_PAL(PREC, EDIT, CHECK)                                                                                                      \
+#define PNR_LAUNCH_PAL(PREC, EDIT, CHECK) PNR_LAUNCH_PAL_NB(PREC, EDIT, CHECK, 0, 8, attr_set[PREC + (CHECK ? 2 : 0)][EDIT])
+#define PNR_LAUNCH_PAL_NB(PREC, EDIT, CHECK, NB, WAVES, FLAGS)                                                                                 \
     do {                                                                                                                                       \
-        if (!ensure_dynamic_lds(k_palette_field_fwd<PREC, EDIT, CHECK>, kLdsLimit, attr_set[PREC + (CHECK ? 2 : 0)][EDIT])) return PNR_ERR_LAUNCH; \
-        hipLaunchKernelGGL((k_palette_field_fwd<PREC, EDIT, CHECK>), dim3(grid), dim3(kPalThreads), lds, s,                                    \
+        if (!ensure_dynamic_lds(k_palette_field_fwd<PREC, EDIT, CHECK, NB, WAVES>, kLdsLimit, FLAGS)) return PNR_ERR_LAUNCH;                   \
+        hipLaunchKernelGGL((k_palette_field_fwd<PREC, EDIT, CHECK, NB, WAVES>), dim3(grid), dim3(WAVES * 64), lds, s,                          \
                            static_cast<const FrameCtlView*>(a->ctl), a->B, a->enc, a->enc_palette, a->enc_clip, a->level_stride, a->dirs,      \
                            a->deltas, static_cast<const unsigned char*>(a->packed), packed_bytes, pp, a->sigmas, a->rgbs, a->aux,              \
                            stage_stride, fuse ? a->rays_alive : nullptr, fuse ? a->weights_sum : nullptr, fuse ? a->aux_map : nullptr,         \
@@ -601,11 +623,15 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
     if (a->precision == PNR_FIELD_F16X3 && a->overflow_flag) {   // the instantiation that watches its split operands
         if (edit_mode == 0) PNR_LAUNCH_PAL(1, 0, true); else if (edit_mode == 1) PNR_LAUNCH_PAL(1, 1, true); else PNR_LAUNCH_PAL(1, 2, true);
     } else if (a->precision == PNR_FIELD_F16X3) {
-        if (edit_mode == 0) PNR_LAUNCH_PAL(1, 0, false); else if (edit_mode == 1) PNR_LAUNCH_PAL(1, 1, false); else PNR_LAUNCH_PAL(1, 2, false);
+        static bool attr_nb4[2][kMaxDevices] = {};
+        if (nb4 && wide) PNR_LAUNCH_PAL_NB(1, 0, false, 4, 12, attr_nb4[1]);   // the shipped default (main_palette.py:76): specialised epilogue
+        else if (nb4) PNR_LAUNCH_PAL_NB(1, 0, false, 4, 8, attr_nb4[0]);
+        else if (edit_mode == 0) PNR_LAUNCH_PAL(1, 0, false); else if (edit_mode == 1) PNR_LAUNCH_PAL(1, 1, false); else PNR_LAUNCH_PAL(1, 2, false);
     } else {
         if (edit_mode == 0) PNR_LAUNCH_PAL(0, 0, false); else if (edit_mode == 1) PNR_LAUNCH_PAL(0, 1, false); else PNR_LAUNCH_PAL(0, 2, false);
     }
 #undef PNR_LAUNCH_PAL
+#undef PNR_LAUNCH_PAL_NB
     return check_launch();
 }
 
