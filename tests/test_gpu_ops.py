@@ -562,7 +562,7 @@ def test_fused_palette_field_matches_torch_module(cuda, pred_clip):
     m.offsets_weight, m.view_dep_weight = 0.7, 1.3
     fused = PaletteFieldFused(m)
     nb = 4
-    for B in (1, 33, 256, 4097):
+    for B in (1, 33, 256, 383, 384, 385, 4097, 12289):   # around the 256- and 384-sample workgroup tiles of the 8- and 12-wave kernels
         x = dev(rng.random((B, 3)).astype(np.float32) * 4 - 2, cuda)
         d = rng.standard_normal((B, 3)).astype(np.float32)
         d = dev(d / np.linalg.norm(d, axis=1, keepdims=True), cuda)
@@ -1168,6 +1168,41 @@ def test_image_to_uint8_matches_the_host_conversion(cuda):
     got = host(rays.image_to_uint8(t, linear_to_srgb=True))
     diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
     assert diff.max() <= 1 and (diff != 0).mean() < 1e-4
+
+
+def test_palette_field_kernel_variants_are_bit_identical(cuda):
+    """The 4-basis PaletteNeRF field has a specialised instantiation (no predication over the basis loops) that runs 12-wave workgroups; it
+    must return the bits of the 8-wave one -- per-sample arithmetic does not depend on which lane, wave or tile a sample lands in -- and
+    permuting the samples must permute the outputs.  (This is the test that exposed a VALU-write -> MFMA-read hazard behind the inline-asm
+    fp16 split: results differed by 1e-6 from run to run until the wait states were added.)"""
+    from palettenerf_amd import _lib, network, renderer
+    from palettenerf_amd.fused import PaletteFieldFused
+    m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True, density_scale=30.0, min_near=0.2)
+    scene.seed_field_(m, 5)
+    m = m.to(cuda).eval()
+    f = PaletteFieldFused(m)
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(0)
+    try:
+        for B in (5000, 200000):
+            x = (torch.rand(B, 3, generator=g) * 1.2 - 0.6).to(cuda)
+            d = torch.randn(B, 3, generator=g)
+            d = (d / d.norm(dim=1, keepdim=True)).to(cuda)
+            perm = torch.randperm(B, generator=g).to(cuda)
+            inv = torch.empty_like(perm)
+            inv[perm] = torch.arange(B, device=cuda)
+            outs = []
+            for w12 in (0, 1):
+                assert lib.pnr_set_option(b"palette_waves12", w12) == 0
+                for rep in range(3):     # run-to-run reproducibility too
+                    outs.append(f(x, d))
+                s, c, a = f(x[perm].contiguous(), d[perm].contiguous())
+                outs.append((s[inv], c[inv], a[inv]))
+            for o in outs[1:]:
+                for u, v in zip(o, outs[0]):
+                    assert torch.equal(u, v)
+    finally:
+        lib.pnr_set_option(b"palette_waves12", 1)
 
 
 # ------------------------------------------------------------------------------------------ optimiser step
