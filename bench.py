@@ -503,6 +503,14 @@ def main(argv=None):
                     ms, rend = timed_frames(mm, bank, kk, n, False, first_step=args.warmup)
                     extra[f"{name}_ms_per_step"] = ms
                     extra[f"{name}_rendered_per_step"] = rend
+                    if name == "palette":   # the same frames with a RegionEdit active (palette/renderer.py:121-147): it runs inside the field kernel's epilogue
+                        from palettenerf_amd import renderer as prenderer
+                        mm.edit = prenderer.RegionEdit(mm.opt)
+                        mm.edit.update_cent(mean_xyz=torch.tensor([0.2, 0.1, -0.1], device=device))
+                        mm.edit.update_std(std_xyz=0.3)
+                        mm.edit.update_delta_hsv(mm.basis_color.data.clamp(0, 1), (mm.basis_color.data * 0.5 + 0.3).flip(0).clamp(0, 1))
+                        timed_frames(mm, bank, kk, 3, False)
+                        extra["palette_region_edit_ms_per_step"], _ = timed_frames(mm, bank, kk, n, False, first_step=args.warmup)
                     del mm
                 except RuntimeError as e:   # reported, never hidden
                     extra[f"{name}_error"] = str(e)

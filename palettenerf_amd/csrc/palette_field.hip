@@ -581,7 +581,7 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
     const uint32_t rows_ub = a->B;
     // one persistent workgroup per CU (100-126 KiB of LDS): 8 waves, or 12 for the specialised 4-basis kernel when its staging fits (three waves per SIMD
     // at <= 168 registers: the dependent layer chain of a wave leaves the SIMD idle too often with two)
-    const bool nb4 = a->precision == PNR_FIELD_F16X3 && edit_mode == 0 && a->num_basis == 4 && !a->overflow_flag;
+    const bool nb4 = a->precision == PNR_FIELD_F16X3 && a->num_basis == 4 && !a->overflow_flag;
     const bool wide = nb4 && g_opt_palette_waves12 && packed_bytes + 12u * 32u * (a->aux_stride + 3u) * 4u <= 160u * 1024u;
     const uint32_t waves = wide ? 12u : 8u;
     const uint32_t ntiles = cdiv(rows_ub ? rows_ub : 1, waves * 32);
@@ -623,9 +623,14 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
     if (a->precision == PNR_FIELD_F16X3 && a->overflow_flag) {   // the instantiation that watches its split operands
         if (edit_mode == 0) PNR_LAUNCH_PAL(1, 0, true); else if (edit_mode == 1) PNR_LAUNCH_PAL(1, 1, true); else PNR_LAUNCH_PAL(1, 2, true);
     } else if (a->precision == PNR_FIELD_F16X3) {
-        static bool attr_nb4[2][kMaxDevices] = {};
-        if (nb4 && wide) PNR_LAUNCH_PAL_NB(1, 0, false, 4, 12, attr_nb4[1]);   // the shipped default (main_palette.py:76): specialised epilogue
-        else if (nb4) PNR_LAUNCH_PAL_NB(1, 0, false, 4, 8, attr_nb4[0]);
+        static bool attr_nb4[6][kMaxDevices] = {};
+        // the shipped default of 4 bases (main_palette.py:76): specialised epilogue, 12-wave workgroups when the staging fits
+        if (nb4 && wide && edit_mode == 0) PNR_LAUNCH_PAL_NB(1, 0, false, 4, 12, attr_nb4[0]);
+        else if (nb4 && wide && edit_mode == 1) PNR_LAUNCH_PAL_NB(1, 1, false, 4, 12, attr_nb4[1]);
+        else if (nb4 && wide) PNR_LAUNCH_PAL_NB(1, 2, false, 4, 12, attr_nb4[2]);
+        else if (nb4 && edit_mode == 0) PNR_LAUNCH_PAL_NB(1, 0, false, 4, 8, attr_nb4[3]);
+        else if (nb4 && edit_mode == 1) PNR_LAUNCH_PAL_NB(1, 1, false, 4, 8, attr_nb4[4]);
+        else if (nb4) PNR_LAUNCH_PAL_NB(1, 2, false, 4, 8, attr_nb4[5]);
         else if (edit_mode == 0) PNR_LAUNCH_PAL(1, 0, false); else if (edit_mode == 1) PNR_LAUNCH_PAL(1, 1, false); else PNR_LAUNCH_PAL(1, 2, false);
     } else {
         if (edit_mode == 0) PNR_LAUNCH_PAL(0, 0, false); else if (edit_mode == 1) PNR_LAUNCH_PAL(0, 1, false); else PNR_LAUNCH_PAL(0, 2, false);
