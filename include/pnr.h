@@ -336,6 +336,7 @@ typedef struct pnr_palette_field_args {
     const void* edit_device;       /* internal (frame loop): the edit parameters already on the device; NULL for callers */
     float enc_scale[3];            /* power-of-two prescales of enc / enc_palette / enc_clip in the split-fp16 path (0 or 1 = none) */
     int32_t* overflow_flag;        /* optional (device): set to 1 when a split-fp16 operand exceeds fp16's range (the kernel then watches its operands) */
+    void* tile_counter;            /* internal (frame loop): device uint32, zero at launch -- waves fetch their 32-sample tiles from it; NULL = static schedule */
 } pnr_palette_field_args;
 int pnr_palette_field_stages_aux(uint32_t num_basis, uint32_t clip_dim, int pred_clip);   /* 1 when the field kernel stages aux rows in LDS (then it can composite them) */
 uint64_t pnr_palette_field_packed_bytes(uint32_t num_basis, uint32_t clip_dim, int pred_clip);

@@ -132,7 +132,7 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
 // Workgroup 0 also adds the previous march's sample partials and writes this iteration's control block for the kernels that follow.
 template <bool MIP, bool POW2>
 __global__ void __launch_bounds__(kRayBlock) k_frame_march(const FrameCtl* __restrict__ prev, FrameCtl* __restrict__ cur, const int32_t* __restrict__ alive_prev,
-                                                           int32_t* __restrict__ rays_alive, const int32_t* __restrict__ scratch, uint32_t N, uint32_t max_steps,
+                                                           int32_t* __restrict__ rays_alive, const int32_t* __restrict__ scratch, int32_t* __restrict__ scratch_rw, uint32_t N, uint32_t max_steps,
                                                            const int32_t* __restrict__ partials_prev, uint32_t n_partials_prev,
                                                            const float* __restrict__ rays_t, const float* __restrict__ rays_o,
                                                            const float* __restrict__ rays_d, MarchParams p, const uint8_t* __restrict__ grid,
@@ -165,6 +165,7 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_march(const FrameCtl* __res
             c.done = done;
             c.pad0 = scratch[1];   // fp16-range overflow flag raised by a field launch of an earlier iteration (0 = none)
             *cur = c;
+            scratch_rw[2] = 0;     // the wave-tile counter of this iteration's field launch
         }
     }
     if (done || blockIdx.x >= nchunks) { if (threadIdx.x == 0) emitted_partials[blockIdx.x] = 0; return; }
@@ -825,6 +826,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
         pf.precision = a->field_precision; pf.xyzs = w.xyzs;
         for (int k = 0; k < 3; k++) pf.enc_scale[k] = a->enc_scale[k];
         pf.overflow_flag = a->watch_overflow ? w.scratch + 1 : nullptr;
+        pf.tile_counter = g_opt_dynamic_tiles ? w.scratch + 2 : nullptr;
         if (pal->edit && pal->edit->mode != 0) {   // RegionEdit / Stylizer: parameters uploaded once for the whole frame
             const int rc = pnr_internal_edit_upload(pal->edit, w.edit, s);
             if (rc != PNR_OK) return rc;
@@ -881,16 +883,16 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             const uint32_t rows_ub = (uint64_t)alive_ub * 8 < N ? alive_ub * 8 : N;
             const dim3 gm(ray_blocks < 2048u ? ray_blocks : 2048u), bm(kRayBlock);
             if (use_mip && pow2)
-                hipLaunchKernelGGL((k_frame_march<true, true>), gm, bm, march_lds, s, prev, cur, alive_prev, alive_in, w.scratch, N, a->max_steps, w.partials[(iter + 1) & 1], prev_partials,
+                hipLaunchKernelGGL((k_frame_march<true, true>), gm, bm, march_lds, s, prev, cur, alive_prev, alive_in, w.scratch, w.scratch, N, a->max_steps, w.partials[(iter + 1) & 1], prev_partials,
                                    w.rays_t, in_o, in_d, mp, a->bitfield, in_far, w.xyzs, w.dirs, w.deltas, mip, w.partials[iter & 1]);
             else if (use_mip)
-                hipLaunchKernelGGL((k_frame_march<true, false>), gm, bm, march_lds, s, prev, cur, alive_prev, alive_in, w.scratch, N, a->max_steps, w.partials[(iter + 1) & 1], prev_partials,
+                hipLaunchKernelGGL((k_frame_march<true, false>), gm, bm, march_lds, s, prev, cur, alive_prev, alive_in, w.scratch, w.scratch, N, a->max_steps, w.partials[(iter + 1) & 1], prev_partials,
                                    w.rays_t, in_o, in_d, mp, a->bitfield, in_far, w.xyzs, w.dirs, w.deltas, mip, w.partials[iter & 1]);
             else if (pow2)
-                hipLaunchKernelGGL((k_frame_march<false, true>), gm, bm, march_lds, s, prev, cur, alive_prev, alive_in, w.scratch, N, a->max_steps, w.partials[(iter + 1) & 1], prev_partials,
+                hipLaunchKernelGGL((k_frame_march<false, true>), gm, bm, march_lds, s, prev, cur, alive_prev, alive_in, w.scratch, w.scratch, N, a->max_steps, w.partials[(iter + 1) & 1], prev_partials,
                                    w.rays_t, in_o, in_d, mp, a->bitfield, in_far, w.xyzs, w.dirs, w.deltas, mip, w.partials[iter & 1]);
             else
-                hipLaunchKernelGGL((k_frame_march<false, false>), gm, bm, march_lds, s, prev, cur, alive_prev, alive_in, w.scratch, N, a->max_steps, w.partials[(iter + 1) & 1], prev_partials,
+                hipLaunchKernelGGL((k_frame_march<false, false>), gm, bm, march_lds, s, prev, cur, alive_prev, alive_in, w.scratch, w.scratch, N, a->max_steps, w.partials[(iter + 1) & 1], prev_partials,
                                    w.rays_t, in_o, in_d, mp, a->bitfield, in_far, w.xyzs, w.dirs, w.deltas, mip, w.partials[iter & 1]);
             const uint32_t gx = cdiv(rows_ub, 256);
             hipEvent_t e0 = timing ? next_event() : nullptr, e1 = timing ? next_event() : nullptr;

@@ -184,7 +184,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
                                                                    float* __restrict__ rgbs, float* __restrict__ aux, uint32_t stage_stride,
                                                                    const int32_t* __restrict__ rays_alive, const float* __restrict__ weights_sum,
                                                                    float* __restrict__ aux_map, float T_thresh, const float* __restrict__ xyzs,
-                                                                   const EditParams* __restrict__ ep, int32_t* __restrict__ overflow_flag) {
+                                                                   const EditParams* __restrict__ ep, int32_t* __restrict__ overflow_flag,
+                                                                   uint32_t* __restrict__ tile_counter) {
     if (ctl && ctl->done) return;
     const uint32_t B = ctl ? (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step : B_arg;
     constexpr uint32_t kTile = WAVES * 32;
@@ -201,8 +202,22 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
     // can run here (fstep = samples per ray), otherwise the composite launch does it
     const uint32_t fstep = (stage_stride && ctl && aux_map && ctl->n_step <= 8 && (32 % ctl->n_step) == 0) ? (uint32_t)ctl->n_step : 0u;
     const bool fuse_composite = fstep != 0;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint32_t n = tile * kTile + wave * 32 + (lane & 31);
+    // Work is handed out per 32-sample wave tile: the static persistent schedule (workgroup b takes tiles b, b + grid, ...), or -- an experiment
+    // kept behind pnr_set_option("dynamic_tiles") -- every wave fetching its next wave tile from a device counter (tile_counter, zeroed by the
+    // iteration's march launch).  The idea: a launch of 11.08 workgroup tiles per CU takes the time of 12 with the static schedule.  Measured:
+    // garden frame 14.6 -> 20.2 ms -- 34 k waves queue on one counter and a workgroup's waves no longer read neighbouring rows.  Off.
+    const uint32_t nwt = (B + 31) / 32;
+    for (uint32_t it = 0;; it++) {
+        uint32_t wt;
+        if (tile_counter) {
+            uint32_t got = 0;
+            if (lane == 0) got = atomicAdd(tile_counter, 1u);
+            wt = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+        } else {
+            wt = (blockIdx.x + it * gridDim.x) * WAVES + wave;
+        }
+        if (wt >= nwt) break;
+        const uint32_t n = wt * 32 + (lane & 31);
         const bool valid = n < B && (!deltas || deltas[(size_t)(n < B ? n : 0) * 2] != 0.0f);
         if (!__any(valid)) continue;
         const uint32_t row = n < B ? n : (B - 1);
@@ -420,7 +435,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
         if (stage_stride) {   // same wave wrote the slab: DS operations of a wave complete in order
             float* slab = reinterpret_cast<float*>(w + packed_bytes) + (size_t)wave * 32 * stage_stride;
             float* ex = reinterpret_cast<float*>(w + packed_bytes) + (size_t)WAVES * 32 * stage_stride + (size_t)wave * 96;
-            const uint32_t n0 = tile * kTile + wave * 32, nq = (uint32_t)pp.aux_stride / 4;
+            const uint32_t n0 = wt * 32, nq = (uint32_t)pp.aux_stride / 4;
             const unsigned long long live = __ballot(valid && h == 0);     // rows of dead / out-of-range slots hold stale slab data: skip them
             if (fuse_composite) {
                 // aux_map[ray] += sum_k weight_k * row_k: the recurrence of raymarching.cu:1114-1185 (weights from the weights_sum of
@@ -618,7 +633,7 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
                            static_cast<const FrameCtlView*>(a->ctl), a->B, a->enc, a->enc_palette, a->enc_clip, a->level_stride, a->dirs,      \
                            a->deltas, static_cast<const unsigned char*>(a->packed), packed_bytes, pp, a->sigmas, a->rgbs, a->aux,              \
                            stage_stride, fuse ? a->rays_alive : nullptr, fuse ? a->weights_sum : nullptr, fuse ? a->aux_map : nullptr,         \
-                           a->T_thresh, a->xyzs, ep_dev, a->overflow_flag);                                                                    \
+                           a->T_thresh, a->xyzs, ep_dev, a->overflow_flag, static_cast<uint32_t*>(a->tile_counter));                          \
     } while (0)
     if (a->precision == PNR_FIELD_F16X3 && a->overflow_flag) {   // the instantiation that watches its split operands
         if (edit_mode == 0) PNR_LAUNCH_PAL(1, 0, true); else if (edit_mode == 1) PNR_LAUNCH_PAL(1, 1, true); else PNR_LAUNCH_PAL(1, 2, true);

@@ -88,4 +88,5 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
 extern int g_opt_block_skip;   // exact jumps over empty 4^3 / 8^3 / 16^3 blocks in the march
 extern int g_opt_aux_fusion;   // PaletteNeRF frame loop: aux composite inside the field kernel
 extern int g_opt_composite_fusion;   // NeRF frame loop: n_step == 1 iterations composited inside the field kernel
+extern int g_opt_dynamic_tiles;      // frame loops: field kernels hand wave tiles out through a device counter instead of a static schedule
 extern int g_opt_iteration_margin;   // frame loops: spare iterations enqueued beyond the previous frame's count before the first host look
