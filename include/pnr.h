@@ -464,6 +464,19 @@ int pnr_palette_train_shade_backward(uint32_t M, uint32_t num_basis, uint32_t cl
                                      float* grad_clip_feat, float* grad_smooth_norm, float* grad_basis_color, void* workspace,
                                      uint64_t workspace_bytes, pnr_stream_t stream);
 
+/* The two heads of PaletteNetwork.color under autograd as one launch each way (replaces, per training step, the two library GEMMs + bias add +
+ * softplus + add + row sum + divide of palette/network.py:262-268 and their backward -- about twenty launches):
+ *   h [M, in_dim] (basis_net's output, in_dim <= 16), w_offsets_radiance [3nb+1, in_dim], b_offsets_radiance [3nb+1], w_omega [nb, in_dim]
+ *   -> offsets_radiance [M, 3nb+1] = h W_or^T + b,   omega [M, nb] = s / sum(s), s = softplus(h W_om^T) + 0.05      (fp32 fma chains)
+ * backward: grad_offsets_radiance [M, 3nb+1], grad_omega [M, nb] -> grad_h [M, in_dim] (NULL: not wanted) and
+ *   grad_pre [M, 3nb+1+nb] = [grad_offsets_radiance | dL/d(h W_om^T)], from which pnr_linear_wgrad(h, grad_pre) gives the stacked weight
+ *   gradient [3nb+1+nb, in_dim] and pnr_linear_bgrad(grad_pre)[:3nb+1] the bias gradient.  nb <= PNR_MAX_BASIS. */
+int pnr_palette_heads_forward(const float* h, const float* w_offsets_radiance, const float* b_offsets_radiance, const float* w_omega, uint32_t M,
+                              uint32_t num_basis, uint32_t in_dim, float* offsets_radiance, float* omega, pnr_stream_t stream);
+int pnr_palette_heads_backward(const float* h, const float* w_offsets_radiance, const float* w_omega, const float* grad_offsets_radiance,
+                               const float* grad_omega, uint32_t M, uint32_t num_basis, uint32_t in_dim, float* grad_h, float* grad_pre,
+                               pnr_stream_t stream);
+
 /* replace rgb_to_hsv / hsv_to_rgb, palette/src/palette_func.h, palette.cu:135-149 */
 int pnr_rgb_to_hsv(uint32_t n, const float* input, float* output, pnr_stream_t stream);
 int pnr_hsv_to_rgb(uint32_t n, const float* input, float* output, pnr_stream_t stream);

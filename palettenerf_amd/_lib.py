@@ -74,6 +74,8 @@ SIGNATURES = {
     "pnr_palette_train_shade_workspace_bytes": [_u32],
     "pnr_palette_train_shade_forward": [_u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "pnr_palette_train_shade_backward": [_u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _ptr],
+    "pnr_palette_heads_forward": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr, _ptr],
+    "pnr_palette_heads_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr, _ptr],
     "pnr_image_to_uint8": [_ptr, _u64, _int, _ptr, _ptr],
     "pnr_adam_max_tensors": [],
     "pnr_adam_step": [_ptr, _u32, _ptr, _ptr],

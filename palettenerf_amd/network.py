@@ -11,7 +11,8 @@ import torch.nn.functional as F
 from .activation import trunc_exp
 from .encoding import get_encoder
 from .linear import Linear
-from .mlp import encode_mlp, run_mlp
+from .mlp import MIN_ROWS as _MLP_MIN_ROWS, encode_mlp, run_mlp
+from .palette_utils import palette_heads
 from .renderer import NeRFRenderer, PaletteRenderer
 
 
@@ -39,6 +40,13 @@ def _fused_arch_ok(m):
 
 def _fused_density_ok(m, x):
     return bool(m.fused_field) and x.is_cuda and not torch.is_grad_enabled() and not torch.is_autocast_enabled() and _fused_arch_ok(m)
+
+
+def _fused_heads_ok(m, h):
+    """Training batches (fp32, autograd on, not under autocast) take the two colour heads through pnr_palette_heads_*."""
+    return (h.is_cuda and h.ndim == 2 and h.dtype == torch.float32 and torch.is_grad_enabled() and not torch.is_autocast_enabled()
+            and h.shape[0] >= _MLP_MIN_ROWS and h.shape[1] <= 16 and m.num_basis <= 10 and m.offsets_radiance_net.weight.dtype == torch.float32
+            and (h.requires_grad or m.offsets_radiance_net.weight.requires_grad or m.omega_net[0].weight.requires_grad))
 
 
 class NeRFNetwork(NeRFRenderer):
@@ -155,9 +163,12 @@ class PaletteNetwork(PaletteRenderer):
         diffuse = torch.sigmoid(_run(self.diff_net, g))
         view_dep = torch.sigmoid(_run(self.color_net, torch.cat([self.encoder_dir(d), g], dim=-1)))
         h = encode_mlp(self.encoder_palette, x, self.bound, diffuse.detach(), self.basis_net, act=F.elu)   # cat([encoder_palette(x), diffuse]) -> basis_net
-        offsets_radiance = self.offsets_radiance_net(h)
-        omega = self.omega_net(h) + 0.05
-        omega = omega / omega.sum(dim=-1, keepdim=True)
+        if _fused_heads_ok(self, h):
+            offsets_radiance, omega = palette_heads(h, self.offsets_radiance_net, self.omega_net[0])
+        else:
+            offsets_radiance = self.offsets_radiance_net(h)
+            omega = self.omega_net(h) + 0.05
+            omega = omega / omega.sum(dim=-1, keepdim=True)
         return omega, offsets_radiance, view_dep, diffuse
 
     def get_params(self, lr):

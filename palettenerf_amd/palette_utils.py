@@ -125,6 +125,54 @@ class _palette_train_shade(Function):
 palette_train_shade = _palette_train_shade.apply
 
 
+class _palette_heads(Function):
+    """offsets_radiance_net + omega_net + normalisation of PaletteNetwork.color (palette/network.py:262-268) as one HIP launch each way:
+    see `pnr_palette_heads_forward` in include/pnr.h.  h [M, in] -> (offsets_radiance [M, 3 nb + 1], omega [M, nb])."""
+
+    @staticmethod
+    def forward(ctx, h, w_or, b_or, w_om):
+        f32 = torch.float32
+        h, w_or = require(h.contiguous(), f32, "h"), require(w_or.contiguous(), f32, "offsets_radiance_net.weight")
+        b_or, w_om = require(b_or.contiguous(), f32, "offsets_radiance_net.bias"), require(w_om.contiguous(), f32, "omega_net.0.weight")
+        M, n_in = h.shape
+        nb = w_om.shape[0]
+        if w_or.shape != (3 * nb + 1, n_in) or b_or.shape != (3 * nb + 1,) or w_om.shape != (nb, n_in):
+            raise RuntimeError("palette_heads: offsets_radiance_net must be Linear(in, 3 nb + 1) and omega_net.0 Linear(in, nb, bias=False)")
+        offsets_radiance = torch.empty(M, 3 * nb + 1, device=h.device, dtype=f32)
+        omega = torch.empty(M, nb, device=h.device, dtype=f32)
+        call("pnr_palette_heads_forward", ptr(h), ptr(w_or), ptr(b_or), ptr(w_om), _u32(M), _u32(nb), _u32(n_in), ptr(offsets_radiance), ptr(omega))
+        ctx.save_for_backward(h, w_or, w_om)
+        return offsets_radiance, omega
+
+    @staticmethod
+    def backward(ctx, g_or, g_omega):
+        from .linear import bias_grad, weight_grad
+        h, w_or, w_om = ctx.saved_tensors
+        M, n_in = h.shape
+        nb = w_om.shape[0]
+        orw = 3 * nb + 1
+        dev, f32 = h.device, torch.float32
+        g_or = torch.zeros(M, orw, device=dev, dtype=f32) if g_or is None else g_or.contiguous().float()
+        g_omega = torch.zeros(M, nb, device=dev, dtype=f32) if g_omega is None else g_omega.contiguous().float()
+        g_h = torch.empty_like(h) if ctx.needs_input_grad[0] else None
+        g_pre = torch.empty(M, orw + nb, device=dev, dtype=f32)
+        call("pnr_palette_heads_backward", ptr(h), ptr(w_or), ptr(w_om), ptr(g_or), ptr(g_omega), _u32(M), _u32(nb), _u32(n_in), ptr(g_h), ptr(g_pre))
+        g_w_or = g_b = g_w_om = None
+        if M == 0:
+            return g_h, torch.zeros_like(w_or), torch.zeros(orw, device=dev, dtype=f32), torch.zeros_like(w_om)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[3]:
+            g_w = weight_grad(h, g_pre)            # [3 nb + 1 + nb, in]: both heads in one reduction
+            g_w_or, g_w_om = g_w[:orw], g_w[orw:]
+        if ctx.needs_input_grad[2]:
+            g_b = bias_grad(g_pre)[:orw]
+        return g_h, g_w_or, g_b, g_w_om
+
+
+def palette_heads(h, offsets_radiance_net, omega_linear):
+    """(offsets_radiance, omega) from basis_net's output through the fused heads kernel."""
+    return _palette_heads.apply(h, offsets_radiance_net.weight, offsets_radiance_net.bias, omega_linear.weight)
+
+
 def get_palette_weight_with_hist(rgb, hist_weights):
     """palette/utils.py:117-124: per-pixel palette weights read from the extraction's 3-D colour LUT `hist_weights` [1, nb, R, G, B]
     (PaletteRenderer.initialize_palette keeps it in that layout) by trilinear interpolation at the pixel's colour; zero outside [0, 1]^3.

@@ -129,6 +129,11 @@ def test_training_entry_points_validate_without_gpu():
     assert lib.pnr_palette_train_shade_workspace_bytes(u32(4)) == 512 * 4 * 3 * 4
     assert lib.pnr_palette_train_shade_forward(u32(8), u32(17), u32(0), None, None, None, None, None, None, None, None, None, None) == -2   # nb > 16
     assert lib.pnr_palette_train_shade_forward(u32(0), u32(4), u32(16), None, None, None, None, None, None, None, None, None, None) == 0
+    assert lib.pnr_palette_heads_forward(None, None, None, None, u32(8), u32(11), u32(15), None, None, None) == -2                          # nb > PNR_MAX_BASIS
+    assert lib.pnr_palette_heads_forward(None, None, None, None, u32(8), u32(4), u32(17), None, None, None) == -2                           # in_dim > 16
+    assert lib.pnr_palette_heads_forward(None, None, None, None, u32(0), u32(4), u32(15), None, None, None) == 0
+    assert lib.pnr_palette_heads_forward(None, None, None, None, u32(8), u32(4), u32(15), None, None, None) == -1
+    assert lib.pnr_palette_heads_backward(None, None, None, None, None, u32(8), u32(4), u32(15), None, None, None) == -1
     assert lib.pnr_nerf_density_forward(None, None, u32(8), f32(1.0), None, None, i32(7), f32(1.0), None) == -2                                      # precision
     assert lib.pnr_nerf_density_forward(None, None, u32(8), f32(1.0), None, None, i32(1), f32(1.0), None) == -1
     assert lib.pnr_linear_bgrad(None, i32(0), u32(0), u32(13), None, i32(1), None, u64(0), None) == -1                                      # no output

@@ -952,6 +952,74 @@ def test_march_sparse_scene_block_jumps_bit_exact(cuda, dt_gamma):
     np.testing.assert_array_equal(host(dl), odl)
 
 
+@pytest.mark.parametrize("nb,n_in,frozen_h", [(4, 15, False), (5, 15, True), (1, 16, False), (10, 7, False)])
+def test_palette_heads_match_the_torch_formulas(cuda, nb, n_in, frozen_h):
+    """pnr_palette_heads_* against the reference's torch arithmetic for the two colour heads (palette/network.py:262-268: Linear with bias,
+    Linear + Softplus, + 0.05, / row sum) evaluated in float64 with autograd: forward 2e-6, gradients 2e-5 of each tensor's largest
+    gradient.  Rows around softplus' linear threshold, nb = 1 (omega == 1, zero gradient) and PNR_MAX_BASIS, a partial last tile."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(nb * 31 + n_in)
+    M = 9000 + nb
+    h = torch.randn(M, n_in, generator=g)
+    w_or, b_or = torch.randn(3 * nb + 1, n_in, generator=g) * 0.3, torch.randn(3 * nb + 1, generator=g) * 0.1
+    w_om = torch.randn(nb, n_in, generator=g) * 0.5
+    h[:40] *= torch.linspace(5.0, 30.0, 40)[:, None]                 # pre-activations beyond F.softplus' threshold (20)
+    w1, w2 = torch.randn(M, 3 * nb + 1, generator=g), torch.randn(M, nb, generator=g)
+
+    def leafs(dtype, device):
+        return [t.to(device=device, dtype=dtype).requires_grad_(not (frozen_h and k == 0)) for k, t in enumerate((h, w_or, b_or, w_om))]
+
+    hh, a, b, c = leafs(torch.float64, "cpu")
+    offrad = F.linear(hh, a, b)
+    om = F.softplus(F.linear(hh, c)) + 0.05
+    om = om / om.sum(-1, keepdim=True)
+    ((offrad * w1.double()).sum() + (om * w2.double()).sum()).backward()
+
+    h2, a2, b2, c2 = leafs(torch.float32, cuda)
+    offrad2, om2 = palette_utils._palette_heads.apply(h2, a2, b2, c2)
+    np.testing.assert_allclose(offrad2.detach().cpu().numpy(), offrad.detach().numpy(), rtol=2e-6, atol=2e-5)
+    np.testing.assert_allclose(om2.detach().cpu().numpy(), om.detach().numpy(), rtol=2e-6, atol=2e-6)
+    ((offrad2 * w1.to(cuda)).sum() + (om2 * w2.to(cuda)).sum()).backward()
+    for name, got, want in zip(("h", "w_offsets_radiance", "b_offsets_radiance", "w_omega"), (h2, a2, b2, c2), (hh, a, b, c)):
+        if name == "h" and frozen_h:
+            assert got.grad is None
+            continue
+        scale = float(want.grad.abs().max()) + 1e-12
+        err = float((got.grad.cpu().double() - want.grad).abs().max())
+        assert err <= 2e-5 * scale + 1e-7, (name, err, scale)
+
+
+def test_palette_network_colour_heads_take_the_fused_kernel_in_training(cuda):
+    """PaletteNetwork.color on a training batch routes the heads through pnr_palette_heads_* and gives the same outputs and parameter gradients
+    as the layer-by-layer path (library GEMMs) to 1e-5 relative."""
+    from palettenerf_amd import network, renderer, scene
+    m = network.PaletteNetwork(renderer.default_opt(test=False), bound=2, cuda_ray=True)
+    scene.seed_field_(m, 0)
+    m = m.to(cuda).train()
+    g = torch.Generator().manual_seed(3)
+    M = 10000
+    x = (torch.rand(M, 3, generator=g) * 2 - 1).to(cuda)
+    d = torch.nn.functional.normalize(torch.randn(M, 3, generator=g), dim=-1).to(cuda)
+    geo = torch.randn(M, 15, generator=g).to(cuda)
+    wts = [torch.randn(M, k, generator=g).to(cuda) for k in (m.num_basis, 3 * m.num_basis + 1)]
+    results = []
+    for fused in (True, False):
+        m.zero_grad(set_to_none=True)
+        saved = network._fused_heads_ok
+        if not fused:
+            network._fused_heads_ok = lambda *_: False
+        try:
+            omega, offrad, _, _ = m.color(x, d, geo_feat=geo)
+        finally:
+            network._fused_heads_ok = saved
+        ((omega * wts[0]).sum() + (offrad * wts[1]).sum()).backward()
+        results.append((omega.detach(), offrad.detach(), m.offsets_radiance_net.weight.grad.clone(), m.offsets_radiance_net.bias.grad.clone(),
+                        m.omega_net[0].weight.grad.clone(), m.encoder_palette.embeddings.grad.clone()))
+    for a, b in zip(*results):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 1e-5 * scale + 1e-7
+
+
 @pytest.mark.parametrize("nb,clip_dim,has_clip,has_smooth,frozen", [(4, 16, False, False, False), (4, 16, True, True, False), (6, 0, False, False, True),
                                                                     (1, 3, True, False, False), (16, 2, True, True, False)])
 def test_palette_train_shade_matches_the_torch_formulas(cuda, nb, clip_dim, has_clip, has_smooth, frozen):
