@@ -130,8 +130,17 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
 // loads per thread out of L2) -- that gives n_alive and n_step of this iteration without a separate launch -- and derives the output
 // offset of its chunk by summing the counts in front of it; a surviving ray is written to its compacted slot and marched from there.
 // Workgroup 0 also adds the previous march's sample partials and writes this iteration's control block for the kernels that follow.
+#ifdef PNR_MARCH_TIMING
+// instrumented builds only: per-wave time stamps (wall_clock64: 100 MHz) of ONE iteration's march launch (g_march_timing_iter)
+constexpr int kTimingWaves = 8192;
+__device__ unsigned long long g_march_timing[kTimingWaves * 8];
+__device__ int g_march_timing_iter = 3;
+#define PNR_STAMP(k) do { if (timing && (threadIdx.x & 63) == 0) g_march_timing[(size_t)twave * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define PNR_STAMP(k) do { } while (0)
+#endif
 template <bool MIP, bool POW2>
-__global__ void __launch_bounds__(kRayBlock) k_frame_march(const FrameCtl* __restrict__ prev, FrameCtl* __restrict__ cur, const int32_t* __restrict__ alive_prev,
+__global__ void __launch_bounds__(kRayBlock) __attribute__((amdgpu_waves_per_eu(6))) k_frame_march(const FrameCtl* __restrict__ prev, FrameCtl* __restrict__ cur, const int32_t* __restrict__ alive_prev,
                                                            int32_t* __restrict__ rays_alive, const int32_t* __restrict__ scratch, int32_t* __restrict__ scratch_rw, uint32_t N, uint32_t max_steps,
                                                            const int32_t* __restrict__ partials_prev, uint32_t n_partials_prev,
                                                            const float* __restrict__ rays_t, const float* __restrict__ rays_o,
@@ -141,12 +150,53 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_march(const FrameCtl* __res
                                                            int32_t* __restrict__ emitted_partials /* [gridDim.x] */) {
     __shared__ int csum[kRayBlock / PNR_WAVE];
     __shared__ unsigned long long red[kRayBlock / PNR_WAVE];
+#ifdef PNR_MARCH_TIMING
+    const bool timing = prev->iterations + 1 == g_march_timing_iter && blockIdx.x * (kRayBlock / PNR_WAVE) < (uint32_t)kTimingWaves;
+    const uint32_t twave = blockIdx.x * (kRayBlock / PNR_WAVE) + threadIdx.x / PNR_WAVE;
+#endif
+    PNR_STAMP(0);
+    const int32_t* counts = scratch + kHdr;
+    // Every independent load of the prologue is issued before the first wait: the chunk counts (their total is n_alive, the part in front of
+    // this workgroup's chunk its output offset), this thread's slot of the previous alive list and the occupancy mip on its way to LDS --
+    // one trip to L2 instead of three dependent ones (profiles/march_timing.py on a PNR_MARCH_TIMING build: the median wave has its compacted
+    // slot 6.2 -> 3.9 us after the launch; the launch itself is bounded by its few longest rays, ~1.3 us per probe of the slowest lane).
+    constexpr int kCountLoads = 8, kMipLoads = 5;
+    const uint32_t max_chunks = (N + kRayBlock - 1) / kRayBlock;   // the counts array and the alive lists are sized for N rays: loads inside that
+    int32_t cv[kCountLoads];                                       // range need not wait for the control block (masked once it has arrived)
+#pragma unroll
+    for (int u = 0; u < kCountLoads; u++) {
+        const uint32_t j = threadIdx.x + (uint32_t)u * kRayBlock;
+        cv[u] = j < max_chunks ? counts[j] : 0;
+    }
+    const uint32_t slot0 = blockIdx.x * kRayBlock + threadIdx.x;
+    int index0 = slot0 < N ? alive_prev[slot0] : -1;
+    extern __shared__ uint32_t mip_smem[];
+    const uint32_t mip_n = MIP ? 2 * p.mip_words + 8 : 0;   // 'any' mask, 'all' mask, occupied box (stage_mip's layout)
+    const bool mip_fast = MIP && mip_n <= (uint32_t)kMipLoads * kRayBlock * 4 && (mip_n & 3u) == 0;
+    uint4 mv[kMipLoads];
+    if (mip_fast) {
+#pragma unroll
+        for (int u = 0; u < kMipLoads; u++) {
+            const uint32_t i = (threadIdx.x + (uint32_t)u * kRayBlock) * 4;
+            mv[u] = i < mip_n ? *reinterpret_cast<const uint4*>(&mip[i]) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
     if (prev->done) { if (blockIdx.x == 0 && threadIdx.x == 0) *cur = *prev; return; }
     const uint32_t n_prev = (uint32_t)prev->n_alive, nchunks = (n_prev + kRayBlock - 1) / kRayBlock;
-    const int32_t* counts = scratch + kHdr;
-    unsigned long long part = 0;
-    for (uint32_t j = threadIdx.x; j < nchunks; j += kRayBlock) part += (unsigned long long)counts[j];
-    const uint32_t n_alive = (uint32_t)block_sum_u64(part, red);
+    if (slot0 >= n_prev) index0 = -1;
+    unsigned long long part = 0;   // high word: all chunks, low word: the chunks in front of this workgroup's first one
+#pragma unroll
+    for (int u = 0; u < kCountLoads; u++) {
+        const uint32_t j = threadIdx.x + (uint32_t)u * kRayBlock;
+        if (j >= nchunks) cv[u] = 0;
+        part += ((unsigned long long)(uint32_t)cv[u] << 32) | (j < blockIdx.x ? (unsigned long long)(uint32_t)cv[u] : 0ull);
+    }
+    for (uint32_t j = threadIdx.x + kCountLoads * kRayBlock; j < nchunks; j += kRayBlock) {
+        const unsigned long long v = (unsigned long long)(uint32_t)counts[j];
+        part += (v << 32) | (j < blockIdx.x ? v : 0ull);
+    }
+    const unsigned long long sums = block_sum_u64(part, red);
+    const uint32_t n_alive = (uint32_t)(sums >> 32);
     const uint32_t n_step = (uint32_t)schedule_n_step((int)N, (int)n_alive);
     const int step_now = prev->step + prev->n_step;
     const bool done = n_alive == 0 || (uint32_t)step_now >= max_steps;
@@ -170,16 +220,32 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_march(const FrameCtl* __res
     }
     if (done || blockIdx.x >= nchunks) { if (threadIdx.x == 0) emitted_partials[blockIdx.x] = 0; return; }
     const int lane = threadIdx.x & (PNR_WAVE - 1), wave = threadIdx.x / PNR_WAVE;
-    const uint32_t* mip_lds = stage_mip(mip, MIP ? p.mip_words : 0);
+    PNR_STAMP(1);
+    const uint32_t* mip_lds = nullptr;
+    if (mip_fast) {
+#pragma unroll
+        for (int u = 0; u < kMipLoads; u++) {
+            const uint32_t i = (threadIdx.x + (uint32_t)u * kRayBlock) * 4;
+            if (i < mip_n) *reinterpret_cast<uint4*>(&mip_smem[i]) = mv[u];
+        }
+        __syncthreads();
+        mip_lds = mip_smem;
+    } else {
+        mip_lds = stage_mip(mip, MIP ? p.mip_words : 0);
+    }
+    PNR_STAMP(2);
     uint32_t emitted = 0;
-    uint32_t base = 0, summed_to = 0;   // base = sum of counts[0 .. summed_to)
+    uint32_t base = (uint32_t)(sums & 0xffffffffull), summed_to = blockIdx.x;   // base = sum of counts[0 .. summed_to)
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        unsigned long long pre = 0;
-        for (uint32_t j = summed_to + threadIdx.x; j < chunk; j += kRayBlock) pre += (unsigned long long)counts[j];
-        base += (uint32_t)block_sum_u64(pre, red);
-        summed_to = chunk;
-        const uint32_t slot = chunk * kRayBlock + threadIdx.x;
-        const int index = slot < n_prev ? alive_prev[slot] : -1;
+        int index = index0;
+        if (chunk != blockIdx.x) {   // a second chunk for this workgroup (frames of more than gridDim.x * 256 rays): the plain sequence
+            unsigned long long pre = 0;
+            for (uint32_t j = summed_to + threadIdx.x; j < chunk; j += kRayBlock) pre += (unsigned long long)counts[j];
+            base += (uint32_t)block_sum_u64(pre, red);
+            summed_to = chunk;
+            const uint32_t slot = chunk * kRayBlock + threadIdx.x;
+            index = slot < n_prev ? alive_prev[slot] : -1;
+        }
         const int keep = index >= 0 ? 1 : 0;
         const unsigned long long alive_mask = __ballot(keep);
         if (lane == 0) csum[wave] = __popcll(alive_mask);
@@ -187,6 +253,7 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_march(const FrameCtl* __res
         int woff = 0;
         for (int wv = 0; wv < wave; wv++) woff += csum[wv];
         __syncthreads();
+        PNR_STAMP(3);
         if (!keep) continue;
         const uint32_t n = base + (uint32_t)woff + (uint32_t)__popcll(alive_mask & ((1ull << lane) - 1ull));
         rays_alive[n] = index;
@@ -202,11 +269,18 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_march(const FrameCtl* __res
         float last_t = t, x, y, z, dt;
         t = skip_to_box<MIP && POW2>(c, bh, t);
         uint32_t step = 0;
+        PNR_STAMP(4);
+#ifdef PNR_MARCH_TIMING
+        uint32_t my_probes = 0;
+#endif
 #ifdef PNR_MARCH_STATS
         unsigned long long probes = 0, empties = 0;
         unsigned int kinds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
         while (t < far && step < n_step) {
+#ifdef PNR_MARCH_TIMING
+            my_probes++;
+#endif
 #ifdef PNR_MARCH_STATS
             probes++;
             int kind = 7;
@@ -240,6 +314,14 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_march(const FrameCtl* __res
 #endif
         emitted += step;
         for (; step < n_step; step++) { pl[0] = 0.0f; pl[1] = 0.0f; pl += 2; }
+        PNR_STAMP(5);
+#ifdef PNR_MARCH_TIMING
+        if (timing) {   // wave maxima of the probe count and of the dependent global brick loads
+            uint32_t mp = my_probes, ml = c.n_loads;
+            for (int off = 32; off > 0; off >>= 1) { mp = max(mp, (uint32_t)__shfl_xor((int)mp, off, 64)); ml = max(ml, (uint32_t)__shfl_xor((int)ml, off, 64)); }
+            if ((threadIdx.x & 63) == 0) { g_march_timing[(size_t)twave * 8 + 6] = mp; g_march_timing[(size_t)twave * 8 + 7] = ml; }
+        }
+#endif
     }
     // one partial per workgroup, summed by workgroup 0 of the next iteration's march: thousands of same-address atomics would serialise in L2
     __shared__ uint32_t wsum[kRayBlock / PNR_WAVE];
@@ -980,6 +1062,15 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
 
 }  // extern "C"
 
+#ifdef PNR_MARCH_TIMING
+extern "C" int pnr_debug_march_timing(unsigned long long* out, int iteration) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(pnr::g_march_timing), sizeof(unsigned long long) * pnr::kTimingWaves * 8) != hipSuccess) return -3;
+    if (iteration >= 0) hipMemcpyToSymbol(HIP_SYMBOL(pnr::g_march_timing_iter), &iteration, sizeof(int));
+    std::vector<unsigned long long> z((size_t)pnr::kTimingWaves * 8, 0ull);
+    hipMemcpyToSymbol(HIP_SYMBOL(pnr::g_march_timing), z.data(), z.size() * sizeof(unsigned long long));
+    return 0;
+}
+#endif
 #ifdef PNR_MARCH_STATS
 extern "C" int pnr_debug_march_kinds(unsigned int* out) {
     hipDeviceSynchronize();

@@ -40,6 +40,13 @@ struct RayCtx {
     const uint32_t* mip_all;
     const float* box;         // LDS: occupied box (min xyz, max xyz), or nullptr
     bool block_skip;          // empty 4^3/8^3/16^3 blocks may be jumped (needs H % 64 == 0 so that blocks nest in the cascades)
+    // the 64 cells of the last MIXED brick this ray looked at (one aligned 8-byte word of the Morton-ordered bitfield): a ray that walks a
+    // partly filled brick cell by cell pays one dependent global load per brick instead of one per cell
+    mutable uint32_t cached_brick;
+    mutable unsigned long long cached_bits;
+#ifdef PNR_MARCH_TIMING
+    mutable uint32_t n_loads;
+#endif
 };
 
 struct MarchParams {  // ray-independent constants, computed once on the host
@@ -77,6 +84,10 @@ __device__ __forceinline__ void ctx_init(RayCtx& c, const float* __restrict__ o,
     c.mip_all = mip_lds ? mip_lds + p.mip_words : nullptr;
     c.box = mip_lds ? reinterpret_cast<const float*>(mip_lds + 2 * p.mip_words) : nullptr;
     c.block_skip = mip_lds != nullptr && (p.H % 64u) == 0 && p.block_skip != 0;
+    c.cached_brick = 0xffffffffu; c.cached_bits = 0ull;
+#ifdef PNR_MARCH_TIMING
+    c.n_loads = 0;
+#endif
 }
 
 // Slab test of the ray against the occupied box.  `far`: parameter beyond which the ray is outside the box for good
@@ -157,6 +168,14 @@ __device__ __forceinline__ bool cell_occupied(const RayCtx& c, uint32_t index) {
         const uint32_t brick = index >> 6, word = brick >> 5, bit = 1u << (brick & 31u);
         if (!(c.mip_any[word] & bit)) return false;
         if (c.mip_all[word] & bit) return true;
+        if (brick != c.cached_brick) {   // (the mip builder reads the bitfield as 8-byte words too: the alignment is part of its contract)
+            c.cached_bits = *reinterpret_cast<const unsigned long long*>(c.grid + (size_t)brick * 8);
+            c.cached_brick = brick;
+#ifdef PNR_MARCH_TIMING
+            c.n_loads++;
+#endif
+        }
+        return (c.cached_bits >> (index & 63u)) & 1ull;
     }
     return c.grid[index >> 3] & (1u << (index & 7u));
 }

@@ -20,10 +20,10 @@ ro, rd = ro.to(dev), rd.to(dev)
 lib = _lib.load()
 out = (ctypes.c_ulonglong * 8)()
 with torch.no_grad():
-    r = m.render(ro, rd, perturb=False, dt_gamma=args.dt_gamma, max_steps=1024, T_thresh=1e-4)
+    r = m.render(ro, rd, perturb=False, dt_gamma=args.wl["dt_gamma"], max_steps=1024, T_thresh=1e-4)
     lib.pnr_debug_march_stats(out, 1)
     lib.pnr_debug_march_max((ctypes.c_uint * 64)(), 1)
-    r = m.render(ro, rd, perturb=False, dt_gamma=args.dt_gamma, max_steps=1024, T_thresh=1e-4)
+    r = m.render(ro, rd, perturb=False, dt_gamma=args.wl["dt_gamma"], max_steps=1024, T_thresh=1e-4)
     lib.pnr_debug_march_stats(out, 1)
 mx = (ctypes.c_uint * 64)()
 lib.pnr_debug_march_max(mx, 1)
