@@ -277,6 +277,7 @@ __device__ __forceinline__ bool march_probe(const RayCtx& c, float& t, float& x,
                 for (int k = 0; k < 3; k++) {
                     const float b = t0 + (fmaf((float)k, back, face) - xc) * rdc;
                     const float eps = fmaf(c.bound * 2.3841858e-7f, ard, (fabsf(b) + 1.0f) * 9.5367432e-7f);  // as in skip_to_box()
+                    if (kind) *kind = k == 0 ? 6 : 7;   // instrumented builds: 6 = the exit plane is too close / its window is taken, 7 = an inner plane as well
                     if (!(b - t0 > 2.0f * eps)) break;
                     float q, prev;
                     lattice_advance(t0, d, b, q, prev);
