@@ -522,9 +522,13 @@ class PaletteFieldFused(_PrecisionGuard):
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         mip = raymarching.occupancy_mip(m.density_bitfield, m.cascade, m.grid_size, m.bound)
         enc = m.encoder
-        for other in (m.encoder_palette, m.encoder_clip):
-            if not torch.equal(other.offsets, enc.offsets) or other.per_level_scale != enc.per_level_scale:
-                raise RuntimeError("the three hash grids must share one level layout")
+        # checked once per set of offset buffers: torch.equal is a device comparison plus a host read, twice per frame in front of the launch otherwise
+        layout_key = tuple((o.offsets.data_ptr(), o.offsets._version, o.per_level_scale) for o in (enc, m.encoder_palette, m.encoder_clip))
+        if getattr(self, "_layout_key", None) != layout_key:
+            for other in (m.encoder_palette, m.encoder_clip):
+                if not torch.equal(other.offsets, enc.offsets) or other.per_level_scale != enc.per_level_scale:
+                    raise RuntimeError("the three hash grids must share one level layout")
+            self._layout_key = layout_key
         stats = (ctypes.c_uint64 * 6)()
         kms = (ctypes.c_float * 2)()
         prec, watch = self.frame_precision()

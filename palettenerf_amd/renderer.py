@@ -664,24 +664,27 @@ class PaletteRenderer(_RendererBase):
             return results
 
         f32 = dict(dtype=torch.float32, device=device)
-        view_dep_rgb_map = torch.zeros(N, 3, **f32)
-        direct_rgb_map = torch.zeros(N, 3, **f32)
-        basis_rgb_map = torch.zeros(N, 3 * nb, **f32)
-        unscaled_basis_rgb_map = torch.zeros(N, 3 * nb, **f32)
-        basis_acc_map = torch.zeros(N, nb, **f32)
-        clip_feat_map = torch.zeros(N, clip_dim, **f32)
-
         # under fp16 autocast only the native loop takes the fused path (fp16 tables, fp32-accurate field); it has no clip-head variant there
         autocast_ok = not torch.is_autocast_enabled() or (self.march_mode == "native" and not perturb and not self.opt.pred_clip)
         # RegionEdit and the Stylizer run inside the fused field kernel's epilogue (pnr_palette_edit): editing costs no extra launch
         use_fused = bool(getattr(self, "fused_field", False)) and autocast_ok
         if use_fused and self.stylizer is not None and not gui_mode:
             raise RuntimeError("the Stylizer renders in gui_mode only (palette/renderer.py:481-488 defines no basis maps for it)")
+        native = use_fused and self.march_mode == "native" and not perturb
         if use_fused:
             if getattr(self, "_fused", None) is None:
                 from .fused import PaletteFieldFused
                 self._fused = PaletteFieldFused(self)
-            aux_map = torch.zeros(N, self._fused.aux_channels, **f32)
+            if not native:   # the device-driven loop brings its own (uninitialised, fully written) aux map
+                aux_map = torch.zeros(N, self._fused.aux_channels, **f32)
+        if not use_fused:    # the reference's six maps (palette/renderer.py:436-441); the fused paths composite one packed aux row instead
+            view_dep_rgb_map = torch.zeros(N, 3, **f32)
+            direct_rgb_map = torch.zeros(N, 3, **f32)
+            basis_rgb_map = torch.zeros(N, 3 * nb, **f32)
+            unscaled_basis_rgb_map = torch.zeros(N, 3 * nb, **f32)
+            basis_acc_map = torch.zeros(N, nb, **f32)
+        if not use_fused or self._fused.clip_dim != clip_dim:
+            clip_feat_map = torch.zeros(N, clip_dim, **f32)
 
         def shade_fused(st, n_alive, n_step, xyzs, dirs, deltas):
             # one fused field launch + ONE flex composite over the packed aux row instead of ~40 launches and 6 flex composites
@@ -728,7 +731,6 @@ class PaletteRenderer(_RendererBase):
             # must come last: the only composite that mutates rays_alive / rays_t / weights_sum (palette/renderer.py:517-519)
             raymarching.composite_rays(*a, st.rays_alive, st.rays_t, sigmas, rgbs, deltas, st.weights_sum, st.depth, st.image, T_thresh)
 
-        native = use_fused and self.march_mode == "native" and not perturb
         if native:  # device-driven loop: same schedule and arithmetic, no per-iteration host sync (pnr_palette_render_frame)
             was_half = self._fused.table_half
             self._fused.table_half = was_half or torch.is_autocast_enabled()     # -O mode: fp16 tables with the reference's half interpolation
