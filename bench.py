@@ -64,6 +64,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra driver-observed legs (exact-fp32 field, palette model)")
     ap.add_argument("--extra-steps", type=int, default=20)
+    ap.add_argument("--frames-in-flight", type=int, nargs="*", default=[2, 3], metavar="F",
+                    help="extra leg (1 GPU): the same camera path with F frames in flight, one host thread + stream + fused-field object each (video throughput)")
     ap.add_argument("--shard-emulation", type=int, default=0, metavar="S",
                     help="1 GPU: also render each of the S tile shards of pose 0 on its own and report max / mean shard ms (load balance of the S-GPU split)")
     ap.add_argument("--no-interleave", action="store_true", help="-m palette: separate hash-table lookups instead of the interleaved copy (A/B)")
@@ -522,6 +524,41 @@ def main(argv=None):
                 except RuntimeError as e:   # reported, never hidden
                     extra[f"{name}_error"] = str(e)
             extra["extra_steps"] = n
+        # --- the same camera path with several frames in flight (palettenerf_amd/pipeline.py: one host thread, fused-field object and stream per
+        #     frame in flight, the same weights).  Throughput of a video render; the headline above stays one frame at a time (its ms/frame is a latency).
+        if not args.no_extras and native and not args.fp16 and args.frames_in_flight:
+            import gc
+            from palettenerf_amd.pipeline import FramesInFlight
+            legs = {}
+            for F in args.frames_in_flight:
+                n = -(-max(6, int(1.5 * args.extra_steps)) // F) * F   # every handle renders the same number of frames
+                try:
+                    fif = FramesInFlight(m, F, device)
+                    t_sub, t_done = {}, {}
+
+                    def rays_of(i, t_sub=t_sub):
+                        t_sub[i] = time.perf_counter()
+                        return bank.get(args.warmup + i)
+
+                    def consume(i, r, t_done=t_done):
+                        t_done[i] = time.perf_counter()
+                        return int(r["rendered"].sum())
+                    fif.render(lambda i: bank.get(i), 2 * F, consume=lambda i, r: 0, **kw)   # every handle: workspace, packed weights, iteration prediction
+                    torch.cuda.synchronize()
+                    gc.collect()
+                    gc.disable()
+                    t0 = time.perf_counter()
+                    counts = fif.render(rays_of, n, consume=consume, **kw)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                    gc.enable()
+                    lat = sorted(t_done[i] - t_sub[i] for i in range(n))
+                    legs[str(F)] = {"value": sum(counts) / dt, "unit": "samples/s", "ms_per_step": dt / n * 1e3, "steps": n,
+                                    "frame_latency_ms_median": lat[n // 2] * 1e3}
+                    del fif
+                except RuntimeError as e:   # reported, never hidden
+                    legs[str(F)] = {"error": str(e)}
+            extra["frames_in_flight"] = legs
         if args.shard_emulation > 1 and native:
             S = args.shard_emulation
             times, samples = [], []

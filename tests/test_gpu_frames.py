@@ -677,3 +677,47 @@ def test_checkpoint_file_to_native_render(cuda, golden_dir, tmp_path, kind, case
     best = checkpoint.save_model(m, str(tmp_path / "ngp.pth"), best=True)
     info = checkpoint.load_model(build().to(cuda), best)
     assert info["missing"] == ["density_grid"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["nerf", "palette"])
+def test_frames_in_flight_equal_frames_rendered_one_by_one(cuda, kind):
+    """palettenerf_amd.pipeline.FramesInFlight: three frames in flight (three host threads, each with its own fused-field object, workspace
+    and stream on the SAME weights) give, pose by pose, bit for bit the images, depths and sample counts of the frames rendered one after
+    another -- the per-thread / per-device state of pnr_*_render_frame and the shared read-only caches hold under concurrency."""
+    from palettenerf_amd import network, renderer, scene
+    from palettenerf_amd.fused import NeRFFieldFused, PaletteFieldFused
+    from palettenerf_amd.pipeline import FramesInFlight
+    if kind == "nerf":
+        m = network.NeRFNetwork(bound=2, cuda_ray=True)
+    else:
+        m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True)
+    scene.seed_field_(m, 0)
+    m = m.to(cuda).eval()
+    m.density_grid.copy_(torch.from_numpy(scene.brick_density_grid()).to(cuda))
+    raymarching.packbits(m.density_grid, 0.5, m.density_bitfield)
+    m.march_mode, m.fused_field, m.count_rendered = "native", True, True
+    m._fused = NeRFFieldFused(m) if kind == "nerf" else PaletteFieldFused(m)
+    H = W = 160
+    intr = scene.intrinsics_from_fov(H, W)
+    rays = []
+    for i in range(7):
+        pose = torch.from_numpy(scene.lookat_pose(azimuth_deg=20.0 + 17.0 * i))[None]
+        ro, rd = scene.get_rays(pose, intr, H, W)
+        rays.append((ro.to(cuda), rd.to(cuda)))
+    kw = dict(perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+    if kind == "palette":
+        kw["gui_mode"] = False
+    keys = ("image", "depth", "weights_sum") + (("basis_rgb", "basis_acc", "view_dep_rgb") if kind == "palette" else ())
+    with torch.no_grad():
+        one_by_one = [m.render(ro, rd, **kw) for ro, rd in rays]
+    want = [{k: r[k].clone() for k in keys} | {"rendered": int(r["rendered"].sum())} for r in one_by_one]
+    fif = FramesInFlight(m, 3)
+    for _ in range(2):   # twice: the second pass runs on warm handles (each thread's iteration prediction comes from a different pose)
+        got = fif.render(lambda i: rays[i], len(rays), **kw)
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert int(g["rendered"].sum()) == w["rendered"], i
+            for k in keys:
+                a, b = g[k].cpu().numpy(), w[k].cpu().numpy()
+                np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+                np.testing.assert_array_equal(np.nan_to_num(a), np.nan_to_num(b), err_msg=f"frame {i} {k}")
