@@ -13,6 +13,9 @@
  *   - return value: 0 on success, PNR_ERR_* (<0) otherwise; pnr_error_string() describes it.
  *     The Python shim turns a non-zero return into RuntimeError (the reference raises
  *     RuntimeError through TORCH_CHECK / std::runtime_error).
+ *   - threads: no entry point keeps global mutable state (pnr_set_option's switches apart); the frame calls keep a pinned control
+ *     block and the previous frame's iteration count per host thread and device and work inside the caller's workspace, so
+ *     several frames may be in flight at once -- one host thread, one workspace and one stream each (palettenerf_amd/pipeline.py).
  *
  * Each entry point cites the reference interface it replaces (file:line under the reference).
  */

@@ -48,7 +48,12 @@ def run(m, frames, stream, out, lat=None):
 
 
 F = int(os.environ.get("FRAMES_IN_FLIGHT", "2"))
-models = [make() for _ in range(F)]
+if os.environ.get("SEPARATE_WEIGHTS"):   # A/B: every handle with its own copy of the weights instead of clone_for_concurrent_frames
+    models = [make() for _ in range(F)]
+else:
+    from palettenerf_amd.pipeline import clone_for_concurrent_frames
+    models = [make()]
+    models += [clone_for_concurrent_frames(models[0]) for _ in range(F - 1)]
 streams = [torch.cuda.Stream() for _ in range(F)]
 for m, s in zip(models, streams):
     run(m, range(4), s, [])
