@@ -73,3 +73,33 @@ class FramesInFlight:
         if errors:
             raise errors[0]
         return out
+
+
+def render_path(model, poses, intrinsics, H, W, frames_in_flight=2, linear_to_srgb=False, to_host=True, **render_kwargs):
+    """The inner loop of the reference's `Trainer.test` over a camera path (nerf/utils.py:704-731, palette/utils.py:993-1044) without the file
+    writer: for every pose  get_rays (:133-147) -> model.render -> [linear_to_srgb for linear-colour scenes] -> `(pred * 255).astype(np.uint8)`
+    for colour and depth.  Rays are generated on the device (pnr_get_rays), the bytes are formed on the device (pnr_image_to_uint8: a frame
+    crosses PCIe as 4 bytes per pixel), and `frames_in_flight` poses are rendered concurrently.
+    poses: [n, 4, 4] camera-to-world (host or device).  Returns (rgb uint8 [n, H, W, 3], depth uint8 [n, H, W]): numpy arrays, or device
+    tensors with to_host=False."""
+    from . import rays as prays
+    poses = torch.as_tensor(poses, dtype=torch.float32)
+    n = poses.shape[0]
+    device = next(model.parameters()).device
+    poses = poses.to(device)
+    fif = FramesInFlight(model, max(1, min(int(frames_in_flight), n)), device)
+
+    def rays_of(i):
+        ro, rd = prays.rays_from_indices(poses[i:i + 1], intrinsics, H, W, None)
+        return ro, rd
+
+    def consume(i, r):
+        rgb = prays.image_to_uint8(r["image"].reshape(H, W, 3), linear_to_srgb)
+        dep = prays.image_to_uint8(r["depth"].reshape(H, W), False)
+        return (rgb.cpu(), dep.cpu()) if to_host else (rgb, dep)
+
+    frames = fif.render(rays_of, n, consume=consume, **render_kwargs)
+    if to_host:
+        import numpy as np
+        return np.stack([f[0].numpy() for f in frames]), np.stack([f[1].numpy() for f in frames])
+    return torch.stack([f[0] for f in frames]), torch.stack([f[1] for f in frames])

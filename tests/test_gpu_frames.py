@@ -721,3 +721,36 @@ def test_frames_in_flight_equal_frames_rendered_one_by_one(cuda, kind):
                 a, b = g[k].cpu().numpy(), w[k].cpu().numpy()
                 np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
                 np.testing.assert_array_equal(np.nan_to_num(a), np.nan_to_num(b), err_msg=f"frame {i} {k}")
+
+
+@pytest.mark.gpu
+def test_render_path_equals_the_reference_test_loop_arithmetic(cuda):
+    """pipeline.render_path (Trainer.test's inner loop, nerf/utils.py:704-731, with two poses in flight) against the same loop written out as the
+    reference does it: get_rays -> render -> `(pred * 255).astype(np.uint8)` on the host.  Bytes are equal wherever the float is finite (the
+    reference's cast of the NaN depth of rays that miss the scene, quirk 7, is platform-defined)."""
+    from palettenerf_amd.fused import NeRFFieldFused
+    from palettenerf_amd import rays as prays
+    from palettenerf_amd.pipeline import render_path
+    m = network.NeRFNetwork(bound=2, cuda_ray=True)
+    scene.seed_field_(m, 0)
+    m = m.to(cuda).eval()
+    m.density_grid.copy_(torch.from_numpy(scene.brick_density_grid()).to(cuda))
+    raymarching.packbits(m.density_grid, 0.5, m.density_bitfield)
+    m.march_mode, m.fused_field = "native", True
+    m._fused = NeRFFieldFused(m)
+    H, W = 96, 128
+    intr = scene.intrinsics_from_fov(H, W)
+    poses = np.stack([scene.lookat_pose(azimuth_deg=30.0 + 40.0 * i) for i in range(5)])
+    kw = dict(perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4, bg_color=1)
+    rgb, dep = render_path(m, poses, intr, H, W, frames_in_flight=2, **kw)
+    assert rgb.shape == (5, H, W, 3) and rgb.dtype == np.uint8 and dep.shape == (5, H, W) and dep.dtype == np.uint8
+    with torch.no_grad():
+        for i in range(5):
+            ro, rd = prays.rays_from_indices(torch.from_numpy(poses[i:i + 1]).to(cuda), intr, H, W, None)   # the device ray generator render_path uses
+            r = m.render(ro, rd, **kw)
+            pred = r["image"].reshape(H, W, 3).cpu().numpy()
+            pdep = r["depth"].reshape(H, W).cpu().numpy()
+            np.testing.assert_array_equal(rgb[i], (pred * 255).astype(np.uint8))
+            ok = np.isfinite(pdep)
+            assert ok.mean() > 0.2
+            np.testing.assert_array_equal(dep[i][ok], (pdep[ok] * 255).astype(np.uint8))
