@@ -338,3 +338,26 @@ def test_stylizer_matches_its_formula_and_starts_as_the_plain_composite():
     want = (omega * want).sum(-2)
     torch.testing.assert_close(st(radiance, omega, palette.expand(M, nb, 3), offsets), want)
     assert float(st.ARAP_loss()) > 0.0
+
+
+# ------------------------------------------------------------------ several frames in flight (host side of palettenerf_amd/pipeline.py)
+def test_concurrent_frame_handles_share_weights_and_refuse_the_cpu():
+    """clone_for_concurrent_frames: the extra handle shares every Parameter and buffer object with the model (no copy) and owns a fused-field
+    object of its own with the model's settings; FramesInFlight has no CPU path and says so."""
+    from palettenerf_amd.fused import NeRFFieldFused
+    from palettenerf_amd.pipeline import FramesInFlight, clone_for_concurrent_frames
+    m = network.NeRFNetwork(bound=2, cuda_ray=True)
+    with pytest.raises(RuntimeError):
+        clone_for_concurrent_frames(m)                      # no fused field yet
+    m._fused = NeRFFieldFused(m)
+    m._fused.precision = 0
+    m._fused.ray_order = torch.arange(4, dtype=torch.int32)
+    twin = clone_for_concurrent_frames(m)
+    assert twin is not m and twin._fused is not m._fused and twin._fused.model is twin
+    assert twin._fused.precision == 0 and twin._fused.ray_order is m._fused.ray_order
+    for (na, pa), (nb_, pb) in zip(m.named_parameters(), twin.named_parameters()):
+        assert na == nb_ and pa is pb
+    assert twin.density_bitfield is m.density_bitfield
+    assert m._fused.model is m                              # the original is untouched
+    with pytest.raises(RuntimeError):
+        FramesInFlight(m, 2)                                # CPU model: the product path is the HIP library, nothing else
