@@ -55,7 +55,7 @@ def parse(argv=None):
     ap.add_argument("--density-scale", type=float, default=100.0, help="opaque, trained-scene-like early termination; ~0 = translucent")
     ap.add_argument("--fp16", action="store_true", help="the reference's -O mode: autocast, half hash tables")
     ap.add_argument("--mode", choices=["compat", "device", "fused", "native"], default=None)
-    ap.add_argument("--field-precision", choices=["f16x3", "fp32"], default="f16x3",
+    ap.add_argument("--field-precision", choices=["f16x3", "fp32", "f16x2"], default="f16x3",
                     help="matrix path of the fused field: split-fp16 (3 MFMAs per product, ~2^-22 relative) or exact fp32 MFMA")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--ray-order", choices=["tile8", "tile4", "tile16", "morton", "rowmajor"], default="tile8", help="initial order of the alive list in the native loop")
@@ -154,7 +154,7 @@ def build_model(args, device, model_kind=None, field_precision=None):
         from palettenerf_amd.fused import NeRFFieldFused, PaletteFieldFused
         m.fused_field = True
         m._fused = NeRFFieldFused(m) if model_kind == "nerf" else PaletteFieldFused(m)
-        m._fused.precision = 0 if prec == "fp32" else 1
+        m._fused.precision = {"fp32": 0, "f16x3": 1, "f16x2": 2}[prec]   # f16x2: NeRF field only (the PaletteNeRF field runs it as f16x3)
         m._fused.table_half = bool(args.half_tables)
         if model_kind == "palette" and args.no_interleave:
             m._fused.interleave_tables = False
@@ -477,6 +477,7 @@ def main(argv=None):
     if use_dist:
         dist.barrier()
     extra = {}
+    crop_ref = None   # (rays_o, rays_d, oracle results) of the parity crop, for the extra legs
     if rank == 0 and world == 1:
         # --- PSNR / max-abs against the oracle + the CPU baseline, on a centre crop of pose 0 (same device-generated rays for both sides)
         if not args.no_cpu_baseline:
@@ -492,6 +493,7 @@ def main(argv=None):
             if native:
                 m._fused.ray_order = saved_order
             rec, ref = cpu_baseline(args, (cro.cpu(), crd.cpu()))
+            crop_ref = (cro, crd, ref)
             out["cpu_baseline"] = rec
             gi, ri = g["image"].cpu(), ref["image"]
             out["parity"] = {"psnr_vs_oracle_db": scene.psnr(gi, ri), "max_abs_rgb": float((gi - ri).abs().max()),
@@ -501,7 +503,8 @@ def main(argv=None):
         # --- extra driver-observed legs on the same box: the exact-fp32 field and the PaletteNeRF model (configs[2]) on the same camera path
         if not args.no_extras and native and args.workload == "lego" and not args.fp16:
             n = max(1, args.extra_steps)
-            for name, kind, prec in (("fp32_field", "nerf", "fp32"), ("palette", "palette", "f16x3"), ("palette_fp32_field", "palette", "fp32")):
+            for name, kind, prec in (("fp32_field", "nerf", "fp32"), ("f16x2_field", "nerf", "f16x2"), ("palette", "palette", "f16x3"), ("palette_f16x2_field", "palette", "f16x2"),
+                                     ("palette_fp32_field", "palette", "fp32")):
                 try:
                     mm = build_model(args, device, kind, prec)
                     mm._fused.ray_order = m._fused.ray_order
@@ -512,6 +515,15 @@ def main(argv=None):
                     ms, rend = timed_frames(mm, bank, kk, n, False, first_step=args.warmup)
                     extra[f"{name}_ms_per_step"] = ms
                     extra[f"{name}_rendered_per_step"] = rend
+                    if name == "f16x2_field" and crop_ref is not None:   # the rounded-activation form against the same oracle crop as the headline's parity block
+                        saved = mm._fused.ray_order
+                        mm._fused.ray_order = None
+                        with torch.no_grad():
+                            g2 = mm.render(crop_ref[0], crop_ref[1], **kk)
+                        mm._fused.ray_order = saved
+                        extra["f16x2_field_parity"] = {"psnr_vs_oracle_db": scene.psnr(g2["image"].cpu(), crop_ref[2]["image"]),
+                                                       "max_abs_rgb": float((g2["image"].cpu() - crop_ref[2]["image"]).abs().max()),
+                                                       "rendered_samples_gpu": int(g2["rendered"].sum()), "tolerance": "1e-4 abs (north_star)"}
                     if name == "palette":   # the same frames with a RegionEdit active (palette/renderer.py:121-147): it runs inside the field kernel's epilogue
                         from palettenerf_amd import renderer as prenderer
                         mm.edit = prenderer.RegionEdit(mm.opt)

@@ -147,7 +147,7 @@ int pnr_nerf_field_pack(const float* w_sigma0, const float* w_sigma1, const floa
     if (precision == PNR_FIELD_FP32)
         hipLaunchKernelGGL(k_nerf_field_pack, dim3(cdiv(kPackedFloats, 256)), dim3(256), 0, as_stream(stream), w_sigma0, w_sigma1, w_color0, w_color1,
                            w_color2, packed);
-    else if (precision == PNR_FIELD_F16X3)
+    else if (precision == PNR_FIELD_F16X3 || precision == PNR_FIELD_F16X2)
         hipLaunchKernelGGL(k_nerf_field_pack_f16x3, dim3(cdiv(kF16Blocks * 512, 256)), dim3(256), 0, as_stream(stream), w_sigma0, w_sigma1, w_color0,
                            w_color1, w_color2, reinterpret_cast<unsigned char*>(packed));
     else
@@ -158,13 +158,15 @@ int pnr_nerf_field_pack(const float* w_sigma0, const float* w_sigma1, const floa
 int pnr_nerf_field_forward(const float* enc, const float* dirs, const float* packed, uint32_t B, float* sigmas, float* rgbs, int precision,
                            float enc_scale, pnr_stream_t stream) {
     if (!(enc_scale > 0.0f)) enc_scale = 1.0f;
-    if (precision != PNR_FIELD_FP32 && precision != PNR_FIELD_F16X3) return PNR_ERR_UNSUPPORTED;
+    if (precision != PNR_FIELD_FP32 && precision != PNR_FIELD_F16X3 && precision != PNR_FIELD_F16X2) return PNR_ERR_UNSUPPORTED;
     if (B == 0) return PNR_OK;
     if (!enc || !dirs || !packed || !sigmas || !rgbs) return PNR_ERR_INVALID;
     const uint32_t ntiles = cdiv(B, 256);
     const uint32_t grid = ntiles < 512u ? ntiles : 512u;  // 2 persistent workgroups per CU
     if (precision == PNR_FIELD_FP32)
         hipLaunchKernelGGL(k_nerf_field_fwd<0>, dim3(grid), dim3(kFieldThreads), 0, as_stream(stream), enc, dirs, packed, B, sigmas, rgbs, enc_scale);
+    else if (precision == PNR_FIELD_F16X2)
+        hipLaunchKernelGGL(k_nerf_field_fwd<2>, dim3(grid), dim3(kFieldThreads), 0, as_stream(stream), enc, dirs, packed, B, sigmas, rgbs, enc_scale);
     else
         hipLaunchKernelGGL(k_nerf_field_fwd<1>, dim3(grid), dim3(kFieldThreads), 0, as_stream(stream), enc, dirs, packed, B, sigmas, rgbs, enc_scale);
     return check_launch();
@@ -173,6 +175,7 @@ int pnr_nerf_field_forward(const float* enc, const float* dirs, const float* pac
 int pnr_nerf_density_forward(const float* enc, const float* packed, uint32_t B, float scale, float* sigmas, float* geo_feat, int precision,
                              float enc_scale, pnr_stream_t stream) {
     if (!(enc_scale > 0.0f)) enc_scale = 1.0f;
+    if (precision == PNR_FIELD_F16X2) precision = PNR_FIELD_F16X3;   // sigma feeds the occupancy grid and the training composites: always the split form
     if (precision != PNR_FIELD_FP32 && precision != PNR_FIELD_F16X3) return PNR_ERR_UNSUPPORTED;
     if (B == 0) return PNR_OK;
     if (!enc || !packed || !sigmas) return PNR_ERR_INVALID;

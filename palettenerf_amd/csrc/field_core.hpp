@@ -138,6 +138,42 @@ __device__ __forceinline__ f32x16 mma3(f32x16 acc, const unsigned char* __restri
     return acc;
 }
 
+// "f16x2": the activation rounded ONCE to fp16 (no lo half: one v_cvt_pk_f16_f32 per pair instead of three instructions), the weight still
+// split -- a_hi.b + a_lo.b, two MFMAs instead of three.  The rounding of b costs 2^-12 relative per activation: ~1e-5 on a colour, ~6e-5
+// relative on sigma with unit-scale weights (tests/) -- inside the 1e-4 colour contract, four digits short of the split form.
+__device__ __forceinline__ void round8(const float v[8], h8& hi) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 hw;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const h2v hp = {(_Float16)v[j], (_Float16)v[j + 1]};
+        hw[j / 2] = __builtin_bit_cast(uint32_t, hp);
+    }
+    hi = __builtin_bit_cast(h8, hw);
+}
+__device__ __forceinline__ f32x16 mma2(f32x16 acc, const unsigned char* __restrict__ wblock, const h8& bhi, int lane) {
+    const h8 ahi = *reinterpret_cast<const h8*>(wblock + lane * 16);
+    const h8 alo = *reinterpret_cast<const h8*>(wblock + 1024 + lane * 16);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc, 0, 0, 0);
+    return acc;
+}
+// the two forms behind one name: LO = true is the split form (f16x3), LO = false the rounded one (f16x2)
+template <bool LO> __device__ __forceinline__ void splitx(const float v[8], h8& hi, h8& lo) {
+    if constexpr (LO) split8(v, hi, lo); else round8(v, hi);
+}
+template <bool LO> __device__ __forceinline__ f32x16 mmax(f32x16 acc, const unsigned char* __restrict__ wblock, const h8& bhi, const h8& blo, int lane) {
+    if constexpr (LO) return mma3(acc, wblock, bhi, blo, lane); else return mma2(acc, wblock, bhi, lane);
+}
+template <bool LO, bool CHECK>
+__device__ __forceinline__ void splitx_frag_w(SplitWatch<CHECK>& sw, const f32x16& a, int half_idx, h8& hi, h8& lo) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = a[half_idx * 8 + j];
+    sw.see(v);
+    splitx<LO>(v, hi, lo);
+}
+
 // ------------------------------------------------------------------------------------------
 // One K = 16 weight block against one group of 8 activations per lane-half, in either arithmetic -- the PaletteNeRF field is written
 // once over this interface.  A block is 2 KiB in both layouts: split-fp16 [hi: 64 lanes x 8 halfs][lo: same], or fp32 [8 steps][64 lanes]
@@ -146,11 +182,13 @@ __device__ __forceinline__ f32x16 mma3(f32x16 acc, const unsigned char* __restri
 // ------------------------------------------------------------------------------------------
 template <int PREC> struct BOp;
 template <> struct BOp<1> { h8 hi, lo; };
+template <> struct BOp<2> { h8 hi; };        // f16x2: the activation rounded once (mma2)
 template <> struct BOp<0> { float v[8]; };
 
 template <int PREC, bool CHECK = false> __device__ __forceinline__ BOp<PREC> make_op(const float v[8], SplitWatch<CHECK>* sw = nullptr) {
     BOp<PREC> o;
     if constexpr (PREC == 1) { if constexpr (CHECK) sw->see(v); split8(v, o.hi, o.lo); }
+    else if constexpr (PREC == 2) { if constexpr (CHECK) sw->see(v); round8(v, o.hi); }
     else {
 #pragma unroll
         for (int j = 0; j < 8; j++) o.v[j] = v[j];
@@ -165,6 +203,7 @@ template <int PREC, bool CHECK = false> __device__ __forceinline__ BOp<PREC> fra
 }
 template <int PREC> __device__ __forceinline__ f32x16 mma_blk(f32x16 acc, const unsigned char* __restrict__ wblock, const BOp<PREC>& b, int lane) {
     if constexpr (PREC == 1) return mma3(acc, wblock, b.hi, b.lo, lane);
+    else if constexpr (PREC == 2) return mma2(acc, wblock, b.hi, lane);
     else {
         const float* w = reinterpret_cast<const float*>(wblock);
 #pragma unroll
@@ -179,7 +218,7 @@ struct FieldOut { float sigma_logit, o0, o1, o2; };
 // enc_scale: a power of two (1 = none) the encoder features are multiplied by before they are split into fp16 pairs, and sigma_net's 16
 // outputs divided by afterwards -- exact, since the bias-free ReLU stack is positively homogeneous.  It keeps the `lo` halves of very small
 // features (hash tables at the reference's initialisation scale U(-1e-4, 1e-4), gridencoder/grid.py:107) out of the fp16 subnormal range.
-template <bool CHECK>
+template <bool CHECK, bool LO = true>
 __device__ __forceinline__ FieldOut nerf_field_tile_f16x3(const unsigned char* __restrict__ w, int lane, bool valid, const float* __restrict__ enc,
                                                           size_t level_stride, uint32_t row, float dx, float dy, float dz, float enc_scale,
                                                           SplitWatch<CHECK>& sw) {
@@ -200,23 +239,23 @@ __device__ __forceinline__ FieldOut nerf_field_tile_f16x3(const unsigned char* _
             for (int j = 0; j < 8; j++) { x[0][j] *= enc_scale; x[1][j] *= enc_scale; }
         }
         sw.see(x[0]); sw.see(x[1]);
-        split8(x[0], bh[0], bl[0]);
-        split8(x[1], bh[1], bl[1]);
+        splitx<LO>(x[0], bh[0], bl[0]);
+        splitx<LO>(x[1], bh[1], bl[1]);
     }
     f32x16 h0 = zero16(), h1 = zero16();
-    h0 = mma3(h0, w + 0 * kF16BlockBytes, bh[0], bl[0], lane);
-    h0 = mma3(h0, w + 1 * kF16BlockBytes, bh[1], bl[1], lane);
-    h1 = mma3(h1, w + 2 * kF16BlockBytes, bh[0], bl[0], lane);
-    h1 = mma3(h1, w + 3 * kF16BlockBytes, bh[1], bl[1], lane);
+    h0 = mmax<LO>(h0, w + 0 * kF16BlockBytes, bh[0], bl[0], lane);
+    h0 = mmax<LO>(h0, w + 1 * kF16BlockBytes, bh[1], bl[1], lane);
+    h1 = mmax<LO>(h1, w + 2 * kF16BlockBytes, bh[0], bl[0], lane);
+    h1 = mmax<LO>(h1, w + 3 * kF16BlockBytes, bh[1], bl[1], lane);
     __builtin_amdgcn_sched_barrier(0);
     h0 = relu16(h0); h1 = relu16(h1);
 
     // sigma_net[1]: 64 -> 16
-    split_frag_w(sw, h0, 0, bh[0], bl[0]); split_frag_w(sw, h0, 1, bh[1], bl[1]);
-    split_frag_w(sw, h1, 0, bh[2], bl[2]); split_frag_w(sw, h1, 1, bh[3], bl[3]);
+    splitx_frag_w<LO>(sw, h0, 0, bh[0], bl[0]); splitx_frag_w<LO>(sw, h0, 1, bh[1], bl[1]);
+    splitx_frag_w<LO>(sw, h1, 0, bh[2], bl[2]); splitx_frag_w<LO>(sw, h1, 1, bh[3], bl[3]);
     f32x16 g = zero16();
 #pragma unroll
-    for (int kb = 0; kb < 4; kb++) g = mma3(g, w + (4 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
+    for (int kb = 0; kb < 4; kb++) g = mmax<LO>(g, w + (4 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
     __builtin_amdgcn_sched_barrier(0);
     if (enc_scale != 1.0f) {
         const float inv = 1.0f / enc_scale;
@@ -233,34 +272,34 @@ __device__ __forceinline__ FieldOut nerf_field_tile_f16x3(const unsigned char* _
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) v[j] = select_half(h, sh[j], sh[8 + j]);
-        split8(v, bh[0], bl[0]);
+        splitx<LO>(v, bh[0], bl[0]);
     }
-    split_frag_w(sw, g, 0, bh[1], bl[1]);
+    splitx_frag_w<LO>(sw, g, 0, bh[1], bl[1]);
     f32x16 c0 = zero16(), c1 = zero16();
-    c0 = mma3(c0, w + 8 * kF16BlockBytes, bh[0], bl[0], lane);
-    c0 = mma3(c0, w + 9 * kF16BlockBytes, bh[1], bl[1], lane);
-    c1 = mma3(c1, w + 10 * kF16BlockBytes, bh[0], bl[0], lane);
-    c1 = mma3(c1, w + 11 * kF16BlockBytes, bh[1], bl[1], lane);
+    c0 = mmax<LO>(c0, w + 8 * kF16BlockBytes, bh[0], bl[0], lane);
+    c0 = mmax<LO>(c0, w + 9 * kF16BlockBytes, bh[1], bl[1], lane);
+    c1 = mmax<LO>(c1, w + 10 * kF16BlockBytes, bh[0], bl[0], lane);
+    c1 = mmax<LO>(c1, w + 11 * kF16BlockBytes, bh[1], bl[1], lane);
     __builtin_amdgcn_sched_barrier(0);
     c0 = relu16(c0); c1 = relu16(c1);
 
     // color_net[1]: 64 -> 64
-    split_frag_w(sw, c0, 0, bh[0], bl[0]); split_frag_w(sw, c0, 1, bh[1], bl[1]);
-    split_frag_w(sw, c1, 0, bh[2], bl[2]); split_frag_w(sw, c1, 1, bh[3], bl[3]);
+    splitx_frag_w<LO>(sw, c0, 0, bh[0], bl[0]); splitx_frag_w<LO>(sw, c0, 1, bh[1], bl[1]);
+    splitx_frag_w<LO>(sw, c1, 0, bh[2], bl[2]); splitx_frag_w<LO>(sw, c1, 1, bh[3], bl[3]);
     f32x16 d0 = zero16(), d1 = zero16();
 #pragma unroll
-    for (int kb = 0; kb < 4; kb++) d0 = mma3(d0, w + (12 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
+    for (int kb = 0; kb < 4; kb++) d0 = mmax<LO>(d0, w + (12 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
 #pragma unroll
-    for (int kb = 0; kb < 4; kb++) d1 = mma3(d1, w + (16 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
+    for (int kb = 0; kb < 4; kb++) d1 = mmax<LO>(d1, w + (16 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
     __builtin_amdgcn_sched_barrier(0);
     d0 = relu16(d0); d1 = relu16(d1);
 
     // color_net[2]: 64 -> 3
-    split_frag_w(sw, d0, 0, bh[0], bl[0]); split_frag_w(sw, d0, 1, bh[1], bl[1]);
-    split_frag_w(sw, d1, 0, bh[2], bl[2]); split_frag_w(sw, d1, 1, bh[3], bl[3]);
+    splitx_frag_w<LO>(sw, d0, 0, bh[0], bl[0]); splitx_frag_w<LO>(sw, d0, 1, bh[1], bl[1]);
+    splitx_frag_w<LO>(sw, d1, 0, bh[2], bl[2]); splitx_frag_w<LO>(sw, d1, 1, bh[3], bl[3]);
     f32x16 o = zero16();
 #pragma unroll
-    for (int kb = 0; kb < 4; kb++) o = mma3(o, w + (20 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
+    for (int kb = 0; kb < 4; kb++) o = mmax<LO>(o, w + (20 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
     out.o0 = o[0]; out.o1 = o[1]; out.o2 = o[2];
     return out;
 }
@@ -381,7 +420,7 @@ template <int PREC, bool CHECK = false>
 __device__ __forceinline__ FieldOut nerf_field_tile(const float* __restrict__ w, int lane, bool valid, const float* __restrict__ enc,
                                                     size_t level_stride, uint32_t row, float dx, float dy, float dz, float enc_scale, SplitWatch<CHECK>& sw) {
     if constexpr (PREC == 0) return nerf_field_tile_f32(w, lane, valid, enc, level_stride, row, dx, dy, dz);   // exact fp32: no scaling needed
-    else return nerf_field_tile_f16x3<CHECK>(reinterpret_cast<const unsigned char*>(w), lane, valid, enc, level_stride, row, dx, dy, dz, enc_scale, sw);
+    else return nerf_field_tile_f16x3<CHECK, PREC == 1>(reinterpret_cast<const unsigned char*>(w), lane, valid, enc, level_stride, row, dx, dy, dz, enc_scale, sw);
 }
 template <int PREC>
 __device__ __forceinline__ FieldOut nerf_field_tile(const float* __restrict__ w, int lane, bool valid, const float* __restrict__ enc,

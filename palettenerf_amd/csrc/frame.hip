@@ -870,7 +870,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
         !a->depth || !a->image || !a->workspace)
         return PNR_ERR_INVALID;
     if (a->C == 0 || a->C > 16 || a->H == 0 || a->max_steps == 0 || a->num_levels != 16) return PNR_ERR_UNSUPPORTED;
-    if (a->field_precision != PNR_FIELD_FP32 && a->field_precision != PNR_FIELD_F16X3) return PNR_ERR_UNSUPPORTED;
+    if (a->field_precision != PNR_FIELD_FP32 && a->field_precision != PNR_FIELD_F16X3 && a->field_precision != PNR_FIELD_F16X2) return PNR_ERR_UNSUPPORTED;
     const uint32_t aux_stride = pal ? pnr_palette_aux_channels(pal->num_basis, pal->clip_dim) : 0;
     const bool with_clip = pal && pal->pred_clip;
     hipStream_t s = as_stream(stream);
@@ -1002,6 +1002,14 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
                 if (rc != PNR_OK) return rc;
             } else if (a->field_precision == PNR_FIELD_FP32)
                 hipLaunchKernelGGL((k_frame_field<0, false>), dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas,
+                                   a->packed_weights, a->density_scale, enc_scale, w.sigmas, w.rgbs, composite_fused, a->T_thresh, alive_in, w.rays_t, out_ws, out_depth,
+                                   out_image, w.scratch);
+            else if (a->field_precision == PNR_FIELD_F16X2 && a->watch_overflow)
+                hipLaunchKernelGGL((k_frame_field<2, true>), dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas,
+                                   a->packed_weights, a->density_scale, enc_scale, w.sigmas, w.rgbs, composite_fused, a->T_thresh, alive_in, w.rays_t, out_ws, out_depth,
+                                   out_image, w.scratch);
+            else if (a->field_precision == PNR_FIELD_F16X2)
+                hipLaunchKernelGGL((k_frame_field<2, false>), dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas,
                                    a->packed_weights, a->density_scale, enc_scale, w.sigmas, w.rgbs, composite_fused, a->T_thresh, alive_in, w.rays_t, out_ws, out_depth,
                                    out_image, w.scratch);
             else if (a->watch_overflow)

@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
         if (valid) { dx = dirs[(size_t)row * 3]; dy = dirs[(size_t)row * 3 + 1]; dz = dirs[(size_t)row * 3 + 2]; }
 
         // ---------------- sigma_net (prescaled by a power of two when the table's entries are tiny: undone exactly on its 16 outputs)
-        const bool pre_s = PREC == 1 && pp.enc_scale[0] != 1.0f, pre_p = PREC == 1 && pp.enc_scale[1] != 1.0f, pre_c = PREC == 1 && pp.enc_scale[2] != 1.0f;
+        const bool pre_s = PREC != 0 && pp.enc_scale[0] != 1.0f, pre_p = PREC != 0 && pp.enc_scale[1] != 1.0f, pre_c = PREC != 0 && pp.enc_scale[2] != 1.0f;
         if (pre_s) scale8x2(xs, pp.enc_scale[0]);
         f32x16 t0 = zero16(), t1 = zero16();
         {
@@ -530,7 +530,7 @@ uint32_t pnr_palette_aux_channels(uint32_t num_basis, uint32_t clip_dim) { retur
 int pnr_palette_field_pack(const pnr_palette_weights* pw, void* packed, pnr_stream_t stream) {
     if (!pw || !packed) return PNR_ERR_INVALID;
     if (!shape_ok(pw->num_basis, pw->clip_dim)) return PNR_ERR_UNSUPPORTED;
-    if (pw->precision != PNR_FIELD_FP32 && pw->precision != PNR_FIELD_F16X3) return PNR_ERR_UNSUPPORTED;
+    if (pw->precision != PNR_FIELD_FP32 && pw->precision != PNR_FIELD_F16X3 && pw->precision != PNR_FIELD_F16X2) return PNR_ERR_UNSUPPORTED;
     if (!pw->sigma0 || !pw->sigma1 || !pw->diff0 || !pw->diff1 || !pw->diff2 || !pw->color0 || !pw->color1 || !pw->color2 || !pw->basis0 || !pw->basis1 ||
         !pw->offsets_radiance || !pw->omega || !pw->basis_color || !pw->or_bias)
         return PNR_ERR_INVALID;
@@ -564,7 +564,7 @@ int pnr_palette_field_pack(const pnr_palette_weights* pw, void* packed, pnr_stre
     t.n = pal_blocks(nb, (int)pw->clip_dim, pw->pred_clip ? 1 : 0);
     if (q < t.n) return PNR_ERR_INVALID;
     const dim3 grid(cdiv((uint32_t)t.n * 512, 256));
-    if (pw->precision == PNR_FIELD_F16X3) hipLaunchKernelGGL(k_pack_blocks<1>, grid, dim3(256), 0, as_stream(stream), t, static_cast<unsigned char*>(packed));
+    if (pw->precision != PNR_FIELD_FP32) hipLaunchKernelGGL(k_pack_blocks<1>, grid, dim3(256), 0, as_stream(stream), t, static_cast<unsigned char*>(packed));
     else hipLaunchKernelGGL(k_pack_blocks<0>, grid, dim3(256), 0, as_stream(stream), t, static_cast<unsigned char*>(packed));
     hipLaunchKernelGGL(k_pack_tables, dim3(1), dim3(64), 0, as_stream(stream), pw->basis_color, pw->or_bias, nb,
                        reinterpret_cast<float*>(static_cast<unsigned char*>(packed) + (size_t)t.n * kF16BlockBytes));
@@ -580,7 +580,7 @@ int pnr_palette_field_stages_aux(uint32_t num_basis, uint32_t clip_dim, int pred
 int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stream) {
     if (!a) return PNR_ERR_INVALID;
     if (!shape_ok(a->num_basis, a->clip_dim)) return PNR_ERR_UNSUPPORTED;
-    if (a->precision != PNR_FIELD_FP32 && a->precision != PNR_FIELD_F16X3) return PNR_ERR_UNSUPPORTED;
+    if (a->precision != PNR_FIELD_FP32 && a->precision != PNR_FIELD_F16X3 && a->precision != PNR_FIELD_F16X2) return PNR_ERR_UNSUPPORTED;
     if (a->aux_stride < 6 + 7 * a->num_basis + a->clip_dim || a->aux_stride > PNR_CHANNEL_MAXIMUM || (a->aux_stride & 3u)) return PNR_ERR_INVALID;
     if (a->B == 0 && !a->ctl) return PNR_OK;
     if (!a->enc || !a->enc_palette || !a->dirs || !a->packed || !a->sigmas || !a->rgbs || !a->aux) return PNR_ERR_INVALID;
@@ -596,7 +596,10 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
     const uint32_t rows_ub = a->B;
     // one persistent workgroup per CU (100-126 KiB of LDS): 8 waves, or 12 for the specialised 4-basis kernel when its staging fits (three waves per SIMD
     // at <= 168 registers: the dependent layer chain of a wave leaves the SIMD idle too often with two)
-    const bool nb4 = a->precision == PNR_FIELD_F16X3 && a->num_basis == 4 && !a->overflow_flag;
+    // PNR_FIELD_F16X2 (opt-in: activations rounded once to fp16) exists for the specialised 4-basis kernel without an edit head; everything else runs it as F16X3
+    const bool fp16 = a->precision != PNR_FIELD_FP32;
+    const bool nb4 = fp16 && a->num_basis == 4 && !a->overflow_flag;
+    const bool x2 = a->precision == PNR_FIELD_F16X2 && nb4 && edit_mode == 0;
     const bool wide = nb4 && g_opt_palette_waves12 && packed_bytes + 12u * 32u * (a->aux_stride + 3u) * 4u <= 160u * 1024u;
     const uint32_t waves = wide ? 12u : 8u;
     const uint32_t ntiles = cdiv(rows_ub ? rows_ub : 1, waves * 32);
@@ -635,12 +638,14 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
                            stage_stride, fuse ? a->rays_alive : nullptr, fuse ? a->weights_sum : nullptr, fuse ? a->aux_map : nullptr,         \
                            a->T_thresh, a->xyzs, ep_dev, a->overflow_flag, static_cast<uint32_t*>(a->tile_counter));                          \
     } while (0)
-    if (a->precision == PNR_FIELD_F16X3 && a->overflow_flag) {   // the instantiation that watches its split operands
+    if (fp16 && a->overflow_flag) {   // the instantiation that watches its split operands
         if (edit_mode == 0) PNR_LAUNCH_PAL(1, 0, true); else if (edit_mode == 1) PNR_LAUNCH_PAL(1, 1, true); else PNR_LAUNCH_PAL(1, 2, true);
-    } else if (a->precision == PNR_FIELD_F16X3) {
-        static bool attr_nb4[6][kMaxDevices] = {};
+    } else if (fp16) {
+        static bool attr_nb4[8][kMaxDevices] = {};
         // the shipped default of 4 bases (main_palette.py:76): specialised epilogue, 12-wave workgroups when the staging fits
-        if (nb4 && wide && edit_mode == 0) PNR_LAUNCH_PAL_NB(1, 0, false, 4, 12, attr_nb4[0]);
+        if (x2 && wide) PNR_LAUNCH_PAL_NB(2, 0, false, 4, 12, attr_nb4[6]);
+        else if (x2) PNR_LAUNCH_PAL_NB(2, 0, false, 4, 8, attr_nb4[7]);
+        else if (nb4 && wide && edit_mode == 0) PNR_LAUNCH_PAL_NB(1, 0, false, 4, 12, attr_nb4[0]);
         else if (nb4 && wide && edit_mode == 1) PNR_LAUNCH_PAL_NB(1, 1, false, 4, 12, attr_nb4[1]);
         else if (nb4 && wide) PNR_LAUNCH_PAL_NB(1, 2, false, 4, 12, attr_nb4[2]);
         else if (nb4 && edit_mode == 0) PNR_LAUNCH_PAL_NB(1, 0, false, 4, 8, attr_nb4[3]);

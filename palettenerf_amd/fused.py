@@ -121,13 +121,17 @@ class _PrecisionGuard:
     def enc_scales(self, prec=None):
         """[s_encoder, s_encoder_palette, s_encoder_clip] for the split-fp16 path (all 1.0 on the fp32 path)."""
         prec = self.effective_precision() if prec is None else prec
-        return self._guard()[0] if prec == 1 else [1.0, 1.0, 1.0]
+        return self._guard()[0] if prec in (1, 2) else [1.0, 1.0, 1.0]
+
+    def _fp16_level(self):
+        """1 = PNR_FIELD_F16X3 (split operands), 2 = PNR_FIELD_F16X2 (opt-in, NeRF field only: activations rounded once to fp16)."""
+        return 2 if int(self.precision) == 2 and getattr(self, "supports_f16x2", False) else 1
 
     def effective_precision(self):
-        """Matrix path of the stand-alone ops: split-fp16 only when the static bound rules an fp16 overflow out."""
+        """Matrix path of the stand-alone ops: an fp16 form only when the static bound rules an fp16 overflow out."""
         if int(self.precision) == 0:
             return 0
-        return 1 if self._guard()[1] < F16X3_SAFE_ACTIVATION and self._guard()[2] < F16X3_MAX_WEIGHT else 0
+        return self._fp16_level() if self._guard()[1] < F16X3_SAFE_ACTIVATION and self._guard()[2] < F16X3_MAX_WEIGHT else 0
 
     def frame_precision(self):
         """(precision, watch) for the device-driven frame loops.  The static bound is a guarantee but pessimistic (products of L1 norms): trained
@@ -137,10 +141,10 @@ class _PrecisionGuard:
         if int(self.precision) == 0 or not self._guard()[2] < F16X3_MAX_WEIGHT:   # a weight itself beyond fp16's range: nothing to watch for
             return 0, False
         if self._guard()[1] < F16X3_SAFE_ACTIVATION:
-            return 1, False
+            return self._fp16_level(), False
         if getattr(self, "_overflowed_key", None) == self._guard_key:
             return 0, False
-        return 1, True
+        return self._fp16_level(), True
 
     def _note_overflow(self):
         import warnings
@@ -181,7 +185,8 @@ class NeRFFieldFused(_PrecisionGuard):
         self.model = model
         self.packed = None
         self.versions = None
-        self.precision = 1  # PNR_FIELD_F16X3 (split-fp16 matrix path, ~2^-22 relative); 0 = PNR_FIELD_FP32 (exact fmaf chains)
+        self.precision = 1  # PNR_FIELD_F16X3 (split-fp16 matrix path, ~2^-22 relative); 0 = PNR_FIELD_FP32 (exact fmaf chains); 2 = PNR_FIELD_F16X2 (opt-in: ~1e-5 on a colour)
+        self.supports_f16x2 = True
         self.time_grid_kernel = False  # bench.py: HIP-event timing of the grid-encode launches inside the native frame loop
         self.table_half = False        # native loop: look the hash table up as fp16 with the reference's half interpolation (its --fp16 mode)
         m = model
@@ -356,7 +361,8 @@ class PaletteFieldFused(_PrecisionGuard):
         # without a clip head the reference composites clip_dim channels of zeros (palette/renderer.py:477,510): the map is zero whatever
         # happens, so those channels are left out of the packed aux row (52 -> 36 floats per sample for 4 bases) and returned as zeros
         self.clip_dim = int(m.opt.clip_dim) if self.pred_clip else 0
-        self.precision = 1              # PNR_FIELD_F16X3; 0 = PNR_FIELD_FP32 (exact fmaf chains, pnr_palette_*'s fp32 matrix path)
+        self.precision = 1              # PNR_FIELD_F16X3; 0 = PNR_FIELD_FP32 (exact fmaf chains, pnr_palette_*'s fp32 matrix path); 2 = PNR_FIELD_F16X2 (opt-in)
+        self.supports_f16x2 = True      # honoured by the 4-basis kernel without an edit head; the library runs every other shape as F16X3
         self.interleave_tables = True   # native loop: look both hash tables up through one interleaved copy (see _pair_table)
         self.table_half = False         # native loop: fp16 tables with the reference's half interpolation (its --fp16 mode; no clip head)
         self.aux_channels = int(_lib.load().pnr_palette_aux_channels(self.nb, self.clip_dim))

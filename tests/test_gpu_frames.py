@@ -754,3 +754,43 @@ def test_render_path_equals_the_reference_test_loop_arithmetic(cuda):
             ok = np.isfinite(pdep)
             assert ok.mean() > 0.2
             np.testing.assert_array_equal(dep[i][ok], (pdep[ok] * 255).astype(np.uint8))
+
+
+@pytest.mark.gpu
+def test_palette_frame_f16x2_is_inside_the_colour_contract(cuda):
+    """PNR_FIELD_F16X2 on the PaletteNeRF frame loop (opt-in; the specialised 4-basis kernel with activations rounded once to fp16): every map
+    within 1e-4 of the split-fp16 frame (north-star colour contract), PSNR above 85 dB, the same march (sample count within 0.01 %: a ray's last
+    samples depend on its transmittance reaching T_thresh).  With an edit head or another basis count the library runs the split form: bit-identical."""
+    from palettenerf_amd.fused import PaletteFieldFused
+    m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True, density_scale=100.0)
+    scene.seed_field_(m, 0)
+    m = m.to(cuda).eval()
+    m.density_grid.copy_(torch.from_numpy(scene.brick_density_grid()).to(cuda))
+    raymarching.packbits(m.density_grid, 0.5, m.density_bitfield)
+    m.march_mode, m.fused_field, m.count_rendered = "native", True, True
+    m._fused = PaletteFieldFused(m)
+    H = W = 160
+    ro, rd = scene.get_rays(torch.from_numpy(scene.lookat_pose())[None], scene.intrinsics_from_fov(H, W), H, W)
+    ro, rd = ro.to(cuda), rd.to(cuda)
+    kw = dict(perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4, gui_mode=False, bg_color=1)
+    keys = ("image", "direct_rgb", "view_dep_rgb", "basis_rgb", "unscaled_basis_rgb", "basis_acc", "weights_sum")
+    with torch.no_grad():
+        ref = m.render(ro, rd, **kw)
+        m._fused.precision = 2
+        fast = m.render(ro, rd, **kw)
+    assert abs(int(fast["rendered"].sum()) - int(ref["rendered"].sum())) <= 1e-4 * int(ref["rendered"].sum())
+    worst = 0.0
+    for k in keys:
+        worst = max(worst, float((fast[k] - ref[k]).abs().max()))
+    assert 1e-8 < worst < 1e-4, worst      # really the rounded form, and inside the contract
+    assert scene.psnr(fast["image"].cpu(), ref["image"].cpu()) > 85.0
+    # an edit head: the library falls back to the split form
+    m.edit = renderer.RegionEdit(m.opt)
+    m.edit.update_cent(mean_xyz=torch.tensor([0.2, 0.1, -0.1], device=cuda))
+    m.edit.update_std(std_xyz=0.3)
+    m.edit.update_delta_hsv(m.basis_color.data.clamp(0, 1), (m.basis_color.data * 0.5 + 0.3).flip(0).clamp(0, 1))
+    with torch.no_grad():
+        e2 = m.render(ro, rd, **kw)
+        m._fused.precision = 1
+        e1 = m.render(ro, rd, **kw)
+    assert torch.equal(e1["image"], e2["image"])
