@@ -36,8 +36,9 @@ def shard_indices(H, W, rank, world_size, tile=TILE):
 class FrameGatherer:
     """Static plan of one frame's all-gather: send/receive buffers and the pixel -> gathered-row index."""
 
-    def __init__(self, H, W, K, device, group=None, tile=TILE):
+    def __init__(self, H, W, K, device, group=None, tile=TILE, slots=2):
         self.H, self.W, self.K, self.group = H, W, K, group
+        self.slots = int(slots)
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         owner = tile_assignment(H, W, self.world, tile)
@@ -51,17 +52,18 @@ class FrameGatherer:
             if r == self.rank:
                 self.idx = sel
         self.gather_index = (owner * self.n_max + local_pos).to(device)
-        # two buffer pairs: the all-gather of frame k may still be in flight while frame k+1 is packed (start / finish below)
-        self.send = [torch.zeros(self.n_max, K, dtype=torch.float32, device=device) for _ in range(2)]
-        self.recv = [torch.empty(self.world * self.n_max, K, dtype=torch.float32, device=device) for _ in range(2)]
+        # `slots` buffer pairs (two by default): the all-gather of frame k may still be in flight while frame k+1 is packed (start / finish
+        # below); with F frames in flight (pipeline.FramesInFlight + OrderedGather) up to F + 1 gathers are outstanding
+        self.send = [torch.zeros(self.n_max, K, dtype=torch.float32, device=device) for _ in range(self.slots)]
+        self.recv = [torch.empty(self.world * self.n_max, K, dtype=torch.float32, device=device) for _ in range(self.slots)]
         self._turn = 0
 
     def start(self, parts):
         """Pack this rank's rows and launch the all-gather WITHOUT making the compute stream wait for it: the collective runs on the
-        communicator's stream while the next frame is rendered.  Returns a handle for finish().  At most two frames in flight."""
+        communicator's stream while the next frame is rendered.  Returns a handle for finish().  At most `slots` gathers outstanding."""
         n = self.idx.numel()
         slot = self._turn
-        self._turn ^= 1
+        self._turn = (self._turn + 1) % self.slots
         torch.cat(parts, dim=1, out=self.send[slot][:n])
         work = dist.all_gather_into_tensor(self.recv[slot], self.send[slot], group=self.group, async_op=True)
         return work, slot
@@ -75,6 +77,31 @@ class FrameGatherer:
     def __call__(self, parts):
         """parts: tensors [n_local, k_i] (sum k_i == K), rows ordered like self.idx.  Returns the [H*W, K] frame on every rank."""
         return self.finish(self.start(parts))
+
+
+class OrderedGather:
+    """Frames rendered by several host threads (pipeline.FramesInFlight), ONE communicator: a collective must be issued in the same order on
+    every rank, so the gather of frame i is started only after the gathers of frames 0 .. i-1 -- whichever thread rendered them.  submit() is
+    called on the thread (and stream) that rendered frame i; it blocks only while an earlier frame's gather has not been started yet.  No
+    thread ever waits for a later frame, so the turnstile cannot deadlock as long as every frame index is submitted exactly once."""
+
+    def __init__(self, gatherer, first_frame=0):
+        import threading
+        self.gatherer = gatherer
+        self._next = int(first_frame)
+        self._cv = threading.Condition()
+
+    def submit(self, i, parts):
+        with self._cv:
+            while self._next != i:
+                self._cv.wait()
+            handle = self.gatherer.start(parts)
+            self._next += 1
+            self._cv.notify_all()
+        return handle
+
+    def finish(self, handle):
+        return self.gatherer.finish(handle)
 
 
 def gather_frame(local, idx, n_max, H, W, group=None):

@@ -44,10 +44,11 @@ class FramesInFlight:
         self.models = [model] + [clone_for_concurrent_frames(model) for _ in range(n - 1)]
         self.streams = [torch.cuda.Stream(self.device) for _ in range(n)]
 
-    def render(self, rays_of, n_frames, consume=None, **kwargs):
+    def render(self, rays_of, n_frames, consume=None, before=None, **kwargs):
         """Render frames 0 .. n_frames-1; `rays_of(i)` -> (rays_o, rays_d) resident on the device; `consume(i, results)` is called on
-        the rendering thread as soon as frame i is complete (default: keep the results).  Returns the list of results (or of
-        consume's return values) in frame order.  Exceptions of a worker are re-raised here."""
+        the rendering thread (inside its stream context) as soon as frame i is complete (default: keep the results); `before(i, model)`
+        right in front of the frame.  Returns the list of results (or of consume's return values) in frame order.  Exceptions of a
+        worker are re-raised here."""
         out = [None] * n_frames
         errors = []
         ready = torch.cuda.Event()
@@ -59,6 +60,8 @@ class FramesInFlight:
                     self.streams[k].wait_event(ready)
                     for i in range(k, n_frames, len(self.models)):
                         ro, rd = rays_of(i)
+                        if before is not None:
+                            before(i, self.models[k])
                         r = self.models[k].render(ro, rd, **kwargs)
                         out[i] = consume(i, r) if consume is not None else r
                     self.streams[k].synchronize()

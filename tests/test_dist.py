@@ -59,3 +59,52 @@ def test_gather_frame_gloo(world, H, W):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mp.spawn(_worker, args=(world, port, H, W, 5), nprocs=world, join=True)
+
+
+def _ordered_worker(rank, world, port, H, W, K, F, n_frames):
+    """Frames produced by F threads per rank in scrambled completion order; the gathers must still pair up frame by frame across ranks."""
+    import threading
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = pdist.FrameGatherer(H, W, K, torch.device("cpu"), slots=F + 1)
+        og = pdist.OrderedGather(g)
+        base = torch.arange(H * W * K, dtype=torch.float32).reshape(H * W, K)
+        out, errors = [None] * n_frames, []
+
+        def work(k):
+            try:
+                prev = None
+                for i in range(k, n_frames, F):
+                    time.sleep(0.002 * ((i * 7 + rank * 3 + k) % 5))       # "render": threads and ranks finish their frames in different orders
+                    h = og.submit(i, [(base + i)[g.idx].clone()])
+                    if prev is not None:
+                        out[prev[0]] = og.finish(prev[1])
+                    prev = (i, h)
+                if prev is not None:
+                    out[prev[0]] = og.finish(prev[1])
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(F)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=60)
+            assert not t.is_alive(), "turnstile deadlocked"
+        assert not errors, errors
+        for i in range(n_frames):
+            assert torch.equal(out[i], base + i), f"rank {rank}: frame {i} was gathered from another frame's rows"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,F", [(2, 2), (2, 3)])
+def test_ordered_gather_with_several_render_threads_gloo(world, F):
+    """dist.OrderedGather: F render threads per rank share one communicator; frame i's all-gather is issued as the i-th collective on every rank
+    whatever order the threads finish in, so every rank assembles frame i from frame i's shards (and nothing deadlocks)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_ordered_worker, args=(world, port, 40, 36, 3, F, 12), nprocs=world, join=True)

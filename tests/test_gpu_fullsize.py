@@ -1,6 +1,7 @@
 """Parity at BASELINE.json's full size (800x800 = 640 000 rays, scene S0) through size-independent properties and
 checksums: the oracle needs ~40 s of CPU for this march, so its per-ray counts are pinned here by constants computed
 once in the build container (oracle.march_rays_train on the same rays; see the comment next to each constant)."""
+import os
 import zlib
 
 import numpy as np
@@ -260,3 +261,25 @@ def test_palette_two_stage_training_converges(cuda):
     spec.loader.exec_module(mod)
     log = mod.main(["--steps", "400", "--nerf-steps", "400", "--log-every", "200", "--res", "0.125"])
     assert log[0][1] < 15.0 and log[-1][1] > 28.0, log
+
+
+@pytest.mark.gpu
+def test_bench_line_with_frames_in_flight_over_rccl(cuda):
+    """`bench.py --main-frames-in-flight 2` through the RCCL path on one GPU (PNR_BENCH_FORCE_DIST: a one-rank communicator): two render threads, their
+    all-gathers issued in frame order (dist.OrderedGather), one JSON line whose sample count equals the plain run's on the same camera path."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PNR_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    common = [sys.executable, os.path.join(root, "bench.py"), "--res", "200", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-extras"]
+    lines = []
+    for extra in ([], ["--main-frames-in-flight", "2"]):
+        out = subprocess.run(common + extra, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines.append(json.loads(out.stdout.strip().splitlines()[-1]))
+    plain, piped = lines
+    assert plain["config"]["frames_in_flight"] == 1 and piped["config"]["frames_in_flight"] == 2
+    assert piped["config"]["rccl_ranks"] == 1 and piped["config"]["gathered_floats_per_ray"] == 5
+    assert piped["config"]["rendered_samples_per_step"] == plain["config"]["rendered_samples_per_step"]
+    assert piped["value"] > 0 and "note_frames_in_flight" in piped["roofline"]
