@@ -40,10 +40,10 @@ extern "C" {
  * or split-fp16 (3 x v_mfma_f32_32x32x16_f16 per product, ~2^-22 relative, fp32 accumulate; ~5x fewer MFMA cycles) */
 #define PNR_FIELD_FP32 0
 #define PNR_FIELD_F16X3 1
-/* opt-in: weights split as above, activations rounded ONCE to fp16 (2 MFMAs per product, one conversion per activation pair): ~1e-5 on a colour
- * and ~6e-5 relative on sigma with unit-scale weights -- inside the 1e-4 colour contract, not fp32-class.  Same packed blobs as PNR_FIELD_F16X3.
- * Exists for the NeRF field and for the 4-basis PaletteNeRF field without an edit head; the density-only call, other basis counts, edited and
- * watched launches run it as PNR_FIELD_F16X3. */
+/* opt-in: the COLOUR layers with weights split as above and activations rounded ONCE to fp16 (2 MFMAs per product, one conversion per activation
+ * pair): ~1e-5 on a colour with unit-scale weights -- inside the 1e-4 colour contract, not fp32-class.  sigma_net keeps the split form: densities,
+ * alphas, depth and the march are bit for bit those of PNR_FIELD_F16X3.  Same packed blobs.  Exists for the NeRF field and for the 4-basis PaletteNeRF
+ * field without an edit head; the density-only call, other basis counts, edited and watched launches run it as PNR_FIELD_F16X3. */
 #define PNR_FIELD_F16X2 2
 
 #define PNR_CHANNEL_MAXIMUM 128   /* raymarching/src/raymarching.cu:13 */

@@ -139,7 +139,8 @@ __device__ __forceinline__ f32x16 mma3(f32x16 acc, const unsigned char* __restri
 }
 
 // "f16x2": the activation rounded ONCE to fp16 (no lo half: one v_cvt_pk_f16_f32 per pair instead of three instructions), the weight still
-// split -- a_hi.b + a_lo.b, two MFMAs instead of three.  The rounding of b costs 2^-12 relative per activation: ~1e-5 on a colour, ~6e-5
+// split -- a_hi.b + a_lo.b, two MFMAs instead of three.  Used for the COLOUR layers only: sigma_net keeps the split form, so densities, alphas and
+// the march are bit for bit those of f16x3 and a pixel's error is bounded by the per-sample colour error.  The rounding of b costs 2^-12 relative per activation: ~1e-5 on a colour, ~6e-5
 // relative on sigma with unit-scale weights (tests/) -- inside the 1e-4 colour contract, four digits short of the split form.
 __device__ __forceinline__ void round8(const float v[8], h8& hi) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -239,23 +240,23 @@ __device__ __forceinline__ FieldOut nerf_field_tile_f16x3(const unsigned char* _
             for (int j = 0; j < 8; j++) { x[0][j] *= enc_scale; x[1][j] *= enc_scale; }
         }
         sw.see(x[0]); sw.see(x[1]);
-        splitx<LO>(x[0], bh[0], bl[0]);
-        splitx<LO>(x[1], bh[1], bl[1]);
+        split8(x[0], bh[0], bl[0]);
+        split8(x[1], bh[1], bl[1]);
     }
     f32x16 h0 = zero16(), h1 = zero16();
-    h0 = mmax<LO>(h0, w + 0 * kF16BlockBytes, bh[0], bl[0], lane);
-    h0 = mmax<LO>(h0, w + 1 * kF16BlockBytes, bh[1], bl[1], lane);
-    h1 = mmax<LO>(h1, w + 2 * kF16BlockBytes, bh[0], bl[0], lane);
-    h1 = mmax<LO>(h1, w + 3 * kF16BlockBytes, bh[1], bl[1], lane);
+    h0 = mma3(h0, w + 0 * kF16BlockBytes, bh[0], bl[0], lane);
+    h0 = mma3(h0, w + 1 * kF16BlockBytes, bh[1], bl[1], lane);
+    h1 = mma3(h1, w + 2 * kF16BlockBytes, bh[0], bl[0], lane);
+    h1 = mma3(h1, w + 3 * kF16BlockBytes, bh[1], bl[1], lane);
     __builtin_amdgcn_sched_barrier(0);
     h0 = relu16(h0); h1 = relu16(h1);
 
     // sigma_net[1]: 64 -> 16
-    splitx_frag_w<LO>(sw, h0, 0, bh[0], bl[0]); splitx_frag_w<LO>(sw, h0, 1, bh[1], bl[1]);
-    splitx_frag_w<LO>(sw, h1, 0, bh[2], bl[2]); splitx_frag_w<LO>(sw, h1, 1, bh[3], bl[3]);
+    split_frag_w(sw, h0, 0, bh[0], bl[0]); split_frag_w(sw, h0, 1, bh[1], bl[1]);
+    split_frag_w(sw, h1, 0, bh[2], bl[2]); split_frag_w(sw, h1, 1, bh[3], bl[3]);
     f32x16 g = zero16();
 #pragma unroll
-    for (int kb = 0; kb < 4; kb++) g = mmax<LO>(g, w + (4 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
+    for (int kb = 0; kb < 4; kb++) g = mma3(g, w + (4 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
     __builtin_amdgcn_sched_barrier(0);
     if (enc_scale != 1.0f) {
         const float inv = 1.0f / enc_scale;

@@ -234,17 +234,20 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
         // ---------------- sigma_net (prescaled by a power of two when the table's entries are tiny: undone exactly on its 16 outputs)
         const bool pre_s = PREC != 0 && pp.enc_scale[0] != 1.0f, pre_p = PREC != 0 && pp.enc_scale[1] != 1.0f, pre_c = PREC != 0 && pp.enc_scale[2] != 1.0f;
         if (pre_s) scale8x2(xs, pp.enc_scale[0]);
+        // F16X2 rounds the activations of the COLOUR heads only: sigma_net keeps the split form (PS), so densities, alphas, the transmittance cut-off and
+        // with them the march are those of F16X3 bit for bit, and a pixel's error is bounded by the per-sample colour error whatever the ray's length
+        constexpr int PS = PREC == 2 ? 1 : PREC;
         f32x16 t0 = zero16(), t1 = zero16();
         {
-            const BOp<PREC> b0 = make_op<PREC, CHECK>(xs[0], sw), b1 = make_op<PREC, CHECK>(xs[1], sw);
-            t0 = mma_blk<PREC>(t0, w + (PB_S0 + 0) * kF16BlockBytes, b0, lane);
-            t0 = mma_blk<PREC>(t0, w + (PB_S0 + 1) * kF16BlockBytes, b1, lane);
-            t1 = mma_blk<PREC>(t1, w + (PB_S0 + 2) * kF16BlockBytes, b0, lane);
-            t1 = mma_blk<PREC>(t1, w + (PB_S0 + 3) * kF16BlockBytes, b1, lane);
+            const BOp<PS> b0 = make_op<PS, CHECK>(xs[0], sw), b1 = make_op<PS, CHECK>(xs[1], sw);
+            t0 = mma_blk<PS>(t0, w + (PB_S0 + 0) * kF16BlockBytes, b0, lane);
+            t0 = mma_blk<PS>(t0, w + (PB_S0 + 1) * kF16BlockBytes, b1, lane);
+            t1 = mma_blk<PS>(t1, w + (PB_S0 + 2) * kF16BlockBytes, b0, lane);
+            t1 = mma_blk<PS>(t1, w + (PB_S0 + 3) * kF16BlockBytes, b1, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
         t0 = relu16(t0); t1 = relu16(t1);
-        f32x16 g = dense64<PREC, CHECK>(zero16(), w, PB_S1, t0, t1, lane, sw);   // rows 0..15: sigma logit, geo_feat 1..15
+        f32x16 g = dense64<PS, CHECK>(zero16(), w, PB_S1, t0, t1, lane, sw);   // rows 0..15: sigma logit, geo_feat 1..15
         if (pre_s) g = scale16(g, 1.0f / pp.enc_scale[0]);
         const float sigma_logit = g[0];
         const BOp<PREC> geo = frag_op<PREC, CHECK>(g, 0, sw);                           // the geo k-block, shared by diff_net and color_net

@@ -549,9 +549,10 @@ def test_fused_nerf_field_matches_oracle_and_torch(cuda, precision):
 
 
 def test_fused_nerf_field_f16x2_is_inside_the_colour_contract(cuda):
-    """PNR_FIELD_F16X2 (opt-in: weights split, activations rounded once to fp16 -- two MFMAs per product): against the oracle's fp32 field on seeded
-    weights the colours stay within 5e-5 (north-star contract: 1e-4) and sigma within 2e-4 relative; it is NOT the fp32-class path (the split form
-    is held to 2e-6 / 2e-5 above) and a frame rendered with it has the same samples and a PSNR above 85 dB against the split form."""
+    """PNR_FIELD_F16X2 (opt-in: the colour layers with their activations rounded once to fp16 -- two MFMAs per product; sigma_net keeps the split
+    form): against the oracle's fp32 field on seeded weights the colours stay within 5e-5 (north-star contract: 1e-4) and sigma is the split form's
+    to 2e-5; it is NOT the fp32-class path for colours (the split form is held to 2e-6 above).  A frame rendered with it has exactly the split form's
+    samples and alphas, and a PSNR above 85 dB against it."""
     from palettenerf_amd import network
     from palettenerf_amd.fused import NeRFFieldFused
     rng = np.random.default_rng(51)
@@ -573,7 +574,7 @@ def test_fused_nerf_field_f16x2_is_inside_the_colour_contract(cuda):
     so, co = oracle.nerf_field_forward(enc, d, *w)
     err_c = np.abs(host(c) - co).max()
     err_s = np.abs(host(s) / so - 1).max()
-    assert 1e-7 < err_c < 5e-5 and err_s < 2e-4, (err_c, err_s)       # really the rounded form, and inside the contract
+    assert 1e-7 < err_c < 5e-5 and err_s < 2e-5, (err_c, err_s)       # really the rounded form for colours, inside the contract; sigma as the split form
     # a frame: same march, same sample count, colours within the contract
     m.density_grid.copy_(torch.from_numpy(scene.brick_density_grid()).to(cuda))
     raymarching.packbits(m.density_grid, 0.5, m.density_bitfield)
@@ -586,6 +587,7 @@ def test_fused_nerf_field_f16x2_is_inside_the_colour_contract(cuda):
         m._fused.precision = 1
         ref = m.render(ro.to(cuda), rd.to(cuda), **kw)
     assert int(fast["rendered"].sum()) == int(ref["rendered"].sum())
+    assert torch.equal(fast["weights_sum"], ref["weights_sum"]) and torch.equal(torch.nan_to_num(fast["depth"]), torch.nan_to_num(ref["depth"]))   # densities untouched
     diff = (fast["image"] - ref["image"]).abs().max().item()
     assert diff < 1e-4, diff
     assert scene.psnr(fast["image"].cpu(), ref["image"].cpu()) > 85.0
