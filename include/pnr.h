@@ -148,6 +148,65 @@ int pnr_march_rays_train_mip(const float* rays_o, const float* rays_d, const uin
                                                rows are then written 16 lanes per ray without a second walk; same outputs */,
                              pnr_stream_t stream);
 
+/* ---------------------------------------------------------------- occupancy maintenance ----- */
+
+/* Device-resident producer of the bitfield: replaces NeRFRenderer.update_extra_state, nerf/renderer.py:467-561
+ * (= PaletteRenderer's, palette/renderer.py), whose reference form is Python over torch ops with a host read of the mean (`.item()`),
+ * `nonzero`, boolean-mask scatters and raymarching.packbits (raymarching.h:11).  Per cascade c and visited cell: a jittered point
+ *     p = (2 q / (H - 1) - 1) * (b_c - b_c / H) + (2 u - 1) * b_c / H,   b_c = min(2^c, bound), q = the cell's integer coordinates, u = noise
+ * (fp32, operation by operation as the reference's torch expressions round on a GPU) -> sigma(p) * density_scale -> candidate of the cell;
+ * then density_grid = max(density_grid * decay, candidate) where both are >= 0, mean = mean(max(density_grid, 0)),
+ * bitfield = packbits(density_grid > min(mean, density_thresh)) and the brick mip of the march.  No step involves the host.
+ *   mode 0 (the reference while iter_density < 16): every cell once; noise [C, H^3, 3], row = the cell's MORTON index (the order of density_grid).
+ *   mode 1: per cascade n_partial uniformly drawn cells, coords int32 [C, n_partial, 3] in [0, H), followed by n_partial cells drawn from the
+ *           currently occupied ones (density > 0), the k-th in ascending Morton order with k = occ_rand[c][j] % (number occupied) -- occ_rand
+ *           int32 [C, n_partial] of non-negative random integers (what torch.randint reduces modulo the range); a cascade without an occupied
+ *           cell skips that half (the reference raises there).  noise [C, 2 n_partial, 3] in sample order.
+ * The random numbers are the CALLER's (the reference draws them with torch.rand_like / torch.randint), so two implementations can be compared.
+ * Cells drawn more than once keep the LARGEST candidate (the reference keeps an unspecified one of them).
+ *   pnr_occupancy_update   the whole sweep for the shipped field (16-level x 2 hash grid -> sigma_net 32 -> 64 -> 16): level-major lookup +
+ *                          exact-fp32 matrix-core sigma_net (packed_sigma_net = a PNR_FIELD_FP32 blob of pnr_nerf_field_pack) + commit.
+ *   any other field:       pnr_occupancy_begin; for slices of [0, pnr_occupancy_samples): pnr_occupancy_points -> caller's sigma(points)
+ *                          -> pnr_occupancy_scatter; pnr_occupancy_commit.
+ * points rows are float4 = world x, y, z and the global cell id c * H^3 + morton as int32 bits (-1: no sample).
+ * workspace: pnr_occupancy_workspace_bytes(C, H, chunk) bytes, 256-byte aligned; `chunk` = samples in flight in pnr_occupancy_update (>= 256; the
+ * other entry points need chunk 0 only).  H % 4 == 0, C <= 16, C * H^3 < 2^31.  state (optional): device float[2] = mean, threshold used. */
+typedef struct pnr_occupancy_args {
+    uint32_t C, H;
+    float bound;
+    float* density_grid;               /* [C, H^3] in/out */
+    uint8_t* density_bitfield;         /* [C * H^3 / 8] out */
+    void* mip;                         /* pnr_occupancy_mip_bytes(C, H) out, or NULL */
+    float density_scale, decay, density_thresh;
+    int mode;
+    uint32_t n_partial;
+    const float* noise;
+    const int32_t* coords;
+    const int32_t* occ_rand;
+    const float* embeddings;           /* pnr_occupancy_update only: fp32 hash table [rows, 2] ... */
+    const int32_t* offsets;
+    uint32_t num_levels;
+    float S;
+    uint32_t base_resolution, gridtype;
+    const float* packed_sigma_net;
+    void* workspace;
+    uint64_t workspace_bytes;
+    float* state;
+    float* points_out;                 /* pnr_occupancy_update only, optional: [samples, 4], every sample's point kept for inspection */
+} pnr_occupancy_args;
+uint64_t pnr_occupancy_workspace_bytes(uint32_t C, uint32_t H, uint32_t chunk);
+uint32_t pnr_occupancy_samples(const pnr_occupancy_args* args);
+int pnr_occupancy_update(const pnr_occupancy_args* args, pnr_stream_t stream);
+int pnr_occupancy_begin(const pnr_occupancy_args* args, pnr_stream_t stream);
+int pnr_occupancy_points(const pnr_occupancy_args* args, uint32_t first, uint32_t count, float* points, pnr_stream_t stream);
+int pnr_occupancy_scatter(const pnr_occupancy_args* args, const float* points, const float* sigmas, uint32_t count, pnr_stream_t stream);
+int pnr_occupancy_commit(const pnr_occupancy_args* args, pnr_stream_t stream);
+/* replaces NeRFRenderer.mark_untrained_grid, nerf/renderer.py:395-465: cells whose centre no training camera has in its frustum (slack of one
+ * cell), or that some camera sees closer than min_near (filter_close_point: or that lie within min_near of a camera), get density -1.
+ * poses [B,4,4] row-major cam2world; n_marked (optional): device int32, number of cells marked. */
+int pnr_mark_untrained_grid(const float* poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t C, uint32_t H, float bound, float min_near,
+                            int filter_close_point, float* density_grid, int32_t* n_marked, pnr_stream_t stream);
+
 /* Stable compaction replacing the host-side `rays_alive[rays_alive >= 0]` boolean mask
  * (nerf/renderer.py:376, palette/renderer.py:521).  Writes the surviving ids, in order, to
  * rays_alive_out and their number to n_alive_out[0].  scratch >= pnr_scan_scratch_bytes(n_alive). */
@@ -175,7 +234,8 @@ int pnr_grid_encode_backward(const void* grad, const float* inputs, const void* 
  * nerf/network.py:95-124 does after the hash-grid lookup (sigma_net 32->64->16, exp, SH degree 4, concat,
  * color_net 31->64->64->3, sigmoid) in one kernel on the fp32 matrix cores.
  *   pnr_nerf_field_pack: gathers the five bias-free nn.Linear weight matrices (row-major [out][in], device fp32)
- *                        into the MFMA-fragment-ordered blob `packed` (pnr_nerf_field_packed_bytes() bytes).
+ *                        into the MFMA-fragment-ordered blob `packed` (pnr_nerf_field_packed_bytes() bytes).  With all three colour
+ *                        weights NULL only the sigma_net part is written (enough for pnr_nerf_density_forward / pnr_occupancy_update).
  *   pnr_nerf_field_forward: enc = raw [16,B,2] output of pnr_grid_encode_forward (fp32), dirs [B,3] -> sigmas [B]
  *                        (= exp(h0), NOT multiplied by density_scale), rgbs [B,3]. */
 uint64_t pnr_nerf_field_packed_bytes(void);

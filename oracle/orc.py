@@ -372,3 +372,45 @@ def nerf_field_forward(enc, dirs, w_sigma0, w_sigma1, w_color0, w_color1, w_colo
     o = linear(c, w_color2)
     rgb = (np.float32(1) / (np.float32(1) + np.exp(-o))).astype(np.float32)
     return sigma, rgb
+
+
+# ------------------------------------------------------------------ occupancy maintenance (nerf/renderer.py:395-561)
+def occupancy_points(C, H, bound, noise, coords=None, occ_rand=None, density_grid=None, n_partial=0, first=0, count=None):
+    """Jittered world points of an occupancy sweep + the global cell id of each ([count,3] float32, [count] int32; id -1 = no sample).
+    n_partial == 0: every cell once (Morton order); otherwise the partial sweep of renderer.py:512-537 with the caller's random numbers."""
+    mode = 1 if n_partial else 0
+    total = C * H ** 3 if mode == 0 else C * 2 * n_partial
+    count = total - first if count is None else count
+    pts = np.empty((count, 4), np.float32)
+    noise = _f32(noise)
+    coords = _i32(coords) if coords is not None else None
+    occ_rand = _i32(occ_rand) if occ_rand is not None else None
+    grid = _f32(density_grid) if density_grid is not None else None
+    lib().orc_occupancy_points(_u(C), _u(H), _f(bound), _i(mode), _u(n_partial), _p(noise), _p(coords), _p(occ_rand), _p(grid), _u(first), _u(count), _p(pts))
+    return pts[:, :3].copy(), pts[:, 3].copy().view(np.int32), pts
+
+
+def occupancy_commit(density_grid, points4, candidates, decay, density_thresh):
+    """EMA-max of `candidates` (sigma * density_scale per sample of `points4`) into density_grid (modified in place, [C, H^3] float32),
+    then mean / threshold / packbits.  Returns (bitfield, mean, threshold)."""
+    assert density_grid.dtype == np.float32 and density_grid.flags.c_contiguous
+    C, H3 = density_grid.shape
+    H = round(H3 ** (1 / 3))
+    bits = np.empty(C * H3 // 8, np.uint8)
+    state = np.zeros(2, np.float32)
+    points4, candidates = _f32(points4), _f32(candidates)
+    lib().orc_occupancy_commit(_u(C), _u(H), _p(density_grid), _p(points4), _p(candidates), _u(points4.shape[0]), _f(decay), _f(density_thresh), _p(bits), _p(state))
+    return bits, float(state[0]), float(state[1])
+
+
+def mark_untrained_grid(poses, intrinsic, density_grid, bound, min_near, filter_close_point=False):
+    """nerf/renderer.py:395-465 on density_grid [C, H^3] (in place).  Returns the number of cells marked -1."""
+    assert density_grid.dtype == np.float32 and density_grid.flags.c_contiguous
+    C, H3 = density_grid.shape
+    H = round(H3 ** (1 / 3))
+    poses = _f32(poses).reshape(-1, 4, 4)
+    fx, fy, cx, cy = [float(v) for v in intrinsic]
+    n = np.zeros(1, np.int32)
+    lib().orc_mark_untrained_grid(_p(poses), _u(poses.shape[0]), _f(fx), _f(fy), _f(cx), _f(cy), _u(C), _u(H), _f(bound), _f(min_near), _i(int(filter_close_point)),
+                                  _p(density_grid), _p(n))
+    return int(n[0])

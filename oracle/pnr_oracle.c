@@ -803,3 +803,119 @@ ORC_API void orc_linear(const float* x, const float* W, const float* bias, float
             y[(size_t)b * out_dim + o] = acc;
         }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* occupancy maintenance: NeRFRenderer.update_extra_state / mark_untrained_grid                 */
+/* (nerf/renderer.py:467-561, :395-465).  The reference's methods are Python over torch ops; the */
+/* arithmetic those ops perform ON A GPU is restated here -- separate elementwise kernels, so no */
+/* contraction, and a division by a host scalar is a multiplication by its fp32 reciprocal      */
+/* (ATen's div kernel for a CPU-scalar operand).  The random numbers are inputs.                */
+/* ------------------------------------------------------------------------------------------ */
+/* per-cascade constants as Python forms them: doubles, narrowed to fp32 where they meet the fp32 tensor (renderer.py:494-499) */
+static void orc_occ_cascade(uint32_t c, float bound, uint32_t H, float* span, float* half_cell) {
+    double b = ldexp(1.0, (int)c);
+    if ((double)bound < b) b = (double)bound;
+    const double half = b / (double)H;
+    *span = (float)(b - half);
+    *half_cell = (float)half;
+}
+/* points [count,4] = world x, y, z, global cell id (c * H^3 + morton) as int32 bits, -1 = no sample.
+ * mode 0: sample s = c * H^3 + morton cell; mode 1: s = c * 2n + j, j < n: coords[c][j] (renderer.py:516-517), j >= n: the
+ * (occ_rand[c][j-n] % nnz)-th cell with density_grid > 0 in ascending order (:520-523).  noise [samples,3]. */
+ORC_API void orc_occupancy_points(uint32_t C, uint32_t H, float bound, int mode, uint32_t n, const float* noise, const int32_t* coords,
+                                  const int32_t* occ_rand, const float* density_grid, uint32_t first, uint32_t count, float* points) {
+    const uint32_t cells = H * H * H;
+    const float inv_hm1 = 1.0f / (float)(H - 1);
+    int32_t* occ = NULL;
+    uint32_t* nnz = NULL;
+    if (mode == 1) {
+        occ = (int32_t*)malloc((size_t)C * cells * sizeof(int32_t));
+        nnz = (uint32_t*)calloc(C, sizeof(uint32_t));
+        for (uint32_t c = 0; c < C; c++)
+            for (uint32_t m = 0; m < cells; m++)
+                if (density_grid[(size_t)c * cells + m] > 0.0f) occ[(size_t)c * cells + nnz[c]++] = (int32_t)m;
+    }
+    for (uint32_t i = 0; i < count; i++) {
+        const uint32_t s = first + i;
+        uint32_t c, cell;
+        int live = 1;
+        if (mode == 0) { c = s / cells; cell = s % cells; }
+        else {
+            c = s / (2 * n);
+            const uint32_t j = s % (2 * n);
+            if (j < n) {
+                const int32_t* q = coords + ((size_t)c * n + j) * 3;
+                cell = orc_morton((uint32_t)q[0], (uint32_t)q[1], (uint32_t)q[2]);
+            } else if (nnz[c] > 0) cell = (uint32_t)occ[(size_t)c * cells + (uint32_t)occ_rand[(size_t)c * n + (j - n)] % nnz[c]];
+            else { cell = 0; live = 0; }
+        }
+        float span, half_cell;
+        orc_occ_cascade(c, bound, H, &span, &half_cell);
+        const uint32_t q[3] = {orc_compact_bits(cell), orc_compact_bits(cell >> 1), orc_compact_bits(cell >> 2)};
+        for (int d = 0; d < 3; d++) {
+            const float x = (2.0f * (float)q[d]) * inv_hm1 - 1.0f;                        /* renderer.py:491 */
+            const float r = (noise[(size_t)s * 3 + d] * 2.0f - 1.0f) * half_cell;         /* :499 */
+            points[(size_t)i * 4 + d] = x * span + r;                                    /* :497, :499 */
+        }
+        const int32_t id = live ? (int32_t)(c * cells + cell) : -1;
+        memcpy(&points[(size_t)i * 4 + 3], &id, 4);
+    }
+    free(occ); free(nnz);
+}
+/* candidates (sigma * density_scale per sample, cells from orc_occupancy_points) -> tmp grid (largest candidate of a cell; the reference
+ * keeps an unspecified one, renderer.py:505/537) -> EMA-max (:541-542) -> mean (:543) -> min(mean, density_thresh) (:549) -> packbits (:550).
+ * state[0] = mean, state[1] = threshold. */
+ORC_API void orc_occupancy_commit(uint32_t C, uint32_t H, float* density_grid, const float* points, const float* candidates, uint32_t count,
+                                  float decay, float density_thresh, uint8_t* bitfield, float* state) {
+    const size_t total = (size_t)C * H * H * H;
+    float* tmp = (float*)malloc(total * sizeof(float));
+    for (size_t i = 0; i < total; i++) tmp[i] = -1.0f;
+    for (uint32_t i = 0; i < count; i++) {
+        int32_t id, a, b;
+        memcpy(&id, &points[(size_t)i * 4 + 3], 4);
+        if (id < 0) continue;
+        memcpy(&a, &tmp[id], 4); memcpy(&b, &candidates[i], 4);
+        if (b > a) tmp[id] = candidates[i];        /* order of the bit patterns = order of non-negative floats; -1 loses to all of them */
+    }
+    double sum = 0.0;
+    for (size_t i = 0; i < total; i++) {
+        if (density_grid[i] >= 0.0f && tmp[i] >= 0.0f) density_grid[i] = fmaxf(density_grid[i] * decay, tmp[i]);
+        sum += (double)(density_grid[i] > 0.0f ? density_grid[i] : 0.0f);
+    }
+    const float mean = (float)(sum * (1.0 / (double)total));
+    const float thresh = density_thresh < mean ? density_thresh : mean;
+    if (state) { state[0] = mean; state[1] = thresh; }
+    orc_packbits(density_grid, (uint32_t)(total / 8), thresh, bitfield);
+    free(tmp);
+}
+/* nerf/renderer.py:395-465: cam = (world - t) @ R per pose (an i-ordered fma chain here), frustum test with a cell of slack, count / too_close */
+ORC_API void orc_mark_untrained_grid(const float* poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t C, uint32_t H, float bound,
+                                     float min_near, int filter_close_point, float* density_grid, int32_t* n_marked) {
+    const uint32_t cells = H * H * H;
+    const float inv_hm1 = 1.0f / (float)(H - 1), kx = cx / fx, ky = cy / fy;
+    int32_t marked = 0;
+    for (uint32_t c = 0; c < C; c++) {
+        float span, half_cell;
+        orc_occ_cascade(c, bound, H, &span, &half_cell);
+        const float slack = half_cell * 2.0f;
+        for (uint32_t cell = 0; cell < cells; cell++) {
+            const uint32_t q[3] = {orc_compact_bits(cell), orc_compact_bits(cell >> 1), orc_compact_bits(cell >> 2)};
+            float w[3];
+            for (int d = 0; d < 3; d++) w[d] = ((2.0f * (float)q[d]) * inv_hm1 - 1.0f) * span;
+            uint32_t seen = 0, close = 0;
+            for (uint32_t b = 0; b < B; b++) {
+                const float* P = poses + (size_t)b * 16;
+                const float d0 = w[0] - P[3], d1 = w[1] - P[7], d2 = w[2] - P[11];
+                const float X = fmaf(d2, P[8], fmaf(d1, P[4], d0 * P[0]));
+                const float Y = fmaf(d2, P[9], fmaf(d1, P[5], d0 * P[1]));
+                const float Z = fmaf(d2, P[10], fmaf(d1, P[6], d0 * P[2]));
+                const int in = Z > 0.0f && fabsf(X) < kx * Z + slack && fabsf(Y) < ky * Z + slack;
+                seen += (uint32_t)in;
+                close += (uint32_t)(in && Z < min_near);
+                if (filter_close_point) close += (uint32_t)(sqrtf(X * X + Y * Y + Z * Z) < min_near);
+            }
+            if (seen == 0 || close != 0) { density_grid[(size_t)c * cells + cell] = -1.0f; marked++; }
+        }
+    }
+    if (n_marked) *n_marked = marked;
+}

@@ -80,8 +80,16 @@ SIGNATURES = {
     "pnr_adam_max_tensors": [],
     "pnr_adam_step": [_ptr, _u32, _ptr, _ptr],
     "pnr_get_rays": [_ptr, _u32, _f32, _f32, _f32, _f32, _u32, _u32, _ptr, _u32, _ptr, _ptr, _ptr],
+    "pnr_occupancy_workspace_bytes": [_u32, _u32, _u32],
+    "pnr_occupancy_samples": [_ptr],
+    "pnr_occupancy_update": [_ptr, _ptr],
+    "pnr_occupancy_begin": [_ptr, _ptr],
+    "pnr_occupancy_points": [_ptr, _u32, _u32, _ptr, _ptr],
+    "pnr_occupancy_scatter": [_ptr, _ptr, _ptr, _u32, _ptr],
+    "pnr_occupancy_commit": [_ptr, _ptr],
+    "pnr_mark_untrained_grid": [_ptr, _u32, _f32, _f32, _f32, _f32, _u32, _u32, _f32, _f32, _int, _ptr, _ptr, _ptr],
 }
-_RESTYPES = {"pnr_adam_max_tensors": _u32, "pnr_error_string": ctypes.c_char_p, "pnr_scan_scratch_bytes": _u64, "pnr_nerf_field_packed_bytes": _u64, "pnr_occupancy_mip_bytes": _u64, "pnr_nerf_frame_workspace_bytes": _u64, "pnr_palette_field_packed_bytes": _u64, "pnr_palette_frame_workspace_bytes": _u64,
+_RESTYPES = {"pnr_occupancy_workspace_bytes": _u64, "pnr_occupancy_samples": _u32, "pnr_adam_max_tensors": _u32, "pnr_error_string": ctypes.c_char_p, "pnr_scan_scratch_bytes": _u64, "pnr_nerf_field_packed_bytes": _u64, "pnr_occupancy_mip_bytes": _u64, "pnr_nerf_frame_workspace_bytes": _u64, "pnr_palette_field_packed_bytes": _u64, "pnr_palette_frame_workspace_bytes": _u64,
              "pnr_palette_aux_channels": _u32, "pnr_linear_wgrad_workspace_bytes": _u64, "pnr_grid_backward_binned_workspace_bytes": _u64,
              "pnr_palette_train_shade_workspace_bytes": _u64, "pnr_mlp_packed_bytes": _u64, "pnr_mlp_backward_workspace_bytes": _u64}
 
@@ -98,6 +106,14 @@ class AdamScalars(ctypes.Structure):
 class MlpDesc(ctypes.Structure):
     """Mirror of `pnr_mlp_desc` (include/pnr.h)."""
     _fields_ = [("n_layers", _u32), ("dims", _u32 * 4), ("activation", _int)]
+
+
+class OccupancyArgs(ctypes.Structure):
+    """Mirror of `pnr_occupancy_args` (include/pnr.h)."""
+    _fields_ = [("C", _u32), ("H", _u32), ("bound", _f32), ("density_grid", _ptr), ("density_bitfield", _ptr), ("mip", _ptr), ("density_scale", _f32),
+                ("decay", _f32), ("density_thresh", _f32), ("mode", _int), ("n_partial", _u32), ("noise", _ptr), ("coords", _ptr), ("occ_rand", _ptr),
+                ("embeddings", _ptr), ("offsets", _ptr), ("num_levels", _u32), ("S", _f32), ("base_resolution", _u32), ("gridtype", _u32),
+                ("packed_sigma_net", _ptr), ("workspace", _ptr), ("workspace_bytes", _u64), ("state", _ptr), ("points_out", _ptr)]
 
 
 class NerfFrameArgs(ctypes.Structure):

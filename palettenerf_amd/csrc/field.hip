@@ -30,9 +30,9 @@ namespace pnr {
 // One thread per packed element: decode (layer, row tile, step, lane) and fetch the weight.
 __global__ void __launch_bounds__(256) k_nerf_field_pack(const float* __restrict__ Ws0, const float* __restrict__ Ws1,
                                                          const float* __restrict__ Wc0, const float* __restrict__ Wc1,
-                                                         const float* __restrict__ Wc2, float* __restrict__ packed) {
+                                                         const float* __restrict__ Wc2, float* __restrict__ packed, int limit) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= kPackedFloats) return;
+    if (e >= limit) return;
     const int lane = e & 63, i = lane & 31, h = lane >> 5;
     float v = 0.0f;
     if (e < kS1) {                       // sigma_net[0]  W[64][32]; k order is the natural one
@@ -60,9 +60,9 @@ __global__ void __launch_bounds__(256) k_nerf_field_pack(const float* __restrict
 // pack kernel of the split-fp16 blob: one thread per (block, lane, element)
 __global__ void __launch_bounds__(256) k_nerf_field_pack_f16x3(const float* __restrict__ Ws0, const float* __restrict__ Ws1,
                                                                const float* __restrict__ Wc0, const float* __restrict__ Wc1,
-                                                               const float* __restrict__ Wc2, unsigned char* __restrict__ packed) {
+                                                               const float* __restrict__ Wc2, unsigned char* __restrict__ packed, int limit) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= kF16Blocks * 64 * 8) return;
+    if (e >= limit) return;
     const int q = e / 512, lane = (e / 8) & 63, j = e & 7, i = lane & 31, h = lane >> 5;
     float v = 0.0f;
     if (q < 4) { const int rt = q / 2, kb = q % 2; v = Ws0[(rt * 32 + i) * 32 + f16_col_S0(kb, h, j)]; }
@@ -143,13 +143,15 @@ uint64_t pnr_nerf_field_packed_bytes(void) { return (uint64_t)kPackedFloats * 4;
 
 int pnr_nerf_field_pack(const float* w_sigma0, const float* w_sigma1, const float* w_color0, const float* w_color1, const float* w_color2,
                         float* packed, int precision, pnr_stream_t stream) {
-    if (!w_sigma0 || !w_sigma1 || !w_color0 || !w_color1 || !w_color2 || !packed) return PNR_ERR_INVALID;
+    if (!w_sigma0 || !w_sigma1 || !packed) return PNR_ERR_INVALID;
+    const bool sigma_only = !w_color0 && !w_color1 && !w_color2;     // the density-only users (pnr_nerf_density_forward, pnr_occupancy_update) read that part alone
+    if (!sigma_only && (!w_color0 || !w_color1 || !w_color2)) return PNR_ERR_INVALID;
     if (precision == PNR_FIELD_FP32)
         hipLaunchKernelGGL(k_nerf_field_pack, dim3(cdiv(kPackedFloats, 256)), dim3(256), 0, as_stream(stream), w_sigma0, w_sigma1, w_color0, w_color1,
-                           w_color2, packed);
+                           w_color2, packed, sigma_only ? kC0 : kPackedFloats);
     else if (precision == PNR_FIELD_F16X3 || precision == PNR_FIELD_F16X2)
         hipLaunchKernelGGL(k_nerf_field_pack_f16x3, dim3(cdiv(kF16Blocks * 512, 256)), dim3(256), 0, as_stream(stream), w_sigma0, w_sigma1, w_color0,
-                           w_color1, w_color2, reinterpret_cast<unsigned char*>(packed));
+                           w_color1, w_color2, reinterpret_cast<unsigned char*>(packed), (sigma_only ? 8 : kF16Blocks) * 512);
     else
         return PNR_ERR_UNSUPPORTED;
     return check_launch();

@@ -1,0 +1,507 @@
+// occupancy.hip -- producer of the density bitfield the march consumes, as device-resident HIP for gfx950.
+//
+// What it computes is NeRFRenderer.update_extra_state / mark_untrained_grid (nerf/renderer.py:467-561, :395-465; PaletteRenderer has neither:
+// its grid is the NeRF stage's): per cascade, a jittered point in each visited cell -> density of the field there ->
+// EMA-max into density_grid -> mean -> threshold min(mean, density_thresh) -> packbits (raymarching.cu:271-292) -> the brick mip the march
+// stages in LDS.  How it is organised is not the reference's: nothing crosses to the host.  The reference's `.item()` (mean), `nonzero`
+// (occupied list), boolean-mask scatters and per-block Python loops become
+//     begin    : tmp grid := -1; partial sweeps: stable compaction of the occupied cells (count / scan / write, wave64 ballots)
+//     sample   : k_occ_points (cell -> jittered world point)  ->  k_occ_lookup (level-major hash-grid gathers, the roofline kernel's loop)
+//                ->  k_occ_sigma (sigma_net on v_mfma_f32_32x32x2_f32, exact fp32; exp, density_scale, atomic max into the tmp grid)
+//     commit   : k_occ_ema (EMA-max, fp64 partial sums in a fixed order)  ->  k_occ_pack (mean, threshold and packbits on the device)
+//                ->  pnr_build_occupancy_mip
+// A field this library has no fused kernel for slots its own density() between pnr_occupancy_points and pnr_occupancy_scatter.
+//
+// Cells are visited in Morton order (the order density_grid is stored in): a 256-sample tile is an 8x8x4 block of cells, so the gathers
+// of a wave hit neighbouring rows on every level, and every access to the density / tmp grids is coalesced.
+//
+// Duplicates (partial sweeps draw cells with repetition, and the uniform and occupied halves overlap): the reference's
+// `tmp_grid[cas, indices] = sigmas` keeps whichever duplicate the scatter kernel happens to write last -- scheduling dependent on a GPU.
+// Here the LARGEST candidate wins (atomic max on the bit pattern; sigma >= 0): one of the values the reference may keep, and deterministic.
+#include "pnr_common.hpp"
+#include "grid_core.hpp"
+#include "field_core.hpp"
+
+extern "C" int pnr_build_occupancy_mip(const uint8_t* grid, uint32_t C, uint32_t H, float bound, void* mip, pnr_stream_t stream);
+
+namespace pnr {
+
+constexpr uint32_t kOccMaxCascades = 16;
+constexpr uint32_t kListBlock = 1024;     // cells per workgroup of the occupied-list passes (256 threads x 4)
+constexpr uint32_t kEmaBlock = 8192;      // cells per workgroup of the EMA pass = one fp64 partial sum
+constexpr uint32_t kOccSampleBytes = 16 + 128;   // workspace per in-flight sample: point (float4) + level-major encoder row
+
+struct OccGeom {
+    uint32_t C, H, cells;                 // cells = H^3
+    float inv_hm1;                        // 1.0f / (H - 1): torch's GPU division by a host scalar multiplies by the fp32 reciprocal
+    float span[kOccMaxCascades];          // (float)(b_c - b_c / H), b_c = min(2^c, bound), formed in double as Python does
+    float half_cell[kOccMaxCascades];     // (float)(b_c / H)
+    int mode;                             // 0: every cell once; 1: n uniform + n occupied cells per cascade
+    uint32_t n;                           // partial: cells per half and cascade
+};
+
+struct OccWorkspace {
+    float* tmp;              // [C * cells]   candidate densities of this sweep, -1 = not visited
+    int32_t* occ_list;       // [C * cells]   partial: Morton indices of the cells with density > 0, ascending, per cascade
+    int32_t* blk;            // [C * nblk]    per-block counts, then exclusive offsets
+    int32_t* nnz;            // [C]
+    double* partial;         // [ceil(C * cells / kEmaBlock)]
+    float* pts;              // [chunk][4]
+    float* enc;              // [16][chunk][2]
+    uint32_t chunk;
+};
+
+static inline uint64_t align256(uint64_t v) { return (v + 255) & ~(uint64_t)255; }
+static inline uint32_t list_blocks(uint32_t cells) { return (cells + kListBlock - 1) / kListBlock; }
+static uint64_t fixed_bytes(uint32_t C, uint32_t H) {
+    const uint64_t cells = (uint64_t)H * H * H, total = C * cells;
+    return align256(total * 4) * 2 + align256((uint64_t)C * list_blocks((uint32_t)cells) * 4) + align256(C * 4) + align256(((total + kEmaBlock - 1) / kEmaBlock) * 8);
+}
+static bool carve(const pnr_occupancy_args* a, OccWorkspace* w) {
+    const uint64_t cells = (uint64_t)a->H * a->H * a->H, total = a->C * cells;
+    const uint64_t fixed = fixed_bytes(a->C, a->H);
+    if (!a->workspace || a->workspace_bytes < fixed || (reinterpret_cast<uintptr_t>(a->workspace) & 255)) return false;
+    unsigned char* p = static_cast<unsigned char*>(a->workspace);
+    w->tmp = reinterpret_cast<float*>(p); p += align256(total * 4);
+    w->occ_list = reinterpret_cast<int32_t*>(p); p += align256(total * 4);
+    w->blk = reinterpret_cast<int32_t*>(p); p += align256((uint64_t)a->C * list_blocks((uint32_t)cells) * 4);
+    w->nnz = reinterpret_cast<int32_t*>(p); p += align256(a->C * 4);
+    w->partial = reinterpret_cast<double*>(p); p += align256(((total + kEmaBlock - 1) / kEmaBlock) * 8);
+    const uint64_t left = a->workspace_bytes - fixed;
+    uint64_t chunk = (left / kOccSampleBytes) & ~(uint64_t)255;
+    if (chunk > (1u << 22)) chunk = 1u << 22;
+    w->chunk = (uint32_t)chunk;
+    w->pts = reinterpret_cast<float*>(p);
+    w->enc = reinterpret_cast<float*>(p + chunk * 16);
+    return true;
+}
+static bool make_geom(const pnr_occupancy_args* a, OccGeom* g) {
+    if (!a || a->C == 0 || a->C > kOccMaxCascades || a->H < 2 || a->H > 1024 || (a->H % 4) != 0 || !(a->bound > 0.0f)) return false;
+    const uint64_t total = (uint64_t)a->C * a->H * a->H * a->H;
+    if (total > (1ull << 31) || (total % 8) != 0) return false;
+    if (a->mode != 0 && a->mode != 1) return false;
+    if (a->mode == 1 && (a->n_partial == 0 || (uint64_t)2 * a->n_partial * a->C > (1ull << 31))) return false;
+    g->C = a->C; g->H = a->H; g->cells = a->H * a->H * a->H;
+    g->inv_hm1 = 1.0f / (float)(a->H - 1);
+    for (uint32_t c = 0; c < kOccMaxCascades; c++) {
+        double b = ldexp(1.0, (int)c);                       // min(2 ** cas, self.bound), nerf/renderer.py:494
+        if ((double)a->bound < b) b = (double)a->bound;
+        const double half = b / (double)a->H;                // half_grid_size, :495
+        g->span[c] = (float)(b - half);                      // the Python scalar meets the fp32 tensor as fp32 (:497)
+        g->half_cell[c] = (float)half;
+    }
+    g->mode = a->mode; g->n = a->n_partial;
+    return true;
+}
+static inline uint32_t total_samples(const OccGeom& g) { return g.mode == 0 ? g.C * g.cells : g.C * 2u * g.n; }
+
+// ------------------------------------------------------------------------------------------ begin
+__global__ void __launch_bounds__(256) k_occ_fill(float4* __restrict__ tmp, uint32_t n4) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) tmp[i] = make_float4(-1.0f, -1.0f, -1.0f, -1.0f);
+}
+
+// `torch.nonzero(self.density_grid[cas] > 0)` (nerf/renderer.py:520) as a stable three-pass compaction.  Thread t of a block owns the four
+// consecutive cells 4t .. 4t+3, so ranks follow the cell order.
+__device__ __forceinline__ uint32_t occ_mask4(const float* __restrict__ grid, uint32_t cell0, uint32_t cells) {
+    uint32_t m = 0;
+    if (cell0 + 3 < cells) {
+        const float4 v = *reinterpret_cast<const float4*>(grid + cell0);
+        m = (v.x > 0.0f ? 1u : 0u) | (v.y > 0.0f ? 2u : 0u) | (v.z > 0.0f ? 4u : 0u) | (v.w > 0.0f ? 8u : 0u);
+    } else {
+        for (uint32_t k = 0; k < 4; k++) if (cell0 + k < cells && grid[cell0 + k] > 0.0f) m |= 1u << k;
+    }
+    return m;
+}
+__global__ void __launch_bounds__(256) k_occ_count(const float* __restrict__ grid, uint32_t cells, uint32_t nblk, int32_t* __restrict__ blk) {
+    __shared__ int wsum[4];
+    const uint32_t c = blockIdx.y;
+    const uint32_t cell0 = blockIdx.x * kListBlock + threadIdx.x * 4;
+    int v = __popc(occ_mask4(grid + (size_t)c * cells, cell0, cells));
+    for (int off = PNR_WAVE / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, PNR_WAVE);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) blk[c * nblk + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+// one workgroup per cascade: exclusive scan of the block counts in place, total to nnz[c]
+__global__ void __launch_bounds__(1024) k_occ_scan(int32_t* __restrict__ blk, uint32_t nblk, int32_t* __restrict__ nnz) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    int32_t* b = blk + (size_t)blockIdx.x * nblk;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < nblk; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const int v = i < nblk ? b[i] : 0;
+        const int incl = wave_inclusive_scan(v);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int off = carry;
+        for (int w = 0; w < wave; w++) off += wsum[w];
+        if (i < nblk) b[i] = off + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) nnz[blockIdx.x] = carry;
+}
+__global__ void __launch_bounds__(256) k_occ_write(const float* __restrict__ grid, uint32_t cells, uint32_t nblk, const int32_t* __restrict__ blk,
+                                                   int32_t* __restrict__ occ_list) {
+    __shared__ int wsum[4];
+    const uint32_t c = blockIdx.y;
+    const uint32_t cell0 = blockIdx.x * kListBlock + threadIdx.x * 4;
+    const uint32_t m = occ_mask4(grid + (size_t)c * cells, cell0, cells);
+    const int v = __popc(m);
+    const int incl = wave_inclusive_scan(v);
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int off = blk[c * nblk + blockIdx.x] + incl - v;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) off += wsum[w];
+    int32_t* out = occ_list + (size_t)c * cells;
+    for (uint32_t k = 0; k < 4; k++) if (m & (1u << k)) out[off++] = (int32_t)(cell0 + k);
+}
+
+// ------------------------------------------------------------------------------------------ sample
+// Sample s of the sweep -> (cascade, Morton cell, jitter row).  full: s = c * cells + cell, jitter noise[s].  partial: s = c * 2n + j;
+// j < n: the caller's uniform cell coords[c][j]; j >= n: the (rand % nnz)-th occupied cell (`occ_indices[rand_mask]`, renderer.py:521-522;
+// torch.randint IS `raw % range`), nothing when the cascade has no occupied cell.
+// The point, op for op as the reference's torch expressions evaluate on a GPU (separate elementwise kernels: no contraction):
+//     xyzs = 2 * coords.float() / (G - 1) - 1          (:491; the division by a host scalar is a multiplication by its fp32 reciprocal)
+//     cas_xyzs = xyzs * (bound - half_grid_size)       (:497)
+//     cas_xyzs += (rand * 2 - 1) * half_grid_size      (:499)
+__global__ void __launch_bounds__(256) k_occ_points(OccGeom g, uint32_t first, uint32_t count, const float* __restrict__ noise,
+                                                    const int32_t* __restrict__ coords, const int32_t* __restrict__ occ_rand,
+                                                    const int32_t* __restrict__ occ_list, const int32_t* __restrict__ nnz, float4* __restrict__ pts) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t s = first + i;
+    uint32_t c, cell;
+    bool live = true;
+    if (g.mode == 0) { c = s / g.cells; cell = s % g.cells; }
+    else {
+        c = s / (2u * g.n);
+        const uint32_t j = s % (2u * g.n);
+        if (j < g.n) {
+            const int32_t* q = coords + ((size_t)c * g.n + j) * 3;
+            cell = morton3((uint32_t)q[0], (uint32_t)q[1], (uint32_t)q[2]);
+            live = (uint32_t)q[0] < g.H && (uint32_t)q[1] < g.H && (uint32_t)q[2] < g.H;
+        } else {
+            const int32_t k = nnz[c];
+            live = k > 0;
+            cell = live ? (uint32_t)occ_list[(size_t)c * g.cells + (uint32_t)occ_rand[(size_t)c * g.n + (j - g.n)] % (uint32_t)k] : 0u;
+        }
+    }
+    const uint32_t q[3] = {gather3(cell), gather3(cell >> 1), gather3(cell >> 2)};
+    float p[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const float x = (2.0f * (float)q[d]) * g.inv_hm1 - 1.0f;
+        const float r = (noise[(size_t)s * 3 + d] * 2.0f - 1.0f) * g.half_cell[c];
+        p[d] = x * g.span[c] + r;
+    }
+    pts[i] = make_float4(p[0], p[1], p[2], __int_as_float(live ? (int32_t)(c * g.cells + cell) : -1));
+}
+
+// gridencoder.cu:75-175 for D = 3, C = 2, fp32 with GridEncoder.forward's (x + bound) / (2 bound) folded in (gridencoder/grid.py:142):
+// the loop of k_frame_grid over the sweep's points.  grid = (blocks, levels): a block column works on one level.
+__global__ void __launch_bounds__(256) k_occ_lookup(const float4* __restrict__ pts, uint32_t count, const float* __restrict__ table,
+                                                    const int32_t* __restrict__ offsets, LevelParams lp, float* __restrict__ enc, uint32_t level_stride,
+                                                    float bound, float two_bound, uint32_t gridtype) {
+    const uint32_t level = blockIdx.y;
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    const float* g = table + (size_t)off0 * 2;
+    const float scale = lp.scale[level];
+    const uint32_t resolution = lp.resolution[level];
+    for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < count; b += gridDim.x * 256) {
+        const float4 p = pts[b];
+        if (__float_as_int(p.w) < 0) continue;
+        const float x[3] = {p.x, p.y, p.z};
+        float in[3];
+        bool oob = false;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            in[d] = (x[d] + bound) / two_bound;
+            oob |= (in[d] < 0.0f) | (in[d] > 1.0f);
+        }
+        float2 out = make_float2(0.0f, 0.0f);
+        if (!oob) {
+            float pos[3];
+            uint32_t pg[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                pos[d] = fmaf(in[d], scale, 0.5f);
+                const float fl = floorf(pos[d]);
+                pg[d] = (uint32_t)fl;
+                pos[d] -= (float)pg[d];
+            }
+            uint32_t idxs[8];
+            float ws[8];
+#pragma unroll
+            for (uint32_t idx = 0; idx < 8; idx++) {
+                float w = 1.0f;
+                uint32_t pl[3];
+#pragma unroll
+                for (uint32_t d = 0; d < 3; d++) {
+                    if ((idx & (1u << d)) == 0) { w *= 1.0f - pos[d]; pl[d] = pg[d]; }
+                    else { w *= pos[d]; pl[d] = pg[d] + 1; }
+                }
+                ws[idx] = w;
+                idxs[idx] = grid_index<3, 2>(gridtype, false, hashmap_size, resolution, pl);
+            }
+            float acc[2] = {0.0f, 0.0f};
+#pragma unroll
+            for (uint32_t idx = 0; idx < 8; idx++) corner_accumulate<2>(acc, ws[idx], g + idxs[idx]);
+            out = make_float2(acc[0], acc[1]);
+        }
+        *reinterpret_cast<float2*>(enc + ((size_t)level * level_stride + b) * 2) = out;
+    }
+}
+
+// sigma_net on the matrix cores (exact fp32: nerf_density_tile<0>, the arithmetic of k_nerf_density_fwd<0>), sigma = exp(h0) * density_scale
+// (nerf/network.py:137, renderer.py:503), largest candidate per cell kept in the tmp grid.
+__global__ void __launch_bounds__(512) k_occ_sigma(const float4* __restrict__ pts, uint32_t count, const float* __restrict__ enc, uint32_t level_stride,
+                                                   const float* __restrict__ packed, float density_scale, float* __restrict__ tmp) {
+    __shared__ float w[kC0];
+    for (int i = threadIdx.x * 4; i < kC0; i += 512 * 4) *reinterpret_cast<float4*>(&w[i]) = *reinterpret_cast<const float4*>(&packed[i]);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const uint32_t ntiles = (count + 255) / 256;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t n = tile * 256 + wave * 32 + (lane & 31);
+        const bool inside = n < count;
+        const int32_t cell = inside ? __float_as_int(pts[n].w) : -1;
+        const bool valid = cell >= 0;
+        const f32x16 g = nerf_density_tile<0>(w, lane, valid, enc, level_stride, inside ? n : 0u);
+        if (valid && h == 0) atomicMax(reinterpret_cast<int*>(tmp) + cell, __float_as_int(density_scale * expf(g[0])));
+    }
+}
+
+// generic fields: the caller evaluated sigma at the points itself
+__global__ void __launch_bounds__(256) k_occ_scatter(const float4* __restrict__ pts, const float* __restrict__ sigmas, uint32_t count, float density_scale,
+                                                     float* __restrict__ tmp) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const int32_t cell = __float_as_int(pts[i].w);
+    if (cell >= 0) atomicMax(reinterpret_cast<int*>(tmp) + cell, __float_as_int(sigmas[i] * density_scale));
+}
+
+// ------------------------------------------------------------------------------------------ commit
+__device__ __forceinline__ double block_sum_f64(double v, double* red /* [4] */) {
+    for (int off = PNR_WAVE / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, PNR_WAVE);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// nerf/renderer.py:541-543: valid = (grid >= 0) & (tmp >= 0); grid[valid] = max(grid[valid] * decay, tmp[valid]); and the addends of
+// `mean(grid.clamp(min=0))` as one fp64 partial per workgroup (fixed order: the mean does not depend on scheduling)
+__global__ void __launch_bounds__(256) k_occ_ema(float* __restrict__ grid, const float* __restrict__ tmp, uint32_t total, float decay,
+                                                 double* __restrict__ partial) {
+    __shared__ double red[4];
+    const uint32_t base = blockIdx.x * kEmaBlock;
+    double acc = 0.0;
+    for (uint32_t k = threadIdx.x * 4; k < kEmaBlock; k += 1024) {
+        const uint32_t i = base + k;
+        if (i >= total) break;
+        float4 o = *reinterpret_cast<const float4*>(grid + i);
+        const float4 t = *reinterpret_cast<const float4*>(tmp + i);
+        bool dirty = false;
+        float* ov = reinterpret_cast<float*>(&o);
+        const float* tv = reinterpret_cast<const float*>(&t);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            if (ov[e] >= 0.0f && tv[e] >= 0.0f) { ov[e] = fmaxf(ov[e] * decay, tv[e]); dirty = true; }
+            acc += (double)(ov[e] > 0.0f ? ov[e] : 0.0f);
+        }
+        if (dirty) *reinterpret_cast<float4*>(grid + i) = o;
+    }
+    const double s = block_sum_f64(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// mean -> threshold -> packbits (raymarching.cu:271-292: strict >), one output byte per thread.  Every workgroup re-derives the mean from the
+// partials in the same fixed order (a few KiB out of L2), so no launch sits between the EMA pass and this one.
+__global__ void __launch_bounds__(256) k_occ_pack(const float* __restrict__ grid, uint32_t nbytes, const double* __restrict__ partial, uint32_t nparts,
+                                                  double inv_total, float density_thresh, uint8_t* __restrict__ bitfield, float* __restrict__ state) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (uint32_t k = threadIdx.x; k < nparts; k += 256) acc += partial[k];
+    const float mean = (float)(block_sum_f64(acc, red) * inv_total);
+    const float thresh = density_thresh < mean ? density_thresh : mean;      // Python's min(mean, density_thresh), renderer.py:549
+    if (state && blockIdx.x == 0 && threadIdx.x == 0) { state[0] = mean; state[1] = thresh; }
+    const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= nbytes) return;
+    const float4* gp = reinterpret_cast<const float4*>(grid) + (size_t)n * 2;
+    const float4 a = gp[0], b = gp[1];
+    uint32_t bits = 0;
+    bits |= (a.x > thresh) ? 1u : 0u;   bits |= (a.y > thresh) ? 2u : 0u;
+    bits |= (a.z > thresh) ? 4u : 0u;   bits |= (a.w > thresh) ? 8u : 0u;
+    bits |= (b.x > thresh) ? 16u : 0u;  bits |= (b.y > thresh) ? 32u : 0u;
+    bits |= (b.z > thresh) ? 64u : 0u;  bits |= (b.w > thresh) ? 128u : 0u;
+    bitfield[n] = (uint8_t)bits;
+}
+
+// ------------------------------------------------------------------------------------------ mark_untrained_grid
+// nerf/renderer.py:395-465 in one launch: a cell keeps density 0 when at least one training camera has its centre inside the frustum
+// (half a cell of slack) and no camera sees it closer than min_near; every other cell is set to -1 and never sampled.  One thread per
+// (cascade, cell); the poses pass through LDS in tiles.  cam = (world - t) @ R as an fmaf chain over the three axes.
+constexpr uint32_t kPoseTile = 512;    // poses staged in LDS at a time (24 KiB)
+__global__ void __launch_bounds__(256) k_mark_untrained(OccGeom g, const float* __restrict__ poses /* [B,4,4] */, uint32_t B, float fx, float fy, float cx,
+                                                        float cy, float min_near, int filter_close_point, float* __restrict__ grid,
+                                                        int32_t* __restrict__ n_marked) {
+    __shared__ float sp[kPoseTile * 12];   // per pose: R row-major (9), t (3)
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    const bool inside = s < g.C * g.cells;
+    const uint32_t c = inside ? s / g.cells : 0u, cell = inside ? s % g.cells : 0u;
+    const uint32_t q[3] = {gather3(cell), gather3(cell >> 1), gather3(cell >> 2)};
+    float wpt[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) wpt[d] = ((2.0f * (float)q[d]) * g.inv_hm1 - 1.0f) * g.span[c];
+    const float slack = g.half_cell[c] * 2.0f, kx = cx / fx, ky = cy / fy;
+    uint32_t seen = 0, close = 0;
+    for (uint32_t b0 = 0; b0 < B; b0 += kPoseTile) {
+        const uint32_t nb = B - b0 < kPoseTile ? B - b0 : kPoseTile;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nb * 12; i += 256) {
+            const uint32_t b = b0 + i / 12, e = i % 12;
+            sp[i] = e < 9 ? poses[(size_t)b * 16 + (e / 3) * 4 + (e % 3)] : poses[(size_t)b * 16 + (e - 9) * 4 + 3];
+        }
+        __syncthreads();
+        for (uint32_t b = 0; b < nb; b++) {
+            const float* R = sp + b * 12;
+            const float d0 = wpt[0] - R[9], d1 = wpt[1] - R[10], d2 = wpt[2] - R[11];
+            const float X = fmaf(d2, R[6], fmaf(d1, R[3], d0 * R[0]));
+            const float Y = fmaf(d2, R[7], fmaf(d1, R[4], d0 * R[1]));
+            const float Z = fmaf(d2, R[8], fmaf(d1, R[5], d0 * R[2]));
+            const bool in = Z > 0.0f && fabsf(X) < kx * Z + slack && fabsf(Y) < ky * Z + slack;
+            seen += in ? 1u : 0u;
+            close += (in && Z < min_near) ? 1u : 0u;
+            if (filter_close_point) close += sqrtf(X * X + Y * Y + Z * Z) < min_near ? 1u : 0u;
+        }
+    }
+    const bool mark = inside && (seen == 0 || close != 0);
+    if (mark) grid[s] = -1.0f;
+    if (n_marked) {
+        const unsigned long long m = __ballot(mark);
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_marked, (int32_t)__popcll(m));
+    }
+}
+
+static int launch_points(const pnr_occupancy_args* a, const OccGeom& g, const OccWorkspace& w, uint32_t first, uint32_t count, float* pts, hipStream_t s) {
+    if (!a->noise || (g.mode == 1 && (!a->coords || !a->occ_rand))) return PNR_ERR_INVALID;
+    hipLaunchKernelGGL(k_occ_points, dim3(cdiv(count, 256)), dim3(256), 0, s, g, first, count, a->noise, a->coords, a->occ_rand, w.occ_list, w.nnz,
+                       reinterpret_cast<float4*>(pts));
+    return check_launch();
+}
+
+}  // namespace pnr
+
+using namespace pnr;
+
+extern "C" {
+
+uint64_t pnr_occupancy_workspace_bytes(uint32_t C, uint32_t H, uint32_t chunk) {
+    if (C == 0 || C > kOccMaxCascades || H == 0) return 0;
+    return fixed_bytes(C, H) + (uint64_t)((chunk + 255u) & ~255u) * kOccSampleBytes;
+}
+
+uint32_t pnr_occupancy_samples(const pnr_occupancy_args* a) {
+    OccGeom g;
+    return make_geom(a, &g) ? total_samples(g) : 0u;
+}
+
+int pnr_occupancy_begin(const pnr_occupancy_args* a, pnr_stream_t stream) {
+    OccGeom g; OccWorkspace w;
+    if (!make_geom(a, &g)) return PNR_ERR_UNSUPPORTED;
+    if (!a->density_grid || !carve(a, &w)) return PNR_ERR_INVALID;
+    hipStream_t s = as_stream(stream);
+    const uint32_t total = g.C * g.cells;
+    hipLaunchKernelGGL(k_occ_fill, dim3(cdiv(total / 4, 256)), dim3(256), 0, s, reinterpret_cast<float4*>(w.tmp), total / 4);
+    if (g.mode == 1) {
+        const uint32_t nblk = list_blocks(g.cells);
+        hipLaunchKernelGGL(k_occ_count, dim3(nblk, g.C), dim3(256), 0, s, a->density_grid, g.cells, nblk, w.blk);
+        hipLaunchKernelGGL(k_occ_scan, dim3(g.C), dim3(1024), 0, s, w.blk, nblk, w.nnz);
+        hipLaunchKernelGGL(k_occ_write, dim3(nblk, g.C), dim3(256), 0, s, a->density_grid, g.cells, nblk, w.blk, w.occ_list);
+    }
+    return check_launch();
+}
+
+int pnr_occupancy_points(const pnr_occupancy_args* a, uint32_t first, uint32_t count, float* points, pnr_stream_t stream) {
+    OccGeom g; OccWorkspace w;
+    if (!make_geom(a, &g)) return PNR_ERR_UNSUPPORTED;
+    if (!points || !carve(a, &w) || (uint64_t)first + count > total_samples(g)) return PNR_ERR_INVALID;
+    if (count == 0) return PNR_OK;
+    return launch_points(a, g, w, first, count, points, as_stream(stream));
+}
+
+int pnr_occupancy_scatter(const pnr_occupancy_args* a, const float* points, const float* sigmas, uint32_t count, pnr_stream_t stream) {
+    OccGeom g; OccWorkspace w;
+    if (!make_geom(a, &g)) return PNR_ERR_UNSUPPORTED;
+    if (!points || !sigmas || !carve(a, &w)) return PNR_ERR_INVALID;
+    if (count == 0) return PNR_OK;
+    hipLaunchKernelGGL(k_occ_scatter, dim3(cdiv(count, 256)), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4*>(points), sigmas, count,
+                       a->density_scale, w.tmp);
+    return check_launch();
+}
+
+int pnr_occupancy_commit(const pnr_occupancy_args* a, pnr_stream_t stream) {
+    OccGeom g; OccWorkspace w;
+    if (!make_geom(a, &g)) return PNR_ERR_UNSUPPORTED;
+    if (!a->density_grid || !a->density_bitfield || !carve(a, &w)) return PNR_ERR_INVALID;
+    if ((reinterpret_cast<uintptr_t>(a->density_grid) & 15)) return PNR_ERR_UNSUPPORTED;
+    hipStream_t s = as_stream(stream);
+    const uint32_t total = g.C * g.cells, nparts = cdiv(total, kEmaBlock);
+    hipLaunchKernelGGL(k_occ_ema, dim3(nparts), dim3(256), 0, s, a->density_grid, w.tmp, total, a->decay, w.partial);
+    hipLaunchKernelGGL(k_occ_pack, dim3(cdiv(total / 8, 256)), dim3(256), 0, s, a->density_grid, total / 8, w.partial, nparts, 1.0 / (double)total,
+                       a->density_thresh, a->density_bitfield, a->state);
+    int rc = check_launch();
+    if (rc == PNR_OK && a->mip) rc = pnr_build_occupancy_mip(a->density_bitfield, g.C, g.H, a->bound, a->mip, stream);
+    return rc;
+}
+
+int pnr_occupancy_update(const pnr_occupancy_args* a, pnr_stream_t stream) {
+    OccGeom g; OccWorkspace w;
+    if (!make_geom(a, &g)) return PNR_ERR_UNSUPPORTED;
+    if (!a->embeddings || !a->offsets || !a->packed_sigma_net || !carve(a, &w)) return PNR_ERR_INVALID;
+    if (a->num_levels != 16 || a->gridtype > 1) return PNR_ERR_UNSUPPORTED;     // the fused sigma_net kernel is the shipped 16 x 2 -> 64 -> 16 stack
+    const uint32_t total = total_samples(g);
+    if (w.chunk < 256 || (a->points_out == nullptr && w.chunk == 0)) return PNR_ERR_INVALID;
+    int rc = pnr_occupancy_begin(a, stream);
+    if (rc != PNR_OK) return rc;
+    hipStream_t s = as_stream(stream);
+    const LevelParams lp = make_level_params(a->num_levels, a->S, a->base_resolution);
+    for (uint32_t first = 0; first < total; first += w.chunk) {
+        const uint32_t count = total - first < w.chunk ? total - first : w.chunk;
+        float* pts = a->points_out ? a->points_out + (size_t)first * 4 : w.pts;
+        rc = launch_points(a, g, w, first, count, pts, s);
+        if (rc != PNR_OK) return rc;
+        const uint32_t bx = cdiv(count, 256);
+        hipLaunchKernelGGL(k_occ_lookup, dim3(bx, a->num_levels), dim3(256), 0, s, reinterpret_cast<const float4*>(pts), count, a->embeddings, a->offsets, lp,
+                           w.enc, w.chunk, a->bound, 2.0f * a->bound, a->gridtype);
+        const uint32_t grid = bx < 1024u ? bx : 1024u;
+        hipLaunchKernelGGL(k_occ_sigma, dim3(grid), dim3(512), 0, s, reinterpret_cast<const float4*>(pts), count, w.enc, w.chunk, a->packed_sigma_net,
+                           a->density_scale, w.tmp);
+    }
+    rc = check_launch();
+    if (rc != PNR_OK) return rc;
+    return pnr_occupancy_commit(a, stream);
+}
+
+int pnr_mark_untrained_grid(const float* poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t C, uint32_t H, float bound, float min_near,
+                            int filter_close_point, float* density_grid, int32_t* n_marked, pnr_stream_t stream) {
+    pnr_occupancy_args a = {};
+    a.C = C; a.H = H; a.bound = bound;
+    OccGeom g;
+    if (!make_geom(&a, &g)) return PNR_ERR_UNSUPPORTED;
+    if (!poses || !density_grid || B == 0) return PNR_ERR_INVALID;
+    hipStream_t s = as_stream(stream);
+    if (n_marked) (void)hipMemsetAsync(n_marked, 0, sizeof(int32_t), s);
+    hipLaunchKernelGGL(k_mark_untrained, dim3(cdiv(g.C * g.cells, 256)), dim3(256), 0, s, g, poses, B, fx, fy, cx, cy, min_near,
+                       filter_close_point, density_grid, n_marked);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -42,6 +42,15 @@ def occupancy_mip(bitfield, C, H, bound):
     return mip
 
 
+def note_bitfield_written(bitfield, C, H, bound, mip=None):
+    """A raw kernel rewrote `bitfield` (the occupancy sweep): bump its version counter, which retires every mip cached for the old
+    contents, and -- when the writer also rebuilt the mip -- install that one for the new contents."""
+    torch.autograd.graph.increment_version(bitfield)
+    if mip is not None:
+        key = (bitfield._version, bitfield.data_ptr(), str(bitfield.device), int(C), int(H), float(bound), bitfield.numel())
+        setattr(bitfield, _MIP_ATTR, (key, mip))
+
+
 def invalidate_occupancy_mip(bitfield=None):
     """Drop the cached mip of `bitfield` (only needed after writes that bypass torch's version counter).  Without an argument this is a
     no-op kept for callers of the former process-wide cache."""

@@ -12,6 +12,7 @@ Two execution modes for inference frames:
 The pure-PyTorch (`cuda_ray=False`) renderer of the reference is dead code there
  and is not mirrored here.
 """
+import ctypes
 import math
 from types import SimpleNamespace
 
@@ -19,7 +20,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import raymarching
+from . import _lib, raymarching
+from ._torch_glue import call, ptr, require
 from .palette_utils import hsv_to_rgb, palette_train_shade, rgb_to_hsv
 
 
@@ -69,101 +71,165 @@ class _MarchState:
         self.rendered = torch.zeros(1, dtype=torch.int64, device=device)  # march-emitted samples (delta > 0), device-side
 
 
-def _sweep_blocks(G, S, device):
-    """Yield int32 [n,3] cell coordinates of the G^3 grid in S^3 blocks (x-major inside a block)."""
-    axes = torch.arange(G, dtype=torch.int32, device=device).split(S)
-    for xs in axes:
-        for ys in axes:
-            for zs in axes:
-                xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
-                yield torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], dim=-1)
+class _LazyScalar:
+    """A number the device (or an in-flight copy) still owes the host: resolved -- one wait -- the first time somebody asks for it."""
+
+    def __init__(self, fetch):
+        self._fetch, self._value = fetch, None
+
+    def get(self):
+        if self._fetch is not None:
+            self._value, self._fetch = self._fetch(), None
+        return self._value
+
+
+def _lazy_property(name):
+    slot = "_lazy_" + name
+
+    def get(self):
+        v = self.__dict__.get(slot, 0)
+        return v.get() if isinstance(v, _LazyScalar) else v
+
+    def put(self, value):
+        self.__dict__[slot] = value
+
+    return property(get, put)
 
 
 class _OccupancyMaintenance:
-    """Producer of the density bitfield the march consumes: the reference's
-    NeRFRenderer.mark_untrained_grid / update_extra_state (nerf/renderer.py:395-561), on the HIP morton / packbits ops."""
+    """Producer of the density bitfield the march consumes: NeRFRenderer.mark_untrained_grid / update_extra_state
+    (nerf/renderer.py:395-561) as calls into the device-resident sweep of csrc/occupancy.hip.  The reference's methods are host Python
+    over torch ops (a `.item()` for the mean, `nonzero`, boolean-mask scatters); here the host only draws the random numbers (as the
+    reference does, with torch's generator) and enqueues: no step waits for the device.  `mean_density` and `mean_count` stay plain
+    numbers to their readers (the checkpoint writer, march_rays_train) but are fetched only when read."""
+
+    mean_density = _lazy_property("mean_density")
+    mean_count = _lazy_property("mean_count")
+    occupancy_chunk = 1 << 20      # samples in flight per lookup / sigma_net launch pair of the fused sweep (144 B of workspace each)
 
     @torch.no_grad()
     def mark_untrained_grid(self, poses, intrinsic, S=64):
-        """Cells no training camera sees (or that sit closer than min_near) get density -1 and are never sampled."""
+        """Cells no training camera sees (or that a camera sees closer than min_near) get density -1 and are never sampled.  Returns the
+        number of cells marked as a 0-dim device tensor (the reference prints it)."""
         if not self.cuda_ray:
             return
-        poses = torch.as_tensor(poses)
-        B = poses.shape[0]
-        fx, fy, cx, cy = intrinsic
-        G = self.grid_size
         dev = self.density_bitfield.device
-        count = torch.zeros_like(self.density_grid)
-        too_close = torch.zeros_like(self.density_grid)
-        poses = poses.to(dev)
-        for coords in _sweep_blocks(G, S, dev):
-            indices = raymarching.morton3D(coords).long()
-            world_xyzs = (2 * coords.float() / (G - 1) - 1).unsqueeze(0)
-            for cas in range(self.cascade):
-                bound = min(2 ** cas, self.bound)
-                half_grid_size = bound / G
-                cas_world_xyzs = world_xyzs * (bound - half_grid_size)
-                for head in range(0, B, S):
-                    tail = min(head + S, B)
-                    cam_xyzs = (cas_world_xyzs - poses[head:tail, :3, 3].unsqueeze(1)) @ poses[head:tail, :3, :3]
-                    mask_z = cam_xyzs[:, :, 2] > 0
-                    mask_x = torch.abs(cam_xyzs[:, :, 0]) < cx / fx * cam_xyzs[:, :, 2] + half_grid_size * 2
-                    mask_y = torch.abs(cam_xyzs[:, :, 1]) < cy / fy * cam_xyzs[:, :, 2] + half_grid_size * 2
-                    seen = mask_z & mask_x & mask_y
-                    count[cas, indices] += seen.sum(0).reshape(-1)
-                    too_close[cas, indices] += ((cam_xyzs[:, :, 2] < self.min_near) & seen).sum(0).reshape(-1)
-                    if getattr(self, "filter_close_point", False):
-                        too_close[cas, indices] += (cam_xyzs.norm(dim=-1) < self.min_near).sum(0).reshape(-1)
-        count = count * (too_close == 0).long()
-        self.density_grid[count == 0] = -1
-        return int((count == 0).sum())
+        poses = torch.as_tensor(poses).to(device=dev, dtype=torch.float32).contiguous()
+        fx, fy, cx, cy = [float(v) for v in intrinsic]
+        marked = torch.empty((), dtype=torch.int32, device=dev)
+        call("pnr_mark_untrained_grid", ptr(poses), ctypes.c_uint32(poses.shape[0]), ctypes.c_float(fx), ctypes.c_float(fy), ctypes.c_float(cx), ctypes.c_float(cy),
+             ctypes.c_uint32(self.cascade), ctypes.c_uint32(self.grid_size), ctypes.c_float(self.bound), ctypes.c_float(self.min_near),
+             ctypes.c_int(int(bool(getattr(self, "filter_close_point", False)))), ptr(require(self.density_grid, torch.float32, "density_grid")), ptr(marked))
+        return marked
 
-    def _query_cells(self, cas, coords):
-        """sigma * density_scale at a jittered point inside every given cell of cascade `cas`."""
-        G = self.grid_size
-        xyzs = 2 * coords.float() / (G - 1) - 1
-        bound = min(2 ** cas, self.bound)
-        half_grid_size = bound / G
-        cas_xyzs = xyzs * (bound - half_grid_size)
-        cas_xyzs += (torch.rand_like(cas_xyzs) * 2 - 1) * half_grid_size
-        sigmas = self.density(cas_xyzs)["sigma"].reshape(-1).detach().float()
-        return sigmas * self.density_scale
+    def _fused_sweep_ok(self):
+        """The shipped field (16 x 2 hash grid, fp32 table, sigma_net 32 -> 64 -> 16) evaluated by its own density(): the whole sweep is one
+        C-ABI call.  Anything else -- another architecture, a density() replaced on the instance -- goes through its density() between the
+        point and scatter kernels."""
+        enc, net = getattr(self, "encoder", None), getattr(self, "sigma_net", None)
+        if "density" in self.__dict__ or enc is None or net is None or getattr(self, "occupancy_generic", False):
+            return False
+        emb = getattr(enc, "embeddings", None)
+        return (emb is not None and emb.is_cuda and emb.dtype == torch.float32 and getattr(enc, "num_levels", 0) == 16 and getattr(enc, "level_dim", 0) == 2
+                and getattr(enc, "input_dim", 0) == 3 and not getattr(enc, "align_corners", False) and len(net) == 2
+                and tuple(net[0].weight.shape) == (64, 32) and tuple(net[1].weight.shape) == (16, 64) and net[0].weight.dtype == torch.float32)
+
+    def _occupancy_workspace(self, chunk):
+        need = int(_lib.load().pnr_occupancy_workspace_bytes(self.cascade, self.grid_size, int(chunk)))
+        ws = self.__dict__.get("_occ_ws")
+        if ws is None or ws.numel() < need or ws.device != self.density_grid.device:
+            ws = self.__dict__["_occ_ws"] = torch.empty(need, dtype=torch.uint8, device=self.density_grid.device)
+        return ws
+
+    def _sigma_blob(self):
+        """sigma_net as the exact-fp32 blob of the matrix-core kernels (the sigma_net part of the NeRF field blob; no colour weights are
+        passed, so only that part is written).  Packed anew for every sweep -- one tiny launch -- so it cannot go stale whichever way the
+        weights were written (optimiser kernels, `.data` swaps of an EMA)."""
+        w0, w1 = self.sigma_net[0].weight, self.sigma_net[1].weight
+        blob = self.__dict__.get("_occ_blob")
+        if blob is None or blob.device != w0.device:
+            blob = self.__dict__["_occ_blob"] = torch.empty(int(_lib.load().pnr_nerf_field_packed_bytes()) // 4, dtype=torch.float32, device=w0.device)
+        a, b = require(w0.detach().contiguous(), torch.float32, "sigma_net.0"), require(w1.detach().contiguous(), torch.float32, "sigma_net.1")
+        call("pnr_nerf_field_pack", ptr(a), ptr(b), None, None, None, ptr(blob), ctypes.c_int(0))
+        return blob
 
     @torch.no_grad()
-    def update_extra_state(self, decay=0.95, S=128):
-        """EMA-max update of density_grid from the field, repack the bitfield, refresh mean_count (nerf/renderer.py:467-561)."""
+    def update_extra_state(self, decay=0.95, S=128, noise=None, coords=None, occ_rand=None):
+        """EMA-max update of density_grid from the field, repack the bitfield (+ its mip), refresh mean_density / mean_count
+        (nerf/renderer.py:467-561).  noise / coords / occ_rand: the sweep's random numbers when the caller wants to supply them
+        (include/pnr.h, pnr_occupancy_args); drawn here with torch's generator otherwise, as the reference draws them."""
         if not self.cuda_ray:
             return
-        G = self.grid_size
-        dev = self.density_bitfield.device
-        tmp_grid = -torch.ones_like(self.density_grid)
-        if self.iter_density < 16:  # full sweeps while the field is young
-            for coords in _sweep_blocks(G, S, dev):
-                indices = raymarching.morton3D(coords).long()
-                for cas in range(self.cascade):
-                    tmp_grid[cas, indices] = self._query_cells(cas, coords)
-        else:  # afterwards: G^3/4 uniform cells + G^3/4 currently occupied cells per cascade
-            n = G ** 3 // 4
-            for cas in range(self.cascade):
-                coords = torch.randint(0, G, (n, 3), device=dev)
-                indices = raymarching.morton3D(coords).long()
-                occ_indices = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
-                if occ_indices.numel() > 0:
-                    occ_indices = occ_indices[torch.randint(0, occ_indices.shape[0], [n], dtype=torch.long, device=dev)]
-                    occ_coords = raymarching.morton3D_invert(occ_indices)
-                    indices = torch.cat([indices, occ_indices], dim=0)
-                    coords = torch.cat([coords, occ_coords], dim=0)
-                tmp_grid[cas, indices] = self._query_cells(cas, coords)
-        valid_mask = (self.density_grid >= 0) & (tmp_grid >= 0)
-        self.density_grid[valid_mask] = torch.maximum(self.density_grid[valid_mask] * decay, tmp_grid[valid_mask])
-        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
-        self.iter_density += 1
-        density_thresh = min(self.mean_density, self.density_thresh)
-        self.density_bitfield = raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
+        G, C = self.grid_size, self.cascade
+        dev = self.density_grid.device
+        # mean_count first: its source, the last <= 16 step counters, is complete once the training steps already enqueued have run -- the
+        # copy is queued in FRONT of the sweep, so whoever reads mean_count next waits for those steps only, not for the sweep
         total_step = min(16, self.local_step)
         if total_step > 0:
-            self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+            host = torch.empty(total_step, dtype=torch.int32).pin_memory()
+            host.copy_(self.step_counter[:total_step, 0], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+
+            def fetch(host=host, done=done, total_step=total_step):
+                done.synchronize()
+                return int(int(host.sum()) / total_step)
+            self.mean_count = _LazyScalar(fetch)
         self.local_step = 0
+
+        a = _lib.OccupancyArgs()
+        a.C, a.H, a.bound = C, G, float(self.bound)
+        grid = require(self.density_grid, torch.float32, "density_grid")
+        bits = require(self.density_bitfield, torch.uint8, "density_bitfield")
+        a.density_grid, a.density_bitfield = grid.data_ptr(), bits.data_ptr()
+        a.density_scale, a.decay, a.density_thresh = float(self.density_scale), float(decay), float(self.density_thresh)
+        if self.iter_density < 16:      # every cell while the field is young
+            a.mode, a.n_partial = 0, 0
+            if noise is None:
+                noise = torch.rand(C, G ** 3, 3, device=dev)
+        else:                           # afterwards G^3/4 uniform cells + G^3/4 currently occupied ones per cascade
+            n = G ** 3 // 4
+            a.mode, a.n_partial = 1, n
+            if coords is None:
+                coords = torch.randint(0, G, (C, n, 3), device=dev, dtype=torch.int32)
+            if occ_rand is None:
+                occ_rand = torch.randint(0, 2 ** 31 - 1, (C, n), device=dev, dtype=torch.int32)
+            if noise is None:
+                noise = torch.rand(C, 2 * n, 3, device=dev)
+            coords, occ_rand = require(coords, torch.int32, "coords"), require(occ_rand, torch.int32, "occ_rand")
+            a.coords, a.occ_rand = coords.data_ptr(), occ_rand.data_ptr()
+        a.noise = require(noise, torch.float32, "noise").data_ptr()
+        state = torch.empty(2, dtype=torch.float32, device=dev)
+        a.state = state.data_ptr()
+        mip_bytes = int(_lib.load().pnr_occupancy_mip_bytes(C, G))
+        mip = torch.empty(mip_bytes // 4, dtype=torch.int32, device=dev) if raymarching.USE_MIP and G % 4 == 0 and mip_bytes <= 64 * 1024 and bits.data_ptr() % 8 == 0 else None
+        a.mip = mip.data_ptr() if mip is not None else None
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        lib = _lib.load()
+        if self._fused_sweep_ok():
+            enc = self.encoder
+            ws = self._occupancy_workspace(self.occupancy_chunk)
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+            a.embeddings, a.offsets = enc.embeddings.detach().data_ptr(), enc.offsets.data_ptr()
+            a.num_levels, a.S, a.base_resolution, a.gridtype = enc.num_levels, float(math.log2(enc.per_level_scale)), enc.base_resolution, enc.gridtype_id
+            a.packed_sigma_net = self._sigma_blob().data_ptr()
+            _lib.check(lib.pnr_occupancy_update(ctypes.byref(a), stream), "pnr_occupancy_update")
+        else:
+            ws = self._occupancy_workspace(0)
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+            _lib.check(lib.pnr_occupancy_begin(ctypes.byref(a), stream), "pnr_occupancy_begin")
+            total = int(lib.pnr_occupancy_samples(ctypes.byref(a)))
+            step = max(int(S), 1) ** 3
+            for first in range(0, total, step):
+                count = min(step, total - first)
+                pts = torch.empty(count, 4, dtype=torch.float32, device=dev)
+                _lib.check(lib.pnr_occupancy_points(ctypes.byref(a), first, count, ctypes.c_void_p(pts.data_ptr()), stream), "pnr_occupancy_points")
+                sig = self.density(pts[:, :3].contiguous())["sigma"].reshape(-1).detach().float().contiguous()
+                _lib.check(lib.pnr_occupancy_scatter(ctypes.byref(a), ctypes.c_void_p(pts.data_ptr()), ctypes.c_void_p(sig.data_ptr()), count, stream), "pnr_occupancy_scatter")
+            _lib.check(lib.pnr_occupancy_commit(ctypes.byref(a), stream), "pnr_occupancy_commit")
+        raymarching.note_bitfield_written(bits, C, G, self.bound, mip)
+        self.mean_density = _LazyScalar(lambda state=state: float(state[0]))
+        self.iter_density += 1
 
 
 class _RendererBase(nn.Module):

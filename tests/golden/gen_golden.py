@@ -348,8 +348,110 @@ def gen_hist():
     print("hist", {k: v.shape for k, v in out.items()})
 
 
+# ------------------------------------------------------------------------------------------ occupancy maintenance
+def gen_occupancy(G=32):
+    """occupancy.npz: the reference's own NeRFRenderer.update_extra_state and mark_untrained_grid (nerf/renderer.py:395-561, imported
+    unmodified; oracle injected as the kernel layer) run on the CPU with a G^3 grid (the attribute the reference hard-codes to 128 is set
+    to G before its buffers are rebuilt -- every expression of the two methods is in terms of self.grid_size).  The random numbers the
+    methods draw are recorded (torch.rand_like is made to return multiples of 1/256 so that they store as bytes) together with the points
+    they query, the sigmas the field returns and the grids / bitfields they leave."""
+    ref_nerf, _, _ = import_reference()
+    torch.set_num_threads(1)      # `tmp_grid[cas, indices] = sigmas` with repeated indices: sequential on one thread, the last write wins
+    m = ref_nerf.NeRFNetwork(bound=2, cuda_ray=True, density_scale=0.5, min_near=0.2, density_thresh=1e9)
+    scene.seed_field_(m, 31)
+    m.grid_size = G
+    m.density_grid = torch.zeros(m.cascade, G ** 3)
+    m.density_bitfield = torch.zeros(m.cascade * G ** 3 // 8, dtype=torch.uint8)
+    m.train()
+    log = {"rand": [], "randint": [], "points": [], "sigma": []}
+    real_rand_like, real_randint, real_density = torch.rand_like, torch.randint, m.density
+    gen = torch.Generator().manual_seed(99)
+
+    def rand_like(t, **kw):
+        r = real_randint(0, 256, t.shape, generator=gen).to(torch.uint8)
+        log["rand"].append(r.numpy().copy())
+        return r.to(t.dtype) / 256
+
+    def randint(lo, hi, size, **kw):
+        r = real_randint(lo, hi, size, generator=gen, dtype=kw.get("dtype", torch.int64))
+        log["randint"].append(r.numpy().copy())
+        return r
+
+    def density(x):
+        log["points"].append(x.detach().numpy().copy())
+        out = real_density(x)
+        log["sigma"].append(out["sigma"].detach().numpy().reshape(-1).copy())
+        return out
+
+    torch.rand_like, torch.randint, m.density = rand_like, randint, density
+    try:
+        out = {"G": G, "seed": 31, "bound": 2.0, "density_scale": 0.5}
+        # ---- full sweep from an empty grid; threshold = the mean
+        m.local_step = 3
+        m.step_counter[:3, 0] = torch.tensor([100, 200, 330], dtype=torch.int32)
+        m.update_extra_state()
+        C = m.cascade
+        idx = oracle.morton3D(np.stack(np.meshgrid(*[np.arange(G, dtype=np.int32)] * 3, indexing="ij"), -1).reshape(-1, 3)).astype(np.int64)
+        noise = np.zeros((C, G ** 3, 3), np.uint8)
+        pts = np.zeros((C, G ** 3, 3), np.float32)
+        sig = np.zeros((C, G ** 3), np.float32)
+        for c in range(C):       # the reference visits the cells in meshgrid order; rows are stored by Morton index
+            noise[c, idx], pts[c, idx], sig[c, idx] = log["rand"][c], log["points"][c], log["sigma"][c]
+        # where the reference's CPU arithmetic (torch divides by G - 1) and the canonical GPU form (multiplies by the fp32 reciprocal) give the very
+        # same point: only there can sigmas be compared tightly -- one ulp of a coordinate moves sigma by up to ~1e-4 through the finest levels
+        oxyz = oracle.occupancy_points(C, G, 2.0, noise.astype(np.float32) / 256)[0].reshape(C, G ** 3, 3)
+        out["full_points_same"] = np.packbits((oxyz == pts).all(-1))
+        out.update(full_noise_u8=noise, full_points_every16=pts[:, ::16].copy(), full_sigma=sig, full_grid=m.density_grid.numpy().copy(),
+                   full_bitfield=m.density_bitfield.numpy().copy(), full_mean=np.float32(m.mean_density), full_mean_count=m.mean_count)
+        print("occupancy full: mean", m.mean_density, "occupied bits", int(np.unpackbits(m.density_bitfield.numpy()).sum()), "mean_count", m.mean_count)
+        # ---- partial sweep on top of it (iter_density >= 16); threshold = density_thresh
+        for k in log:
+            log[k].clear()
+        m.iter_density = 16
+        m.density_thresh = 0.48
+        m.density_grid[0, :64] = -1.0           # a few cells mark_untrained_grid would have retired: never updated, never drawn as occupied
+        before = m.density_grid.numpy().copy()
+        m.update_extra_state(decay=0.9)
+        n = G ** 3 // 4
+        coords = np.stack([log["randint"][2 * c] for c in range(C)]).astype(np.uint8)            # [C, n, 3]
+        rand_mask = np.stack([log["randint"][2 * c + 1] for c in range(C)]).astype(np.int32)       # [C, n]: already < the number of occupied cells
+        oxyz = oracle.occupancy_points(C, G, 2.0, np.stack(log["rand"]).astype(np.float32) / 256, coords=coords.astype(np.int32), occ_rand=rand_mask,
+                                       density_grid=before, n_partial=n)[0].reshape(C, 2 * n, 3)
+        out["part_points_same"] = np.packbits((oxyz == np.stack(log["points"])).all(-1))
+        out.update(part_before=before, part_coords_u8=coords, part_occ_rand=rand_mask, part_noise_u8=np.stack(log["rand"]), part_sigma=np.stack(log["sigma"]),
+                   part_points_every16=np.stack(log["points"])[:, ::16].copy(), part_grid=m.density_grid.numpy().copy(),
+                   part_bitfield=m.density_bitfield.numpy().copy(), part_mean=np.float32(m.mean_density), part_decay=0.9, part_density_thresh=0.48)
+        assert coords.shape == (C, n, 3) and rand_mask.shape == (C, n)
+        print("occupancy partial: mean", m.mean_density, "occupied bits", int(np.unpackbits(m.density_bitfield.numpy()).sum()))
+    finally:
+        torch.rand_like, torch.randint = real_rand_like, real_randint
+    # ---- mark_untrained_grid: six cameras on a ring looking at the origin + one sitting inside the grid (too-close cells)
+    m2 = ref_nerf.NeRFNetwork(bound=2, cuda_ray=True, min_near=0.2)
+    m2.grid_size = G
+    m2.density_grid = torch.zeros(m2.cascade, G ** 3)
+    m2.density_bitfield = torch.zeros(m2.cascade * G ** 3 // 8, dtype=torch.uint8)
+    poses = np.stack([scene.lookat_pose(elevation_deg=20.0 + 5 * k, azimuth_deg=60.0 * k, radius=3.2) for k in range(6)]
+                     + [scene.lookat_pose(elevation_deg=10.0, azimuth_deg=200.0, radius=0.9)]).astype(np.float32)
+    intr = (55.0, 60.0, 32.0, 24.0)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()) as buf:
+        m2.mark_untrained_grid(poses, intr)
+    print(buf.getvalue().strip())
+    marks = {"mark_poses": poses, "mark_intrinsics": np.array(intr, np.float32), "mark_grid": (m2.density_grid.numpy() < 0)}
+    m2.density_grid.zero_()
+    m2.filter_close_point = True
+    with contextlib.redirect_stdout(io.StringIO()):
+        m2.mark_untrained_grid(poses, intr)
+    marks["mark_grid_filter_close"] = (m2.density_grid.numpy() < 0)
+    out.update({k: (np.packbits(v) if v.dtype == bool else v) for k, v in marks.items()})
+    np.savez_compressed(os.path.join(HERE, "occupancy.npz"), **out)
+    print("occupancy.npz", os.path.getsize(os.path.join(HERE, "occupancy.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["sh", "frames"]
+    if "occupancy" in which:
+        gen_occupancy()
     if "hist" in which:
         gen_hist()
     if "palette_extra" in which:

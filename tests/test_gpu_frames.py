@@ -455,33 +455,6 @@ def test_uniform_sampling_path_on_the_hip_ops(cuda, golden_dir, case, fused):
     close(r["depth"], g["depth"], what="depth")
 
 
-def test_update_extra_state_with_the_fused_density_kernel(cuda):
-    """the occupancy sweep through pnr_nerf_density_forward (fused_field=True) against the same sweep through the torch sigma_net:
-    same jitter (seeded), density grid within 2e-5 relative, bitfield identical up to cells that sit within that tolerance of the threshold."""
-    grids, bits = [], []
-    for fused in (False, True):
-        m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=1.0, min_near=0.2)
-        scene.seed_field_(m, 21)
-        m = m.to(cuda).train()
-        m.fused_field = fused
-        torch.manual_seed(77)
-        m.update_extra_state()          # full sweep (iter_density < 16): every cell once, so the result is a function of the seed
-        grids.append(m.density_grid.clone())
-        bits.append(m.density_bitfield.clone())
-        mean = m.mean_density
-        m.iter_density = 16
-        m.update_extra_state()          # partial update: random cells with repeats (which jitter wins is scheduling-dependent): runs, stays sane
-        assert torch.isfinite(m.density_grid).all() and float((m.density_grid >= grids[-1] * 0.95 - 1e-6).float().mean()) == 1.0
-    a, b = grids
-    assert float((a > 0).float().mean()) > 0.5
-    rel = ((a - b).abs() / a.abs().clamp(min=1e-12)).max()
-    assert float(rel) < 2e-5, float(rel)
-    diff_bits = int((bits[0] ^ bits[1]).to(torch.int32).ne(0).sum())
-    thresh = min(mean, 0.01)
-    near = int(((a - thresh).abs() <= 2e-5 * a.abs()).sum())
-    assert diff_bits <= near
-
-
 @pytest.mark.parametrize("model_kind", ["nerf", "palette"])
 def test_native_loop_under_fp16_autocast_uses_half_tables(cuda, model_kind):
     """The reference's -O mode (fp16 autocast): the native loop then looks the tables up as fp16 with the reference's half interpolation and keeps

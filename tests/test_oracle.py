@@ -603,3 +603,74 @@ def test_rgb_histogram_against_the_reference_build(golden_dir):
             bw, bc = oracle.compute_RGB_histogram(rgb2, w2, bpc)
             np.testing.assert_array_equal(bw, np.asarray(rbw))
             np.testing.assert_array_equal(bc, np.asarray(rbc))
+
+
+# ------------------------------------------------------------------------------------------ occupancy maintenance
+def _occupancy_fixture():
+    g = np.load(os.path.join(GOLDEN, "occupancy.npz"))
+    return g, int(g["G"]), 2
+
+
+def test_occupancy_full_sweep_against_the_reference_method():
+    """tests/golden/occupancy.npz holds what the reference's own NeRFRenderer.update_extra_state (nerf/renderer.py:467-561, imported
+    unmodified, CPU) drew, queried and left behind.  The oracle, fed the same random numbers, must produce the same points; fed the
+    reference's sigmas, the same density grid, mean and bitfield."""
+    g, G, C = _occupancy_fixture()
+    noise = g["full_noise_u8"].astype(np.float32) / 256
+    xyz, cells, p4 = oracle.occupancy_points(C, G, float(g["bound"]), noise)
+    assert np.array_equal(cells, np.arange(C * G ** 3, dtype=np.int32))
+    got, ref = xyz.reshape(C, G ** 3, 3)[:, ::16], g["full_points_every16"]
+    # the reference ran on the CPU, where torch divides by (G - 1); on a GPU -- the canonical form, restated by the oracle -- torch multiplies
+    # by the fp32 reciprocal: at most one ulp apart
+    assert np.abs(got - ref).max() <= 2.4e-7 * float(g["bound"])
+    grid = np.zeros((C, G ** 3), np.float32)
+    cand = (g["full_sigma"] * np.float32(g["density_scale"])).reshape(-1)
+    bits, mean, thresh = oracle.occupancy_commit(grid, p4, cand, 0.95, 1e9)
+    assert np.array_equal(grid, g["full_grid"])
+    assert abs(mean - float(g["full_mean"])) <= 1e-6 * mean and thresh == mean      # torch's fp32 tree sum vs the exact (fp64) mean
+    near = np.abs(grid - mean) <= 1e-6 * mean
+    diff = np.unpackbits(bits ^ g["full_bitfield"], bitorder="little").reshape(C, -1).astype(bool)
+    assert not (diff & ~near).any() and diff.sum() <= near.sum()
+
+
+def test_occupancy_partial_sweep_against_the_reference_method():
+    """The partial sweep (iter_density >= 16): uniform cells + cells drawn from the occupied list, with repeats.  The reference keeps the
+    LAST candidate of a repeated cell on one CPU thread (an unspecified one on a GPU); the oracle keeps the largest.  So: every cell of the
+    reference's grid is one of the oracle's candidates for it, and where a cell was drawn once the two agree exactly."""
+    g, G, C = _occupancy_fixture()
+    n = G ** 3 // 4
+    before = g["part_before"].copy()
+    xyz, cells, p4 = oracle.occupancy_points(C, G, float(g["bound"]), g["part_noise_u8"].astype(np.float32) / 256, coords=g["part_coords_u8"].astype(np.int32),
+                                             occ_rand=g["part_occ_rand"], density_grid=before, n_partial=n)
+    assert np.abs(xyz.reshape(C, 2 * n, 3)[:, ::16] - g["part_points_every16"]).max() <= 2.4e-7 * float(g["bound"])
+    assert (cells >= 0).all() and not np.isin(cells.reshape(C, 2 * n)[:, n:], np.arange(64)).any()      # the 64 retired cells (density -1) are never drawn from the occupied list ...
+    grid = before.copy()
+    cand = (g["part_sigma"] * np.float32(g["density_scale"])).reshape(-1)
+    decay, dth = float(g["part_decay"]), float(g["part_density_thresh"])
+    bits, mean, thresh = oracle.occupancy_commit(grid, p4, cand, decay, dth)
+    assert thresh == np.float32(dth) and mean > dth
+    ref = g["part_grid"]
+    assert np.array_equal(grid[0, :64], before[0, :64]) and (grid[0, :64] == -1).all()     # ... and never updated
+    counts = np.bincount(cells, minlength=C * G ** 3).reshape(C, -1)
+    once = counts <= 1
+    assert np.array_equal(grid[once], ref[once])
+    assert (grid >= ref).all()
+    order = np.argsort(cells, kind="stable")
+    sc, sv = cells[order], np.maximum(before.reshape(-1)[cells[order]] * np.float32(decay), cand[order])
+    flat_ref = ref.reshape(-1)
+    hit = np.zeros(C * G ** 3, bool)
+    np.logical_or.at(hit, sc, sv == flat_ref[sc])
+    drawn = np.unique(cells)
+    drawn = drawn[before.reshape(-1)[drawn] >= 0]      # (retired cells may be drawn by the uniform half; they keep their -1)
+    assert hit[drawn].all()          # the reference's value of every drawn cell is one of its candidates
+    assert np.array_equal(np.unpackbits(bits, bitorder="little").reshape(C, -1).astype(bool), grid > thresh)
+
+
+@pytest.mark.parametrize("key,filt", [("mark_grid", False), ("mark_grid_filter_close", True)])
+def test_mark_untrained_grid_against_the_reference_method(key, filt):
+    g, G, C = _occupancy_fixture()
+    grid = np.zeros((C, G ** 3), np.float32)
+    n = oracle.mark_untrained_grid(g["mark_poses"], g["mark_intrinsics"], grid, float(g["bound"]), 0.2, filt)
+    ref = np.unpackbits(g[key])[:C * G ** 3].reshape(C, -1).astype(bool)
+    assert n == int(ref.sum()) and np.array_equal(grid < 0, ref)
+    assert 0 < n < C * G ** 3
