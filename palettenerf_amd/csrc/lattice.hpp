@@ -73,6 +73,35 @@ PNR_HD void lattice_advance(float tc, float d, float tt, float& q, float& prev) 
     }
 }
 
+// Exactly:   for (i = 0; i < k; i++) tc += d;      (d > 0 constant) -- the k-th lattice point after tc, same binade-wise integer
+// arithmetic as lattice_advance(): the wave-cooperative march tail hands lane k of a wave the k-th point of one ray's lattice.
+PNR_HD float lattice_steps(float tc, float d, uint32_t k) {
+    const uint32_t db = lat_bits(d);
+    const int ed = (int)((db >> 23) & 0xffu);
+    const uint32_t md = (db & 0x7fffffu) | 0x800000u;
+    const bool d_ok = d > 0.0f && ed > 0 && ed < 255;
+    while (k > 0) {
+        const uint32_t tb = lat_bits(tc);
+        const int e = (int)((tb >> 23) & 0xffu);
+        const int s = e - ed;
+        bool fast = d_ok && (tb >> 31) == 0 && e > 0 && e < 254 && s >= 1 && s <= 23;
+        uint32_t D = 0;
+        if (fast) {
+            const uint32_t half = 1u << (s - 1), rem = md & ((1u << s) - 1u);
+            if (rem == half) fast = false;
+            else D = (md + half) >> s;
+        }
+        if (!fast) { tc += d; k--; continue; }
+        const uint32_t Tc = (tb & 0x7fffffu) | 0x800000u;
+        const uint32_t room = ((1u << 24) - 1u - Tc) / D;                         // steps that stay inside the binade
+        if (k <= room) return lat_float(((uint32_t)e << 23) | ((Tc + k * D) & 0x7fffffu));
+        tc = lat_float(((uint32_t)e << 23) | ((Tc + room * D) & 0x7fffffu));       // the binade's last lattice point ...
+        tc += d;                                                                  // ... and one real addition across the boundary
+        k -= room + 1u;
+    }
+    return tc;
+}
+
 // The general lattice walk (any dt_gamma): the reference loop itself, without probing.
 PNR_HD void lattice_walk(float tc, float dt_gamma, float dt_min, float dt_max, float tt, float& q, float& prev) {
     do {

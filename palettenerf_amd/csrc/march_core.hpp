@@ -54,6 +54,7 @@ struct MarchParams {  // ray-independent constants, computed once on the host
     uint32_t C, H, max_steps;
     uint32_t mip_words;  // uint32 words per mask; 0 = no mip
     uint32_t block_skip; // empty-block jumps allowed (PNR_NO_BLOCK_SKIP=1 in the environment turns them off for A/B measurements)
+    uint32_t coop;       // frame loop: the last rays of a wave are marched by the whole wave (march_coop_tail); same outputs
 };
 
 static MarchParams make_march_params(float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, bool with_mip) {
@@ -65,6 +66,7 @@ static MarchParams make_march_params(float bound, float dt_gamma, uint32_t max_s
     p.C = C; p.H = H; p.max_steps = max_steps;
     p.mip_words = with_mip ? (uint32_t)(((uint64_t)C * H * H * H / 64 + 31) / 32) : 0;
     p.block_skip = g_opt_block_skip ? 1u : 0u;
+    p.coop = g_opt_coop_march ? 1u : 0u;
     return p;
 }
 static inline bool is_pow2f(float v) {
@@ -148,7 +150,7 @@ __device__ __forceinline__ float skip_to_box(const RayCtx& c, const BoxHit& h, f
         const float eps = fmaf(c.bound * 2.3841858e-7f, ard, (fabsf(b) + 1.0f) * 9.5367432e-7f);  // 2^-22 bound |rd| + 2^-20 (|b| + 1)
         if (!(b - t > 2.0f * eps)) return t;
         float q, prev;
-        if (const_min) lattice_advance(t, c.dt_min, b, q, prev);
+        if (const_min) lattice_advance(t, fminf(c.dt_min, c.dt_max), b, q, prev);   // clamp(x <= dt_min) = min(dt_max, dt_min): max_steps so small that dt_min > dt_max steps by dt_max
         else if (const_max) lattice_advance(t, c.dt_max, b, q, prev);
         else lattice_walk(t, c.dt_gamma, c.dt_min, c.dt_max, b, q, prev);
         if (q - b > 2.0f * eps && b - prev > 2.0f * eps) return q;
@@ -271,7 +273,7 @@ __device__ __forceinline__ bool march_probe(const RayCtx& c, float& t, float& x,
             if (ok) {
                 // Exit plane first; when a lattice point sits in its window, the cell planes just inside R serve equally (R minus
                 // its last cell layers is still an aligned box of empty cells): the ray then needs one or two ordinary steps more.
-                const float d = const_min ? c.dt_min : c.dt_max;
+                const float d = const_min ? fminf(c.dt_min, c.dt_max) : c.dt_max;   // the value clamp() takes below dt_min (raymarching.cu:37-39: min(hi, max(lo, x)))
                 const float back = (rdc > 0.0f ? -2.0f : 2.0f) * mip_bound * c.rH;   // one cell, against the direction of travel
 #pragma unroll 1
                 for (int k = 0; k < 3; k++) {

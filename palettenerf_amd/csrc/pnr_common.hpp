@@ -86,6 +86,7 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
 // Run-time switches for A/B measurements and tests (pnr_set_option; initialised from PNR_NO_BLOCK_SKIP / PNR_NO_AUX_FUSION).
 // Neither changes any result.
 extern int g_opt_block_skip;   // exact jumps over empty 4^3 / 8^3 / 16^3 blocks in the march
+extern int g_opt_coop_march;   // frame loops: wave-cooperative march tail (frame.hip: march_coop_tail)
 extern int g_opt_aux_fusion;   // PaletteNeRF frame loop: aux composite inside the field kernel
 extern int g_opt_composite_fusion;   // NeRF frame loop: n_step == 1 iterations composited inside the field kernel
 extern int g_opt_dynamic_tiles;      // frame loops: field kernels hand wave tiles out through a device counter instead of a static schedule

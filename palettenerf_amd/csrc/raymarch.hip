@@ -484,6 +484,7 @@ __global__ void __launch_bounds__(kBlock) k_get_rays(const float* __restrict__ p
 // C ABI
 // ==========================================================================================
 int g_opt_block_skip = getenv("PNR_NO_BLOCK_SKIP") ? 0 : 1;
+int g_opt_coop_march = getenv("PNR_NO_COOP_MARCH") ? 0 : 1;
 int g_opt_aux_fusion = getenv("PNR_NO_AUX_FUSION") ? 0 : 1;
 int g_opt_composite_fusion = getenv("PNR_NO_COMPOSITE_FUSION") ? 0 : 1;
 int g_opt_iteration_margin = getenv("PNR_ITERATION_MARGIN") ? atoi(getenv("PNR_ITERATION_MARGIN")) : 0;   // measured 0 / 1 / 2 / 4 on the moving-camera bench: 4.239 / 4.247 / 4.277 / 4.265 ms -- a look costs less than a spare iteration
@@ -500,6 +501,7 @@ int pnr_abi_version(void) { return 3; }
 int pnr_set_option(const char* name, int value) {
     if (!name) return PNR_ERR_INVALID;
     if (!strcmp(name, "block_skip")) { g_opt_block_skip = value != 0; return PNR_OK; }
+    if (!strcmp(name, "coop_march")) { g_opt_coop_march = value != 0; return PNR_OK; }
     if (!strcmp(name, "aux_fusion")) { g_opt_aux_fusion = value != 0; return PNR_OK; }
     if (!strcmp(name, "composite_fusion")) { g_opt_composite_fusion = value != 0; return PNR_OK; }
     if (!strcmp(name, "palette_waves12")) { g_opt_palette_waves12 = value != 0; return PNR_OK; }

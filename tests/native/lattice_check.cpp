@@ -49,3 +49,31 @@ extern "C" int lattice_fuzz(uint64_t seed, int n, int mode, float* bad /* [3] fi
     }
     return mismatches;
 }
+
+// lattice_steps() against the literal loop: k plain additions.  Returns the number of mismatching cases.
+extern "C" int lattice_steps_fuzz(uint64_t seed, int n, int mode, float* bad /* [3] first failing (tc, d, k) */) {
+    rng_state = seed * 0x9E3779B97F4A7C15ull + 7;
+    int mismatches = 0;
+    for (int i = 0; i < n; i++) {
+        float d;
+        if (mode == 0) d = expf(uniform(logf(1e-4f), logf(0.1f)));
+        else if (mode == 1) {
+            const float two_sqrt3 = 2.0f * 1.7320508075688772f;
+            const int k = (int)(rng() % 9u);
+            d = k < 5 ? two_sqrt3 / (float)(256 << k) : two_sqrt3 * (float)(1 << (k - 5)) / 128.0f;
+        } else {
+            const uint32_t m = 0x800000u | ((rng() & 0x7u) << 20);
+            d = ldexpf((float)m, -24 - (int)(rng() % 10u) - 3);
+        }
+        const float tc = expf(uniform(logf(0.01f), logf(40.0f)));
+        const uint32_t k = rng() % ((rng() & 3u) ? 65u : 3000u);
+        float t = tc;
+        for (uint32_t j = 0; j < k; j++) t += d;
+        const float got = pnr::lattice_steps(tc, d, k);
+        if (pnr::lat_bits(got) != pnr::lat_bits(t)) {
+            if (mismatches == 0 && bad) { bad[0] = tc; bad[1] = d; bad[2] = (float)k; }
+            mismatches++;
+        }
+    }
+    return mismatches;
+}

@@ -243,6 +243,39 @@ def test_native_loop_edge_cases_match_reference_style_loop(cuda, model_kind):
     assert b["iterations"] > 40
 
 
+@pytest.mark.parametrize("dt_gamma,density_scale,max_steps", [(0.0, 1.0, 1024), (1.0 / 128, 0.02, 1024), (0.0, 0.05, 1024), (0.0, 1.0, 16), (1.0 / 32, 0.3, 256)])
+@pytest.mark.parametrize("scene_kind", ["bricks", "sparse"])
+def test_coop_march_tail_is_bit_identical(cuda, dt_gamma, density_scale, max_steps, scene_kind):
+    """The wave-cooperative march tail (frame.hip: march_coop_tail -- the last <= 4 rays of a wave marched by all 64 lanes, one lattice
+    point per lane) against the same frame with it switched off: every output bit, the sample count and the iteration count.  Opaque and
+    translucent fields (n_step from 1 to 8), constant and growing steps, the degenerate dt_min > dt_max budget, dense and sparse scenes."""
+    from palettenerf_amd import _lib
+    lib = _lib.load()
+    m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=density_scale, min_near=0.2)
+    scene.seed_field_(m, 3)
+    m = m.to(cuda).eval()
+    grid = scene.brick_density_grid() if scene_kind == "bricks" else scene.sparse_density_grid()
+    m.density_grid.copy_(torch.from_numpy(grid).to(cuda))
+    raymarching.packbits(m.density_grid, 0.5, m.density_bitfield)
+    m.march_mode, m.fused_field, m.count_rendered = "native", True, True
+    pose = torch.from_numpy(scene.lookat_pose(azimuth_deg=70.0))[None]
+    ro, rd = scene.get_rays(pose, scene.intrinsics_from_fov(160, 200), 160, 200)
+    ro, rd = ro.to(cuda), rd.to(cuda)
+    out = []
+    try:
+        for coop in (1, 0):
+            assert lib.pnr_set_option(b"coop_march", coop) == 0
+            with torch.no_grad():
+                r = m.render(ro, rd, perturb=False, dt_gamma=dt_gamma, max_steps=max_steps, T_thresh=1e-4)
+            out.append({k: r[k].clone() for k in ("image", "depth", "weights_sum", "rendered")})
+    finally:
+        lib.pnr_set_option(b"coop_march", 1)
+    a, b = out
+    assert int(a["rendered"]) == int(b["rendered"]) > 1000
+    for k in ("image", "depth", "weights_sum"):
+        assert torch.equal(torch.nan_to_num(a[k], nan=-7.0), torch.nan_to_num(b[k], nan=-7.0)), k
+
+
 @pytest.mark.parametrize("model_kind", ["nerf", "palette"])
 def test_native_loop_ray_order_leaves_every_output_bit_identical(cuda, model_kind):
     """pnr_*_frame_args::ray_order (tile order, a random permutation) changes the processing order only: image, depth, weights_sum,

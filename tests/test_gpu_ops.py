@@ -976,21 +976,24 @@ def test_march_other_grid_sizes_bit_exact(cuda, bound, H):
         np.testing.assert_array_equal(host(dl), odl)
 
 
+@pytest.mark.parametrize("max_steps", [1024, 16])
 @pytest.mark.parametrize("dt_gamma", [0.0, 1.0 / 128])
-def test_march_sparse_scene_block_jumps_bit_exact(cuda, dt_gamma):
+def test_march_sparse_scene_block_jumps_bit_exact(cuda, dt_gamma, max_steps):
     """Scene S1 (scattered 4^3 bricks, the occupied box ~94 % air): nearly every probe of a ray is an empty-block jump
-    (csrc/march_core.hpp); counts, offsets, positions and deltas must still equal the oracle's cell-by-cell walk bit for bit."""
+    (csrc/march_core.hpp); counts, offsets, positions and deltas must still equal the oracle's cell-by-cell walk bit for bit.
+    max_steps = 16 makes dt_min (2 sqrt3 / 16) LARGER than dt_max: clamp(x, dt_min, dt_max) = min(dt_max, max(dt_min, x)) then steps by dt_max,
+    which is what the jumps' closed form has to use (round 3: it used dt_min there; the frame loops agreed with each other, not with this)."""
     grid = scene.sparse_density_grid()
     bf = scene.packbits_np(grid, 0.5)
     ro, rd = rays_of(96, 80)
     aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
     on, of = oracle.near_far_from_aabb(ro, rd, aabb, 0.2)
     cnt = np.zeros(2, np.int32)
-    ox, od, odl, orays = oracle.march_rays_train(ro, rd, 2.0, bf, 2, 128, on, of, cnt, align=128, force_all_rays=True, dt_gamma=dt_gamma)
+    ox, od, odl, orays = oracle.march_rays_train(ro, rd, 2.0, bf, 2, 128, on, of, cnt, align=128, force_all_rays=True, dt_gamma=dt_gamma, max_steps=max_steps)
     counter = torch.zeros(2, dtype=torch.int32, device=cuda)
     x, d, dl, rays = raymarching.march_rays_train(dev(ro, cuda), dev(rd, cuda), 2.0, dev(bf, cuda), 2, 128, dev(on, cuda), dev(of, cuda), counter,
-                                                  -1, False, 128, True, dt_gamma, 1024)
-    assert int(cnt[0]) > 10000
+                                                  -1, False, 128, True, dt_gamma, max_steps)
+    assert int(cnt[0]) > (10000 if max_steps == 1024 else 1000)
     np.testing.assert_array_equal(host(counter), cnt)
     np.testing.assert_array_equal(host(rays), orays)
     np.testing.assert_array_equal(host(x), ox)

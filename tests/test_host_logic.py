@@ -159,7 +159,19 @@ def _lattice_lib(tmp_path_factory):
     lib = ctypes.CDLL(str(out))
     lib.lattice_fuzz.argtypes = [ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.lattice_case.argtypes = [ctypes.c_float] * 3 + [ctypes.c_void_p] * 4
+    lib.lattice_steps_fuzz.argtypes = [ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     return lib
+
+
+def test_lattice_steps_equals_k_plain_additions(tmp_path_factory):
+    """lattice_steps(t, d, k) -- the k-th lattice point after t, which the wave-cooperative march tail hands to lane k -- must be bit for bit
+    what k additions `t += d` give (raymarching.cu:389, :399-401)."""
+    lib = _lattice_lib(tmp_path_factory)
+    bad = np.zeros(3, np.float32)
+    for mode in (0, 1, 2):
+        for seed in (1, 2, 3):
+            n = lib.lattice_steps_fuzz(seed * 104729 + mode, 200000, mode, bad.ctypes.data)
+            assert n == 0, f"mode {mode} seed {seed}: {n} mismatches, first at (tc, d, k) = {bad}"
 
 
 def test_lattice_advance_equals_the_stepping_loop(tmp_path_factory):
