@@ -152,7 +152,10 @@ __device__ int g_march_timing_iter = 3;
 // sample rows to the lanes that hold them, and stops at n_step samples, at `far`, or at the end of the window, where the next batch
 // continues.  Probes at points the reference never visits are discarded.  13 dependent probes become one or two batches.
 // ------------------------------------------------------------------------------------------
-constexpr int kCoopRays = 4;
+#ifndef PNR_COOP_RAYS
+#define PNR_COOP_RAYS 2       // measured 1 / 2 / 4: lego 4.07 / 4.07 / 4.13 ms -- with 4 rays a group is 16 lattice points (3.5 cells): one batch then buys what 3 probes buy
+#endif
+constexpr int kCoopRays = PNR_COOP_RAYS;   // 1, 2 or 4
 struct CoopShared {                 // per wave
     float f[kCoopRays][12];         // ox oy oz dx dy dz t far last_t
     int32_t i[kCoopRays][4];        // first row of the ray's slots (n * n_step), samples so far, still marching, (unused)
@@ -188,7 +191,7 @@ __device__ __forceinline__ uint32_t march_coop_tail(CoopShared& sh, const MarchP
         mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)mask);
         if (mask == 0) break;
         const int ns = __popc(mask);
-        const int glog = (!const_step || ns > 2) ? 2 : (ns == 2 ? 1 : 0);   // 4 / 2 / 1 groups; a growing step is walked point by point: short windows
+        const int glog = ns > 2 ? 2 : ((ns == 2 || !const_step) ? 1 : 0);   // 4 / 2 / 1 groups; a growing step is walked point by point: windows of at most 32
         const int wlog = 6 - glog, W = 1 << wlog;
         const int g = lane >> wlog, k = lane & (W - 1);
         int slot = -1;
@@ -272,7 +275,8 @@ __device__ __forceinline__ uint32_t march_coop_tail(CoopShared& sh, const MarchP
 }
 
 #ifndef PNR_MARCH_WAVES
-#define PNR_MARCH_WAVES 6     // waves per SIMD the march kernel is compiled for (register budget 512 / PNR_MARCH_WAVES)
+#define PNR_MARCH_WAVES 4     // waves per SIMD the march kernel is compiled for (register budget 512 / PNR_MARCH_WAVES): with the cooperative tail it needs 114 VGPRs;
+                              // squeezed into 80 (6 waves, all chunks of a later iteration resident at once) it spills and the lego frame is 0.3 ms slower (4.38 vs 4.07 ms)
 #endif
 template <bool MIP, bool POW2>
 __global__ void __launch_bounds__(kRayBlock) __attribute__((amdgpu_waves_per_eu(PNR_MARCH_WAVES))) k_frame_march(const FrameCtl* __restrict__ prev, FrameCtl* __restrict__ cur, const int32_t* __restrict__ alive_prev,
@@ -471,7 +475,8 @@ __global__ void __launch_bounds__(kRayBlock) __attribute__((amdgpu_waves_per_eu(
         if (timing) {   // wave maxima of the probe count and of the dependent global brick loads
             uint32_t mp = my_probes, ml = c.n_loads;
             for (int off = 32; off > 0; off >>= 1) { mp = max(mp, (uint32_t)__shfl_xor((int)mp, off, 64)); ml = max(ml, (uint32_t)__shfl_xor((int)ml, off, 64)); }
-            if ((threadIdx.x & 63) == 0) { g_march_timing[(size_t)twave * 8 + 6] = mp; g_march_timing[(size_t)twave * 8 + 7] = ml; }
+            const uint32_t crowd = (uint32_t)__popcll(__ballot(my_probes >= 5u));   // lanes of this wave with a long walk: a crowd marches at full SIMT efficiency, a loner leaves 63 lanes idle
+            if ((threadIdx.x & 63) == 0) { g_march_timing[(size_t)twave * 8 + 6] = mp; g_march_timing[(size_t)twave * 8 + 7] = ml | ((unsigned long long)crowd << 16); }
         }
 #endif
     }

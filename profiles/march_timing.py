@@ -52,9 +52,12 @@ with torch.no_grad():
         live = t[:, 0] > 0
         wave_ids = np.nonzero(live)[0]
         t = t[live]
+        crowd = t[:, 7] >> 16          # lanes of the wave with >= 5 probes (SIMT probes only: the cooperative tail is not counted)
+        t[:, 7] &= 0xffff
         t0 = t[:, 0].min()
         marched = t[:, 5] > 0
         full = t[marched]
+        crowd = crowd[marched]
         full_ids = wave_ids[marched]
         tick = 10.0   # ns per wall_clock64 tick (100 MHz)
         print(f"iteration {it}: {live.sum()} waves stamped, {len(full)} marched; launch span {(t[:, :6].max() - t0) * tick / 1e3:.1f} us")
@@ -68,7 +71,9 @@ with torch.no_grad():
         order = np.argsort(full[:, 5])[::-1][:12]
         print("  slowest-ending waves (us since launch: start, counts, mip, compaction, ctx, end):")
         for w in order:
-            print("   ", " ".join(f"{(full[w, k] - t0) * tick / 1e3:6.2f}" for k in range(6)))
+            print("   ", " ".join(f"{(full[w, k] - t0) * tick / 1e3:6.2f}" for k in range(6)), f"  max probes {full[w, 6]:3d}  lanes with >= 5 probes {crowd[w]:2d}")
+        slow = np.argsort(full[:, 5])[::-1][:200]
+        print(f"  the 200 last waves: lanes with >= 5 probes: median {np.median(crowd[slow]):.0f}, <= 2 in {(crowd[slow] <= 2).sum()}, <= 8 in {(crowd[slow] <= 8).sum()}, >= 32 in {(crowd[slow] >= 32).sum()}; max probes median {np.median(full[slow, 6]):.0f}")
         late = full[(full[:, 0] - t0) * tick / 1e3 > 1.0]
         print(f"  waves starting later than 1 us: {len(late)}; their probe phase: median {np.median((late[:, 5] - late[:, 4])) * tick / 1e3 if len(late) else 0:.2f} us")
         hist, edges = np.histogram((full[:, 5] - t0) * tick / 1e3, bins=12)
