@@ -435,7 +435,7 @@ def main(argv=None):
                             first.update(grid_ms=r.get("grid_ms", 0.0), grid_launches=r.get("grid_launches", 0), rendered=int(r["rendered"].sum()))
                 return None
 
-            fif.render(lambda i: bank.get(offset + i), n, consume=consume, before=before if native else None, **kw)
+            fif.render(lambda i: bank.get(offset + i), n, consume=consume, before=before if native else None, abort=og.abort if og is not None else None, **kw)
             for h in last.values():      # the last gather of every thread completes inside the (timed) region
                 og.finish(h)
 

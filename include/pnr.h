@@ -493,6 +493,14 @@ typedef struct pnr_adam_scalars { float one_minus_beta1, beta2, one_minus_beta2,
 uint32_t pnr_adam_max_tensors(void);
 int pnr_adam_step(const pnr_adam_tensor* tensors, uint32_t count, const pnr_adam_scalars* scalars, pnr_stream_t stream);
 
+/* ---------------------------------------------------------------- cache guard -------------- */
+
+/* 64-bit checksums of `count` (<= 24) device buffers in one launch: buffers / nbytes / word_stride are HOST arrays (device pointers, sizes in
+ * bytes -- multiples of 4 --, and the stride in 4-byte words at which a buffer is sampled: 1 or 0 = every word); out = device uint64[count].
+ * Order-independent sums of position-dependent word hashes: deterministic.  Used by the frame loops to notice that the parameters a packed
+ * blob was derived from were rewritten behind torch's version counters (`p.data` writes: torch_ema's copy_to / restore, nerf/utils.py:829-839). */
+int pnr_checksum(const void* const* buffers, const uint64_t* nbytes, const uint32_t* word_stride, uint32_t count, uint64_t* out, pnr_stream_t stream);
+
 /* ---------------------------------------------------------------- ray generation ----------- */
 
 /* device counterpart of the deterministic core of get_rays (nerf/utils.py:53-149; torch ops on the GPU in the reference):

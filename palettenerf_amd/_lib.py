@@ -80,6 +80,7 @@ SIGNATURES = {
     "pnr_adam_max_tensors": [],
     "pnr_adam_step": [_ptr, _u32, _ptr, _ptr],
     "pnr_get_rays": [_ptr, _u32, _f32, _f32, _f32, _f32, _u32, _u32, _ptr, _u32, _ptr, _ptr, _ptr],
+    "pnr_checksum": [_ptr, _ptr, _ptr, _u32, _ptr, _ptr],
     "pnr_occupancy_workspace_bytes": [_u32, _u32, _u32],
     "pnr_occupancy_samples": [_ptr],
     "pnr_occupancy_update": [_ptr, _ptr],

@@ -1075,7 +1075,14 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
 
     // per host thread AND per device (a process may drive several GPUs): the pinned read-back slot, the timing events and the iteration
     // prediction of the previous frame rendered there
-    struct PerDevice { FrameCtl* host_ctl = nullptr; std::vector<hipEvent_t> ev; uint32_t predicted_iterations = 0; };
+    // (released when the host thread ends: a pool that replaces its worker threads does not accumulate pinned blocks and events)
+    struct PerDevice {
+        FrameCtl* host_ctl = nullptr; std::vector<hipEvent_t> ev; uint32_t predicted_iterations = 0;
+        ~PerDevice() {
+            if (host_ctl) (void)hipHostFree(host_ctl);
+            for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        }
+    };
     static thread_local PerDevice per_device[kMaxDevices];
     PerDevice& dev_state = per_device[current_device()];
     FrameCtl*& host_ctl = dev_state.host_ctl;  // one in-flight frame per host thread and device

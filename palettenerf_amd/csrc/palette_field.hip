@@ -25,6 +25,7 @@
 #include "hsv_core.hpp"
 #include <string.h>
 #include <stdlib.h>
+#include <mutex>
 
 namespace pnr {
 
@@ -495,10 +496,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
 using namespace pnr;
 
 namespace {
-// device copy of the edit parameters: a small ring of slots per device, so that launches in flight keep their own
+// device copy of the edit parameters of the STAND-ALONE op (the frame loops upload theirs into the frame workspace): a ring of slots per
+// device, so that launches in flight keep their own.  Several host threads may call the op: the slot cursor and the lazy allocation sit behind
+// a mutex, the host source of the copy is this call's own stack (pageable: staged by the runtime before hipMemcpyAsync returns), and a slot
+// is handed out again only behind the event recorded after the launch that read it last (it may have been on another stream).
 constexpr int kEditSlots = 64;
-struct EditRing { EditParams* dev = nullptr; EditParams* host = nullptr; int next = 0; };
+struct EditRing { EditParams* dev = nullptr; hipEvent_t used[kEditSlots] = {}; int next = 0; };
 EditRing g_edit_ring[kMaxDevices];
+std::mutex g_edit_ring_mutex;
 
 bool shape_ok(uint32_t nb, uint32_t clip_dim) { return nb >= 1 && nb <= PNR_MAX_BASIS && clip_dim <= PNR_MAX_CLIP; }
 
@@ -615,20 +620,23 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
     const bool fuse = a->ctl && a->rays_alive && a->weights_sum && a->aux_map;
     hipStream_t s = as_stream(stream);
     const EditParams* ep_dev = nullptr;
+    int edit_slot = -1;
     if (edit_mode && a->edit_device) ep_dev = static_cast<const EditParams*>(a->edit_device);   // frame loop: uploaded once per frame
-    else if (edit_mode) {   // this call's parameters go into the next slot of the device's ring (pinned staging copy, async copy on the launch stream)
+    else if (edit_mode) {   // this call's parameters go into the next slot of the device's ring (async copy on the launch stream)
         EditRing& ring = g_edit_ring[current_device()];
-        if (!ring.dev) {
-            if (hipMalloc(reinterpret_cast<void**>(&ring.dev), sizeof(EditParams) * kEditSlots) != hipSuccess) return PNR_ERR_LAUNCH;
-            if (hipHostMalloc(reinterpret_cast<void**>(&ring.host), sizeof(EditParams) * kEditSlots, hipHostMallocPortable) != hipSuccess) return PNR_ERR_LAUNCH;
+        {
+            std::lock_guard<std::mutex> lock(g_edit_ring_mutex);
+            if (!ring.dev && hipMalloc(reinterpret_cast<void**>(&ring.dev), sizeof(EditParams) * kEditSlots) != hipSuccess) return PNR_ERR_LAUNCH;
+            edit_slot = ring.next;
+            ring.next = (ring.next + 1) % kEditSlots;
+            if (!ring.used[edit_slot]) {
+                if (hipEventCreateWithFlags(&ring.used[edit_slot], hipEventDisableTiming) != hipSuccess) return PNR_ERR_LAUNCH;
+            } else if (hipStreamWaitEvent(s, ring.used[edit_slot], 0) != hipSuccess) return PNR_ERR_LAUNCH;   // the launch that read this slot 64 calls ago
         }
-        const int slot = ring.next;
-        ring.next = (ring.next + 1) % kEditSlots;
-        EditParams& e = ring.host[slot];
-        const pnr_palette_edit& src = *a->edit;
-        fill_edit(e, src);
-        if (hipMemcpyAsync(ring.dev + slot, &e, sizeof(EditParams), hipMemcpyHostToDevice, s) != hipSuccess) return PNR_ERR_LAUNCH;
-        ep_dev = ring.dev + slot;
+        EditParams e;
+        fill_edit(e, *a->edit);
+        if (hipMemcpyAsync(ring.dev + edit_slot, &e, sizeof(EditParams), hipMemcpyHostToDevice, s) != hipSuccess) return PNR_ERR_LAUNCH;
+        ep_dev = ring.dev + edit_slot;
     }
     static bool attr_set[4][3][kMaxDevices] = {};   // [PREC + 2 * CHECK][EDIT]
 #define PNR_LAUNCH_PAL(PREC, EDIT, CHECK) PNR_LAUNCH_PAL_NB(PREC, EDIT, CHECK, 0, 8, attr_set[PREC + (CHECK ? 2 : 0)][EDIT])
@@ -660,6 +668,7 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
     }
 #undef PNR_LAUNCH_PAL
 #undef PNR_LAUNCH_PAL_NB
+    if (edit_slot >= 0 && hipEventRecord(g_edit_ring[current_device()].used[edit_slot], s) != hipSuccess) return PNR_ERR_LAUNCH;
     return check_launch();
 }
 

@@ -57,22 +57,46 @@ class FrameGatherer:
         self.send = [torch.zeros(self.n_max, K, dtype=torch.float32, device=device) for _ in range(self.slots)]
         self.recv = [torch.empty(self.world * self.n_max, K, dtype=torch.float32, device=device) for _ in range(self.slots)]
         self._turn = 0
+        # Re-use of a buffer pair is safe by construction, whoever calls from whichever thread and stream: a slot is `busy` from start() to
+        # finish() (start() refuses a busy slot; OrderedGather.submit waits for it), and the packing of the next frame into it is ordered
+        # behind the last reader of its receive rows (an event recorded after finish()'s index_select) and behind the previous collective.
+        self._busy = [False] * self.slots
+        self._read = [None] * self.slots
+        self._work = [None] * self.slots
+
+    def next_slot_free(self):
+        return not self._busy[self._turn]
 
     def start(self, parts):
         """Pack this rank's rows and launch the all-gather WITHOUT making the compute stream wait for it: the collective runs on the
-        communicator's stream while the next frame is rendered.  Returns a handle for finish().  At most `slots` gathers outstanding."""
+        communicator's stream while the next frame is rendered.  Returns a handle for finish().  At most `slots` gathers outstanding:
+        starting one more before the oldest has been finish()ed is an error (its rows would be overwritten unread)."""
         n = self.idx.numel()
         slot = self._turn
+        if self._busy[slot]:
+            raise RuntimeError(f"FrameGatherer.start: all {self.slots} buffer pairs hold a gather that has not been finish()ed")
         self._turn = (self._turn + 1) % self.slots
+        self._busy[slot] = True
+        if self._work[slot] is not None:
+            self._work[slot].wait()          # (already complete: its finish() ran) orders this stream behind the collective that read send[slot]
+        if self._read[slot] is not None:
+            torch.cuda.current_stream(self.send[slot].device).wait_event(self._read[slot])   # the index_select that read recv[slot], maybe on another stream
         torch.cat(parts, dim=1, out=self.send[slot][:n])
         work = dist.all_gather_into_tensor(self.recv[slot], self.send[slot], group=self.group, async_op=True)
+        self._work[slot] = work
         return work, slot
 
     def finish(self, handle):
         """Wait for a started all-gather and return the [H*W, K] frame (every rank gets the full frame)."""
         work, slot = handle
         work.wait()
-        return self.recv[slot].index_select(0, self.gather_index)
+        out = self.recv[slot].index_select(0, self.gather_index)
+        if out.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(out.device))
+            self._read[slot] = ev
+        self._busy[slot] = False
+        return out
 
     def __call__(self, parts):
         """parts: tensors [n_local, k_i] (sum k_i == K), rows ordered like self.idx.  Returns the [H*W, K] frame on every rank."""
@@ -90,18 +114,33 @@ class OrderedGather:
         self.gatherer = gatherer
         self._next = int(first_frame)
         self._cv = threading.Condition()
+        self._aborted = None
 
     def submit(self, i, parts):
         with self._cv:
-            while self._next != i:
-                self._cv.wait()
+            # frame i's turn, and a free buffer pair: with F render threads and F + 1 pairs the pair of frame i is the one frame i - F - 1 used,
+            # whose finish() its thread calls right after submitting frame i - 1 -- so this wait is short and cannot deadlock
+            while self._aborted is None and (self._next != i or not self.gatherer.next_slot_free()):
+                self._cv.wait(timeout=1.0)
+            if self._aborted is not None:
+                raise RuntimeError("OrderedGather: aborted because another frame's worker failed") from self._aborted
             handle = self.gatherer.start(parts)
             self._next += 1
             self._cv.notify_all()
         return handle
 
     def finish(self, handle):
-        return self.gatherer.finish(handle)
+        out = self.gatherer.finish(handle)
+        with self._cv:
+            self._cv.notify_all()        # a buffer pair became free
+        return out
+
+    def abort(self, error=None):
+        """A worker failed: frames it would have submitted never come, so every thread waiting for its turn must give up (the peers of a
+        multi-rank job then fail in the collective's timeout instead of hanging in a join)."""
+        with self._cv:
+            self._aborted = error if error is not None else RuntimeError("aborted")
+            self._cv.notify_all()
 
 
 def gather_frame(local, idx, n_max, H, W, group=None):

@@ -58,6 +58,10 @@ def invalidate_fused_caches(model):
         f = getattr(model, attr, None)
         if f is not None:
             f.invalidate_caches()
+    for ref in list(model.__dict__.get("_fused_twins", [])):      # handles made by pipeline.clone_for_concurrent_frames: same weights, own blobs
+        twin = ref()
+        if twin is not None and twin is not model:
+            invalidate_fused_caches(twin)
 
 
 def _half_copy(owner, attr, t):
@@ -153,6 +157,58 @@ class _PrecisionGuard:
                       "fp32 path, which these weights keep from now on")
 
 
+TABLE_CHECK_STRIDE = 1 if PARANOID else 61     # hash tables are checksummed on every 61st word per frame (0.8 MB of a 50 MB table); weights in full
+
+
+class _SourceWatch:
+    """Blobs derived from parameters go stale SILENTLY when the parameters are rewritten through `.data` (torch_ema's copy_to / restore around
+    an evaluation, nerf/utils.py:829-839, 959-961): neither identity nor version moves, so the keys above cannot tell.  The frame loops
+    therefore checksum the sources on the device once per frame (pnr_checksum: one small launch, 8 bytes per source back with the frame's own
+    read-back) and compare with the checksums taken when the blobs were built; on a mismatch the blobs are rebuilt and the frame is rendered
+    again.  When torch CAN tell (a key changed) every blob of the object is rebuilt in that frame and its checksums become the reference, so a
+    `.data` write can never hide behind an unrelated version bump.  Tables are sampled (TABLE_CHECK_STRIDE): a swap or a re-initialisation
+    touches every row; PNR_PARANOID_CACHE=1 checks every word."""
+
+    def _watched(self):
+        """[(tensor, stride in 4-byte words)]: everything a cached blob of this object is derived from."""
+        raise NotImplementedError
+
+    def _watch_begin(self):
+        srcs = self._watched()
+        keys = tuple(_pkey(t) for t, _ in srcs)
+        had = getattr(self, "_watch_keys", None)
+        record = had != keys or getattr(self, "_watch_ref", None) is None
+        if had is not None and had != keys:
+            self.invalidate_caches()
+        self._watch_keys = keys
+        n, dev = len(srcs), srcs[0][0].device
+        if getattr(self, "_watch_dev", None) is None or self._watch_dev.device != dev or self._watch_dev.numel() < n:
+            self._watch_dev = torch.zeros(max(n, 24), dtype=torch.int64, device=dev)
+            self._watch_host = torch.zeros(max(n, 24), dtype=torch.int64).pin_memory()
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _ in srcs])
+        sizes = (ctypes.c_uint64 * n)(*[t.numel() * t.element_size() for t, _ in srcs])
+        strides = (_u32 * n)(*[int(st) for _, st in srcs])
+        call("pnr_checksum", ptrs, sizes, strides, _u32(n), ptr(self._watch_dev))
+        self._watch_host.copy_(self._watch_dev, non_blocking=True)     # complete once the frame's own read-back is (same stream)
+        return record, n
+
+    def _watch_end(self, state):
+        """True: the frame just rendered used blobs that match their sources."""
+        record, n = state
+        now = tuple(self._watch_host[:n].tolist())
+        if record:
+            self._watch_ref = now
+            return True
+        return now == self._watch_ref
+
+    def _watch_failed(self):
+        import warnings
+        warnings.warn("fused field: parameters were rewritten behind torch's version counters (a `.data` write); the packed blobs were rebuilt and "
+                      "the frame rendered again -- invalidate_fused_caches(model) after such writes avoids the double render")
+        self.invalidate_caches()
+        self._watch_ref = None
+
+
 def _set_finish(a, bg_color, N, mask):
     """Fill the finish / bg fields of a frame-args struct; returns True when the call will apply the epilogue."""
     a.finish, a.bg_map = 0, None
@@ -178,7 +234,7 @@ def _set_finish(a, bg_color, N, mask):
     return True
 
 
-class NeRFFieldFused(_PrecisionGuard):
+class NeRFFieldFused(_PrecisionGuard, _SourceWatch):
     """Caches the MFMA-ordered weight blob of a NeRFNetwork and evaluates (sigma, rgb) for sample batches."""
 
     def __init__(self, model):
@@ -206,6 +262,9 @@ class NeRFFieldFused(_PrecisionGuard):
 
     def _guard_tables(self):
         return [self.model.encoder.embeddings]
+
+    def _watched(self):
+        return [(w, 1) for w in self._weights()] + [(self.model.encoder.embeddings, TABLE_CHECK_STRIDE)]
 
     def _guard_bound(self, tmax, scales):
         ws = self._weights()
@@ -241,6 +300,7 @@ class NeRFFieldFused(_PrecisionGuard):
         N = rays_o.shape[0]
         dev = rays_o.device
         lib = _lib.load()
+        watch_state = self._watch_begin()
         ws = torch.empty(N, dtype=torch.float32, device=dev)
         depth = torch.empty(N, dtype=torch.float32, device=dev)
         image = torch.empty(N, 3, dtype=torch.float32, device=dev)
@@ -282,6 +342,9 @@ class NeRFFieldFused(_PrecisionGuard):
             require(t, torch.float32, name)
         rc = lib.pnr_nerf_render_frame(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         _lib.check(rc, "pnr_nerf_render_frame")
+        if not self._watch_end(watch_state):
+            self._watch_failed()
+            return self.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color=bg_color)
         if watch and stats[5]:
             self._note_overflow()
             return self.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color=bg_color)
@@ -344,7 +407,7 @@ def density_fused(model):
     return d
 
 
-class PaletteFieldFused(_PrecisionGuard):
+class PaletteFieldFused(_PrecisionGuard, _SourceWatch):
     """Fused PaletteNeRF field + colour-basis composite (pnr_palette_field_forward).  Produces, per sample,
     sigma * density_scale, rgb and one packed aux row [direct 3 | view_dep 3 | omega nb | basis_rgb 3nb | unscaled 3nb | clip | pad]."""
 
@@ -384,6 +447,9 @@ class PaletteFieldFused(_PrecisionGuard):
     def invalidate_caches(self):
         self.versions = None
         self._pair_key = self._triple_key = self._guard_key = None
+
+    def _watched(self):
+        return [(w, 1) for w in self._weights() + self._tables()] + [(t, TABLE_CHECK_STRIDE) for t in self._guard_tables()]
 
     def _guard_tables(self):
         m = self.model
@@ -519,6 +585,7 @@ class PaletteFieldFused(_PrecisionGuard):
         N = rays_o.shape[0]
         dev = rays_o.device
         lib = _lib.load()
+        watch_state = self._watch_begin()
         ws = torch.empty(N, dtype=torch.float32, device=dev)
         depth = torch.empty(N, dtype=torch.float32, device=dev)
         image = torch.empty(N, 3, dtype=torch.float32, device=dev)
@@ -579,6 +646,9 @@ class PaletteFieldFused(_PrecisionGuard):
             require(t, torch.float32, name)
         rc = lib.pnr_palette_render_frame(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         _lib.check(rc, "pnr_palette_render_frame")
+        if not self._watch_end(watch_state):
+            self._watch_failed()
+            return self.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh)
         if watch and stats[5]:
             self._note_overflow()
             return self.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh)

@@ -31,23 +31,26 @@ class Adam(torch.optim.Optimizer):
         # ONE launch for every tensor that shares its hyperparameters and step count (the reference's get_params makes ten param groups with the
         # same lr / betas / eps: torch runs them group by group); tensors that joined later have their own bias corrections and go separately
         batches = {}
-        for group in self.param_groups:
-            beta1, beta2 = group["betas"]
+        todo = []
+        for group in self.param_groups:      # first pass: every check, nothing touched -- a rejected tensor must not leave earlier ones a step ahead
             for p in group["params"]:
                 if p.grad is None:
                     continue
                 if p.grad.is_sparse or p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_cuda:
                     raise RuntimeError("palettenerf_amd.optim.Adam: dense fp32 CUDA(HIP) parameters only (no CPU fallback)")
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = torch.tensor(0.0)   # host tensor, as torch keeps it for non-capturable Adam
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
                 if not (p.is_contiguous() and p.grad.is_contiguous()):
                     raise RuntimeError("palettenerf_amd.optim.Adam: parameters and gradients must be contiguous")
-                key = (float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), int(st["step"].item()), p.device.index)
-                batches.setdefault(key, []).append((p, st))
+                todo.append((group, p))
+        for group, p in todo:
+            beta1, beta2 = group["betas"]
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0)   # host tensor, as torch keeps it for non-capturable Adam
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["step"] += 1
+            key = (float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), int(st["step"].item()), p.device.index)
+            batches.setdefault(key, []).append((p, st))
         for (lr, beta1, beta2, eps, step, _dev), items in batches.items():
             # the host scalars exactly as torch/optim/adam.py forms them (Python floats), narrowed where its CUDA kernels narrow them
             bias_correction1 = 1 - beta1 ** step

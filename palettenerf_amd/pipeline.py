@@ -20,20 +20,68 @@ _FUSED_SETTINGS = ("precision", "table_half", "interleave_tables", "ray_order", 
 
 def clone_for_concurrent_frames(model):
     """A second handle on `model`'s weights for another host thread: parameters, buffers and sub-modules are shared (nothing is
-    copied), the fused-field object -- workspace, packed-weight blob, interleaved tables -- is its own."""
+    copied), the fused-field object -- workspace, packed-weight blob, interleaved tables -- is its own.  Plain attributes (edit,
+    stylizer, offsets_weight, density_scale, ...) are snapshots of the moment: FramesInFlight.render re-syncs them from the model
+    before every run (sync_twin), and the model keeps a weak list of its twins so that invalidate_fused_caches reaches their blobs."""
+    import weakref
     fused = getattr(model, "_fused", None)
     if fused is None:
         raise RuntimeError("clone_for_concurrent_frames: the model has no fused field (fused_field = True and one frame rendered, or _fused set)")
     twin = copy.copy(model)                 # shallow: the same Parameter / buffer tensors
+    twin.__dict__.pop("_fused_twins", None)
     twin._fused = type(fused)(twin)
     for name in _FUSED_SETTINGS:
         if hasattr(fused, name):
             setattr(twin._fused, name, getattr(fused, name))
+    model.__dict__.setdefault("_fused_twins", []).append(weakref.ref(twin))
     return twin
 
 
+def sync_twin(model, twin):
+    """Bring a twin's plain attributes up to date with the model's (everything but its own fused-field object and its private caches):
+    `model.edit = RegionEdit(...)`, a changed offsets_weight or density_scale after the clone would otherwise be shadowed by the snapshot."""
+    keep = {k: twin.__dict__[k] for k in ("_fused", "_density_fused", "_occ_ws", "_occ_blob") if k in twin.__dict__}
+    for k, v in model.__dict__.items():
+        if k not in ("_fused", "_density_fused", "_occ_ws", "_occ_blob", "_fused_twins"):
+            twin.__dict__[k] = v
+    for k in list(twin.__dict__):
+        if k not in model.__dict__ and k not in keep:
+            del twin.__dict__[k]
+    twin.__dict__.update(keep)
+    src = getattr(model, "_fused", None)
+    if src is not None:
+        for name in _FUSED_SETTINGS:
+            if hasattr(src, name):
+                setattr(twin._fused, name, getattr(src, name))
+
+
+class _Worker(threading.Thread):
+    """One render thread of a FramesInFlight pool, alive until close(): the frame calls keep a pinned control block, their timing events and
+    the previous frame's iteration count per HOST THREAD (csrc/frame.hip), so a thread that survives from one render() to the next starts its
+    frames with a warm prediction and allocates nothing (round 2 made new threads per call: a hipHostMalloc and cold predictions every time)."""
+
+    def __init__(self, name):
+        super().__init__(name=name, daemon=True)
+        import queue
+        self.jobs = queue.SimpleQueue()
+        self.done = queue.SimpleQueue()
+        self.start()
+
+    def run(self):
+        while True:
+            job = self.jobs.get()
+            if job is None:
+                return
+            try:
+                job()
+                self.done.put(None)
+            except BaseException as e:   # noqa: BLE001 -- handed to the caller
+                self.done.put(e)
+
+
 class FramesInFlight:
-    """`n` frames in flight: frame i of a sequence goes to handle i % n, each handle renders on its own host thread and stream."""
+    """`n` frames in flight: frame i of a sequence goes to handle i % n, each handle renders on its own host thread and stream.  The
+    threads live as long as the object (close() or garbage collection ends them)."""
 
     def __init__(self, model, n, device=None):
         if n < 1:
@@ -43,14 +91,33 @@ class FramesInFlight:
             raise RuntimeError("FramesInFlight needs the HIP path (a CUDA/HIP device); there is no CPU fallback")
         self.models = [model] + [clone_for_concurrent_frames(model) for _ in range(n - 1)]
         self.streams = [torch.cuda.Stream(self.device) for _ in range(n)]
+        self.workers = [_Worker(f"pnr-frame-{k}") for k in range(n)]
 
-    def render(self, rays_of, n_frames, consume=None, before=None, **kwargs):
+    def close(self):
+        for w in self.workers:
+            if w.is_alive():
+                w.jobs.put(None)
+        for w in self.workers:
+            w.join(timeout=5.0)
+        self.workers = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    def render(self, rays_of, n_frames, consume=None, before=None, abort=None, **kwargs):
         """Render frames 0 .. n_frames-1; `rays_of(i)` -> (rays_o, rays_d) resident on the device; `consume(i, results)` is called on
         the rendering thread (inside its stream context) as soon as frame i is complete (default: keep the results); `before(i, model)`
         right in front of the frame.  Returns the list of results (or of consume's return values) in frame order.  Exceptions of a
-        worker are re-raised here."""
+        worker are re-raised here; `abort(error)` is called first, on the failing thread -- pass dist.OrderedGather.abort when consume()
+        takes turns through one, or the other threads wait for a frame that will never be submitted."""
+        if not self.workers:
+            raise RuntimeError("FramesInFlight: closed")
         out = [None] * n_frames
-        errors = []
+        for twin in self.models[1:]:
+            sync_twin(self.models[0], twin)
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(self.device))   # the inputs may have been produced on the caller's stream
 
@@ -65,14 +132,14 @@ class FramesInFlight:
                         r = self.models[k].render(ro, rd, **kwargs)
                         out[i] = consume(i, r) if consume is not None else r
                     self.streams[k].synchronize()
-            except BaseException as e:   # noqa: BLE001 -- handed to the caller
-                errors.append(e)
+            except BaseException as e:   # noqa: BLE001
+                if abort is not None:
+                    abort(e)
+                raise
 
-        threads = [threading.Thread(target=work, args=(k,), name=f"pnr-frame-{k}") for k in range(len(self.models))]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+        for k, w in enumerate(self.workers):
+            w.jobs.put(lambda k=k: work(k))
+        errors = [e for e in (w.done.get() for w in self.workers) if e is not None]
         if errors:
             raise errors[0]
         return out

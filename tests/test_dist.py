@@ -108,3 +108,86 @@ def test_ordered_gather_with_several_render_threads_gloo(world, F):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mp.spawn(_ordered_worker, args=(world, port, 40, 36, 3, F, 12), nprocs=world, join=True)
+
+
+def _slot_reuse_worker(rank, world, port, H, W, K, F, n_frames):
+    """The round-2 advisor's scenario: the consumer of a frame is SLOW to finish() (the buffer pair of frame i - F - 1 is still being read
+    when frame i is ready).  A pair is handed out again only after its finish(): submit() waits, start() alone refuses."""
+    import threading
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = pdist.FrameGatherer(H, W, K, torch.device("cpu"), slots=F + 1)
+        og = pdist.OrderedGather(g)
+        base = torch.arange(H * W * K, dtype=torch.float32).reshape(H * W, K)
+        out, errors = [None] * n_frames, []
+
+        def work(k):
+            try:
+                prev = None
+                for i in range(k, n_frames, F):
+                    h = og.submit(i, [(base + i)[g.idx].clone()])
+                    if prev is not None:
+                        time.sleep(0.01 * ((prev[0] + rank) % 3))        # a lagging consumer: the other threads race ahead to the pair it still owns
+                        out[prev[0]] = og.finish(prev[1])
+                    prev = (i, h)
+                if prev is not None:
+                    out[prev[0]] = og.finish(prev[1])
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+                og.abort(e)
+
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(F)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=60)
+            assert not t.is_alive(), "deadlock"
+        assert not errors, errors
+        for i in range(n_frames):
+            assert torch.equal(out[i], base + i), f"rank {rank}: frame {i} holds another frame's rows"
+        # the plan alone: F + 1 gathers outstanding is the limit, one more is refused instead of overwriting unread rows
+        hs = [g.start([(base + 100 + j)[g.idx].clone()]) for j in range(F + 1)]
+        with pytest.raises(RuntimeError, match="not been finish"):
+            g.start([base[g.idx].clone()])
+        for j, h in enumerate(hs):
+            assert torch.equal(g.finish(h), base + 100 + j)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,F", [(2, 2), (2, 3)])
+def test_gather_buffers_are_not_reused_before_their_consumer_is_done_gloo(world, F):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_slot_reuse_worker, args=(world, port, 40, 36, 3, F, 14), nprocs=world, join=True)
+
+
+def test_ordered_gather_abort_releases_the_waiting_threads():
+    """A render thread that dies never submits its frames; abort() makes every thread waiting for its turn raise instead of waiting for ever
+    (pipeline.FramesInFlight calls it from the failing worker).  No communicator needed: nothing is started."""
+    import threading
+
+    class NoGather:
+        def next_slot_free(self):
+            return True
+
+        def start(self, parts):
+            raise AssertionError("frame 1 must never start: frame 0 was not submitted")
+
+    og = pdist.OrderedGather(NoGather())
+    caught = []
+
+    def waiter():
+        try:
+            og.submit(1, [])          # frame 0 belongs to the thread that failed
+        except RuntimeError as e:
+            caught.append(e)
+
+    t = threading.Thread(target=waiter)
+    t.start()
+    og.abort(ValueError("render of frame 0 failed"))
+    t.join(timeout=10)
+    assert not t.is_alive() and len(caught) == 1 and isinstance(caught[0].__cause__, ValueError)

@@ -520,8 +520,8 @@ def test_native_loop_under_fp16_autocast_uses_half_tables(cuda, model_kind):
 
 def test_fused_blobs_follow_parameter_updates(cuda, golden_dir):
     """The packed MFMA weights, interleaved tables and host-side parameter copies are caches of the parameters: optimizer-style in-place
-    updates, load_state_dict and initialize_palette must all show up in the next native frame; writes through `.data` (an EMA swap,
-    nerf/utils.py:829-839) need invalidate_fused_caches() and then show up too."""
+    updates, load_state_dict and initialize_palette must all show up in the next native frame; so must writes through `.data` (an EMA swap,
+    nerf/utils.py:829-839), which torch's version counters do not see (fused._SourceWatch)."""
     g = load(golden_dir, "frame_palette_a")
     opt = renderer.default_opt()
     m = network.PaletteNetwork(opt, bound=2, cuda_ray=True, density_scale=float(g["density_scale"]), min_near=0.2)
@@ -550,11 +550,28 @@ def test_fused_blobs_follow_parameter_updates(cuda, golden_dir):
         m.basis_color.mul_(0.5)
     n1, c1 = both()
     assert float((n1 - n0).abs().max()) > 1e-2 and float((n1 - c1).abs().max()) < COLOUR_TOL
-    # 2. a write through .data does not bump the version: stale until invalidated, correct afterwards
+    # 2. a write through .data moves neither identity nor version (torch_ema's copy_to / restore, nerf/utils.py:829-839): the frame loop's
+    #    per-frame checksum of the blobs' sources notices it, rebuilds and renders again -- no invalidate_fused_caches() call needed
     m.color_net[1].weight.data.mul_(-1.0)
-    m.invalidate_fused_caches()
-    n2, c2 = both()
+    with pytest.warns(UserWarning, match="rewritten behind torch's version counters"):
+        n2, c2 = both()
     assert float((n2 - n1).abs().max()) > 1e-3 and float((n2 - c2).abs().max()) < COLOUR_TOL
+    m.encoder_palette.embeddings.data.copy_(m.encoder_palette.embeddings.data.flip(0))       # a table (sampled checksum), as an EMA swap rewrites it
+    m.basis_color.data.add_(0.05)
+    with pytest.warns(UserWarning, match="rewritten behind torch's version counters"):
+        n2b, c2b = both()
+    assert float((n2b - n2).abs().max()) > 1e-3 and float((n2b - c2b).abs().max()) < COLOUR_TOL
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")               # nothing changed: no second render, no warning
+        n2c, _ = both()
+    assert torch.equal(n2c, n2b)
+    m.color_net[1].weight.data.mul_(-1.0)            # the documented way still works, and without the double render
+    m.invalidate_fused_caches()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        n2d, c2d = both()
+    assert float((n2d - c2d).abs().max()) < COLOUR_TOL
     # 3. load_state_dict (same Parameter objects, new values) and a second initialize_palette (a NEW Parameter object at version 0)
     fresh = network.PaletteNetwork(opt, bound=2, cuda_ray=True, density_scale=float(g["density_scale"]), min_near=0.2)
     scene.seed_field_(fresh, int(g["seed"]))
