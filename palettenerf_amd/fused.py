@@ -206,7 +206,6 @@ class _SourceWatch:
         warnings.warn("fused field: parameters were rewritten behind torch's version counters (a `.data` write); the packed blobs were rebuilt and "
                       "the frame rendered again -- invalidate_fused_caches(model) after such writes avoids the double render")
         self.invalidate_caches()
-        self._watch_ref = None
 
 
 def _set_finish(a, bg_color, N, mask):
@@ -259,6 +258,7 @@ class NeRFFieldFused(_PrecisionGuard, _SourceWatch):
         self.versions = None
         self._emb_half = None
         self._guard_key = None
+        self._watch_ref = None       # the next frame rebuilds every blob: its source checksums become the reference
 
     def _guard_tables(self):
         return [self.model.encoder.embeddings]
@@ -447,6 +447,7 @@ class PaletteFieldFused(_PrecisionGuard, _SourceWatch):
     def invalidate_caches(self):
         self.versions = None
         self._pair_key = self._triple_key = self._guard_key = None
+        self._watch_ref = None       # the next frame rebuilds every blob: its source checksums become the reference
 
     def _watched(self):
         return [(w, 1) for w in self._weights() + self._tables()] + [(t, TABLE_CHECK_STRIDE) for t in self._guard_tables()]

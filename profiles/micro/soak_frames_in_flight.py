@@ -34,3 +34,40 @@ for kind in ("nerf", "palette"):
                 if not np.array_equal(np.nan_to_num(a), np.nan_to_num(b)):
                     bad += 1
     print(kind, "frames compared:", 3 * 8 * 96, "mismatching:", bad)
+
+# Round 3: 1000 render() calls on ONE pool (the worker threads persist, so the frame calls' per-thread pinned block, events and iteration
+# prediction are allocated once) and 200 pools made and closed (their threads end: the per-thread state is freed).  Host memory must stay flat.
+import gc, psutil
+proc = psutil.Process()
+m = network.NeRFNetwork(bound=2, cuda_ray=True)
+scene.seed_field_(m, 0)
+m = m.to(dev).eval()
+m.density_grid.copy_(torch.from_numpy(scene.brick_density_grid()).to(dev))
+raymarching.packbits(m.density_grid, 0.5, m.density_bitfield)
+m.march_mode, m.fused_field = "native", True
+m._fused = NeRFFieldFused(m)
+kw = dict(perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+pose = torch.from_numpy(scene.lookat_pose())[None]
+ro, rd = scene.get_rays(pose, scene.intrinsics_from_fov(96, 96), 96, 96)
+ro, rd = ro.to(dev), rd.to(dev)
+fif = FramesInFlight(m, 2)
+names = {w.name: w.ident for w in fif.workers}
+rss = []
+for call in range(1000):
+    fif.render(lambda i: (ro, rd), 2, **kw)
+    if call % 100 == 99:
+        gc.collect()
+        rss.append(proc.memory_info().rss >> 20)
+assert names == {w.name: w.ident for w in fif.workers}
+print("1000 render() calls on one pool: RSS MiB every 100 calls", rss)
+fif.close()
+rss2 = []
+for k in range(200):
+    f2 = FramesInFlight(m, 2)
+    f2.render(lambda i: (ro, rd), 2, **kw)
+    f2.close()
+    if k % 50 == 49:
+        gc.collect()
+        rss2.append(proc.memory_info().rss >> 20)
+print("200 pools made and closed: RSS MiB every 50 pools", rss2)
+assert rss[-1] - rss[2] <= 8 and rss2[-1] - rss2[0] <= 16, (rss, rss2)
