@@ -323,6 +323,193 @@ def timed_frames(m, bank, kw, steps, fp16, first_step=0):
     return dt / steps * 1e3, rendered // steps
 
 
+# ------------------------------------------------------------------------------------------------ configs[3]: the training step
+def make_training_step(model_kind, rays, device, fp16=False, torch_adam=False):
+    """configs[3]-shaped training step (main_palette.py:223 / palette/utils.py:481 on LLFF-like input): `rays` random rays per step from a
+    forward-facing 17-camera rig over the slab scene, dt_gamma 1/128, march_rays_train -> field -> composite_rays_train (+ the flex composite
+    of the palette model) -> losses -> backward (composite, MLPs, grid_encode backward) -> Adam.  Returns (model, step(i) -> None)."""
+    import numpy as np
+    import torch
+    from palettenerf_amd import network, raymarching, renderer, scene
+    if model_kind == "palette":
+        m = network.PaletteNetwork(renderer.default_opt(test=False), bound=2, cuda_ray=True, min_near=0.02)
+    else:
+        m = network.NeRFNetwork(bound=2, cuda_ray=True, min_near=0.02)
+    scene.seed_field_(m, 0)
+    m = m.to(device).train()
+    m.density_grid.copy_(torch.from_numpy(scene.slab_density_grid()).to(device))
+    raymarching.packbits(m.density_grid, 0.5, m.density_bitfield)
+    H, W = 756, 1008          # LLFF fern images_4
+    g = torch.Generator().manual_seed(0)
+    poses = []
+    for i in range(17):       # cameras on a 0.3-radius disc at z = 1.5 looking down -z
+        a = 2 * np.pi * i / 17
+        p = np.eye(4, dtype=np.float32)
+        p[:3, 0], p[:3, 1], p[:3, 2] = [1, 0, 0], [0, -1, 0], [0, 0, -1]
+        p[:3, 3] = [0.3 * np.cos(a), 0.3 * np.sin(a), 1.5]
+        poses.append(p)
+    ro_all, rd_all = scene.get_rays(torch.from_numpy(np.stack(poses)), scene.intrinsics_from_fov(H, W, 0.9), H, W)
+    ro_all, rd_all = ro_all.to(device), rd_all.to(device)
+    if torch_adam or fp16:
+        opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    else:
+        from palettenerf_amd import optim
+        opt = optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    scaler = torch.amp.GradScaler("cuda", enabled=fp16)
+    target = torch.rand(rays, 3, device=device)
+    inds_all = torch.randint(0, H * W, [64, rays], generator=g).to(device)     # the index draws of 64 steps, resident (the reference draws them on the device)
+
+    def step(i):
+        inds = inds_all[i % 64]
+        ro, rd = ro_all[i % 17, inds][None], rd_all[i % 17, inds][None]
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=fp16):
+            r = m.run_cuda(ro, rd, dt_gamma=1 / 128, perturb=True, force_all_rays=True, max_steps=1024, T_thresh=1e-4)
+            loss = ((r["image"][0] - target) ** 2).mean()
+            if model_kind == "palette":
+                loss = loss + 1e-3 * r["omega_sparsity"].mean() + 1e-2 * r["offsets_norm"].mean() + ((r["direct_rgb"][0] - target) ** 2).mean()
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+
+    return m, step
+
+
+def training_leg(model_kind, device, steps=50, warmup=8, rays=4096):
+    """Wall ms per training step over `steps` steps, and -- from a torch.profiler trace of 10 further steps -- the device time of a step's
+    kernels and the number of launches per step (every kernel of the process is traced, the C-ABI ones included)."""
+    import torch
+    m, step = make_training_step(model_kind, rays, device)
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps * 1e3
+    rec = {"wall_ms_per_step": wall, "steps": steps, "rays_per_step": rays, "samples_per_step": int(m.step_counter[(m.local_step - 1) % 16, 0]),
+           "what": f"configs[3] shape: -m {model_kind} training step, {rays} rays, slab scene, dt_gamma 1/128, Adam; synthetic targets"}
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        n = 10
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for i in range(n):
+                step(warmup + steps + i)
+            torch.cuda.synchronize()
+        kernels = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA and "memcpy" not in e.name.lower() and "memset" not in e.name.lower()]
+        if kernels:
+            rec["kernel_ms_per_step"] = sum(e.device_time for e in kernels) / n / 1e3
+            rec["launches_per_step"] = len(kernels) / n
+            rec["wall_over_kernel"] = wall / rec["kernel_ms_per_step"]
+    except Exception as e:   # noqa: BLE001 -- a profiler that does not work on this box is reported, the wall figure stands
+        rec["profiler_error"] = repr(e)
+    return rec
+
+
+def occupancy_leg(device):
+    """one update_extra_state of a 2 x 128^3 grid through csrc/occupancy.hip -- full sweep (iter_density < 16) and partial --
+    device time between two events around the call (its random numbers drawn outside) and host time of the call (nothing waits)."""
+    import torch
+    from palettenerf_amd import network, scene
+    m = network.NeRFNetwork(bound=2, cuda_ray=True, min_near=0.2)
+    scene.seed_field_(m, 0)
+    m = m.to(device).train()
+    G, n = 128, 128 ** 3 // 4
+    out = {}
+    for name, start in (("full", 0), ("partial", 16)):
+        draws = dict(noise=torch.rand(2, G ** 3, 3, device=device)) if start == 0 else dict(
+            noise=torch.rand(2, 2 * n, 3, device=device), coords=torch.randint(0, G, (2, n, 3), device=device, dtype=torch.int32),
+            occ_rand=torch.randint(0, 2 ** 31 - 1, (2, n), device=device, dtype=torch.int32))
+        for _ in range(3):
+            m.iter_density = start
+            m.update_extra_state(**draws)
+        torch.cuda.synchronize()
+        dev_ms, host_ms = [], []
+        for _ in range(10):
+            m.iter_density = start
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            h0 = time.perf_counter()
+            m.update_extra_state(**draws)
+            host_ms.append((time.perf_counter() - h0) * 1e3)
+            e1.record()
+            torch.cuda.synchronize()
+            dev_ms.append(e0.elapsed_time(e1))
+        out[name] = {"device_ms": sorted(dev_ms)[5], "host_ms": sorted(host_ms)[5], "samples": 2 * G ** 3 if start == 0 else 4 * n}
+    out["what"] = "update_extra_state, 2 x 128^3 cells, fused HIP sweep (no host wait); median of 10"
+    return out
+
+
+def strong_leg(args, m, kw, device, world, rank, steps):
+    """The north-star's N > 1 question next to the weak-scaling headline: ONE frame's rays split over the ranks (32 x 32 tiles round-robin),
+    every rank renders its share, one all-gather assembles the frame on every rank.  Returns ms per frame (max over ranks, gathers
+    pipelined as in the headline loop), the same with a blocking gather per frame, and the all-gather alone."""
+    import torch
+    import torch.distributed as dist
+    from palettenerf_amd import dist as pdist
+    from palettenerf_amd.fused import tile_ray_order
+    H, W = args.wl["H"], args.wl["W"]
+    nb = int(getattr(m, "num_basis", 0))
+    K = 5 if args.model == "nerf" else 8 + 4 * nb
+    idx, _ = pdist.shard_indices(H, W, rank, world)
+    bank = RayBank(args, 1, idx, device)
+    saved = getattr(m._fused, "ray_order", None)
+    m._fused.ray_order = tile_ray_order(idx, W, 8).to(device)
+    g = pdist.FrameGatherer(H, W, K, device)
+
+    def run(n, first, blocking):
+        pending, rendered = None, 0
+        for i in range(n):
+            ro, rd = bank.get(first + i)
+            with torch.no_grad():
+                r = m.render(ro, rd, **kw)
+            rendered += int(r["rendered"].sum())
+            h = g.start(gather_parts(args, r, nb))
+            if blocking:
+                g.finish(h)
+            else:
+                if pending is not None:
+                    g.finish(pending)
+                pending = h
+        if pending is not None:
+            g.finish(pending)
+        return rendered
+
+    out = {}
+    try:
+        for i in range(min(steps + 3, bank.n_steps)):
+            bank.get(i)
+        run(3, 0, False)
+        for name, blocking in (("pipelined", False), ("blocking_gather", True)):
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            rendered = run(steps, 3, blocking)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t = torch.tensor([time.perf_counter() - t0, float(rendered)], dtype=torch.float64, device=device)
+            tmax = t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            out[name] = {"ms_per_frame": float(tmax[0]) / steps * 1e3, "value": float(t[1]) / float(tmax[0]), "unit": "samples/s"}
+        parts = [torch.zeros(idx.numel(), K, device=device)]
+        for _ in range(3):
+            g(parts)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            g(parts)
+        torch.cuda.synchronize()
+        out["all_gather_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+        out.update(steps=steps, rays_per_rank=int(idx.numel()), gathered_floats_per_ray=K, bytes_per_rank=int(idx.numel()) * K * 4,
+                   what=f"ONE {H}x{W} frame split over {world} ranks in 32x32 tiles + one all_gather_into_tensor per frame (strong scaling)")
+    finally:
+        m._fused.ray_order = saved
+    return out
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse(argv)
@@ -503,11 +690,15 @@ def main(argv=None):
             kernel_name = "k_frame_grid (device-driven frame loop)" if args.model == "nerf" else "k_frame_grid_pair/_triple (device-driven frame loop, tables interleaved)"
         achieved = (k_units * per_sample) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic = None  # HBM-side bytes per launch from the committed PMC passes of this workload (profiles/r02_traffic.json; regenerate with profiles/pmc_pass.sh)
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
+        if not os.path.exists(tpath):
+            tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if native and args.density_scale == 100.0 and not args.fp16 and not args.half_tables and world == 1 and os.path.exists(tpath):
             tr = json.load(open(tpath)).get(args.workload if args.res == 800 else "")
             if tr:
                 traffic = tr["traffic_bytes_per_launch"]
+        field_note = {"f16x3": "field: f16x3 split products, fp32 accumulate", "f16x2": "field: f16x3 for sigma_net, colour layers with activations rounded once to f16", "fp32": "field: exact fp32 MFMA"}[args.field_precision]
+        dtype_label = ("f16 tables + autocast" if args.fp16 else "f32") + (f" ({field_note})" if getattr(m, "fused_field", False) else "")
         raw_steps = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
         slowest = max(range(args.steps), key=lambda i: raw_steps[i])
         per_step = sorted(raw_steps)
@@ -515,7 +706,7 @@ def main(argv=None):
             "metric": "rendered_samples_per_sec", "value": total_rendered / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "step_ms": {"min": per_step[0], "median": per_step[len(per_step) // 2], "max": per_step[-1], "slowest_step": slowest}, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f16" if args.fp16 else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype_label, "data": "synthetic",
             "config": {"workload": f"{wl['label']}, {H}x{W}, {n_views} view(s)/step, camera moving ({'static pose' if args.static_pose else 'one pose of the path per step'})",
                        "rays_per_step": n_views * H * W, "rendered_samples_per_step": total_rendered // args.steps,
                        "evaluated_rows_per_step_rank0": rows // args.steps, "density_scale": args.density_scale, "dt_gamma": wl["dt_gamma"], "march_mode": m.march_mode,
@@ -525,7 +716,9 @@ def main(argv=None):
                        "gathered_floats_per_ray": K if use_dist else 0, "rccl_ranks": dist.get_world_size() if use_dist else 1,
                        "parallelism": f"32x32 ray tiles of {n_views} view(s) round-robin over {world} GPUs + one all_gather/step" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "launches": n_launches,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": (os.path.relpath(tpath, ROOT) + " (PMC passes of this command, not measured in this run)") if traffic is not None else None,
+                         "launches": n_launches,
                          "avg_launch_ms": k_ms / max(1, n_launches), "avg_live_samples_per_launch": k_units / max(1, n_launches) / (n_tables if native else 1),
                          "algorithmic_bytes_per_sample": per_sample * (n_tables if native else 1),
                          "algorithmic_bytes_per_launch": per_sample * k_units / max(1, n_launches)},
@@ -539,6 +732,15 @@ def main(argv=None):
     if use_dist:
         dist.barrier()
     extra = {}
+    if world > 1 and native and args.scaling == "weak" and not args.no_extras and F_main == 1:
+        # every rank takes part; rank 0 reports.  (--scaling strong makes this split the headline itself.)
+        try:
+            strong = strong_leg(args, m, kw, device, world, rank, max(5, args.extra_steps))
+            if rank == 0:
+                extra["strong"] = strong
+        except RuntimeError as e:
+            if rank == 0:
+                extra["strong_error"] = str(e)
     crop_ref = None   # (rays_o, rays_d, oracle results) of the parity crop, for the extra legs
     if rank == 0 and world == 1:
         # --- PSNR / max-abs against the oracle + the CPU baseline, on a centre crop of pose 0 (same device-generated rays for both sides)
@@ -648,8 +850,78 @@ def main(argv=None):
                 samples.append(rend)
             extra["shard_emulation"] = {"shards": S, "ms": times, "max_ms": max(times), "mean_ms": sum(times) / S, "samples": samples,
                                         "imbalance_max_over_mean": max(times) / (sum(times) / S)}
-        if extra:
-            out["extra"] = extra
+        # --- round 3 legs: the reference's -O mode, a long run, configs[4] split 8 ways (emulated), configs[3] training steps, the occupancy sweep
+        if not args.no_extras and native and args.workload == "lego" and not args.fp16 and F_main == 1:
+            n = max(1, args.extra_steps)
+            try:     # `-O` = fp16 autocast + half tables (main_nerf.py:72-75): what every script of the reference runs
+                fargs = argparse.Namespace(**vars(args))
+                fargs.fp16 = True
+                mm = build_model(fargs, device, "nerf")
+                mm._fused.ray_order = m._fused.ray_order
+                timed_frames(mm, bank, kw, 3, True)
+                extra["fp16_mode_ms_per_step"], extra["fp16_mode_rendered_per_step"] = timed_frames(mm, bank, kw, n, True, first_step=args.warmup)
+                del mm
+            except RuntimeError as e:
+                extra["fp16_mode_error"] = str(e)
+            try:     # stability over seconds: 500 frames of the camera path, per-frame time from events (no sync inside the loop)
+                L = 500
+                evs = [torch.cuda.Event(enable_timing=True) for _ in range(L + 1)]
+                import gc
+                gc.collect()
+                gc.disable()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                evs[0].record()
+                for i in range(L):
+                    ro, rd = bank.get(args.warmup + i)
+                    with torch.no_grad():
+                        m.render(ro, rd, **kw)
+                    evs[i + 1].record()
+                torch.cuda.synchronize()
+                wall = time.perf_counter() - t0
+                gc.enable()
+                ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(L))
+                extra["long_run"] = {"steps": L, "seconds": wall, "ms_per_step": wall / L * 1e3, "step_ms": {"min": ms[0], "p05": ms[L // 20], "median": ms[L // 2], "p95": ms[L - L // 20], "max": ms[-1]}}
+            except RuntimeError as e:
+                extra["long_run_error"] = str(e)
+            try:     # configs[4] (garden video frame) split into 8 tile shards rendered one after another on this GPU: the load balance an 8-GPU split would see
+                gargs = parse(["--workload", "garden", "--no-cpu-baseline"])
+                gm = build_model(gargs, device)
+                gH, gW = gargs.wl["H"], gargs.wl["W"]
+                gkw = dict(perturb=False, dt_gamma=gargs.wl["dt_gamma"], max_steps=1024, T_thresh=1e-4, gui_mode=False)
+                gargs.static_pose = True
+                full_idx, _ = pdist.shard_indices(gH, gW, 0, 1)
+                gbank = RayBank(gargs, 1, full_idx, device)
+                gm._fused.ray_order = tile_ray_order(full_idx, gW, 8).to(device)
+                timed_frames(gm, gbank, gkw, 2, False)
+                full_ms, full_rend = timed_frames(gm, gbank, gkw, 5, False)
+                times, samples = [], []
+                for sh in range(8):
+                    sidx, _ = pdist.shard_indices(gH, gW, sh, 8)
+                    sbank = RayBank(gargs, 1, sidx, device)
+                    gm._fused.ray_order = tile_ray_order(sidx, gW, 8).to(device)
+                    timed_frames(gm, sbank, gkw, 2, False)
+                    ms_, rend = timed_frames(gm, sbank, gkw, 5, False)
+                    times.append(ms_)
+                    samples.append(rend)
+                extra["garden_shard_emulation_8"] = {"full_frame_ms": full_ms, "full_frame_samples": full_rend, "shard_ms": times, "shard_samples": samples,
+                                                     "max_shard_ms": max(times), "imbalance_max_over_mean": max(times) / (sum(times) / 8),
+                                                     "speedup_before_all_gather": full_ms / max(times),
+                                                     "what": f"configs[4]: one {gH}x{gW} PaletteNeRF garden frame, its 8 interleaved-tile shards rendered one after another on this GPU"}
+                del gm
+            except RuntimeError as e:
+                extra["garden_shard_emulation_8_error"] = str(e)
+            for kind in ("palette", "nerf"):
+                try:
+                    extra[f"train_{kind}"] = training_leg(kind, device)
+                except RuntimeError as e:
+                    extra[f"train_{kind}_error"] = str(e)
+            try:
+                extra["occupancy_sweep"] = occupancy_leg(device)
+            except RuntimeError as e:
+                extra["occupancy_sweep_error"] = str(e)
+    if rank == 0 and extra:
+        out["extra"] = extra
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
