@@ -732,7 +732,7 @@ def main(argv=None):
     if use_dist:
         dist.barrier()
     extra = {}
-    if world > 1 and native and args.scaling == "weak" and not args.no_extras and F_main == 1:
+    if use_dist and native and args.scaling == "weak" and not args.no_extras and F_main == 1:   # (PNR_BENCH_FORCE_DIST=1 runs it over a one-rank communicator)
         # every rank takes part; rank 0 reports.  (--scaling strong makes this split the headline itself.)
         try:
             strong = strong_leg(args, m, kw, device, world, rank, max(5, args.extra_steps))

@@ -12,6 +12,11 @@ from palettenerf_amd import network, raymarching, renderer, scene
 pytestmark = pytest.mark.gpu
 
 COLOUR_TOL = 1e-4
+# Round 2 checked edited images at 3e-4, depth at 2e-4 and depth_origin at 5e-4 "because the hue wrap amplifies rounding".  Measured in round 3
+# (profiles/edit_tolerance.py, profiles/r03_edit_tolerance.txt): every mode is within 9.5e-7 of the goldens on the images, edited or not,
+# 5.3e-7 on depth and 2.9e-6 on depth_origin (values up to 2.4); no pixel is above 2e-5.  The looser bounds were never needed.
+EDIT_TOL = 1e-4
+DEPTH_TOL = 1e-4
 
 
 def load(golden_dir, name):
@@ -59,7 +64,7 @@ def test_nerf_inference_frame(cuda, golden_dir, case, mode):
         r = m.render(ro, rd, staged=True, dt_gamma=float(g["dt_gamma"]), perturb=False, max_steps=1024, T_thresh=1e-4)
     close(r["image"], g["image"], what="image")
     close(r["weights_sum"], g["weights_sum"], what="weights_sum")
-    close(r["depth"], g["depth"], tol=2e-4, what="depth")
+    close(r["depth"], g["depth"], tol=DEPTH_TOL, what="depth")
     assert scene.psnr(r["image"].cpu(), torch.from_numpy(g["image"])) > 80.0
     _RENDERED.setdefault(case, {})[mode] = (int(r["rendered"].item()), int(r["n_samples"]))
     if len(_RENDERED[case]) == 5:  # every execution mode marched exactly the same samples (schedule and compaction identical)
@@ -82,7 +87,7 @@ def test_nerf_training_step(cuda, golden_dir, case):
     assert m.step_counter[0].cpu().numpy().tolist() == g["counter"].tolist()  # sample / ray counts: bit-exact
     close(r["image"], g["image"], what="image")
     close(r["weights_sum"], g["weights_sum"], what="weights_sum")
-    close(r["depth"], g["depth"], tol=2e-4, what="depth")
+    close(r["depth"], g["depth"], tol=DEPTH_TOL, what="depth")
     loss = (r["image"] ** 2).mean() + 0.1 * r["weights_sum"].mean()
     assert abs(float(loss) - float(g["loss"])) < 1e-5
     loss.backward()
@@ -110,8 +115,8 @@ def test_palette_inference_frame_all_maps_and_edit(cuda, golden_dir, case):
             r = m.render(ro, rd, dt_gamma=float(g["dt_gamma"]), perturb=False, max_steps=1024, T_thresh=1e-4, gui_mode=False)
         for k in ("image", "weights_sum", "clip_feat", "direct_rgb", "view_dep_rgb", "basis_rgb", "unscaled_basis_rgb", "basis_acc"):
             close(r[k], g[k], what=f"{mode}:{k}")
-        close(r["depth"], g["depth"], tol=2e-4, what="depth")
-        close(r["depth_origin"], g["depth_origin"], tol=5e-4, what="depth_origin")
+        close(r["depth"], g["depth"], tol=DEPTH_TOL, what="depth")
+        close(r["depth_origin"], g["depth_origin"], tol=DEPTH_TOL, what="depth_origin")
     # regional edit: RGB->HSV->RGB inside the fused field epilogue of the device-driven loop (the last mode set above)
     m.edit = renderer.RegionEdit(opt)
     m.edit.update_cent(mean_xyz=torch.tensor([0.1, 0.0, -0.2], device=cuda))
@@ -119,7 +124,7 @@ def test_palette_inference_frame_all_maps_and_edit(cuda, golden_dir, case):
     m.edit.update_delta_hsv(m.basis_color.data.clamp(0, 1), (m.basis_color.data * 0.6 + 0.2).flip(0).clamp(0, 1))
     with torch.no_grad():
         r2 = m.render(ro, rd, dt_gamma=float(g["dt_gamma"]), perturb=False, max_steps=1024, T_thresh=1e-4, gui_mode=True)
-    close(r2["image"], g["edit_image"], tol=3e-4, what="edit_image")  # HSV hue wrap amplifies rounding a little
+    close(r2["image"], g["edit_image"], tol=EDIT_TOL, what="edit_image")
     assert "basis_rgb" not in r2
 
 
@@ -135,7 +140,7 @@ def test_palette_training_step(cuda, golden_dir, case):
     r = m.run_cuda(ro, rd, dt_gamma=float(g["dt_gamma"]), perturb=False, force_all_rays=True, max_steps=1024, T_thresh=1e-4)
     assert m.step_counter[0].cpu().numpy().tolist() == g["counter"].tolist()
     for k in ("image", "weights_sum", "omega_sparsity", "view_dep_norm", "offsets_norm", "direct_rgb", "view_dep_rgb", "diffuse_rgb", "clip_feat", "basis_acc"):
-        close(r[k], g[k], tol=2e-4, what=k)
+        close(r[k], g[k], tol=COLOUR_TOL, what=k)
     loss = (r["image"] ** 2).mean() + 0.01 * r["omega_sparsity"].mean() + 0.1 * r["offsets_norm"].mean() + (r["direct_rgb"] ** 2).mean() \
         + 0.1 * (r["clip_feat"] ** 2).mean() + 0.1 * r["basis_acc"].mean()
     assert abs(float(loss) - float(g["loss"])) < 2e-5
@@ -226,7 +231,7 @@ def test_native_loop_edge_cases_match_reference_style_loop(cuda, model_kind):
         assert int(a["rendered"].item()) == int(b["rendered"].item()), kw
         for k in ("image", "weights_sum"):
             close(b[k], a[k].cpu().numpy(), tol=1e-4, what=k)
-        close(b["depth"], a["depth"].cpu().numpy(), tol=3e-4, what="depth")   # NaN pattern (0/0 for missed rays) must agree too
+        close(b["depth"], a["depth"].cpu().numpy(), tol=DEPTH_TOL, what="depth")   # NaN pattern (0/0 for missed rays) must agree too
         return a, b
 
     a, b = both(ro[:, 1000:1001].contiguous(), rd[:, 1000:1001].contiguous(), dt_gamma=0, max_steps=1024)       # N = 1
@@ -614,7 +619,7 @@ def test_palette_stylizer_edit_and_many_basis_frames_in_every_mode(cuda, golden_
             r = m.render(ro, rd, gui_mode=False, **kw)
             for k in maps:
                 close(r[k], g[k], what=f"{mode}:{k}")
-            close(r["depth"], g["depth"], tol=2e-4, what=f"{mode}:depth")
+            close(r["depth"], g["depth"], tol=DEPTH_TOL, what=f"{mode}:depth")
             set_extra_stylizer(m, opt, g, cuda)
             close(m.render(ro, rd, gui_mode=True, **kw)["image"], g["style_image"], what=f"{mode}:style_image")
             if m.fused_field:
@@ -623,8 +628,8 @@ def test_palette_stylizer_edit_and_many_basis_frames_in_every_mode(cuda, golden_
             m.stylizer = None
             set_extra_edit(m, opt, cuda)
             e = m.render(ro, rd, gui_mode=False, **kw)
-            close(e["image"], g["edit_image"], tol=3e-4, what=f"{mode}:edit_image")          # HSV hue wrap amplifies rounding a little
-            close(e["basis_rgb"], g["edit_basis_rgb"], tol=3e-4, what=f"{mode}:edit_basis_rgb")
+            close(e["image"], g["edit_image"], tol=EDIT_TOL, what=f"{mode}:edit_image")
+            close(e["basis_rgb"], g["edit_basis_rgb"], tol=EDIT_TOL, what=f"{mode}:edit_basis_rgb")
             m.edit.weight_mode = True
             close(m.render(ro, rd, gui_mode=True, **kw)["image"], g["edit_weight_image"], what=f"{mode}:edit_weight_image")
             m.edit = None
@@ -647,7 +652,7 @@ def test_native_loop_renders_the_round1_edit_fixture(cuda, golden_dir):
         m.edit.update_delta_hsv(m.basis_color.data.clamp(0, 1), (m.basis_color.data * 0.6 + 0.2).flip(0).clamp(0, 1))
         with torch.no_grad():
             r = m.render(ro, rd, dt_gamma=float(g["dt_gamma"]), perturb=False, max_steps=1024, T_thresh=1e-4, gui_mode=True)
-        close(r["image"], g["edit_image"], tol=3e-4, what=f"edit_image {case}")
+        close(r["image"], g["edit_image"], tol=EDIT_TOL, what=f"edit_image {case}")
         assert "iterations" in r                                                         # it really took the device-driven loop
 
 
@@ -690,7 +695,7 @@ def test_checkpoint_file_to_native_render(cuda, golden_dir, tmp_path, kind, case
     assert m._fused is fused and not torch.equal(fused.packed, blob_before)            # same object, blob rebuilt from the loaded weights
     close(r["image"], g["image"], what="image")
     close(r["weights_sum"], g["weights_sum"], what="weights_sum")
-    close(r["depth"], g["depth"], tol=2e-4, what="depth")
+    close(r["depth"], g["depth"], tol=DEPTH_TOL, what="depth")
     if kind == "palette":
         for k in ("clip_feat", "direct_rgb", "view_dep_rgb", "basis_rgb", "unscaled_basis_rgb", "basis_acc"):
             close(r[k], g[k], what=k)

@@ -140,7 +140,7 @@ def test_garden_video_frame_native_equals_reference_style_loop(cuda):
         assert float((a[k] - b[k]).abs().max()) < 1e-4, k
     assert scene.psnr(a["image"], b["image"]) > 80.0
     fin = torch.isfinite(a["depth"])
-    assert torch.equal(fin, torch.isfinite(b["depth"])) and float((a["depth"][fin] - b["depth"][fin]).abs().max()) < 2e-4
+    assert torch.equal(fin, torch.isfinite(b["depth"])) and float((a["depth"][fin] - b["depth"][fin]).abs().max()) < 1e-4
     hit = float((b["weights_sum"] > 0.5).float().mean())
     assert 0.3 < hit <= 1.0   # the ground slab and the object fill a large part of every view of the path
     # the 8-GPU split of this frame on one GPU: every tile shard rendered on its own (tile-ordered alive list, as bench.py does) gives its
@@ -194,7 +194,7 @@ def test_palette_frame_800_native_equals_reference_style_loop(cuda, frame800):
     m.edit.update_std(std_xyz=0.3)
     m.edit.update_delta_hsv(m.basis_color.data.clamp(0, 1), (m.basis_color.data * 0.5 + 0.3).flip(0).clamp(0, 1))
     c, d = both()
-    assert float((c["image"] - d["image"]).abs().max()) < 3e-4 and float((c["image"] - a["image"]).abs().max()) > 1e-2   # the edit is visible, and identical
+    assert float((c["image"] - d["image"]).abs().max()) < 1e-4 and float((c["image"] - a["image"]).abs().max()) > 1e-2   # the edit is visible, and identical
     assert d["iterations"] == b["iterations"]                     # the edited frame takes the same device-driven loop, launch for launch
 
 
