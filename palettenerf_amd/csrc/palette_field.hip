@@ -106,13 +106,18 @@ __device__ __forceinline__ f32x16 elu16(f32x16 v) {
 // the 8 encoder rows of a lane (levels 4h..4h+3 and 8+4h..8+4h+3), raw: issued at the top of a tile for every table so that the
 // loads of the later networks are in flight while the earlier ones compute (the workgroup has registers to spare: LDS, not VGPRs,
 // limits it to two waves per SIMD)
-__device__ __forceinline__ void load_enc_raw(const float* __restrict__ enc, size_t level_stride, uint32_t row, bool valid, int h, float x[2][8]) {
+// Addresses are base + a 32-bit byte offset (16 levels x level_stride rows x 8 bytes < 4 GiB: checked by the host): with 64-bit address
+// arithmetic the compiler keeps one loop-invariant 64-bit `level * level_stride` base per level and table in scalar registers -- 64 of the
+// kernel's ~100 -- and spills them to vector-register lanes (v_readlane in the tile loop).
+__device__ __forceinline__ void load_enc_raw(const float* __restrict__ enc, uint32_t level_stride, uint32_t row, bool valid, int h, float x[2][8]) {
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(enc);
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int level = 8 * kb + 4 * h + q;
-            const float2 v = valid ? *reinterpret_cast<const float2*>(enc + ((size_t)level * level_stride + row) * 2) : make_float2(0.0f, 0.0f);
+            const uint32_t level = (uint32_t)(8 * kb + 4 * h + q);
+            const uint32_t off = (level * level_stride + row) * 8u;
+            const float2 v = valid ? *reinterpret_cast<const float2*>(base + off) : make_float2(0.0f, 0.0f);
             x[kb][2 * q] = v.x; x[kb][2 * q + 1] = v.y;
         }
 }
