@@ -112,6 +112,7 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_unsort_outputs(uint32_t N, 
 #ifdef PNR_MARCH_STATS
 __device__ unsigned long long g_march_stats[8];
 __device__ unsigned int g_march_max[64];   // per iteration: max probes of any ray
+__device__ unsigned int g_march_hist[2][32];   // probes per ray and launch: [0] first launch of a frame, [1] later launches (last bin: 31 or more)
 __device__ unsigned int g_march_kinds[64][8];   // per iteration: probe kinds of (one of) the slowest rays  // probes, empty probes, (unused), ray-launches
 #endif
 __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long* sh /* [kRayBlock / 64] */) {
@@ -458,6 +459,7 @@ __global__ void __launch_bounds__(kRayBlock) __attribute__((amdgpu_waves_per_eu(
             if (atomicMax(&g_march_max[(prev->iterations + 1) & 63], (unsigned int)probes) < (unsigned int)probes)
                 for (int kk = 0; kk < 8; kk++) g_march_kinds[(prev->iterations + 1) & 63][kk] = kinds[kk];
             atomicAdd(&g_march_stats[so + 0], probes); atomicAdd(&g_march_stats[so + 1], empties); atomicAdd(&g_march_stats[so + 3], 1ull);
+            atomicAdd(&g_march_hist[so ? 1 : 0][probes > 31 ? 31 : (int)probes], 1u);
         }
         {   // wave-level: max probes over the wave (what the wave actually executes)
             unsigned long long mx = probes;
@@ -1247,6 +1249,10 @@ extern "C" int pnr_debug_march_timing(unsigned long long* out, int iteration) {
 extern "C" int pnr_debug_march_kinds(unsigned int* out) {
     hipDeviceSynchronize();
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(pnr::g_march_kinds), 64 * 8 * 4) == hipSuccess ? 0 : -3;
+}
+extern "C" int pnr_debug_march_hist(unsigned int* out) {
+    hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pnr::g_march_hist), 64 * 4) == hipSuccess ? 0 : -3;
 }
 extern "C" int pnr_debug_march_max(unsigned int* out, int reset) {
     hipDeviceSynchronize();

@@ -35,3 +35,11 @@ for it in range(30):
     print(it, list(kd)[it * 8:it * 8 + 8])
 print("first launch:", list(out[0:4]), "later launches:", list(out[4:8]))
 print("probes", out[0], "empty", out[1], "sum over waves of max-lane probes x64", out[2] * 64, "ray-launches", out[3], "rendered", int(r["rendered"].item()))
+
+hist = (ctypes.c_uint * 64)()
+if hasattr(lib, "pnr_debug_march_hist") and lib.pnr_debug_march_hist(hist) == 0:
+    for name, h in (("first launch", list(hist)[:32]), ("later launches", list(hist)[32:])):
+        tot = sum(h)
+        if tot:
+            tail = [sum(h[k + 1:]) / tot for k in range(12)]
+            print(f"probes per ray, {name} ({tot} ray-launches over both frames): share with MORE than k probes, k = 0..11:", " ".join(f"{v * 100:.2f}%" for v in tail))
