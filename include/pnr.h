@@ -57,7 +57,9 @@ int pnr_abi_version(void);
  * "aux_fusion" (PaletteNeRF frame loop: aux composite inside the field kernel), "composite_fusion" (NeRF frame loop: iterations with one
  * sample per ray composited inside the field kernel); all default to 1.  "adam_variant" (0..7, default 0): which multiply-adds of pnr_adam_step
  * are left uncontracted (kept for re-deriving the bit-exact form against a new torch build); "iteration_margin" (default 0): spare iterations
- * the frame loops enqueue beyond the previous frame's count before their first look at the control block */
+ * the frame loops enqueue beyond the previous frame's count before their first look at the control block; "hosted_tail" (default 1): the frame
+ * loops' march launches hand the rays they have not finished within "march_budget" (default 2; "march_budget0" for a frame's first launch, default
+ * 0 = that launch finishes every ray itself) sample-less probes to the first workgroups of the lookup launch that follows -- same rows, bit for bit */
 int pnr_set_option(const char* name, int value);
 
 /* ---------------------------------------------------------------- raymarching: utils ------- */

@@ -36,13 +36,49 @@ static_assert(sizeof(FrameCtl) == 64, "FrameCtl layout");
 constexpr uint32_t kRayBlock = 256;
 constexpr uint32_t kHdr = 4;  // scratch header ints before the per-chunk counts
 
+// ------------------------------------------------------------------------------------------
+// Hosted march tail (round 3).  A march launch lasts as long as its slowest rays -- 0.5 % of a later lego launch need more than two
+// probes (profiles/march_stats.py), and the launch waited 20-30 us for them at ~1.3 us per dependent probe.  Kernels of one stream
+// cannot overlap (hipExtAnyOrderLaunch is not honoured on gfx9: profiles/micro/any_order.hip), so the overlap happens INSIDE the next
+// launch: k_frame_march<.., 2> gives every ray `budget` probe rounds, writes the rays that are still marching to a queue in the frame
+// workspace (their exact t / last_t / samples so far) and ends; the first kHostedBlocks workgroups of the lookup launch (they are
+// dispatched first) take those rays 64 to a wave, run the very same march_probe() loop from the recorded state -- the same rows, bit
+// for bit -- and look the new rows up themselves on all 16 levels, while the other workgroups do the lookup of everybody else's rows
+// and skip the handed-over ones (a per-row flag the march wrote: stable for the whole launch, no race).  Field, composite and
+// compaction see a complete iteration.  Schedule, sample rows and per-ray arithmetic are unchanged.
+// ------------------------------------------------------------------------------------------
+struct StragglerRec { int32_t n, index, step; float t, last_t, far; int32_t pad0, pad1; };   // 32 bytes
+static_assert(sizeof(StragglerRec) == 32, "StragglerRec layout");
+constexpr int kQueueCtrs = 4;             // counters per set (two sets ping-ponged by iteration parity): [0] rays queued
+constexpr uint32_t kHostedBlocks = 256;   // workgroups of a lookup launch that serve the queue first (one wave per SIMD of the chip)
+constexpr uint32_t kMaxMarchBlocks = 2048;
+// What the hosted march tail needs on top of the lookup's own arguments.  The frame-constant part lives in the workspace (k_frame_init
+// writes it there from its own arguments): the lookup kernels' argument block stays the size it had.
+struct HostedConst {
+    const int32_t* qctr_all;      // [2][kQueueCtrs]: per iteration parity, [0] rays queued
+    const StragglerRec* qrecs;
+    const float* rays_o; const float* rays_d;
+    const uint8_t* bitfield; const uint32_t* mip;
+    MarchParams p;
+    float* xyzs; float* dirs; float* deltas;
+    int32_t* partials[2];         // per iteration parity: the march's per-workgroup sample counts; the hosted workgroups' follow at [partial_base]
+};
+struct HostedArgs {
+    const HostedConst* hc;
+    const uint8_t* rowflag;       // [rows] 1 = the row belongs to a queued ray (the ordinary workgroups skip it); nullptr = no flags this iteration
+    uint32_t blocks;              // workgroups at the front of the launch that serve the straggler queue (0: none)
+    uint32_t partial_base;        // first slot of the hosted workgroups in partials[parity] (= workgroups of this iteration's march launch)
+};
+
+
 __device__ __forceinline__ int schedule_n_step(int N, int n_alive) {  // nerf/renderer.py:364
     return n_alive > 0 ? max(min(N / n_alive, 8), 1) : 1;
 }
 
 __global__ void __launch_bounds__(kRayBlock) k_frame_init(uint32_t N, const float* __restrict__ nears, int32_t* __restrict__ alive,
                                                           float* __restrict__ rays_t, float* __restrict__ weights_sum, float* __restrict__ depth,
-                                                          float* __restrict__ image, FrameCtl* __restrict__ ctl, int32_t* __restrict__ counts) {
+                                                          float* __restrict__ image, FrameCtl* __restrict__ ctl, int32_t* __restrict__ counts,
+                                                          int32_t* __restrict__ qctr_all, HostedConst hc, HostedConst* __restrict__ hc_out) {
     const uint32_t i = blockIdx.x * kRayBlock + threadIdx.x;
     if (i < N) {
         alive[i] = (int32_t)i;   // the reference's arange (nerf/renderer.py:352)
@@ -58,6 +94,8 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_init(uint32_t N, const floa
         c.n_alive = (int32_t)N; c.n_step = 0; c.iterations = -1; c.done = N == 0;
         ctl[0] = c; ctl[1] = c;
         counts[1 - (int)kHdr] = 0;   // scratch[1]: the fp16-range overflow flag of this frame
+        for (int k = 0; k < 2 * kQueueCtrs; k++) qctr_all[k] = 0;   // both counter sets of the straggler queue
+        *hc_out = hc;
     }
 }
 
@@ -276,21 +314,28 @@ __device__ __forceinline__ uint32_t march_coop_tail(CoopShared& sh, const MarchP
 }
 
 #ifndef PNR_MARCH_WAVES
-#define PNR_MARCH_WAVES 4     // waves per SIMD the march kernel is compiled for (register budget 512 / PNR_MARCH_WAVES): with the cooperative tail it needs 114 VGPRs;
+#define PNR_MARCH_WAVES 4     // waves per SIMD the march kernel WITH the in-wave cooperative tail is compiled for (register budget 512 / PNR_MARCH_WAVES): it needs 114 VGPRs;
                               // squeezed into 80 (6 waves, all chunks of a later iteration resident at once) it spills and the lego frame is 0.3 ms slower (4.38 vs 4.07 ms)
 #endif
-template <bool MIP, bool POW2>
-__global__ void __launch_bounds__(kRayBlock) __attribute__((amdgpu_waves_per_eu(PNR_MARCH_WAVES))) k_frame_march(const FrameCtl* __restrict__ prev, FrameCtl* __restrict__ cur, const int32_t* __restrict__ alive_prev,
+#ifndef PNR_MARCH_WAVES_Q
+#define PNR_MARCH_WAVES_Q 5   // waves per SIMD of the budgeted march (MODE 2: no in-wave tail; 80 VGPRs spill 24 registers: 23 us per launch against 17.8 at 102)
+#endif
+// MODE 1: every ray is finished here, the last rays of a wave cooperatively (march_coop_tail; p.coop == 0: plain SIMT loop).
+// MODE 2: `budget` probe rounds per ray, then the rays still marching go to the straggler queue (hosted_march_tail finishes them).
+template <bool MIP, bool POW2, int MODE>
+__global__ void __launch_bounds__(kRayBlock) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? PNR_MARCH_WAVES_Q : PNR_MARCH_WAVES))) k_frame_march(const FrameCtl* __restrict__ prev, FrameCtl* __restrict__ cur, const int32_t* __restrict__ alive_prev,
                                                            int32_t* __restrict__ rays_alive, const int32_t* __restrict__ scratch, int32_t* __restrict__ scratch_rw, uint32_t N, uint32_t max_steps,
                                                            const int32_t* __restrict__ partials_prev, uint32_t n_partials_prev,
                                                            const float* __restrict__ rays_t, const float* __restrict__ rays_o,
                                                            const float* __restrict__ rays_d, MarchParams p, const uint8_t* __restrict__ grid,
                                                            const float* __restrict__ fars, float* __restrict__ xyzs, float* __restrict__ dirs,
                                                            float* __restrict__ deltas, const uint32_t* __restrict__ mip,
-                                                           int32_t* __restrict__ emitted_partials /* [gridDim.x] */) {
+                                                           int32_t* __restrict__ emitted_partials /* [gridDim.x] */, uint32_t budget,
+                                                           int32_t* __restrict__ qctr_all /* [2][kQueueCtrs] */, StragglerRec* __restrict__ qrecs,
+                                                           uint8_t* __restrict__ rowflag /* [rows]: 1 = the row belongs to a queued ray */) {
     __shared__ int csum[kRayBlock / PNR_WAVE];
     __shared__ unsigned long long red[kRayBlock / PNR_WAVE];
-    __shared__ CoopShared coop[kRayBlock / PNR_WAVE];
+    __shared__ CoopShared coop[MODE == 1 ? kRayBlock / PNR_WAVE : 1];
 #ifdef PNR_MARCH_TIMING
     const bool timing = prev->iterations + 1 == g_march_timing_iter && blockIdx.x * (kRayBlock / PNR_WAVE) < (uint32_t)kTimingWaves;
     const uint32_t twave = blockIdx.x * (kRayBlock / PNR_WAVE) + threadIdx.x / PNR_WAVE;
@@ -357,6 +402,7 @@ __global__ void __launch_bounds__(kRayBlock) __attribute__((amdgpu_waves_per_eu(
             c.pad0 = scratch[1];   // fp16-range overflow flag raised by a field launch of an earlier iteration (0 = none)
             *cur = c;
             scratch_rw[2] = 0;     // the wave-tile counter of this iteration's field launch
+            qctr_all[((c.iterations + 1) & 1) * kQueueCtrs] = 0;   // the NEXT iteration's straggler count (this iteration's set is in use; the other one was last read by the previous lookup launch)
         }
     }
     if (done || blockIdx.x >= nchunks) { if (threadIdx.x == 0) emitted_partials[blockIdx.x] = 0; return; }
@@ -419,9 +465,32 @@ __global__ void __launch_bounds__(kRayBlock) __attribute__((amdgpu_waves_per_eu(
         unsigned int kinds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
         bool active = keep && t < far;     // n_step >= 1
-        for (;;) {
+        [[maybe_unused]] bool queued = false;       // MODE 2: this lane's ray went to the straggler queue
+        [[maybe_unused]] uint32_t step_queued = 0;  // ... with this many samples already written here
+        for (uint32_t round = 0;; round++) {
             const unsigned long long am = __ballot(active);
-            if (am == 0ull || (p.coop && __popcll(am) <= kCoopRays)) break;
+            if (am == 0ull) break;
+            if constexpr (MODE == 1) { if (p.coop && __popcll(am) <= kCoopRays) break; }
+            if constexpr (MODE == 2) {
+                // a ray that has spent `budget` probes WITHOUT finding a sample is handed over (a ray that emits a sample per probe -- n_step of them in the
+                // last iterations -- is not a straggler): one counter atomic per wave and round in which any lane gives up
+                const bool give_up = active && round - step >= budget;
+                const unsigned long long gm = __ballot(give_up);
+                if (gm != 0ull) {
+                    int32_t* qctr = qctr_all + ((prev->iterations + 1) & 1) * kQueueCtrs;
+                    const int leader = __ffsll((long long)gm) - 1;
+                    int slot0 = 0;
+                    if (lane == leader) slot0 = atomicAdd(&qctr[0], __popcll(gm));
+                    slot0 = __builtin_amdgcn_readlane(slot0, leader);
+                    if (give_up) {
+                        StragglerRec r;
+                        r.n = (int32_t)n; r.index = index; r.step = (int32_t)step; r.t = t; r.last_t = last_t; r.far = far; r.pad0 = 0; r.pad1 = 0;
+                        qrecs[(uint32_t)slot0 + (uint32_t)__popcll(gm & ((1ull << lane) - 1ull))] = r;
+                        queued = true; step_queued = step; active = false;
+                    }
+                    if (gm == am) break;
+                }
+            }
             if (active) {
                 float x, y, z, dt;
 #ifdef PNR_MARCH_TIMING
@@ -451,8 +520,10 @@ __global__ void __launch_bounds__(kRayBlock) __attribute__((amdgpu_waves_per_eu(
                 active = t < far && step < n_step;
             }
         }
-        if (p.coop && __ballot(active) != 0ull)
-            step = march_coop_tail<MIP, POW2>(coop[wave], p, grid, mip_lds, n_step, active, c, t, far, last_t, n, step, xyzs, dirs, deltas);
+        if constexpr (MODE == 1) {
+            if (p.coop && __ballot(active) != 0ull)
+                step = march_coop_tail<MIP, POW2>(coop[wave], p, grid, mip_lds, n_step, active, c, t, far, last_t, n, step, xyzs, dirs, deltas);
+        }
 #ifdef PNR_MARCH_STATS
         if (keep) {
             const int so = prev->iterations + 1 == 0 ? 0 : 4;
@@ -469,6 +540,11 @@ __global__ void __launch_bounds__(kRayBlock) __attribute__((amdgpu_waves_per_eu(
 #endif
         if (keep) {
             emitted += step;
+            if constexpr (MODE == 2) {   // rows from step_queued on belong to the queue's consumer (samples, then the sentinel): the lookup's other workgroups skip them
+                uint8_t* pf = rowflag + (size_t)n * n_step;
+                for (uint32_t k = 0; k < n_step; k++) pf[k] = (queued && k >= step_queued) ? 1 : 0;
+                if (queued) step = n_step;
+            }
             float* pl = deltas + ((size_t)n * n_step + step) * 2;
             for (; step < n_step; step++) { pl[0] = 0.0f; pl[1] = 0.0f; pl += 2; }
         }
@@ -494,264 +570,144 @@ __global__ void __launch_bounds__(kRayBlock) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
-// gridencoder.cu:75-175 for D = 3, C = 2, fp32, fused with GridEncoder.forward's (x + bound) / (2 bound)
-// (gridencoder/grid.py:142); rows from the control block; dead slots (delta == 0) are skipped.
-struct GridSet { const float* table[3]; float* enc[3]; };  // up to three hash tables (encoder, encoder_palette, encoder_clip): blockIdx.z
-
-__global__ void __launch_bounds__(256) k_frame_grid(const FrameCtl* __restrict__ ctl, const float* __restrict__ xyzs, const float* __restrict__ deltas,
-                                                    GridSet gs, const int32_t* __restrict__ offsets, LevelParams lp,
-                                                    uint32_t level_stride, float bound, float two_bound, uint32_t gridtype) {
-    if (ctl->done) return;
-    const float* __restrict__ table = gs.table[blockIdx.z];
-    float* __restrict__ enc = gs.enc[blockIdx.z];
-    const uint32_t rows = (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step;
-    const uint32_t level = blockIdx.y;
-    const uint32_t off0 = (uint32_t)offsets[level];
-    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
-    const float* g = table + (size_t)off0 * 2;
-    const float scale = lp.scale[level];
-    const uint32_t resolution = lp.resolution[level];
-    for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < rows; b += gridDim.x * 256) {
-        if (deltas[(size_t)b * 2] == 0.0f) continue;
-        float in[3];
-        bool oob = false;
+// ------------------------------------------------------------------------------------------
+// Hash-grid lookup of the frame loop: gridencoder.cu:75-175 for D = 3, C = 2, fused with GridEncoder.forward's (x + bound) / (2 bound)
+// (gridencoder/grid.py:142); rows from the control block; dead slots (delta == 0) are skipped.  One row body per table layout
+// (grid_row<KIND>), used by the launch's ordinary workgroups -- level-major: blockIdx.y is the level, its constants are scalars --
+// and by the hosted march tail, which looks its own rows up on all levels.
+//   GK_SINGLE  up to three separate fp32 tables (encoder, encoder_palette, encoder_clip): blockIdx.z
+//   GK_PAIR    PaletteNeRF's `encoder` and `encoder_palette` (looked up at the same positions) interleaved row by row -- (a.x, a.y, b.x, b.y) =
+//              16 bytes per index: one gather fetches both tables' rows, the lookup of the pair costs the lane requests and L2->L1 line fills of
+//              ONE table.  Same corner order and fmaf chains as two separate lookups: the encoder outputs are bit-identical.
+//   GK_TRIPLE  --pred_clip: the three tables in one copy, 32 bytes per row (two 16-byte loads from the same sector per corner)
+//   GK_HALF1/2 fp16 tables (the reference's -O / --fp16 mode: `embeddings.to(torch.half)`, gridencoder/grid.py:38): 1 or 2 tables interleaved
+//              row by row, a row = NT x half2.  Interpolation with the reference's half accumulator -- every addend and every partial sum
+//              rounded to fp16 (gridencoder.cu:142,165 with scalar_t = at::Half) -- so the encoder output equals k_grid_fwd<__half>'s bit for
+//              bit; it is handed to the field kernel as fp32 (exact).
+// ------------------------------------------------------------------------------------------
+enum GridKind { GK_SINGLE = 0, GK_PAIR = 1, GK_TRIPLE = 2, GK_HALF1 = 3, GK_HALF2 = 4 };
+struct GridArgs {
+    const float* xyzs; const float* deltas;
+    const void* table[3]; float* enc[3];
+    const int32_t* offsets; LevelParams lp;
+    uint32_t level_stride; float bound, two_bound; uint32_t gridtype;
+};
+struct LevelCtx { uint32_t off0, hashmap_size, resolution; float scale; };
+__device__ __forceinline__ LevelCtx level_ctx(const GridArgs& g, uint32_t level) {
+    LevelCtx lc;
+    lc.off0 = (uint32_t)g.offsets[level];
+    lc.hashmap_size = (uint32_t)g.offsets[level + 1] - lc.off0;
+    lc.scale = g.lp.scale[level];
+    lc.resolution = g.lp.resolution[level];
+    return lc;
+}
+// the eight corners of row b's cell on one level: row indices (x CMUL) and the fractional position the weights come from; false = the point is outside [0, 1]^3
+template <uint32_t CMUL>
+__device__ __forceinline__ bool grid_corner_rows(const GridArgs& g, const LevelCtx& lc, uint32_t b, uint32_t idxs[8], float pos[3]) {
+    float in[3];
+    bool oob = false;
 #pragma unroll
-        for (int d = 0; d < 3; d++) {
-            in[d] = (xyzs[(size_t)b * 3 + d] + bound) / two_bound;
-            oob |= (in[d] < 0.0f) | (in[d] > 1.0f);
-        }
-        float2 out = make_float2(0.0f, 0.0f);
-        if (!oob) {
-            float pos[3];
-            uint32_t pg[3];
+    for (int d = 0; d < 3; d++) {
+        in[d] = (g.xyzs[(size_t)b * 3 + d] + g.bound) / g.two_bound;
+        oob |= (in[d] < 0.0f) | (in[d] > 1.0f);
+    }
+    if (oob) return false;
+    uint32_t pg[3];
 #pragma unroll
-            for (int d = 0; d < 3; d++) {
-                pos[d] = fmaf(in[d], scale, 0.5f);
-                const float fl = floorf(pos[d]);
-                pg[d] = (uint32_t)fl;
-                pos[d] -= (float)pg[d];
-            }
-            uint32_t idxs[8];
-            float ws[8];
+    for (int d = 0; d < 3; d++) {
+        pos[d] = fmaf(in[d], lc.scale, 0.5f);
+        const float fl = floorf(pos[d]);
+        pg[d] = (uint32_t)fl;
+        pos[d] -= (float)pg[d];
+    }
 #pragma unroll
-            for (uint32_t idx = 0; idx < 8; idx++) {
-                float w = 1.0f;
-                uint32_t pl[3];
+    for (uint32_t idx = 0; idx < 8; idx++) {
+        uint32_t pl[3];
 #pragma unroll
-                for (uint32_t d = 0; d < 3; d++) {
-                    if ((idx & (1u << d)) == 0) { w *= 1.0f - pos[d]; pl[d] = pg[d]; }
-                    else { w *= pos[d]; pl[d] = pg[d] + 1; }
-                }
-                ws[idx] = w;
-                idxs[idx] = grid_index<3, 2>(gridtype, false, hashmap_size, resolution, pl);
-            }
-            float acc[2] = {0.0f, 0.0f};
+        for (uint32_t d = 0; d < 3; d++) pl[d] = pg[d] + ((idx >> d) & 1u);
+        idxs[idx] = grid_index<3, CMUL>(g.gridtype, false, lc.hashmap_size, lc.resolution, pl);
+    }
+    return true;
+}
+// trilinear weights in the reference's order of multiplications (gridencoder.cu:150-163)
+__device__ __forceinline__ void grid_corner_weights(const float pos[3], float ws[8]) {
 #pragma unroll
-            for (uint32_t idx = 0; idx < 8; idx++) corner_accumulate<2>(acc, ws[idx], g + idxs[idx]);
-            out = make_float2(acc[0], acc[1]);
-        }
-        *reinterpret_cast<float2*>(enc + ((size_t)level * level_stride + b) * 2) = out;
+    for (uint32_t idx = 0; idx < 8; idx++) {
+        float w = 1.0f;
+#pragma unroll
+        for (uint32_t d = 0; d < 3; d++) w *= (idx & (1u << d)) ? pos[d] : 1.0f - pos[d];
+        ws[idx] = w;
     }
 }
-
-// fp16 tables (the reference's -O / --fp16 mode: `embeddings.to(torch.half)`, gridencoder/grid.py:38): NT tables interleaved row by
-// row, a row = NT x half2 (4 or 8 bytes).  Interpolation with the reference's half accumulator -- every addend and every partial
-// sum rounded to fp16 (gridencoder.cu:142,165 with scalar_t = at::Half) -- so the encoder output equals k_grid_fwd<__half>'s bit
-// for bit; it is handed to the field kernel as fp32 (exact).
-template <int NT>
-__global__ void __launch_bounds__(256) k_frame_grid_h(const FrameCtl* __restrict__ ctl, const float* __restrict__ xyzs, const float* __restrict__ deltas,
-                                                      const __half* __restrict__ table, float* __restrict__ enc_a, float* __restrict__ enc_b,
-                                                      const int32_t* __restrict__ offsets, LevelParams lp, uint32_t level_stride, float bound,
-                                                      float two_bound, uint32_t gridtype) {
-    if (ctl->done) return;
-    const uint32_t rows = (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step;
-    const uint32_t level = blockIdx.y;
-    const uint32_t off0 = (uint32_t)offsets[level];
-    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
-    const __half* g = table + (size_t)off0 * 2 * NT;
-    const float scale = lp.scale[level];
-    const uint32_t resolution = lp.resolution[level];
-    for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < rows; b += gridDim.x * 256) {
-        if (deltas[(size_t)b * 2] == 0.0f) continue;
-        float in[3];
-        bool oob = false;
+// The eight gathers of a row go out first, back to back, and the weights are formed while they are in flight: every address exists before
+// the first load (one empty asm statement with all of them as operands pins that point) and nothing is scheduled across the end of the
+// group.  Left to itself the compiler does this too -- until it is asked to keep the kernel within a register budget
+// (amdgpu_waves_per_eu, which the hosted tail needs): then it forms the weights first and threads the loads between the address
+// arithmetic, and the lego launch takes 76 instead of 66 us with the very same instructions (profiles/scratch/prof_ref.sh).
+typedef float f32x2 __attribute__((ext_vector_type(2)));   // (built-in vector types: a load through an address-space pointer needs no operator=)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <typename T>
+struct GlobalPtr { typedef const T __attribute__((address_space(1))) * type; };   // (the asm statement hides where a pointer came from: say "global" again, or the loads become flat_load)
+// ORDERED = false (the hosted tail's own few rows; GK_TRIPLE, whose 16 addresses + 48 values do not fit the budget): the compiler's order.
+template <typename T, uint32_t MUL, bool ORDERED>
+__device__ __forceinline__ void gather8(const T* tab, const uint32_t idxs[8], T v[8]) {
+    const T* p[8];
 #pragma unroll
-        for (int d = 0; d < 3; d++) {
-            in[d] = (xyzs[(size_t)b * 3 + d] + bound) / two_bound;
-            oob |= (in[d] < 0.0f) | (in[d] > 1.0f);
-        }
-        __half acc[2 * NT];
+    for (int i = 0; i < 8; i++) p[i] = tab + (size_t)idxs[i] * MUL;
+    if constexpr (!ORDERED) {
 #pragma unroll
-        for (int ch = 0; ch < 2 * NT; ch++) acc[ch] = __float2half(0.0f);
-        if (!oob) {
-            float pos[3];
-            uint32_t pg[3];
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                pos[d] = fmaf(in[d], scale, 0.5f);
-                const float fl = floorf(pos[d]);
-                pg[d] = (uint32_t)fl;
-                pos[d] -= (float)pg[d];
-            }
-            uint32_t idxs[8];
-            float ws[8];
-#pragma unroll
-            for (uint32_t idx = 0; idx < 8; idx++) {
-                float w = 1.0f;
-                uint32_t pl[3];
-#pragma unroll
-                for (uint32_t d = 0; d < 3; d++) {
-                    if ((idx & (1u << d)) == 0) { w *= 1.0f - pos[d]; pl[d] = pg[d]; }
-                    else { w *= pos[d]; pl[d] = pg[d] + 1; }
-                }
-                ws[idx] = w;
-                idxs[idx] = grid_index<3, 1>(gridtype, false, hashmap_size, resolution, pl);
-            }
-#pragma unroll
-            for (uint32_t idx = 0; idx < 8; idx++) corner_accumulate<2 * NT>(acc, ws[idx], g + (size_t)idxs[idx] * 2 * NT);
-        }
-        *reinterpret_cast<float2*>(enc_a + ((size_t)level * level_stride + b) * 2) = make_float2(__half2float(acc[0]), __half2float(acc[1]));
-        if constexpr (NT == 2)
-            *reinterpret_cast<float2*>(enc_b + ((size_t)level * level_stride + b) * 2) = make_float2(__half2float(acc[2]), __half2float(acc[3]));
+        for (int i = 0; i < 8; i++) v[i] = *p[i];
+        return;
     }
-}
-
-// Two hash tables with one level layout (PaletteNeRF's `encoder` and `encoder_palette` are looked up at the same positions)
-// interleaved row by row -- (a.x, a.y, b.x, b.y) = 16 bytes per index: one gather fetches both tables' rows, so the lookup of
-// the pair costs the lane requests and L2->L1 line fills of ONE table.  Same corner order and fmaf chains as two separate
-// lookups: the encoder outputs are bit-identical.
-__global__ void __launch_bounds__(256) k_interleave_tables(const float2* __restrict__ a, const float2* __restrict__ b, uint64_t rows,
-                                                           float4* __restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < rows) { const float2 u = a[i], v = b[i]; out[i] = make_float4(u.x, u.y, v.x, v.y); }
-}
-
-__global__ void __launch_bounds__(256) k_frame_grid_pair(const FrameCtl* __restrict__ ctl, const float* __restrict__ xyzs, const float* __restrict__ deltas,
-                                                         const float4* __restrict__ table, float* __restrict__ enc_a, float* __restrict__ enc_b,
-                                                         const int32_t* __restrict__ offsets, LevelParams lp, uint32_t level_stride, float bound,
-                                                         float two_bound, uint32_t gridtype) {
-    if (ctl->done) return;
-    const uint32_t rows = (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step;
-    const uint32_t level = blockIdx.y;
-    const uint32_t off0 = (uint32_t)offsets[level];
-    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
-    const float4* g = table + off0;
-    const float scale = lp.scale[level];
-    const uint32_t resolution = lp.resolution[level];
-    for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < rows; b += gridDim.x * 256) {
-        if (deltas[(size_t)b * 2] == 0.0f) continue;
-        float in[3];
-        bool oob = false;
+    asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]));
 #pragma unroll
-        for (int d = 0; d < 3; d++) {
-            in[d] = (xyzs[(size_t)b * 3 + d] + bound) / two_bound;
-            oob |= (in[d] < 0.0f) | (in[d] > 1.0f);
+    for (int i = 0; i < 8; i++) v[i] = *(typename GlobalPtr<T>::type)(uintptr_t)p[i];
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef PNR_GATHER_MAY_OVERWRITE_ADDRESS
+    // (the addresses stay alive past the loads, so no load returns into the registers its own address came from)
+    asm volatile("" :: "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]));
+#endif
+}
+// (table / enc0: the table and first output of this call -- GK_SINGLE picks them per blockIdx.z; resolved by the caller, outside its row loop)
+template <int KIND, bool ORDERED = true>
+__device__ __forceinline__ void grid_row(const GridArgs& g, const LevelCtx& lc, uint32_t level, const void* __restrict__ table, float* __restrict__ enc0, uint32_t b) {
+    uint32_t idxs[8];
+    float pos[3], ws[8];
+    const size_t o = ((size_t)level * g.level_stride + b) * 2;
+    if constexpr (KIND == GK_SINGLE) {
+        float acc[2] = {0.0f, 0.0f};
+        if (grid_corner_rows<1>(g, lc, b, idxs, pos)) {
+            f32x2 v[8];
+            gather8<f32x2, 1, ORDERED>(static_cast<const f32x2*>(table) + lc.off0, idxs, v);
+            grid_corner_weights(pos, ws);
+#pragma unroll
+            for (uint32_t idx = 0; idx < 8; idx++) { acc[0] = fmaf(ws[idx], v[idx].x, acc[0]); acc[1] = fmaf(ws[idx], v[idx].y, acc[1]); }
         }
+        *reinterpret_cast<float2*>(enc0 + o) = make_float2(acc[0], acc[1]);
+    } else if constexpr (KIND == GK_PAIR) {
         float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (!oob) {
-            float pos[3];
-            uint32_t pg[3];
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                pos[d] = fmaf(in[d], scale, 0.5f);
-                const float fl = floorf(pos[d]);
-                pg[d] = (uint32_t)fl;
-                pos[d] -= (float)pg[d];
-            }
-            uint32_t idxs[8];
-            float ws[8];
-#pragma unroll
-            for (uint32_t idx = 0; idx < 8; idx++) {
-                float w = 1.0f;
-                uint32_t pl[3];
-#pragma unroll
-                for (uint32_t d = 0; d < 3; d++) {
-                    if ((idx & (1u << d)) == 0) { w *= 1.0f - pos[d]; pl[d] = pg[d]; }
-                    else { w *= pos[d]; pl[d] = pg[d] + 1; }
-                }
-                ws[idx] = w;
-                idxs[idx] = grid_index<3, 1>(gridtype, false, hashmap_size, resolution, pl);
-            }
-            float4 v[8];
-#pragma unroll
-            for (uint32_t idx = 0; idx < 8; idx++) v[idx] = g[idxs[idx]];
+        if (grid_corner_rows<1>(g, lc, b, idxs, pos)) {
+            f32x4 v[8];
+            gather8<f32x4, 1, ORDERED>(static_cast<const f32x4*>(table) + lc.off0, idxs, v);
+            grid_corner_weights(pos, ws);
 #pragma unroll
             for (uint32_t idx = 0; idx < 8; idx++) {
                 out.x = fmaf(ws[idx], v[idx].x, out.x); out.y = fmaf(ws[idx], v[idx].y, out.y);
                 out.z = fmaf(ws[idx], v[idx].z, out.z); out.w = fmaf(ws[idx], v[idx].w, out.w);
             }
         }
-        *reinterpret_cast<float2*>(enc_a + ((size_t)level * level_stride + b) * 2) = make_float2(out.x, out.y);
-        *reinterpret_cast<float2*>(enc_b + ((size_t)level * level_stride + b) * 2) = make_float2(out.z, out.w);
-    }
-}
-
-// --pred_clip: `encoder`, `encoder_palette` and `encoder_clip` in one copy, 32 bytes per row (two 16-byte loads from the same sector
-// per corner instead of three scattered 8-byte ones); same corner order and fmaf chains: bit-identical encoder outputs
-__global__ void __launch_bounds__(256) k_interleave_tables3(const float2* __restrict__ a, const float2* __restrict__ b, const float2* __restrict__ c,
-                                                            uint64_t rows, float4* __restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < rows) {
-        const float2 u = a[i], v = b[i], t = c[i];
-        out[2 * i] = make_float4(u.x, u.y, v.x, v.y);
-        out[2 * i + 1] = make_float4(t.x, t.y, 0.0f, 0.0f);
-    }
-}
-
-__global__ void __launch_bounds__(256) k_frame_grid_triple(const FrameCtl* __restrict__ ctl, const float* __restrict__ xyzs, const float* __restrict__ deltas,
-                                                           const float4* __restrict__ table, float* __restrict__ enc_a, float* __restrict__ enc_b,
-                                                           float* __restrict__ enc_c, const int32_t* __restrict__ offsets, LevelParams lp,
-                                                           uint32_t level_stride, float bound, float two_bound, uint32_t gridtype) {
-    if (ctl->done) return;
-    const uint32_t rows = (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step;
-    const uint32_t level = blockIdx.y;
-    const uint32_t off0 = (uint32_t)offsets[level];
-    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
-    const float4* g = table + (size_t)off0 * 2;
-    const float scale = lp.scale[level];
-    const uint32_t resolution = lp.resolution[level];
-    for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < rows; b += gridDim.x * 256) {
-        if (deltas[(size_t)b * 2] == 0.0f) continue;
-        float in[3];
-        bool oob = false;
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-            in[d] = (xyzs[(size_t)b * 3 + d] + bound) / two_bound;
-            oob |= (in[d] < 0.0f) | (in[d] > 1.0f);
-        }
+        *reinterpret_cast<float2*>(enc0 + o) = make_float2(out.x, out.y);
+        *reinterpret_cast<float2*>(g.enc[1] + o) = make_float2(out.z, out.w);
+    } else if constexpr (KIND == GK_TRIPLE) {
         float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         float2 outc = make_float2(0.0f, 0.0f);
-        if (!oob) {
-            float pos[3];
-            uint32_t pg[3];
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                pos[d] = fmaf(in[d], scale, 0.5f);
-                const float fl = floorf(pos[d]);
-                pg[d] = (uint32_t)fl;
-                pos[d] -= (float)pg[d];
-            }
-            uint32_t idxs[8];
-            float ws[8];
-#pragma unroll
-            for (uint32_t idx = 0; idx < 8; idx++) {
-                float w = 1.0f;
-                uint32_t pl[3];
-#pragma unroll
-                for (uint32_t d = 0; d < 3; d++) {
-                    if ((idx & (1u << d)) == 0) { w *= 1.0f - pos[d]; pl[d] = pg[d]; }
-                    else { w *= pos[d]; pl[d] = pg[d] + 1; }
-                }
-                ws[idx] = w;
-                idxs[idx] = grid_index<3, 1>(gridtype, false, hashmap_size, resolution, pl);
-            }
-            float4 v[8];
-            float2 vc[8];
-#pragma unroll
-            for (uint32_t idx = 0; idx < 8; idx++) {
-                v[idx] = g[(size_t)idxs[idx] * 2];
-                vc[idx] = *reinterpret_cast<const float2*>(&g[(size_t)idxs[idx] * 2 + 1]);
-            }
+        if (grid_corner_rows<1>(g, lc, b, idxs, pos)) {
+            f32x4 v[8];
+            f32x2 vc[8];
+            const f32x4* tab = static_cast<const f32x4*>(table) + (size_t)lc.off0 * 2;
+            gather8<f32x4, 2, false>(tab, idxs, v);
+            gather8<f32x2, 4, false>(reinterpret_cast<const f32x2*>(tab + 1), idxs, vc);
+            grid_corner_weights(pos, ws);
 #pragma unroll
             for (uint32_t idx = 0; idx < 8; idx++) {
                 out.x = fmaf(ws[idx], v[idx].x, out.x); out.y = fmaf(ws[idx], v[idx].y, out.y);
@@ -759,9 +715,220 @@ __global__ void __launch_bounds__(256) k_frame_grid_triple(const FrameCtl* __res
                 outc.x = fmaf(ws[idx], vc[idx].x, outc.x); outc.y = fmaf(ws[idx], vc[idx].y, outc.y);
             }
         }
-        *reinterpret_cast<float2*>(enc_a + ((size_t)level * level_stride + b) * 2) = make_float2(out.x, out.y);
-        *reinterpret_cast<float2*>(enc_b + ((size_t)level * level_stride + b) * 2) = make_float2(out.z, out.w);
-        *reinterpret_cast<float2*>(enc_c + ((size_t)level * level_stride + b) * 2) = outc;
+        *reinterpret_cast<float2*>(enc0 + o) = make_float2(out.x, out.y);
+        *reinterpret_cast<float2*>(g.enc[1] + o) = make_float2(out.z, out.w);
+        *reinterpret_cast<float2*>(g.enc[2] + o) = outc;
+    } else {
+        constexpr int NT = KIND == GK_HALF2 ? 2 : 1;
+        typedef uint32_t RowT __attribute__((ext_vector_type(NT)));   // NT x half2
+        __half acc[2 * NT];
+#pragma unroll
+        for (int ch = 0; ch < 2 * NT; ch++) acc[ch] = __float2half(0.0f);
+        if (grid_corner_rows<1>(g, lc, b, idxs, pos)) {
+            RowT v[8];
+            gather8<RowT, 1, ORDERED>(static_cast<const RowT*>(table) + lc.off0, idxs, v);
+            grid_corner_weights(pos, ws);
+#pragma unroll
+            for (uint32_t idx = 0; idx < 8; idx++) {
+                __half hv[2 * NT];
+                __builtin_memcpy(hv, &v[idx], sizeof(RowT));
+#pragma unroll
+                for (int ch = 0; ch < 2 * NT; ch++)   // the reference's half accumulator: addend and sum rounded to fp16 (corner_accumulate<__half>)
+                    acc[ch] = __float2half(__half2float(acc[ch]) + __half2float(__float2half(ws[idx] * __half2float(hv[ch]))));
+            }
+        }
+        *reinterpret_cast<float2*>(enc0 + o) = make_float2(__half2float(acc[0]), __half2float(acc[1]));
+        if constexpr (NT == 2) *reinterpret_cast<float2*>(g.enc[1] + o) = make_float2(__half2float(acc[2]), __half2float(acc[3]));
+    }
+}
+
+#ifdef PNR_HOSTED_TIMING
+// instrumented builds only: wall-clock stamps (100 MHz) of ONE iteration's lookup launch.  [0..7]: launch-wide (earliest start, latest end of an
+// ordinary workgroup, latest end of a hosted one, rays queued); then 8 per hosted workgroup: start, mip staged, march done, lookups done, probes of its slowest lane
+__device__ unsigned long long g_hosted_timing[8 + 8 * 256 + 2 * 16 * 128];   // ... then (start, end) of every 16th ordinary workgroup of the first 2048 per level
+__device__ int g_hosted_timing_iter = 3;
+#endif
+#ifndef PNR_HOSTED_JUMPS
+#define PNR_HOSTED_JUMPS false
+#endif
+// The queue's consumer: rays_per_wave rays to a wave (8 when the queue is short -- the lookups that follow then spread over more waves --
+// up to 64), the march loop of k_frame_march from the recorded state, then the new rows' lookups, (row, level) pairs dealt to the lanes.
+template <int KIND>
+__device__ __forceinline__ void hosted_march_tail(const FrameCtl* ctl, const GridArgs& g, const HostedArgs& ha) {
+    struct { uint32_t blocks; const int32_t* qctr; const StragglerRec* qrecs; const float* rays_o; const float* rays_d; const uint8_t* bitfield;
+             const uint32_t* mip; MarchParams p; float* xyzs; float* dirs; float* deltas; int32_t* partials; } h;
+    {
+        const HostedConst* hc = ha.hc;
+        const int par = ctl->iterations & 1;
+        h.blocks = ha.blocks; h.qctr = hc->qctr_all + par * kQueueCtrs; h.qrecs = hc->qrecs; h.rays_o = hc->rays_o; h.rays_d = hc->rays_d;
+        h.bitfield = hc->bitfield; h.mip = hc->mip; h.p = hc->p; h.xyzs = hc->xyzs; h.dirs = hc->dirs; h.deltas = hc->deltas;
+        h.partials = hc->partials[par] + ha.partial_base;
+    }
+    // These waves carry a dependent chain and share their SIMD with up to seven lookup waves that have plenty of independent work: they go first.
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ float lv_scale[16];
+    __shared__ uint32_t lv_res[16], lv_off[16], lv_size[16];
+    __shared__ uint32_t wrows[kRayBlock / PNR_WAVE][PNR_WAVE];
+    __shared__ uint32_t wemit[kRayBlock / PNR_WAVE];
+    const uint32_t count = (uint32_t)h.qctr[0];
+    const int lane = threadIdx.x & (PNR_WAVE - 1), wave = threadIdx.x / PNR_WAVE;
+    const uint32_t glog = count > 32768u ? 6u : (count > 16384u ? 5u : (count > 8192u ? 4u : 3u));
+    const uint32_t G = 1u << glog;
+    const uint32_t ntasks = (count + G - 1) >> glog;
+    if (blockIdx.x >= ntasks) { if (threadIdx.x == 0) h.partials[blockIdx.x] = 0; return; }   // block-uniform (also: count == 0)
+#ifdef PNR_HOSTED_TIMING
+    const bool timing = ctl->iterations == g_hosted_timing_iter;
+    unsigned long long* tm = g_hosted_timing + 8 + 8 * blockIdx.x;
+    uint32_t my_probes = 0;
+    if (timing && threadIdx.x == 0) { tm[0] = wall_clock64(); g_hosted_timing[3] = count; }
+#endif
+    const uint32_t* mip_lds = stage_mip(h.mip, h.p.mip_words);
+#ifdef PNR_HOSTED_TIMING
+    if (timing && threadIdx.x == 0) tm[1] = wall_clock64();
+#endif
+    if (threadIdx.x < 16) {
+        const LevelCtx lc = level_ctx(g, threadIdx.x);
+        lv_scale[threadIdx.x] = lc.scale; lv_res[threadIdx.x] = lc.resolution; lv_off[threadIdx.x] = lc.off0; lv_size[threadIdx.x] = lc.hashmap_size;
+    }
+    __syncthreads();
+    const uint32_t n_step = (uint32_t)ctl->n_step;
+    const uint32_t n_tab = KIND == GK_SINGLE ? gridDim.z : 1u;
+    uint32_t emitted = 0;
+    for (uint32_t task = (uint32_t)wave * h.blocks + blockIdx.x; task < ntasks; task += h.blocks * (kRayBlock / PNR_WAVE)) {
+        const uint32_t qi = (task << glog) + (uint32_t)lane;
+        const bool have = (uint32_t)lane < G && qi < count;
+        StragglerRec r = {};
+        if (have) r = h.qrecs[qi];
+        const uint32_t row0 = (uint32_t)r.n * n_step;
+        uint32_t step = (uint32_t)r.step;
+        if (have) {
+            RayCtx c;
+            ctx_init(c, h.rays_o + (size_t)r.index * 3, h.rays_d + (size_t)r.index * 3, h.p, h.bitfield, mip_lds);
+            float t = r.t, last_t = r.last_t;
+            bool active = t < r.far && step < n_step;
+            while (active) {
+                float x, y, z, dt;
+#ifdef PNR_HOSTED_TIMING
+                my_probes++;
+#endif
+                if (march_probe<true, true, PNR_HOSTED_JUMPS>(c, t, x, y, z, dt)) {
+                    const size_t row = (size_t)row0 + step;
+                    float* px = h.xyzs + row * 3;
+                    float* pd = h.dirs + row * 3;
+                    float* pl = h.deltas + row * 2;
+                    px[0] = x; px[1] = y; px[2] = z;
+                    pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
+                    t += dt;
+                    pl[0] = dt; pl[1] = t - last_t;
+                    last_t = t;
+                    step++;
+                }
+                active = t < r.far && step < n_step;
+            }
+            emitted += step - (uint32_t)r.step;
+            float* pl = h.deltas + ((size_t)row0 + step) * 2;
+            for (uint32_t k = step; k < n_step; k++) { pl[0] = 0.0f; pl[1] = 0.0f; pl += 2; }   // the unfilled slots' sentinel
+        }
+        // lookups of the rows just written (this wave's own stores: program order + the fence make them visible to its loads)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#ifdef PNR_HOSTED_TIMING
+        if (timing) {
+            uint32_t mp = my_probes;
+            for (int off = 32; off > 0; off >>= 1) mp = max(mp, (uint32_t)__shfl_xor((int)mp, off, 64));
+            if (lane == 0) { atomicMax(&tm[2], wall_clock64()); atomicMax(&tm[4], (unsigned long long)mp); }
+        }
+#endif
+        const uint32_t nnew = have ? step - (uint32_t)r.step : 0u;
+        for (uint32_t k = 0; k < n_step; k++) {   // the k-th new row of every ray that has one (n_step is 1 in most iterations)
+            const bool has_row = k < nnew;
+            const unsigned long long m = __ballot(has_row);
+            if (m == 0ull) break;
+            const uint32_t cnt = (uint32_t)__popcll(m);
+            if (has_row) wrows[wave][__popcll(m & ((1ull << lane) - 1ull))] = row0 + (uint32_t)r.step + k;
+            wave_lds_sync();
+            for (uint32_t pi = (uint32_t)lane; pi < cnt * 16u; pi += PNR_WAVE) {
+                const uint32_t b = wrows[wave][pi >> 4], level = pi & 15u;
+                LevelCtx lc;
+                lc.scale = lv_scale[level]; lc.resolution = lv_res[level]; lc.off0 = lv_off[level]; lc.hashmap_size = lv_size[level];
+                for (uint32_t tz = 0; tz < n_tab; tz++) grid_row<KIND, false>(g, lc, level, g.table[tz], g.enc[tz], b);
+            }
+            wave_lds_sync();
+        }
+    }
+    for (int off = PNR_WAVE / 2; off > 0; off >>= 1) emitted += __shfl_xor(emitted, off, PNR_WAVE);
+    if (lane == 0) wemit[wave] = emitted;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int wv = 0; wv < (int)(kRayBlock / PNR_WAVE); wv++) tot += wemit[wv];
+        h.partials[blockIdx.x] = (int32_t)tot;
+#ifdef PNR_HOSTED_TIMING
+        if (timing) tm[3] = wall_clock64();
+#endif
+    }
+}
+
+template <int KIND>
+__device__ __forceinline__ void frame_grid_body(const FrameCtl* __restrict__ ctl, const GridArgs& g, const HostedArgs& h) {
+    if (ctl->done) return;
+    uint32_t bx = blockIdx.x;
+    if (h.blocks) {   // launch-uniform
+        if (bx < h.blocks) {
+#ifndef PNR_NO_HOSTED_CODE
+            if (blockIdx.y == 0 && blockIdx.z == 0) hosted_march_tail<KIND>(ctl, g, h);
+#endif
+            return;
+        }
+        bx -= h.blocks;
+    }
+    const uint32_t stride = (gridDim.x - h.blocks) * 256u;
+    const uint32_t rows = (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step;
+    const uint32_t level = blockIdx.y;
+#ifdef PNR_HOSTED_TIMING
+    const bool timing = ctl->iterations == g_hosted_timing_iter && (bx & 15u) == 0 && bx < 2048u && blockIdx.z == 0;
+    unsigned long long* tmm = g_hosted_timing + 8 + 8 * 256 + 2 * (level * 128 + (bx >> 4));
+    if (timing && threadIdx.x == 0) tmm[0] = wall_clock64();
+#endif
+    const LevelCtx lc = level_ctx(g, level);
+    const void* table = g.table[KIND == GK_SINGLE ? blockIdx.z : 0];
+    float* enc0 = g.enc[KIND == GK_SINGLE ? blockIdx.z : 0];
+    for (uint32_t b = bx * 256u + threadIdx.x; b < rows; b += stride) {
+        const float d0 = g.deltas[(size_t)b * 2];
+        const uint32_t fl = h.rowflag ? h.rowflag[b] : 0u;
+        if (d0 == 0.0f || fl) continue;
+        grid_row<KIND>(g, lc, level, table, enc0, b);
+    }
+#ifdef PNR_HOSTED_TIMING
+    if (timing && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tmm[1] = wall_clock64(); }
+#endif
+}
+
+#ifndef PNR_GRID_WAVES
+#define PNR_GRID_WAVES 8
+#endif
+#define PNR_GRID_KERNEL(NAME, KIND)                                                                                                          \
+    __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PNR_GRID_WAVES))) NAME(const FrameCtl* __restrict__ ctl, GridArgs g, HostedArgs h) { \
+        frame_grid_body<KIND>(ctl, g, h);                                                                                                    \
+    }
+PNR_GRID_KERNEL(k_frame_grid, GK_SINGLE)
+PNR_GRID_KERNEL(k_frame_grid_pair, GK_PAIR)
+PNR_GRID_KERNEL(k_frame_grid_triple, GK_TRIPLE)
+PNR_GRID_KERNEL(k_frame_grid_h1, GK_HALF1)
+PNR_GRID_KERNEL(k_frame_grid_h2, GK_HALF2)
+#undef PNR_GRID_KERNEL
+
+__global__ void __launch_bounds__(256) k_interleave_tables(const float2* __restrict__ a, const float2* __restrict__ b, uint64_t rows,
+                                                           float4* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < rows) { const float2 u = a[i], v = b[i]; out[i] = make_float4(u.x, u.y, v.x, v.y); }
+}
+__global__ void __launch_bounds__(256) k_interleave_tables3(const float2* __restrict__ a, const float2* __restrict__ b, const float2* __restrict__ c,
+                                                            uint64_t rows, float4* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < rows) {
+        const float2 u = a[i], v = b[i], t = c[i];
+        out[2 * i] = make_float4(u.x, u.y, v.x, v.y);
+        out[2 * i + 1] = make_float4(t.x, t.y, 0.0f, 0.0f);
     }
 }
 
@@ -945,7 +1112,11 @@ struct FrameWorkspace {
     void* edit;                       // palette model only: device image of the edit parameters
     float *s_o, *s_d, *s_near, *s_far, *s_ws, *s_depth, *s_image, *s_aux;  // ray_order: inputs / outputs in processing order
     int32_t* scratch;
-    int32_t* partials[2];   // the march's per-workgroup sample counts: written by iteration i, summed by iteration i + 1
+    int32_t* partials[2];   // the march's per-workgroup sample counts (+ the hosted tail's): written by iteration i, summed by iteration i + 1
+    HostedConst* hosted;    // hosted march tail: frame constants (written by k_frame_init)
+    int32_t* qctr;          // straggler queue: two counter sets ...
+    StragglerRec* qrecs;    // ... its records (one iteration's worth: a march launch fills it, the lookup launch that follows empties it) ...
+    uint8_t* rowflag;       // ... and the per-row "belongs to a queued ray" flags
     uint64_t bytes;
 };
 static FrameWorkspace carve(void* base, uint32_t N, uint32_t aux_stride = 0, bool with_clip = false) {
@@ -964,8 +1135,8 @@ static FrameWorkspace carve(void* base, uint32_t N, uint32_t aux_stride = 0, boo
     w.sigmas = reinterpret_cast<float*>(take(n * 4));
     w.rgbs = reinterpret_cast<float*>(take(n * 12));
     w.scratch = reinterpret_cast<int32_t*>(take((kHdr + n / kRayBlock + 2) * 4));
-    w.partials[0] = reinterpret_cast<int32_t*>(take(2048 * 4));
-    w.partials[1] = reinterpret_cast<int32_t*>(take(2048 * 4));
+    w.partials[0] = reinterpret_cast<int32_t*>(take((kMaxMarchBlocks + kHostedBlocks) * 4));
+    w.partials[1] = reinterpret_cast<int32_t*>(take((kMaxMarchBlocks + kHostedBlocks) * 4));
     w.enc_pal = w.enc_clip = w.aux = nullptr;
     w.edit = nullptr;
     if (aux_stride) {
@@ -979,6 +1150,11 @@ static FrameWorkspace carve(void* base, uint32_t N, uint32_t aux_stride = 0, boo
     w.s_ws = reinterpret_cast<float*>(take(n * 4)); w.s_depth = reinterpret_cast<float*>(take(n * 4));
     w.s_image = reinterpret_cast<float*>(take(n * 12));
     w.s_aux = aux_stride ? reinterpret_cast<float*>(take(n * aux_stride * 4)) : nullptr;
+    // (the hosted tail's arrays come last: everything above keeps the offsets it had)
+    w.hosted = reinterpret_cast<HostedConst*>(take(sizeof(HostedConst)));
+    w.qctr = reinterpret_cast<int32_t*>(take(2 * kQueueCtrs * 4));
+    w.qrecs = reinterpret_cast<StragglerRec*>(take(n * sizeof(StragglerRec)));
+    w.rowflag = reinterpret_cast<uint8_t*>(take(n));
     w.bytes = off;
     return w;
 }
@@ -1046,10 +1222,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
         out_ws = w.s_ws; out_depth = w.s_depth; out_image = w.s_image; out_aux = pal ? w.s_aux : nullptr;
     }
     if (pal && hipMemsetAsync(out_aux, 0, (size_t)N * aux_stride * 4, s) != hipSuccess) return PNR_ERR_LAUNCH;
-    GridSet gs;
-    gs.table[0] = a->embeddings; gs.enc[0] = w.enc;
-    gs.table[1] = pal ? pal->embeddings_palette : nullptr; gs.enc[1] = w.enc_pal;
-    gs.table[2] = with_clip ? pal->embeddings_clip : nullptr; gs.enc[2] = w.enc_clip;
+    const float* tables[3] = {a->embeddings, pal ? pal->embeddings_palette : nullptr, with_clip ? pal->embeddings_clip : nullptr};
     const uint32_t n_enc = pal ? (with_clip ? 3u : 2u) : 1u;
     const int aux_fused = (pal && g_opt_aux_fusion && pnr_palette_field_stages_aux(pal->num_basis, pal->clip_dim, pal->pred_clip)) ? 1 : 0;
     const int composite_fused = (!pal && g_opt_composite_fusion) ? 1 : 0;   // NeRF: one-sample-per-ray iterations are composited inside the field kernel
@@ -1097,9 +1270,13 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     const uint32_t march_lds = mp.mip_words ? (2 * mp.mip_words + 8) * 4 : 0;
     const LevelParams lp = make_level_params(16, a->S, a->base_resolution);
     const uint32_t* mip = static_cast<const uint32_t*>(a->mip);
+    const bool hosted = g_opt_hosted_tail && use_mip && pow2 && mp.mip_words != 0 && (a->H % 64u) == 0;   // (what MODE 2 and hosted_march_tail are compiled for)
 
+    HostedConst hconst = {};
+    hconst.qctr_all = w.qctr; hconst.qrecs = w.qrecs; hconst.rays_o = in_o; hconst.rays_d = in_d; hconst.bitfield = a->bitfield; hconst.mip = mip; hconst.p = mp;
+    hconst.xyzs = w.xyzs; hconst.dirs = w.dirs; hconst.deltas = w.deltas; hconst.partials[0] = w.partials[0]; hconst.partials[1] = w.partials[1];
     hipLaunchKernelGGL(k_frame_init, dim3(cdiv(N, kRayBlock)), dim3(kRayBlock), 0, s, N, in_near, w.alive[1], w.rays_t, out_ws, out_depth, out_image,
-                       w.ctl, w.scratch + kHdr);
+                       w.ctl, w.scratch + kHdr, w.qctr, hconst, w.hosted);
     // optional live timing of the roofline kernel: HIP events on the launch stream around every k_frame_grid launch
     std::vector<hipEvent_t>& ev = dev_state.ev;
     size_t ev_used = 0;
@@ -1129,37 +1306,47 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             const int32_t* alive_prev = w.alive[(iter + 1) & 1];
             const uint32_t ray_blocks = cdiv(alive_ub, kRayBlock);
             const uint32_t rows_ub = (uint64_t)alive_ub * 8 < N ? alive_ub * 8 : N;
-            const dim3 gm(ray_blocks < 2048u ? ray_blocks : 2048u), bm(kRayBlock);
-            if (use_mip && pow2)
-                hipLaunchKernelGGL((k_frame_march<true, true>), gm, bm, march_lds, s, prev, cur, alive_prev, alive_in, w.scratch, w.scratch, N, a->max_steps, w.partials[(iter + 1) & 1], prev_partials,
-                                   w.rays_t, in_o, in_d, mp, a->bitfield, in_far, w.xyzs, w.dirs, w.deltas, mip, w.partials[iter & 1]);
-            else if (use_mip)
-                hipLaunchKernelGGL((k_frame_march<true, false>), gm, bm, march_lds, s, prev, cur, alive_prev, alive_in, w.scratch, w.scratch, N, a->max_steps, w.partials[(iter + 1) & 1], prev_partials,
-                                   w.rays_t, in_o, in_d, mp, a->bitfield, in_far, w.xyzs, w.dirs, w.deltas, mip, w.partials[iter & 1]);
-            else if (pow2)
-                hipLaunchKernelGGL((k_frame_march<false, true>), gm, bm, march_lds, s, prev, cur, alive_prev, alive_in, w.scratch, w.scratch, N, a->max_steps, w.partials[(iter + 1) & 1], prev_partials,
-                                   w.rays_t, in_o, in_d, mp, a->bitfield, in_far, w.xyzs, w.dirs, w.deltas, mip, w.partials[iter & 1]);
-            else
-                hipLaunchKernelGGL((k_frame_march<false, false>), gm, bm, march_lds, s, prev, cur, alive_prev, alive_in, w.scratch, w.scratch, N, a->max_steps, w.partials[(iter + 1) & 1], prev_partials,
-                                   w.rays_t, in_o, in_d, mp, a->bitfield, in_far, w.xyzs, w.dirs, w.deltas, mip, w.partials[iter & 1]);
+            const dim3 gm(ray_blocks < kMaxMarchBlocks ? ray_blocks : kMaxMarchBlocks), bm(kRayBlock);
+            // hosted tail (MODE 2): the march gives every ray `budget` probe rounds and queues the rest for the lookup launch's first workgroups
+            const uint32_t budget = hosted ? (uint32_t)(iter == 0 ? g_opt_march_budget0 : g_opt_march_budget) : 0u;
+            const int mode = budget ? 2 : 1;
+#define PNR_LAUNCH_MARCH(MIPV, P2V, MODEV)                                                                                                                \
+            hipLaunchKernelGGL((k_frame_march<MIPV, P2V, MODEV>), gm, bm, march_lds, s, prev, cur, alive_prev, alive_in, w.scratch, w.scratch, N, a->max_steps,    \
+                               w.partials[(iter + 1) & 1], prev_partials, w.rays_t, in_o, in_d, mp, a->bitfield, in_far, w.xyzs, w.dirs, w.deltas, mip,           \
+                               w.partials[iter & 1], budget, w.qctr, w.qrecs, w.rowflag)
+            if (mode == 2) PNR_LAUNCH_MARCH(true, true, 2);   // (hosted implies the mip and power-of-two configuration)
+            else if (use_mip && pow2) PNR_LAUNCH_MARCH(true, true, 1);
+            else if (use_mip) PNR_LAUNCH_MARCH(true, false, 1);
+            else if (pow2) PNR_LAUNCH_MARCH(false, true, 1);
+            else PNR_LAUNCH_MARCH(false, false, 1);
+#undef PNR_LAUNCH_MARCH
             const uint32_t gx = cdiv(rows_ub, 256);
+            const uint32_t gxc = gx < 1024u ? gx : 1024u;
+            HostedArgs ha = {};
+            if (mode == 2) { ha.hc = w.hosted; ha.rowflag = w.rowflag; ha.blocks = kHostedBlocks; ha.partial_base = gm.x; }
+            const uint32_t grid_lds = mode == 2 ? march_lds : 0u;
+            GridArgs ga = {};
+            ga.xyzs = w.xyzs; ga.deltas = w.deltas; ga.offsets = a->offsets; ga.lp = lp; ga.level_stride = N; ga.bound = a->bound; ga.two_bound = 2.0f * a->bound;
+            ga.gridtype = a->gridtype;
+            ga.enc[0] = w.enc; ga.enc[1] = w.enc_pal; ga.enc[2] = w.enc_clip;
             hipEvent_t e0 = timing ? next_event() : nullptr, e1 = timing ? next_event() : nullptr;
             if (e0) (void)hipEventRecord(e0, s);
-            if (half_tables && pal)
-                hipLaunchKernelGGL(k_frame_grid_h<2>, dim3(gx < 1024u ? gx : 1024u, 16), dim3(256), 0, s, cur, w.xyzs, w.deltas,
-                                   reinterpret_cast<const __half*>(pal->embeddings_pair), w.enc, w.enc_pal, a->offsets, lp, N, a->bound, 2.0f * a->bound, a->gridtype);
-            else if (half_tables)
-                hipLaunchKernelGGL(k_frame_grid_h<1>, dim3(gx < 1024u ? gx : 1024u, 16), dim3(256), 0, s, cur, w.xyzs, w.deltas,
-                                   reinterpret_cast<const __half*>(a->embeddings), w.enc, (float*)nullptr, a->offsets, lp, N, a->bound, 2.0f * a->bound, a->gridtype);
-            else if (triple_table)
-                hipLaunchKernelGGL(k_frame_grid_triple, dim3(gx < 1024u ? gx : 1024u, 16), dim3(256), 0, s, cur, w.xyzs, w.deltas, triple_table, w.enc, w.enc_pal,
-                                   w.enc_clip, a->offsets, lp, N, a->bound, 2.0f * a->bound, a->gridtype);
-            else if (pair_table)
-                hipLaunchKernelGGL(k_frame_grid_pair, dim3(gx < 1024u ? gx : 1024u, 16), dim3(256), 0, s, cur, w.xyzs, w.deltas, pair_table, w.enc, w.enc_pal,
-                                   a->offsets, lp, N, a->bound, 2.0f * a->bound, a->gridtype);
-            else
-                hipLaunchKernelGGL(k_frame_grid, dim3(gx < 1024u ? gx : 1024u, 16, n_enc), dim3(256), 0, s, cur, w.xyzs, w.deltas, gs, a->offsets, lp, N,
-                                   a->bound, 2.0f * a->bound, a->gridtype);
+            if (half_tables && pal) {
+                ga.table[0] = pal->embeddings_pair;
+                hipLaunchKernelGGL(k_frame_grid_h2, dim3(gxc + ha.blocks, 16), dim3(256), grid_lds, s, cur, ga, ha);
+            } else if (half_tables) {
+                ga.table[0] = a->embeddings;
+                hipLaunchKernelGGL(k_frame_grid_h1, dim3(gxc + ha.blocks, 16), dim3(256), grid_lds, s, cur, ga, ha);
+            } else if (triple_table) {
+                ga.table[0] = triple_table;
+                hipLaunchKernelGGL(k_frame_grid_triple, dim3(gxc + ha.blocks, 16), dim3(256), grid_lds, s, cur, ga, ha);
+            } else if (pair_table) {
+                ga.table[0] = pair_table;
+                hipLaunchKernelGGL(k_frame_grid_pair, dim3(gxc + ha.blocks, 16), dim3(256), grid_lds, s, cur, ga, ha);
+            } else {
+                for (int k = 0; k < 3; k++) ga.table[k] = tables[k];
+                hipLaunchKernelGGL(k_frame_grid, dim3(gxc + ha.blocks, 16, n_enc), dim3(256), grid_lds, s, cur, ga, ha);
+            }
             if (e1) (void)hipEventRecord(e1, s);
             if (pal) {
                 pf.ctl = cur; pf.B = rows_ub;
@@ -1188,7 +1375,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
                                    out_image, w.scratch);
             hipLaunchKernelGGL(k_frame_composite, gm, bm, 0, s, cur, a->T_thresh, alive_in, w.rays_t, w.sigmas, w.rgbs, w.deltas, out_ws, out_depth, out_image,
                                w.scratch, (const float*)w.aux, out_aux, aux_stride, aux_fused, composite_fused);
-            prev_partials = gm.x;
+            prev_partials = gm.x + ha.blocks;
         }
         if (hipMemcpyAsync(host_ctl, w.ctl + ((iter - 1) & 1), sizeof(FrameCtl), hipMemcpyDeviceToHost, s) != hipSuccess) return PNR_ERR_LAUNCH;   // the last launched iteration's
         if (hipStreamSynchronize(s) != hipSuccess) return PNR_ERR_LAUNCH;
@@ -1242,6 +1429,17 @@ extern "C" int pnr_debug_march_timing(unsigned long long* out, int iteration) {
     if (iteration >= 0) hipMemcpyToSymbol(HIP_SYMBOL(pnr::g_march_timing_iter), &iteration, sizeof(int));
     std::vector<unsigned long long> z((size_t)pnr::kTimingWaves * 8, 0ull);
     hipMemcpyToSymbol(HIP_SYMBOL(pnr::g_march_timing), z.data(), z.size() * sizeof(unsigned long long));
+    return 0;
+}
+#endif
+#ifdef PNR_HOSTED_TIMING
+extern "C" int pnr_debug_hosted_timing(unsigned long long* out, int iteration) {
+    hipDeviceSynchronize();
+    constexpr size_t kWords = 8 + 8 * 256 + 2 * 16 * 128;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(pnr::g_hosted_timing), sizeof(unsigned long long) * kWords) != hipSuccess) return -3;
+    if (iteration >= 0) hipMemcpyToSymbol(HIP_SYMBOL(pnr::g_hosted_timing_iter), &iteration, sizeof(int));
+    std::vector<unsigned long long> z(kWords, 0ull);
+    hipMemcpyToSymbol(HIP_SYMBOL(pnr::g_hosted_timing), z.data(), z.size() * sizeof(unsigned long long));
     return 0;
 }
 #endif

@@ -207,7 +207,9 @@ __device__ __forceinline__ int empty_block_log2(const RayCtx& c, uint32_t index)
 // of R (empty), the reference's last probe p in R has tt(p) <= b + eps (its cell's a-face is at or before R's), and
 // with a lattice-free window around b it lands on the same next point q.  Any check failing = the reference's own
 // one-cell step.
-template <bool MIP, bool POW2>
+// JUMPS = false compiles the block jumps out: every empty probe is the reference's own one-cell step (same results, since a jump is an
+// exact shortcut; fewer registers and a shorter chain for the hosted march tail, whose rays walk partly filled bricks where jumps rarely apply).
+template <bool MIP, bool POW2, bool JUMPS = true>
 __device__ __forceinline__ bool march_probe(const RayCtx& c, float& t, float& x, float& y, float& z, float& dt, int* kind = nullptr) {
     const float t0 = t;
     x = clampf(fmaf(t0, c.dx, c.ox), -c.bound, c.bound);
@@ -237,7 +239,7 @@ __device__ __forceinline__ bool march_probe(const RayCtx& c, float& t, float& x,
         nz = (int)clampf((float)(0.5 * (double)fmaf(z, mip_rbound, 1.0f) * (double)c.H), 0.0f, hi);
     }
     const uint32_t index = (uint32_t)level * c.H3 + morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz);
-    if constexpr (MIP && POW2) {
+    if constexpr (MIP && POW2 && JUMPS) {
         int sh = c.block_skip ? empty_block_log2(c, index) : 0;
         if (kind) *kind = sh == 0 ? 1 : 5;   // instrumented builds only: 0 emit, 1 cell step in a non-empty brick, 2/3/4 block jump, 5 block checks failed
         if (sh == 0) { if (cell_occupied<MIP>(c, index)) { if (kind) *kind = 0; return true; } }
