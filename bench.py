@@ -723,6 +723,27 @@ def main(argv=None):
                          "algorithmic_bytes_per_sample": per_sample * (n_tables if native else 1),
                          "algorithmic_bytes_per_launch": per_sample * k_units / max(1, n_launches)},
         }
+        if native and not os.environ.get("PNR_NO_HOSTED_TAIL"):
+            # The timed lookup launches also finish the march's stragglers (frame.hip: hosted_march_tail): their duration is the lookup's plus what
+            # the hosted waves cost it.  The same frame once more with the tail switched off gives the lookup kernel on its own.
+            from palettenerf_amd import _lib as _plib
+            _l = _plib.load()
+            if not use_dist and F_main == 1 and _l.pnr_set_option(b"hosted_tail", 0) == 0:
+                try:
+                    m._fused.time_grid_kernel = True
+                    with torch.no_grad():
+                        ra, _ = frame(args.warmup)
+                    torch.cuda.synchronize()
+                    a_ms, a_n, a_live = ra.get("grid_ms", 0.0), ra.get("grid_launches", 0), int(ra["rendered"])
+                    if a_ms > 0:
+                        a_ach = a_live * n_tables * per_sample / (a_ms * 1e-3) / 1e9
+                        out["roofline"]["lookup_alone"] = {"achieved": a_ach, "frac": a_ach / HBM_PEAK_GBS, "avg_launch_ms": a_ms / max(1, a_n), "launches": a_n,
+                                                           "note": "same frame, hosted march tail off (pnr_set_option hosted_tail 0): the lookup launches without the stragglers' march inside them"}
+                finally:
+                    m._fused.time_grid_kernel = False
+                    _l.pnr_set_option(b"hosted_tail", 1)
+            out["roofline"]["note_hosted_tail"] = ("the timed launches host the march tail: their first workgroups march the rays the march launch handed over and look those rows up "
+                                                   "(algorithmic bytes count the lookup only; `lookup_alone` is the kernel without that work)")
         if F_main > 1:
             out["roofline"]["note_frames_in_flight"] = (f"{F_main} frames in flight: the timed launches share the chip with another frame's kernels, and "
                                                         "ms_per_step is elapsed / steps, not the latency of a frame")

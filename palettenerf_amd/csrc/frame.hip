@@ -317,6 +317,9 @@ __device__ __forceinline__ uint32_t march_coop_tail(CoopShared& sh, const MarchP
 #define PNR_MARCH_WAVES 4     // waves per SIMD the march kernel WITH the in-wave cooperative tail is compiled for (register budget 512 / PNR_MARCH_WAVES): it needs 114 VGPRs;
                               // squeezed into 80 (6 waves, all chunks of a later iteration resident at once) it spills and the lego frame is 0.3 ms slower (4.38 vs 4.07 ms)
 #endif
+#ifndef PNR_MARCH2_JUMPS
+#define PNR_MARCH2_JUMPS true   // the budgeted march attempts the exact block jumps (false: plain cell steps only -- fewer registers; the rays that would have jumped end up in the queue)
+#endif
 #ifndef PNR_MARCH_WAVES_Q
 #define PNR_MARCH_WAVES_Q 5   // waves per SIMD of the budgeted march (MODE 2: no in-wave tail; 80 VGPRs spill 24 registers: 23 us per launch against 17.8 at 102)
 #endif
@@ -503,7 +506,7 @@ __global__ void __launch_bounds__(kRayBlock) __attribute__((amdgpu_waves_per_eu(
                 kinds[kind & 7]++;
                 if (!hit) empties++;
 #else
-                const bool hit = march_probe<MIP, POW2>(c, t, x, y, z, dt);
+                const bool hit = march_probe<MIP, POW2, (MODE != 2 || PNR_MARCH2_JUMPS)>(c, t, x, y, z, dt);
 #endif
                 if (hit) {
                     const size_t row = (size_t)n * n_step + step;
@@ -748,6 +751,9 @@ __device__ __forceinline__ void grid_row(const GridArgs& g, const LevelCtx& lc, 
 __device__ unsigned long long g_hosted_timing[8 + 8 * 256 + 2 * 16 * 128];   // ... then (start, end) of every 16th ordinary workgroup of the first 2048 per level
 __device__ int g_hosted_timing_iter = 3;
 #endif
+#ifndef PNR_HOSTED_MIN_GLOG
+#define PNR_HOSTED_MIN_GLOG 3u
+#endif
 #ifndef PNR_HOSTED_JUMPS
 #define PNR_HOSTED_JUMPS false
 #endif
@@ -772,7 +778,8 @@ __device__ __forceinline__ void hosted_march_tail(const FrameCtl* ctl, const Gri
     __shared__ uint32_t wemit[kRayBlock / PNR_WAVE];
     const uint32_t count = (uint32_t)h.qctr[0];
     const int lane = threadIdx.x & (PNR_WAVE - 1), wave = threadIdx.x / PNR_WAVE;
-    const uint32_t glog = count > 32768u ? 6u : (count > 16384u ? 5u : (count > 8192u ? 4u : 3u));
+    uint32_t glog = PNR_HOSTED_MIN_GLOG;   // rays per wave: as few as the hosted waves (kHostedBlocks * 4) allow -- a wave marches at the pace of its slowest ray, and its lookups spread over the idle lanes
+    while (glog < 6u && (count >> glog) > kHostedBlocks * (kRayBlock / PNR_WAVE)) glog++;
     const uint32_t G = 1u << glog;
     const uint32_t ntasks = (count + G - 1) >> glog;
     if (blockIdx.x >= ntasks) { if (threadIdx.x == 0) h.partials[blockIdx.x] = 0; return; }   // block-uniform (also: count == 0)

@@ -45,8 +45,11 @@ with torch.no_grad():
         mt = mt[mt[:, 0] > 0]
         live = b[:, 0] > 0
         b = b[live]
+        if not len(mt):
+            print(f"iteration {it}: no lookup work")
+            continue
         if not len(b):
-            print(f"iteration {it}: no hosted workgroup had work (queued {g[3]})")
+            print(f"iteration {it}: no hosted workgroup had work (queued {g[3]}); ordinary workgroups (every 16th): last end {(mt[:, 1].max() - mt[:, 0].min()) / 100.0:.1f} us")
             continue
         t0 = min(mt[:, 0].min(), b[:, 0].min())
         us = lambda v: (v - t0) / 100.0

@@ -281,6 +281,51 @@ def test_coop_march_tail_is_bit_identical(cuda, dt_gamma, density_scale, max_ste
         assert torch.equal(torch.nan_to_num(a[k], nan=-7.0), torch.nan_to_num(b[k], nan=-7.0)), k
 
 
+@pytest.mark.parametrize("layout", ["single", "pair", "triple", "half1", "half2"])
+@pytest.mark.parametrize("dt_gamma,density_scale,scene_kind", [(0.0, 1.0, "bricks"), (1.0 / 128, 0.02, "sparse"), (0.0, 0.05, "sparse")])
+def test_hosted_march_tail_is_bit_identical(cuda, layout, dt_gamma, density_scale, scene_kind):
+    """The hosted march tail (frame.hip: k_frame_march<.., 2> queues the rays it has not finished within its probe budget, the first
+    workgroups of the lookup launch march them and look their rows up) against the same frame without it: every output bit, the sample
+    count and the iteration count -- for every table layout of the lookup kernels (one fp32 table, the interleaved pair, the triple with a
+    clip head, one and two fp16 tables), budgets from 1 probe (most of a frame goes through the queue) to 5, the first launch of a frame
+    budgeted too, opaque and translucent fields (n_step from 1 to 8), constant and growing steps, dense and sparse scenes."""
+    from palettenerf_amd import _lib
+    from palettenerf_amd.fused import NeRFFieldFused, PaletteFieldFused
+    lib = _lib.load()
+    if layout in ("single", "half1"):
+        m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=density_scale, min_near=0.2)
+    else:
+        m = network.PaletteNetwork(renderer.default_opt(pred_clip=layout == "triple"), bound=2, cuda_ray=True, density_scale=density_scale, min_near=0.2)
+    scene.seed_field_(m, 3)
+    m = m.to(cuda).eval()
+    grid = scene.brick_density_grid() if scene_kind == "bricks" else scene.sparse_density_grid()
+    m.density_grid.copy_(torch.from_numpy(grid).to(cuda))
+    raymarching.packbits(m.density_grid, 0.5, m.density_bitfield)
+    m.march_mode, m.fused_field, m.count_rendered = "native", True, True
+    m._fused = (NeRFFieldFused if layout in ("single", "half1") else PaletteFieldFused)(m)
+    m._fused.table_half = layout.startswith("half")
+    pose = torch.from_numpy(scene.lookat_pose(azimuth_deg=70.0))[None]
+    ro, rd = scene.get_rays(pose, scene.intrinsics_from_fov(160, 200), 160, 200)
+    ro, rd = ro.to(cuda), rd.to(cuda)
+    keys = ["image", "depth", "weights_sum", "rendered", "iterations", "view_dep_rgb", "diffuse_rgb", "direct_rgb", "basis_acc", "clip_feat", "omega_sparsity"]
+    out = []
+    try:
+        for hosted, budget, budget0 in ((0, 2, 0), (1, 2, 0), (1, 1, 0), (1, 5, 3), (1, 1, 1)):
+            assert lib.pnr_set_option(b"hosted_tail", hosted) == 0
+            assert lib.pnr_set_option(b"march_budget", budget) == 0 and lib.pnr_set_option(b"march_budget0", budget0) == 0
+            with torch.no_grad():
+                r = m.render(ro, rd, perturb=False, dt_gamma=dt_gamma, max_steps=1024, T_thresh=1e-4)
+            out.append({k: torch.as_tensor(r[k]).clone() for k in keys if k in r})
+    finally:
+        lib.pnr_set_option(b"hosted_tail", 1); lib.pnr_set_option(b"march_budget", 2); lib.pnr_set_option(b"march_budget0", 0)
+    a = out[0]
+    assert int(a["rendered"]) > 1000
+    for b in out[1:]:
+        assert int(a["rendered"]) == int(b["rendered"])
+        for k in a:
+            assert torch.equal(torch.nan_to_num(a[k], nan=-7.0), torch.nan_to_num(b[k], nan=-7.0)), k
+
+
 @pytest.mark.parametrize("model_kind", ["nerf", "palette"])
 def test_native_loop_ray_order_leaves_every_output_bit_identical(cuda, model_kind):
     """pnr_*_frame_args::ray_order (tile order, a random permutation) changes the processing order only: image, depth, weights_sum,
