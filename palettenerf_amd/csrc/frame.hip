@@ -372,6 +372,9 @@ __global__ void __launch_bounds__(kRayBlock) __attribute__((amdgpu_waves_per_eu(
     }
     if (prev->done) { if (blockIdx.x == 0 && threadIdx.x == 0) *cur = *prev; return; }
     const uint32_t n_prev = (uint32_t)prev->n_alive, nchunks = (n_prev + kRayBlock - 1) / kRayBlock;
+    // The host sizes the launch for its upper bound of n_alive (N until it has looked at the control block): the workgroups beyond the last chunk
+    // leave at once -- a third of a typical launch, which otherwise held wave slots through the whole prologue.
+    if (blockIdx.x >= nchunks && blockIdx.x != 0) { if (threadIdx.x == 0) emitted_partials[blockIdx.x] = 0; return; }
     if (slot0 >= n_prev) index0 = -1;
     unsigned long long part = 0;   // high word: all chunks, low word: the chunks in front of this workgroup's first one
 #pragma unroll
@@ -1313,10 +1316,13 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             const int32_t* alive_prev = w.alive[(iter + 1) & 1];
             const uint32_t ray_blocks = cdiv(alive_ub, kRayBlock);
             const uint32_t rows_ub = (uint64_t)alive_ub * 8 < N ? alive_ub * 8 : N;
-            const dim3 gm(ray_blocks < kMaxMarchBlocks ? ray_blocks : kMaxMarchBlocks), bm(kRayBlock);
-            // hosted tail (MODE 2): the march gives every ray `budget` probe rounds and queues the rest for the lookup launch's first workgroups
+            // hosted tail (MODE 2): the march gives every ray `budget` sample-less probes and queues the rest for the lookup launch's first workgroups
             const uint32_t budget = hosted ? (uint32_t)(iter == 0 ? g_opt_march_budget0 : g_opt_march_budget) : 0u;
             const int mode = budget ? 2 : 1;
+            // MODE 2 runs five workgroups per CU: a launch of more than 1280 would start its last workgroups 8 us late, after a full prologue of the others;
+            // capped there, the few workgroups with a second chunk reuse their staged mip and chunk sums (launch 16.9 -> ~14 us with 1 352 chunks)
+            const uint32_t march_cap = mode == 2 ? (uint32_t)g_opt_march_blocks : kMaxMarchBlocks;
+            const dim3 gm(ray_blocks < march_cap ? ray_blocks : march_cap), bm(kRayBlock);
 #define PNR_LAUNCH_MARCH(MIPV, P2V, MODEV)                                                                                                                \
             hipLaunchKernelGGL((k_frame_march<MIPV, P2V, MODEV>), gm, bm, march_lds, s, prev, cur, alive_prev, alive_in, w.scratch, w.scratch, N, a->max_steps,    \
                                w.partials[(iter + 1) & 1], prev_partials, w.rays_t, in_o, in_d, mp, a->bitfield, in_far, w.xyzs, w.dirs, w.deltas, mip,           \

@@ -89,6 +89,7 @@ extern int g_opt_block_skip;   // exact jumps over empty 4^3 / 8^3 / 16^3 blocks
 extern int g_opt_coop_march;   // frame loops: wave-cooperative march tail (frame.hip: march_coop_tail)
 extern int g_opt_hosted_tail;  // frame loops: rays a march launch has not finished within its probe budget are marched by the first workgroups of the lookup launch (frame.hip: hosted_march_tail)
 extern int g_opt_march_budget, g_opt_march_budget0;   // that budget in probe rounds: later launches / a frame's first launch (0 = the first launch keeps the in-wave cooperative tail)
+extern int g_opt_march_blocks;   // frame loops: workgroup cap of a budgeted march launch
 extern int g_opt_aux_fusion;   // PaletteNeRF frame loop: aux composite inside the field kernel
 extern int g_opt_composite_fusion;   // NeRF frame loop: n_step == 1 iterations composited inside the field kernel
 extern int g_opt_dynamic_tiles;      // frame loops: field kernels hand wave tiles out through a device counter instead of a static schedule
