@@ -14,8 +14,12 @@ from palettenerf_amd import _lib, scene  # noqa: E402
 
 argv = list(sys.argv[1:])
 wl = "lego"
-if argv and argv[0] == "--workload":
-    wl = argv[1]
+pose_step = 5
+while argv and argv[0].startswith("--"):
+    if argv[0] == "--workload":
+        wl = argv[1]
+    elif argv[0] == "--pose":
+        pose_step = int(argv[1])
     argv = argv[2:]
 iters = [int(v) for v in argv] or [3, 10, 20]
 sys.argv = [sys.argv[0], "--no-cpu-baseline", "--workload", wl]
@@ -24,7 +28,7 @@ dev = torch.device("cuda", 0)
 m = bench.build_model(args, dev)
 m.march_mode = "native"
 H, W = args.wl["H"], args.wl["W"]
-pose = torch.from_numpy(bench.pose_of(args, 5))[None]
+pose = torch.from_numpy(bench.pose_of(args, pose_step))[None]
 ro, rd = scene.get_rays(pose, scene.intrinsics_from_fov(H, W), H, W)
 ro, rd = ro.to(dev), rd.to(dev)
 lib = _lib.load()
@@ -53,8 +57,8 @@ with torch.no_grad():
             continue
         t0 = min(mt[:, 0].min(), b[:, 0].min())
         us = lambda v: (v - t0) / 100.0
-        print(f"iteration {it}: rays queued {g[3]}, hosted workgroups with work {len(b)}; ordinary workgroups (every 16th): first start {us(mt[:, 0].min()):.1f} us, "
-              f"median end {np.median(us(mt[:, 1])):.1f} us, last end {us(mt[:, 1].max()):.1f} us; hosted: last end {us(b[:, 3].max()):.1f} us")
+        print(f"iteration {it}: rays queued {g[3]}, hosted workgroups with work {len(b)}; ordinary workgroups (every 16th): "
+              f"last end {us(mt[:, 1].max()):.1f} us; hosted: march done {us(b[:, 2].max()):.1f}, last end {us(b[:, 3].max()):.1f} us, probes of the slowest lane: median {np.median(b[:, 4]):.0f} max {b[:, 4].max()}")
         if os.environ.get("HOSTED_TIMING_BRIEF"):
             continue
         for name, col in (("start", 0), ("mip staged", 1), ("march done", 2), ("lookups done", 3)):
