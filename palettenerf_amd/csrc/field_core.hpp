@@ -219,6 +219,21 @@ struct FieldOut { float sigma_logit, o0, o1, o2; };
 // enc_scale: a power of two (1 = none) the encoder features are multiplied by before they are split into fp16 pairs, and sigma_net's 16
 // outputs divided by afterwards -- exact, since the bias-free ReLU stack is positively homogeneous.  It keeps the `lo` halves of very small
 // features (hash tables at the reference's initialisation scale U(-1e-4, 1e-4), gridencoder/grid.py:107) out of the fp16 subnormal range.
+// the 8 encoder rows of a lane (levels 4h..4h+3 and 8+4h..8+4h+3; 32 samples x 2 channels = 256 contiguous bytes per level and half-wave),
+// issued together into fresh registers (load8_fresh, pnr_common.hpp).  `row` is a row that exists (callers clamp it); dead lanes get zeros.
+__device__ __forceinline__ void load_enc_rows8(const float* __restrict__ enc, size_t level_stride, uint32_t row, bool valid, int h, float x[2][8]) {
+    const f32x2* p[8];
+    f32x2 v[8];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) p[4 * kb + q] = reinterpret_cast<const f32x2*>(enc + ((size_t)(8 * kb + 4 * h + q) * level_stride + row) * 2);
+    load8_fresh(p, v);
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) { x[kb][2 * q] = valid ? v[4 * kb + q].x : 0.0f; x[kb][2 * q + 1] = valid ? v[4 * kb + q].y : 0.0f; }
+}
 template <bool CHECK, bool LO = true>
 __device__ __forceinline__ FieldOut nerf_field_tile_f16x3(const unsigned char* __restrict__ w, int lane, bool valid, const float* __restrict__ enc,
                                                           size_t level_stride, uint32_t row, float dx, float dy, float dz, float enc_scale,
@@ -227,14 +242,7 @@ __device__ __forceinline__ FieldOut nerf_field_tile_f16x3(const unsigned char* _
     h8 bh[4], bl[4];
     {   // sigma_net[0] inputs: k-block kb, element j  <-  encoder feature 16 kb + 8 h + j  = (level 8 kb + 4 h + j/2, channel j&1)
         float x[2][8];
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int level = 8 * kb + 4 * h + q;
-                const float2 v = valid ? *reinterpret_cast<const float2*>(enc + ((size_t)level * level_stride + row) * 2) : make_float2(0.0f, 0.0f);
-                x[kb][2 * q] = v.x; x[kb][2 * q + 1] = v.y;
-            }
+        load_enc_rows8(enc, level_stride, row, valid, h, x);
         if (enc_scale != 1.0f) {
 #pragma unroll
             for (int j = 0; j < 8; j++) { x[0][j] *= enc_scale; x[1][j] *= enc_scale; }
@@ -384,14 +392,7 @@ __device__ __forceinline__ f32x16 nerf_density_tile(const float* __restrict__ wf
         const unsigned char* w = reinterpret_cast<const unsigned char*>(wf);
         h8 bh[4], bl[4];
         float x[2][8];
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int level = 8 * kb + 4 * h + q;
-                const float2 v = valid ? *reinterpret_cast<const float2*>(enc + ((size_t)level * level_stride + row) * 2) : make_float2(0.0f, 0.0f);
-                x[kb][2 * q] = v.x; x[kb][2 * q + 1] = v.y;
-            }
+        load_enc_rows8(enc, level_stride, row, valid, h, x);
         if (enc_scale != 1.0f) {
 #pragma unroll
             for (int j = 0; j < 8; j++) { x[0][j] *= enc_scale; x[1][j] *= enc_scale; }

@@ -650,13 +650,9 @@ __device__ __forceinline__ void grid_corner_weights(const float pos[3], float ws
 // group.  Left to itself the compiler does this too -- until it is asked to keep the kernel within a register budget
 // (amdgpu_waves_per_eu, which the hosted tail needs): then it forms the weights first and threads the loads between the address
 // arithmetic, and the lego launch takes 76 instead of 66 us with the very same instructions (profiles/scratch/prof_ref.sh).
-typedef float f32x2 __attribute__((ext_vector_type(2)));   // (built-in vector types: a load through an address-space pointer needs no operator=)
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-template <typename T>
-struct GlobalPtr { typedef const T __attribute__((address_space(1))) * type; };   // (the asm statement hides where a pointer came from: say "global" again, or the loads become flat_load)
 // ORDERED = false (the hosted tail's own few rows; GK_TRIPLE, whose 16 addresses + 48 values do not fit the budget): the compiler's order.
 template <typename T, uint32_t MUL, bool ORDERED>
-__device__ __forceinline__ void gather8(const T* tab, const uint32_t idxs[8], T v[8]) {
+__device__ __forceinline__ void gather8(const T* tab, const uint32_t (&idxs)[8], T (&v)[8]) {
     const T* p[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) p[i] = tab + (size_t)idxs[i] * MUL;
@@ -665,14 +661,7 @@ __device__ __forceinline__ void gather8(const T* tab, const uint32_t idxs[8], T 
         for (int i = 0; i < 8; i++) v[i] = *p[i];
         return;
     }
-    asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]));
-#pragma unroll
-    for (int i = 0; i < 8; i++) v[i] = *(typename GlobalPtr<T>::type)(uintptr_t)p[i];
-    __builtin_amdgcn_sched_barrier(0);
-#ifndef PNR_GATHER_MAY_OVERWRITE_ADDRESS
-    // (the addresses stay alive past the loads, so no load returns into the registers its own address came from)
-    asm volatile("" :: "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]));
-#endif
+    load8_fresh(p, v);
 }
 // (table / enc0: the table and first output of this call -- GK_SINGLE picks them per blockIdx.z; resolved by the caller, outside its row loop)
 template <int KIND, bool ORDERED = true>
@@ -893,7 +882,9 @@ __device__ __forceinline__ void frame_grid_body(const FrameCtl* __restrict__ ctl
     }
     const uint32_t stride = (gridDim.x - h.blocks) * 256u;
     const uint32_t rows = (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step;
-    const uint32_t level = blockIdx.y;
+    // the finest levels -- scattered rows, 5x the time of a dense level -- are dispatched first and the dense ones fill the launch's tail
+    // (ascending order: lego 3.80 ms / lookup at 0.66 of the roofline, descending: 3.79 / 0.675; garden 13.45 -> 13.2 ms)
+    const uint32_t level = gridDim.y - 1u - blockIdx.y;
 #ifdef PNR_HOSTED_TIMING
     const bool timing = ctl->iterations == g_hosted_timing_iter && (bx & 15u) == 0 && bx < 2048u && blockIdx.z == 0;
     unsigned long long* tmm = g_hosted_timing + 8 + 8 * 256 + 2 * (level * 128 + (bx >> 4));

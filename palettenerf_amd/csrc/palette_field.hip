@@ -111,15 +111,22 @@ __device__ __forceinline__ f32x16 elu16(f32x16 v) {
 // kernel's ~100 -- and spills them to vector-register lanes (v_readlane in the tile loop).
 __device__ __forceinline__ void load_enc_raw(const float* __restrict__ enc, uint32_t level_stride, uint32_t row, bool valid, int h, float x[2][8]) {
     const unsigned char* base = reinterpret_cast<const unsigned char*>(enc);
+    // the eight loads go out together and return into registers of their own (pnr_common.hpp: load8_fresh explains why); `row` exists (clamped by the caller)
+    uint32_t off[8];
+    f32x2 v[8];
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t level = (uint32_t)(8 * kb + 4 * h + q);
-            const uint32_t off = (level * level_stride + row) * 8u;
-            const float2 v = valid ? *reinterpret_cast<const float2*>(base + off) : make_float2(0.0f, 0.0f);
-            x[kb][2 * q] = v.x; x[kb][2 * q + 1] = v.y;
-        }
+        for (int q = 0; q < 4; q++) off[4 * kb + q] = ((uint32_t)(8 * kb + 4 * h + q) * level_stride + row) * 8u;
+    asm volatile("" : "+v"(off[0]), "+v"(off[1]), "+v"(off[2]), "+v"(off[3]), "+v"(off[4]), "+v"(off[5]), "+v"(off[6]), "+v"(off[7]));
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = *(GlobalPtr<f32x2>::type)(uintptr_t)(base + off[i]);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" :: "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "v"(off[7]));
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) { x[kb][2 * q] = valid ? v[4 * kb + q].x : 0.0f; x[kb][2 * q + 1] = valid ? v[4 * kb + q].y : 0.0f; }
 }
 // 64 -> N layer from two activation tiles: 4 k-blocks starting at block q0
 template <int PREC, bool CHECK>

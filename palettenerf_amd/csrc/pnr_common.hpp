@@ -70,6 +70,25 @@ __device__ __forceinline__ int mip_from_dt(float dt, float H, float max_cascade)
     return (int)fminf(max_cascade - 1.0f, fmaxf(0.0f, (float)e));
 }
 
+// Eight independent global loads issued back to back, each returning into registers of its own.  On gfx950 a load whose destination
+// overlaps its own address registers (`global_load_dwordx2 v[6:7], v[6:7], off` -- what the compiler writes once registers are scarce) is
+// slow: the lookup launch of the frame loop took 75.6 instead of 65.6 us with otherwise identical code ("March: the hosted
+// tail").  All eight addresses are formed first (one empty asm statement with all of them as operands pins that point; it also hides where
+// a pointer came from, hence the address-space cast: without it the loads become flat_load), nothing is scheduled into the group, and the
+// addresses stay alive past the loads.
+typedef float f32x2 __attribute__((ext_vector_type(2)));   // (built-in vector types: a load through an address-space pointer needs no operator=)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <typename T>
+struct GlobalPtr { typedef const T __attribute__((address_space(1))) * type; };
+template <typename T>
+__device__ __forceinline__ void load8_fresh(const T* (&p)[8], T (&v)[8]) {
+    asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]));
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = *(typename GlobalPtr<T>::type)(uintptr_t)p[i];
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" :: "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]));
+}
+
 // wave64 inclusive prefix sum of an int (DPP-free, shuffle based)
 __device__ __forceinline__ int wave_inclusive_scan(int v) {
     const int lane = threadIdx.x & (PNR_WAVE - 1);
