@@ -78,7 +78,8 @@ __device__ __forceinline__ int schedule_n_step(int N, int n_alive) {  // nerf/re
 __global__ void __launch_bounds__(kRayBlock) k_frame_init(uint32_t N, const float* __restrict__ nears, int32_t* __restrict__ alive,
                                                           float* __restrict__ rays_t, float* __restrict__ weights_sum, float* __restrict__ depth,
                                                           float* __restrict__ image, FrameCtl* __restrict__ ctl, int32_t* __restrict__ counts,
-                                                          int32_t* __restrict__ qctr_all, HostedConst hc, HostedConst* __restrict__ hc_out) {
+                                                          int32_t* __restrict__ scratch_hdr, int32_t* __restrict__ qctr_all, HostedConst hc,
+                                                          HostedConst* __restrict__ hc_out) {
     const uint32_t i = blockIdx.x * kRayBlock + threadIdx.x;
     if (i < N) {
         alive[i] = (int32_t)i;   // the reference's arange (nerf/renderer.py:352)
@@ -93,7 +94,7 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_init(uint32_t N, const floa
         FrameCtl c = {};
         c.n_alive = (int32_t)N; c.n_step = 0; c.iterations = -1; c.done = N == 0;
         ctl[0] = c; ctl[1] = c;
-        counts[1 - (int)kHdr] = 0;   // scratch[1]: the fp16-range overflow flag of this frame
+        scratch_hdr[1] = 0;   // the fp16-range overflow flag of this frame
         for (int k = 0; k < 2 * kQueueCtrs; k++) qctr_all[k] = 0;   // both counter sets of the straggler queue
         *hc_out = hc;
     }
@@ -327,7 +328,9 @@ __device__ __forceinline__ uint32_t march_coop_tail(CoopShared& sh, const MarchP
 // MODE 2: `budget` probe rounds per ray, then the rays still marching go to the straggler queue (hosted_march_tail finishes them).
 template <bool MIP, bool POW2, int MODE>
 __global__ void __launch_bounds__(kRayBlock) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? PNR_MARCH_WAVES_Q : PNR_MARCH_WAVES))) k_frame_march(const FrameCtl* __restrict__ prev, FrameCtl* __restrict__ cur, const int32_t* __restrict__ alive_prev,
-                                                           int32_t* __restrict__ rays_alive, const int32_t* __restrict__ scratch, int32_t* __restrict__ scratch_rw, uint32_t N, uint32_t max_steps,
+                                                           int32_t* __restrict__ rays_alive, const int32_t* __restrict__ counts /* the previous iteration's survivors per chunk */,
+                                                           int32_t* __restrict__ counts_cur /* this iteration's: cleared here, filled by its field / composite launch */,
+                                                           int32_t* __restrict__ scratch_rw, uint32_t N, uint32_t max_steps,
                                                            const int32_t* __restrict__ partials_prev, uint32_t n_partials_prev,
                                                            const float* __restrict__ rays_t, const float* __restrict__ rays_o,
                                                            const float* __restrict__ rays_d, MarchParams p, const uint8_t* __restrict__ grid,
@@ -344,7 +347,6 @@ __global__ void __launch_bounds__(kRayBlock) __attribute__((amdgpu_waves_per_eu(
     const uint32_t twave = blockIdx.x * (kRayBlock / PNR_WAVE) + threadIdx.x / PNR_WAVE;
 #endif
     PNR_STAMP(0);
-    const int32_t* counts = scratch + kHdr;
     // Every independent load of the prologue is issued before the first wait: the chunk counts (their total is n_alive, the part in front of
     // this workgroup's chunk its output offset), this thread's slot of the previous alive list and the occupancy mip on its way to LDS --
     // one trip to L2 instead of three dependent ones (profiles/march_timing.py on a PNR_MARCH_TIMING build: the median wave has its compacted
@@ -405,7 +407,7 @@ __global__ void __launch_bounds__(kRayBlock) __attribute__((amdgpu_waves_per_eu(
             c.n_alive = (int32_t)n_alive;
             c.n_step = (int32_t)n_step;
             c.done = done;
-            c.pad0 = scratch[1];   // fp16-range overflow flag raised by a field launch of an earlier iteration (0 = none)
+            c.pad0 = scratch_rw[1];   // fp16-range overflow flag raised by a field launch of an earlier iteration (0 = none)
             *cur = c;
             scratch_rw[2] = 0;     // the wave-tile counter of this iteration's field launch
             qctr_all[((c.iterations + 1) & 1) * kQueueCtrs] = 0;   // the NEXT iteration's straggler count (this iteration's set is in use; the other one was last read by the previous lookup launch)
@@ -430,6 +432,7 @@ __global__ void __launch_bounds__(kRayBlock) __attribute__((amdgpu_waves_per_eu(
     uint32_t emitted = 0;
     uint32_t base = (uint32_t)(sums & 0xffffffffull), summed_to = blockIdx.x;   // base = sum of counts[0 .. summed_to)
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        if (threadIdx.x == 0) counts_cur[chunk] = 0;   // (the two count arrays alternate: nobody reads this one before the iteration's field launch adds to it)
         int index = index0;
         if (chunk != blockIdx.x) {   // a second chunk for this workgroup (frames of more than gridDim.x * 256 rays): the plain sequence
             unsigned long long pre = 0;
@@ -935,22 +938,30 @@ __global__ void __launch_bounds__(256) k_interleave_tables3(const float2* __rest
 
 // the fused MFMA field of field.hip with rows from the control block, dead-slot skipping and density_scale
 constexpr int kFieldThreads = 512;
-// With one sample per ray (n_step == 1: 27 of the 29 iterations of the benchmark frame) the compositing step of the iteration is done
-// right here by the lanes that hold the sample's sigma and rgb (`fuse`): same operations in the same order as k_frame_composite's
-// phase 2 on the same values (what it would re-read from sigmas / rgbs), including the per-chunk survivor counts of the compaction --
-// a 256-sample tile IS chunk `tile` of the alive list.  k_frame_composite returns at once on such iterations.
+// The compositing step of the iteration is done right here by the lanes that hold the samples' sigma and rgb: same operations in the same
+// order as k_frame_composite's phase 2 on the same values (what it would re-read from sigmas / rgbs), including the per-chunk survivor
+// counts of the compaction.  fuse_mode 1: iterations with one sample per ray only (27 of the 29 of the benchmark frame; a 256-sample tile
+// IS chunk `tile` of the alive list, one plain store per tile) -- k_frame_composite returns at once on such iterations; fuse_mode 2
+// (default): every iteration, and the frame loop has no composite launch.  With n_step samples per ray a wave tile holds
+// floor(32 / n_step) whole rays (30 or 28 of its 32 rows for n_step = 3, 5, 6, 7); the lane of a ray's first row walks the ray's rows
+// through wave shuffles; survivors are added to their chunk's count with at most two atomics per wave (the count arrays alternate between
+// iterations and the march launch clears the one its iteration fills).
 // CHECK (split-fp16 only): watch the split operands for magnitudes beyond fp16's range and raise scratch[1] (SplitWatch, field_core.hpp)
 template <int PREC, bool CHECK>
 __global__ void __launch_bounds__(kFieldThreads) k_frame_field(const FrameCtl* __restrict__ ctl, const float* __restrict__ enc, uint32_t level_stride,
                                                                const float* __restrict__ dirs, const float* __restrict__ deltas,
                                                                const float* __restrict__ packed, float density_scale, float enc_scale, float* __restrict__ sigmas,
-                                                               float* __restrict__ rgbs, int fuse_one_step, float T_thresh, int32_t* __restrict__ rays_alive,
+                                                               float* __restrict__ rgbs, int fuse_mode, float T_thresh, int32_t* __restrict__ rays_alive,
                                                                float* __restrict__ rays_t, float* __restrict__ weights_sum, float* __restrict__ depth,
-                                                               float* __restrict__ image, int32_t* __restrict__ scratch) {
+                                                               float* __restrict__ image, int32_t* __restrict__ scratch, int32_t* __restrict__ counts_cur) {
     if (ctl->done) return;
-    const uint32_t B = (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step;
-    const bool fuse = fuse_one_step && ctl->n_step == 1;
-    const uint32_t ntiles = (B + 255) / 256;
+    const uint32_t n_step = (uint32_t)ctl->n_step;
+    const uint32_t B = (uint32_t)ctl->n_alive * n_step;
+    const bool fuse = fuse_mode && n_step == 1;
+    const bool fuse_rays = fuse_mode == 2 && n_step > 1;
+    const uint32_t rpw = fuse_rays ? (32u / n_step) * n_step : 32u;   // rows of a wave tile: whole rays
+    const uint32_t rpt = rpw * (kFieldThreads / PNR_WAVE);
+    const uint32_t ntiles = (B + rpt - 1) / rpt;
     if (blockIdx.x >= ntiles) return;
     __shared__ float w[kPackedFloats];
     __shared__ int wsum[kFieldThreads / PNR_WAVE];
@@ -958,10 +969,12 @@ __global__ void __launch_bounds__(kFieldThreads) k_frame_field(const FrameCtl* _
         *reinterpret_cast<float4*>(&w[i]) = *reinterpret_cast<const float4*>(&packed[i]);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const uint32_t l = (uint32_t)lane & 31u;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint32_t n = tile * 256 + wave * 32 + (lane & 31);
-        const float dl0 = n < B ? deltas[(size_t)n * 2] : 0.0f;
-        const bool valid = n < B && dl0 != 0.0f;
+        const uint32_t n = tile * rpt + wave * rpw + l;
+        const bool mine = l < rpw && n < B;
+        const float dl0 = mine ? deltas[(size_t)n * 2] : 0.0f;
+        const bool valid = mine && dl0 != 0.0f;
         FieldOut o = {0.0f, 0.0f, 0.0f, 0.0f};
         if (__any(valid)) {   // wave-uniform: otherwise all 32 slots of this wave are dead or out of range
             const uint32_t nc = n < B ? n : (B - 1);
@@ -977,7 +990,7 @@ __global__ void __launch_bounds__(kFieldThreads) k_frame_field(const FrameCtl* _
             cr = __frcp_rn(1.0f + __expf(-o.o0));
             cg = __frcp_rn(1.0f + __expf(-o.o1));
             cb = __frcp_rn(1.0f + __expf(-o.o2));
-            if (!fuse) {
+            if (!fuse && !fuse_rays) {
                 sigmas[n] = sigma;
                 rgbs[(size_t)n * 3] = cr; rgbs[(size_t)n * 3 + 1] = cg; rgbs[(size_t)n * 3 + 2] = cb;
             }
@@ -1009,9 +1022,55 @@ __global__ void __launch_bounds__(kFieldThreads) k_frame_field(const FrameCtl* _
             if (threadIdx.x == 0) {
                 int tot = 0;
                 for (int wv = 0; wv < kFieldThreads / (int)PNR_WAVE; wv++) tot += wsum[wv];
-                scratch[kHdr + tile] = tot;
+                counts_cur[tile] = tot;
             }
             __syncthreads();
+        } else if (fuse_rays) {   // block-uniform: k_frame_composite phase 2 for rays of n_step rows, all inside this wave's lower half
+            const float dl1 = (valid && h == 0) ? deltas[(size_t)n * 2 + 1] : 0.0f;
+            const bool leader = h == 0 && mine && (l % n_step) == 0;
+            const uint32_t slot = n / n_step;
+            int index = 0;
+            float ws = 0.0f, t = 0.0f, d = 0.0f, r = 0.0f, g = 0.0f, b = 0.0f;
+            if (leader) {
+                index = rays_alive[slot];
+                ws = weights_sum[index]; t = rays_t[index]; d = depth[index];
+                r = image[index * 3]; g = image[index * 3 + 1]; b = image[index * 3 + 2];
+            }
+            uint32_t step = 0;
+            bool running = leader;
+            for (uint32_t k = 0; k < n_step; k++) {   // wave-uniform: row k of every ray in lock step
+                const int src = lane + (int)k;
+                const float s_k = __shfl(sigma, src), a_k = __shfl(dl0, src), b_k = __shfl(dl1, src);
+                const float r_k = __shfl(cr, src), g_k = __shfl(cg, src), c_k = __shfl(cb, src);
+                if (running) {
+                    if (a_k == 0.0f) running = false;
+                    else {
+                        const float alpha = 1.0f - __expf(-s_k * a_k);
+                        const float T = 1.0f - ws;
+                        const float wgt = alpha * T;
+                        ws += wgt;
+                        t += b_k;
+                        d = fmaf(wgt, t, d);
+                        r = fmaf(wgt, r_k, r); g = fmaf(wgt, g_k, g); b = fmaf(wgt, c_k, b);
+                        if (T < T_thresh) running = false; else step++;
+                    }
+                }
+            }
+            int keep = 0;
+            if (leader) {
+                if (step < n_step) rays_alive[slot] = -1; else { rays_t[index] = t; keep = 1; }
+                weights_sum[index] = ws; depth[index] = d;
+                image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+            }
+            const unsigned long long km = __ballot(keep);
+            if (km != 0ull) {   // the wave's rays are consecutive slots: at most two chunks
+                const uint32_t c0 = ((tile * rpt + wave * rpw) / n_step) >> 8;
+                const unsigned long long k0 = __ballot(keep && (slot >> 8) == c0);
+                if (lane == 0) {
+                    if (k0) atomicAdd(&counts_cur[c0], __popcll(k0));
+                    if (km & ~k0) atomicAdd(&counts_cur[c0 + 1], __popcll(km & ~k0));
+                }
+            }
         }
     }
 }
@@ -1023,7 +1082,7 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_composite(const FrameCtl* _
                                                                float* __restrict__ rays_t, const float* __restrict__ sigmas,
                                                                const float* __restrict__ rgbs, const float* __restrict__ deltas,
                                                                float* __restrict__ weights_sum, float* __restrict__ depth, float* __restrict__ image,
-                                                               int32_t* __restrict__ scratch, const float* __restrict__ aux, float* __restrict__ aux_map,
+                                                               int32_t* __restrict__ counts_cur, const float* __restrict__ aux, float* __restrict__ aux_map,
                                                                uint32_t aux_stride, int aux_done_when_one_step, int all_done_when_one_step) {
     if (ctl->done) return;
     const uint32_t n_alive = (uint32_t)ctl->n_alive, n_step = (uint32_t)ctl->n_step;
@@ -1097,7 +1156,7 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_composite(const FrameCtl* _
         if (threadIdx.x == 0) {
             int tot = 0;
             for (int wv = 0; wv < (int)(kRayBlock / PNR_WAVE); wv++) tot += wsum[wv];
-            scratch[kHdr + chunk] = tot;
+            counts_cur[chunk] = tot;
         }
         __syncthreads();
     }
@@ -1135,7 +1194,7 @@ static FrameWorkspace carve(void* base, uint32_t N, uint32_t aux_stride = 0, boo
     w.enc = reinterpret_cast<float*>(take(n * 16 * 2 * 4));
     w.sigmas = reinterpret_cast<float*>(take(n * 4));
     w.rgbs = reinterpret_cast<float*>(take(n * 12));
-    w.scratch = reinterpret_cast<int32_t*>(take((kHdr + n / kRayBlock + 2) * 4));
+    w.scratch = reinterpret_cast<int32_t*>(take((kHdr + 2 * (n / kRayBlock + 2)) * 4));   // header, then the two per-chunk survivor count arrays
     w.partials[0] = reinterpret_cast<int32_t*>(take((kMaxMarchBlocks + kHostedBlocks) * 4));
     w.partials[1] = reinterpret_cast<int32_t*>(take((kMaxMarchBlocks + kHostedBlocks) * 4));
     w.enc_pal = w.enc_clip = w.aux = nullptr;
@@ -1226,7 +1285,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     const float* tables[3] = {a->embeddings, pal ? pal->embeddings_palette : nullptr, with_clip ? pal->embeddings_clip : nullptr};
     const uint32_t n_enc = pal ? (with_clip ? 3u : 2u) : 1u;
     const int aux_fused = (pal && g_opt_aux_fusion && pnr_palette_field_stages_aux(pal->num_basis, pal->clip_dim, pal->pred_clip)) ? 1 : 0;
-    const int composite_fused = (!pal && g_opt_composite_fusion) ? 1 : 0;   // NeRF: one-sample-per-ray iterations are composited inside the field kernel
+    const int composite_fused = (!pal && g_opt_composite_fusion) ? g_opt_composite_fusion : 0;   // NeRF: 1 = one-sample-per-ray iterations are composited inside the field kernel, 2 = all of them (no composite launch)
     const bool half_tables = a->table_dtype == PNR_DTYPE_F16;   // fp16 tables: nerf = `embeddings` as halves; palette = embeddings_pair as interleaved halves
     if (half_tables && pal && (with_clip || !pal->embeddings_pair)) return PNR_ERR_UNSUPPORTED;
     if (a->table_dtype != PNR_DTYPE_F32 && a->table_dtype != PNR_DTYPE_F16) return PNR_ERR_UNSUPPORTED;
@@ -1273,11 +1332,13 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     const uint32_t* mip = static_cast<const uint32_t*>(a->mip);
     const bool hosted = g_opt_hosted_tail && use_mip && pow2 && mp.mip_words != 0 && (a->H % 64u) == 0;   // (what MODE 2 and hosted_march_tail are compiled for)
 
+    const uint32_t cstride = N / kRayBlock + 2;
+    auto counts_of = [&](int parity) { return w.scratch + kHdr + (uint32_t)(parity & 1) * cstride; };   // iteration i fills counts_of(i), its march reads counts_of(i + 1)
     HostedConst hconst = {};
     hconst.qctr_all = w.qctr; hconst.qrecs = w.qrecs; hconst.rays_o = in_o; hconst.rays_d = in_d; hconst.bitfield = a->bitfield; hconst.mip = mip; hconst.p = mp;
     hconst.xyzs = w.xyzs; hconst.dirs = w.dirs; hconst.deltas = w.deltas; hconst.partials[0] = w.partials[0]; hconst.partials[1] = w.partials[1];
     hipLaunchKernelGGL(k_frame_init, dim3(cdiv(N, kRayBlock)), dim3(kRayBlock), 0, s, N, in_near, w.alive[1], w.rays_t, out_ws, out_depth, out_image,
-                       w.ctl, w.scratch + kHdr, w.qctr, hconst, w.hosted);
+                       w.ctl, counts_of(1), w.scratch, w.qctr, hconst, w.hosted);
     // optional live timing of the roofline kernel: HIP events on the launch stream around every k_frame_grid launch
     std::vector<hipEvent_t>& ev = dev_state.ev;
     size_t ev_used = 0;
@@ -1315,7 +1376,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             const uint32_t march_cap = mode == 2 ? (uint32_t)g_opt_march_blocks : kMaxMarchBlocks;
             const dim3 gm(ray_blocks < march_cap ? ray_blocks : march_cap), bm(kRayBlock);
 #define PNR_LAUNCH_MARCH(MIPV, P2V, MODEV)                                                                                                                \
-            hipLaunchKernelGGL((k_frame_march<MIPV, P2V, MODEV>), gm, bm, march_lds, s, prev, cur, alive_prev, alive_in, w.scratch, w.scratch, N, a->max_steps,    \
+            hipLaunchKernelGGL((k_frame_march<MIPV, P2V, MODEV>), gm, bm, march_lds, s, prev, cur, alive_prev, alive_in, counts_of(iter + 1), counts_of(iter), w.scratch, N, a->max_steps,    \
                                w.partials[(iter + 1) & 1], prev_partials, w.rays_t, in_o, in_d, mp, a->bitfield, in_far, w.xyzs, w.dirs, w.deltas, mip,           \
                                w.partials[iter & 1], budget, w.qctr, w.qrecs, w.rowflag)
             if (mode == 2) PNR_LAUNCH_MARCH(true, true, 2);   // (hosted implies the mip and power-of-two configuration)
@@ -1360,25 +1421,26 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             } else if (a->field_precision == PNR_FIELD_FP32)
                 hipLaunchKernelGGL((k_frame_field<0, false>), dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas,
                                    a->packed_weights, a->density_scale, enc_scale, w.sigmas, w.rgbs, composite_fused, a->T_thresh, alive_in, w.rays_t, out_ws, out_depth,
-                                   out_image, w.scratch);
+                                   out_image, w.scratch, counts_of(iter));
             else if (a->field_precision == PNR_FIELD_F16X2 && a->watch_overflow)
                 hipLaunchKernelGGL((k_frame_field<2, true>), dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas,
                                    a->packed_weights, a->density_scale, enc_scale, w.sigmas, w.rgbs, composite_fused, a->T_thresh, alive_in, w.rays_t, out_ws, out_depth,
-                                   out_image, w.scratch);
+                                   out_image, w.scratch, counts_of(iter));
             else if (a->field_precision == PNR_FIELD_F16X2)
                 hipLaunchKernelGGL((k_frame_field<2, false>), dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas,
                                    a->packed_weights, a->density_scale, enc_scale, w.sigmas, w.rgbs, composite_fused, a->T_thresh, alive_in, w.rays_t, out_ws, out_depth,
-                                   out_image, w.scratch);
+                                   out_image, w.scratch, counts_of(iter));
             else if (a->watch_overflow)
                 hipLaunchKernelGGL((k_frame_field<1, true>), dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas,
                                    a->packed_weights, a->density_scale, enc_scale, w.sigmas, w.rgbs, composite_fused, a->T_thresh, alive_in, w.rays_t, out_ws, out_depth,
-                                   out_image, w.scratch);
+                                   out_image, w.scratch, counts_of(iter));
             else
                 hipLaunchKernelGGL((k_frame_field<1, false>), dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas,
                                    a->packed_weights, a->density_scale, enc_scale, w.sigmas, w.rgbs, composite_fused, a->T_thresh, alive_in, w.rays_t, out_ws, out_depth,
-                                   out_image, w.scratch);
-            hipLaunchKernelGGL(k_frame_composite, gm, bm, 0, s, cur, a->T_thresh, alive_in, w.rays_t, w.sigmas, w.rgbs, w.deltas, out_ws, out_depth, out_image,
-                               w.scratch, (const float*)w.aux, out_aux, aux_stride, aux_fused, composite_fused);
+                                   out_image, w.scratch, counts_of(iter));
+            if (composite_fused != 2)   // (the NeRF field kernel composites every iteration itself)
+                hipLaunchKernelGGL(k_frame_composite, gm, bm, 0, s, cur, a->T_thresh, alive_in, w.rays_t, w.sigmas, w.rgbs, w.deltas, out_ws, out_depth, out_image,
+                                   counts_of(iter), (const float*)w.aux, out_aux, aux_stride, aux_fused, composite_fused);
             prev_partials = gm.x + ha.blocks;
         }
         if (hipMemcpyAsync(host_ctl, w.ctl + ((iter - 1) & 1), sizeof(FrameCtl), hipMemcpyDeviceToHost, s) != hipSuccess) return PNR_ERR_LAUNCH;   // the last launched iteration's

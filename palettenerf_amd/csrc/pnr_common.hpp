@@ -110,6 +110,6 @@ extern int g_opt_hosted_tail;  // frame loops: rays a march launch has not finis
 extern int g_opt_march_budget, g_opt_march_budget0;   // that budget in probe rounds: later launches / a frame's first launch (0 = the first launch keeps the in-wave cooperative tail)
 extern int g_opt_march_blocks;   // frame loops: workgroup cap of a budgeted march launch
 extern int g_opt_aux_fusion;   // PaletteNeRF frame loop: aux composite inside the field kernel
-extern int g_opt_composite_fusion;   // NeRF frame loop: n_step == 1 iterations composited inside the field kernel
+extern int g_opt_composite_fusion;   // NeRF frame loop: 1 = n_step == 1 iterations composited inside the field kernel, 2 = every iteration (no composite launch)
 extern int g_opt_dynamic_tiles;      // frame loops: field kernels hand wave tiles out through a device counter instead of a static schedule
 extern int g_opt_iteration_margin;   // frame loops: spare iterations enqueued beyond the previous frame's count before the first host look

@@ -490,7 +490,7 @@ int g_opt_march_budget = getenv("PNR_MARCH_BUDGET") ? atoi(getenv("PNR_MARCH_BUD
 int g_opt_march_budget0 = getenv("PNR_MARCH_BUDGET0") ? atoi(getenv("PNR_MARCH_BUDGET0")) : 0;  // the same for a frame's first launch; 0 = that launch keeps the in-wave cooperative tail
 int g_opt_march_blocks = getenv("PNR_MARCH_BLOCKS") ? atoi(getenv("PNR_MARCH_BLOCKS")) : 1280;    // workgroups of a budgeted march launch (5 per CU resident)
 int g_opt_aux_fusion = getenv("PNR_NO_AUX_FUSION") ? 0 : 1;
-int g_opt_composite_fusion = getenv("PNR_NO_COMPOSITE_FUSION") ? 0 : 1;
+int g_opt_composite_fusion = getenv("PNR_NO_COMPOSITE_FUSION") ? 0 : (getenv("PNR_COMPOSITE_FUSION") ? atoi(getenv("PNR_COMPOSITE_FUSION")) : 2);   // 2: the NeRF frame loop has no composite launch
 int g_opt_iteration_margin = getenv("PNR_ITERATION_MARGIN") ? atoi(getenv("PNR_ITERATION_MARGIN")) : 0;   // measured 0 / 1 / 2 / 4 on the moving-camera bench: 4.239 / 4.247 / 4.277 / 4.265 ms -- a look costs less than a spare iteration
 int g_opt_palette_waves12 = getenv("PNR_PALETTE_WAVES8") ? 0 : 1;   // specialised PaletteNeRF field kernel: 12-wave workgroups (three waves per SIMD)
 int g_opt_dynamic_tiles = getenv("PNR_DYNAMIC_TILES") ? 1 : 0;   // measured: garden 14.6 -> 20.2 ms with it on (one contended counter, scattered tiles): off
@@ -511,7 +511,7 @@ int pnr_set_option(const char* name, int value) {
     if (!strcmp(name, "march_budget0")) { g_opt_march_budget0 = value < 0 ? 0 : (value > 1024 ? 1024 : value); return PNR_OK; }
     if (!strcmp(name, "march_blocks")) { g_opt_march_blocks = value < 1 ? 1 : (value > 2048 ? 2048 : value); return PNR_OK; }
     if (!strcmp(name, "aux_fusion")) { g_opt_aux_fusion = value != 0; return PNR_OK; }
-    if (!strcmp(name, "composite_fusion")) { g_opt_composite_fusion = value != 0; return PNR_OK; }
+    if (!strcmp(name, "composite_fusion")) { g_opt_composite_fusion = value < 0 ? 0 : (value > 2 ? 2 : value); return PNR_OK; }
     if (!strcmp(name, "palette_waves12")) { g_opt_palette_waves12 = value != 0; return PNR_OK; }
     if (!strcmp(name, "dynamic_tiles")) { g_opt_dynamic_tiles = value != 0; return PNR_OK; }
     if (!strcmp(name, "adam_variant")) { g_opt_adam_variant = value & 7; return PNR_OK; }

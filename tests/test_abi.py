@@ -137,4 +137,4 @@ def test_training_entry_points_validate_without_gpu():
     assert lib.pnr_nerf_density_forward(None, None, u32(8), f32(1.0), None, None, i32(7), f32(1.0), None) == -2                                      # precision
     assert lib.pnr_nerf_density_forward(None, None, u32(8), f32(1.0), None, None, i32(1), f32(1.0), None) == -1
     assert lib.pnr_linear_bgrad(None, i32(0), u32(0), u32(13), None, i32(1), None, u64(0), None) == -1                                      # no output
-    assert lib.pnr_set_option(b"composite_fusion", 1) == 0
+    assert lib.pnr_set_option(b"composite_fusion", 2) == 0

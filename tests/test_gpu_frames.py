@@ -416,10 +416,11 @@ def test_palette_native_loop_pair_table_is_bit_identical(cuda, pred_clip):
 
 @pytest.mark.parametrize("precision", [0, 1])
 def test_nerf_composite_fusion_is_bit_identical(cuda, precision):
-    """NeRF native loop with the one-sample-per-ray iterations composited inside the field kernel against the same loop with the separate
-    composite launch (pnr_set_option composite_fusion 0): image, depth, weights and the sample count bit-identical.  An opaque field
-    (most iterations have n_step 1, rays die by T_thresh or by leaving the solid) and a translucent one (n_step climbs to 8, so fused and
-    unfused iterations alternate within one frame); 100 x 90 rays: the last chunk of the alive list is partial."""
+    """NeRF native loop with every iteration composited inside the field kernel (composite_fusion 2, the default: no composite launch at all;
+    rays of 2 ... 8 rows walked through wave shuffles, wave tiles of whole rays, survivor counts by atomics) and with the one-sample-per-ray
+    iterations only (1) against the same loop with the separate composite launch (0): image, depth, weights and the sample count
+    bit-identical.  An opaque field (most iterations have n_step 1, rays die by T_thresh or by leaving the solid) and translucent ones
+    (n_step climbs through 2, 3, ... 8); 100 x 90 rays: the last chunk of the alive list is partial."""
     from palettenerf_amd import _lib
     from palettenerf_amd.fused import NeRFFieldFused
     lib = _lib.load()
@@ -427,7 +428,7 @@ def test_nerf_composite_fusion_is_bit_identical(cuda, precision):
     ro, rd = scene.get_rays(pose, scene.intrinsics_from_fov(100, 90), 100, 90)
     ro, rd = ro.to(cuda), rd.to(cuda)
     try:
-        for density in (100.0, 0.5):
+        for density in (100.0, 0.5, 0.05):
             m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=density, min_near=0.2)
             scene.seed_field_(m, 23)
             m = m.to(cuda).eval()
@@ -437,18 +438,19 @@ def test_nerf_composite_fusion_is_bit_identical(cuda, precision):
             m._fused = NeRFFieldFused(m)
             m._fused.precision = precision
             outs = []
-            for flag in (1, 0):
+            for flag in (0, 1, 2):
                 assert lib.pnr_set_option(b"composite_fusion", flag) == 0
                 with torch.no_grad():
                     outs.append(m.render(ro, rd, perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4))
-            a, b = outs
-            assert int(a["rendered"].item()) == int(b["rendered"].item()) > 1000 and a["iterations"] == b["iterations"]
-            if density < 1:
-                assert a["iterations"] > 30
-            for k in ("image", "depth", "weights_sum"):
-                assert torch.equal(torch.nan_to_num(b[k], nan=-7.0), torch.nan_to_num(a[k], nan=-7.0)), (density, k)
+            b = outs[0]
+            for a in outs[1:]:
+                assert int(a["rendered"].item()) == int(b["rendered"].item()) > 1000 and a["iterations"] == b["iterations"]
+                if density < 1:
+                    assert a["iterations"] > 30
+                for k in ("image", "depth", "weights_sum"):
+                    assert torch.equal(torch.nan_to_num(b[k], nan=-7.0), torch.nan_to_num(a[k], nan=-7.0)), (density, k)
     finally:
-        lib.pnr_set_option(b"composite_fusion", 1)
+        lib.pnr_set_option(b"composite_fusion", 2)
 
 
 def test_palette_aux_fusion_is_bit_identical(cuda):
