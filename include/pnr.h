@@ -407,6 +407,14 @@ typedef struct pnr_palette_field_args {
     float enc_scale[3];            /* power-of-two prescales of enc / enc_palette / enc_clip in the split-fp16 path (0 or 1 = none) */
     int32_t* overflow_flag;        /* optional (device): set to 1 when a split-fp16 operand exceeds fp16's range (the kernel then watches its operands) */
     void* tile_counter;            /* internal (frame loop): device uint32, zero at launch -- waves fetch their 32-sample tiles from it; NULL = static schedule */
+    /* internal (frame loop), all or none: with these the kernel also does the ray-state half of the iteration's compositing step (what the frame loop's
+     * composite launch did): weights_sum / depth / image / rays_t of every ray, the alive list's holes, the per-chunk survivor counts */
+    float* rays_t;                 /* [N] */
+    float* weights_sum_rw;         /* [N] = weights_sum */
+    float* depth;                  /* [N] */
+    float* image;                  /* [N,3] */
+    int32_t* rays_alive_rw;        /* [n_alive] = rays_alive */
+    int32_t* counts_cur;           /* [chunks] survivors per 256-ray chunk of the alive list, cleared by the iteration's march launch */
 } pnr_palette_field_args;
 int pnr_palette_field_stages_aux(uint32_t num_basis, uint32_t clip_dim, int pred_clip);   /* 1 when the field kernel stages aux rows in LDS (then it can composite them) */
 uint64_t pnr_palette_field_packed_bytes(uint32_t num_basis, uint32_t clip_dim, int pred_clip);

@@ -155,7 +155,8 @@ class PaletteFieldArgs(ctypes.Structure):
                 ("deltas", _ptr), ("packed", _ptr), ("num_basis", _u32), ("clip_dim", _u32),
                 ("pred_clip", _int), ("density_scale", _f32), ("offsets_weight", _f32), ("view_dep_weight", _f32), ("aux_stride", _u32),
                 ("sigmas", _ptr), ("rgbs", _ptr), ("aux", _ptr), ("rays_alive", _ptr), ("weights_sum", _ptr), ("aux_map", _ptr), ("T_thresh", _f32),
-                ("precision", _int), ("edit", _ptr), ("xyzs", _ptr), ("edit_device", _ptr), ("enc_scale", _f32 * 3), ("overflow_flag", _ptr), ("tile_counter", _ptr)]
+                ("precision", _int), ("edit", _ptr), ("xyzs", _ptr), ("edit_device", _ptr), ("enc_scale", _f32 * 3), ("overflow_flag", _ptr), ("tile_counter", _ptr),
+                ("rays_t", _ptr), ("weights_sum_rw", _ptr), ("depth", _ptr), ("image", _ptr), ("rays_alive_rw", _ptr), ("counts_cur", _ptr)]   # frame loop only: leave NULL
 
 
 _lib = None

@@ -1286,6 +1286,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     const uint32_t n_enc = pal ? (with_clip ? 3u : 2u) : 1u;
     const int aux_fused = (pal && g_opt_aux_fusion && pnr_palette_field_stages_aux(pal->num_basis, pal->clip_dim, pal->pred_clip)) ? 1 : 0;
     const int composite_fused = (!pal && g_opt_composite_fusion) ? g_opt_composite_fusion : 0;   // NeRF: 1 = one-sample-per-ray iterations are composited inside the field kernel, 2 = all of them (no composite launch)
+    const bool pal_composite_fused = pal && aux_fused && g_opt_composite_fusion == 2;   // PaletteNeRF: the ray state is composited inside the field kernel as well (needs the staged aux rows)
     const bool half_tables = a->table_dtype == PNR_DTYPE_F16;   // fp16 tables: nerf = `embeddings` as halves; palette = embeddings_pair as interleaved halves
     if (half_tables && pal && (with_clip || !pal->embeddings_pair)) return PNR_ERR_UNSUPPORTED;
     if (a->table_dtype != PNR_DTYPE_F32 && a->table_dtype != PNR_DTYPE_F16) return PNR_ERR_UNSUPPORTED;
@@ -1416,6 +1417,9 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             if (pal) {
                 pf.ctl = cur; pf.B = rows_ub;
                 if (aux_fused) { pf.rays_alive = alive_in; pf.weights_sum = out_ws; pf.aux_map = out_aux; pf.T_thresh = a->T_thresh; }
+                if (pal_composite_fused) {   // the field kernel does the whole compositing step: no composite launch
+                    pf.rays_t = w.rays_t; pf.weights_sum_rw = out_ws; pf.depth = out_depth; pf.image = out_image; pf.rays_alive_rw = alive_in; pf.counts_cur = counts_of(iter);
+                }
                 const int rc = pnr_palette_field_forward(&pf, stream);
                 if (rc != PNR_OK) return rc;
             } else if (a->field_precision == PNR_FIELD_FP32)
@@ -1438,7 +1442,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
                 hipLaunchKernelGGL((k_frame_field<1, false>), dim3(gx < 512u ? gx : 512u), dim3(kFieldThreads), 0, s, cur, w.enc, N, w.dirs, w.deltas,
                                    a->packed_weights, a->density_scale, enc_scale, w.sigmas, w.rgbs, composite_fused, a->T_thresh, alive_in, w.rays_t, out_ws, out_depth,
                                    out_image, w.scratch, counts_of(iter));
-            if (composite_fused != 2)   // (the NeRF field kernel composites every iteration itself)
+            if (composite_fused != 2 && !pal_composite_fused)   // (the field kernels composite every iteration themselves)
                 hipLaunchKernelGGL(k_frame_composite, gm, bm, 0, s, cur, a->T_thresh, alive_in, w.rays_t, w.sigmas, w.rgbs, w.deltas, out_ws, out_depth, out_image,
                                    counts_of(iter), (const float*)w.aux, out_aux, aux_stride, aux_fused, composite_fused);
             prev_partials = gm.x + ha.blocks;

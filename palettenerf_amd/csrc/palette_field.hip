@@ -180,6 +180,11 @@ constexpr int kPalThreads = 512;
 // dead slots (delta == 0) are skipped.
 struct FrameCtlView { int32_t n_alive, n_step, step, done; };
 
+// frame loop, optional: the ray state the iteration's compositing step updates.  With it (and the aux rows staged) the kernel does
+// k_frame_composite's second phase itself -- weights_sum / depth / image / rays_t of every ray, the alive list's holes and the per-chunk
+// survivor counts -- for any number of samples per ray: a wave tile then holds floor(32 / n_step) whole rays.  All NULL: as before.
+struct RayState { float* rays_t; float* weights_sum; float* depth; float* image; int32_t* rays_alive; int32_t* counts_cur; };
+
 // torch.lerp(start, end, weight) for fp32 (ATen/native/Lerp.h): the branch keeps both ends exact
 __device__ __forceinline__ float torch_lerp(float a, float b, float w) { const float d = b - a; return w < 0.5f ? a + w * d : b - d * (1.0f - w); }
 
@@ -198,11 +203,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
                                                                    const int32_t* __restrict__ rays_alive, const float* __restrict__ weights_sum,
                                                                    float* __restrict__ aux_map, float T_thresh, const float* __restrict__ xyzs,
                                                                    const EditParams* __restrict__ ep, int32_t* __restrict__ overflow_flag,
-                                                                   uint32_t* __restrict__ tile_counter) {
+                                                                   uint32_t* __restrict__ tile_counter, RayState rs) {
     if (ctl && ctl->done) return;
     const uint32_t B = ctl ? (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step : B_arg;
-    constexpr uint32_t kTile = WAVES * 32;
-    const uint32_t ntiles = (B + kTile - 1) / kTile;
+    // rows of a ray are consecutive.  Whole rays per wave tile (rpw rows of its 32) when the kernel also composites the ray state; otherwise 32 rows,
+    // and the aux composite runs here only with 1, 2, 4 or 8 samples per ray (a ray's rows then sit inside one wave tile anyway)
+    const bool ray_tiles = stage_stride && ctl && aux_map && rs.rays_t;
+    const uint32_t rpw = ray_tiles ? (32u / (uint32_t)ctl->n_step) * (uint32_t)ctl->n_step : 32u;
+    const uint32_t ntiles = (B + WAVES * rpw - 1) / (WAVES * rpw);
     if (blockIdx.x >= ntiles) return;
     extern __shared__ unsigned char w[];
     for (uint32_t i = threadIdx.x * 16; i < packed_bytes; i += WAVES * 64 * 16)   // weights + the PaletteTables behind them
@@ -213,13 +221,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
     constexpr int kLoopNb = NB ? NB : kMaxNb;
     // rows of a ray are consecutive; with 1, 2, 4 or 8 samples per ray they sit inside one 32-row wave tile and the aux composite
     // can run here (fstep = samples per ray), otherwise the composite launch does it
-    const uint32_t fstep = (stage_stride && ctl && aux_map && ctl->n_step <= 8 && (32 % ctl->n_step) == 0) ? (uint32_t)ctl->n_step : 0u;
+    const uint32_t fstep = (stage_stride && ctl && aux_map && ctl->n_step <= 8 && (ray_tiles || (32 % ctl->n_step) == 0)) ? (uint32_t)ctl->n_step : 0u;
     const bool fuse_composite = fstep != 0;
     // Work is handed out per 32-sample wave tile: the static persistent schedule (workgroup b takes tiles b, b + grid, ...), or -- an experiment
     // kept behind pnr_set_option("dynamic_tiles") -- every wave fetching its next wave tile from a device counter (tile_counter, zeroed by the
     // iteration's march launch).  The idea: a launch of 11.08 workgroup tiles per CU takes the time of 12 with the static schedule.  Measured:
     // garden frame 14.6 -> 20.2 ms -- 34 k waves queue on one counter and a workgroup's waves no longer read neighbouring rows.  Off.
-    const uint32_t nwt = (B + 31) / 32;
+    const uint32_t nwt = (B + rpw - 1) / rpw;
     for (uint32_t it = 0;; it++) {
         uint32_t wt;
         if (tile_counter) {
@@ -230,9 +238,17 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
             wt = (blockIdx.x + it * gridDim.x) * WAVES + wave;
         }
         if (wt >= nwt) break;
-        const uint32_t n = wt * 32 + (lane & 31);
-        const bool valid = n < B && (!deltas || deltas[(size_t)(n < B ? n : 0) * 2] != 0.0f);
-        if (!__any(valid)) continue;
+        const uint32_t n = wt * rpw + (lane & 31);
+        const bool mine = (uint32_t)(lane & 31) < rpw && n < B;
+        const bool valid = mine && (!deltas || deltas[(size_t)(mine ? n : 0) * 2] != 0.0f);
+        if (!__any(valid)) {
+            // nothing to evaluate -- but with the ray state composited here, the rays of this wave tile (all their rows dead) must still leave the alive list
+            if (rs.rays_t) {
+                const uint32_t l = (uint32_t)(lane & 31), ns = (uint32_t)ctl->n_step;
+                if (h == 0 && l < rpw && (l % ns) == 0 && n / ns < (uint32_t)ctl->n_alive) rs.rays_alive[n / ns] = -1;
+            }
+            continue;
+        }
         const uint32_t row = n < B ? n : (B - 1);
 
         SplitWatch<CHECK> sw_, *sw = &sw_;
@@ -353,6 +369,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
 
         // ---------------- scalar epilogue on the lower half-wave: the palette colour-basis composite
         asm volatile("" : "+s"(toff));
+        float rgb_out[3] = {0.0f, 0.0f, 0.0f};   // this row's final colour, kept for the ray-state composite below
         if (valid && h == 0) {
             const PaletteTables& T = *reinterpret_cast<const PaletteTables*>(w + toff);
             float omega[kMaxNb], osum = 0.0f;
@@ -445,24 +462,27 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
             if (fuse_composite) ex[(lane & 31) * 3] = 1.0f - __expf(-sigma * deltas[(size_t)n * 2]);   // alpha, exactly as k_frame_composite forms it
             const float kvd = EDIT == 2 ? 1.0f : pp.view_dep_weight;   // the Stylizer adds view_dep unscaled (palette/renderer.py:181)
 #pragma unroll
-            for (int k = 0; k < 3; k++) rgbs[(size_t)n * 3 + k] = rgb[k] + kvd * view_dep[k];
+            for (int k = 0; k < 3; k++) { rgb_out[k] = rgb[k] + kvd * view_dep[k]; rgbs[(size_t)n * 3 + k] = rgb_out[k]; }
         }
         if constexpr (CHECK) { if (overflow_flag && sw_.overflowed()) *overflow_flag = 1; }
         if (stage_stride) {   // same wave wrote the slab: DS operations of a wave complete in order
             float* slab = reinterpret_cast<float*>(w + packed_bytes) + (size_t)wave * 32 * stage_stride;
             float* ex = reinterpret_cast<float*>(w + packed_bytes) + (size_t)WAVES * 32 * stage_stride + (size_t)wave * 96;
-            const uint32_t n0 = wt * 32, nq = (uint32_t)pp.aux_stride / 4;
+            const uint32_t n0 = wt * rpw, nq = (uint32_t)pp.aux_stride / 4;
             const unsigned long long live = __ballot(valid && h == 0);     // rows of dead / out-of-range slots hold stale slab data: skip them
             if (fuse_composite) {
                 // aux_map[ray] += sum_k weight_k * row_k: the recurrence of raymarching.cu:1114-1185 (weights from the weights_sum of
                 // BEFORE this iteration, stop at a dead row, stop after the sample that sees T < T_thresh), same fmaf order.
                 // Leader lane of a ray: weights of its rows, how many count, and the ray id, left in the slab's spare columns.
+                const bool leader = (uint32_t)lane < rpw && (lane % fstep) == 0 && (n0 + lane) / fstep < (uint32_t)ctl->n_alive;
+                const uint32_t slot = (n0 + lane) / fstep;
+                int cnt = 0, index = 0;
+                float ws = 0.0f;
+                bool stopped = false;   // the last row that counts saw T < T_thresh
                 if (lane < 32 && (lane % fstep) == 0) {
-                    const uint32_t slot = (n0 + lane) / fstep;
-                    int cnt = 0, index = 0;
-                    if (slot < (uint32_t)ctl->n_alive && ((live >> lane) & 1ull)) {
+                    if (leader && ((live >> lane) & 1ull)) {
                         index = rays_alive[slot];
-                        float ws = weights_sum[index];
+                        ws = weights_sum[index];
                         for (uint32_t k = 0; k < fstep; k++) {
                             if (!((live >> (lane + k)) & 1ull)) break;
                             const float T = 1.0f - ws;
@@ -470,13 +490,47 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
                             ws += wgt;
                             ex[(lane + k) * 3] = wgt;
                             cnt++;
-                            if (T < T_thresh) break;
+                            if (T < T_thresh) { stopped = true; break; }
                         }
+                    } else if (leader && rs.rays_t) {
+                        index = rays_alive[slot];
+                        ws = weights_sum[index];
                     }
                     ex[lane * 3 + 1] = __int_as_float(index);
                     ex[lane * 3 + 2] = __int_as_float(cnt);
                 }
-                const uint32_t rays_in_tile = 32 / fstep;
+                if (rs.rays_t) {
+                    // k_frame_composite's second phase (raymarching.cu:1025-1111) for the rays of this wave tile: the weights are the ones just formed
+                    // (same alpha, same T recurrence), the rows' colours come from the lanes that hold them
+                    float t = 0.0f, d = 0.0f, r = 0.0f, g = 0.0f, b = 0.0f;
+                    if (leader) { t = rs.rays_t[index]; d = rs.depth[index]; r = rs.image[index * 3]; g = rs.image[index * 3 + 1]; b = rs.image[index * 3 + 2]; }
+                    for (uint32_t k = 0; k < fstep; k++) {   // wave-uniform
+                        const int src = lane + (int)k;
+                        const float r_k = __shfl(rgb_out[0], src), g_k = __shfl(rgb_out[1], src), b_k = __shfl(rgb_out[2], src);
+                        if (leader && (int)k < cnt) {
+                            const float wgt = ex[(lane + k) * 3];
+                            t += deltas[(size_t)(n0 + lane + k) * 2 + 1];
+                            d = fmaf(wgt, t, d);
+                            r = fmaf(wgt, r_k, r); g = fmaf(wgt, g_k, g); b = fmaf(wgt, b_k, b);
+                        }
+                    }
+                    int keep = 0;
+                    if (leader) {
+                        if (cnt == (int)fstep && !stopped) { rs.rays_t[index] = t; keep = 1; } else rs.rays_alive[slot] = -1;
+                        rs.weights_sum[index] = ws; rs.depth[index] = d;
+                        rs.image[index * 3] = r; rs.image[index * 3 + 1] = g; rs.image[index * 3 + 2] = b;
+                    }
+                    const unsigned long long km = __ballot(keep);
+                    if (km != 0ull) {   // consecutive slots: at most two chunks of the alive list
+                        const uint32_t c0 = (n0 / fstep) >> 8;
+                        const unsigned long long k0 = __ballot(keep && (slot >> 8) == c0);
+                        if (lane == 0) {
+                            if (k0) atomicAdd(&rs.counts_cur[c0], __popcll(k0));
+                            if (km & ~k0) atomicAdd(&rs.counts_cur[c0 + 1], __popcll(km & ~k0));
+                        }
+                    }
+                }
+                const uint32_t rays_in_tile = rpw / fstep;
                 for (uint32_t i = (uint32_t)lane; i < rays_in_tile * nq; i += 64) {
                     const uint32_t ray = i / nq, q = i - ray * nq, base = ray * fstep;
                     const int cnt = __float_as_int(ex[base * 3 + 2]);
@@ -622,7 +676,7 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
     const bool x2 = a->precision == PNR_FIELD_F16X2 && nb4 && edit_mode == 0;
     const bool wide = nb4 && g_opt_palette_waves12 && packed_bytes + 12u * 32u * (a->aux_stride + 3u) * 4u <= 160u * 1024u;
     const uint32_t waves = wide ? 12u : 8u;
-    const uint32_t ntiles = cdiv(rows_ub ? rows_ub : 1, waves * 32);
+    const uint32_t ntiles = cdiv(rows_ub ? rows_ub : 1, waves * 28);   // (a wave tile holds 28 ... 32 rows when it holds whole rays)
     const uint32_t grid = ntiles < 256u ? ntiles : 256u;
     constexpr uint32_t kLdsLimit = 160 * 1024;
     // staging slab for coalesced aux rows: 8 waves x 32 rows x (aux_stride + 4) floats, when it fits next to the weights
@@ -630,6 +684,11 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
     const uint32_t stage_stride = stages ? a->aux_stride : 0;
     const uint32_t lds = packed_bytes + (stages ? waves * 32 * (stage_stride + 3) * 4 : 0);
     const bool fuse = a->ctl && a->rays_alive && a->weights_sum && a->aux_map;
+    RayState rs = {};
+    if (fuse && stages && a->rays_t && a->depth && a->image && a->rays_alive_rw && a->counts_cur) {
+        rs.rays_t = a->rays_t; rs.weights_sum = a->weights_sum_rw; rs.depth = a->depth; rs.image = a->image; rs.rays_alive = a->rays_alive_rw; rs.counts_cur = a->counts_cur;
+        if (!rs.weights_sum) return PNR_ERR_INVALID;
+    }
     hipStream_t s = as_stream(stream);
     const EditParams* ep_dev = nullptr;
     int edit_slot = -1;
@@ -659,7 +718,7 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
                            static_cast<const FrameCtlView*>(a->ctl), a->B, a->enc, a->enc_palette, a->enc_clip, a->level_stride, a->dirs,      \
                            a->deltas, static_cast<const unsigned char*>(a->packed), packed_bytes, pp, a->sigmas, a->rgbs, a->aux,              \
                            stage_stride, fuse ? a->rays_alive : nullptr, fuse ? a->weights_sum : nullptr, fuse ? a->aux_map : nullptr,         \
-                           a->T_thresh, a->xyzs, ep_dev, a->overflow_flag, static_cast<uint32_t*>(a->tile_counter));                          \
+                           a->T_thresh, a->xyzs, ep_dev, a->overflow_flag, static_cast<uint32_t*>(a->tile_counter), rs);                      \
     } while (0)
     if (fp16 && a->overflow_flag) {   // the instantiation that watches its split operands
         if (edit_mode == 0) PNR_LAUNCH_PAL(1, 0, true); else if (edit_mode == 1) PNR_LAUNCH_PAL(1, 1, true); else PNR_LAUNCH_PAL(1, 2, true);

@@ -454,9 +454,10 @@ def test_nerf_composite_fusion_is_bit_identical(cuda, precision):
 
 
 def test_palette_aux_fusion_is_bit_identical(cuda):
-    """PaletteNeRF native loop with the aux composite inside the field kernel (1, 2, 4, 8 samples per ray) against the same loop with
-    the separate composite launch doing it (pnr_set_option aux_fusion 0): every map bit-identical.  Two densities so that the frame
-    goes through n_step 1, 2, 4 and 8 and through the T_thresh early exits."""
+    """PaletteNeRF native loop with the whole compositing step inside the field kernel (the default: aux rows and the ray state, any number of
+    samples per ray, wave tiles of whole rays; no composite launch), with the aux composite only inside it (composite_fusion 1: 1, 2, 4, 8
+    samples per ray) and with the separate composite launch doing everything (aux_fusion 0): every map bit-identical.  Three densities so
+    that the frame goes through n_step 1 ... 8 and through the T_thresh early exits; with and without a clip head (52- and 36-float rows)."""
     from palettenerf_amd import _lib
     from palettenerf_amd.fused import PaletteFieldFused
     lib = _lib.load()
@@ -464,8 +465,8 @@ def test_palette_aux_fusion_is_bit_identical(cuda):
     ro, rd = scene.get_rays(pose, scene.intrinsics_from_fov(64, 56), 64, 56)
     ro, rd = ro.to(cuda), rd.to(cuda)
     try:
-        for density in (40.0, 0.5):
-            m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True, density_scale=density, min_near=0.2)
+        for density, pred_clip in ((40.0, False), (0.5, False), (0.05, False), (0.5, True)):
+            m = network.PaletteNetwork(renderer.default_opt(pred_clip=pred_clip), bound=2, cuda_ray=True, density_scale=density, min_near=0.2)
             scene.seed_field_(m, 21)
             m = m.to(cuda).eval()
             put_scene(m, cuda)
@@ -473,19 +474,20 @@ def test_palette_aux_fusion_is_bit_identical(cuda):
             m.march_mode, m.fused_field = "native", True
             m._fused = PaletteFieldFused(m)
             outs = []
-            for flag in (1, 0):
-                assert lib.pnr_set_option(b"aux_fusion", flag) == 0
+            for aux, comp in ((0, 2), (1, 2), (1, 1)):
+                assert lib.pnr_set_option(b"aux_fusion", aux) == 0 and lib.pnr_set_option(b"composite_fusion", comp) == 0
                 with torch.no_grad():
                     outs.append(m.render(ro, rd, perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4, gui_mode=False))
-            a, b = outs
-            assert int(a["rendered"].item()) == int(b["rendered"].item()) > 1000 and a["iterations"] == b["iterations"]
-            if density < 1:
-                assert a["iterations"] > 30          # translucent: the schedule reaches 8 samples per ray
-            for k, v in a.items():
-                if torch.is_tensor(v) and v.dtype.is_floating_point and v.numel() > 1:
-                    assert torch.equal(torch.nan_to_num(b[k], nan=-7.0), torch.nan_to_num(v, nan=-7.0)), (density, k)
+            b = outs[0]
+            for a in outs[1:]:
+                assert int(a["rendered"].item()) == int(b["rendered"].item()) > 1000 and a["iterations"] == b["iterations"]
+                if density < 1:
+                    assert a["iterations"] > 30          # translucent: the schedule reaches 8 samples per ray
+                for k, v in a.items():
+                    if torch.is_tensor(v) and v.dtype.is_floating_point and v.numel() > 1:
+                        assert torch.equal(torch.nan_to_num(b[k], nan=-7.0), torch.nan_to_num(v, nan=-7.0)), (density, pred_clip, k)
     finally:
-        lib.pnr_set_option(b"aux_fusion", 1)
+        lib.pnr_set_option(b"aux_fusion", 1); lib.pnr_set_option(b"composite_fusion", 2)
     assert lib.pnr_set_option(b"no_such_option", 1) != 0
 
 
