@@ -499,17 +499,38 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
                     ex[lane * 3 + 1] = __int_as_float(index);
                     ex[lane * 3 + 2] = __int_as_float(cnt);
                 }
+                // the ray state is requested here and used behind the aux rows' composite below (the loads land under it)
+                float t = 0.0f, d = 0.0f, r = 0.0f, g = 0.0f, b = 0.0f;
+                float dl1_0 = 0.0f;
+                if (rs.rays_t && leader) {
+                    t = rs.rays_t[index]; d = rs.depth[index]; r = rs.image[index * 3]; g = rs.image[index * 3 + 1]; b = rs.image[index * 3 + 2];
+                    dl1_0 = deltas[(size_t)(n0 + lane) * 2 + 1];
+                }
+                const uint32_t rays_in_tile = rpw / fstep;
+                for (uint32_t i = (uint32_t)lane; i < rays_in_tile * nq; i += 64) {
+                    const uint32_t ray = i / nq, q = i - ray * nq, base = ray * fstep;
+                    const int cnt = __float_as_int(ex[base * 3 + 2]);
+                    if (cnt == 0) continue;
+                    const int index = __float_as_int(ex[base * 3 + 1]);
+                    float4* dst = reinterpret_cast<float4*>(aux_map + (size_t)index * pp.aux_stride) + q;
+                    float4 acc = *dst;
+                    for (int k = 0; k < cnt; k++) {
+                        const float* r = slab + (base + k) * stage_stride;
+                        const float wgt = ex[(base + k) * 3];
+                        const float4 v = *reinterpret_cast<const float4*>(r + q * 4);
+                        acc.x = fmaf(wgt, v.x, acc.x); acc.y = fmaf(wgt, v.y, acc.y); acc.z = fmaf(wgt, v.z, acc.z); acc.w = fmaf(wgt, v.w, acc.w);
+                    }
+                    *dst = acc;
+                }
                 if (rs.rays_t) {
                     // k_frame_composite's second phase (raymarching.cu:1025-1111) for the rays of this wave tile: the weights are the ones just formed
                     // (same alpha, same T recurrence), the rows' colours come from the lanes that hold them
-                    float t = 0.0f, d = 0.0f, r = 0.0f, g = 0.0f, b = 0.0f;
-                    if (leader) { t = rs.rays_t[index]; d = rs.depth[index]; r = rs.image[index * 3]; g = rs.image[index * 3 + 1]; b = rs.image[index * 3 + 2]; }
                     for (uint32_t k = 0; k < fstep; k++) {   // wave-uniform
                         const int src = lane + (int)k;
                         const float r_k = __shfl(rgb_out[0], src), g_k = __shfl(rgb_out[1], src), b_k = __shfl(rgb_out[2], src);
                         if (leader && (int)k < cnt) {
                             const float wgt = ex[(lane + k) * 3];
-                            t += deltas[(size_t)(n0 + lane + k) * 2 + 1];
+                            t += k == 0 ? dl1_0 : deltas[(size_t)(n0 + lane + k) * 2 + 1];
                             d = fmaf(wgt, t, d);
                             r = fmaf(wgt, r_k, r); g = fmaf(wgt, g_k, g); b = fmaf(wgt, b_k, b);
                         }
@@ -529,22 +550,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
                             if (km & ~k0) atomicAdd(&rs.counts_cur[c0 + 1], __popcll(km & ~k0));
                         }
                     }
-                }
-                const uint32_t rays_in_tile = rpw / fstep;
-                for (uint32_t i = (uint32_t)lane; i < rays_in_tile * nq; i += 64) {
-                    const uint32_t ray = i / nq, q = i - ray * nq, base = ray * fstep;
-                    const int cnt = __float_as_int(ex[base * 3 + 2]);
-                    if (cnt == 0) continue;
-                    const int index = __float_as_int(ex[base * 3 + 1]);
-                    float4* dst = reinterpret_cast<float4*>(aux_map + (size_t)index * pp.aux_stride) + q;
-                    float4 acc = *dst;
-                    for (int k = 0; k < cnt; k++) {
-                        const float* r = slab + (base + k) * stage_stride;
-                        const float wgt = ex[(base + k) * 3];
-                        const float4 v = *reinterpret_cast<const float4*>(r + q * 4);
-                        acc.x = fmaf(wgt, v.x, acc.x); acc.y = fmaf(wgt, v.y, acc.y); acc.z = fmaf(wgt, v.z, acc.z); acc.w = fmaf(wgt, v.w, acc.w);
-                    }
-                    *dst = acc;
                 }
             } else {
                 for (uint32_t i = (uint32_t)lane; i < 32 * nq; i += 64) {
