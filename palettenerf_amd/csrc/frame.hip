@@ -910,15 +910,18 @@ __device__ __forceinline__ void frame_grid_body(const FrameCtl* __restrict__ ctl
 #ifndef PNR_GRID_WAVES
 #define PNR_GRID_WAVES 8
 #endif
-#define PNR_GRID_KERNEL(NAME, KIND)                                                                                                          \
-    __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PNR_GRID_WAVES))) NAME(const FrameCtl* __restrict__ ctl, GridArgs g, HostedArgs h) { \
+#ifndef PNR_GRID_WAVES_SINGLE
+#define PNR_GRID_WAVES_SINGLE 7   // the one-table kernel with its hosted tail: 72 registers (fewer spills in the tail) beat the eighth wave -- lego 3.80 -> 3.68 ms; the pair kernel is better off with eight (garden 13.3 against 13.6)
+#endif
+#define PNR_GRID_KERNEL(NAME, KIND, WAVES)                                                                                                   \
+    __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) NAME(const FrameCtl* __restrict__ ctl, GridArgs g, HostedArgs h) { \
         frame_grid_body<KIND>(ctl, g, h);                                                                                                    \
     }
-PNR_GRID_KERNEL(k_frame_grid, GK_SINGLE)
-PNR_GRID_KERNEL(k_frame_grid_pair, GK_PAIR)
-PNR_GRID_KERNEL(k_frame_grid_triple, GK_TRIPLE)
-PNR_GRID_KERNEL(k_frame_grid_h1, GK_HALF1)
-PNR_GRID_KERNEL(k_frame_grid_h2, GK_HALF2)
+PNR_GRID_KERNEL(k_frame_grid, GK_SINGLE, PNR_GRID_WAVES_SINGLE)
+PNR_GRID_KERNEL(k_frame_grid_pair, GK_PAIR, PNR_GRID_WAVES)
+PNR_GRID_KERNEL(k_frame_grid_triple, GK_TRIPLE, PNR_GRID_WAVES)
+PNR_GRID_KERNEL(k_frame_grid_h1, GK_HALF1, PNR_GRID_WAVES)
+PNR_GRID_KERNEL(k_frame_grid_h2, GK_HALF2, PNR_GRID_WAVES)
 #undef PNR_GRID_KERNEL
 
 __global__ void __launch_bounds__(256) k_interleave_tables(const float2* __restrict__ a, const float2* __restrict__ b, uint64_t rows,
