@@ -54,12 +54,14 @@ const char* pnr_error_string(int code);
 /* ABI version of this header; bumped on any signature change. */
 int pnr_abi_version(void);
 /* run-time switches that change speed only, for A/B measurements and tests: "block_skip" (exact jumps over empty blocks in the march),
- * "aux_fusion" (PaletteNeRF frame loop: aux composite inside the field kernel), "composite_fusion" (NeRF frame loop: iterations with one
- * sample per ray composited inside the field kernel); all default to 1.  "adam_variant" (0..7, default 0): which multiply-adds of pnr_adam_step
+ * "aux_fusion" (PaletteNeRF frame loop: aux composite inside the field kernel), "coop_march" (wave-cooperative march tail); these default to 1.
+ * "composite_fusion" (frame loops; default 2): 2 = the field kernels do the whole compositing step of every iteration (three launches per
+ * iteration), 1 = the NeRF field kernel composites the iterations with one sample per ray only, 0 = the composite launch does.  "adam_variant" (0..7, default 0): which multiply-adds of pnr_adam_step
  * are left uncontracted (kept for re-deriving the bit-exact form against a new torch build); "iteration_margin" (default 0): spare iterations
  * the frame loops enqueue beyond the previous frame's count before their first look at the control block; "hosted_tail" (default 1): the frame
  * loops' march launches hand the rays they have not finished within "march_budget" (default 2; "march_budget0" for a frame's first launch, default
- * 0 = that launch finishes every ray itself) sample-less probes to the first workgroups of the lookup launch that follows -- same rows, bit for bit */
+ * 0 = that launch finishes every ray itself) sample-less probes to the first workgroups of the lookup launch that follows -- same rows, bit for bit;
+ * "march_blocks" (default 1280): workgroup cap of such a budgeted march launch */
 int pnr_set_option(const char* name, int value);
 
 /* ---------------------------------------------------------------- raymarching: utils ------- */
