@@ -401,6 +401,10 @@ def training_leg(model_kind, device, steps=50, warmup=8, rays=4096):
         if kernels:
             rec["kernel_ms_per_step"] = sum(e.device_time for e in kernels) / n / 1e3
             rec["launches_per_step"] = len(kernels) / n
+            hip = [e for e in kernels if e.name.startswith("pnr::") or "pnr::" in e.name[:12]]
+            rec["launches_hip_per_step"] = len(hip) / n          # this repository's kernels: march, lookups, MLP stacks, composites, binned gradient, Adam
+            rec["kernel_ms_hip_per_step"] = sum(e.device_time for e in hip) / n / 1e3
+            rec["launches_torch_per_step"] = (len(kernels) - len(hip)) / n   # torch's: the loss arithmetic of the (stand-in) trainer, the renderer's bg blend / depth normalisation, sigmoids, one cat, fills, gradient accumulation
             rec["wall_over_kernel"] = wall / rec["kernel_ms_per_step"]
     except Exception as e:   # noqa: BLE001 -- a profiler that does not work on this box is reported, the wall figure stands
         rec["profiler_error"] = repr(e)

@@ -1375,8 +1375,9 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             // hosted tail (MODE 2): the march gives every ray `budget` sample-less probes and queues the rest for the lookup launch's first workgroups
             const uint32_t budget = hosted ? (uint32_t)(iter == 0 ? g_opt_march_budget0 : g_opt_march_budget) : 0u;
             const int mode = budget ? 2 : 1;
-            // MODE 2 runs five workgroups per CU: a launch of more than 1280 would start its last workgroups 8 us late, after a full prologue of the others;
-            // capped there, the few workgroups with a second chunk reuse their staged mip and chunk sums (launch 16.9 -> ~14 us with 1 352 chunks)
+            // MODE 2 runs five workgroups per CU; a typical later launch of 1 352 chunks therefore starts its last 72 workgroups ~8 us late (launch 16.9 us).
+            // Capping the launch at the 1 280 resident workgroups ("march_blocks") is no way out: a workgroup's second chunk waits at the block barriers for
+            // the slowest wave of its first one -- 18.4 us (profiles/march_timing.py).  The cap stays an option, default off.
             const uint32_t march_cap = mode == 2 ? (uint32_t)g_opt_march_blocks : kMaxMarchBlocks;
             const dim3 gm(ray_blocks < march_cap ? ray_blocks : march_cap), bm(kRayBlock);
 #define PNR_LAUNCH_MARCH(MIPV, P2V, MODEV)                                                                                                                \
