@@ -64,6 +64,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra driver-observed legs (exact-fp32 field, palette model)")
     ap.add_argument("--extra-steps", type=int, default=20)
+    ap.add_argument("--shared-stream", action="store_true",
+                    help="with --main-frames-in-flight F > 1: all F handles enqueue into one stream (frames back to back without the host's gap, kernels never overlap)")
     ap.add_argument("--main-frames-in-flight", type=int, default=1, metavar="F",
                     help="render the TIMED steps themselves with F frames in flight (any --gpus N: the ranks' all-gathers are issued in frame order through one "
                          "communicator).  Default 1: a step is one frame at a time, ms_per_step is a frame's latency and the roofline launches run alone")
@@ -595,7 +597,7 @@ def main(argv=None):
         # previous gather after it has started the next one.
         import threading
         from palettenerf_amd.pipeline import FramesInFlight
-        fif = FramesInFlight(m, F_main, device)
+        fif = FramesInFlight(m, F_main, device, shared_stream=args.shared_stream)
         if use_dist:
             gatherer = pdist.FrameGatherer(VH, W, K, device, slots=F_main + 1)
         acc = {"rendered": 0, "rows": 0, "looks": 0, "iterations": 0}

@@ -1316,9 +1316,10 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     // prediction of the previous frame rendered there
     // (released when the host thread ends: a pool that replaces its worker threads does not accumulate pinned blocks and events)
     struct PerDevice {
-        FrameCtl* host_ctl = nullptr; std::vector<hipEvent_t> ev; uint32_t predicted_iterations = 0;
+        FrameCtl* host_ctl = nullptr; std::vector<hipEvent_t> ev; uint32_t predicted_iterations = 0; hipEvent_t done_ev = nullptr;
         ~PerDevice() {
             if (host_ctl) (void)hipHostFree(host_ctl);
+            if (done_ev) (void)hipEventDestroy(done_ev);
             for (hipEvent_t e : ev) (void)hipEventDestroy(e);
         }
     };
@@ -1452,7 +1453,10 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             prev_partials = gm.x + ha.blocks;
         }
         if (hipMemcpyAsync(host_ctl, w.ctl + ((iter - 1) & 1), sizeof(FrameCtl), hipMemcpyDeviceToHost, s) != hipSuccess) return PNR_ERR_LAUNCH;   // the last launched iteration's
-        if (hipStreamSynchronize(s) != hipSuccess) return PNR_ERR_LAUNCH;
+        // wait for THIS read-back, not for the stream: another host thread may already have queued the next frame behind it (pipeline.FramesInFlight
+        // with a shared stream: frames back to back without the host's gap between them, kernels never overlapping)
+        if (!dev_state.done_ev && hipEventCreateWithFlags(&dev_state.done_ev, hipEventDisableTiming) != hipSuccess) return PNR_ERR_LAUNCH;
+        if (hipEventRecord(dev_state.done_ev, s) != hipSuccess || hipEventSynchronize(dev_state.done_ev) != hipSuccess) return PNR_ERR_LAUNCH;
         if (host_ctl->done) break;
         alive_ub = (uint32_t)host_ctl->n_alive;
         if (looks == 0) chunk = predicted_iterations ? 4u : 8u;

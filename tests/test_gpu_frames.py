@@ -789,15 +789,17 @@ def test_frames_in_flight_equal_frames_rendered_one_by_one(cuda, kind):
     with torch.no_grad():
         one_by_one = [m.render(ro, rd, **kw) for ro, rd in rays]
     want = [{k: r[k].clone() for k in keys} | {"rendered": int(r["rendered"].sum())} for r in one_by_one]
-    fif = FramesInFlight(m, 3)
-    for _ in range(2):   # twice: the second pass runs on warm handles (each thread's iteration prediction comes from a different pose)
-        got = fif.render(lambda i: rays[i], len(rays), **kw)
-        for i, (g, w) in enumerate(zip(got, want)):
-            assert int(g["rendered"].sum()) == w["rendered"], i
-            for k in keys:
-                a, b = g[k].cpu().numpy(), w[k].cpu().numpy()
-                np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
-                np.testing.assert_array_equal(np.nan_to_num(a), np.nan_to_num(b), err_msg=f"frame {i} {k}")
+    for shared in (False, True):   # a stream per handle (kernels of different frames overlap) / one stream for all (frames back to back, the host's gap hidden)
+        fif = FramesInFlight(m, 3, shared_stream=shared)
+        for _ in range(2):   # twice: the second pass runs on warm handles (each thread's iteration prediction comes from a different pose)
+            got = fif.render(lambda i: rays[i], len(rays), **kw)
+            for i, (g, w) in enumerate(zip(got, want)):
+                assert int(g["rendered"].sum()) == w["rendered"], i
+                for k in keys:
+                    a, b = g[k].cpu().numpy(), w[k].cpu().numpy()
+                    np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+                    np.testing.assert_array_equal(np.nan_to_num(a), np.nan_to_num(b), err_msg=f"frame {i} {k} shared_stream={shared}")
+        fif.close()
 
 
 @pytest.mark.gpu
