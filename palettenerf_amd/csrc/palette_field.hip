@@ -391,11 +391,17 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
             // compositing weight; per ray leader: ray id and number of rows that count)
             float* a = stage_stride ? reinterpret_cast<float*>(w + packed_bytes) + ((size_t)wave * 32 + (lane & 31)) * stage_stride
                                     : aux + (size_t)n * pp.aux_stride;
+            // `a` is LDS or global, so its stores would be flat_store (57 per tile through both the vector-memory and the LDS queue); the 12-wave
+            // kernels always stage (the launcher sees to it): there the row is written with ds_write
+            auto put = [&](int idx, float v) {
+                if constexpr (WAVES == 12) reinterpret_cast<__attribute__((address_space(3))) float*>(reinterpret_cast<uintptr_t>(a))[idx] = v;
+                else a[idx] = v;
+            };
             float* ex = reinterpret_cast<float*>(w + packed_bytes) + (size_t)WAVES * 32 * stage_stride + (size_t)wave * 96;
 #pragma unroll
-            for (int k = 0; k < 3; k++) { a[k] = diffuse[k] + view_dep[k]; a[3 + k] = view_dep[k]; }   // direct_rgb, view_dep_rgb
+            for (int k = 0; k < 3; k++) { put(k, diffuse[k] + view_dep[k]); put(3 + k, view_dep[k]); }   // direct_rgb, view_dep_rgb
 #pragma unroll
-            for (int b = 0; b < kLoopNb; b++) if (NB || b < nb) { omega[b] = omega[b] / osum; a[6 + b] = omega[b]; }
+            for (int b = 0; b < kLoopNb; b++) if (NB || b < nb) { omega[b] = omega[b] / osum; put(6 + b, omega[b]); }
             float edit_w = 1.0f;
             if constexpr (EDIT == 1) {   // RegionEdit's window (palette/renderer.py:126-134)
                 if (ep->has_mean_xyz) {
@@ -449,20 +455,23 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
                 for (int k = 0; k < 3; k++) {
                     const float brgb = omega[b] * fin[k];
                     rgb[k] += brgb;
-                    a[6 + nb + 3 * b + k] = brgb;                                    // basis_rgb
-                    a[6 + 4 * nb + 3 * b + k] = T.basis_color[b][k] + off[k];       // unscaled_basis_rgb
+                    put(6 + nb + 3 * b + k, brgb);                                    // basis_rgb
+                    put(6 + 4 * nb + 3 * b + k, T.basis_color[b][k] + off[k]);       // unscaled_basis_rgb
                 }
             }
             int c = 6 + 7 * nb;
+            if (pp.pred_clip) {   // the clip head's outputs sit in registers: compile-time indices
 #pragma unroll
-            for (int k = 0; k < PNR_MAX_CLIP; k++) if (k < pp.clip_dim) a[c + k] = pp.pred_clip ? (k < 16 ? clip[k & 15] : clip2[k & 15]) : 0.0f;
-            for (c += pp.clip_dim; c < pp.aux_stride; c++) a[c] = 0.0f;
+                for (int k = 0; k < PNR_MAX_CLIP; k++) if (k < pp.clip_dim) put(c + k, k < 16 ? clip[k & 15] : clip2[k & 15]);
+                c += pp.clip_dim;
+            }
+            for (; c < pp.aux_stride; c++) put(c, 0.0f);   // (without a clip head the clip_dim columns are zeros too, as the reference's torch.zeros clip_feat)
             const float sigma = pp.density_scale * __expf(sigma_logit);
-            sigmas[n] = sigma;
+            if (!rs.rays_t) sigmas[n] = sigma;   // (with the ray state composited here nobody reads sigmas / rgbs)
             if (fuse_composite) ex[(lane & 31) * 3] = 1.0f - __expf(-sigma * deltas[(size_t)n * 2]);   // alpha, exactly as k_frame_composite forms it
             const float kvd = EDIT == 2 ? 1.0f : pp.view_dep_weight;   // the Stylizer adds view_dep unscaled (palette/renderer.py:181)
 #pragma unroll
-            for (int k = 0; k < 3; k++) { rgb_out[k] = rgb[k] + kvd * view_dep[k]; rgbs[(size_t)n * 3 + k] = rgb_out[k]; }
+            for (int k = 0; k < 3; k++) { rgb_out[k] = rgb[k] + kvd * view_dep[k]; if (!rs.rays_t) rgbs[(size_t)n * 3 + k] = rgb_out[k]; }
         }
         if constexpr (CHECK) { if (overflow_flag && sw_.overflowed()) *overflow_flag = 1; }
         if (stage_stride) {   // same wave wrote the slab: DS operations of a wave complete in order
@@ -679,7 +688,8 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
     const bool fp16 = a->precision != PNR_FIELD_FP32;
     const bool nb4 = fp16 && a->num_basis == 4 && !a->overflow_flag;
     const bool x2 = a->precision == PNR_FIELD_F16X2 && nb4 && edit_mode == 0;
-    const bool wide = nb4 && g_opt_palette_waves12 && packed_bytes + 12u * 32u * (a->aux_stride + 3u) * 4u <= 160u * 1024u;
+    const bool stages_pre = a->aux_stride == pnr_palette_aux_channels(a->num_basis, a->clip_dim) && pnr_palette_field_stages_aux(a->num_basis, a->clip_dim, pp.pred_clip);
+    const bool wide = nb4 && stages_pre && g_opt_palette_waves12 && packed_bytes + 12u * 32u * (a->aux_stride + 3u) * 4u <= 160u * 1024u;   // (the 12-wave kernels write their aux rows to LDS unconditionally)
     const uint32_t waves = wide ? 12u : 8u;
     const uint32_t ntiles = cdiv(rows_ub ? rows_ub : 1, waves * 28);   // (a wave tile holds 28 ... 32 rows when it holds whole rays)
     const uint32_t grid = ntiles < 256u ? ntiles : 256u;
