@@ -393,9 +393,17 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
                                     : aux + (size_t)n * pp.aux_stride;
             // `a` is LDS or global, so its stores would be flat_store (57 per tile through both the vector-memory and the LDS queue); the 12-wave
             // kernels always stage (the launcher sees to it): there the row is written with ds_write
-            auto put = [&](int idx, float v) {
-                if constexpr (WAVES == 12) reinterpret_cast<__attribute__((address_space(3))) float*>(reinterpret_cast<uintptr_t>(a))[idx] = v;
+            // ... and, with the shipped 4 bases, the first 32 floats of the row (compile-time positions) leave as eight 16-byte writes
+            typedef __attribute__((address_space(3))) float lds_float;
+            constexpr bool kRowRegs = NB == 4 && WAVES == 12;
+            float rowv[32];
+            auto put_tail = [&](int idx, float v) {   // run-time positions (clip columns, padding)
+                if constexpr (WAVES == 12) reinterpret_cast<lds_float*>(reinterpret_cast<uintptr_t>(a))[idx] = v;
                 else a[idx] = v;
+            };
+            auto put = [&](int idx, float v) {
+                if constexpr (kRowRegs) { if (idx < 32) rowv[idx] = v; else put_tail(idx, v); }
+                else put_tail(idx, v);
             };
             float* ex = reinterpret_cast<float*>(w + packed_bytes) + (size_t)WAVES * 32 * stage_stride + (size_t)wave * 96;
 #pragma unroll
@@ -460,12 +468,18 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
                 }
             }
             int c = 6 + 7 * nb;
+            if constexpr (kRowRegs) {
+                typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+                lds_f32x4* a4 = reinterpret_cast<lds_f32x4*>(reinterpret_cast<uintptr_t>(a));   // rows are 16-byte aligned: stage_stride is a multiple of 4
+#pragma unroll
+                for (int q = 0; q < 8; q++) { f32x4 v4; v4.x = rowv[4 * q]; v4.y = rowv[4 * q + 1]; v4.z = rowv[4 * q + 2]; v4.w = rowv[4 * q + 3]; a4[q] = v4; }
+            }
             if (pp.pred_clip) {   // the clip head's outputs sit in registers: compile-time indices
 #pragma unroll
-                for (int k = 0; k < PNR_MAX_CLIP; k++) if (k < pp.clip_dim) put(c + k, k < 16 ? clip[k & 15] : clip2[k & 15]);
+                for (int k = 0; k < PNR_MAX_CLIP; k++) if (k < pp.clip_dim) put_tail(c + k, k < 16 ? clip[k & 15] : clip2[k & 15]);
                 c += pp.clip_dim;
             }
-            for (; c < pp.aux_stride; c++) put(c, 0.0f);   // (without a clip head the clip_dim columns are zeros too, as the reference's torch.zeros clip_feat)
+            for (; c < pp.aux_stride; c++) put_tail(c, 0.0f);   // (without a clip head the clip_dim columns are zeros too, as the reference's torch.zeros clip_feat)
             const float sigma = pp.density_scale * __expf(sigma_logit);
             if (!rs.rays_t) sigmas[n] = sigma;   // (with the ray state composited here nobody reads sigmas / rgbs)
             if (fuse_composite) ex[(lane & 31) * 3] = 1.0f - __expf(-sigma * deltas[(size_t)n * 2]);   // alpha, exactly as k_frame_composite forms it
