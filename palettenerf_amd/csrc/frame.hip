@@ -154,8 +154,19 @@ __device__ unsigned int g_march_max[64];   // per iteration: max probes of any r
 __device__ unsigned int g_march_hist[2][32];   // probes per ray and launch: [0] first launch of a frame, [1] later launches (last bin: 31 or more)
 __device__ unsigned int g_march_kinds[64][8];   // per iteration: probe kinds of (one of) the slowest rays  // probes, empty probes, (unused), ray-launches
 #endif
+// xor-shuffle whose lane index is formed on the spot: left to the compiler, the six `(lane ^ off) * 4` addresses of a wave reduction are
+// computed once, kept for every later reduction of the kernel -- and spilled to scratch when registers are scarce (k_frame_march at six waves
+// per SIMD: 7 of its 23 spill slots, reloaded on the prologue's critical path)
+__device__ __forceinline__ uint32_t shfl_xor_fresh(uint32_t v, int off) {
+    int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(lane));
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ off) << 2, (int)v);
+}
+__device__ __forceinline__ unsigned long long shfl_xor_fresh(unsigned long long v, int off) {
+    return ((unsigned long long)shfl_xor_fresh((uint32_t)(v >> 32), off) << 32) | shfl_xor_fresh((uint32_t)v, off);
+}
 __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long* sh /* [kRayBlock / 64] */) {
-    for (int off = PNR_WAVE / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, PNR_WAVE);
+    for (int off = PNR_WAVE / 2; off > 0; off >>= 1) v += shfl_xor_fresh(v, off);
     __syncthreads();
     if ((threadIdx.x & (PNR_WAVE - 1)) == 0) sh[threadIdx.x / PNR_WAVE] = v;
     __syncthreads();
@@ -364,19 +375,21 @@ __global__ void __launch_bounds__(kRayBlock) __attribute__((amdgpu_waves_per_eu(
     extern __shared__ uint32_t mip_smem[];
     const uint32_t mip_n = MIP ? 2 * p.mip_words + 8 : 0;   // 'any' mask, 'all' mask, occupied box (stage_mip's layout)
     const bool mip_fast = MIP && mip_n <= (uint32_t)kMipLoads * kRayBlock * 4 && (mip_n & 3u) == 0;
-    uint4 mv[kMipLoads];
+    // (global_load_lds: 16 bytes per lane straight into LDS, destination = wave-uniform base + lane x 16 -- exactly this layout; no staging
+    // registers (20 per lane before) and no ds_write pass.  A wave must not end while such a load is in flight: the early exits below wait.)
     if (mip_fast) {
 #pragma unroll
         for (int u = 0; u < kMipLoads; u++) {
             const uint32_t i = (threadIdx.x + (uint32_t)u * kRayBlock) * 4;
-            mv[u] = i < mip_n ? *reinterpret_cast<const uint4*>(&mip[i]) : make_uint4(0u, 0u, 0u, 0u);
+            if (i < mip_n) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(&mip[i]),
+                                                            (__attribute__((address_space(3))) void*)(&mip_smem[i]), 16, 0, 0);
         }
     }
-    if (prev->done) { if (blockIdx.x == 0 && threadIdx.x == 0) *cur = *prev; return; }
+    if (prev->done) { if (blockIdx.x == 0 && threadIdx.x == 0) *cur = *prev; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
     const uint32_t n_prev = (uint32_t)prev->n_alive, nchunks = (n_prev + kRayBlock - 1) / kRayBlock;
     // The host sizes the launch for its upper bound of n_alive (N until it has looked at the control block): the workgroups beyond the last chunk
     // leave at once -- a third of a typical launch, which otherwise held wave slots through the whole prologue.
-    if (blockIdx.x >= nchunks && blockIdx.x != 0) { if (threadIdx.x == 0) emitted_partials[blockIdx.x] = 0; return; }
+    if (blockIdx.x >= nchunks && blockIdx.x != 0) { if (threadIdx.x == 0) emitted_partials[blockIdx.x] = 0; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
     if (slot0 >= n_prev) index0 = -1;
     unsigned long long part = 0;   // high word: all chunks, low word: the chunks in front of this workgroup's first one
 #pragma unroll
@@ -413,16 +426,12 @@ __global__ void __launch_bounds__(kRayBlock) __attribute__((amdgpu_waves_per_eu(
             qctr_all[((c.iterations + 1) & 1) * kQueueCtrs] = 0;   // the NEXT iteration's straggler count (this iteration's set is in use; the other one was last read by the previous lookup launch)
         }
     }
-    if (done || blockIdx.x >= nchunks) { if (threadIdx.x == 0) emitted_partials[blockIdx.x] = 0; return; }
+    if (done || blockIdx.x >= nchunks) { if (threadIdx.x == 0) emitted_partials[blockIdx.x] = 0; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
     const int lane = threadIdx.x & (PNR_WAVE - 1), wave = threadIdx.x / PNR_WAVE;
     PNR_STAMP(1);
     const uint32_t* mip_lds = nullptr;
     if (mip_fast) {
-#pragma unroll
-        for (int u = 0; u < kMipLoads; u++) {
-            const uint32_t i = (threadIdx.x + (uint32_t)u * kRayBlock) * 4;
-            if (i < mip_n) *reinterpret_cast<uint4*>(&mip_smem[i]) = mv[u];
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the mip has landed in LDS
         __syncthreads();
         mip_lds = mip_smem;
     } else {
@@ -569,7 +578,7 @@ __global__ void __launch_bounds__(kRayBlock) __attribute__((amdgpu_waves_per_eu(
     }
     // one partial per workgroup, summed by workgroup 0 of the next iteration's march: thousands of same-address atomics would serialise in L2
     __shared__ uint32_t wsum[kRayBlock / PNR_WAVE];
-    for (int off = PNR_WAVE / 2; off > 0; off >>= 1) emitted += __shfl_xor(emitted, off, PNR_WAVE);
+    for (int off = PNR_WAVE / 2; off > 0; off >>= 1) emitted += shfl_xor_fresh(emitted, off);
     if ((threadIdx.x & (PNR_WAVE - 1)) == 0) wsum[threadIdx.x / PNR_WAVE] = emitted;
     __syncthreads();
     if (threadIdx.x == 0) {
