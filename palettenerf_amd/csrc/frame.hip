@@ -977,8 +977,8 @@ __global__ void __launch_bounds__(kFieldThreads) k_frame_field(const FrameCtl* _
     if (blockIdx.x >= ntiles) return;
     __shared__ float w[kPackedFloats];
     __shared__ int wsum[kFieldThreads / PNR_WAVE];
-    for (int i = threadIdx.x * 4; i < kPackedFloats; i += kFieldThreads * 4)
-        *reinterpret_cast<float4*>(&w[i]) = *reinterpret_cast<const float4*>(&packed[i]);
+    for (int i = threadIdx.x * 4; i < kPackedFloats; i += kFieldThreads * 4) lds_copy16(&packed[i], &w[i]);
+    lds_copy_wait();
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     const uint32_t l = (uint32_t)lane & 31u;

@@ -213,8 +213,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
     const uint32_t ntiles = (B + WAVES * rpw - 1) / (WAVES * rpw);
     if (blockIdx.x >= ntiles) return;
     extern __shared__ unsigned char w[];
-    for (uint32_t i = threadIdx.x * 16; i < packed_bytes; i += WAVES * 64 * 16)   // weights + the PaletteTables behind them
-        *reinterpret_cast<uint4*>(&w[i]) = *reinterpret_cast<const uint4*>(&packed[i]);
+    for (uint32_t i = threadIdx.x * 16; i < packed_bytes; i += WAVES * 64 * 16) lds_copy16(&packed[i], &w[i]);   // weights + the PaletteTables behind them
+    lds_copy_wait();
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     const int nb = NB ? NB : pp.nb;

@@ -89,6 +89,14 @@ __device__ __forceinline__ void load8_fresh(const T* (&p)[8], T (&v)[8]) {
     asm volatile("" :: "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]));
 }
 
+// 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4: no staging registers, no ds_write pass).  The LDS
+// destination of a wave is its first lane's address + lane x 16, so `lds` must be lane-linear -- a plain copy loop over float4 indices is.
+// Completion: s_waitcnt vmcnt(0) (lds_copy_wait) and then the workgroup barrier; a wave must not end before its copies have landed.
+__device__ __forceinline__ void lds_copy16(const void* gsrc, void* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+__device__ __forceinline__ void lds_copy_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // wave64 inclusive prefix sum of an int (DPP-free, shuffle based)
 __device__ __forceinline__ int wave_inclusive_scan(int v) {
     const int lane = threadIdx.x & (PNR_WAVE - 1);
