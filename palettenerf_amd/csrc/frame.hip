@@ -786,7 +786,10 @@ __device__ __forceinline__ void hosted_march_tail(const FrameCtl* ctl, const Gri
     while (glog < 6u && (count >> glog) > kHostedBlocks * (kRayBlock / PNR_WAVE)) glog++;
     const uint32_t G = 1u << glog;
     const uint32_t ntasks = (count + G - 1) >> glog;
-    if (blockIdx.x >= ntasks) { if (threadIdx.x == 0) h.partials[blockIdx.x] = 0; return; }   // block-uniform (also: count == 0)
+    // tasks are dealt four to a workgroup (one per wave): a workgroup with a task has no idle wave sitting on a wave slot through the whole march,
+    // and the workgroups beyond the queue leave at once (one wave per workgroup, the first form: 576 idle resident waves on a typical later launch)
+    constexpr uint32_t kWavesPerBlock = kRayBlock / PNR_WAVE;
+    if (blockIdx.x * kWavesPerBlock >= ntasks) { if (threadIdx.x == 0) h.partials[blockIdx.x] = 0; return; }   // block-uniform (also: count == 0)
 #ifdef PNR_HOSTED_TIMING
     const bool timing = ctl->iterations == g_hosted_timing_iter;
     unsigned long long* tm = g_hosted_timing + 8 + 8 * blockIdx.x;
@@ -805,7 +808,7 @@ __device__ __forceinline__ void hosted_march_tail(const FrameCtl* ctl, const Gri
     const uint32_t n_step = (uint32_t)ctl->n_step;
     const uint32_t n_tab = KIND == GK_SINGLE ? gridDim.z : 1u;
     uint32_t emitted = 0;
-    for (uint32_t task = (uint32_t)wave * h.blocks + blockIdx.x; task < ntasks; task += h.blocks * (kRayBlock / PNR_WAVE)) {
+    for (uint32_t task = blockIdx.x * kWavesPerBlock + (uint32_t)wave; task < ntasks; task += h.blocks * kWavesPerBlock) {
         const uint32_t qi = (task << glog) + (uint32_t)lane;
         const bool have = (uint32_t)lane < G && qi < count;
         StragglerRec r = {};
