@@ -9,8 +9,10 @@
 //   * no staging buffers are zero-filled: the march writes the delta == 0 sentinel itself, padding
 //     rows do not exist, dead slots are skipped by the grid and field kernels;
 //   * world -> [0,1] normalisation, density_scale and the sample counter are folded into kernels.
-// Per iteration: march (+ compaction of the previous alive list + this iteration's schedule), grid (level-major, L2-resident
-// tables), field (MFMA; + the composite when a ray has one sample), composite(+count) = 4 launches, no host round trip.
+// Per iteration: march (+ compaction of the previous alive list + this iteration's schedule; the rays it does not finish within its probe
+// budget go to a queue), grid (level-major, L2-resident tables; its first workgroups finish the queued rays: hosted march tail), field
+// (MFMA + the iteration's whole compositing step + the survivor counts of the compaction) = 3 launches, no host round trip.
+// (k_frame_composite remains for pnr_set_option("composite_fusion", 0 / 1) and for PaletteNeRF shapes whose aux rows do not fit the LDS.)
 #include "pnr_common.hpp"
 #include "march_core.hpp"
 #include "grid_core.hpp"
