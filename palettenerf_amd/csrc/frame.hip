@@ -53,7 +53,10 @@ struct StragglerRec { int32_t n, index, step; float t, last_t, far; int32_t pad0
 static_assert(sizeof(StragglerRec) == 32, "StragglerRec layout");
 constexpr int kQueueCtrs = 4;             // counters per set (two sets ping-ponged by iteration parity): [0] rays queued
 constexpr uint32_t kHostedBlocks = 256;   // workgroups of a lookup launch that serve the queue first (one wave per SIMD of the chip)
-constexpr uint32_t kMaxMarchBlocks = 2048;
+#ifndef PNR_MAX_MARCH_BLOCKS
+#define PNR_MAX_MARCH_BLOCKS 4096   // (2048: a frame of 2 500 chunks gave 452 workgroups a second chunk behind their block barriers; first launch 88.1 -> 86.4 us on average)
+#endif
+constexpr uint32_t kMaxMarchBlocks = PNR_MAX_MARCH_BLOCKS;
 // What the hosted march tail needs on top of the lookup's own arguments.  The frame-constant part lives in the workspace (k_frame_init
 // writes it there from its own arguments): the lookup kernels' argument block stays the size it had.
 struct HostedConst {
@@ -1393,7 +1396,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             // MODE 2 runs five workgroups per CU; a typical later launch of 1 352 chunks therefore starts its last 72 workgroups ~8 us late (launch 16.9 us).
             // Capping the launch at the 1 280 resident workgroups ("march_blocks") is no way out: a workgroup's second chunk waits at the block barriers for
             // the slowest wave of its first one -- 18.4 us (profiles/march_timing.py).  The cap stays an option, default off.
-            const uint32_t march_cap = mode == 2 ? (uint32_t)g_opt_march_blocks : kMaxMarchBlocks;
+            const uint32_t march_cap = mode == 2 ? ((uint32_t)g_opt_march_blocks < kMaxMarchBlocks ? (uint32_t)g_opt_march_blocks : kMaxMarchBlocks) : kMaxMarchBlocks;
             const dim3 gm(ray_blocks < march_cap ? ray_blocks : march_cap), bm(kRayBlock);
 #define PNR_LAUNCH_MARCH(MIPV, P2V, MODEV)                                                                                                                \
             hipLaunchKernelGGL((k_frame_march<MIPV, P2V, MODEV>), gm, bm, march_lds, s, prev, cur, alive_prev, alive_in, counts_of(iter + 1), counts_of(iter), w.scratch, N, a->max_steps,    \
