@@ -986,8 +986,7 @@ __global__ void __launch_bounds__(kFieldThreads) k_frame_field(const FrameCtl* _
     __shared__ float w[kPackedFloats];
     __shared__ int wsum[kFieldThreads / PNR_WAVE];
     for (int i = threadIdx.x * 4; i < kPackedFloats; i += kFieldThreads * 4) lds_copy16(&packed[i], &w[i]);
-    lds_copy_wait();
-    __syncthreads();
+    bool weights_ready = false;   // the wait for the weights sits behind the first tile's own loads (every wave passes it exactly once: here or after the loop)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
     const uint32_t l = (uint32_t)lane & 31u;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -996,10 +995,11 @@ __global__ void __launch_bounds__(kFieldThreads) k_frame_field(const FrameCtl* _
         const float dl0 = mine ? deltas[(size_t)n * 2] : 0.0f;
         const bool valid = mine && dl0 != 0.0f;
         FieldOut o = {0.0f, 0.0f, 0.0f, 0.0f};
+        const uint32_t nc = n < B ? n : (B - 1);
+        float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+        if (valid) { dx = dirs[(size_t)nc * 3]; dy = dirs[(size_t)nc * 3 + 1]; dz = dirs[(size_t)nc * 3 + 2]; }
+        if (!weights_ready) { lds_copy_wait(); __syncthreads(); weights_ready = true; }   // (tile loop trip counts are block-uniform: all waves of a block are here together)
         if (__any(valid)) {   // wave-uniform: otherwise all 32 slots of this wave are dead or out of range
-            const uint32_t nc = n < B ? n : (B - 1);
-            float dx = 0.0f, dy = 0.0f, dz = 0.0f;
-            if (valid) { dx = dirs[(size_t)nc * 3]; dy = dirs[(size_t)nc * 3 + 1]; dz = dirs[(size_t)nc * 3 + 2]; }
             SplitWatch<CHECK> sw;
             o = nerf_field_tile<PREC, CHECK>(w, lane, valid, enc, level_stride, nc, dx, dy, dz, enc_scale, sw);
             if constexpr (CHECK) { if (sw.overflowed()) scratch[1] = 1; }
