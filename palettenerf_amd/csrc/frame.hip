@@ -17,6 +17,7 @@
 #include "march_core.hpp"
 #include "grid_core.hpp"
 #include "field_core.hpp"
+#include <hip/hip_ext.h>
 #include <vector>
 #include <stdlib.h>
 
@@ -1417,25 +1418,28 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             ga.xyzs = w.xyzs; ga.deltas = w.deltas; ga.offsets = a->offsets; ga.lp = lp; ga.level_stride = N; ga.bound = a->bound; ga.two_bound = 2.0f * a->bound;
             ga.gridtype = a->gridtype;
             ga.enc[0] = w.enc; ga.enc[1] = w.enc_pal; ga.enc[2] = w.enc_clip;
+            // live timing of the roofline kernel: the launch carries its own start / stop events (hipExtLaunchKernelGGL: the dispatch's begin and end
+            // time stamps, what rocprofv3 reports) -- events recorded around the launch are packets of their own and measured 79.7 us where the
+            // kernel took 71.0
             hipEvent_t e0 = timing ? next_event() : nullptr, e1 = timing ? next_event() : nullptr;
-            if (e0) (void)hipEventRecord(e0, s);
+#define PNR_LAUNCH_GRID(KERNEL, GRID) hipExtLaunchKernelGGL(KERNEL, GRID, dim3(256), grid_lds, s, e0, e1, 0, cur, ga, ha)
             if (half_tables && pal) {
                 ga.table[0] = pal->embeddings_pair;
-                hipLaunchKernelGGL(k_frame_grid_h2, dim3(gxc + ha.blocks, 16), dim3(256), grid_lds, s, cur, ga, ha);
+                PNR_LAUNCH_GRID(k_frame_grid_h2, dim3(gxc + ha.blocks, 16));
             } else if (half_tables) {
                 ga.table[0] = a->embeddings;
-                hipLaunchKernelGGL(k_frame_grid_h1, dim3(gxc + ha.blocks, 16), dim3(256), grid_lds, s, cur, ga, ha);
+                PNR_LAUNCH_GRID(k_frame_grid_h1, dim3(gxc + ha.blocks, 16));
             } else if (triple_table) {
                 ga.table[0] = triple_table;
-                hipLaunchKernelGGL(k_frame_grid_triple, dim3(gxc + ha.blocks, 16), dim3(256), grid_lds, s, cur, ga, ha);
+                PNR_LAUNCH_GRID(k_frame_grid_triple, dim3(gxc + ha.blocks, 16));
             } else if (pair_table) {
                 ga.table[0] = pair_table;
-                hipLaunchKernelGGL(k_frame_grid_pair, dim3(gxc + ha.blocks, 16), dim3(256), grid_lds, s, cur, ga, ha);
+                PNR_LAUNCH_GRID(k_frame_grid_pair, dim3(gxc + ha.blocks, 16));
             } else {
                 for (int k = 0; k < 3; k++) ga.table[k] = tables[k];
-                hipLaunchKernelGGL(k_frame_grid, dim3(gxc + ha.blocks, 16, n_enc), dim3(256), grid_lds, s, cur, ga, ha);
+                PNR_LAUNCH_GRID(k_frame_grid, dim3(gxc + ha.blocks, 16, n_enc));
             }
-            if (e1) (void)hipEventRecord(e1, s);
+#undef PNR_LAUNCH_GRID
             if (pal) {
                 pf.ctl = cur; pf.B = rows_ub;
                 if (aux_fused) { pf.rays_alive = alive_in; pf.weights_sum = out_ws; pf.aux_map = out_aux; pf.T_thresh = a->T_thresh; }
