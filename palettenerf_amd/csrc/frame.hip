@@ -74,6 +74,7 @@ struct HostedArgs {
     const uint8_t* rowflag;       // [rows] 1 = the row belongs to a queued ray (the ordinary workgroups skip it); nullptr = no flags this iteration
     uint32_t blocks;              // workgroups at the front of the launch that serve the straggler queue (0: none)
     uint32_t partial_base;        // first slot of the hosted workgroups in partials[parity] (= workgroups of this iteration's march launch)
+    uint32_t gx, n_tab;           // with hosted workgroups the launch is one-dimensional: blocks + gx x 16 levels x n_tab tables (no empty workgroups next to the hosted ones)
 };
 
 
@@ -812,7 +813,7 @@ __device__ __forceinline__ void hosted_march_tail(const FrameCtl* ctl, const Gri
     }
     __syncthreads();
     const uint32_t n_step = (uint32_t)ctl->n_step;
-    const uint32_t n_tab = KIND == GK_SINGLE ? gridDim.z : 1u;
+    const uint32_t n_tab = KIND == GK_SINGLE ? ha.n_tab : 1u;
     uint32_t emitted = 0;
     for (uint32_t task = blockIdx.x * kWavesPerBlock + (uint32_t)wave; task < ntasks; task += h.blocks * kWavesPerBlock) {
         const uint32_t qi = (task << glog) + (uint32_t)lane;
@@ -891,29 +892,30 @@ __device__ __forceinline__ void hosted_march_tail(const FrameCtl* ctl, const Gri
 template <int KIND>
 __device__ __forceinline__ void frame_grid_body(const FrameCtl* __restrict__ ctl, const GridArgs& g, const HostedArgs& h) {
     if (ctl->done) return;
-    uint32_t bx = blockIdx.x;
-    if (h.blocks) {   // launch-uniform
+    uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z, nbx = gridDim.x;
+    if (h.blocks) {   // launch-uniform: a one-dimensional launch, the hosted workgroups first
         if (bx < h.blocks) {
 #ifndef PNR_NO_HOSTED_CODE
-            if (blockIdx.y == 0 && blockIdx.z == 0) hosted_march_tail<KIND>(ctl, g, h);
+            hosted_march_tail<KIND>(ctl, g, h);
 #endif
             return;
         }
-        bx -= h.blocks;
+        const uint32_t id = bx - h.blocks, yz = id / h.gx;
+        bx = id - yz * h.gx; by = yz & 15u; bz = yz >> 4; nbx = h.gx;
     }
-    const uint32_t stride = (gridDim.x - h.blocks) * 256u;
+    const uint32_t stride = nbx * 256u;
     const uint32_t rows = (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step;
     // the finest levels -- scattered rows, 5x the time of a dense level -- are dispatched first and the dense ones fill the launch's tail
     // (ascending order: lego 3.80 ms / lookup at 0.66 of the roofline, descending: 3.79 / 0.675; garden 13.45 -> 13.2 ms)
-    const uint32_t level = gridDim.y - 1u - blockIdx.y;
+    const uint32_t level = 15u - by;
 #ifdef PNR_HOSTED_TIMING
-    const bool timing = ctl->iterations == g_hosted_timing_iter && (bx & 15u) == 0 && bx < 2048u && blockIdx.z == 0;
+    const bool timing = ctl->iterations == g_hosted_timing_iter && (bx & 15u) == 0 && bx < 2048u && bz == 0;
     unsigned long long* tmm = g_hosted_timing + 8 + 8 * 256 + 2 * (level * 128 + (bx >> 4));
     if (timing && threadIdx.x == 0) tmm[0] = wall_clock64();
 #endif
     const LevelCtx lc = level_ctx(g, level);
-    const void* table = g.table[KIND == GK_SINGLE ? blockIdx.z : 0];
-    float* enc0 = g.enc[KIND == GK_SINGLE ? blockIdx.z : 0];
+    const void* table = g.table[KIND == GK_SINGLE ? bz : 0];
+    float* enc0 = g.enc[KIND == GK_SINGLE ? bz : 0];
     for (uint32_t b = bx * 256u + threadIdx.x; b < rows; b += stride) {
         const float d0 = g.deltas[(size_t)b * 2];
         const uint32_t fl = h.rowflag ? h.rowflag[b] : 0u;
@@ -1412,7 +1414,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             const uint32_t gx = cdiv(rows_ub, 256);
             const uint32_t gxc = gx < 1024u ? gx : 1024u;
             HostedArgs ha = {};
-            if (mode == 2) { ha.hc = w.hosted; ha.rowflag = w.rowflag; ha.blocks = kHostedBlocks; ha.partial_base = gm.x; }
+            if (mode == 2) { ha.hc = w.hosted; ha.rowflag = w.rowflag; ha.blocks = kHostedBlocks; ha.partial_base = gm.x; ha.gx = gxc; ha.n_tab = n_enc; }
             const uint32_t grid_lds = mode == 2 ? march_lds : 0u;
             GridArgs ga = {};
             ga.xyzs = w.xyzs; ga.deltas = w.deltas; ga.offsets = a->offsets; ga.lp = lp; ga.level_stride = N; ga.bound = a->bound; ga.two_bound = 2.0f * a->bound;
@@ -1422,22 +1424,22 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             // time stamps, what rocprofv3 reports) -- events recorded around the launch are packets of their own and measured 79.7 us where the
             // kernel took 71.0
             hipEvent_t e0 = timing ? next_event() : nullptr, e1 = timing ? next_event() : nullptr;
-#define PNR_LAUNCH_GRID(KERNEL, GRID) hipExtLaunchKernelGGL(KERNEL, GRID, dim3(256), grid_lds, s, e0, e1, 0, cur, ga, ha)
+#define PNR_LAUNCH_GRID(KERNEL, GRID) hipExtLaunchKernelGGL(KERNEL, (ha.blocks ? dim3(ha.blocks + (GRID).x * (GRID).y * (GRID).z) : (GRID)), dim3(256), grid_lds, s, e0, e1, 0, cur, ga, ha)
             if (half_tables && pal) {
                 ga.table[0] = pal->embeddings_pair;
-                PNR_LAUNCH_GRID(k_frame_grid_h2, dim3(gxc + ha.blocks, 16));
+                PNR_LAUNCH_GRID(k_frame_grid_h2, dim3(gxc, 16));
             } else if (half_tables) {
                 ga.table[0] = a->embeddings;
-                PNR_LAUNCH_GRID(k_frame_grid_h1, dim3(gxc + ha.blocks, 16));
+                PNR_LAUNCH_GRID(k_frame_grid_h1, dim3(gxc, 16));
             } else if (triple_table) {
                 ga.table[0] = triple_table;
-                PNR_LAUNCH_GRID(k_frame_grid_triple, dim3(gxc + ha.blocks, 16));
+                PNR_LAUNCH_GRID(k_frame_grid_triple, dim3(gxc, 16));
             } else if (pair_table) {
                 ga.table[0] = pair_table;
-                PNR_LAUNCH_GRID(k_frame_grid_pair, dim3(gxc + ha.blocks, 16));
+                PNR_LAUNCH_GRID(k_frame_grid_pair, dim3(gxc, 16));
             } else {
                 for (int k = 0; k < 3; k++) ga.table[k] = tables[k];
-                PNR_LAUNCH_GRID(k_frame_grid, dim3(gxc + ha.blocks, 16, n_enc));
+                PNR_LAUNCH_GRID(k_frame_grid, dim3(gxc, 16, n_enc));
             }
 #undef PNR_LAUNCH_GRID
             if (pal) {
