@@ -138,3 +138,12 @@ def test_training_entry_points_validate_without_gpu():
     assert lib.pnr_nerf_density_forward(None, None, u32(8), f32(1.0), None, None, i32(1), f32(1.0), None) == -1
     assert lib.pnr_linear_bgrad(None, i32(0), u32(0), u32(13), None, i32(1), None, u64(0), None) == -1                                      # no output
     assert lib.pnr_set_option(b"composite_fusion", 2) == 0
+    # the round-3 switches of the frame loops (speed only): names exist, values are clamped, unknown names are refused
+    for name, value in ((b"hosted_tail", 1), (b"march_budget", 2), (b"march_budget0", 0), (b"march_blocks", 65536), (b"coop_march", 1)):
+        assert lib.pnr_set_option(name, value) == 0
+    assert lib.pnr_set_option(b"no_such_switch", 1) != 0 and lib.pnr_set_option(None, 1) != 0
+    assert lib.pnr_abi_version() >= 4
+    # pnr_palette_field_args grew at its end (frame-loop-only ray-state pointers): the ctypes mirror has them and leaves them NULL
+    from palettenerf_amd import _lib as L
+    names = [f[0] for f in L.PaletteFieldArgs._fields_]
+    assert names[-6:] == ["rays_t", "weights_sum_rw", "depth", "image", "rays_alive_rw", "counts_cur"] and L.PaletteFieldArgs().rays_t is None
