@@ -1396,10 +1396,16 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             // hosted tail (MODE 2): the march gives every ray `budget` sample-less probes and queues the rest for the lookup launch's first workgroups
             const uint32_t budget = hosted ? (uint32_t)(iter == 0 ? g_opt_march_budget0 : g_opt_march_budget) : 0u;
             const int mode = budget ? 2 : 1;
-            // MODE 2 runs five workgroups per CU; a typical later launch of 1 352 chunks therefore starts its last 72 workgroups ~8 us late (launch 16.9 us).
-            // Capping the launch at the 1 280 resident workgroups ("march_blocks") is no way out: a workgroup's second chunk waits at the block barriers for
-            // the slowest wave of its first one -- 18.4 us (profiles/march_timing.py).  The cap stays an option, default off.
-            const uint32_t march_cap = mode == 2 ? ((uint32_t)g_opt_march_blocks < kMaxMarchBlocks ? (uint32_t)g_opt_march_blocks : kMaxMarchBlocks) : kMaxMarchBlocks;
+            // MODE 2 runs five workgroups per CU (1 280 resident).  A typical later lego launch has 1 352 chunks: its last 72 workgroups start ~8 us late
+            // (launch 16.9 us), and capping the launch at 1 280 is no way out -- a workgroup's second chunk waits at the block barriers for the slowest
+            // wave of its first one (18.4 us).  With three chunks and more per resident workgroup (garden: 4 256) the cap does pay: the chunks of a
+            // workgroup share its prologue (mip staging, chunk sums): 38.7 -> 33.1 us per launch.  "march_blocks" overrides (0 / 65536 = this rule).
+            const uint32_t kResident = 1280;
+            uint32_t march_cap = kMaxMarchBlocks;
+            if (mode == 2) {
+                if (g_opt_march_blocks > 0 && g_opt_march_blocks < 65536) march_cap = (uint32_t)g_opt_march_blocks < kMaxMarchBlocks ? (uint32_t)g_opt_march_blocks : kMaxMarchBlocks;
+                else if (ray_blocks >= 2 * kResident) march_cap = kResident;
+            }
             const dim3 gm(ray_blocks < march_cap ? ray_blocks : march_cap), bm(kRayBlock);
 #define PNR_LAUNCH_MARCH(MIPV, P2V, MODEV)                                                                                                                \
             hipLaunchKernelGGL((k_frame_march<MIPV, P2V, MODEV>), gm, bm, march_lds, s, prev, cur, alive_prev, alive_in, counts_of(iter + 1), counts_of(iter), w.scratch, N, a->max_steps,    \

@@ -488,7 +488,7 @@ int g_opt_coop_march = getenv("PNR_NO_COOP_MARCH") ? 0 : 1;
 int g_opt_hosted_tail = getenv("PNR_NO_HOSTED_TAIL") ? 0 : 1;   // frame loops: march stragglers finished inside the lookup launch (frame.hip: hosted_march_tail)
 int g_opt_march_budget = getenv("PNR_MARCH_BUDGET") ? atoi(getenv("PNR_MARCH_BUDGET")) : 2;     // probe rounds a later march launch spends on a ray before it hands it over
 int g_opt_march_budget0 = getenv("PNR_MARCH_BUDGET0") ? atoi(getenv("PNR_MARCH_BUDGET0")) : 0;  // the same for a frame's first launch; 0 = that launch keeps the in-wave cooperative tail
-int g_opt_march_blocks = getenv("PNR_MARCH_BLOCKS") ? atoi(getenv("PNR_MARCH_BLOCKS")) : 65536;    // workgroup cap of a budgeted march launch (1 280 = the five per CU that are resident: measured slower, below)
+int g_opt_march_blocks = getenv("PNR_MARCH_BLOCKS") ? atoi(getenv("PNR_MARCH_BLOCKS")) : 0;    // workgroup cap of a budgeted march launch; 0 (or 65536) = automatic: the 1 280 resident workgroups once a frame has twice as many chunks (frame.hip)
 int g_opt_aux_fusion = getenv("PNR_NO_AUX_FUSION") ? 0 : 1;
 int g_opt_composite_fusion = getenv("PNR_NO_COMPOSITE_FUSION") ? 0 : (getenv("PNR_COMPOSITE_FUSION") ? atoi(getenv("PNR_COMPOSITE_FUSION")) : 2);   // 2: the NeRF frame loop has no composite launch
 int g_opt_iteration_margin = getenv("PNR_ITERATION_MARGIN") ? atoi(getenv("PNR_ITERATION_MARGIN")) : 0;   // measured 0 / 1 / 2 / 4 on the moving-camera bench: 4.239 / 4.247 / 4.277 / 4.265 ms -- a look costs less than a spare iteration

@@ -139,7 +139,7 @@ def test_training_entry_points_validate_without_gpu():
     assert lib.pnr_linear_bgrad(None, i32(0), u32(0), u32(13), None, i32(1), None, u64(0), None) == -1                                      # no output
     assert lib.pnr_set_option(b"composite_fusion", 2) == 0
     # the round-3 switches of the frame loops (speed only): names exist, values are clamped, unknown names are refused
-    for name, value in ((b"hosted_tail", 1), (b"march_budget", 2), (b"march_budget0", 0), (b"march_blocks", 65536), (b"coop_march", 1)):
+    for name, value in ((b"hosted_tail", 1), (b"march_budget", 2), (b"march_budget0", 0), (b"march_blocks", 0), (b"coop_march", 1)):
         assert lib.pnr_set_option(name, value) == 0
     assert lib.pnr_set_option(b"no_such_switch", 1) != 0 and lib.pnr_set_option(None, 1) != 0
     assert lib.pnr_abi_version() >= 4
