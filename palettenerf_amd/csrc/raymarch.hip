@@ -509,7 +509,7 @@ int pnr_set_option(const char* name, int value) {
     if (!strcmp(name, "hosted_tail")) { g_opt_hosted_tail = value != 0; return PNR_OK; }
     if (!strcmp(name, "march_budget")) { g_opt_march_budget = value < 1 ? 1 : (value > 1024 ? 1024 : value); return PNR_OK; }
     if (!strcmp(name, "march_budget0")) { g_opt_march_budget0 = value < 0 ? 0 : (value > 1024 ? 1024 : value); return PNR_OK; }
-    if (!strcmp(name, "march_blocks")) { g_opt_march_blocks = value < 1 ? 1 : value; return PNR_OK; }
+    if (!strcmp(name, "march_blocks")) { g_opt_march_blocks = value < 0 ? 0 : value; return PNR_OK; }
     if (!strcmp(name, "aux_fusion")) { g_opt_aux_fusion = value != 0; return PNR_OK; }
     if (!strcmp(name, "composite_fusion")) { g_opt_composite_fusion = value < 0 ? 0 : (value > 2 ? 2 : value); return PNR_OK; }
     if (!strcmp(name, "palette_waves12")) { g_opt_palette_waves12 = value != 0; return PNR_OK; }
