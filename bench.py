@@ -326,10 +326,13 @@ def timed_frames(m, bank, kw, steps, fp16, first_step=0):
 
 
 # ------------------------------------------------------------------------------------------------ configs[3]: the training step
-def make_training_step(model_kind, rays, device, fp16=False, torch_adam=False):
+def make_training_step(model_kind, rays, device, fp16=False, torch_adam=False, torch_loss=False):
     """configs[3]-shaped training step (main_palette.py:223 / palette/utils.py:481 on LLFF-like input): `rays` random rays per step from a
     forward-facing 17-camera rig over the slab scene, dt_gamma 1/128, march_rays_train -> field -> composite_rays_train (+ the flex composite
-    of the palette model) -> losses -> backward (composite, MLPs, grid_encode backward) -> Adam.  Returns (model, step(i) -> None)."""
+    of the palette model) -> PaletteTrainer.train_step's loss with main_palette.py's default weights (palette/utils.py:483-600: colour MSE,
+    direct-colour MSE, sparsity / offsets / view-dependence regularisers, palette anchor; the NeRF model: colour MSE) -> backward (composite,
+    MLPs, grid_encode backward) -> Adam.  torch_loss: the same loss written with torch on the result dict (as the reference's trainer does)
+    instead of palettenerf_amd.train_loss.  Returns (model, step(i) -> None)."""
     import numpy as np
     import torch
     from palettenerf_amd import network, raymarching, renderer, scene
@@ -361,15 +364,30 @@ def make_training_step(model_kind, rays, device, fp16=False, torch_adam=False):
     target = torch.rand(rays, 3, device=device)
     inds_all = torch.randint(0, H * W, [64, rays], generator=g).to(device)     # the index draws of 64 steps, resident (the reference draws them on the device)
 
+    from palettenerf_amd.train_loss import train_loss
+    lam = dict(lambda_sparsity=2e-4, lambda_offsets=0.03, lambda_view_dep=0.1, lambda_palette=1e-3)     # main_palette.py:83-89 (no smooth loss, no weight guide)
+    target = target[None]
+    origin = (m.basis_color.detach() + 0.02).clone() if model_kind == "palette" else None    # basis_color_origin: the extracted palette the anchor term pulls towards
+
     def step(i):
         inds = inds_all[i % 64]
         ro, rd = ro_all[i % 17, inds][None], rd_all[i % 17, inds][None]
         opt.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.float16, enabled=fp16):
             r = m.run_cuda(ro, rd, dt_gamma=1 / 128, perturb=True, force_all_rays=True, max_steps=1024, T_thresh=1e-4)
-            loss = ((r["image"][0] - target) ** 2).mean()
-            if model_kind == "palette":
-                loss = loss + 1e-3 * r["omega_sparsity"].mean() + 1e-2 * r["offsets_norm"].mean() + ((r["direct_rgb"][0] - target) ** 2).mean()
+            if not torch_loss:
+                if model_kind == "palette":
+                    loss, _ = train_loss(r, target, basis_color=m.basis_color, basis_color_origin=origin, **lam)
+                else:
+                    loss, _ = train_loss(r, target)
+            else:
+                loss = ((r["image"] - target) ** 2).mean(-1)
+                if model_kind == "palette":
+                    loss = loss + lam["lambda_sparsity"] * r["omega_sparsity"].mean() + lam["lambda_offsets"] * r["offsets_norm"].mean()
+                    loss = loss + lam["lambda_view_dep"] * r["view_dep_norm"].mean()
+                    loss = loss + lam["lambda_palette"] * ((m.basis_color - origin) ** 2).sum(dim=-1).mean()
+                    loss = loss + ((r["direct_rgb"] - target) ** 2).mean()
+                loss = loss.mean()
         scaler.scale(loss).backward()
         scaler.step(opt)
         scaler.update()

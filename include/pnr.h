@@ -430,6 +430,11 @@ int pnr_palette_field_forward(const pnr_palette_field_args* args, pnr_stream_t s
  * fp32 only (the reference's Python forces fp32, sphere_harmonics.py:16). dy_dx may be NULL. */
 int pnr_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C, float* dy_dx,
                           pnr_stream_t stream);
+/* color_net's input rows [SH(dirs) | tail] = torch.cat([encoder_dir(d), geo_feat], dim=-1) (nerf/network.py:109-115, palette/network.py:248-249) in one
+ * launch: inputs [B,3] unit directions, tail [B,tail_cols] -> outputs [B, C*C + tail_cols]; the SH columns are pnr_sh_encode_forward's bits.
+ * C*C + tail_cols <= 64.  (No Jacobian: directions get no gradient on this path; the tail's gradient is the column slice of the output's.) */
+int pnr_sh_encode_cat_forward(const float* inputs, const float* tail, uint32_t tail_cols, float* outputs, uint32_t B, uint32_t C,
+                              pnr_stream_t stream);
 int pnr_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t C,
                            const float* dy_dx, float* grad_inputs, pnr_stream_t stream);
 
@@ -564,6 +569,63 @@ int pnr_palette_heads_forward(const float* h, const float* w_offsets_radiance, c
 int pnr_palette_heads_backward(const float* h, const float* w_offsets_radiance, const float* w_omega, const float* grad_offsets_radiance,
                                const float* grad_omega, uint32_t M, uint32_t num_basis, uint32_t in_dim, float* grad_h, float* grad_pre,
                                pnr_stream_t stream);
+
+/* The ray-level tail of a training step as ONE launch each way: the renderer's epilogue (palette/renderer.py:387-403 -- background blend of
+ * image and direct_rgb, depth normalisation; nerf/renderer.py:331-336) and the trainer's loss on it (palette/utils.py:483-600 with the
+ * MSELoss(reduction='none') criterion of main_palette.py:181,222; nerf/utils.py:534-556 when all_map is NULL).  In torch these are ~45
+ * launches of 4096-element tensors per step, forward and backward.
+ *   image      = image_raw + (1 - weights_sum) bg              depth = clamp(depth_raw - nears, 0) / (fars - nears)
+ *   direct_rgb = all_map[:, 7:10] + (1 - weights_sum) bg
+ *   loss = mean_n mean_c (image - gt_rgb)^2                                                                  terms[1]
+ *        + lambda_sparsity mean all_map[:, 0] + lambda_offsets mean all_map[:, 2] + lambda_view_dep mean all_map[:, 1]   terms[2..4]
+ *        + lambda_smooth mean all_map[:, 3]                                                                  terms[5]
+ *        + lambda_palette mean_b sum_c (basis_color - basis_color_origin)^2     (both NULL: 0)               terms[6]
+ *        + lambda_weight mean (gt_weights - all_map[:, 13+clip_dim:])^2         (gt_weights NULL: 0)         terms[7]
+ *        + mean (direct_rgb - gt_rgb)^2                                                                      terms[8]
+ *        + mean (all_map[:, 13:13+clip_dim] - gt_clip)^2                        (gt_clip NULL: 0)            terms[9]
+ *   terms[0] = loss;  loss_ray [N] = mean_c (image - gt_rgb)^2 (what the reference's error map reads before the scalar terms are added)
+ * all_map columns are those of pnr_palette_train_shade_forward's all_buffer after the flex composite; n_channel = 13 + clip_dim + num_basis,
+ * or 0 with all_map NULL (the NeRF model: only the first term).  bg_mode 0: the constant bg_const; 1: bg_color [3]; 2: bg_color [N,3]
+ * (no gradient reaches the background).  The sums are reduced in a fixed order (workgroup partials in `workspace`, combined by the last
+ * workgroup to finish), so the value is reproducible.  The backward multiplies by the device scalar *grad_loss and writes EVERY element of
+ * grad_weights_sum [N], grad_image_raw [N,3], grad_all_map [N,n_channel] and (if not NULL) grad_basis_color [num_basis,3].
+ * image / depth / direct_rgb / loss_ray may be NULL (not wanted); depth needs depth_raw, nears and fars. */
+typedef struct pnr_train_loss_args {
+    uint32_t N, n_channel, num_basis, clip_dim;
+    const float* weights_sum;
+    const float* depth_raw;
+    const float* image_raw;
+    const float* all_map;
+    const float* nears;
+    const float* fars;
+    const float* bg_color;
+    float bg_const;
+    int32_t bg_mode;
+    const float* gt_rgb;
+    const float* gt_clip;
+    const float* gt_weights;
+    const float* basis_color;
+    const float* basis_color_origin;
+    float lambda_sparsity, lambda_offsets, lambda_view_dep, lambda_smooth, lambda_weight, lambda_palette;
+    /* forward outputs */
+    float* image;
+    float* depth;
+    float* direct_rgb;
+    float* loss_ray;
+    float* terms;            /* [PNR_TRAIN_LOSS_TERMS] */
+    /* backward */
+    const float* grad_loss;  /* device scalar */
+    float* grad_weights_sum;
+    float* grad_image_raw;
+    float* grad_all_map;
+    float* grad_basis_color;
+    void* workspace;         /* forward only; pnr_train_loss_workspace_bytes(N), zero-filled once by the caller before its first use */
+    uint64_t workspace_bytes;
+} pnr_train_loss_args;
+#define PNR_TRAIN_LOSS_TERMS 10
+uint64_t pnr_train_loss_workspace_bytes(uint32_t N);
+int pnr_train_loss_forward(const pnr_train_loss_args* args, pnr_stream_t stream);
+int pnr_train_loss_backward(const pnr_train_loss_args* args, pnr_stream_t stream);
 
 /* replace rgb_to_hsv / hsv_to_rgb, palette/src/palette_func.h, palette.cu:135-149 */
 int pnr_rgb_to_hsv(uint32_t n, const float* input, float* output, pnr_stream_t stream);

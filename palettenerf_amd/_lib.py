@@ -52,6 +52,7 @@ SIGNATURES = {
     "pnr_palette_frame_workspace_bytes": [_u32, _u32, _u32, _int],
     "pnr_palette_render_frame": [_ptr, _ptr],
     "pnr_sh_encode_forward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr],
+    "pnr_sh_encode_cat_forward": [_ptr, _ptr, _u32, _ptr, _u32, _u32, _ptr],
     "pnr_sh_encode_backward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr, _ptr],
     "pnr_rgb_to_hsv": [_u32, _ptr, _ptr, _ptr],
     "pnr_hsv_to_rgb": [_u32, _ptr, _ptr, _ptr],
@@ -68,6 +69,9 @@ SIGNATURES = {
     "pnr_mlp_forward_lm": [_ptr, _ptr, _ptr, _u32, _ptr, _u32, _ptr, _ptr],
     "pnr_mlp_backward_lm": [_ptr, _ptr, _ptr, _u32, _ptr, _ptr, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _ptr],
     "pnr_linear_bgrad": [_ptr, _int, _u32, _u32, _ptr, _int, _ptr, _u64, _ptr],
+    "pnr_train_loss_workspace_bytes": [_u32],
+    "pnr_train_loss_forward": [_ptr, _ptr],
+    "pnr_train_loss_backward": [_ptr, _ptr],
     "pnr_palette_field_stages_aux": [_u32, _u32, _int],
     "pnr_interleave_tables": [_ptr, _ptr, _u64, _ptr, _ptr],
     "pnr_interleave_tables3": [_ptr, _ptr, _ptr, _u64, _ptr, _ptr],
@@ -92,7 +96,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"pnr_occupancy_workspace_bytes": _u64, "pnr_occupancy_samples": _u32, "pnr_adam_max_tensors": _u32, "pnr_error_string": ctypes.c_char_p, "pnr_scan_scratch_bytes": _u64, "pnr_nerf_field_packed_bytes": _u64, "pnr_occupancy_mip_bytes": _u64, "pnr_nerf_frame_workspace_bytes": _u64, "pnr_palette_field_packed_bytes": _u64, "pnr_palette_frame_workspace_bytes": _u64,
              "pnr_palette_aux_channels": _u32, "pnr_linear_wgrad_workspace_bytes": _u64, "pnr_grid_backward_binned_workspace_bytes": _u64,
-             "pnr_palette_train_shade_workspace_bytes": _u64, "pnr_mlp_packed_bytes": _u64, "pnr_mlp_backward_workspace_bytes": _u64}
+             "pnr_palette_train_shade_workspace_bytes": _u64, "pnr_train_loss_workspace_bytes": _u64, "pnr_mlp_packed_bytes": _u64, "pnr_mlp_backward_workspace_bytes": _u64}
 
 class AdamTensor(ctypes.Structure):
     """Mirror of `pnr_adam_tensor` (include/pnr.h)."""
@@ -157,6 +161,21 @@ class PaletteFieldArgs(ctypes.Structure):
                 ("sigmas", _ptr), ("rgbs", _ptr), ("aux", _ptr), ("rays_alive", _ptr), ("weights_sum", _ptr), ("aux_map", _ptr), ("T_thresh", _f32),
                 ("precision", _int), ("edit", _ptr), ("xyzs", _ptr), ("edit_device", _ptr), ("enc_scale", _f32 * 3), ("overflow_flag", _ptr), ("tile_counter", _ptr),
                 ("rays_t", _ptr), ("weights_sum_rw", _ptr), ("depth", _ptr), ("image", _ptr), ("rays_alive_rw", _ptr), ("counts_cur", _ptr)]   # frame loop only: leave NULL
+
+
+class TrainLossArgs(ctypes.Structure):
+    """Mirror of `pnr_train_loss_args` (include/pnr.h)."""
+    _fields_ = ([(n, _u32) for n in ("N", "n_channel", "num_basis", "clip_dim")]
+                + [(n, _ptr) for n in ("weights_sum", "depth_raw", "image_raw", "all_map", "nears", "fars", "bg_color")]
+                + [("bg_const", _f32), ("bg_mode", ctypes.c_int32)]
+                + [(n, _ptr) for n in ("gt_rgb", "gt_clip", "gt_weights", "basis_color", "basis_color_origin")]
+                + [(n, _f32) for n in ("lambda_sparsity", "lambda_offsets", "lambda_view_dep", "lambda_smooth", "lambda_weight", "lambda_palette")]
+                + [(n, _ptr) for n in ("image", "depth", "direct_rgb", "loss_ray", "terms", "grad_loss", "grad_weights_sum", "grad_image_raw",
+                                       "grad_all_map", "grad_basis_color", "workspace")]
+                + [("workspace_bytes", _u64)])
+
+
+TRAIN_LOSS_TERMS = 10   # PNR_TRAIN_LOSS_TERMS
 
 
 _lib = None

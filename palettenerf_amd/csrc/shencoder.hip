@@ -79,6 +79,55 @@ __global__ void __launch_bounds__(256) k_sh_bwd(const float* __restrict__ grad, 
     grad_inputs[t] = acc;
 }
 
+// [SH(dir) | tail] rows in one pass: color_net's input torch.cat([encoder_dir(d), geo_feat]) (nerf/network.py:109-115, palette/network.py:248-249)
+// without the [B, C2] intermediate and the concatenation's round trip.  The SH values are k_sh_fwd<DEG, false>'s, operation for operation.
+// A workgroup's 256 rows are put together in LDS (row stride W = C2 + t) and leave as one contiguous block of 16-byte stores.
+template <int DEG>
+__global__ void __launch_bounds__(256) k_sh_cat_fwd(const float* __restrict__ inputs, const float* __restrict__ tail, uint32_t t,
+                                                    float* __restrict__ outputs, uint32_t B) {
+    extern __shared__ float tile[];
+    constexpr int C2 = DEG * DEG;
+    const uint32_t W = C2 + t, row0 = blockIdx.x * 256, b = row0 + threadIdx.x, nrows = B - row0 < 256u ? B - row0 : 256u;
+    if (b < B) {
+        const float x = inputs[(size_t)b * 3], y = inputs[(size_t)b * 3 + 1], z = inputs[(size_t)b * 3 + 2];
+        const float z2 = z * z;
+        float re[DEG], im[DEG];
+        re[0] = 1.0f; im[0] = 0.0f;
+#pragma unroll
+        for (int m = 1; m < DEG; m++) {
+            re[m] = x * re[m - 1] - y * im[m - 1];
+            im[m] = fmaf(x, im[m - 1], y * re[m - 1]);
+        }
+        float* o = tile + threadIdx.x * W;
+#pragma unroll
+        for (int l = 0; l < DEG; l++) {
+#pragma unroll
+            for (int m = 0; m <= l; m++) {
+                const float q = sh_poly(SH_Q[l][m], z, z2);
+                o[l * l + l + m] = re[m] * q;
+                if (m) o[l * l + l - m] = im[m] * q;
+            }
+        }
+    }
+    const float* tsrc = tail + (size_t)row0 * t;
+    for (uint32_t i = threadIdx.x; i < nrows * t; i += 256) {
+        const uint32_t r = i / t, c = i - r * t;
+        tile[r * W + C2 + c] = tsrc[i];
+    }
+    __syncthreads();
+    float* dst = outputs + (size_t)row0 * W;      // 256 W floats per workgroup: 16-byte aligned for every W
+    const uint32_t total = nrows * W, quads = total / 4;
+    for (uint32_t i = threadIdx.x; i < quads; i += 256)
+        reinterpret_cast<float4*>(dst)[i] = make_float4(tile[i * 4], tile[i * 4 + 1], tile[i * 4 + 2], tile[i * 4 + 3]);
+    for (uint32_t i = quads * 4 + threadIdx.x; i < total; i += 256) dst[i] = tile[i];
+}
+
+template <int DEG>
+static int launch_sh_cat(const float* inputs, const float* tail, uint32_t t, float* outputs, uint32_t B, hipStream_t s) {
+    hipLaunchKernelGGL((k_sh_cat_fwd<DEG>), dim3(cdiv(B, 256)), dim3(256), 256 * (DEG * DEG + t) * sizeof(float), s, inputs, tail, t, outputs, B);
+    return check_launch();
+}
+
 template <int DEG>
 static int launch_sh(const float* inputs, float* outputs, uint32_t B, uint32_t D, float* dy_dx, hipStream_t s) {
     const dim3 grid(cdiv(B, 256)), block(256);
@@ -108,6 +157,22 @@ int pnr_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint3
         case 6: return launch_sh<6>(inputs, outputs, B, D, dy_dx, s);
         case 7: return launch_sh<7>(inputs, outputs, B, D, dy_dx, s);
         default: return launch_sh<8>(inputs, outputs, B, D, dy_dx, s);
+    }
+}
+
+int pnr_sh_encode_cat_forward(const float* inputs, const float* tail, uint32_t tail_cols, float* outputs, uint32_t B, uint32_t C, pnr_stream_t stream) {
+    if (C < 1 || C > 8 || tail_cols == 0 || C * C + tail_cols > 64) return PNR_ERR_UNSUPPORTED;   // one LDS tile of 256 x 64 floats at most
+    if (B == 0) return PNR_OK;
+    if (!inputs || !tail || !outputs) return PNR_ERR_INVALID;
+    hipStream_t s = as_stream(stream);
+    switch (C) {
+        case 1: return launch_sh_cat<1>(inputs, tail, tail_cols, outputs, B, s);
+        case 2: return launch_sh_cat<2>(inputs, tail, tail_cols, outputs, B, s);
+        case 3: return launch_sh_cat<3>(inputs, tail, tail_cols, outputs, B, s);
+        case 4: return launch_sh_cat<4>(inputs, tail, tail_cols, outputs, B, s);
+        case 5: return launch_sh_cat<5>(inputs, tail, tail_cols, outputs, B, s);
+        case 6: return launch_sh_cat<6>(inputs, tail, tail_cols, outputs, B, s);
+        default: return launch_sh_cat<7>(inputs, tail, tail_cols, outputs, B, s);   // C == 8 has no room for a tail (64 + t > 64)
     }
 }
 

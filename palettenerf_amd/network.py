@@ -14,6 +14,7 @@ from .linear import Linear
 from .mlp import MIN_ROWS as _MLP_MIN_ROWS, encode_mlp, run_mlp
 from .palette_utils import palette_heads
 from .renderer import NeRFRenderer, PaletteRenderer
+from .shencoder import sh_encode_cat
 
 
 def _mlp(dims):
@@ -75,7 +76,7 @@ class NeRFNetwork(NeRFRenderer):
         h = encode_mlp(self.encoder, x, self.bound, None, self.sigma_net)
         sigma = trunc_exp(h[..., 0])
         geo_feat = h[..., 1:]
-        h = _run(self.color_net, torch.cat([self.encoder_dir(d), geo_feat], dim=-1))
+        h = _run(self.color_net, sh_encode_cat(self.encoder_dir, d, geo_feat))
         return sigma, torch.sigmoid(h)
 
     def density(self, x):
@@ -93,7 +94,7 @@ class NeRFNetwork(NeRFRenderer):
             if not mask.any():
                 return rgbs
             d, geo_feat = d[mask], geo_feat[mask]
-        h = torch.sigmoid(_run(self.color_net, torch.cat([self.encoder_dir(d), geo_feat], dim=-1)))
+        h = torch.sigmoid(_run(self.color_net, sh_encode_cat(self.encoder_dir, d, geo_feat)))
         if mask is None:
             return h
         rgbs[mask] = h.to(rgbs.dtype)
@@ -144,7 +145,7 @@ class PaletteNetwork(PaletteRenderer):
         if self.opt.pred_clip:
             clip_feat = encode_mlp(self.encoder_clip, x, self.bound, None, self.clip_net)
         else:
-            clip_feat = torch.zeros_like(sigma[..., None].repeat(1, self.opt.clip_dim))
+            clip_feat = sigma.new_zeros(*sigma.shape, self.opt.clip_dim)   # palette/network.py:179 (zeros_like of a repeat there)
         omega, offsets_radiance, view_dep, diffuse = self.color(x, d, geo_feat=geo_feat)
         return sigma, clip_feat, omega, offsets_radiance, view_dep, diffuse
 
@@ -161,7 +162,7 @@ class PaletteNetwork(PaletteRenderer):
             raise NotImplementedError("masked colour queries belong to the non-cuda_ray path, which is dead code in the reference")
         g = geo_feat.detach()
         diffuse = torch.sigmoid(_run(self.diff_net, g))
-        view_dep = torch.sigmoid(_run(self.color_net, torch.cat([self.encoder_dir(d), g], dim=-1)))
+        view_dep = torch.sigmoid(_run(self.color_net, sh_encode_cat(self.encoder_dir, d, g)))
         h = encode_mlp(self.encoder_palette, x, self.bound, diffuse.detach(), self.basis_net, act=F.elu)   # cat([encoder_palette(x), diffuse]) -> basis_net
         if _fused_heads_ok(self, h):
             offsets_radiance, omega = palette_heads(h, self.offsets_radiance_net, self.omega_net[0])

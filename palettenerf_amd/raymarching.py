@@ -240,15 +240,19 @@ class _composite_rays_train(Function):
              ptr(weights_sum), ptr(depth), ptr(image))
         ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, depth, image)
         ctx.dims = [M, N, T_thresh]
+        ctx.set_materialize_grads(False)   # depth's gradient is never read: no zero tensor is made for it
         return weights_sum, depth, image
 
     @staticmethod
     @_bwd
     def backward(ctx, grad_weights_sum, grad_depth, grad_image):
         # grad_depth is ignored, as in the reference (raymarching.py:275)
-        grad_weights_sum, grad_image = grad_weights_sum.contiguous(), grad_image.contiguous()
         sigmas, rgbs, deltas, rays, weights_sum, depth, image = ctx.saved_tensors
         M, N, T_thresh = ctx.dims
+        if grad_weights_sum is None and grad_image is None:
+            return None, None, None, None, None
+        grad_weights_sum = torch.zeros_like(weights_sum) if grad_weights_sum is None else grad_weights_sum.contiguous()
+        grad_image = torch.zeros_like(image) if grad_image is None else grad_image.contiguous()
         grad_sigmas, grad_rgbs = torch.zeros_like(sigmas), torch.zeros_like(rgbs)
         call("pnr_composite_rays_train_backward", ptr(require(grad_weights_sum, torch.float32, "grad_weights_sum")),
              ptr(require(grad_image, torch.float32, "grad_image")), ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays), ptr(weights_sum),

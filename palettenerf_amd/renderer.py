@@ -23,6 +23,7 @@ import torch.nn.functional as F
 from . import _lib, raymarching
 from ._torch_glue import call, ptr, require
 from .palette_utils import hsv_to_rgb, palette_train_shade, rgb_to_hsv
+from .train_loss import RawTrain, TrainResults
 
 
 def default_opt(**kw):
@@ -450,16 +451,18 @@ class NeRFRenderer(_OccupancyMaintenance, _RendererBase):
                 gt_rgbs = torch.zeros_like(xyzs)
                 raymarching.spread_ray_to_sample(rays_gt, rays, gt_rgbs)
                 rgb_norm = ((gt_rgbs - rgbs) ** 2).sum(-1, keepdim=True).repeat(1, 3)
-            else:
-                rgb_norm = torch.zeros_like(rgbs)
             weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
-            _, _, rgb_norm_map = raymarching.composite_rays_train(sigmas, rgb_norm, deltas, rays, T_thresh)
-            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
-            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
-            image = image.view(*prefix, 3)
-            depth = depth.view(*prefix)
-            rgb_norm_map = rgb_norm_map.mean(dim=-1).view(*prefix)
+            if rays_gt is not None:
+                _, _, rgb_norm_map = raymarching.composite_rays_train(sigmas, rgb_norm, deltas, rays, T_thresh)
+                rgb_norm_map = rgb_norm_map.mean(dim=-1).view(*prefix)
+            else:   # the reference composites an all-zero rgb_norm here (nerf/renderer.py:304-309, 327): the map is exactly zero and so is its gradient
+                rgb_norm_map = torch.zeros(*prefix, dtype=image.dtype, device=image.device)
+            # image and depth (nerf/renderer.py:328-332: background blend, depth normalisation) are formed on first access; train_loss()
+            # computes them, the loss and the gradients from results.raw in one launch each way instead
+            results = TrainResults(RawTrain(weights_sum, depth, image, None, nears, fars, bg_color, tuple(prefix), 0, 0))
+            results["rgb_norm"] = rgb_norm_map
             results["weights_sum"] = weights_sum
+            return results
         elif self.march_mode == "native":
             # device-driven loop: same schedule and arithmetic, no per-iteration host sync (pnr_nerf_render_frame)
             if getattr(self, "_fused", None) is None:
@@ -713,17 +716,15 @@ class PaletteRenderer(_RendererBase):
                                         omega[..., 0]], dim=-1)
             weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
             all_map = raymarching.composite_rays_flex_train(sigmas, all_buffer, deltas, rays, T_thresh)
-            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
-            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
-            results["depth"] = depth.view(*prefix)
-            results["image"] = image.view(*prefix, 3)
+            # image, depth and direct_rgb (palette/renderer.py:387-391,399: background blend, depth normalisation) are formed on first access;
+            # train_loss() computes them, the loss and every gradient from results.raw in one launch each way instead
+            results = TrainResults(RawTrain(weights_sum, depth, image, all_map, nears, fars, bg_color, tuple(prefix), nb, clip_dim))
             results["weights_sum"] = weights_sum
             results["omega_sparsity"] = all_map[..., 0:1].view(*prefix)
             results["view_dep_norm"] = all_map[..., 1:2].view(*prefix)
             results["offsets_norm"] = all_map[..., 2:3].view(*prefix)
             results["smooth_norm"] = all_map[..., 3:4].view(*prefix)
             results["view_dep_rgb"] = all_map[..., 4:7].view(*prefix, 3)
-            results["direct_rgb"] = (all_map[..., 7:10] + (1 - weights_sum).unsqueeze(-1) * bg_color).view(*prefix, 3)
             results["diffuse_rgb"] = all_map[..., 10:13].view(*prefix, 3)
             results["clip_feat"] = all_map[..., 13:13 + clip_dim].view(*prefix, clip_dim)
             results["basis_acc"] = all_map[..., 13 + clip_dim:13 + clip_dim + nb].view(*prefix, nb)

@@ -44,6 +44,40 @@ class _sh_encoder(Function):
 sh_encode = _sh_encoder.apply
 
 
+class _sh_encode_cat(Function):
+    """torch.cat([sh_encode(dirs, degree), tail], dim=-1) as one launch (pnr_sh_encode_cat_forward); no gradient for dirs, the tail's
+    gradient is the column slice of the output's."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, dirs, tail, degree):
+        dirs = require(dirs.contiguous(), torch.float32, "inputs")
+        tail = require(tail.contiguous(), torch.float32, "tail")
+        n, t = tail.shape
+        out = torch.empty(n, degree * degree + t, dtype=torch.float32, device=dirs.device)
+        call("pnr_sh_encode_cat_forward", ptr(dirs), ptr(tail), _u32(t), ptr(out), _u32(n), _u32(degree))
+        ctx.width = degree * degree
+        return out
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad):
+        return None, grad[:, ctx.width:], None
+
+
+def sh_encode_cat(encoder, dirs, tail):
+    """`torch.cat([encoder(dirs), tail], dim=-1)` for an SHEncoder: one launch when it can be (CUDA, [B,3] directions that need no gradient,
+    degree^2 + tail columns <= 64), the plain composition otherwise."""
+    ok = (isinstance(encoder, SHEncoder) and dirs.is_cuda and dirs.ndim == 2 and tail.ndim == 2 and dirs.shape[0] == tail.shape[0] and dirs.shape[0] > 0
+          and not dirs.requires_grad and 0 < tail.shape[1] and encoder.output_dim + tail.shape[1] <= 64
+          and dirs.dtype in (torch.float32, torch.float16) and tail.dtype in (torch.float32, torch.float16))
+    if ok and not torch.is_autocast_enabled() and not (dirs.dtype == tail.dtype == torch.float32):   # under autocast both are cast up to fp32
+        ok = False
+    if not ok:
+        return torch.cat([encoder(dirs), tail], dim=-1)
+    return _sh_encode_cat.apply(dirs, tail, encoder.degree)
+
+
 class SHEncoder(nn.Module):
     def __init__(self, input_dim=3, degree=4):
         super().__init__()

@@ -21,9 +21,10 @@ def main():
     ap.add_argument("--fp16", action="store_true")
     ap.add_argument("--sync-each-step", action="store_true", help="loss.item()-style host read every step, as the reference's trainer does")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of palettenerf_amd.optim.Adam (pnr_adam_step: one launch for all tensors, same bits)")
+    ap.add_argument("--torch-loss", action="store_true", help="the trainer's loss written with torch on the result dict instead of palettenerf_amd.train_loss")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    m, step = bench.make_training_step(args.model, args.rays, dev, fp16=args.fp16, torch_adam=args.torch_adam)
+    m, step = bench.make_training_step(args.model, args.rays, dev, fp16=args.fp16, torch_adam=args.torch_adam, torch_loss=args.torch_loss)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()

@@ -138,6 +138,10 @@ def test_training_entry_points_validate_without_gpu():
     assert lib.pnr_nerf_density_forward(None, None, u32(8), f32(1.0), None, None, i32(1), f32(1.0), None) == -1
     assert lib.pnr_linear_bgrad(None, i32(0), u32(0), u32(13), None, i32(1), None, u64(0), None) == -1                                      # no output
     assert lib.pnr_set_option(b"composite_fusion", 2) == 0
+    assert lib.pnr_sh_encode_cat_forward(None, None, u32(15), None, u32(8), u32(8), None) == -2     # 64 + 15 columns: no room in the LDS tile
+    assert lib.pnr_sh_encode_cat_forward(None, None, u32(0), None, u32(8), u32(4), None) == -2      # nothing to append
+    assert lib.pnr_sh_encode_cat_forward(None, None, u32(15), None, u32(8), u32(4), None) == -1     # null pointers
+    assert lib.pnr_sh_encode_cat_forward(None, None, u32(15), None, u32(0), u32(4), None) == 0
     # the round-3 switches of the frame loops (speed only): names exist, values are clamped, unknown names are refused
     for name, value in ((b"hosted_tail", 1), (b"march_budget", 2), (b"march_budget0", 0), (b"march_blocks", 0), (b"coop_march", 1)):
         assert lib.pnr_set_option(name, value) == 0

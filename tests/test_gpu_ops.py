@@ -476,6 +476,28 @@ def test_sh_encode_forward_and_grad(cuda, degree, golden_dir):
         np.testing.assert_allclose(host(shencoder.sh_encode(dev(gold["x"], cuda), degree, False)), gold[f"y{degree}"], atol=2e-6)
 
 
+@pytest.mark.parametrize("degree,t,B", [(4, 15, 100003), (4, 15, 1), (1, 63, 255), (7, 15, 257), (3, 1, 4096), (5, 39, 513)])
+def test_sh_encode_cat_is_the_concatenation(cuda, degree, t, B):
+    """pnr_sh_encode_cat_forward == torch.cat([sh_encode(d), tail]) bit for bit (color_net's input, nerf/network.py:109-115); the tail's
+    gradient is the column slice, directions get none."""
+    g = torch.Generator().manual_seed(B + degree)
+    d = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1).to(cuda)
+    tail = torch.randn(B, t, generator=g).to(cuda).requires_grad_(True)
+    enc = shencoder.SHEncoder(degree=degree)
+    ref = torch.cat([enc(d), tail], dim=-1)
+    out = shencoder.sh_encode_cat(enc, d, tail)
+    assert out.grad_fn is not None and type(out.grad_fn).__name__.startswith("_sh_encode_cat")
+    assert torch.equal(out, ref)
+    w = torch.randn(B, degree * degree + t, generator=g).to(cuda)
+    (g_out,) = torch.autograd.grad((out * w).sum(), tail)
+    (g_ref,) = torch.autograd.grad((ref * w).sum(), tail)
+    assert torch.equal(g_out, g_ref)
+    # outside the fused form's reach: the plain composition (directions that want a gradient; too many columns)
+    d2 = d.clone().requires_grad_(True)
+    assert type(shencoder.sh_encode_cat(enc, d2, tail).grad_fn).__name__ == "CatBackward0"
+    assert type(shencoder.sh_encode_cat(shencoder.SHEncoder(degree=8), d, tail).grad_fn).__name__ == "CatBackward0"
+
+
 def test_sh_matches_reference_cuda_polynomials_off_sphere(cuda, golden_dir):
     import ctypes
     from palettenerf_amd._torch_glue import call, ptr
