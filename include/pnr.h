@@ -461,23 +461,25 @@ int pnr_linear_wgrad(const void* x, int x_dtype, const void* dy, int dy_dtype, u
                      int accumulate, void* workspace, uint64_t workspace_bytes, pnr_stream_t stream);
 /* The fields' small bias-free MLPs for TRAINING as one launch forward and one launch backward (replaces the nn.Linear(bias=False) stacks
  * of nerf/network.py:33-93 and palette/network.py:60-153 under autograd: per layer a GEMM + activation kernel forward, two GEMMs + an
- * activation kernel backward).  2 or 3 layers, every width <= 64, hidden activation 0 = ReLU, 1 = ELU(alpha 1), no output activation;
+ * activation kernel backward).  2 or 3 layers, every width <= 64, hidden activation 0 = ReLU, 1 = ELU(alpha 1), optionally torch.sigmoid on the output;
  * fp32 (exact fma chains on v_mfma_f32_32x32x2_f32).  weights w_l are [dims[l+1]][dims[l]] row-major as nn.Linear stores them.
  *   pnr_mlp_pack      weights -> MFMA-ordered blob of pnr_mlp_packed_bytes (W_l and W_l^T); call again after every optimiser step
  *   pnr_mlp_forward   x [B, dims[0]] -> y [B, dims[n_layers]]
  *   pnr_mlp_backward  x, dy [B, dims[n_layers]] -> dx [B, dims[0]] (NULL: not wanted), dw_l [dims[l+1]][dims[l]] (NULL: not wanted);
- *                     hidden activations are recomputed from x; dw is reduced deterministically through `workspace`. */
+ *                     hidden activations are recomputed from x; dw is reduced deterministically through `workspace`.
+ *                     y: the forward's output, read only with PNR_MLP_OUT_SIGMOID (dZ = dY (1 - y) y; NULL otherwise). */
 typedef struct {
     uint32_t n_layers;      /* 2 or 3 */
     uint32_t dims[4];       /* dims[0] = input width ... dims[n_layers] = output width, each 1..64 */
-    int activation;         /* 0 ReLU, 1 ELU */
+    int activation;         /* between layers: 0 ReLU, 1 ELU;  | PNR_MLP_OUT_SIGMOID: torch.sigmoid on the last layer's output as well */
 } pnr_mlp_desc;
+#define PNR_MLP_OUT_SIGMOID 0x100   /* colour heads: torch.sigmoid(h) behind color_net / diff_net (nerf/network.py:122, palette/network.py:245,254) */
 uint64_t pnr_mlp_packed_bytes(const pnr_mlp_desc* desc);
 int pnr_mlp_pack(const pnr_mlp_desc* desc, const float* w0, const float* w1, const float* w2, float* packed, pnr_stream_t stream);
 int pnr_mlp_forward(const pnr_mlp_desc* desc, const float* packed, const float* x, uint32_t B, float* y, pnr_stream_t stream);
 uint64_t pnr_mlp_backward_workspace_bytes(const pnr_mlp_desc* desc, uint32_t B);
-int pnr_mlp_backward(const pnr_mlp_desc* desc, const float* packed, const float* x, const float* dy, uint32_t B, float* dx, float* dw0, float* dw1,
-                     float* dw2, void* workspace, uint64_t workspace_bytes, pnr_stream_t stream);
+int pnr_mlp_backward(const pnr_mlp_desc* desc, const float* packed, const float* x, const float* y, const float* dy, uint32_t B, float* dx, float* dw0,
+                     float* dw1, float* dw2, void* workspace, uint64_t workspace_bytes, pnr_stream_t stream);
 
 /* The same with the first 32 input columns taken straight from a hash-grid encoder output in its native level-major layout
  * enc [16][B][2] (pnr_grid_encode_forward's `outputs`) and the remaining dims[0] - 32 columns from a row-major x_tail [B, dims[0]-32]

@@ -65,7 +65,7 @@ SIGNATURES = {
     "pnr_mlp_pack": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "pnr_mlp_forward": [_ptr, _ptr, _ptr, _u32, _ptr, _ptr],
     "pnr_mlp_backward_workspace_bytes": [_ptr, _u32],
-    "pnr_mlp_backward": [_ptr, _ptr, _ptr, _ptr, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _ptr],
+    "pnr_mlp_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _ptr],
     "pnr_mlp_forward_lm": [_ptr, _ptr, _ptr, _u32, _ptr, _u32, _ptr, _ptr],
     "pnr_mlp_backward_lm": [_ptr, _ptr, _ptr, _u32, _ptr, _ptr, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _u64, _ptr],
     "pnr_linear_bgrad": [_ptr, _int, _u32, _u32, _ptr, _int, _ptr, _u64, _ptr],
@@ -106,6 +106,9 @@ class AdamTensor(ctypes.Structure):
 class AdamScalars(ctypes.Structure):
     """Mirror of `pnr_adam_scalars` (include/pnr.h)."""
     _fields_ = [(n, _f32) for n in ("one_minus_beta1", "beta2", "one_minus_beta2", "bias_correction2_sqrt", "eps", "neg_step_size", "inv_grad_scale")]
+
+
+MLP_OUT_SIGMOID = 0x100   # PNR_MLP_OUT_SIGMOID
 
 
 class MlpDesc(ctypes.Structure):

@@ -23,7 +23,7 @@ constexpr uint32_t kMlpMaxBlocks = 256;          // one persistent workgroup per
 __host__ __device__ constexpr uint32_t tiles32(uint32_t n) { return (n + 31u) / 32u; }
 
 struct MlpPlan {
-    uint32_t n_layers, act;
+    uint32_t n_layers, act, out_act;   // out_act 1: sigmoid on the last layer's output
     uint32_t dims[4];
     uint32_t w_off[3], wt_off[3];    // float offsets of the packed W_l / W_l^T slots
     uint32_t dw_off[3];              // float offsets of dW_l inside a partial row
@@ -37,9 +37,12 @@ struct MlpPlan {
 __host__ __device__ inline uint32_t plan_tiles(const MlpPlan& p, uint32_t d) { return (d == 0 || d == p.n_layers) ? tiles32(p.dims[d]) : 2u; }
 
 static bool make_plan(const pnr_mlp_desc* d, MlpPlan& p) {
-    if (!d || d->n_layers < 2 || d->n_layers > 3 || (d->activation != 0 && d->activation != 1)) return false;
+    if (!d || d->n_layers < 2 || d->n_layers > 3) return false;
+    const int hidden = d->activation & ~PNR_MLP_OUT_SIGMOID;
+    if (hidden != 0 && hidden != 1) return false;
     p.n_layers = d->n_layers;
-    p.act = (uint32_t)d->activation;
+    p.act = (uint32_t)hidden;
+    p.out_act = (d->activation & PNR_MLP_OUT_SIGMOID) ? 1u : 0u;
     uint32_t off = 0, dw = 0;
     for (uint32_t l = 0; l <= d->n_layers; l++) {
         if (d->dims[l] == 0 || d->dims[l] > 64) return false;
@@ -295,6 +298,12 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_fwd(MlpPlan p, const float*
             o[0] = a[0];
             if constexpr (TO == 2) o[1] = a[1];
         }
+        if (p.out_act) {
+#pragma unroll
+            for (int tt = 0; tt < TO; tt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[tt][r] = 1.0f / (1.0f + expf(-o[tt][r]));   // torch.sigmoid
+        }
         wave_sync();
         frag_to_stage<TO>(stage, lane, o);
         wave_sync();
@@ -305,7 +314,8 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_fwd(MlpPlan p, const float*
 
 template <int NL, int TI, int TO, int ACT>
 __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd(MlpPlan p, const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ x_tail, const float* __restrict__ dy,
-                                                         uint32_t B, float* __restrict__ dx, float* __restrict__ partial /* [gridDim.x][dw_floats] */) {
+                                                         const float* __restrict__ yout /* the forward's output: out_act only */, uint32_t B, float* __restrict__ dx,
+                                                         float* __restrict__ partial /* [gridDim.x][dw_floats] */) {
     extern __shared__ float lds[];
     float* w = lds;
     for (uint32_t i = threadIdx.x * 4; i < p.packed_floats; i += kMlpThreads * 4) *reinterpret_cast<float4*>(&w[i]) = *reinterpret_cast<const float4*>(&packed[i]);
@@ -319,18 +329,24 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd(MlpPlan p, const float*
 #pragma unroll
         for (int j = 0; j < 2; j++) { dw0[i][j] = zero16(); dw1[i][j] = zero16(); dw2[i][j] = zero16(); }
     const uint32_t nblock_tiles = (B + 32 * kMlpWaves - 1) / (32 * kMlpWaves);
-    float xr[16 * TI], yn[16 * TO];
+    float xr[16 * TI], yn[16 * TO], sn[16 * TO];
     if (p.lm) raw_load_lm<TI>(xr, x, x_tail, p.tail, (blockIdx.x * kMlpWaves + wave) * 32, B, lane);
     else raw_load<TI>(xr, x, (blockIdx.x * kMlpWaves + wave) * 32, B, p.dims[0], lane);
     raw_load<TO>(yn, dy, (blockIdx.x * kMlpWaves + wave) * 32, B, p.dims[NL], lane);
+    if (yout) raw_load<TO>(sn, yout, (blockIdx.x * kMlpWaves + wave) * 32, B, p.dims[NL], lane);
     for (uint32_t bt = blockIdx.x; bt < nblock_tiles; bt += gridDim.x) {
         const uint32_t row0 = (bt * kMlpWaves + wave) * 32;
         if (p.lm) raw_to_stage_lm<TI>(GB, xr, p.tail, p.tail_magic, row0, B, lane);
         else raw_to_stage<TI>(GB, xr, row0, B, p.dims[0], p.magic[0], lane);
+        if (yout) {   // dZ = dY (1 - y) y: sigmoid_backward, in the raw layout both tiles share
+#pragma unroll
+            for (int k = 0; k < 16 * TO; k++) yn[k] = (yn[k] * (1.0f - sn[k])) * sn[k];
+        }
         raw_to_stage<TO>(GA, yn, row0, B, p.dims[NL], p.magic[NL], lane);
         wave_sync();
         const uint32_t next0 = ((bt + gridDim.x) * kMlpWaves + wave) * 32;
         raw_load<TO>(yn, dy, next0, B, p.dims[NL], lane);          // the next tile's dY flies during this tile's matrix work
+        if (yout) raw_load<TO>(sn, yout, next0, B, p.dims[NL], lane);
         // recompute the hidden activations h1 (after layer 0) and h2 (after layer 1, NL == 3)
         f32x16 xin[2], h1[2], h2[2], g[2], t[2];
         frag_from_stage<TI>(GB, lane, xin);
@@ -533,7 +549,7 @@ uint64_t pnr_mlp_backward_workspace_bytes(const pnr_mlp_desc* desc, uint32_t B) 
     return (uint64_t)mlp_blocks(B) * p.dw_floats * 4;
 }
 
-static int mlp_backward_impl(const pnr_mlp_desc* desc, const float* packed, const float* x, uint32_t lm_levels, const float* x_tail, const float* dy,
+static int mlp_backward_impl(const pnr_mlp_desc* desc, const float* packed, const float* x, uint32_t lm_levels, const float* x_tail, const float* y, const float* dy,
                              uint32_t B, float* dx, float* dw0, float* dw1, float* dw2, void* workspace, uint64_t workspace_bytes, pnr_stream_t stream) {
     MlpPlan p;
     if (!make_plan(desc, p)) return PNR_ERR_UNSUPPORTED;
@@ -545,26 +561,28 @@ static int mlp_backward_impl(const pnr_mlp_desc* desc, const float* packed, cons
             if (gr.dw[l] && hipMemsetAsync(gr.dw[l], 0, (size_t)p.dims[l] * p.dims[l + 1] * 4, s) != hipSuccess) return PNR_ERR_LAUNCH;
         return PNR_OK;
     }
-    if (!packed || !x || !dy || !workspace) return PNR_ERR_INVALID;
+    if (!packed || !x || !dy || !workspace || (p.out_act && !y)) return PNR_ERR_INVALID;
+    if (!p.out_act) y = nullptr;
     if ((uint64_t)B * 64 >= (1ull << 32)) return PNR_ERR_UNSUPPORTED;   // element indices are 32-bit
     if (workspace_bytes < pnr_mlp_backward_workspace_bytes(desc, B)) return PNR_ERR_INVALID;
     const size_t lds = ((size_t)p.packed_floats + kMlpWaves * 2 * kStageFloats) * 4;
     if (lds > 160 * 1024 || p.dw_floats > (uint32_t)(kMlpWaves * 2 * kStageFloats)) return PNR_ERR_UNSUPPORTED;
     const uint32_t blocks = mlp_blocks(B), grid = blocks;
     float* partial = static_cast<float*>(workspace);
-    PNR_MLP_SWITCH(k_mlp_bwd, p, packed, x, x_tail, dy, B, dx, partial);
+    PNR_MLP_SWITCH(k_mlp_bwd, p, packed, x, x_tail, dy, y, B, dx, partial);
     hipLaunchKernelGGL(k_mlp_dw_reduce, dim3(cdiv(p.dw_floats, 32)), dim3(256), 0, s, partial, blocks, p, gr);
     return check_launch();
 }
 
-int pnr_mlp_backward(const pnr_mlp_desc* desc, const float* packed, const float* x, const float* dy, uint32_t B, float* dx, float* dw0, float* dw1,
-                     float* dw2, void* workspace, uint64_t workspace_bytes, pnr_stream_t stream) {
-    return mlp_backward_impl(desc, packed, x, 0, nullptr, dy, B, dx, dw0, dw1, dw2, workspace, workspace_bytes, stream);
+int pnr_mlp_backward(const pnr_mlp_desc* desc, const float* packed, const float* x, const float* y, const float* dy, uint32_t B, float* dx, float* dw0,
+                     float* dw1, float* dw2, void* workspace, uint64_t workspace_bytes, pnr_stream_t stream) {
+    return mlp_backward_impl(desc, packed, x, 0, nullptr, y, dy, B, dx, dw0, dw1, dw2, workspace, workspace_bytes, stream);
 }
 int pnr_mlp_backward_lm(const pnr_mlp_desc* desc, const float* packed, const float* enc_level_major, uint32_t levels, const float* x_tail, const float* dy,
                         uint32_t B, float* denc_level_major, float* dw0, float* dw1, float* dw2, void* workspace, uint64_t workspace_bytes,
                         pnr_stream_t stream) {
-    return mlp_backward_impl(desc, packed, enc_level_major, levels, x_tail, dy, B, denc_level_major, dw0, dw1, dw2, workspace, workspace_bytes, stream);
+    if (desc && (desc->activation & PNR_MLP_OUT_SIGMOID)) return PNR_ERR_UNSUPPORTED;   // no stack behind an encoder ends in a sigmoid
+    return mlp_backward_impl(desc, packed, enc_level_major, levels, x_tail, nullptr, dy, B, denc_level_major, dw0, dw1, dw2, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

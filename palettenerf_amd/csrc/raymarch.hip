@@ -500,7 +500,7 @@ using namespace pnr;
 
 extern "C" {
 
-int pnr_abi_version(void) { return 4; }
+int pnr_abi_version(void) { return 5; }
 
 int pnr_set_option(const char* name, int value) {
     if (!name) return PNR_ERR_INVALID;

@@ -31,7 +31,7 @@ def _desc(dims, act):
 class _FusedMLP(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)   # under autocast: fp32 in, fp32 out (at least the accuracy of the half GEMMs)
-    def forward(ctx, x, act, *weights):
+    def forward(ctx, x, act, *weights):   # act: _ACT code, | _lib.MLP_OUT_SIGMOID for torch.sigmoid on the output
         dims = [weights[0].shape[1]] + [w.shape[0] for w in weights]
         desc = _desc(dims, act)
         lib = _lib.load()
@@ -43,14 +43,14 @@ class _FusedMLP(torch.autograd.Function):
         B = x2.shape[0]
         y = torch.empty(B, dims[-1], dtype=torch.float32, device=dev)
         call("pnr_mlp_forward", ctypes.byref(desc), ptr(packed), ptr(x2), ctypes.c_uint32(B), ptr(y))
-        ctx.save_for_backward(x2, packed)
+        ctx.save_for_backward(x2, packed, y if act & _lib.MLP_OUT_SIGMOID else None)
         ctx.dims, ctx.act, ctx.x_shape = dims, act, x.shape
         return y.reshape(*x.shape[:-1], dims[-1])
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy):
-        x2, packed = ctx.saved_tensors
+        x2, packed, y = ctx.saved_tensors
         dims, act = ctx.dims, ctx.act
         desc = _desc(dims, act)
         lib = _lib.load()
@@ -62,7 +62,7 @@ class _FusedMLP(torch.autograd.Function):
         dws = [torch.empty(dims[l + 1], dims[l], dtype=torch.float32, device=dev) if ctx.needs_input_grad[2 + l] else None for l in range(n)]
         nbytes = int(lib.pnr_mlp_backward_workspace_bytes(ctypes.byref(desc), B))
         ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
-        call("pnr_mlp_backward", ctypes.byref(desc), ptr(packed), ptr(x2), ptr(dy2), ctypes.c_uint32(B), ptr(dx), ptr(dws[0]), ptr(dws[1]),
+        call("pnr_mlp_backward", ctypes.byref(desc), ptr(packed), ptr(x2), ptr(y), ptr(dy2), ctypes.c_uint32(B), ptr(dx), ptr(dws[0]), ptr(dws[1]),
              ptr(dws[2]) if n == 3 else None, ptr(ws), ctypes.c_uint64(nbytes))
         return (dx.reshape(ctx.x_shape) if dx is not None else None, None, *dws)
 
@@ -84,14 +84,18 @@ def fusable(net, h, act):
     return h.requires_grad or any(l.weight.requires_grad for l in net)
 
 
-def run_mlp(net, h, act=F.relu):
+def run_mlp(net, h, act=F.relu, out=None):
+    """out: None, or torch.sigmoid applied to the stack's output (the colour heads: nerf/network.py:122, palette/network.py:245,254) -- inside
+    the same two launches on the fused path."""
+    if out not in (None, torch.sigmoid):
+        raise ValueError("run_mlp: the output activation is None or torch.sigmoid")
     if fusable(net, h, act):
-        return _FusedMLP.apply(h, _ACT[act], *[l.weight for l in net])
+        return _FusedMLP.apply(h, _ACT[act] | (_lib.MLP_OUT_SIGMOID if out is not None else 0), *[l.weight for l in net])
     for i, layer in enumerate(net):
         h = layer(h)
         if i != len(net) - 1:
             h = act(h, inplace=True)
-    return h
+    return h if out is None else out(h)
 
 
 class _EncodeMLP(torch.autograd.Function):

@@ -22,9 +22,10 @@ def _mlp(dims):
     return nn.ModuleList([Linear(dims[i], dims[i + 1], bias=False) for i in range(len(dims) - 1)])
 
 
-def _run(net, h, act=F.relu):
-    """The reference's layer loop; on the GPU under autograd the whole stack is one fused launch each way (mlp.run_mlp)."""
-    return run_mlp(net, h, act)
+def _run(net, h, act=F.relu, out=None):
+    """The reference's layer loop (+ `out`: torch.sigmoid behind a colour head); on the GPU under autograd the whole stack is one fused launch
+    each way (mlp.run_mlp)."""
+    return run_mlp(net, h, act, out)
 
 
 def density_fused(model):
@@ -76,8 +77,7 @@ class NeRFNetwork(NeRFRenderer):
         h = encode_mlp(self.encoder, x, self.bound, None, self.sigma_net)
         sigma = trunc_exp(h[..., 0])
         geo_feat = h[..., 1:]
-        h = _run(self.color_net, sh_encode_cat(self.encoder_dir, d, geo_feat))
-        return sigma, torch.sigmoid(h)
+        return sigma, _run(self.color_net, sh_encode_cat(self.encoder_dir, d, geo_feat), out=torch.sigmoid)
 
     def density(self, x):
         """nerf/network.py:126-143"""
@@ -94,7 +94,7 @@ class NeRFNetwork(NeRFRenderer):
             if not mask.any():
                 return rgbs
             d, geo_feat = d[mask], geo_feat[mask]
-        h = torch.sigmoid(_run(self.color_net, sh_encode_cat(self.encoder_dir, d, geo_feat)))
+        h = _run(self.color_net, sh_encode_cat(self.encoder_dir, d, geo_feat), out=torch.sigmoid)
         if mask is None:
             return h
         rgbs[mask] = h.to(rgbs.dtype)
@@ -145,7 +145,13 @@ class PaletteNetwork(PaletteRenderer):
         if self.opt.pred_clip:
             clip_feat = encode_mlp(self.encoder_clip, x, self.bound, None, self.clip_net)
         else:
-            clip_feat = sigma.new_zeros(*sigma.shape, self.opt.clip_dim)   # palette/network.py:179 (zeros_like of a repeat there)
+            if self.training and torch.is_grad_enabled():   # a read-only broadcast of one zero (nobody writes the training batch's clip_feat): no fill of [M, clip_dim]
+                z = getattr(self, "_zero", None)
+                if z is None or z.device != sigma.device or z.dtype != sigma.dtype:
+                    z = self._zero = torch.zeros(1, dtype=sigma.dtype, device=sigma.device)
+                clip_feat = z.expand(*sigma.shape, self.opt.clip_dim)
+            else:
+                clip_feat = sigma.new_zeros(*sigma.shape, self.opt.clip_dim)   # palette/network.py:179 (zeros_like of a repeat there)
         omega, offsets_radiance, view_dep, diffuse = self.color(x, d, geo_feat=geo_feat)
         return sigma, clip_feat, omega, offsets_radiance, view_dep, diffuse
 
@@ -161,8 +167,8 @@ class PaletteNetwork(PaletteRenderer):
         if mask is not None:
             raise NotImplementedError("masked colour queries belong to the non-cuda_ray path, which is dead code in the reference")
         g = geo_feat.detach()
-        diffuse = torch.sigmoid(_run(self.diff_net, g))
-        view_dep = torch.sigmoid(_run(self.color_net, sh_encode_cat(self.encoder_dir, d, g)))
+        diffuse = _run(self.diff_net, g, out=torch.sigmoid)
+        view_dep = _run(self.color_net, sh_encode_cat(self.encoder_dir, d, g), out=torch.sigmoid)
         h = encode_mlp(self.encoder_palette, x, self.bound, diffuse.detach(), self.basis_net, act=F.elu)   # cat([encoder_palette(x), diffuse]) -> basis_net
         if _fused_heads_ok(self, h):
             offsets_radiance, omega = palette_heads(h, self.offsets_radiance_net, self.omega_net[0])

@@ -121,6 +121,11 @@ def test_training_entry_points_validate_without_gpu():
     assert lib.pnr_mlp_packed_bytes(ctypes.byref(colour)) == 2 * (2 + 4 + 2) * 4096
     assert lib.pnr_mlp_backward_workspace_bytes(ctypes.byref(colour), u32(627000)) == 256 * (31 * 64 + 64 * 64 + 64 * 3) * 4
     assert lib.pnr_mlp_packed_bytes(ctypes.byref(desc([31, 65, 3]))) == 0            # a width above 64
+    assert lib.pnr_mlp_packed_bytes(ctypes.byref(desc([31, 64, 64, 3], act=_lib.MLP_OUT_SIGMOID))) == 2 * (2 + 4 + 2) * 4096   # + sigmoid on the output
+    assert lib.pnr_mlp_backward(ctypes.byref(desc([31, 64, 64, 3], act=_lib.MLP_OUT_SIGMOID)), *[ctypes.c_void_p(8)] * 2, None, ctypes.c_void_p(8), u32(8),
+                                *[None] * 4, ctypes.c_void_p(8), u64(1 << 30), None) == -1                                                # ... needs the forward's y
+    assert lib.pnr_mlp_backward_lm(ctypes.byref(desc([32, 64, 16], act=_lib.MLP_OUT_SIGMOID)), ctypes.c_void_p(8), ctypes.c_void_p(8), u32(16), None,
+                                   ctypes.c_void_p(8), u32(8), *[None] * 4, ctypes.c_void_p(8), u64(1 << 30), None) == -2
     bad = desc([31, 64, 3], act=2)
     assert lib.pnr_mlp_forward(ctypes.byref(bad), None, None, u32(8), None, None) == -2
     assert lib.pnr_mlp_forward(ctypes.byref(colour), None, None, u32(8), None, None) == -1      # null pointers
@@ -146,7 +151,7 @@ def test_training_entry_points_validate_without_gpu():
     for name, value in ((b"hosted_tail", 1), (b"march_budget", 2), (b"march_budget0", 0), (b"march_blocks", 0), (b"coop_march", 1)):
         assert lib.pnr_set_option(name, value) == 0
     assert lib.pnr_set_option(b"no_such_switch", 1) != 0 and lib.pnr_set_option(None, 1) != 0
-    assert lib.pnr_abi_version() >= 4
+    assert lib.pnr_abi_version() >= 5
     # pnr_palette_field_args grew at its end (frame-loop-only ray-state pointers): the ctypes mirror has them and leaves them NULL
     from palettenerf_amd import _lib as L
     names = [f[0] for f in L.PaletteFieldArgs._fields_]

@@ -1192,7 +1192,8 @@ def test_fused_density_matches_the_torch_sigma_net(cuda, kind, precision):
 
 
 @pytest.mark.parametrize("dims,act", [((31, 64, 64, 3), "relu"), ((15, 64, 64, 3), "relu"), ((35, 64, 15), "elu"), ((32, 64, 16), "relu"),
-                                      ((7, 20, 40), "elu"), ((64, 33, 64, 16), "relu")])
+                                      ((7, 20, 40), "elu"), ((64, 33, 64, 16), "relu"),
+                                      ((31, 64, 64, 3), "relu+sigmoid"), ((15, 64, 64, 3), "relu+sigmoid"), ((7, 20, 40), "elu+sigmoid")])
 def test_fused_mlp_forward_backward_match_float64(cuda, dims, act):
     """pnr_mlp_forward / pnr_mlp_backward (csrc/mlp.hip) against the layer loop in float64: output 2e-6 relative to the largest output,
     dX and every dW 2e-5 relative to that gradient's largest entry (fp32 accumulation over 5e4 samples).  Shapes of every net of both
@@ -1204,6 +1205,8 @@ def test_fused_mlp_forward_backward_match_float64(cuda, dims, act):
     net = torch.nn.ModuleList([torch.nn.Linear(dims[i], dims[i + 1], bias=False) for i in range(len(dims) - 1)]).to(cuda)
     for l in net:
         torch.nn.init.normal_(l.weight, std=1.0 / l.in_features ** 0.5)
+    act, _, out_name = act.partition("+")
+    out = torch.sigmoid if out_name == "sigmoid" else None     # the colour heads' torch.sigmoid inside the same launches (PNR_MLP_OUT_SIGMOID)
     fact = F.relu if act == "relu" else F.elu
     x = torch.randn(B, dims[0], device=cuda, requires_grad=True)
     wy = torch.randn(B, dims[-1], device=cuda)
@@ -1219,7 +1222,8 @@ def test_fused_mlp_forward_backward_match_float64(cuda, dims, act):
         assert int(ambiguous.sum()) < 200
         wy[ambiguous.to(cuda)] = 0.0
     assert mlp.fusable(net, x, fact)
-    y = mlp.run_mlp(net, x, fact)
+    y = mlp.run_mlp(net, x, fact, out)
+    assert type(y.grad_fn).__name__.startswith("_FusedMLP")
     (y * wy).sum().backward()
     got = [x.grad.clone()] + [l.weight.grad.clone() for l in net]
     # float64 reference on the host
@@ -1230,6 +1234,8 @@ def test_fused_mlp_forward_backward_match_float64(cuda, dims, act):
         h = h @ w.t()
         if i != len(wd) - 1:
             h = fact(h)
+    if out is not None:
+        h = out(h)
     (h * wy.double().cpu()).sum().backward()
     want = [xd.grad] + [w.grad for w in wd]
     scale = float(h.abs().max())
@@ -1240,12 +1246,12 @@ def test_fused_mlp_forward_backward_match_float64(cuda, dims, act):
     for l in net:
         l.weight.grad = None
     x.grad = None
-    (mlp.run_mlp(net, x, fact) * wy).sum().backward()
+    (mlp.run_mlp(net, x, fact, out) * wy).sum().backward()
     assert all(torch.equal(l.weight.grad, g) for l, g in zip(net, got[1:]))
     # no input gradient wanted: same dW
     for l in net:
         l.weight.grad = None
-    (mlp.run_mlp(net, x.detach(), fact) * wy).sum().backward()
+    (mlp.run_mlp(net, x.detach(), fact, out) * wy).sum().backward()
     assert all(torch.equal(l.weight.grad, g) for l, g in zip(net, got[1:]))
 
 
