@@ -167,16 +167,22 @@ __device__ __forceinline__ void raw_to_stage(float* __restrict__ buf, const floa
     for (uint32_t c = width + ((uint32_t)lane >> 5); c < 32u * NT; c += 2) buf[((uint32_t)lane & 31u) * kStage + c] = 0.0f;
 }
 template <int NT>
-__device__ __forceinline__ void stage_to_global(const float* __restrict__ buf, float* __restrict__ g, uint32_t row0, uint32_t B, uint32_t width, uint32_t magic, int lane) {
+__device__ __forceinline__ void stage_to_global(const float* __restrict__ buf, float* __restrict__ g, uint32_t row0, uint32_t B, uint32_t width, uint32_t magic, int lane,
+                                                bool sigmoid = false) {
     const uint32_t total = B * width, base = row0 * width;
 #pragma unroll
     for (int kt = 0; kt < NT; kt++)
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) {
         const int k = kt * 16 + kk;
+        if (sigmoid && 64u * k >= 32u * width) break;   // wave-uniform: only the tile's real elements pay for the exponential
         const uint32_t f = (uint32_t)lane + 64u * k;
         const uint32_t r = __umulhi(f, magic), c = f - r * width;
-        if (r < 32u && base + f < total) g[base + f] = buf[r * kStage + c];
+        if (r < 32u && base + f < total) {
+            float v = buf[r * kStage + c];
+            if (sigmoid) v = 1.0f / (1.0f + expf(-v));   // torch.sigmoid
+            g[base + f] = v;
+        }
     }
 }
 
@@ -298,16 +304,10 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_fwd(MlpPlan p, const float*
             o[0] = a[0];
             if constexpr (TO == 2) o[1] = a[1];
         }
-        if (p.out_act) {
-#pragma unroll
-            for (int tt = 0; tt < TO; tt++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) o[tt][r] = 1.0f / (1.0f + expf(-o[tt][r]));   // torch.sigmoid
-        }
         wave_sync();
         frag_to_stage<TO>(stage, lane, o);
         wave_sync();
-        stage_to_global<TO>(stage, y, row0, B, p.dims[NL], p.magic[NL], lane);
+        stage_to_global<TO>(stage, y, row0, B, p.dims[NL], p.magic[NL], lane, p.out_act != 0);   // + the colour heads' sigmoid, on the real outputs only
         wave_sync();
     }
 }
