@@ -395,11 +395,12 @@ def make_training_step(model_kind, rays, device, fp16=False, torch_adam=False, t
     return m, step
 
 
-def training_leg(model_kind, device, steps=50, warmup=8, rays=4096):
+def training_leg(model_kind, device, steps=50, warmup=8, rays=4096, torch_loss=False):
     """Wall ms per training step over `steps` steps, and -- from a torch.profiler trace of 10 further steps -- the device time of a step's
-    kernels and the number of launches per step (every kernel of the process is traced, the C-ABI ones included)."""
+    kernels and the number of launches per step (every kernel of the process is traced, the C-ABI ones included).  torch_loss: the trainer's
+    loss written with torch on the result dict, as the reference's trainer has it (what pnr_train_loss_* replaces)."""
     import torch
-    m, step = make_training_step(model_kind, rays, device)
+    m, step = make_training_step(model_kind, rays, device, torch_loss=torch_loss)
     for i in range(warmup):
         step(i)
     torch.cuda.synchronize()
@@ -409,7 +410,8 @@ def training_leg(model_kind, device, steps=50, warmup=8, rays=4096):
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / steps * 1e3
     rec = {"wall_ms_per_step": wall, "steps": steps, "rays_per_step": rays, "samples_per_step": int(m.step_counter[(m.local_step - 1) % 16, 0]),
-           "what": f"configs[3] shape: -m {model_kind} training step, {rays} rays, slab scene, dt_gamma 1/128, Adam; synthetic targets"}
+           "what": f"configs[3] shape: -m {model_kind} training step, {rays} rays, slab scene, dt_gamma 1/128, Adam; synthetic targets; PaletteTrainer.train_step's loss "
+                   f"(main_palette.py's default weights) {'written with torch on the result dict' if torch_loss else 'through pnr_train_loss_* (one launch each way)'}"}
     try:
         from torch.profiler import ProfilerActivity, profile
         n = 10
@@ -424,7 +426,7 @@ def training_leg(model_kind, device, steps=50, warmup=8, rays=4096):
             hip = [e for e in kernels if e.name.startswith("pnr::") or "pnr::" in e.name[:12]]
             rec["launches_hip_per_step"] = len(hip) / n          # this repository's kernels: march, lookups, MLP stacks, composites, binned gradient, Adam
             rec["kernel_ms_hip_per_step"] = sum(e.device_time for e in hip) / n / 1e3
-            rec["launches_torch_per_step"] = (len(kernels) - len(hip)) / n   # torch's: the loss arithmetic of the (stand-in) trainer, the renderer's bg blend / depth normalisation, sigmoids, one cat, fills, gradient accumulation
+            rec["launches_torch_per_step"] = (len(kernels) - len(hip)) / n   # torch's: ray selection, march_rays_train's bookkeeping (noise, counter, one host read), gradient zero fills, x -> [0, 1] in front of the encoders, gradient accumulation
             rec["wall_over_kernel"] = wall / rec["kernel_ms_per_step"]
     except Exception as e:   # noqa: BLE001 -- a profiler that does not work on this box is reported, the wall figure stands
         rec["profiler_error"] = repr(e)
@@ -959,6 +961,9 @@ def main(argv=None):
             for kind in ("palette", "nerf"):
                 try:
                     extra[f"train_{kind}"] = training_leg(kind, device)
+                    if kind == "palette":   # the same step with the loss as the reference's trainer writes it: what the fused tail replaces
+                        t = training_leg(kind, device, steps=20, torch_loss=True)
+                        extra[f"train_{kind}"]["with_torch_loss"] = {k: t[k] for k in ("wall_ms_per_step", "kernel_ms_per_step", "launches_per_step") if k in t}
                 except RuntimeError as e:
                     extra[f"train_{kind}_error"] = str(e)
             try:
