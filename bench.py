@@ -410,8 +410,9 @@ def training_leg(model_kind, device, steps=50, warmup=8, rays=4096, torch_loss=F
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / steps * 1e3
     rec = {"wall_ms_per_step": wall, "steps": steps, "rays_per_step": rays, "samples_per_step": int(m.step_counter[(m.local_step - 1) % 16, 0]),
-           "what": f"configs[3] shape: -m {model_kind} training step, {rays} rays, slab scene, dt_gamma 1/128, Adam; synthetic targets; PaletteTrainer.train_step's loss "
-                   f"(main_palette.py's default weights) {'written with torch on the result dict' if torch_loss else 'through pnr_train_loss_* (one launch each way)'}"}
+           "what": f"configs[3] shape: -m {model_kind} training step, {rays} rays, slab scene, dt_gamma 1/128, Adam; synthetic targets; "
+                   + ("PaletteTrainer.train_step's loss (main_palette.py's default weights) " if model_kind == "palette" else "Trainer.train_step's colour MSE (nerf/utils.py:535) ")
+                   + ("written with torch on the result dict" if torch_loss else "through pnr_train_loss_* (one launch each way)")}
     try:
         from torch.profiler import ProfilerActivity, profile
         n = 10
