@@ -40,6 +40,7 @@ def main(argv=None):
     ap.add_argument("--res", type=float, default=0.25, help="fraction of 1008 x 756 (memory / teacher render time only; the step does not depend on it)")
     ap.add_argument("--optimizer", choices=["pnr", "torch"], default="pnr")
     ap.add_argument("--log-every", type=int, default=500)
+    ap.add_argument("--dead-rows", action="store_true", help="after training: how many samples of a step get an all-zero gradient from the composites (profiles/dead_rows.py)")
     ap.add_argument("--torch-loss", action="store_true", help="the losses written with torch on the result dict instead of palettenerf_amd.train_loss")
     args = ap.parse_args(argv)
     dev = torch.device("cuda:0")
@@ -146,6 +147,18 @@ def main(argv=None):
     samples = float(pal.step_counter[:, 0].float().mean())      # the last 16 steps' sample counts
     print(f"stage 2 (-m palette, configs[3]): {args.steps} steps in {total:.1f} s = {total / args.steps * 1e3:.2f} ms/step (optimizer: {args.optimizer}), "
           f"final held-out PSNR {log[-1][1]:.2f} dB; {samples / 1e6:.2f} M samples per step at the end ({total / args.steps * 1e3 / (samples / 1e6):.2f} ms per M samples)")
+    if args.dead_rows:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import dead_rows
+
+        def one_step(_i):
+            ro, rd, gt = batch()
+            out = pal.render(ro, rd, perturb=True, force_all_rays=True, **kw)
+            loss, _ = train_loss(out, gt, lambda_sparsity=lam["sparsity"], lambda_offsets=lam["offsets"], lambda_view_dep=lam["view_dep"], lambda_palette=lam["palette"],
+                                 basis_color=pal.basis_color, basis_color_origin=pal.basis_color_origin, want_outputs=False)
+            o2.zero_grad(set_to_none=True)
+            loss.backward()
+        dead_rows.probe("trained scene (palette)", pal, one_step)
     try:   # device time of a step's kernels at the end of training (the wall figure above includes the host's share)
         from torch.profiler import ProfilerActivity, profile
         with profile(activities=[ProfilerActivity.CUDA]) as prof:
