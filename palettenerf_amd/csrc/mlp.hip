@@ -93,7 +93,11 @@ __device__ __forceinline__ void mlp_layer(const float* __restrict__ wp, const f3
         for (int kt = 0; kt < NKT; kt++) {
             const float* w = wp + (size_t)((rt * NKT + kt) * 16) * 64;
 #pragma unroll
+#ifdef PNR_MLP_FAKE   // timing builds only (WRONG results): every PNR_MLP_FAKE-th matrix instruction, the operand reads stay -- what is left of the kernel without its matrix work
+            for (int r = 0; r < 16; r++) { const float wv = w[r * 64 + lane]; if (r % PNR_MLP_FAKE == 0) out[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, a[kt][r], out[rt], 0, 0, 0); else out[rt][r] += wv; }
+#else
             for (int r = 0; r < 16; r++) out[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r * 64 + lane], a[kt][r], out[rt], 0, 0, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -259,8 +263,15 @@ __device__ __forceinline__ void wgrad_accumulate(f32x16 (&acc)[2][2], const floa
 #pragma unroll
         for (int ct = 0; ct < NCT; ct++) {
 #pragma unroll
+#ifdef PNR_MLP_FAKE
+            for (int p = 0; p < 16; p++) {
+                const float gv = G[(2 * p + h) * kStage + rt * 32 + c], av = A[(2 * p + h) * kStage + ct * 32 + c];
+                if (p % PNR_MLP_FAKE == 0) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, av, acc[rt][ct], 0, 0, 0); else acc[rt][ct][p] += gv * av;
+            }
+#else
             for (int p = 0; p < 16; p++)
                 acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(G[(2 * p + h) * kStage + rt * 32 + c], A[(2 * p + h) * kStage + ct * 32 + c], acc[rt][ct], 0, 0, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     }
