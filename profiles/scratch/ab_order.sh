@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the variant this script measured lost and its code was removed ("Experiments that lost"); kept as the record of how it was measured.
 # cost-ordered first march launch (pnr_set_option march_order / PNR_MARCH_ORDER=1) against the plain order, same build, same box
 run() { python bench.py --steps 40 --warmup 5 --no-extras --no-cpu-baseline "$@" 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],3), round(d['step_ms']['median'],3), d['config'].get('rendered_samples_per_step'))"; }
 R=$PWD; export TMPDIR=/tmp

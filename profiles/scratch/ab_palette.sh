@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the variant this script measured lost and its code was removed ("Experiments that lost"); kept as the record of how it was measured.
 # palette-field A/B on one box: the committed kernel (git stash of the working copy is not available on the box: BASE=<file> holds the old source) against the working copy
 run() { python bench.py --steps 20 --warmup 4 --no-extras --no-cpu-baseline "$@" 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],3), round(d['step_ms']['median'],3))"; }
 R=$PWD; export TMPDIR=/tmp

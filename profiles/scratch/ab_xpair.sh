@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the variant this script measured lost and its code was removed ("Experiments that lost"); kept as the record of how it was measured.
 # x-pair gathers (PNR_GRID_XPAIR) against the default lookup: correctness (frame tests on the variant build), then lego timings + kernel summary per variant
 run() { python bench.py --steps 40 --warmup 5 --no-extras --no-cpu-baseline "$@" 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],3), round(d['value']/1e9,3), round(d['step_ms']['median'],3), round(d['roofline']['frac'],3))"; }
 R=$PWD; export TMPDIR=/tmp
