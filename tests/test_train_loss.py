@@ -114,7 +114,7 @@ def _compare(raw, gt, gt_clip, gt_w, bc, bco, scale=None):
     assert info["terms"][0].item() == loss.item()
     for i, name in enumerate(TERM_NAMES[1:], 1):
         if name in t_ref:
-            assert abs(float(info["terms"][i]) - float(t_ref[name])) <= 2e-6 * abs(float(t_ref[name])) + 1e-12, name
+            assert abs(float(info["terms"][i]) - float(t_ref[name].detach())) <= 2e-6 * abs(float(t_ref[name].detach())) + 1e-12, name
         else:
             assert float(info["terms"][i]) == 0.0
     for a, b in zip(g, g_ref):
@@ -190,3 +190,24 @@ def test_palette_training_step_with_the_fused_loss(cuda):
     assert set(g_ref) == set(g_fus) and "basis_color" in g_fus
     for name in g_ref:
         assert float((g_ref[name] - g_fus[name]).abs().max()) <= 2e-5 * float(g_ref[name].abs().max()) + 1e-12, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["palette", "nerf"])
+def test_training_step_with_the_fused_loss_under_fp16_autocast(cuda, kind):
+    """The reference's -O training mode (fp16 autocast + GradScaler, main_nerf.py:72-75): the fused loss takes the fp32 composites as they are, the scaled
+    backward multiplies its gradients by the scaler's device scalar; three steps run, the loss is finite and the parameters move as with the torch loss."""
+    import bench
+    losses = {}
+    for torch_loss in (False, True):
+        torch.manual_seed(3)
+        m, step = bench.make_training_step(kind, 4096, cuda, fp16=True, torch_loss=torch_loss)
+        p0 = (m.color_net[0].weight if kind == "nerf" else m.diff_net[0].weight).detach().clone()
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+        p1 = (m.color_net[0].weight if kind == "nerf" else m.diff_net[0].weight).detach()
+        assert torch.isfinite(p1).all() and float((p1 - p0).abs().max()) > 0
+        losses[torch_loss] = p1.clone()
+    scale = float(losses[True].abs().max())
+    assert float((losses[False] - losses[True]).abs().max()) <= 5e-2 * scale     # same trajectory to fp16 training noise (perturbed samples differ by the RNG stream only)
