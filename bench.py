@@ -63,6 +63,7 @@ def parse(argv=None):
     ap.add_argument("--pose-step-deg", type=float, default=3.0, help="lego orbit: degrees of azimuth per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra driver-observed legs (exact-fp32 field, palette model)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic (FETCH_SIZE / WRITE_SIZE of the lookup kernel)")
     ap.add_argument("--extra-steps", type=int, default=20)
     ap.add_argument("--shared-stream", action="store_true",
                     help="with --main-frames-in-flight F > 1: all F handles enqueue into one stream (frames back to back without the host's gap, kernels never overlap)")
@@ -96,6 +97,23 @@ def parse(argv=None):
     args.wl = wl
     args.model = wl["model"]
     return args
+
+
+def core_argv(args):
+    """The flags that define the headline workload (what a child pass of this script must repeat)."""
+    a = ["--workload", args.workload, "--res", str(args.res), "--density-scale", repr(float(args.density_scale)), "--field-precision", args.field_precision,
+         "--ray-order", args.ray_order, "--pose-step-deg", repr(float(args.pose_step_deg)), "--num-basis", str(args.num_basis)]
+    for flag, on in (("--fp16", args.fp16), ("--static-pose", args.static_pose), ("--no-interleave", args.no_interleave), ("--pred-clip", args.pred_clip),
+                     ("--half-tables", args.half_tables)):
+        if on:
+            a.append(flag)
+    if args.mode:
+        a += ["--mode", args.mode]
+    if args.scene:
+        a += ["--scene", args.scene]
+    if args.dt_gamma is not None:
+        a += ["--dt-gamma", repr(float(args.dt_gamma))]
+    return a
 
 
 def spawn_ranks(args, argv, script=None):
@@ -255,33 +273,44 @@ def cpu_baseline(args, crop_rays):
                 ref = r
             else:   # the C ops are bit-identical on any thread count (tests/test_oracle.py); torch's CPU GEMMs block differently per thread count
                 legs[name]["max_abs_rgb_vs_1_thread"] = float((r["image"] - ref["image"]).abs().max())
-        # BASELINE configs[0] beside it: the reference's CPU-runnable case, NeRFRenderer.run at 400x400 with --num_steps 512 --upsample_steps 0
-        # (main_nerf.py:31-32): 1024 rays of one max_ray_batch of 4096 (160 such pieces make the frame), OMP_NUM_THREADS=8 as scripts/run_blender.sh:47 sets
-        uniform = None
-        if args.model == "nerf":
-            n_thr = min(8, cores)
+        torch.set_num_threads(1)
+    finally:
+        renderer.raymarching, pge.GridEncoder, psh.SHEncoder = saved
+    # BASELINE configs[0] beside it -- the reference's CPU-runnable case, "pure-PyTorch raymarching on CPU (no CUDA ext)": NeRFRenderer.run at 400x400 with
+    # --num_steps 512 --upsample_steps 0 (main_nerf.py:31-32), hash-grid and SH encoders written with torch ops (oracle/torch_encoders.py; the reference ships no
+    # torch hash grid), nn.Linear fp32, torch threads = min(host cores, 64).  A bounded piece: 512 rays of one max_ray_batch of 4096 (320 such pieces make the frame).
+    uniform = None
+    if args.model == "nerf":
+        from oracle.torch_encoders import TorchGridEncoder, TorchSHEncoder
+        saved2 = (renderer.raymarching, pge.GridEncoder, psh.SHEncoder)
+        renderer.raymarching, pge.GridEncoder, psh.SHEncoder = rm, TorchGridEncoder, TorchSHEncoder    # (run() takes near / far from the ray-box op: the C oracle's)
+        n_thr = min(cores, 64)
+        try:
             torch.set_num_threads(n_thr)
             mu = make_model(args, "nerf", cuda_ray=False)
             scene.seed_field_(mu, 0)
             mu.eval()
             pose = torch.from_numpy(scene.lookat_pose())[None]
             ro0, rd0 = scene.get_rays(pose, scene.intrinsics_from_fov(400, 400), 400, 400)
-            mid = 400 * 200 - 512
-            t0 = time.perf_counter()
+            mid, n_rays = 400 * 200 - 256, 512
             with torch.no_grad():
-                mu.run(ro0[:, mid:mid + 1024].contiguous(), rd0[:, mid:mid + 1024].contiguous(), num_steps=512, upsample_steps=0, perturb=False)
+                mu.run(ro0[:, mid:mid + 32].contiguous(), rd0[:, mid:mid + 32].contiguous(), num_steps=512, upsample_steps=0, perturb=False)   # warm the thread pool
+                t0 = time.perf_counter()
+                mu.run(ro0[:, mid:mid + n_rays].contiguous(), rd0[:, mid:mid + n_rays].contiguous(), num_steps=512, upsample_steps=0, perturb=False)
             du = time.perf_counter() - t0
-            uniform = {"value": 1024 * 512 / du, "unit": "evaluated samples/s", "cores": n_thr, "ms_per_400x400_frame_extrapolated": du * 160 * 1e3,
-                       "sample": f"1024 rays x 512 uniform samples (1/160) of a 400x400 frame ({du:.1f} s; C oracle encoders 1 thread + torch MLP on {n_thr} threads)"}
-        torch.set_num_threads(1)
-    finally:
-        renderer.raymarching, pge.GridEncoder, psh.SHEncoder = saved
-    one = legs["1_thread"]
+            uniform = {"value": n_rays * 512 / du, "unit": "evaluated samples/s", "cores": n_thr, "host_cores": cores, "ms_per_400x400_frame_extrapolated": du * (160000 / n_rays) * 1e3,
+                       "sample": f"{n_rays} rays x 512 uniform samples (1/{160000 // n_rays}) of a 400x400 frame ({du:.1f} s; pure-torch hash grid + SH + nn.Linear, fp32, {n_thr} torch threads)"}
+        finally:
+            renderer.raymarching, pge.GridEncoder, psh.SHEncoder = saved2
+            torch.set_num_threads(1)
+    one, allc = legs["1_thread"], legs["all_cores"]
     n = int(ref["rendered"].item())
-    rec = {"value": one["value"], "unit": "samples/s", "cores": 1, "kind": "port",
-           "sample": f"centre {args.cpu_crop}x{args.cpu_crop} crop of pose 0 of the {args.wl['H']}x{args.wl['W']} frame ({ro.shape[1]} rays, {n} rendered samples, "
-                     f"{one['seconds']:.1f} s; -m {args.model}, C oracle ops + torch CPU MLP, 1 thread; host has {cores} cores)",
-           "all_cores": legs["all_cores"], "uniform_path_config0": uniform}
+    what = (f"centre {args.cpu_crop}x{args.cpu_crop} crop of pose 0 of the {args.wl['H']}x{args.wl['W']} frame ({ro.shape[1]} rays, {n} rendered samples; -m {args.model}, "
+            "C oracle ops + torch CPU MLP")
+    rec = {"value": allc["value"], "unit": "samples/s", "cores": allc["cores"], "host_cores": cores, "kind": "port",
+           "sample": what + f", {allc['seconds']:.1f} s on {allc['cores']} OpenMP threads + {allc['torch_threads']} torch threads of a {cores}-core host)",
+           "one_thread": {"value": one["value"], "unit": "samples/s", "cores": 1, "seconds": one["seconds"], "sample": what + ", 1 thread)"},
+           "all_cores_max_abs_rgb_vs_1_thread": allc.get("max_abs_rgb_vs_1_thread"), "uniform_path_config0": uniform}
     return rec, ref
 
 
@@ -312,16 +341,20 @@ def timed_frames(m, bank, kw, steps, fp16, first_step=0):
         bank.get(first_step + i)
     torch.cuda.synchronize()
     gc.collect()
+    gc_was_on = gc.isenabled()
     gc.disable()      # see main(): no interpreter GC pass inside a timed region
-    t0 = time.perf_counter()
-    for i in range(steps):
-        ro, rd = bank.get(first_step + i)
-        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=fp16):
-            r = m.render(ro, rd, **kw)
-        rendered += int(r["rendered"].sum())
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    gc.enable()
+    try:
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ro, rd = bank.get(first_step + i)
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=fp16):
+                r = m.render(ro, rd, **kw)
+            rendered += int(r["rendered"].sum())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        if gc_was_on:
+            gc.enable()
     return dt / steps * 1e3, rendered // steps
 
 
@@ -468,6 +501,175 @@ def occupancy_leg(device):
     return out
 
 
+MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak (the 5 PF headline includes 2:1 sparsity)
+NERF_FLOP_PER_SAMPLE = 18688.0      # 9 344 MAC
+PALETTE_FLOP_PER_SAMPLE = 36094.0   # 18 047 MAC (nb = 4, no clip head)
+CLOCK_GHZ = 2.4             # MI355X_MICROARCH.md: peak engine clock
+
+
+def mfma_leg(m, model_kind, rows, device, precision, reps=30):
+    """north_star: "MFMA utilisation ... against gfx950 peak".  The fused field kernel -- the path's only MFMA stage -- launched alone on `rows`
+    rows (the headline's average live rows per launch) of seeded encoder features, HIP events on the launch stream; useful FLOP = the
+    reference's MAC count of the layers x 2, issued FLOP = useful x 3 for the split-fp16 form (three matrix products per layer)."""
+    import ctypes
+    import torch
+    from palettenerf_amd import _lib
+    lib = _lib.load()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    f = m._fused
+    prec = {"fp32": 0, "f16x3": 1, "f16x2": 2}[precision]
+    g = torch.Generator().manual_seed(0)
+    B = int(rows)
+    enc = [((torch.rand(16, B, 2, generator=g) - 0.5) * 0.4).to(device) for _ in range(2)]
+    d = torch.randn(B, 3, generator=g)
+    d = (d / d.norm(dim=1, keepdim=True)).to(device)
+    sig, rgb = torch.empty(B, device=device), torch.empty(B, 3, device=device)
+    blob = f._pack(prec)
+    if model_kind == "nerf":
+        name, flop = "k_nerf_field_fwd (pnr_nerf_field_forward)", NERF_FLOP_PER_SAMPLE
+        fn = lambda: lib.pnr_nerf_field_forward(enc[0].data_ptr(), d.data_ptr(), blob.data_ptr(), B, sig.data_ptr(), rgb.data_ptr(), prec, ctypes.c_float(1.0), stream)
+    else:
+        name, flop = "k_palette_field_fwd (pnr_palette_field_forward)", PALETTE_FLOP_PER_SAMPLE
+        aux = torch.empty(B, f.aux_channels, device=device)
+        a = _lib.PaletteFieldArgs()
+        a.ctl, a.B, a.level_stride = None, B, B
+        a.enc, a.enc_palette, a.enc_clip = enc[0].data_ptr(), enc[1].data_ptr(), None
+        a.dirs, a.deltas, a.packed = d.data_ptr(), None, blob.data_ptr()
+        a.num_basis, a.clip_dim, a.pred_clip = f.nb, f.clip_dim, int(f.pred_clip)
+        a.density_scale, a.offsets_weight, a.view_dep_weight, a.aux_stride = 1.0, 1.0, 1.0, f.aux_channels
+        a.sigmas, a.rgbs, a.aux, a.precision = sig.data_ptr(), rgb.data_ptr(), aux.data_ptr(), prec
+        fn = lambda: lib.pnr_palette_field_forward(ctypes.byref(a), stream)
+    for _ in range(3):
+        if fn() != 0:
+            raise RuntimeError("field kernel launch failed")
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    torch.cuda.synchronize()
+    ev[0].record()
+    for i in range(reps):
+        fn()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    t = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))
+    ms = t[len(t) // 2]
+    useful = B * flop / (ms * 1e-3) / 1e12
+    products = {0: 1, 1: 3, 2: 3}[prec]     # f16x2 rounds the colour layers' activations once (2 products there): counted as 3, an upper bound of what is issued
+    rec = {"bound": "mfma", "kernel": name, "rows": B, "avg_launch_ms": ms, "flop_per_sample": flop, "achieved": useful, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": useful / MFMA_PEAK_TFLOPS, "matrix_products_per_layer": products, "issued_frac": useful * products / MFMA_PEAK_TFLOPS if prec else None,
+           "precision": precision,
+           "note": ("stand-alone launches of the fused field kernel on the headline's average live rows per launch; useful FLOP = 2 x the reference layers' MACs; "
+                    + ("issued = useful x 3 split-fp16 products on v_mfma_f32_32x32x16_f16 against the dense fp16 peak" if prec else
+                       "exact-fp32 path on v_mfma_f32_32x32x2_f32: priced against the fp16 peak for comparison only (the fp32 matrix peak is 1/16 of it)"))}
+    return rec
+
+
+def l2_bound_of(samples_per_launch, n_tables_rows, launch_ms):
+    """The lookup kernel's other bound: divergent lane-requests per clock per CU.  Every (sample, level) issues 8 row gathers; the
+    ceilings are profiles/micro/gather_rate.hip's (every lane a random row, 8 loads in flight per lane): 0.43 per clock per CU over an
+    L2-resident 4 MB table, 0.106 over the whole 50 MB table (constants measured in round 2, not re-measured in this run)."""
+    reqs = samples_per_launch * 16 * 8 * n_tables_rows
+    per_clk_cu = reqs / (launch_ms * 1e-3) / (CLOCK_GHZ * 1e9) / 256.0
+    return {"lane_requests_per_launch": reqs, "lane_requests_per_clk_per_cu": per_clk_cu, "clock_ghz_assumed": CLOCK_GHZ,
+            "random_row_ceiling_l2_resident": 0.43, "random_row_ceiling_50mb_table": 0.106,
+            "ratio_to_l2_resident_random_ceiling": per_clk_cu / 0.43,
+            "note": "rows gathered per clock per CU; above the random-row ceilings because neighbouring lanes share 128-byte lines (8x8-pixel wave tiles, level-major launch); "
+                    "ceilings from profiles/micro/gather_rate.hip (committed microbenchmark, not re-run here)"}
+
+
+def measure_traffic(argv_core, kernel_substr="k_frame_grid", timeout=240):
+    """roofline.traffic measured in THIS run: two child passes of this script's headline workload under `rocprofv3 --pmc <counter> --kernel-trace`
+    (FETCH_SIZE and WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md, PMC slots), 2 + 3 frames each; HBM-side bytes per lookup launch =
+    2 x FETCH_SIZE + WRITE_SIZE KiB (the guide's gfx950 correction: FETCH_SIZE reports half the bytes of a coalesced read), mean over the
+    launches that did work.  Children are started as separate processes (never exec'd from this one).  Returns (bytes or None, info)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None, {"error": "rocprofv3 not found"}
+    if any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+        return None, {"error": "already running under a profiler"}
+    vals, info = {}, {}
+    tmp = tempfile.mkdtemp(prefix="pnr_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, counter)
+            cmd = [rp, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out_dir, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   *argv_core, "--steps", "3", "--warmup", "2", "--no-extras", "--no-cpu-baseline", "--no-traffic"]
+            t0 = time.perf_counter()
+            try:
+                pr = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+            except subprocess.TimeoutExpired:
+                return None, {"error": f"{counter} pass timed out after {timeout} s"}
+            info[counter.lower() + "_pass_seconds"] = time.perf_counter() - t0
+            files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True)
+            if pr.returncode != 0 or not files:
+                return None, {"error": f"{counter} pass failed (rc {pr.returncode})", "tail": pr.stdout.decode(errors="replace")[-400:]}
+            rows = [r for r in csv.DictReader(open(files[0])) if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            if not rows:
+                return None, {"error": f"no {kernel_substr} dispatches in the {counter} pass"}
+            dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+            keep = [i for i, d in enumerate(dur) if d > max(dur) / 4]
+            vals[counter] = sum(float(rows[i]["Counter_Value"]) for i in keep) / len(keep)
+            info[counter.lower() + "_kib_per_launch"] = vals[counter]
+            info["launches_counted"] = len(keep)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    info["formula"] = "(2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a coalesced read's bytes)"
+    return (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, info
+
+
+def dropin_leg(args, device, bank, model_kind, steps):
+    """The operator-API path under the reference's own loop (north_star: "nerf/renderer.py and palette/renderer.py drop in unchanged"): this
+    repository's mirror of run_cuda in its `compat` mode issues exactly what an unchanged run_cuda issues -- march_rays / GridEncoder /
+    SHEncoder / composite_rays[_flex] through the per-op HIP kernels behind the reference's Python signatures, torch nn.Linear MLPs, the
+    boolean-mask compaction with its host sync (nerf/renderer.py:354-380, palette/renderer.py:430-550).  No fused field, no device loop."""
+    import torch
+    from palettenerf_amd import _torch_glue
+    cargs = argparse.Namespace(**vars(args))
+    cargs.mode, cargs.fp16, cargs.half_tables = "compat", False, False
+    mm = build_model(cargs, device, model_kind)
+    kk = dict(perturb=False, dt_gamma=args.wl["dt_gamma"], max_steps=1024, T_thresh=1e-4)
+    if model_kind == "palette":
+        kk["gui_mode"] = False
+    timed_frames(mm, bank, kk, 2, False)
+    ms, rend = timed_frames(mm, bank, kk, steps, False, first_step=args.warmup)
+    rec = {"ms_per_step": ms, "value": rend / (ms * 1e-3), "unit": "samples/s", "rendered_per_step": rend, "steps": steps, "march_mode": "compat",
+           "what": f"-m {model_kind} inference, {args.wl['H']}x{args.wl['W']}: per-op HIP kernels behind the reference's operator API + torch nn.Linear MLPs, the reference's loop "
+                   "(host-side boolean-mask compaction, one sync per iteration)"}
+    # the stand-alone lookup op inside this loop: HIP events around every pnr_grid_encode_forward* call of one frame (rows include dead / padded slots)
+    names = ["pnr_grid_encode_forward", "pnr_grid_encode_forward_layout"]
+    prof = _torch_glue.profile_kernels(names)
+    ro, rd = bank.get(args.warmup)
+    with torch.no_grad():
+        mm.render(ro, rd, **kk)
+    torch.cuda.synchronize()
+    _torch_glue.profile_kernels(None)
+    ev = [e for n in names for e in prof[n]]
+    if ev:
+        k_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in ev)
+        rows = sum(u for _, _, u in ev)
+        rec["lookup_op"] = {"kernel": "k_grid_fwd_d3c2 (pnr_grid_encode_forward)", "launches": len(ev), "avg_launch_ms": k_ms / len(ev), "rows_per_launch": rows / len(ev),
+                            "achieved_gbs_evaluated_rows": rows * GRID_BYTES_PER_SAMPLE_FP32 / (k_ms * 1e-3) / 1e9,
+                            "frac_evaluated_rows": rows * GRID_BYTES_PER_SAMPLE_FP32 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "note": "rows = every row the loop hands the encoder (dead slots and the 128-row alignment padding included: their gathers all hit one cell); events around the call"}
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CUDA]) as tp:
+            with torch.no_grad():
+                mm.render(ro, rd, **kk)
+            torch.cuda.synchronize()
+        kernels = [e for e in tp.events() if e.device_type == torch.autograd.DeviceType.CUDA and "memcpy" not in e.name.lower() and "memset" not in e.name.lower()]
+        hip = [e for e in kernels if "pnr::" in e.name[:16]]
+        rec.update(launches_per_frame=len(kernels), launches_hip_per_frame=len(hip), kernel_ms_per_frame=sum(e.device_time for e in kernels) / 1e3,
+                   kernel_ms_hip_per_frame=sum(e.device_time for e in hip) / 1e3)
+    except Exception as e:   # noqa: BLE001 -- reported, the wall figure stands
+        rec["profiler_error"] = repr(e)
+    del mm
+    return rec
+
+
 def strong_leg(args, m, kw, device, world, rank, steps):
     """The north-star's N > 1 question next to the weak-scaling headline: ONE frame's rays split over the ranks (32 x 32 tiles round-robin),
     every rank renders its share, one all-gather assembles the frame on every rank.  Returns ms per frame (max over ranks, gathers
@@ -479,11 +681,28 @@ def strong_leg(args, m, kw, device, world, rank, steps):
     H, W = args.wl["H"], args.wl["W"]
     nb = int(getattr(m, "num_basis", 0))
     K = 5 if args.model == "nerf" else 8 + 4 * nb
-    idx, _ = pdist.shard_indices(H, W, rank, world)
-    bank = RayBank(args, 1, idx, device)
     saved = getattr(m._fused, "ray_order", None)
-    m._fused.ray_order = tile_ray_order(idx, W, 8).to(device)
-    g = pdist.FrameGatherer(H, W, K, device)
+
+    def agree(ok):
+        """All ranks leave the leg together or none does: a rank that failed locally must not walk on to later collectives while the others
+        still sit in this leg's (the job would hang until the RCCL timeout).  One all_reduce of an error flag on the control path."""
+        flag = torch.tensor([0 if ok else 1], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return int(flag.item()) == 0
+
+    err = None
+    try:   # set-up: allocations that can fail on one rank only
+        idx, _ = pdist.shard_indices(H, W, rank, world)
+        bank = RayBank(args, 1, idx, device)
+        m._fused.ray_order = tile_ray_order(idx, W, 8).to(device)
+        g = pdist.FrameGatherer(H, W, K, device)
+        for i in range(min(steps + 3, bank.n_steps)):
+            bank.get(i)
+    except RuntimeError as e:
+        err = e
+    if not agree(err is None):
+        m._fused.ray_order = saved
+        raise RuntimeError(f"strong leg skipped on every rank: set-up failed on {'this' if err is not None else 'another'} rank" + (f" ({err})" if err is not None else ""))
 
     def run(n, first, blocking):
         pending, rendered = None, 0
@@ -505,8 +724,8 @@ def strong_leg(args, m, kw, device, world, rank, steps):
 
     out = {}
     try:
-        for i in range(min(steps + 3, bank.n_steps)):
-            bank.get(i)
+        # past this point every rank is inside the same sequence of collectives: a failure here is re-raised by main() (the launcher tears the
+        # job down) instead of being swallowed on one rank
         run(3, 0, False)
         for name, blocking in (("pipelined", False), ("blocking_gather", True)):
             torch.cuda.synchronize()
@@ -602,7 +821,8 @@ def main(argv=None):
             gatherer.finish(pending.pop())
         dist.barrier()
     torch.cuda.synchronize()
-    prof = _torch_glue.profile_kernels(["pnr_grid_encode_forward"]) if rank == 0 else None
+    GRID_OPS = ["pnr_grid_encode_forward", "pnr_grid_encode_forward_layout"]
+    prof = _torch_glue.profile_kernels(GRID_OPS) if rank == 0 else None
     rendered = torch.zeros(1, dtype=torch.int64, device=device)
     rendered_host, rows, looks, iterations = 0, 0, 0, 0
     native_ms, native_launches, native_live = 0.0, 0, 0
@@ -707,23 +927,19 @@ def main(argv=None):
         if half_rows:
             per_sample = 12 + 16 * 8 * 2 * 2 + 32 * 4   # half rows gathered, fp32 encoder output written
         n_tables = 1 if args.model == "nerf" else (3 if args.pred_clip else 2)  # palette: encoder + encoder_palette (+ encoder_clip with --pred-clip)
-        launches = prof["pnr_grid_encode_forward"]
+        launches = [e for n in GRID_OPS for e in prof[n]]
         k_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in launches)
         k_units = sum(u for _, _, u in launches)
         n_launches = len(launches)
-        kernel_name = "k_grid_fwd (pnr_grid_encode_forward)"
+        kernel_name = "k_grid_fwd_d3c2 (pnr_grid_encode_forward)"
         if native:  # events recorded inside pnr_*_render_frame around every grid launch of the first timed step; LIVE samples (delta > 0), dead slots are skipped by the kernel
             k_ms, k_units, n_launches = native_ms, native_live * n_tables, native_launches
             kernel_name = "k_frame_grid (device-driven frame loop)" if args.model == "nerf" else "k_frame_grid_pair/_triple (device-driven frame loop, tables interleaved)"
         achieved = (k_units * per_sample) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic = None  # HBM-side bytes per launch from the committed PMC passes of this workload (profiles/r02_traffic.json; regenerate with profiles/pmc_pass.sh)
-        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
-        if not os.path.exists(tpath):
-            tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
-        if native and args.density_scale == 100.0 and not args.fp16 and not args.half_tables and world == 1 and os.path.exists(tpath):
-            tr = json.load(open(tpath)).get(args.workload if args.res == 800 else "")
-            if tr:
-                traffic = tr["traffic_bytes_per_launch"]
+        # HBM-side bytes per lookup launch, MEASURED IN THIS RUN: two child passes of the same workload under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE)
+        traffic, traffic_info = None, None
+        if native and world == 1 and not use_dist and not args.no_traffic and F_main == 1:
+            traffic, traffic_info = measure_traffic(core_argv(args))
         field_note = {"f16x3": "field: f16x3 split products, fp32 accumulate", "f16x2": "field: f16x3 for sigma_net, colour layers with activations rounded once to f16", "fp32": "field: exact fp32 MFMA"}[args.field_precision]
         dtype_label = ("f16 tables + autocast" if args.fp16 else "f32") + (f" ({field_note})" if getattr(m, "fused_field", False) else "")
         raw_steps = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
@@ -744,12 +960,18 @@ def main(argv=None):
                        "parallelism": f"32x32 ray tiles of {n_views} view(s) round-robin over {world} GPUs + one all_gather/step" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": (os.path.relpath(tpath, ROOT) + " (PMC passes of this command, not measured in this run)") if traffic is not None else None,
+                         "traffic_source": traffic_info,
                          "launches": n_launches,
                          "avg_launch_ms": k_ms / max(1, n_launches), "avg_live_samples_per_launch": k_units / max(1, n_launches) / (n_tables if native else 1),
                          "algorithmic_bytes_per_sample": per_sample * (n_tables if native else 1),
                          "algorithmic_bytes_per_launch": per_sample * k_units / max(1, n_launches)},
         }
+        if native and k_ms > 0 and n_launches > 0:
+            out["roofline"]["l2_bound"] = l2_bound_of(k_units / n_launches / n_tables, 1, k_ms / n_launches)
+            try:    # north_star: MFMA utilisation of the fused field kernel against the gfx950 peak
+                out["roofline"]["mfma"] = mfma_leg(m, args.model, max(1024, int(k_units / n_launches / n_tables)), device, args.field_precision)
+            except RuntimeError as e:
+                out["roofline"]["mfma_error"] = str(e)
         if native and not os.environ.get("PNR_NO_HOSTED_TAIL"):
             # The timed lookup launches also finish the march's stragglers (frame.hip: hosted_march_tail): their duration is the lookup's plus what
             # the hosted waves cost it.  The same frame once more with the tail switched off gives the lookup kernel on its own.
@@ -787,6 +1009,8 @@ def main(argv=None):
             if rank == 0:
                 extra["strong"] = strong
         except RuntimeError as e:
+            if "skipped on every rank" not in str(e):
+                raise      # a failure in the middle of the leg's collectives: the other ranks are still inside them -- tear the job down
             if rank == 0:
                 extra["strong_error"] = str(e)
     crop_ref = None   # (rays_o, rays_d, oracle results) of the parity crop, for the extra legs
@@ -870,12 +1094,16 @@ def main(argv=None):
                     fif.render(lambda i: bank.get(i), 2 * F, consume=lambda i, r: 0, **kw)   # every handle: workspace, packed weights, iteration prediction
                     torch.cuda.synchronize()
                     gc.collect()
+                    gc_was_on = gc.isenabled()
                     gc.disable()
-                    t0 = time.perf_counter()
-                    counts = fif.render(rays_of, n, consume=consume, **kw)
-                    torch.cuda.synchronize()
-                    dt = time.perf_counter() - t0
-                    gc.enable()
+                    try:
+                        t0 = time.perf_counter()
+                        counts = fif.render(rays_of, n, consume=consume, **kw)
+                        torch.cuda.synchronize()
+                        dt = time.perf_counter() - t0
+                    finally:
+                        if gc_was_on:
+                            gc.enable()
                     lat = sorted(t_done[i] - t_sub[i] for i in range(n))
                     legs[str(F)] = {"value": sum(counts) / dt, "unit": "samples/s", "ms_per_step": dt / n * 1e3, "steps": n,
                                     "frame_latency_ms_median": lat[n // 2] * 1e3}
@@ -901,6 +1129,26 @@ def main(argv=None):
         # --- round 3 legs: the reference's -O mode, a long run, configs[4] split 8 ways (emulated), configs[3] training steps, the occupancy sweep
         if not args.no_extras and native and args.workload == "lego" and not args.fp16 and F_main == 1:
             n = max(1, args.extra_steps)
+            # --- round 4: the operator-API (drop-in) path on the driver's record: configs[1] and configs[2] under the reference's own loop
+            dropin = {}
+            for kind in ("nerf", "palette"):
+                try:
+                    dropin[kind] = dropin_leg(args, device, bank, kind, max(5, n // 2))
+                except RuntimeError as e:
+                    dropin[kind] = {"error": str(e)}
+            extra["dropin"] = dropin
+            try:     # SURVEY Appendix B's other regime: the translucent field (density_scale 0.02): every ray marches to `far`, ~63 M samples per frame
+                targs = argparse.Namespace(**vars(args))
+                targs.density_scale = 0.02
+                tm = build_model(targs, device, "nerf")
+                tm._fused.ray_order = m._fused.ray_order
+                timed_frames(tm, bank, kw, 2, False)
+                t_ms, t_rend = timed_frames(tm, bank, kw, max(3, n // 4), False, first_step=args.warmup)
+                extra["translucent"] = {"ms_per_step": t_ms, "rendered_per_step": t_rend, "value": t_rend / (t_ms * 1e-3), "unit": "samples/s", "density_scale": 0.02,
+                                        "steps": max(3, n // 4), "what": "configs[1] frame with the translucent field of SURVEY Appendix B (no early termination: every ray to `far`)"}
+                del tm
+            except RuntimeError as e:
+                extra["translucent_error"] = str(e)
             try:     # `-O` = fp16 autocast + half tables (main_nerf.py:72-75): what every script of the reference runs
                 fargs = argparse.Namespace(**vars(args))
                 fargs.fp16 = True
@@ -916,18 +1164,22 @@ def main(argv=None):
                 evs = [torch.cuda.Event(enable_timing=True) for _ in range(L + 1)]
                 import gc
                 gc.collect()
+                gc_was_on = gc.isenabled()
                 gc.disable()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                evs[0].record()
-                for i in range(L):
-                    ro, rd = bank.get(args.warmup + i)
-                    with torch.no_grad():
-                        m.render(ro, rd, **kw)
-                    evs[i + 1].record()
-                torch.cuda.synchronize()
-                wall = time.perf_counter() - t0
-                gc.enable()
+                try:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    evs[0].record()
+                    for i in range(L):
+                        ro, rd = bank.get(args.warmup + i)
+                        with torch.no_grad():
+                            m.render(ro, rd, **kw)
+                        evs[i + 1].record()
+                    torch.cuda.synchronize()
+                    wall = time.perf_counter() - t0
+                finally:
+                    if gc_was_on:      # (main() re-enabled it after the timed region; the legs that follow run under the state they found)
+                        gc.enable()
                 ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(L))
                 extra["long_run"] = {"steps": L, "seconds": wall, "ms_per_step": wall / L * 1e3, "step_ms": {"min": ms[0], "p05": ms[L // 20], "median": ms[L // 2], "p95": ms[L - L // 20], "max": ms[-1]}}
             except RuntimeError as e:
@@ -955,6 +1207,11 @@ def main(argv=None):
                 extra["garden_shard_emulation_8"] = {"full_frame_ms": full_ms, "full_frame_samples": full_rend, "shard_ms": times, "shard_samples": samples,
                                                      "max_shard_ms": max(times), "imbalance_max_over_mean": max(times) / (sum(times) / 8),
                                                      "speedup_before_all_gather": full_ms / max(times),
+                                                     # what the all-gather would add on 8 GPUs (an ESTIMATE from SURVEY 8e's link figure, not a measurement: this box has one GPU):
+                                                     # every rank's packed rows go to its 7 peers over 7 xGMI links concurrently, ~153 GB/s per link
+                                                     "all_gather_estimate": {k: {"floats_per_ray": K_, "bytes_per_rank": int(gH * gW / 8 * K_ * 4), "ms_at_153GBs_per_link": gH * gW / 8 * K_ * 4 / 153e9 * 1e3,
+                                                                                 "speedup_with_it": full_ms / (max(times) + gH * gW / 8 * K_ * 4 / 153e9 * 1e3)}
+                                                                             for k, K_ in (("video_rows_K24", 24), ("full_palette_output_set_K55", 55))},
                                                      "what": f"configs[4]: one {gH}x{gW} PaletteNeRF garden frame, its 8 interleaved-tile shards rendered one after another on this GPU"}
                 del gm
             except RuntimeError as e:

@@ -144,6 +144,14 @@ int pnr_march_rays_mip(uint32_t n_alive, uint32_t n_step, const int32_t* rays_al
                        uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
                        float* xyzs, float* dirs, float* deltas, const float* noises, const void* mip,
                        pnr_stream_t stream);
+/* The same march for buffers that arrive UNINITIALISED (the reference's Python zero-fills xyzs / dirs / deltas with three launches before every
+ * call, raymarching.py:384-386): with fill_rows = the row count of the three buffers (>= n_alive * n_step; the alignment padding included) the
+ * kernel itself zeroes every slot a ray leaves unfilled and the rows beyond n_alive * n_step.  fill_rows = 0: pnr_march_rays_mip. */
+int pnr_march_rays_fill(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                       const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                       uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
+                       float* xyzs, float* dirs, float* deltas, const float* noises, const void* mip, uint32_t fill_rows,
+                       pnr_stream_t stream);
 int pnr_march_rays_train_mip(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
                              float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                              const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
@@ -225,6 +233,14 @@ int pnr_compact_alive(uint32_t n_alive, const int32_t* rays_alive_in, int32_t* r
 int pnr_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
                             uint32_t gridtype, int align_corners, int dtype, pnr_stream_t stream);
+/* MI355X-first addition: the same lookup with the output layout chosen by the caller.  PNR_LAYOUT_LEVELS = [L,B,C] (the reference kernel's,
+ * gridencoder.cu:119); PNR_LAYOUT_ROWS = [B, L*C], what GridEncoder.forward returns after its permute-copy (gridencoder/grid.py:57) -- written
+ * directly, same values.  PNR_LAYOUT_ROWS exists for D = 3, C = 2 without dy_dx (every shipped configuration); PNR_ERR_UNSUPPORTED otherwise. */
+#define PNR_LAYOUT_LEVELS 0
+#define PNR_LAYOUT_ROWS 1
+int pnr_grid_encode_forward_layout(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                                   uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
+                                   uint32_t gridtype, int align_corners, int dtype, int layout, pnr_stream_t stream);
 /* replaces grid_encode_backward, gridencoder.h:13, gridencoder.cu:449-479.
  * grad is [L,B,C]; grad_embeddings caller-zeroed; dy_dx/grad_inputs may both be NULL. */
 int pnr_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,

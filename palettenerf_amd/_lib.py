@@ -34,10 +34,12 @@ SIGNATURES = {
     "pnr_occupancy_mip_bytes": [_u32, _u32],
     "pnr_build_occupancy_mip": [_ptr, _u32, _u32, _f32, _ptr, _ptr],
     "pnr_march_rays_mip": [_u32, _u32, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "pnr_march_rays_fill": [_u32, _u32, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u32, _ptr],
     "pnr_march_rays_train_mip": [_ptr, _ptr, _ptr, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                                  _ptr, _ptr, _ptr, _ptr, _ptr],
     "pnr_compact_alive": [_u32, _ptr, _ptr, _ptr, _ptr, _ptr],
     "pnr_grid_encode_forward": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _u32, _ptr, _u32, _int, _int, _ptr],
+    "pnr_grid_encode_forward_layout": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _u32, _ptr, _u32, _int, _int, _int, _ptr],
     "pnr_grid_encode_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _u32, _ptr, _ptr, _u32, _int, _int, _ptr],
     "pnr_nerf_field_packed_bytes": [],
     "pnr_nerf_field_pack": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _int, _ptr],

@@ -10,6 +10,7 @@
 // <= 4 MiB table stays resident in the XCD L2s while the samples stream through).
 #include "pnr_common.hpp"
 #include "grid_core.hpp"
+#include <type_traits>
 
 namespace pnr {
 
@@ -121,6 +122,110 @@ __global__ void __launch_bounds__(256) k_grid_fwd(const float* __restrict__ inpu
                 else dd[gd * C + ch] = __float2half(ga[ch]);
             }
         }
+    }
+}
+
+// The lookup every shipped configuration issues (D = 3, C = 2, no dy_dx; fp32 or fp16 table): the same cell, corner order and fmaf / half
+// chains as k_grid_fwd<T, 3, 2> above -- bit for bit -- with what the frame loop's lookup (frame.hip: grid_row / gather8) found:
+//   * all eight row addresses exist before the first load and every load returns into registers of its own (load8_fresh);
+//   * the finest levels -- scattered rows, five times the time of a dense level -- are dispatched first (blockIdx.y = 0 is level L-1),
+//     the dense ones fill the launch's tail;
+//   * the row index is formed for the kind of level the block works on (block-uniform): dense (the index is below the level's size, no
+//     modulo), hashed with a power-of-two size (a mask), anything else (the reference's `%`);
+//   * ROWMAJOR: the sample-major [B, L*C] row GridEncoder.forward returns (gridencoder/grid.py:57) is written here, 8 bytes per (sample,
+//     level) -- the reference and k_grid_fwd write [L, B, C] and leave the permute-copy to the caller.
+template <typename T, bool ROWMAJOR, int NT = 0>   // NT (experiment knob, pnr_set_option "grid_nt"): bit 0 = non-temporal output stores, bit 1 = non-temporal input loads
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8)))
+k_grid_fwd_d3c2(const float* __restrict__ inputs, const T* __restrict__ grid, const int32_t* __restrict__ offsets, T* __restrict__ outputs, uint32_t B,
+                uint32_t L, LevelParams lp, uint32_t gridtype, bool align_corners) {
+    typedef typename std::conditional<sizeof(T) == 4, f32x2, uint32_t>::type RowT;   // one table row: float2 or half2
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t level = L - 1u - blockIdx.y;
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    const float scale = lp.scale[level];
+    const uint32_t resolution = lp.resolution[level];
+    const RowT* tab = reinterpret_cast<const RowT*>(grid) + off0;
+    RowT* out = reinterpret_cast<RowT*>(outputs) + (ROWMAJOR ? (size_t)b * L + level : (size_t)level * B + b);
+
+    float in[3];
+    bool oob = false;
+#pragma unroll
+    for (uint32_t d = 0; d < 3; d++) {
+        in[d] = (NT & 2) ? __builtin_nontemporal_load(inputs + (size_t)b * 3 + d) : inputs[(size_t)b * 3 + d];
+        oob |= (in[d] < 0.0f) | (in[d] > 1.0f);
+    }
+    if (oob) {
+        if constexpr (sizeof(T) == 4) *out = RowT{0.0f, 0.0f}; else *out = 0u;
+        return;
+    }
+    float pos[3];
+    uint32_t pg[3];
+#pragma unroll
+    for (uint32_t d = 0; d < 3; d++) {
+        pos[d] = fmaf(in[d], scale, align_corners ? 0.0f : 0.5f);
+        const float fl = floorf(pos[d]);
+        pg[d] = (uint32_t)fl;
+        pos[d] -= (float)pg[d];
+    }
+    // get_grid_index (gridencoder.cu:49-72) per kind of level; all three forms give the generic form's index
+    const uint32_t side = align_corners ? resolution : resolution + 1u;
+    // the reference multiplies a uint32 stride up dimension by dimension while it is <= hashmap_size and hashes iff it ends up larger
+    uint32_t stride = 1u;
+#pragma unroll
+    for (uint32_t d = 0; d < 3; d++)
+        if (stride <= hashmap_size) stride *= side;
+    const bool hashed = gridtype == 0u && stride > hashmap_size;
+    const bool dense = (uint64_t)side * side * side <= (uint64_t)hashmap_size;   // (64-bit: implies every per-dimension test above and no uint32 wrap)
+    uint32_t idxs[8];
+    if (dense) {                                                       // index < side^3 <= size: the reference's `%` is the identity
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++)
+            idxs[i] = (pg[0] + (i & 1u)) + (pg[1] + ((i >> 1) & 1u)) * side + (pg[2] + ((i >> 2) & 1u)) * side * side;
+    } else if (hashed && (hashmap_size & (hashmap_size - 1u)) == 0u) {   // hashed, power-of-two size
+        const uint32_t mask = hashmap_size - 1u;
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++)
+            idxs[i] = ((pg[0] + (i & 1u)) ^ ((pg[1] + ((i >> 1) & 1u)) * 2654435761u) ^ ((pg[2] + ((i >> 2) & 1u)) * 805459861u)) & mask;
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++) {
+            const uint32_t pl[3] = {pg[0] + (i & 1u), pg[1] + ((i >> 1) & 1u), pg[2] + ((i >> 2) & 1u)};
+            idxs[i] = grid_index<3, 1>(gridtype, align_corners, hashmap_size, resolution, pl);
+        }
+    }
+    const RowT* p[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) p[i] = tab + idxs[i];
+    RowT v[8];
+    load8_fresh(p, v);
+    float ws[8];
+#pragma unroll
+    for (uint32_t i = 0; i < 8; i++) {   // the reference's order of multiplications (gridencoder.cu:150-163)
+        float w = 1.0f;
+#pragma unroll
+        for (uint32_t d = 0; d < 3; d++) w *= (i & (1u << d)) ? pos[d] : 1.0f - pos[d];
+        ws[i] = w;
+    }
+    if constexpr (sizeof(T) == 4) {
+        float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++) { a0 = fmaf(ws[i], v[i].x, a0); a1 = fmaf(ws[i], v[i].y, a1); }
+        if constexpr (NT & 1) __builtin_nontemporal_store(RowT{a0, a1}, out); else *out = RowT{a0, a1};
+    } else {
+        __half acc[2] = {__float2half(0.0f), __float2half(0.0f)};
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++) {
+            __half hv[2];
+            __builtin_memcpy(hv, &v[i], 4);
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++)   // corner_accumulate<__half>: addend and sum rounded to fp16
+                acc[ch] = __float2half(__half2float(acc[ch]) + __half2float(__float2half(ws[i] * __half2float(hv[ch]))));
+        }
+        uint32_t o;
+        __builtin_memcpy(&o, acc, 4);
+        *out = o;
     }
 }
 
@@ -264,7 +369,17 @@ static int launch_fwd_c(const float* inputs, const T* emb, const int32_t* offset
 }
 template <typename T>
 static int launch_fwd(const float* inputs, const T* emb, const int32_t* offsets, T* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
-                      const LevelParams& lp, T* dy_dx, uint32_t gridtype, bool ac, hipStream_t s) {
+                      const LevelParams& lp, T* dy_dx, uint32_t gridtype, bool ac, int layout, hipStream_t s) {
+    if (D == 3 && C == 2 && !dy_dx && g_opt_grid_fast) {
+        const dim3 grid(cdiv(B, 256), L), block(256);
+        if (layout == PNR_LAYOUT_ROWS) hipLaunchKernelGGL((k_grid_fwd_d3c2<T, true>), grid, block, 0, s, inputs, emb, offsets, outputs, B, L, lp, gridtype, ac);
+        else if (g_opt_grid_nt == 1) hipLaunchKernelGGL((k_grid_fwd_d3c2<T, false, 1>), grid, block, 0, s, inputs, emb, offsets, outputs, B, L, lp, gridtype, ac);
+        else if (g_opt_grid_nt == 2) hipLaunchKernelGGL((k_grid_fwd_d3c2<T, false, 2>), grid, block, 0, s, inputs, emb, offsets, outputs, B, L, lp, gridtype, ac);
+        else if (g_opt_grid_nt == 3) hipLaunchKernelGGL((k_grid_fwd_d3c2<T, false, 3>), grid, block, 0, s, inputs, emb, offsets, outputs, B, L, lp, gridtype, ac);
+        else hipLaunchKernelGGL((k_grid_fwd_d3c2<T, false>), grid, block, 0, s, inputs, emb, offsets, outputs, B, L, lp, gridtype, ac);
+        return check_launch();
+    }
+    if (layout != PNR_LAYOUT_LEVELS) return PNR_ERR_UNSUPPORTED;
     switch (D) {
         case 1: return launch_fwd_c<T, 1>(inputs, emb, offsets, outputs, B, C, L, lp, dy_dx, gridtype, ac, s);
         case 2: return launch_fwd_c<T, 2>(inputs, emb, offsets, outputs, B, C, L, lp, dy_dx, gridtype, ac, s);
@@ -322,6 +437,13 @@ extern "C" {
 int pnr_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B, uint32_t D,
                             uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx, uint32_t gridtype, int align_corners, int dtype,
                             pnr_stream_t stream) {
+    return pnr_grid_encode_forward_layout(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, dtype, PNR_LAYOUT_LEVELS, stream);
+}
+
+int pnr_grid_encode_forward_layout(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B, uint32_t D,
+                                   uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx, uint32_t gridtype, int align_corners, int dtype,
+                                   int layout, pnr_stream_t stream) {
+    if (layout != PNR_LAYOUT_LEVELS && layout != PNR_LAYOUT_ROWS) return PNR_ERR_INVALID;
     if (L == 0 || L > kMaxLevels) return PNR_ERR_UNSUPPORTED;
     if (dtype != PNR_DTYPE_F32 && dtype != PNR_DTYPE_F16) return PNR_ERR_UNSUPPORTED;
     if (B == 0) return PNR_OK;
@@ -329,9 +451,9 @@ int pnr_grid_encode_forward(const float* inputs, const void* embeddings, const i
     const LevelParams lp = make_level_params(L, S, H);
     if (dtype == PNR_DTYPE_F32)
         return launch_fwd<float>(inputs, static_cast<const float*>(embeddings), offsets, static_cast<float*>(outputs), B, D, C, L, lp,
-                                 static_cast<float*>(dy_dx), gridtype, align_corners != 0, as_stream(stream));
+                                 static_cast<float*>(dy_dx), gridtype, align_corners != 0, layout, as_stream(stream));
     return launch_fwd<__half>(inputs, static_cast<const __half*>(embeddings), offsets, static_cast<__half*>(outputs), B, D, C, L, lp,
-                              static_cast<__half*>(dy_dx), gridtype, align_corners != 0, as_stream(stream));
+                              static_cast<__half*>(dy_dx), gridtype, align_corners != 0, layout, as_stream(stream));
 }
 
 int pnr_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets, void* grad_embeddings,

@@ -324,8 +324,16 @@ __global__ void __launch_bounds__(kBlock) k_march_rays(
     uint32_t n_alive, uint32_t n_step, const int32_t* __restrict__ rays_alive, const float* __restrict__ rays_t,
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, MarchParams p, const uint8_t* __restrict__ grid,
     const float* __restrict__ fars, float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas,
-    const float* __restrict__ noises, const uint32_t* __restrict__ mip) {
+    const float* __restrict__ noises, const uint32_t* __restrict__ mip, uint32_t fill_rows) {
     const uint32_t* mip_lds = stage_mip(mip, MIP ? p.mip_words : 0);
+    // fill_rows != 0 (pnr_march_rays_fill): the buffers arrive uninitialised -- every slot a ray leaves unfilled and the alignment rows
+    // [n_alive * n_step, fill_rows) are zeroed here, so the caller's three zero-fill launches (raymarching.py:384-386) are not needed
+    if (fill_rows)
+        for (uint32_t r = n_alive * n_step + blockIdx.x * kBlock + threadIdx.x; r < fill_rows; r += gridDim.x * kBlock) {
+            xyzs[(size_t)r * 3] = 0.0f; xyzs[(size_t)r * 3 + 1] = 0.0f; xyzs[(size_t)r * 3 + 2] = 0.0f;
+            dirs[(size_t)r * 3] = 0.0f; dirs[(size_t)r * 3 + 1] = 0.0f; dirs[(size_t)r * 3 + 2] = 0.0f;
+            deltas[(size_t)r * 2] = 0.0f; deltas[(size_t)r * 2 + 1] = 0.0f;
+        }
     for (uint32_t n = blockIdx.x * kBlock + threadIdx.x; n < n_alive; n += gridDim.x * kBlock) {
         const int index = rays_alive[n];
         RayCtx c;
@@ -350,6 +358,11 @@ __global__ void __launch_bounds__(kBlock) k_march_rays(
                 px += 3; pd += 3; pl += 2; step++;
             }
         }
+        if (fill_rows)
+            for (; step < n_step; step++) {
+                px[0] = 0.0f; px[1] = 0.0f; px[2] = 0.0f; pd[0] = 0.0f; pd[1] = 0.0f; pd[2] = 0.0f; pl[0] = 0.0f; pl[1] = 0.0f;
+                px += 3; pd += 3; pl += 2;
+            }
     }
 }
 
@@ -494,6 +507,8 @@ int g_opt_composite_fusion = getenv("PNR_NO_COMPOSITE_FUSION") ? 0 : (getenv("PN
 int g_opt_iteration_margin = getenv("PNR_ITERATION_MARGIN") ? atoi(getenv("PNR_ITERATION_MARGIN")) : 0;   // measured 0 / 1 / 2 / 4 on the moving-camera bench: 4.239 / 4.247 / 4.277 / 4.265 ms -- a look costs less than a spare iteration
 int g_opt_palette_waves12 = getenv("PNR_PALETTE_WAVES8") ? 0 : 1;   // specialised PaletteNeRF field kernel: 12-wave workgroups (three waves per SIMD)
 int g_opt_dynamic_tiles = getenv("PNR_DYNAMIC_TILES") ? 1 : 0;   // measured: garden 14.6 -> 20.2 ms with it on (one contended counter, scattered tiles): off
+int g_opt_grid_fast = getenv("PNR_NO_GRID_FAST") ? 0 : 1;   // pnr_grid_encode_forward: the D = 3, C = 2 kernel (k_grid_fwd_d3c2) instead of the generic one (A/B; same bits)
+int g_opt_grid_nt = getenv("PNR_GRID_NT") ? atoi(getenv("PNR_GRID_NT")) : 0;   // experiment: non-temporal stores (1) / input loads (2) in k_grid_fwd_d3c2
 int g_opt_adam_variant = 0;   // experiment switch of adam.hip (which multiply-adds are contracted); 0 = torch's kernels on this platform
 
 using namespace pnr;
@@ -514,6 +529,8 @@ int pnr_set_option(const char* name, int value) {
     if (!strcmp(name, "composite_fusion")) { g_opt_composite_fusion = value < 0 ? 0 : (value > 2 ? 2 : value); return PNR_OK; }
     if (!strcmp(name, "palette_waves12")) { g_opt_palette_waves12 = value != 0; return PNR_OK; }
     if (!strcmp(name, "dynamic_tiles")) { g_opt_dynamic_tiles = value != 0; return PNR_OK; }
+    if (!strcmp(name, "grid_fast")) { g_opt_grid_fast = value != 0; return PNR_OK; }
+    if (!strcmp(name, "grid_nt")) { g_opt_grid_nt = value & 3; return PNR_OK; }
     if (!strcmp(name, "adam_variant")) { g_opt_adam_variant = value & 7; return PNR_OK; }
     if (!strcmp(name, "iteration_margin")) { g_opt_iteration_margin = value < 0 ? 0 : (value > 64 ? 64 : value); return PNR_OK; }
     return PNR_ERR_INVALID;
@@ -662,27 +679,36 @@ int pnr_march_rays_mip(uint32_t n_alive, uint32_t n_step, const int32_t* rays_al
                        const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid,
                        const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas, const float* noises, const void* mip,
                        pnr_stream_t stream) {
+    return pnr_march_rays_fill(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears, fars, xyzs, dirs, deltas, noises, mip, 0, stream);
+}
+
+int pnr_march_rays_fill(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t, const float* rays_o,
+                        const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid,
+                        const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas, const float* noises, const void* mip,
+                        uint32_t fill_rows, pnr_stream_t stream) {
     (void)nears;
-    if (n_alive == 0 || n_step == 0) return PNR_OK;
-    if (!rays_alive || !rays_t || !rays_o || !rays_d || !grid || !fars || !xyzs || !dirs || !deltas) return PNR_ERR_INVALID;
+    if (fill_rows != 0 && fill_rows < n_alive * n_step) return PNR_ERR_INVALID;
+    if ((n_alive == 0 || n_step == 0) && fill_rows == 0) return PNR_OK;
+    if (n_alive != 0 && (!rays_alive || !rays_t || !rays_o || !rays_d || !grid || !fars)) return PNR_ERR_INVALID;
+    if (!xyzs || !dirs || !deltas) return PNR_ERR_INVALID;
     if (C == 0 || C > 16 || H == 0 || max_steps == 0) return PNR_ERR_INVALID;
     const bool use_mip = mip_usable(mip, C, H);
     const bool pow2 = is_pow2f(bound) && (H & (H - 1)) == 0;
     const MarchParams p = make_march_params(bound, dt_gamma, max_steps, C, H, use_mip);
     const uint32_t lds = mip_lds_bytes(p);
-    const uint32_t nb = cdiv(n_alive, kBlock);
+    const uint32_t nb = cdiv(n_alive ? n_alive : 1u, kBlock);
     const uint32_t grid_dim = use_mip ? (nb < 2048u ? nb : 2048u) : nb;  // with the mip staged per workgroup, keep workgroups persistent
     const dim3 g(grid_dim), b(kBlock);
     hipStream_t s = as_stream(stream);
     const uint32_t* m = static_cast<const uint32_t*>(mip);
     if (use_mip && pow2)
-        hipLaunchKernelGGL((k_march_rays<true, true>), g, b, lds, s, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, p, grid, fars, xyzs, dirs, deltas, noises, m);
+        hipLaunchKernelGGL((k_march_rays<true, true>), g, b, lds, s, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, p, grid, fars, xyzs, dirs, deltas, noises, m, fill_rows);
     else if (use_mip)
-        hipLaunchKernelGGL((k_march_rays<true, false>), g, b, lds, s, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, p, grid, fars, xyzs, dirs, deltas, noises, m);
+        hipLaunchKernelGGL((k_march_rays<true, false>), g, b, lds, s, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, p, grid, fars, xyzs, dirs, deltas, noises, m, fill_rows);
     else if (pow2)
-        hipLaunchKernelGGL((k_march_rays<false, true>), g, b, lds, s, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, p, grid, fars, xyzs, dirs, deltas, noises, m);
+        hipLaunchKernelGGL((k_march_rays<false, true>), g, b, lds, s, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, p, grid, fars, xyzs, dirs, deltas, noises, m, fill_rows);
     else
-        hipLaunchKernelGGL((k_march_rays<false, false>), g, b, lds, s, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, p, grid, fars, xyzs, dirs, deltas, noises, m);
+        hipLaunchKernelGGL((k_march_rays<false, false>), g, b, lds, s, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, p, grid, fars, xyzs, dirs, deltas, noises, m, fill_rows);
     return check_launch();
 }
 

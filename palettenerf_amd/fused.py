@@ -53,7 +53,8 @@ def _pkey(p):
 def invalidate_fused_caches(model):
     """Forget every blob derived from the model's parameters (packed MFMA weights, interleaved / half tables, host-side parameter copies).
     Called by load_state_dict and initialize_palette; call it yourself after writing parameters through `.data` (EMA swap-in / restore:
-    nerf/utils.py:829-839, 959-961)."""
+    nerf/utils.py:829-839, 959-961).  Whole-tensor `.data` rewrites are also caught by the per-frame checksum (_SourceWatch); a write to only
+    PART of a hash table is not (tables are checksummed on every 1 021st word): after such a write this call is required."""
     for attr in ("_fused", "_density_fused"):
         f = getattr(model, attr, None)
         if f is not None:
@@ -167,7 +168,9 @@ class _SourceWatch:
     read-back) and compare with the checksums taken when the blobs were built; on a mismatch the blobs are rebuilt and the frame is rendered
     again.  When torch CAN tell (a key changed) every blob of the object is rebuilt in that frame and its checksums become the reference, so a
     `.data` write can never hide behind an unrelated version bump.  Tables are sampled (TABLE_CHECK_STRIDE): a swap or a re-initialisation
-    touches every row; PNR_PARANOID_CACHE=1 checks every word."""
+    touches every row and is caught.  LIMITATION: a `.data` write that touches only PART of a table (loading or pruning some levels, a partial
+    re-initialisation) will usually miss the sampled words and is NOT detected -- call invalidate_fused_caches(model) after such a write, or
+    run with PNR_PARANOID_CACHE=1, which checks every word."""
 
     def _watched(self):
         """[(tensor, stride in 4-byte words)]: everything a cached blob of this object is derived from."""

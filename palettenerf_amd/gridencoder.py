@@ -18,6 +18,8 @@ _u32, _f32, _int = ctypes.c_uint32, ctypes.c_float, ctypes.c_int
 _gridtype_to_id = {"hash": 0, "tiled": 1}
 _DTYPE_ID = {torch.float32: 0, torch.float16: 1}
 BINNED_MIN_ROWS = 32768   # batches from this size on use the bucket-binned table gradient
+ROW_LAYOUT = False        # True: [B, L*C] rows straight from the kernel (pnr_grid_encode_forward_layout; same values).  Measured SLOWER than [L, B, C] + permute-copy
+                          # (2^20 samples: 336 us against 176 + 70 us, profiles/r04_grid_op_bench.txt): 8-byte stores at a 128-byte stride are partial-line writes
 
 
 def level_offsets(input_dim, num_levels, per_level_scale, base_resolution, log2_hashmap_size, align_corners=False):
@@ -47,14 +49,17 @@ class _grid_encode(Function):
             raise RuntimeError("embeddings must be a float32 or float16 tensor")
         embeddings = embeddings.contiguous()
         table_dtype = embeddings.dtype
-        level_major = torch.empty(L, B, C, device=inputs.device, dtype=table_dtype)
         dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=table_dtype) if calc_grad_inputs else None
-        call("pnr_grid_encode_forward", ptr(require(inputs, torch.float32, "inputs")), ptr(require(embeddings, table_dtype, "embeddings")),
-             ptr(require(offsets, torch.int32, "offsets")), ptr(level_major), _u32(B), _u32(D), _u32(C), _u32(L), _f32(S), _u32(H), ptr(dy_dx),
-             _u32(gridtype), _int(int(align_corners)), _int(_DTYPE_ID[table_dtype]), units=B)
+        # D = 3, C = 2 without dy_dx (every shipped configuration): the kernel writes the [B, L*C] rows this function returns; otherwise the
+        # reference's [L, B, C] and its permute-copy (gridencoder/grid.py:41,57)
+        rows = ROW_LAYOUT and D == 3 and C == 2 and dy_dx is None
+        out = torch.empty((B, L * C) if rows else (L, B, C), device=inputs.device, dtype=table_dtype)
+        call("pnr_grid_encode_forward_layout", ptr(require(inputs, torch.float32, "inputs")), ptr(require(embeddings, table_dtype, "embeddings")),
+             ptr(require(offsets, torch.int32, "offsets")), ptr(out), _u32(B), _u32(D), _u32(C), _u32(L), _f32(S), _u32(H), ptr(dy_dx),
+             _u32(gridtype), _int(int(align_corners)), _int(_DTYPE_ID[table_dtype]), _int(1 if rows else 0), units=B)
         ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
         ctx.meta = (B, D, C, L, S, H, gridtype, bool(align_corners))
-        return level_major.permute(1, 0, 2).reshape(B, L * C)
+        return out if rows else out.permute(1, 0, 2).reshape(B, L * C)
 
     @staticmethod
     @custom_bwd(device_type="cuda")

@@ -87,6 +87,8 @@ class NeRFNetwork(NeRFRenderer):
         h = encode_mlp(self.encoder, x, self.bound, None, self.sigma_net)
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
 
+    density._pnr_fused_density = True   # exp(sigma_net(encoder(x))): what pnr_occupancy_update evaluates itself (renderer._fused_sweep_ok)
+
     def color(self, x, d, mask=None, geo_feat=None, **kwargs):
         """nerf/network.py:157-184 -- colour head alone, optionally only where mask is set (other rows stay 0)."""
         if mask is not None:
@@ -161,6 +163,8 @@ class PaletteNetwork(PaletteRenderer):
             return {"sigma": sigma, "geo_feat": geo}
         h = encode_mlp(self.encoder, x, self.bound, None, self.sigma_net)
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
+
+    density._pnr_fused_density = True
 
     def color(self, x, d, mask=None, geo_feat=None, **kwargs):
         """palette/network.py:223-280 (unmasked form: the march path never passes a mask)."""

@@ -308,16 +308,18 @@ class _march_rays(Function):
         M = n_alive * n_step
         if align > 0:
             M += align - (M % align)
-        xyzs = torch.zeros(M, 3, dtype=rays_o.dtype, device=dev)
-        dirs = torch.zeros(M, 3, dtype=rays_o.dtype, device=dev)
-        deltas = torch.zeros(M, 2, dtype=rays_o.dtype, device=dev)
+        # the reference zero-fills the three buffers (raymarching.py:384-386: three launches per call); here the march kernel clears the slots
+        # it does not fill and the alignment rows itself (pnr_march_rays_fill): same contents, one launch
+        xyzs = torch.empty(M, 3, dtype=rays_o.dtype, device=dev)
+        dirs = torch.empty(M, 3, dtype=rays_o.dtype, device=dev)
+        deltas = torch.empty(M, 2, dtype=rays_o.dtype, device=dev)
         noises = torch.rand(n_alive, dtype=rays_o.dtype, device=dev) if perturb else None  # NULL = zeros (no perturbation)
         mip = occupancy_mip(density_bitfield, C, H, bound)
-        call("pnr_march_rays_mip", _u32(n_alive), _u32(n_step), ptr(require(rays_alive, torch.int32, "rays_alive")),
+        call("pnr_march_rays_fill", _u32(n_alive), _u32(n_step), ptr(require(rays_alive, torch.int32, "rays_alive")),
              ptr(require(rays_t, torch.float32, "rays_t")), ptr(require(rays_o, torch.float32, "rays_o")),
              ptr(require(rays_d, torch.float32, "rays_d")), _f32(bound), _f32(dt_gamma), _u32(max_steps), _u32(C), _u32(H),
              ptr(require(density_bitfield, torch.uint8, "density_bitfield")), ptr(require(near, torch.float32, "near")),
-             ptr(require(far, torch.float32, "far")), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(noises), ptr(mip))
+             ptr(require(far, torch.float32, "far")), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(noises), ptr(mip), _u32(M))
         return xyzs, dirs, deltas
 
 

@@ -125,10 +125,14 @@ class _OccupancyMaintenance:
 
     def _fused_sweep_ok(self):
         """The shipped field (16 x 2 hash grid, fp32 table, sigma_net 32 -> 64 -> 16) evaluated by its own density(): the whole sweep is one
-        C-ABI call.  Anything else -- another architecture, a density() replaced on the instance -- goes through its density() between the
+        C-ABI call.  Anything else -- another architecture, a density() replaced on the instance or overridden by a subclass -- goes through its density() between the
         point and scatter kernels."""
         enc, net = getattr(self, "encoder", None), getattr(self, "sigma_net", None)
         if "density" in self.__dict__ or enc is None or net is None or getattr(self, "occupancy_generic", False):
+            return False
+        # a subclass that overrides density() at class level (the reference always calls self.density(), nerf/renderer.py:499) must be asked:
+        # the fused sweep is taken only when the method IS one this library declared fusable (network.py sets `_pnr_fused_density` on its own)
+        if not getattr(getattr(type(self), "density", None), "_pnr_fused_density", False):
             return False
         emb = getattr(enc, "embeddings", None)
         return (emb is not None and emb.is_cuda and emb.dtype == torch.float32 and getattr(enc, "num_levels", 0) == 16 and getattr(enc, "level_dim", 0) == 2

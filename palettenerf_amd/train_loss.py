@@ -53,14 +53,19 @@ class TrainResults(dict):
         return self[key] if key in self else default
 
 
-_workspaces = {}   # device -> zero-initialised int32 tensor (the ticket stays zero between launches: the kernel resets it)
+_workspaces = {}   # (device, stream) -> zero-initialised int32 tensor (the ticket stays zero between launches: the kernel resets it)
 
 
 def _workspace(device, nbytes):
-    ws = _workspaces.get(device)
+    """The last-workgroup ticket + partial-sum rows of pnr_train_loss_forward.  One buffer per (device, STREAM): launches on one stream are
+    ordered, launches on different streams (or from different host threads, which use different streams or serialise on one) must not share
+    the ticket.  (The kernel leaves the ticket at zero; a launch that faults before it does takes the HIP context with it, so there is no
+    next launch to poison.)"""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.zeros((nbytes + 3) // 4 * 2, dtype=torch.int32, device=device)
-        _workspaces[device] = ws
+        _workspaces[key] = ws
     return ws
 
 

@@ -93,16 +93,38 @@ class _Stub(types.ModuleType):
 
 
 def import_reference():
-    rm, ge, sh, pu = make_oracle_modules()
-    sys.modules.update({"raymarching": rm, "gridencoder": ge, "shencoder": sh, "palette.utils": pu})
+    """The reference's Python, imported as it is, over the CPU oracle:
+      * its operator wrappers -- gridencoder/grid.py (GridEncoder, _grid_encode), shencoder/sphere_harmonics.py (SHEncoder, _sh_encoder) and
+        raymarching/raymarching.py -- are the reference's OWN files: each tries `import _<name> as _backend` first (raymarching.py:9-12),
+        and oracle/native_facade.py provides those three pybind modules with the reference's C++ signatures over the C oracle.  So level
+        offsets, per_level_scale, the [L,B,C] buffer and its permute, the half-table cast under autocast, the (x + bound) / (2 bound) map,
+        the zero-fill contracts and the autograd.Function plumbing of every fixture are the reference's;
+      * six functions of raymarching.py force `.cuda()` on their inputs (near_far_from_aabb :34, morton3D :94, morton3D_invert :116,
+        packbits :141, march_rays_train :187, march_rays :373) and cannot run here: the package attributes are replaced by the oracle's
+        facades (oracle/facade.py), which restate those wrappers;
+      * palette/utils.py imports cv2 / skimage / rgbsg: the module is a facade with the three functions the renderer takes from it;
+      * harness-only third-party imports are stubs that raise when called."""
+    from oracle.native_facade import make_native_backends
+    rm_f, _ge_f, _sh_f, pu = make_oracle_modules()
+    nrm, nge, nsh = make_native_backends()
+    sys.modules.update({"_raymarching": nrm, "_gridencoder": nge, "_shencoder": nsh, "palette.utils": pu})
     for name in ("trimesh", "cv2", "mcubes", "tensorboardX", "torch_ema", "lpips", "kornia", "imageio"):
         sys.modules.setdefault(name, _Stub(name))
     nu = types.ModuleType("nerf.utils")
     nu.custom_meshgrid = lambda *a: torch.meshgrid(*a, indexing="ij")
     nu.srgb_to_linear = lambda x: torch.where(x < 0.04045, x / 12.92, ((x + 0.055) / 1.055) ** 2.4)
     sys.modules["nerf.utils"] = nu
-    sys.path.insert(0, REF)
-    # the CPU build of torch has no custom_fwd for 'cuda' autocast issues: activation.py only needs torch.cuda.amp
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", FutureWarning)     # torch.cuda.amp.custom_fwd is deprecated in torch 2.10; the reference uses it
+        import raymarching as ref_raymarching  # noqa  (the reference's package: /root/reference/raymarching)
+        import gridencoder as ref_gridencoder  # noqa
+        import shencoder as ref_shencoder  # noqa
+    assert ref_raymarching.__file__.startswith(REF) and ref_gridencoder.__file__.startswith(REF) and ref_shencoder.__file__.startswith(REF)
+    for name in ("near_far_from_aabb", "march_rays", "march_rays_train", "morton3D", "morton3D_invert", "packbits"):
+        setattr(ref_raymarching, name, getattr(rm_f, name))
     import nerf.network as ref_nerf_network  # noqa
     import palette.network as ref_palette_network  # noqa
     import palette.renderer as ref_palette_renderer  # noqa
@@ -196,6 +218,34 @@ def gen_frames():
                             grad_emb_abs_sum=float(gp.abs().sum()), encoder_grad_is_none=(p.encoder.embeddings.grad is None),
                             **{k: r[k].detach().numpy() for k in tk})
         print("palette train", name, int(p.step_counter[0, 0]), float(loss))
+
+
+# ------------------------------------------------------------------------------------------ the reference's GridEncoder under fp16 autocast (-O mode)
+def gen_grid_autocast():
+    """grid_autocast.npz: the reference's own GridEncoder / _grid_encode (gridencoder/grid.py:19-153, imported from /root/reference) with
+    torch's autocast flag forced on -- the CPU build cannot enter CUDA autocast, and the flag is all grid.py:36-39 looks at: it then hands
+    the kernel a half copy of the table and returns half features.  Pins the `-O` path of the operator (`embeddings.to(torch.half)`, half
+    accumulator, [L,B,C] -> [B, L*C]) against the reference's wrapper; the fp32 call of the same module is stored beside it."""
+    import_reference()
+    import gridencoder as ref_ge
+    enc = ref_ge.GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=4096)
+    g = torch.Generator().manual_seed(77)
+    with torch.no_grad():
+        enc.embeddings.copy_((torch.rand(enc.embeddings.shape, generator=g) - 0.5))
+    x = torch.rand(2048, 3, generator=g) * 4 - 2
+    x[:4] = torch.tensor([[2.0, 2.0, 2.0], [-2.0, -2.0, -2.0], [2.0000005, 0.0, 0.0], [0.0, 0.0, 0.0]])
+    with torch.no_grad():
+        y32 = enc(x, bound=2)
+        real = torch.is_autocast_enabled
+        torch.is_autocast_enabled = lambda *a, **k: True
+        try:
+            y16 = enc(x, bound=2)
+        finally:
+            torch.is_autocast_enabled = real
+    assert y16.dtype == torch.float16 and y32.dtype == torch.float32
+    np.savez_compressed(os.path.join(HERE, "grid_autocast.npz"), seed=77, x=x.numpy(), bound=2.0, y32=y32.numpy(), y16_bits=y16.numpy().view(np.uint16),
+                        offsets=enc.offsets.numpy(), per_level_scale=np.float64(enc.per_level_scale))
+    print("grid_autocast", y16.shape, float(y32.abs().mean()), float((y16.float() - y32).abs().max()))
 
 
 # ------------------------------------------------------------------------------------------ palette extras: Stylizer, edit windows, more bases
@@ -452,6 +502,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["sh", "frames"]
     if "occupancy" in which:
         gen_occupancy()
+    if "grid_autocast" in which:
+        gen_grid_autocast()
     if "hist" in which:
         gen_hist()
     if "palette_extra" in which:

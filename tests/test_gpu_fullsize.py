@@ -283,3 +283,35 @@ def test_bench_line_with_frames_in_flight_over_rccl(cuda):
     assert piped["config"]["rccl_ranks"] == 1 and piped["config"]["gathered_floats_per_ray"] == 5
     assert piped["config"]["rendered_samples_per_step"] == plain["config"]["rendered_samples_per_step"]
     assert piped["value"] > 0 and "note_frames_in_flight" in piped["roofline"]
+
+
+def test_headline_crop_against_the_live_oracle_and_its_committed_digest(cuda, golden_dir):
+    """The comparison bench.py's `parity` block makes, as a test: the centre 400 x 400 crop of pose 0 of the configs[1] frame (800 x 800, S0,
+    -m nerf, density_scale 100) through the device-driven native loop (split-fp16 field: the headline's arithmetic)
+      (a) against the oracle run LIVE on the same rays on this host (per pixel: 1e-5; measured 5.4e-7), and
+      (b) against tests/golden/crop400.npz, the oracle's digest committed from the build container (rendered-sample count exact; 8 x 8 block
+          means of image and alpha to 1e-5), so that an oracle that drifted between the container and this box cannot hide a kernel change."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_crop400", os.path.join(golden_dir, "gen_crop400.py"))
+    gc400 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gc400)
+    fx = np.load(os.path.join(golden_dir, "crop400.npz"))
+    import bench
+    from palettenerf_amd.fused import NeRFFieldFused
+    args = bench.parse(["--no-extras"])
+    m = bench.build_model(args, cuda, "nerf")
+    assert m.march_mode == "native" and isinstance(m._fused, NeRFFieldFused) and m._fused.precision == 1
+    ro, rd = gc400.crop_rays()
+    with torch.no_grad():
+        g = m.render(ro.to(cuda), rd.to(cuda), perturb=False, dt_gamma=0.0, max_steps=1024, T_thresh=1e-4)
+    img, ws = g["image"][0].cpu().numpy(), g["weights_sum"].cpu().numpy()
+    # (b) the committed digest
+    assert int(g["rendered"].sum()) == int(fx["rendered"])                       # march + termination: the same samples as the oracle rendered
+    np.testing.assert_allclose(gc400.block_means(img), fx["image_block_means"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(gc400.block_means(np.repeat(ws[:, None], 3, 1))[..., 0], fx["alpha_block_means"], rtol=0, atol=1e-5)
+    # (a) the live oracle, per pixel
+    oimg, ows, on = gc400.oracle_crop(threads=min(16, os.cpu_count() or 1))
+    assert on == int(fx["rendered"])
+    np.testing.assert_allclose(gc400.block_means(oimg), fx["image_block_means"], rtol=0, atol=2e-6)      # this host's oracle == the container's
+    assert float(np.abs(img - oimg).max()) <= 1e-5 and float(np.abs(ws - ows).max()) <= 1e-5
+    assert scene.psnr(torch.from_numpy(img), torch.from_numpy(oimg)) > 100.0

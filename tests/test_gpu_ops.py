@@ -252,6 +252,10 @@ def test_march_rays_inference_bit_exact(cuda, s0, mip_mode, n_step, bound):
     rays_t = on.copy()
     rays_t[alive[::3]] += 0.5  # some rays already advanced
     ox, od, odl = oracle.march_rays(len(alive), n_step, alive, rays_t, ro, rd, bound, bf, 2, 128, on, of, align=128, dt_gamma=1.0 / 256)
+    # the wrapper hands the kernel UNINITIALISED buffers (pnr_march_rays_fill clears unfilled slots and the alignment rows itself): dirty the
+    # allocator's blocks first so that a slot the kernel forgot cannot pass as the reference's zero-fill by luck
+    for rows in (ox.shape[0] * 3, ox.shape[0] * 3, ox.shape[0] * 2):
+        torch.empty(rows, device=cuda).fill_(float("nan"))
     x, d, dl = raymarching.march_rays(len(alive), n_step, dev(alive, cuda), dev(rays_t, cuda), dev(ro, cuda), dev(rd, cuda), bound, dev(bf, cuda), 2, 128,
                                       dev(on, cuda), dev(of, cuda), 128, False, 1.0 / 256, 1024)
     assert x.shape == ox.shape and x.shape[0] % 128 == 0 and x.shape[0] > len(alive) * n_step - 1
@@ -416,6 +420,77 @@ def test_grid_encode_forward_fp16_table_bit_exact(cuda):
     with torch.autocast("cuda", dtype=torch.float16):
         out2 = gridencoder.grid_encode(dev(x, cuda), dev(emb, cuda), dev(offsets, cuda), pls, 16, False, 0, False)
     np.testing.assert_array_equal(host(out2).view(np.uint16), want.view(np.uint16))
+
+
+def test_grid_forward_d3c2_kernel_and_row_layout_are_bit_identical(cuda):
+    """k_grid_fwd_d3c2 (the D = 3, C = 2 lookup: addresses first, finest levels first, index by kind of level) against the generic kernel,
+    and its [B, L*C] row output against the [L, B, C] one: same bits.  Covers dense levels, hashed levels of power-of-two size, a hashed level
+    whose size is NOT a power of two (hand-made offsets: the reference's `%`), the tiled grid, align_corners, fp16 tables, and the oracle."""
+    import ctypes
+    from palettenerf_amd import _lib
+    from palettenerf_amd._torch_glue import call, ptr
+    lib = _lib.load()
+    u32, f32, cint = ctypes.c_uint32, ctypes.c_float, ctypes.c_int
+    rng = np.random.default_rng(77)
+    cases = []
+    pls, offsets, emb, x = _grid_setup(rng, 16, 16, 19, 4096, 2, 30011)
+    cases.append(("shipped", pls, 16, offsets, emb, x, 0, False))
+    pls, offsets, emb, x = _grid_setup(rng, 6, 8, 10, None, 2, 5003)
+    cases += [("tiled", pls, 8, offsets, emb, x, 1, False), ("hash_ac", pls, 8, offsets, emb, x, 0, True), ("tiled_ac", pls, 8, offsets, emb, x, 1, True)]
+    # odd level sizes: rows per level that are neither (res+1)^3 nor a power of two (the C ABI takes any offsets)
+    sizes = np.array([1000, 3000, 5000, 7777, 10001, 4093], dtype=np.int64)
+    offs_odd = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    emb_odd = (rng.random((int(offs_odd[-1]), 2)) - 0.5).astype(np.float32)
+    cases.append(("odd_sizes", 2.0, 8, offs_odd, emb_odd, x, 0, False))
+    try:
+        for name, pls, H, offsets, emb, x, gridtype, ac in cases:
+            L, B = len(offsets) - 1, x.shape[0]
+            S = float(np.log2(pls))
+            for dtype_id, tab in ((0, emb), (1, emb.astype(np.float16))):
+                tx, tt, to = dev(x, cuda), dev(tab, cuda), dev(offsets, cuda)
+                outs = {}
+                for label, fast, layout in (("generic", 0, 0), ("fast_levels", 1, 0), ("fast_rows", 1, 1)):
+                    assert lib.pnr_set_option(b"grid_fast", fast) == 0
+                    out = torch.full((B * L * 2,), 7.0, device=cuda, dtype=tt.dtype)
+                    call("pnr_grid_encode_forward_layout", ptr(tx), ptr(tt), ptr(to), ptr(out), u32(B), u32(3), u32(2), u32(L), f32(S), u32(H), None, u32(gridtype), cint(int(ac)),
+                         cint(dtype_id), cint(layout))
+                    o = host(out)
+                    outs[label] = o.reshape(B, L, 2) if layout else o.reshape(L, B, 2).transpose(1, 0, 2)
+                bits = np.uint32 if dtype_id == 0 else np.uint16
+                np.testing.assert_array_equal(np.ascontiguousarray(outs["generic"]).view(bits), np.ascontiguousarray(outs["fast_levels"]).view(bits), err_msg=name)
+                np.testing.assert_array_equal(np.ascontiguousarray(outs["generic"]).view(bits), np.ascontiguousarray(outs["fast_rows"]).view(bits), err_msg=name)
+                want = oracle.grid_encode_forward(x, tab, offsets, pls, H, gridtype=gridtype, align_corners=ac)
+                np.testing.assert_array_equal(np.ascontiguousarray(outs["fast_rows"]).reshape(B, L * 2).view(bits), want.view(bits), err_msg=name)
+        # the generic kernel has no row layout: refused, not silently level-major
+        assert lib.pnr_set_option(b"grid_fast", 0) == 0
+        with pytest.raises(RuntimeError, match="unsupported"):
+            call("pnr_grid_encode_forward_layout", ptr(tx), ptr(tt), ptr(to), ptr(out), u32(B), u32(3), u32(2), u32(L), f32(S), u32(H), None, u32(0), cint(0), cint(1), cint(1))
+    finally:
+        lib.pnr_set_option(b"grid_fast", 1)
+
+
+def test_grid_encoder_module_against_the_reference_wrapper_fixture_fp32_and_autocast(cuda, golden_dir):
+    """tests/golden/grid_autocast.npz was produced by the reference's own GridEncoder / _grid_encode (gridencoder/grid.py, imported in the
+    build container over the CPU oracle): once in fp32, once with autocast on (the table goes to half, grid.py:36-39).  The product module under
+    a real torch.autocast("cuda") must return the very same half bits; in fp32 the very same floats."""
+    import os
+    fx = np.load(os.path.join(golden_dir, "grid_autocast.npz"))
+    enc = gridencoder.GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=4096)
+    assert np.array_equal(enc.offsets.numpy(), fx["offsets"]) and float(enc.per_level_scale) == float(fx["per_level_scale"])
+    g = torch.Generator().manual_seed(int(fx["seed"]))
+    with torch.no_grad():
+        enc.embeddings.copy_((torch.rand(enc.embeddings.shape, generator=g) - 0.5))
+    x = torch.rand(2048, 3, generator=g) * 4 - 2
+    x[:4] = torch.tensor([[2.0, 2.0, 2.0], [-2.0, -2.0, -2.0], [2.0000005, 0.0, 0.0], [0.0, 0.0, 0.0]])
+    np.testing.assert_array_equal(x.numpy(), fx["x"])     # same generator stream as the fixture's
+    enc = enc.to(cuda)
+    with torch.no_grad():
+        y32 = enc(x.to(cuda), bound=float(fx["bound"]))
+        with torch.autocast("cuda", dtype=torch.float16):
+            y16 = enc(x.to(cuda), bound=float(fx["bound"]))
+    np.testing.assert_array_equal(host(y32), fx["y32"])
+    assert y16.dtype == torch.float16
+    np.testing.assert_array_equal(host(y16).view(np.uint16), fx["y16_bits"])
 
 
 def test_grid_encode_backward_and_input_grad(cuda):

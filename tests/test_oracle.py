@@ -674,3 +674,122 @@ def test_mark_untrained_grid_against_the_reference_method(key, filt):
     ref = np.unpackbits(g[key])[:C * G ** 3].reshape(C, -1).astype(bool)
     assert n == int(ref.sum()) and np.array_equal(grid < 0, ref)
     assert 0 < n < C * G ** 3
+
+
+# ------------------------------------------------------------------------------------------ round 4: the reference's OWN operator wrappers over the oracle
+REF = "/root/reference"
+ROOT_DIR = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference checkout (build container only; nothing on the GPU box reads it)")
+def test_reference_operator_wrappers_over_the_native_stand_ins_equal_the_restated_facades():
+    """tests/golden/gen_golden.py drives the reference's own gridencoder/grid.py, shencoder/sphere_harmonics.py and the composite Functions
+    of raymarching/raymarching.py (imported from /root/reference, their `_backend` = oracle/native_facade.py).  oracle/facade.py -- the
+    restatement bench.py's cpu_baseline and the host-logic tests still use -- must give the very same numbers: forward, backward, the
+    half-table cast under autocast, the in-place inference composites."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, warnings, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+warnings.simplefilter("ignore")
+sys.path.insert(0, %r + "/tests/golden")
+import gen_golden
+gen_golden.import_reference()
+import raymarching as ref_rm, gridencoder as ref_ge, shencoder as ref_sh
+from gridencoder.grid import grid_encode as ref_grid_encode
+from oracle.facade import make_oracle_modules
+rm, ge, sh, pu = make_oracle_modules()
+torch.manual_seed(0)
+# GridEncoder: construction (offsets, per_level_scale), forward with the bound map, table gradient
+a = ref_ge.GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=4096)
+b = ge.GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=4096)
+assert torch.equal(a.offsets, b.offsets) and a.per_level_scale == b.per_level_scale and a.output_dim == b.output_dim
+with torch.no_grad():
+    a.embeddings.uniform_(-0.5, 0.5); b.embeddings.copy_(a.embeddings)
+x = torch.rand(3001, 3) * 4 - 2
+x[:2] = torch.tensor([[2.0, 2.0, 2.0], [2.0000005, 0.0, 0.0]])
+ya, yb = a(x, bound=2), b(x, bound=2)
+assert torch.equal(ya, yb), float((ya - yb).abs().max())
+g = torch.randn_like(ya)
+(ya * g).sum().backward(); (yb * g).sum().backward()
+assert torch.equal(a.embeddings.grad, b.embeddings.grad)
+# the half-table cast (gridencoder/grid.py:36-39) with the autocast flag forced on: the reference's wrapper hands a half table to the kernel
+real = torch.is_autocast_enabled
+torch.is_autocast_enabled = lambda *a_, **k_: True
+try:
+    yh = ref_grid_encode((x + 2) / 4, a.embeddings.detach(), a.offsets, a.per_level_scale, 16, False, 0, False)
+finally:
+    torch.is_autocast_enabled = real
+import oracle
+want = oracle.grid_encode_forward(((x + 2) / 4).numpy(), a.embeddings.detach().numpy().astype(np.float16), a.offsets.numpy(), a.per_level_scale, 16)
+assert yh.dtype == torch.float16 and np.array_equal(yh.numpy().view(np.uint16), want.view(np.uint16))
+# SHEncoder
+d = torch.randn(1000, 3); d = d / d.norm(dim=1, keepdim=True)
+assert torch.equal(ref_sh.SHEncoder(degree=4)(d), sh.SHEncoder(degree=4)(d))
+# training composites, forward + backward
+M, N = 4000, 64
+cnt = torch.full((N,), M // N, dtype=torch.int32)
+rays = torch.stack([torch.arange(N, dtype=torch.int32), (torch.arange(N, dtype=torch.int32) * (M // N)), cnt], 1).contiguous()
+sig = (torch.rand(M) * 30).requires_grad_(True); rgb = torch.rand(M, 3).requires_grad_(True)
+deltas = torch.rand(M, 2) * 0.01 + 0.003
+out_a = ref_rm.composite_rays_train(sig, rgb, deltas, rays, 1e-4)
+ga = torch.autograd.grad((out_a[0].sum() + (out_a[2] ** 2).sum()), (sig, rgb))
+out_b = rm.composite_rays_train(sig, rgb, deltas, rays, 1e-4)
+gb = torch.autograd.grad((out_b[0].sum() + (out_b[2] ** 2).sum()), (sig, rgb))
+assert all(torch.equal(p, q) for p, q in zip(out_a, out_b)) and all(torch.equal(p, q) for p, q in zip(ga, gb))
+inp = torch.rand(M, 33).requires_grad_(True)
+fa, fb = ref_rm.composite_rays_flex_train(sig, inp, deltas, rays, 1e-4), rm.composite_rays_flex_train(sig, inp, deltas, rays, 1e-4)
+assert torch.equal(fa, fb)
+assert torch.equal(torch.autograd.grad((fa ** 2).sum(), inp)[0], torch.autograd.grad((fb ** 2).sum(), inp)[0])
+# inference composites, in place
+n_alive, n_step = 50, 4
+alive = torch.arange(n_alive, dtype=torch.int32)
+state = lambda: (alive.clone(), torch.full((N,), 0.5), torch.zeros(N), torch.zeros(N), torch.zeros(N, 3))
+s1, s2 = state(), state()
+sg, cl, dl = torch.rand(n_alive * n_step) * 40, torch.rand(n_alive * n_step, 3), torch.rand(n_alive * n_step, 2) * 0.01 + 0.003
+ref_rm.composite_rays(n_alive, n_step, s1[0], s1[1], sg, cl, dl, s1[2], s1[3], s1[4], 1e-4)
+rm.composite_rays(n_alive, n_step, s2[0], s2[1], sg, cl, dl, s2[2], s2[3], s2[4], 1e-4)
+assert all(torch.equal(p, q) for p, q in zip(s1, s2))
+o1, o2 = torch.zeros(N, 12), torch.zeros(N, 12)
+fin = torch.rand(n_alive * n_step, 12)
+ref_rm.composite_rays_flex(n_alive, n_step, 12, alive.clone(), torch.full((N,), 0.5), sg, fin, dl, torch.zeros(N), o1, 1e-4)
+rm.composite_rays_flex(n_alive, n_step, 12, alive.clone(), torch.full((N,), 0.5), sg, fin, dl, torch.zeros(N), o2, 1e-4)
+assert torch.equal(o1, o2) and float(o1.abs().sum()) > 0
+print("WRAPPERS-OK")
+''' % (REF, ROOT_DIR, ROOT_DIR)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)   # own process: the reference's packages must not stay in this one's sys.modules
+    assert r.returncode == 0 and "WRAPPERS-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_pure_torch_encoders_of_the_cpu_baseline_against_the_oracle():
+    """oracle/torch_encoders.py (bench.py's configs[0] leg: the "pure-PyTorch" CPU path) against the C oracle."""
+    from oracle.torch_encoders import TorchGridEncoder, TorchSHEncoder
+    torch.manual_seed(3)
+    g = TorchGridEncoder(num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=4096)
+    with torch.no_grad():
+        g.embeddings.uniform_(-0.5, 0.5)
+    x = torch.rand(4000, 3) * 4 - 2
+    x[:3] = torch.tensor([[2.0, 2.0, 2.0], [-2.0, -2.0, -2.0], [2.0000005, 0.0, 0.0]])
+    with torch.no_grad():
+        out = g(x, bound=2).numpy()
+    want = oracle.grid_encode_forward(((x + 2) / 4).numpy(), g.embeddings.detach().numpy(), g.offsets.numpy(), g.per_level_scale, 16)
+    np.testing.assert_allclose(out, want, rtol=0, atol=2e-7)       # same cells and weights; torch's a*b+c is not contracted where the oracle's fmaf is
+    assert (out[2] == 0).all()                                      # outside [0, 1]: zeros
+    d = torch.randn(1000, 3)
+    d = d / d.norm(dim=1, keepdim=True)
+    for deg in (1, 2, 3, 4):
+        np.testing.assert_allclose(TorchSHEncoder(degree=deg)(d).numpy(), oracle.sh_encode_forward(d.numpy(), deg), rtol=0, atol=1e-6)
+
+
+def test_oracle_against_the_reference_wrapper_fixture_fp32_and_autocast(golden_dir):
+    """grid_autocast.npz (the reference's GridEncoder over the native stand-ins, fp32 and with the autocast flag on): the oracle's NumPy front
+    end -- offsets, level scales, the [L,B,C] permute restated -- reproduces both outputs from the seed alone."""
+    fx = np.load(os.path.join(golden_dir, "grid_autocast.npz"))
+    offs = oracle.grid_offsets(3, 16, float(fx["per_level_scale"]), 16, 19)
+    np.testing.assert_array_equal(offs, fx["offsets"])
+    g = torch.Generator().manual_seed(int(fx["seed"]))
+    emb = (torch.rand(int(offs[-1]), 2, generator=g) - 0.5).numpy()
+    x01 = ((torch.from_numpy(fx["x"]) + 2.0) / 4.0).numpy()
+    np.testing.assert_array_equal(oracle.grid_encode_forward(x01, emb, offs, float(fx["per_level_scale"]), 16), fx["y32"])
+    np.testing.assert_array_equal(oracle.grid_encode_forward(x01, emb.astype(np.float16), offs, float(fx["per_level_scale"]), 16).view(np.uint16), fx["y16_bits"])
