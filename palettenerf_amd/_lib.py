@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpnr_hip.so")
+LIB_PATH = os.environ.get("PNR_LIB_PATH") or os.path.join(_HERE, "libpnr_hip.so")   # PNR_LIB_PATH: an experiment build (palettenerf_amd.build --variant); still no fallback
 
 _u32, _f32, _int, _ptr, _u64 = ctypes.c_uint32, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64
 

@@ -50,11 +50,34 @@ def _compile(src):
     return obj
 
 
+def build_variant(name, extra_flags, only=None, verbose=False):
+    """An experiment build next to the product library: libpnr_hip_<name>.so from the same sources with extra hipcc flags (-D knobs) on the
+    translation units in `only` (default: all), the other objects taken from the product build.  Selected at run time with PNR_LIB_PATH."""
+    build()
+    vobj = os.path.join(CSRC, "_obj", "variant_" + name)
+    os.makedirs(vobj, exist_ok=True)
+    objs = []
+    for src in sources():
+        base = os.path.basename(src)[:-4]
+        if only is None or base in only:
+            obj = os.path.join(vobj, base + ".o")
+            subprocess.check_call([hipcc(), *FLAGS, *extra_flags, "-c", src, "-o", obj])
+        else:
+            obj = os.path.join(OBJ, base + ".o")
+        objs.append(obj)
+    lib = os.path.join(HERE, f"libpnr_hip_{name}.so")
+    subprocess.check_call([hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib, *objs])
+    if verbose:
+        print("built", lib)
+    return lib
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     if force:
         for f in os.listdir(OBJ):
-            os.remove(os.path.join(OBJ, f))
+            if os.path.isfile(os.path.join(OBJ, f)):
+                os.remove(os.path.join(OBJ, f))
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _deps_mtime():
         return LIB
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
@@ -66,4 +89,10 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    if "--variant" in sys.argv:      # python -m palettenerf_amd.build --variant NAME [--only unit,unit] -- -DFLAG ...
+        i = sys.argv.index("--variant")
+        only = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else None
+        flags = sys.argv[sys.argv.index("--") + 1:] if "--" in sys.argv else []
+        build_variant(sys.argv[i + 1], flags, only, verbose=True)
+    else:
+        build(force="--force" in sys.argv, verbose=True)

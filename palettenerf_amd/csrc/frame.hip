@@ -617,13 +617,30 @@ struct GridArgs {
     const int32_t* offsets; LevelParams lp;
     uint32_t level_stride; float bound, two_bound; uint32_t gridtype;
 };
-struct LevelCtx { uint32_t off0, hashmap_size, resolution; float scale; };
+// kind: how a row index is formed on this level (gridencoder.cu:49-72 evaluated once per level instead of once per corner) --
+//   0 the reference's general form (stride test per dimension, hash or tiled, `%`); 1 dense: side^3 <= size, the index is below the size and the
+//   `%` is the identity; 2 hashed with a power-of-two size: a mask.  All three give the same index (tests: every table layout against k_grid_fwd).
+struct LevelCtx { uint32_t off0, hashmap_size, resolution; float scale; uint32_t kind; };
+#ifndef PNR_GRID_KIND
+#define PNR_GRID_KIND 1     // 0: every level through the general form (the A/B of the specialised index forms)
+#endif
+__device__ __forceinline__ uint32_t level_kind(uint32_t gridtype, uint32_t hashmap_size, uint32_t resolution) {
+    if (!PNR_GRID_KIND) return 0u;
+    const uint32_t side = resolution + 1u;
+    if ((uint64_t)side * side * side <= (uint64_t)hashmap_size) return 1u;
+    uint32_t stride = 1u;
+#pragma unroll
+    for (uint32_t d = 0; d < 3; d++)
+        if (stride <= hashmap_size) stride *= side;
+    return (gridtype == 0u && stride > hashmap_size && (hashmap_size & (hashmap_size - 1u)) == 0u) ? 2u : 0u;
+}
 __device__ __forceinline__ LevelCtx level_ctx(const GridArgs& g, uint32_t level) {
     LevelCtx lc;
     lc.off0 = (uint32_t)g.offsets[level];
     lc.hashmap_size = (uint32_t)g.offsets[level + 1] - lc.off0;
     lc.scale = g.lp.scale[level];
     lc.resolution = g.lp.resolution[level];
+    lc.kind = level_kind(g.gridtype, lc.hashmap_size, lc.resolution);
     return lc;
 }
 // the eight corners of row b's cell on one level: row indices (x CMUL) and the fractional position the weights come from; false = the point is outside [0, 1]^3
@@ -645,12 +662,24 @@ __device__ __forceinline__ bool grid_corner_rows(const GridArgs& g, const LevelC
         pg[d] = (uint32_t)fl;
         pos[d] -= (float)pg[d];
     }
+    if (lc.kind == 1u) {          // (wave-uniform in the level-major workgroups; per lane in the hosted tail)
+        const uint32_t side = lc.resolution + 1u;
 #pragma unroll
-    for (uint32_t idx = 0; idx < 8; idx++) {
-        uint32_t pl[3];
+        for (uint32_t idx = 0; idx < 8; idx++)
+            idxs[idx] = ((pg[0] + (idx & 1u)) + (pg[1] + ((idx >> 1) & 1u)) * side + (pg[2] + ((idx >> 2) & 1u)) * side * side) * CMUL;
+    } else if (lc.kind == 2u) {
+        const uint32_t mask = lc.hashmap_size - 1u;
 #pragma unroll
-        for (uint32_t d = 0; d < 3; d++) pl[d] = pg[d] + ((idx >> d) & 1u);
-        idxs[idx] = grid_index<3, CMUL>(g.gridtype, false, lc.hashmap_size, lc.resolution, pl);
+        for (uint32_t idx = 0; idx < 8; idx++)
+            idxs[idx] = (((pg[0] + (idx & 1u)) ^ ((pg[1] + ((idx >> 1) & 1u)) * 2654435761u) ^ ((pg[2] + ((idx >> 2) & 1u)) * 805459861u)) & mask) * CMUL;
+    } else {
+#pragma unroll
+        for (uint32_t idx = 0; idx < 8; idx++) {
+            uint32_t pl[3];
+#pragma unroll
+            for (uint32_t d = 0; d < 3; d++) pl[d] = pg[d] + ((idx >> d) & 1u);
+            idxs[idx] = grid_index<3, CMUL>(g.gridtype, false, lc.hashmap_size, lc.resolution, pl);
+        }
     }
     return true;
 }
@@ -871,6 +900,7 @@ __device__ __forceinline__ void hosted_march_tail(const FrameCtl* ctl, const Gri
                 const uint32_t b = wrows[wave][pi >> 4], level = pi & 15u;
                 LevelCtx lc;
                 lc.scale = lv_scale[level]; lc.resolution = lv_res[level]; lc.off0 = lv_off[level]; lc.hashmap_size = lv_size[level];
+                lc.kind = 0u;   // (levels differ per lane here: the general form)
                 for (uint32_t tz = 0; tz < n_tab; tz++) grid_row<KIND, false>(g, lc, level, g.table[tz], g.enc[tz], b);
             }
             wave_lds_sync();

@@ -175,6 +175,21 @@ struct EditParams {
 };
 
 constexpr int kPalThreads = 512;
+// 12-wave kernels (three waves per SIMD, registers and LDS both full): two requests a tile used to wait for where it needed them are issued at the
+// top of the tile at no cost in registers --
+//   PNR_PAL_EARLY_PAL  the second table's rows (enc_palette, needed by basis_net two thirds into the tile) go straight into this wave's aux staging
+//                      slab with global_load_lds: the slab is idle until the epilogue writes the tile's aux rows into it;
+//   PNR_PAL_EARLY_RAY  a ray leader's slot -> ray id (and then its weights_sum) for the compositing step at the END of the tile.
+#ifndef PNR_PAL_EARLY_PAL
+#define PNR_PAL_EARLY_PAL 0     // measured (profiles/scratch/r04_ab_palette.sh, garden): 13.2 -> 13.55 ms with it on (168 registers + 12 B of scratch): off
+#endif
+#ifndef PNR_PAL_WAVE_MAJOR
+#define PNR_PAL_WAVE_MAJOR 1    // wave tiles dealt wave-major (see the tile loop); 0 = workgroup-major, for the A/B
+#endif
+#ifndef PNR_PAL_EARLY_RAY
+#define PNR_PAL_EARLY_RAY 1     // garden 13.2 -> 13.0 ms (162 registers, no scratch)
+#endif
+
 
 // ctl == nullptr: rows = B (stand-alone op).  Otherwise rows = n_alive * n_step of the frame control block and
 // dead slots (delta == 0) are skipped.
@@ -210,8 +225,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
     // and the aux composite runs here only with 1, 2, 4 or 8 samples per ray (a ray's rows then sit inside one wave tile anyway)
     const bool ray_tiles = stage_stride && ctl && aux_map && rs.rays_t;
     const uint32_t rpw = ray_tiles ? (32u / (uint32_t)ctl->n_step) * (uint32_t)ctl->n_step : 32u;
-    const uint32_t ntiles = (B + WAVES * rpw - 1) / (WAVES * rpw);
-    if (blockIdx.x >= ntiles) return;
+    const uint32_t nwt = (B + rpw - 1) / rpw;    // wave tiles of this launch
+    if (blockIdx.x >= nwt) return;               // (wave 0 of workgroup b takes wave tile b first: a workgroup beyond nwt has nothing at all)
     extern __shared__ unsigned char w[];
     for (uint32_t i = threadIdx.x * 16; i < packed_bytes; i += WAVES * 64 * 16) lds_copy16(&packed[i], &w[i]);   // weights + the PaletteTables behind them
     lds_copy_wait();
@@ -227,7 +242,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
     // kept behind pnr_set_option("dynamic_tiles") -- every wave fetching its next wave tile from a device counter (tile_counter, zeroed by the
     // iteration's march launch).  The idea: a launch of 11.08 workgroup tiles per CU takes the time of 12 with the static schedule.  Measured:
     // garden frame 14.6 -> 20.2 ms -- 34 k waves queue on one counter and a workgroup's waves no longer read neighbouring rows.  Off.
-    const uint32_t nwt = (B + rpw - 1) / rpw;
     for (uint32_t it = 0;; it++) {
         uint32_t wt;
         if (tile_counter) {
@@ -235,7 +249,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
             if (lane == 0) got = atomicAdd(tile_counter, 1u);
             wt = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
         } else {
-            wt = (blockIdx.x + it * gridDim.x) * WAVES + wave;
+            // wave-major: round `it` deals wave tile (it * WAVES + wave) * grid + b to wave `wave` of workgroup b, so the LAST, partial round of a
+            // launch is spread one tile per workgroup (and, past `grid` tiles, one per SIMD: wave w sits on SIMD w % 4) instead of filling all
+            // WAVES waves of its first few workgroups -- garden: 11.09 rounds cost 11 + 1/3 tile times instead of 12; an eighth of a frame:
+            // 1.4 rounds cost 1 + 2/3 instead of 2.  (Workgroup-major, rounds 1-3: (b + it * grid) * WAVES + wave.)
+            if constexpr (PNR_PAL_WAVE_MAJOR != 0) wt = (it * WAVES + (uint32_t)wave) * gridDim.x + blockIdx.x;
+            else wt = (blockIdx.x + it * gridDim.x) * WAVES + wave;
         }
         if (wt >= nwt) break;
         const uint32_t n = wt * rpw + (lane & 31);
@@ -257,8 +276,25 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
         float xs[2][8], xp[2][8];
         load_enc_raw(enc, level_stride, row, valid, h, xs);
         if constexpr (WAVES == 8) load_enc_raw(enc_pal, level_stride, row, valid, h, xp);
+        // 12 waves: enc_palette's 16 levels x 32 rows x 8 bytes of this tile -> the wave's (idle) staging slab, 4 x 1 KiB, one level per 16 lanes.
+        // Needs 16-byte aligned sources (even first row, even level stride) and 32 rows that exist in every level's run (level_stride rows are
+        // allocated per level; rows beyond B hold stale values that their lanes replace by zeros below).  Wave-uniform.
+        const uint32_t n0_tile = wt * rpw;
+        const bool pal_in_lds = PNR_PAL_EARLY_PAL && WAVES == 12 && stage_stride * 32u * 4u >= 4096u && ((level_stride | n0_tile) & 1u) == 0u && n0_tile + 32u <= level_stride;
+        if (pal_in_lds) {
+            unsigned char* slab_b = w + packed_bytes + (size_t)wave * 32 * stage_stride * 4;
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(enc_pal) + ((size_t)(lane >> 4) * level_stride + n0_tile) * 8u + (uint32_t)(lane & 15) * 16u;
+#pragma unroll
+            for (int i = 0; i < 4; i++) lds_copy16(src + (size_t)(4 * i) * level_stride * 8u, slab_b + i * 1024 + lane * 16);
+        }
         float dx = 0.0f, dy = 0.0f, dz = 0.0f;
         if (valid) { dx = dirs[(size_t)row * 3]; dy = dirs[(size_t)row * 3 + 1]; dz = dirs[(size_t)row * 3 + 2]; }
+        // the compositing step's first dependent load (slot -> ray id), requested now; its second (the ray's weights_sum) once sigma_net is done
+        const bool early_ray = PNR_PAL_EARLY_RAY && WAVES == 12 && fuse_composite;
+        const bool lead_lane = early_ray && (uint32_t)lane < rpw && (lane % fstep) == 0 && (n0_tile + lane) / fstep < (uint32_t)ctl->n_alive;
+        int early_index = 0;
+        float early_ws = 0.0f;
+        if (lead_lane) early_index = rays_alive[(n0_tile + lane) / fstep];
 
         // ---------------- sigma_net (prescaled by a power of two when the table's entries are tiny: undone exactly on its 16 outputs)
         const bool pre_s = PREC != 0 && pp.enc_scale[0] != 1.0f, pre_p = PREC != 0 && pp.enc_scale[1] != 1.0f, pre_c = PREC != 0 && pp.enc_scale[2] != 1.0f;
@@ -280,6 +316,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
         if (pre_s) g = scale16(g, 1.0f / pp.enc_scale[0]);
         const float sigma_logit = g[0];
         const BOp<PREC> geo = frag_op<PREC, CHECK>(g, 0, sw);                           // the geo k-block, shared by diff_net and color_net
+        if (lead_lane) early_ws = weights_sum[early_index];
 
         // ---------------- diff_net: 15 -> 64 -> 64 -> 3
         t0 = mma_blk<PREC>(zero16(), w + (PB_D0 + 0) * kF16BlockBytes, geo, lane);
@@ -314,7 +351,22 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
 
         // ---------------- basis_net: [enc_palette(32) ; diffuse(3)] -> 64 (ELU) -> 15
         {
-            if constexpr (WAVES != 8) load_enc_raw(enc_pal, level_stride, row, valid, h, xp);
+            if constexpr (WAVES != 8) {
+                if (pal_in_lds) {   // the rows requested at the top of the tile: level 8 kb + 4 h + q of row (lane & 31)
+                    lds_copy_wait();
+                    typedef __attribute__((address_space(3))) f32x2 lds_f32x2;
+                    const lds_f32x2* sl = reinterpret_cast<const lds_f32x2*>(reinterpret_cast<uintptr_t>(w + packed_bytes + (size_t)wave * 32 * stage_stride * 4));
+#pragma unroll
+                    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const f32x2 v = sl[(8 * kb + 4 * h + q) * 32 + (lane & 31)];
+                            xp[kb][2 * q] = valid ? v.x : 0.0f; xp[kb][2 * q + 1] = valid ? v.y : 0.0f;
+                        }
+                } else {
+                    load_enc_raw(enc_pal, level_stride, row, valid, h, xp);
+                }
+            }
             const float ps = pre_p ? pp.enc_scale[1] : 1.0f;   // the whole 35-wide input row is scaled; the ELU needs the true pre-activations back
             if (pre_p) scale8x2(xp, ps);
             const BOp<PREC> b0 = make_op<PREC, CHECK>(xp[0], sw), b1 = make_op<PREC, CHECK>(xp[1], sw);
@@ -504,8 +556,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
                 bool stopped = false;   // the last row that counts saw T < T_thresh
                 if (lane < 32 && (lane % fstep) == 0) {
                     if (leader && ((live >> lane) & 1ull)) {
-                        index = rays_alive[slot];
-                        ws = weights_sum[index];
+                        if (early_ray) { index = early_index; ws = early_ws; }
+                        else { index = rays_alive[slot]; ws = weights_sum[index]; }
                         for (uint32_t k = 0; k < fstep; k++) {
                             if (!((live >> (lane + k)) & 1ull)) break;
                             const float T = 1.0f - ws;
@@ -516,8 +568,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
                             if (T < T_thresh) { stopped = true; break; }
                         }
                     } else if (leader && rs.rays_t) {
-                        index = rays_alive[slot];
-                        ws = weights_sum[index];
+                        if (early_ray) { index = early_index; ws = early_ws; }
+                        else { index = rays_alive[slot]; ws = weights_sum[index]; }
                     }
                     ex[lane * 3 + 1] = __int_as_float(index);
                     ex[lane * 3 + 2] = __int_as_float(cnt);
@@ -705,7 +757,7 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
     const bool stages_pre = a->aux_stride == pnr_palette_aux_channels(a->num_basis, a->clip_dim) && pnr_palette_field_stages_aux(a->num_basis, a->clip_dim, pp.pred_clip);
     const bool wide = nb4 && stages_pre && g_opt_palette_waves12 && packed_bytes + 12u * 32u * (a->aux_stride + 3u) * 4u <= 160u * 1024u;   // (the 12-wave kernels write their aux rows to LDS unconditionally)
     const uint32_t waves = wide ? 12u : 8u;
-    const uint32_t ntiles = cdiv(rows_ub ? rows_ub : 1, waves * 28);   // (a wave tile holds 28 ... 32 rows when it holds whole rays)
+    const uint32_t ntiles = cdiv(rows_ub ? rows_ub : 1, 28);   // wave tiles (a wave tile holds 28 ... 32 rows when it holds whole rays): dealt wave-major, see the kernel
     const uint32_t grid = ntiles < 256u ? ntiles : 256u;
     constexpr uint32_t kLdsLimit = 160 * 1024;
     // staging slab for coalesced aux rows: 8 waves x 32 rows x (aux_stride + 4) floats, when it fits next to the weights

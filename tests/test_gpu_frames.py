@@ -17,6 +17,10 @@ COLOUR_TOL = 1e-4
 # 5.3e-7 on depth and 2.9e-6 on depth_origin (values up to 2.4); no pixel is above 2e-5.  The looser bounds were never needed.
 EDIT_TOL = 1e-4
 DEPTH_TOL = 1e-4
+# Gradients against the reference-driven goldens, relative to the largest entry of each gradient.  Rounds 1-3 allowed 2e-3; measured in round 4
+# (profiles/grad_tolerance.py, profiles/r04_grad_tolerance.txt): 4e-7 ... 3.8e-5 (the worst: the table gradient of the translucent case b, whose
+# largest entry is 2.4e-8 -- fp32 sums of ~1e4 addends in a different order).  The bound is 4 x the worst measurement.
+GRAD_REL_TOL = 1.6e-4
 
 
 def load(golden_dir, name):
@@ -93,9 +97,9 @@ def test_nerf_training_step(cuda, golden_dir, case):
     loss.backward()
     scale = lambda a: max(1e-6, float(np.abs(a).max()))
     for got, key in ((m.color_net[0].weight.grad, "grad_color0"), (m.sigma_net[1].weight.grad, "grad_sigma1")):
-        close(got, g[key], tol=2e-3 * scale(g[key]), what=key)
+        close(got, g[key], tol=GRAD_REL_TOL * scale(g[key]), what=key)
     rows = torch.from_numpy(g["grad_emb_rows"]).to(cuda)
-    close(m.encoder.embeddings.grad[rows], g["grad_emb_vals"], tol=2e-3 * scale(g["grad_emb_vals"]), what="grad_emb")
+    close(m.encoder.embeddings.grad[rows], g["grad_emb_vals"], tol=GRAD_REL_TOL * scale(g["grad_emb_vals"]), what="grad_emb")
     assert abs(float(m.encoder.embeddings.grad.abs().sum()) / float(g["grad_emb_abs_sum"]) - 1) < 1e-3
 
 
@@ -147,9 +151,9 @@ def test_palette_training_step(cuda, golden_dir, case):
     loss.backward()
     scale = lambda a: max(1e-6, float(np.abs(a).max()))
     for got, key in ((m.offsets_radiance_net.weight.grad, "grad_offsets_radiance"), (m.basis_color.grad, "grad_basis_color"), (m.diff_net[0].weight.grad, "grad_diff0")):
-        close(got, g[key], tol=2e-3 * scale(g[key]), what=key)
+        close(got, g[key], tol=GRAD_REL_TOL * scale(g[key]), what=key)
     rows = torch.from_numpy(g["grad_emb_rows"]).to(cuda)
-    close(m.encoder_palette.embeddings.grad[rows], g["grad_emb_vals"], tol=2e-3 * scale(g["grad_emb_vals"]), what="grad_emb_palette")
+    close(m.encoder_palette.embeddings.grad[rows], g["grad_emb_vals"], tol=GRAD_REL_TOL * scale(g["grad_emb_vals"]), what="grad_emb_palette")
     assert (m.encoder.embeddings.grad is None) == bool(g["encoder_grad_is_none"])  # sigma is detached: geometry frozen
 
 

@@ -239,7 +239,9 @@ def test_palette_training_step_at_config3_size(cuda):
     assert set(g_ref) == set(g_fus) and "encoder.embeddings" not in g_fus and "encoder_palette.embeddings" in g_fus    # geometry frozen (sigma detached)
     for name in g_ref:
         scale = float(g_ref[name].abs().max())
-        assert float((g_ref[name] - g_fus[name]).abs().max()) <= 3e-3 * scale + 1e-9, name
+        # rounds 1-3 allowed 3e-3 of the largest entry; measured (profiles/r04_grad_tolerance.txt): 2.3e-8 ... 1.9e-6 -- both paths are fp32 with
+        # fp32 accumulation, they differ in summation order only.  Bound: 4 x the worst measurement, rounded up.
+        assert float((g_ref[name] - g_fus[name]).abs().max()) <= 1e-5 * scale + 1e-12, name
     # optimiser: same gradients, two identical models, one step each
     m2 = copy.deepcopy(m)
     for (n, p), (_, q) in zip(m.named_parameters(), m2.named_parameters()):
