@@ -615,7 +615,7 @@ struct GridArgs {
     const float* xyzs; const float* deltas;
     const void* table[3]; float* enc[3];
     const int32_t* offsets; LevelParams lp;
-    uint32_t level_stride; float bound, two_bound; uint32_t gridtype;
+    uint32_t level_stride; float bound, two_bound, inv_two_bound /* exact reciprocal when 2 * bound is a power of two, else 0 */; uint32_t gridtype;
 };
 // kind: how a row index is formed on this level (gridencoder.cu:49-72 evaluated once per level instead of once per corner) --
 //   0 the reference's general form (stride test per dimension, hash or tiled, `%`); 1 dense: side^3 <= size, the index is below the size and the
@@ -650,7 +650,11 @@ __device__ __forceinline__ bool grid_corner_rows(const GridArgs& g, const LevelC
     bool oob = false;
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-        in[d] = (g.xyzs[(size_t)b * 3 + d] + g.bound) / g.two_bound;
+        // GridEncoder.forward's (x + bound) / (2 bound) (gridencoder/grid.py:142).  With 2 * bound a power of two -- every shipped scene -- the division
+        // is an exact scaling and so is the multiplication by the exact reciprocal: same bits, one v_mul instead of the ~10-instruction IEEE
+        // division (three per (sample, level): an eighth of this kernel's vector instructions).  Any other bound divides.
+        const float sft = g.xyzs[(size_t)b * 3 + d] + g.bound;
+        in[d] = g.inv_two_bound != 0.0f ? sft * g.inv_two_bound : sft / g.two_bound;
         oob |= (in[d] < 0.0f) | (in[d] > 1.0f);
     }
     if (oob) return false;
@@ -1454,6 +1458,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             const uint32_t grid_lds = mode == 2 ? march_lds : 0u;
             GridArgs ga = {};
             ga.xyzs = w.xyzs; ga.deltas = w.deltas; ga.offsets = a->offsets; ga.lp = lp; ga.level_stride = N; ga.bound = a->bound; ga.two_bound = 2.0f * a->bound;
+            { int e2 = 0; const float mant = frexpf(ga.two_bound, &e2); ga.inv_two_bound = (mant == 0.5f && e2 > -100 && e2 < 100) ? 1.0f / ga.two_bound : 0.0f; }
             ga.gridtype = a->gridtype;
             ga.enc[0] = w.enc; ga.enc[1] = w.enc_pal; ga.enc[2] = w.enc_clip;
             // live timing of the roofline kernel: the launch carries its own start / stop events (hipExtLaunchKernelGGL: the dispatch's begin and end
