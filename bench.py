@@ -620,7 +620,7 @@ def measure_traffic(argv_core, kernel_substr="k_frame_grid", timeout=240):
     return (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, info
 
 
-def dropin_leg(args, device, bank, model_kind, steps):
+def dropin_leg(args, device, bank, model_kind, steps, fuse_field=False):
     """The operator-API path under the reference's own loop (north_star: "nerf/renderer.py and palette/renderer.py drop in unchanged"): this
     repository's mirror of run_cuda in its `compat` mode issues exactly what an unchanged run_cuda issues -- march_rays / GridEncoder /
     SHEncoder / composite_rays[_flex] through the per-op HIP kernels behind the reference's Python signatures, torch nn.Linear MLPs, the
@@ -630,14 +630,18 @@ def dropin_leg(args, device, bank, model_kind, steps):
     cargs = argparse.Namespace(**vars(args))
     cargs.mode, cargs.fp16, cargs.half_tables = "compat", False, False
     mm = build_model(cargs, device, model_kind)
+    if fuse_field:      # palettenerf_amd.dropin.fuse_field: the model's forward() = lookup op + ONE fused MFMA field launch; renderer loop and operator calls unchanged
+        from palettenerf_amd import dropin
+        dropin.fuse_field(mm, args.field_precision)
     kk = dict(perturb=False, dt_gamma=args.wl["dt_gamma"], max_steps=1024, T_thresh=1e-4)
     if model_kind == "palette":
         kk["gui_mode"] = False
     timed_frames(mm, bank, kk, 2, False)
     ms, rend = timed_frames(mm, bank, kk, steps, False, first_step=args.warmup)
     rec = {"ms_per_step": ms, "value": rend / (ms * 1e-3), "unit": "samples/s", "rendered_per_step": rend, "steps": steps, "march_mode": "compat",
-           "what": f"-m {model_kind} inference, {args.wl['H']}x{args.wl['W']}: per-op HIP kernels behind the reference's operator API + torch nn.Linear MLPs, the reference's loop "
-                   "(host-side boolean-mask compaction, one sync per iteration)"}
+           "what": f"-m {model_kind} inference, {args.wl['H']}x{args.wl['W']}: per-op HIP kernels behind the reference's operator API + "
+                   + ("dropin.fuse_field(model): forward() = lookup op + one fused MFMA field launch" if fuse_field else "torch nn.Linear MLPs")
+                   + ", the reference's loop (host-side boolean-mask compaction, one sync per iteration)"}
     # the stand-alone lookup op inside this loop: HIP events around every pnr_grid_encode_forward* call of one frame (rows include dead / padded slots)
     names = ["pnr_grid_encode_forward", "pnr_grid_encode_forward_layout"]
     prof = _torch_glue.profile_kernels(names)
@@ -1136,6 +1140,10 @@ def main(argv=None):
                     dropin[kind] = dropin_leg(args, device, bank, kind, max(5, n // 2))
                 except RuntimeError as e:
                     dropin[kind] = {"error": str(e)}
+            try:     # one step beyond the operator boundary: the same loop, the network's forward() served by the fused field (option A+)
+                dropin["nerf_fuse_field"] = dropin_leg(args, device, bank, "nerf", max(5, n // 2), fuse_field=True)
+            except RuntimeError as e:
+                dropin["nerf_fuse_field"] = {"error": str(e)}
             extra["dropin"] = dropin
             try:     # SURVEY Appendix B's other regime: the translucent field (density_scale 0.02): every ray marches to `far`, ~63 M samples per frame
                 targs = argparse.Namespace(**vars(args))

@@ -40,3 +40,28 @@ def install(patch_palette_utils=True):
         pu = sys.modules["palette.utils"]
         pu.rgb_to_hsv, pu.hsv_to_rgb = _pu.rgb_to_hsv, _pu.hsv_to_rgb
     return installed
+
+
+def fuse_field(model, precision="f16x3"):
+    """Opt-in, one step beyond the operator boundary: give a NeRFNetwork -- the REFERENCE's own class (nerf/network.py, built over the drop-in
+    encoders after install()) or this package's mirror -- the fused MFMA field kernel as its forward() for inference batches.  The reference's
+    renderer (`run_cuda`'s while loop, its boolean-mask compaction, its composite_rays calls) and its network file stay unchanged; what
+    changes is what `self(xyzs, dirs)` executes: one hash-grid lookup + ONE fused launch (sigma_net, SH, color_net, exp / sigmoid on the
+    matrix cores, pnr_nerf_field_forward) instead of encoder permute-copy + 5 GEMMs + 6 elementwise launches.  Same (sigma, rgb) to 2e-6
+    (tests/test_gpu_ops.py), images to 1e-4 of the reference-driven goldens (tests/test_gpu_frames.py).  Batches under autograd or autocast, and
+    CPU tensors, keep the model's own forward.  The model must have the shipped architecture (hashgrid 16 x 2, 64-wide nets, SH degree 4);
+    NeRFFieldFused raises otherwise.  precision: "f16x3" (split-fp16 products, fp32-class), "fp32" (exact fmaf chains) or "f16x2" (opt-in)."""
+    import torch
+    from .fused import NeRFFieldFused
+    fused = NeRFFieldFused(model)
+    fused.precision = {"fp32": 0, "f16x3": 1, "f16x2": 2}[precision]
+    plain = model.forward
+
+    def forward(x, d):
+        if torch.is_grad_enabled() or torch.is_autocast_enabled() or not x.is_cuda:
+            return plain(x, d)
+        return fused(x, d)
+
+    model._fused = fused
+    model.forward = forward      # instance attribute: nn.Module.__call__ resolves self.forward here
+    return model

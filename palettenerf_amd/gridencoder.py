@@ -59,7 +59,9 @@ class _grid_encode(Function):
              _u32(gridtype), _int(int(align_corners)), _int(_DTYPE_ID[table_dtype]), _int(1 if rows else 0), units=B)
         ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
         ctx.meta = (B, D, C, L, S, H, gridtype, bool(align_corners))
-        return out if rows else out.permute(1, 0, 2).reshape(B, L * C)
+        if rows:
+            return out
+        return out.permute(1, 0, 2).reshape(B, L * C)
 
     @staticmethod
     @custom_bwd(device_type="cuda")

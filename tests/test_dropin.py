@@ -67,6 +67,13 @@ def test_reference_network_constructs_on_dropin_modules():
         import palettenerf_amd.network as mine
         mm = mine.NeRFNetwork(bound=2, cuda_ray=True)
         assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in mm.state_dict().items()}
+        # dropin.fuse_field accepts the REFERENCE's class as it is (same attribute names as the mirror: encoder, encoder_dir, sigma_net, color_net,
+        # hidden_dim, ...): forward() becomes an instance attribute, the class and its renderer base stay untouched
+        class_forward = type(m).forward
+        assert dropin.fuse_field(m) is m and "forward" in m.__dict__ and type(m).forward is class_forward
+        assert [tuple(w.shape) for w in m._fused._weights()] == [(64, 32), (16, 64), (64, 31), (64, 64), (3, 64)]
+        with pytest.raises(RuntimeError):      # a different architecture is refused, not silently run on the wrong kernel
+            dropin.fuse_field(ref.NeRFNetwork(bound=2, cuda_ray=True, hidden_dim=32))
     finally:
         sys.path[:] = saved_path
         for k in [k for k in sys.modules if k not in saved]:

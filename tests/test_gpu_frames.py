@@ -80,6 +80,33 @@ _RENDERED = {}
 
 
 @pytest.mark.parametrize("case", ["a", "b"])
+def test_dropin_fuse_field_under_the_reference_style_loop(cuda, golden_dir, case):
+    """dropin.fuse_field(model): the per-op loop (march_rays / composite_rays / boolean-mask compaction, what an unchanged run_cuda issues) with
+    `self(xyzs, dirs)` served by the fused MFMA field -- against the reference-driven golden frame, and the same samples as every other mode."""
+    from palettenerf_amd import dropin
+    g = load(golden_dir, f"frame_nerf_{case}")
+    m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=float(g["density_scale"]), min_near=0.2)
+    scene.seed_field_(m, int(g["seed"]))
+    m = m.to(cuda).eval()
+    put_scene(m, cuda)
+    m.count_rendered = True
+    m.march_mode = "compat"
+    ro, rd = frame_rays(g, cuda)
+    with torch.no_grad():
+        plain = m.render(ro, rd, staged=True, dt_gamma=float(g["dt_gamma"]), perturb=False, max_steps=1024, T_thresh=1e-4)
+    assert dropin.fuse_field(m) is m and m.fused_field is False            # only forward() changed; the renderer's own switches are untouched
+    with torch.no_grad():
+        r = m.render(ro, rd, staged=True, dt_gamma=float(g["dt_gamma"]), perturb=False, max_steps=1024, T_thresh=1e-4)
+    close(r["image"], g["image"], what="image")
+    close(r["weights_sum"], g["weights_sum"], what="weights_sum")
+    close(r["depth"], g["depth"], tol=DEPTH_TOL, what="depth")
+    assert int(r["rendered"].item()) == int(plain["rendered"].item())      # same march, same termination
+    x = torch.rand(64, 3, device=cuda, requires_grad=True)                  # under autograd the model's own forward runs (and differentiates)
+    s_, c_ = m(x * 2 - 1, torch.nn.functional.normalize(torch.randn(64, 3, device=cuda), dim=-1))
+    assert s_.requires_grad and c_.requires_grad
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
 def test_nerf_training_step(cuda, golden_dir, case):
     g = load(golden_dir, f"train_nerf_{case}")
     m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=float(g["density_scale"]), min_near=0.2)
