@@ -358,6 +358,36 @@ def timed_frames(m, bank, kw, steps, fp16, first_step=0):
     return dt / steps * 1e3, rendered // steps
 
 
+def timed_frames_median(m, bank, kw, steps, first_step=0):
+    """Per-frame device time between events recorded behind each frame (no sync inside the loop), median and mean over `steps` frames.  The shard
+    emulation uses the median: a 2.8 ms shard frame is ~90 launches deep, and one host hiccup among five frames (another tenant's process on the
+    box's CPU) moves a mean by a third."""
+    import gc
+    import torch
+    for i in range(steps):
+        bank.get(first_step + i)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    rendered = 0
+    torch.cuda.synchronize()
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        evs[0].record()
+        for i in range(steps):
+            ro, rd = bank.get(first_step + i)
+            with torch.no_grad():
+                r = m.render(ro, rd, **kw)
+            rendered += int(r["rendered"].sum())
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+    finally:
+        if gc_was_on:
+            gc.enable()
+    ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+    return ms[steps // 2], sum(ms) / steps, rendered // steps
+
+
 # ------------------------------------------------------------------------------------------------ configs[3]: the training step
 def make_training_step(model_kind, rays, device, fp16=False, torch_adam=False, torch_loss=False):
     """configs[3]-shaped training step (main_palette.py:223 / palette/utils.py:481 on LLFF-like input): `rays` random rays per step from a
@@ -1202,17 +1232,20 @@ def main(argv=None):
                 gbank = RayBank(gargs, 1, full_idx, device)
                 gm._fused.ray_order = tile_ray_order(full_idx, gW, 8).to(device)
                 timed_frames(gm, gbank, gkw, 2, False)
-                full_ms, full_rend = timed_frames(gm, gbank, gkw, 5, False)
-                times, samples = [], []
+                full_ms, full_mean, full_rend = timed_frames_median(gm, gbank, gkw, 7)
+                times, means, samples = [], [], []
                 for sh in range(8):
                     sidx, _ = pdist.shard_indices(gH, gW, sh, 8)
                     sbank = RayBank(gargs, 1, sidx, device)
                     gm._fused.ray_order = tile_ray_order(sidx, gW, 8).to(device)
                     timed_frames(gm, sbank, gkw, 2, False)
-                    ms_, rend = timed_frames(gm, sbank, gkw, 5, False)
+                    ms_, mean_, rend = timed_frames_median(gm, sbank, gkw, 7)
                     times.append(ms_)
+                    means.append(mean_)
                     samples.append(rend)
-                extra["garden_shard_emulation_8"] = {"full_frame_ms": full_ms, "full_frame_samples": full_rend, "shard_ms": times, "shard_samples": samples,
+                extra["garden_shard_emulation_8"] = {"full_frame_ms": full_ms, "full_frame_ms_mean": full_mean, "full_frame_samples": full_rend, "shard_ms": times, "shard_ms_mean": means,
+                                                     "timing": "median of 7 frames each (device time between events behind consecutive frames); means beside them",
+                                                     "shard_samples": samples,
                                                      "max_shard_ms": max(times), "imbalance_max_over_mean": max(times) / (sum(times) / 8),
                                                      "speedup_before_all_gather": full_ms / max(times),
                                                      # what the all-gather would add on 8 GPUs (an ESTIMATE from SURVEY 8e's link figure, not a measurement: this box has one GPU):

@@ -621,19 +621,6 @@ struct GridArgs {
 //   0 the reference's general form (stride test per dimension, hash or tiled, `%`); 1 dense: side^3 <= size, the index is below the size and the
 //   `%` is the identity; 2 hashed with a power-of-two size: a mask.  All three give the same index (tests: every table layout against k_grid_fwd).
 struct LevelCtx { uint32_t off0, hashmap_size, resolution; float scale; uint32_t kind; };
-#ifndef PNR_GRID_KIND
-#define PNR_GRID_KIND 1     // 0: every level through the general form (the A/B of the specialised index forms)
-#endif
-__device__ __forceinline__ uint32_t level_kind(uint32_t gridtype, uint32_t hashmap_size, uint32_t resolution) {
-    if (!PNR_GRID_KIND) return 0u;
-    const uint32_t side = resolution + 1u;
-    if ((uint64_t)side * side * side <= (uint64_t)hashmap_size) return 1u;
-    uint32_t stride = 1u;
-#pragma unroll
-    for (uint32_t d = 0; d < 3; d++)
-        if (stride <= hashmap_size) stride *= side;
-    return (gridtype == 0u && stride > hashmap_size && (hashmap_size & (hashmap_size - 1u)) == 0u) ? 2u : 0u;
-}
 __device__ __forceinline__ LevelCtx level_ctx(const GridArgs& g, uint32_t level) {
     LevelCtx lc;
     lc.off0 = (uint32_t)g.offsets[level];
@@ -666,25 +653,7 @@ __device__ __forceinline__ bool grid_corner_rows(const GridArgs& g, const LevelC
         pg[d] = (uint32_t)fl;
         pos[d] -= (float)pg[d];
     }
-    if (lc.kind == 1u) {          // (wave-uniform in the level-major workgroups; per lane in the hosted tail)
-        const uint32_t side = lc.resolution + 1u;
-#pragma unroll
-        for (uint32_t idx = 0; idx < 8; idx++)
-            idxs[idx] = ((pg[0] + (idx & 1u)) + (pg[1] + ((idx >> 1) & 1u)) * side + (pg[2] + ((idx >> 2) & 1u)) * side * side) * CMUL;
-    } else if (lc.kind == 2u) {
-        const uint32_t mask = lc.hashmap_size - 1u;
-#pragma unroll
-        for (uint32_t idx = 0; idx < 8; idx++)
-            idxs[idx] = (((pg[0] + (idx & 1u)) ^ ((pg[1] + ((idx >> 1) & 1u)) * 2654435761u) ^ ((pg[2] + ((idx >> 2) & 1u)) * 805459861u)) & mask) * CMUL;
-    } else {
-#pragma unroll
-        for (uint32_t idx = 0; idx < 8; idx++) {
-            uint32_t pl[3];
-#pragma unroll
-            for (uint32_t d = 0; d < 3; d++) pl[d] = pg[d] + ((idx >> d) & 1u);
-            idxs[idx] = grid_index<3, CMUL>(g.gridtype, false, lc.hashmap_size, lc.resolution, pl);
-        }
-    }
+    corner_rows_by_kind<CMUL>(lc.kind, g.gridtype, lc.hashmap_size, lc.resolution, pg, idxs);   // (kind is wave-uniform in the level-major workgroups; 0 in the hosted tail)
     return true;
 }
 // trilinear weights in the reference's order of multiplications (gridencoder.cu:150-163)
@@ -1458,7 +1427,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             const uint32_t grid_lds = mode == 2 ? march_lds : 0u;
             GridArgs ga = {};
             ga.xyzs = w.xyzs; ga.deltas = w.deltas; ga.offsets = a->offsets; ga.lp = lp; ga.level_stride = N; ga.bound = a->bound; ga.two_bound = 2.0f * a->bound;
-            { int e2 = 0; const float mant = frexpf(ga.two_bound, &e2); ga.inv_two_bound = (mant == 0.5f && e2 > -100 && e2 < 100) ? 1.0f / ga.two_bound : 0.0f; }
+            ga.inv_two_bound = exact_reciprocal_or_zero(ga.two_bound);
             ga.gridtype = a->gridtype;
             ga.enc[0] = w.enc; ga.enc[1] = w.enc_pal; ga.enc[2] = w.enc_clip;
             // live timing of the roofline kernel: the launch carries its own start / stop events (hipExtLaunchKernelGGL: the dispatch's begin and end

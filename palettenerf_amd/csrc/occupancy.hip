@@ -205,15 +205,18 @@ __global__ void __launch_bounds__(256) k_occ_points(OccGeom g, uint32_t first, u
 
 // gridencoder.cu:75-175 for D = 3, C = 2, fp32 with GridEncoder.forward's (x + bound) / (2 bound) folded in (gridencoder/grid.py:142):
 // the loop of k_frame_grid over the sweep's points.  grid = (blocks, levels): a block column works on one level.
+// (round 4: what the frame lookup and the D3C2 op learnt -- finest levels dispatched first, the row index formed per kind of level, all eight
+// addresses before the first load and fresh destination registers, the exact reciprocal for power-of-two bounds; same bits as before.)
 __global__ void __launch_bounds__(256) k_occ_lookup(const float4* __restrict__ pts, uint32_t count, const float* __restrict__ table,
                                                     const int32_t* __restrict__ offsets, LevelParams lp, float* __restrict__ enc, uint32_t level_stride,
-                                                    float bound, float two_bound, uint32_t gridtype) {
-    const uint32_t level = blockIdx.y;
+                                                    float bound, float two_bound, float inv_two_bound, uint32_t gridtype) {
+    const uint32_t level = gridDim.y - 1u - blockIdx.y;
     const uint32_t off0 = (uint32_t)offsets[level];
     const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
-    const float* g = table + (size_t)off0 * 2;
+    const f32x2* g = reinterpret_cast<const f32x2*>(table) + off0;
     const float scale = lp.scale[level];
     const uint32_t resolution = lp.resolution[level];
+    const uint32_t kind = level_kind(gridtype, hashmap_size, resolution);
     for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < count; b += gridDim.x * 256) {
         const float4 p = pts[b];
         if (__float_as_int(p.w) < 0) continue;
@@ -222,7 +225,8 @@ __global__ void __launch_bounds__(256) k_occ_lookup(const float4* __restrict__ p
         bool oob = false;
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-            in[d] = (x[d] + bound) / two_bound;
+            const float sft = x[d] + bound;
+            in[d] = inv_two_bound != 0.0f ? sft * inv_two_bound : sft / two_bound;
             oob |= (in[d] < 0.0f) | (in[d] > 1.0f);
         }
         float2 out = make_float2(0.0f, 0.0f);
@@ -237,22 +241,20 @@ __global__ void __launch_bounds__(256) k_occ_lookup(const float4* __restrict__ p
                 pos[d] -= (float)pg[d];
             }
             uint32_t idxs[8];
-            float ws[8];
+            corner_rows_by_kind<1>(kind, gridtype, hashmap_size, resolution, pg, idxs);
+            const f32x2* ptr8[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) ptr8[i] = g + idxs[i];
+            f32x2 v[8];
+            load8_fresh(ptr8, v);
+            float acc[2] = {0.0f, 0.0f};
 #pragma unroll
             for (uint32_t idx = 0; idx < 8; idx++) {
                 float w = 1.0f;
-                uint32_t pl[3];
 #pragma unroll
-                for (uint32_t d = 0; d < 3; d++) {
-                    if ((idx & (1u << d)) == 0) { w *= 1.0f - pos[d]; pl[d] = pg[d]; }
-                    else { w *= pos[d]; pl[d] = pg[d] + 1; }
-                }
-                ws[idx] = w;
-                idxs[idx] = grid_index<3, 2>(gridtype, false, hashmap_size, resolution, pl);
+                for (uint32_t d = 0; d < 3; d++) w *= (idx & (1u << d)) ? pos[d] : 1.0f - pos[d];
+                acc[0] = fmaf(w, v[idx].x, acc[0]); acc[1] = fmaf(w, v[idx].y, acc[1]);
             }
-            float acc[2] = {0.0f, 0.0f};
-#pragma unroll
-            for (uint32_t idx = 0; idx < 8; idx++) corner_accumulate<2>(acc, ws[idx], g + idxs[idx]);
             out = make_float2(acc[0], acc[1]);
         }
         *reinterpret_cast<float2*>(enc + ((size_t)level * level_stride + b) * 2) = out;
@@ -480,7 +482,7 @@ int pnr_occupancy_update(const pnr_occupancy_args* a, pnr_stream_t stream) {
         if (rc != PNR_OK) return rc;
         const uint32_t bx = cdiv(count, 256);
         hipLaunchKernelGGL(k_occ_lookup, dim3(bx, a->num_levels), dim3(256), 0, s, reinterpret_cast<const float4*>(pts), count, a->embeddings, a->offsets, lp,
-                           w.enc, w.chunk, a->bound, 2.0f * a->bound, a->gridtype);
+                           w.enc, w.chunk, a->bound, 2.0f * a->bound, exact_reciprocal_or_zero(2.0f * a->bound), a->gridtype);
         const uint32_t grid = bx < 1024u ? bx : 1024u;
         hipLaunchKernelGGL(k_occ_sigma, dim3(grid), dim3(512), 0, s, reinterpret_cast<const float4*>(pts), count, w.enc, w.chunk, a->packed_sigma_net,
                            a->density_scale, w.tmp);

@@ -1,0 +1,6 @@
+#!/bin/bash
+R=$PWD; export TMPDIR=/tmp
+O=$R/gpurun_out/r04; mkdir -p $O
+timeout 1500 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; echo "pytest rc $?" >> $O/pytest_gpu.log
+timeout 300 python profiles/extra_state_bench.py > $O/extra_state.log 2>&1
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_default.log 2>&1; echo "bench rc $?" >> $O/bench_default.log

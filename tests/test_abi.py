@@ -59,6 +59,15 @@ def test_argument_validation_without_gpu():
     # empty inputs are a no-op
     assert lib.pnr_morton3d(None, u32(0), None, None) == 0
     assert lib.pnr_march_rays(u32(0), u32(4), *([None] * 4), f32(2), f32(0), u32(1024), u32(2), u32(128), *([None] * 8)) == 0
+    # round 4 entry points: the layout flag and the self-filling march validate before they launch
+    assert lib.pnr_grid_encode_forward_layout(None, None, None, None, u32(8), u32(3), u32(2), u32(16), f32(1.0), u32(16), None, u32(0), i32(0), i32(0), i32(2), None) == -1   # unknown layout
+    assert lib.pnr_grid_encode_forward_layout(None, None, None, None, u32(0), u32(3), u32(2), u32(16), f32(1.0), u32(16), None, u32(0), i32(0), i32(0), i32(1), None) == 0    # empty batch
+    assert lib.pnr_grid_encode_forward_layout(None, None, None, None, u32(8), u32(3), u32(2), u32(16), f32(1.0), u32(16), None, u32(0), i32(0), i32(0), i32(1), None) == -1   # null pointers
+    assert lib.pnr_grid_encode_forward_layout(None, None, None, None, u32(8), u32(3), u32(2), u32(40), f32(1.0), u32(16), None, u32(0), i32(0), i32(0), i32(0), None) == -2   # > 32 levels
+    # fill_rows smaller than the rows the march itself may write is a caller bug, not a silent overrun
+    assert lib.pnr_march_rays_fill(u32(10), u32(4), *([None] * 4), f32(2), f32(0), u32(1024), u32(2), u32(128), *([None] * 8), u32(39), None) == -1
+    assert lib.pnr_march_rays_fill(u32(0), u32(4), *([None] * 4), f32(2), f32(0), u32(1024), u32(2), u32(128), *([None] * 8), u32(0), None) == 0
+    assert lib.pnr_set_option(b"grid_fast", 1) == 0 and lib.pnr_set_option(b"grid_nt", 0) == 0 and lib.pnr_set_option(b"no_such_option", 1) == -1
 
 
 def test_palette_field_sizes_and_limits_without_gpu():

@@ -63,3 +63,15 @@ def test_world_from_env(monkeypatch):
         bench.world_from_env(bench.parse(["--gpus", "8"]), [])
     with pytest.raises(SystemExit, match="must agree"):
         bench.world_from_env(bench.parse([]), [])
+
+
+def test_bench_helpers_without_a_gpu():
+    """core_argv (what bench.py's rocprofv3 --pmc child passes repeat) round-trips through parse(); l2_bound_of is plain arithmetic."""
+    import bench
+    args = bench.parse(["--workload", "garden", "--density-scale", "0.5", "--field-precision", "fp32", "--static-pose", "--num-basis", "6", "--dt-gamma", "0.01"])
+    again = bench.parse(bench.core_argv(args) + ["--steps", "3"])
+    for k in ("workload", "density_scale", "field_precision", "static_pose", "num_basis", "ray_order", "fp16", "half_tables", "pred_clip", "no_interleave", "mode", "scene"):
+        assert getattr(args, k) == getattr(again, k), k
+    assert again.wl["dt_gamma"] == 0.01 and again.steps == 3
+    b = bench.l2_bound_of(365482, 1, 0.0766)
+    assert b["lane_requests_per_launch"] == 365482 * 128 and 0.9 < b["lane_requests_per_clk_per_cu"] < 1.1
