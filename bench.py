@@ -1170,10 +1170,11 @@ def main(argv=None):
                     dropin[kind] = dropin_leg(args, device, bank, kind, max(5, n // 2))
                 except RuntimeError as e:
                     dropin[kind] = {"error": str(e)}
-            try:     # one step beyond the operator boundary: the same loop, the network's forward() served by the fused field (option A+)
-                dropin["nerf_fuse_field"] = dropin_leg(args, device, bank, "nerf", max(5, n // 2), fuse_field=True)
-            except RuntimeError as e:
-                dropin["nerf_fuse_field"] = {"error": str(e)}
+            for kind in ("nerf", "palette"):     # one step beyond the operator boundary: the same loop, the network's forward() served by the fused field (option A+)
+                try:
+                    dropin[kind + "_fuse_field"] = dropin_leg(args, device, bank, kind, max(5, n // 2), fuse_field=True)
+                except RuntimeError as e:
+                    dropin[kind + "_fuse_field"] = {"error": str(e)}
             extra["dropin"] = dropin
             try:     # SURVEY Appendix B's other regime: the translucent field (density_scale 0.02): every ray marches to `far`, ~63 M samples per frame
                 targs = argparse.Namespace(**vars(args))

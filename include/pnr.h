@@ -336,11 +336,15 @@ int pnr_nerf_render_frame(const pnr_nerf_frame_args* args, pnr_stream_t stream);
  *           weight = exp(-|xyz - mean_xyz|^2 / std_xyz) * exp(-|clip_feat - mean_clip|^2 / std_clip) (each factor only when its mean is set);
  *           weight_mode != 0 returns the weight itself in every channel (the GUI's region preview).
  *   mode 2  Stylizer.forward (palette/renderer.py:166-183): rgb = sum_b omega_b clamp(max(softplus(r) + dI_b, 0) (P_b + dP_b + offsets_b . ddelta_b), 0, 1)
- *           + view_dep  (offsets_weight / view_dep_weight do not apply, as in the reference). */
+ *           + view_dep  (offsets_weight / view_dep_weight do not apply, as in the reference).
+ *   mode 3  (pnr_palette_field_forward only) "network heads": no composite at all -- the aux row is what PaletteNetwork.forward returns per sample
+ *           (palette/network.py:156-190): omega nb (normalised) | offsets_radiance 3 nb + 1 (raw, bias added) | view_dep 3 | diffuse 3 |
+ *           clip_feat clip_dim | 0-pad; sigmas = density_scale * exp(logit), rgbs = 0.  For callers that keep the reference's own renderer
+ *           arithmetic (palette/renderer.py:452-499) and only want the network as one launch (palettenerf_amd.dropin.fuse_field). */
 #define PNR_MAX_BASIS 10
 #define PNR_MAX_CLIP 32
 typedef struct pnr_palette_edit {
-    int mode;                                /* 0 none, 1 RegionEdit, 2 Stylizer */
+    int mode;                                /* 0 none, 1 RegionEdit, 2 Stylizer, 3 network heads (stand-alone op only) */
     float delta_hsv[PNR_MAX_BASIS][3];
     int has_mean_xyz;  float mean_xyz[3];  float std_xyz;
     int has_mean_clip; float mean_clip[PNR_MAX_CLIP]; float std_clip;   /* has_mean_clip = number of entries (the model's clip_dim), 0 = not set */

@@ -234,6 +234,9 @@ __device__ __forceinline__ void load_enc_rows8(const float* __restrict__ enc, si
 #pragma unroll
         for (int q = 0; q < 4; q++) { x[kb][2 * q] = valid ? v[4 * kb + q].x : 0.0f; x[kb][2 * q + 1] = valid ? v[4 * kb + q].y : 0.0f; }
 }
+#ifndef PNR_NERF_SPLIT_PER_BLOCK
+#define PNR_NERF_SPLIT_PER_BLOCK 1
+#endif
 template <bool CHECK, bool LO = true>
 __device__ __forceinline__ FieldOut nerf_field_tile_f16x3(const unsigned char* __restrict__ w, int lane, bool valid, const float* __restrict__ enc,
                                                           size_t level_stride, uint32_t row, float dx, float dy, float dz, float enc_scale,
@@ -259,12 +262,22 @@ __device__ __forceinline__ FieldOut nerf_field_tile_f16x3(const unsigned char* _
     __builtin_amdgcn_sched_barrier(0);
     h0 = relu16(h0); h1 = relu16(h1);
 
-    // sigma_net[1]: 64 -> 16
+    // sigma_net[1]: 64 -> 16.  (PNR_NERF_SPLIT_PER_BLOCK: each k-block's activations are split right in front of its products, so that hipcc threads
+    // block k + 1's split between block k's matrix instructions -- profiles/micro/mfma_interleave.hip: 134 against 158 cycles per block for
+    // "threaded" against "all splits, then the chain"; same products in the same order per accumulator: same bits.)
+    f32x16 g = zero16();
+#if PNR_NERF_SPLIT_PER_BLOCK
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) {
+        split_frag_w(sw, kb < 2 ? h0 : h1, kb & 1, bh[0], bl[0]);
+        g = mma3(g, w + (4 + kb) * kF16BlockBytes, bh[0], bl[0], lane);
+    }
+#else
     split_frag_w(sw, h0, 0, bh[0], bl[0]); split_frag_w(sw, h0, 1, bh[1], bl[1]);
     split_frag_w(sw, h1, 0, bh[2], bl[2]); split_frag_w(sw, h1, 1, bh[3], bl[3]);
-    f32x16 g = zero16();
 #pragma unroll
     for (int kb = 0; kb < 4; kb++) g = mma3(g, w + (4 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     if (enc_scale != 1.0f) {
         const float inv = 1.0f / enc_scale;
@@ -293,22 +306,39 @@ __device__ __forceinline__ FieldOut nerf_field_tile_f16x3(const unsigned char* _
     c0 = relu16(c0); c1 = relu16(c1);
 
     // color_net[1]: 64 -> 64
+    f32x16 d0 = zero16(), d1 = zero16();
+#if PNR_NERF_SPLIT_PER_BLOCK
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) {
+        splitx_frag_w<LO>(sw, kb < 2 ? c0 : c1, kb & 1, bh[0], bl[0]);
+        d0 = mmax<LO>(d0, w + (12 + kb) * kF16BlockBytes, bh[0], bl[0], lane);
+        d1 = mmax<LO>(d1, w + (16 + kb) * kF16BlockBytes, bh[0], bl[0], lane);
+    }
+#else
     splitx_frag_w<LO>(sw, c0, 0, bh[0], bl[0]); splitx_frag_w<LO>(sw, c0, 1, bh[1], bl[1]);
     splitx_frag_w<LO>(sw, c1, 0, bh[2], bl[2]); splitx_frag_w<LO>(sw, c1, 1, bh[3], bl[3]);
-    f32x16 d0 = zero16(), d1 = zero16();
 #pragma unroll
     for (int kb = 0; kb < 4; kb++) d0 = mmax<LO>(d0, w + (12 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
 #pragma unroll
     for (int kb = 0; kb < 4; kb++) d1 = mmax<LO>(d1, w + (16 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     d0 = relu16(d0); d1 = relu16(d1);
 
     // color_net[2]: 64 -> 3
+    f32x16 o = zero16();
+#if PNR_NERF_SPLIT_PER_BLOCK
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) {
+        splitx_frag_w<LO>(sw, kb < 2 ? d0 : d1, kb & 1, bh[0], bl[0]);
+        o = mmax<LO>(o, w + (20 + kb) * kF16BlockBytes, bh[0], bl[0], lane);
+    }
+#else
     splitx_frag_w<LO>(sw, d0, 0, bh[0], bl[0]); splitx_frag_w<LO>(sw, d0, 1, bh[1], bl[1]);
     splitx_frag_w<LO>(sw, d1, 0, bh[2], bl[2]); splitx_frag_w<LO>(sw, d1, 1, bh[3], bl[3]);
-    f32x16 o = zero16();
 #pragma unroll
     for (int kb = 0; kb < 4; kb++) o = mmax<LO>(o, w + (20 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
+#endif
     out.o0 = o[0]; out.o1 = o[1]; out.o2 = o[2];
     return out;
 }

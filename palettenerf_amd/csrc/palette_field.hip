@@ -458,6 +458,37 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
                 else put_tail(idx, v);
             };
             float* ex = reinterpret_cast<float*>(w + packed_bytes) + (size_t)WAVES * 32 * stage_stride + (size_t)wave * 96;
+            if constexpr (EDIT == 3) {
+                // "network heads" (pnr_palette_edit.mode 3): the row is what PaletteNetwork.forward returns per sample (palette/network.py:156-190) --
+                // [omega nb (normalised) | offsets_radiance 3 nb + 1 (raw, bias added) | view_dep 3 | diffuse 3 | clip_feat clip_dim | 0-pad] -- and the
+                // colour-basis composite is left to the caller (the reference's renderer does it with torch ops).  sigmas = density_scale * exp(logit).
+#pragma unroll
+                for (int b = 0; b < kLoopNb; b++) if (NB || b < nb) put(b, omega[b] / osum);
+#pragma unroll
+                for (int j = 0; j < 3 * kLoopNb + 1; j++) if (NB || j < 3 * nb + 1) put(nb + j, orv(j));
+#pragma unroll
+                for (int k = 0; k < 3; k++) { put(4 * nb + 1 + k, view_dep[k]); put(4 * nb + 4 + k, diffuse[k]); }
+                int c = 4 * nb + 7;
+                if constexpr (kRowRegs) {
+#pragma unroll
+                    for (int q = 23; q < 32; q++) rowv[q] = 0.0f;      // (4 bases: 23 values; the rest of the 32 staged floats)
+                    typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+                    lds_f32x4* a4 = reinterpret_cast<lds_f32x4*>(reinterpret_cast<uintptr_t>(a));
+#pragma unroll
+                    for (int q = 0; q < 8; q++) { f32x4 v4; v4.x = rowv[4 * q]; v4.y = rowv[4 * q + 1]; v4.z = rowv[4 * q + 2]; v4.w = rowv[4 * q + 3]; a4[q] = v4; }
+                    c = 32;
+                }
+                if (pp.pred_clip) {
+                    const int c0 = 4 * nb + 7;
+#pragma unroll
+                    for (int k = 0; k < PNR_MAX_CLIP; k++) if (k < pp.clip_dim) put_tail(c0 + k, k < 16 ? clip[k & 15] : clip2[k & 15]);
+                    if (c < c0 + pp.clip_dim) c = c0 + pp.clip_dim;
+                }
+                for (; c < pp.aux_stride; c++) put_tail(c, 0.0f);
+                sigmas[n] = pp.density_scale * __expf(sigma_logit);
+#pragma unroll
+                for (int k = 0; k < 3; k++) rgbs[(size_t)n * 3 + k] = 0.0f;
+            } else {
 #pragma unroll
             for (int k = 0; k < 3; k++) { put(k, diffuse[k] + view_dep[k]); put(3 + k, view_dep[k]); }   // direct_rgb, view_dep_rgb
 #pragma unroll
@@ -538,6 +569,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
             const float kvd = EDIT == 2 ? 1.0f : pp.view_dep_weight;   // the Stylizer adds view_dep unscaled (palette/renderer.py:181)
 #pragma unroll
             for (int k = 0; k < 3; k++) { rgb_out[k] = rgb[k] + kvd * view_dep[k]; if (!rs.rays_t) rgbs[(size_t)n * 3 + k] = rgb_out[k]; }
+            }   // EDIT != 3
         }
         if constexpr (CHECK) { if (overflow_flag && sw_.overflowed()) *overflow_flag = 1; }
         if (stage_stride) {   // same wave wrote the slab: DS operations of a wave complete in order
@@ -740,7 +772,8 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
     if (!a->enc || !a->enc_palette || !a->dirs || !a->packed || !a->sigmas || !a->rgbs || !a->aux) return PNR_ERR_INVALID;
     if (a->pred_clip && !a->enc_clip) return PNR_ERR_INVALID;
     const int edit_mode = a->edit ? a->edit->mode : 0;
-    if (edit_mode < 0 || edit_mode > 2) return PNR_ERR_UNSUPPORTED;
+    if (edit_mode < 0 || edit_mode > 3) return PNR_ERR_UNSUPPORTED;
+    if (edit_mode == 3 && (a->ctl || a->overflow_flag)) return PNR_ERR_UNSUPPORTED;   // the network-heads row is a stand-alone op (no frame loop, no watch)
     if (edit_mode == 1 && a->edit->has_mean_xyz && !a->xyzs) return PNR_ERR_INVALID;
     PaletteParams pp;
     pp.density_scale = a->density_scale; pp.offsets_weight = a->offsets_weight; pp.view_dep_weight = a->view_dep_weight;
@@ -774,7 +807,7 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
     const EditParams* ep_dev = nullptr;
     int edit_slot = -1;
     if (edit_mode && a->edit_device) ep_dev = static_cast<const EditParams*>(a->edit_device);   // frame loop: uploaded once per frame
-    else if (edit_mode) {   // this call's parameters go into the next slot of the device's ring (async copy on the launch stream)
+    else if (edit_mode == 1 || edit_mode == 2) {   // this call's parameters go into the next slot of the device's ring (async copy on the launch stream)
         EditRing& ring = g_edit_ring[current_device()];
         {
             std::lock_guard<std::mutex> lock(g_edit_ring_mutex);
@@ -790,7 +823,7 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
         if (hipMemcpyAsync(ring.dev + edit_slot, &e, sizeof(EditParams), hipMemcpyHostToDevice, s) != hipSuccess) return PNR_ERR_LAUNCH;
         ep_dev = ring.dev + edit_slot;
     }
-    static bool attr_set[4][3][kMaxDevices] = {};   // [PREC + 2 * CHECK][EDIT]
+    static bool attr_set[4][4][kMaxDevices] = {};   // [PREC + 2 * CHECK][EDIT]
 #define PNR_LAUNCH_PAL(PREC, EDIT, CHECK) PNR_LAUNCH_PAL_NB(PREC, EDIT, CHECK, 0, 8, attr_set[PREC + (CHECK ? 2 : 0)][EDIT])
 #define PNR_LAUNCH_PAL_NB(PREC, EDIT, CHECK, NB, WAVES, FLAGS)                                                                                 \
     do {                                                                                                                                       \
@@ -808,6 +841,8 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
         // the shipped default of 4 bases (main_palette.py:76): specialised epilogue, 12-wave workgroups when the staging fits
         if (x2 && wide) PNR_LAUNCH_PAL_NB(2, 0, false, 4, 12, attr_nb4[6]);
         else if (x2) PNR_LAUNCH_PAL_NB(2, 0, false, 4, 8, attr_nb4[7]);
+        else if (edit_mode == 3 && nb4 && wide) { static bool attr_heads[kMaxDevices] = {}; PNR_LAUNCH_PAL_NB(1, 3, false, 4, 12, attr_heads); }
+        else if (edit_mode == 3) PNR_LAUNCH_PAL(1, 3, false);
         else if (nb4 && wide && edit_mode == 0) PNR_LAUNCH_PAL_NB(1, 0, false, 4, 12, attr_nb4[0]);
         else if (nb4 && wide && edit_mode == 1) PNR_LAUNCH_PAL_NB(1, 1, false, 4, 12, attr_nb4[1]);
         else if (nb4 && wide) PNR_LAUNCH_PAL_NB(1, 2, false, 4, 12, attr_nb4[2]);
@@ -816,7 +851,8 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
         else if (nb4) PNR_LAUNCH_PAL_NB(1, 2, false, 4, 8, attr_nb4[5]);
         else if (edit_mode == 0) PNR_LAUNCH_PAL(1, 0, false); else if (edit_mode == 1) PNR_LAUNCH_PAL(1, 1, false); else PNR_LAUNCH_PAL(1, 2, false);
     } else {
-        if (edit_mode == 0) PNR_LAUNCH_PAL(0, 0, false); else if (edit_mode == 1) PNR_LAUNCH_PAL(0, 1, false); else PNR_LAUNCH_PAL(0, 2, false);
+        if (edit_mode == 0) PNR_LAUNCH_PAL(0, 0, false); else if (edit_mode == 1) PNR_LAUNCH_PAL(0, 1, false); else if (edit_mode == 2) PNR_LAUNCH_PAL(0, 2, false);
+        else PNR_LAUNCH_PAL(0, 3, false);
     }
 #undef PNR_LAUNCH_PAL
 #undef PNR_LAUNCH_PAL_NB

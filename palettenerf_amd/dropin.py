@@ -43,7 +43,7 @@ def install(patch_palette_utils=True):
 
 
 def fuse_field(model, precision="f16x3"):
-    """Opt-in, one step beyond the operator boundary: give a NeRFNetwork -- the REFERENCE's own class (nerf/network.py, built over the drop-in
+    """Opt-in, one step beyond the operator boundary: give a NeRFNetwork or PaletteNetwork -- the REFERENCE's own class (nerf/network.py, built over the drop-in
     encoders after install()) or this package's mirror -- the fused MFMA field kernel as its forward() for inference batches.  The reference's
     renderer (`run_cuda`'s while loop, its boolean-mask compaction, its composite_rays calls) and its network file stay unchanged; what
     changes is what `self(xyzs, dirs)` executes: one hash-grid lookup + ONE fused launch (sigma_net, SH, color_net, exp / sigmoid on the
@@ -52,15 +52,24 @@ def fuse_field(model, precision="f16x3"):
     CPU tensors, keep the model's own forward.  The model must have the shipped architecture (hashgrid 16 x 2, 64-wide nets, SH degree 4);
     NeRFFieldFused raises otherwise.  precision: "f16x3" (split-fp16 products, fp32-class), "fp32" (exact fmaf chains) or "f16x2" (opt-in)."""
     import torch
-    from .fused import NeRFFieldFused
-    fused = NeRFFieldFused(model)
-    fused.precision = {"fp32": 0, "f16x3": 1, "f16x2": 2}[precision]
+    from .fused import NeRFFieldFused, PaletteFieldFused
     plain = model.forward
+    if hasattr(model, "encoder_palette"):
+        # PaletteNetwork (palette/network.py): forward(x, d) -> (sigma, clip_feat, omega, offsets_radiance, view_dep, diffuse) from two (three) lookups +
+        # ONE fused launch (12-14 layers, SH, ELU, the heads' softplus normalisation; pnr_palette_field_forward with the network-heads row).  The
+        # colour-basis composite, RegionEdit / Stylizer and the seven composite_rays_flex calls stay the reference renderer's own code.
+        fused = PaletteFieldFused(model)
+        fused.precision = {"fp32": 0, "f16x3": 1, "f16x2": 1}[precision]
+        run = fused.network_forward
+    else:
+        fused = NeRFFieldFused(model)
+        fused.precision = {"fp32": 0, "f16x3": 1, "f16x2": 2}[precision]
+        run = fused.__call__
 
     def forward(x, d):
         if torch.is_grad_enabled() or torch.is_autocast_enabled() or not x.is_cuda:
             return plain(x, d)
-        return fused(x, d)
+        return run(x, d)
 
     model._fused = fused
     model.forward = forward      # instance attribute: nn.Module.__call__ resolves self.forward here

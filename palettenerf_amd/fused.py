@@ -660,7 +660,22 @@ class PaletteFieldFused(_PrecisionGuard, _SourceWatch):
                                            "grid_ms": float(kms[0]), "grid_launches": int(kms[1])}
 
     @torch.no_grad()
-    def __call__(self, x, d, deltas=None):
+    def network_forward(self, x, d):
+        """PaletteNetwork.forward(x, d) (palette/network.py:156-190) as ONE launch behind the lookups: returns what the reference's method returns --
+        (sigma [B] unscaled, clip_feat [B, clip_dim], omega [B, nb] normalised, offsets_radiance [B, 3 nb + 1], view_dep [B, 3], diffuse [B, 3]) --
+        the last five as slices of one packed row (pnr_palette_edit.mode 3).  Inference only (no autograd graph)."""
+        heads = _lib.PaletteEdit()
+        heads.mode = 3
+        sigmas, _, row = self(x, d, _edit=heads, _density_scale=1.0)
+        nb, cd = self.nb, int(self.model.opt.clip_dim)
+        omega = row[:, :nb]
+        offsets_radiance = row[:, nb:4 * nb + 1]
+        view_dep = row[:, 4 * nb + 1:4 * nb + 4]
+        diffuse = row[:, 4 * nb + 4:4 * nb + 7]
+        clip_feat = row[:, 4 * nb + 7:4 * nb + 7 + cd] if self.pred_clip else sigmas.new_zeros(sigmas.shape[0], cd)    # palette/network.py:179
+        return sigmas, clip_feat, omega, offsets_radiance, view_dep, diffuse
+
+    def __call__(self, x, d, deltas=None, _edit=None, _density_scale=None):
         """x [B,3] world positions, d [B,3] -> (sigmas [B] scaled by density_scale, rgbs [B,3], aux [B, aux_channels])."""
         m = self.model
         lib = _lib.load()
@@ -682,13 +697,15 @@ class PaletteFieldFused(_PrecisionGuard, _SourceWatch):
         a.deltas = deltas.data_ptr() if deltas is not None else None
         a.packed = self._pack().data_ptr()
         a.num_basis, a.clip_dim, a.pred_clip = self.nb, self.clip_dim, int(self.pred_clip)
-        a.density_scale, a.offsets_weight, a.view_dep_weight = float(m.density_scale), float(m.offsets_weight), float(m.view_dep_weight)
+        a.density_scale, a.offsets_weight, a.view_dep_weight = float(m.density_scale if _density_scale is None else _density_scale), float(m.offsets_weight), float(m.view_dep_weight)
         a.aux_stride = self.aux_channels
         a.sigmas, a.rgbs, a.aux = sigmas.data_ptr(), rgbs.data_ptr(), aux.data_ptr()
         a.precision = int(self.effective_precision())
+        if _edit is not None and a.precision == 2:
+            a.precision = 1          # (the rounded-activation form exists for the composite kernels only)
         for k, v in enumerate(self.enc_scales()):
             a.enc_scale[k] = v
-        edit = self._edit_struct()
+        edit = self._edit_struct() if _edit is None else _edit
         a.edit = ctypes.cast(ctypes.pointer(edit), ctypes.c_void_p) if edit is not None else None
         xw = require(x.contiguous(), torch.float32, "xyzs")
         a.xyzs = xw.data_ptr()

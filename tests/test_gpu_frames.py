@@ -160,6 +160,28 @@ def test_palette_inference_frame_all_maps_and_edit(cuda, golden_dir, case):
 
 
 @pytest.mark.parametrize("case", ["a", "b"])
+def test_dropin_fuse_field_palette_under_the_reference_style_loop(cuda, golden_dir, case):
+    """dropin.fuse_field on a PaletteNetwork: the per-op loop with the renderer's own colour-basis arithmetic and its seven flex composites, only
+    `self(xyzs, dirs)` served by the fused kernel's network-heads row -- all maps against the reference-driven golden frame (case b: clip head)."""
+    from palettenerf_amd import dropin
+    g = load(golden_dir, f"frame_palette_{case}")
+    opt = renderer.default_opt(pred_clip=bool(g["pred_clip"]))
+    m = network.PaletteNetwork(opt, bound=2, cuda_ray=True, density_scale=float(g["density_scale"]), min_near=0.2)
+    scene.seed_field_(m, int(g["seed"]))
+    m = m.to(cuda).eval()
+    put_scene(m, cuda)
+    m.march_mode = "compat"
+    dropin.fuse_field(m)
+    assert m.fused_field is False
+    ro, rd = frame_rays(g, cuda)
+    with torch.no_grad():
+        r = m.render(ro, rd, dt_gamma=float(g["dt_gamma"]), perturb=False, max_steps=1024, T_thresh=1e-4, gui_mode=False)
+    for k in ("image", "weights_sum", "clip_feat", "direct_rgb", "view_dep_rgb", "basis_rgb", "unscaled_basis_rgb", "basis_acc"):
+        close(r[k], g[k], what=k)
+    close(r["depth"], g["depth"], tol=DEPTH_TOL, what="depth")
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
 def test_palette_training_step(cuda, golden_dir, case):
     g = load(golden_dir, f"train_palette_{case}")
     opt = renderer.default_opt(pred_clip=bool(g["pred_clip"]))

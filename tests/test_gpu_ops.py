@@ -726,6 +726,35 @@ def test_fused_palette_field_matches_torch_module(cuda, pred_clip):
 
 
 
+@pytest.mark.parametrize("nb,clip_dim,pred_clip,precision", [(4, 16, False, 1), (4, 16, True, 1), (6, 16, False, 1), (8, 32, True, 1), (4, 16, False, 0), (3, 8, True, 0)])
+def test_fused_palette_network_heads_match_the_torch_module(cuda, nb, clip_dim, pred_clip, precision):
+    """PaletteFieldFused.network_forward (pnr_palette_edit.mode 3: the kernel's row = what PaletteNetwork.forward returns, no composite) against
+    the torch module, output by output -- 4 bases on the 12-wave kernel, other shapes on the generic one, split-fp16 and exact fp32."""
+    from palettenerf_amd import network, renderer
+    from palettenerf_amd.fused import PaletteFieldFused
+    rng = np.random.default_rng(62)
+    opt = renderer.default_opt(pred_clip=pred_clip, num_basis=nb, clip_dim=clip_dim)
+    m = network.PaletteNetwork(opt, bound=2, cuda_ray=True, density_scale=3.0)
+    scene.seed_field_(m, 11 + nb)
+    m = m.to(cuda).eval()
+    fused = PaletteFieldFused(m)
+    fused.precision = precision
+    for B in (1, 33, 385, 4097):
+        x = dev(rng.random((B, 3)).astype(np.float32) * 4 - 2, cuda)
+        d = rng.standard_normal((B, 3)).astype(np.float32)
+        d = dev(d / np.linalg.norm(d, axis=1, keepdims=True), cuda)
+        with torch.no_grad():
+            want = m(x, d)
+            got = fused.network_forward(x, d)
+        names = ("sigma", "clip_feat", "omega", "offsets_radiance", "view_dep", "diffuse")
+        assert [tuple(t.shape) for t in got] == [tuple(t.shape) for t in want] == [(B,), (B, clip_dim), (B, nb), (B, 3 * nb + 1), (B, 3), (B, 3)]
+        np.testing.assert_allclose(host(got[0]), host(want[0]), rtol=3e-5, atol=1e-7)          # sigma UNSCALED, as the reference's forward returns it
+        for name, g_, w_ in list(zip(names, got, want))[1:]:
+            np.testing.assert_allclose(host(g_), host(w_), rtol=0, atol=5e-6, err_msg=name)
+        if not pred_clip:
+            assert float(got[1].abs().sum()) == 0.0
+
+
 def _palette_reference_rows(m, x, d, nb):
     """The torch statement of palette/renderer.py:470-500 (no edit): sigma, rgbs and the packed aux row of the unfused module."""
     import torch.nn.functional as F
