@@ -55,6 +55,82 @@ def build(force=False, verbose=False):
     return OUT
 
 
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# Round 4: the reference's CUDA extensions themselves, compiled for gfx950 by the image's own toolchain for CUDA extensions on ROCm.
+#
+# torch.utils.cpp_extension (what the reference's */backend.py call) translates a .cu with torch.utils.hipify and compiles it with hipcc -- that is
+# how ANY CUDA extension is built on a ROCm PyTorch, no file of this repository is involved.  The reference's own recipe fails here only because
+# it passes -std=c++14 (raymarching/backend.py:7,12) to a torch 2.10 whose headers need C++17; with -std=c++17 (and the HIP spelling of its
+# -U__CUDA_NO_HALF_* flags) three of the four extensions compile UNMODIFIED from /root/reference:
+#     _raymarching (raymarching.cu: all 14 kernels), _shencoder (shencoder.cu), _palette_func (palette.cu + bindings.cpp).
+# _gridencoder does NOT: gridencoder.cu:269 calls atomicAdd(__half2*, __half2), an overload ROCm 7.2's headers do not have (they offer
+# unsafeAtomicAdd); supplying it would be a stand-in for a library function the image lacks, so that extension stays unbuilt and the hash
+# grid stays pinned by the reference's Python wrapper over the oracle (oracle/native_facade.py) and by the independent formulations.
+# hipify writes its translation next to the input, /root/reference is read-only: the sources are copied to a scratch directory OUTSIDE the
+# repository, built there, and only the .so files are kept (oracle/_ref/ref_<name>.so).  On the GPU box the tests load them and run the
+# reference's own kernels on the MI355X next to this repository's (tests/test_gpu_reference_kernels.py); bench.py times them (extra.reference_kernels).
+HIP_EXTENSIONS = {
+    "raymarching": ("_raymarching", ("raymarching.cu", "bindings.cpp")),
+    "shencoder": ("_shencoder", ("shencoder.cu", "bindings.cpp")),
+    "palette": ("_palette_func", ("palette.cu", "bindings.cpp")),
+}
+REF_ROOT = "/root/reference"
+
+
+def hip_path(ext):
+    return os.path.join(OUT_DIR, f"ref_{ext}.so")
+
+
+def hip_available(ext):
+    return os.path.exists(hip_path(ext))
+
+
+def build_hip(force=False, verbose=False):
+    """Compile the three buildable reference extensions for gfx950 (no GPU needed).  Returns {ext: path or None}."""
+    out = {}
+    for ext, (modname, files) in HIP_EXTENSIONS.items():
+        srcs = [os.path.join(REF_ROOT, ext, "src", f) for f in files]
+        dst = hip_path(ext)
+        if not all(os.path.exists(p) for p in srcs):
+            out[ext] = dst if os.path.exists(dst) else None
+            continue
+        hdrs = [os.path.join(REF_ROOT, ext, "src", f) for f in os.listdir(os.path.join(REF_ROOT, ext, "src")) if f.endswith(".h")]
+        if not force and os.path.exists(dst) and os.path.getmtime(dst) >= max(os.path.getmtime(p) for p in srcs + hdrs + [os.path.abspath(__file__)]):
+            out[ext] = dst
+            continue
+        import shutil
+        import tempfile
+        os.environ.setdefault("PYTORCH_ROCM_ARCH", "gfx950")
+        os.environ.setdefault("MAX_JOBS", "4")
+        from torch.utils.cpp_extension import load
+        tmp = tempfile.mkdtemp(prefix="pnr_refbuild_", dir="/tmp")
+        try:
+            shutil.copytree(os.path.join(REF_ROOT, ext, "src"), os.path.join(tmp, "src"))      # scratch copy, outside the repository: hipify writes next to its input
+            bd = os.path.join(tmp, "build")
+            os.makedirs(bd)
+            half = ["-U__CUDA_NO_HALF_OPERATORS__", "-U__CUDA_NO_HALF_CONVERSIONS__", "-U__CUDA_NO_HALF2_OPERATORS__"]       # the reference's own flags (backend.py:8) ...
+            half += [f.replace("CUDA", "HIP") for f in half]                                                              # ... and their HIP spelling
+            load(name=modname, extra_cflags=["-O3", "-std=c++17"], extra_cuda_cflags=["-O3", "-std=c++17", *half],
+                 sources=[os.path.join(tmp, "src", f) for f in files], build_directory=bd, verbose=verbose, is_python_module=False)
+            os.makedirs(OUT_DIR, exist_ok=True)
+            shutil.copy2(os.path.join(bd, modname + ".so"), dst)
+            out[ext] = dst
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def load_hip(ext):
+    """Import oracle/_ref/ref_<ext>.so as the reference's extension module (its own PyInit name); needs torch imported (libtorch symbols)."""
+    import importlib.util
+    import torch  # noqa: F401
+    modname = HIP_EXTENSIONS[ext][0]
+    spec = importlib.util.spec_from_file_location(modname, hip_path(ext))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def load():
     """Import the built module (needs torch imported first for its symbols)."""
     import importlib.util
@@ -67,3 +143,4 @@ def load():
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_hip(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
