@@ -303,6 +303,47 @@ def cpu_baseline(args, crop_rays):
         finally:
             renderer.raymarching, pge.GridEncoder, psh.SHEncoder = saved2
             torch.set_num_threads(1)
+    # The reference's OWN kernels on this GPU, beside the CPU port: raymarching.cu and shencoder.cu of /root/reference compiled unmodified for gfx950
+    # (oracle/ref_build.py: build_hip -> oracle/_ref/ref_*.so, built where the reference checkout is, loaded here) under the per-op loop -- the
+    # reference's march / composite / SH kernels, its Python's allocations (three zero-fills per march call), torch MLPs, host-side compaction.
+    # The hash grid is this repository's in both runs (gridencoder.cu does not compile for HIP).  A baseline, like the CPU figures: never `value`.
+    ref_gpu = None
+    try:
+        from oracle import ref_ops
+        if ref_ops.available() and torch.cuda.is_available():
+            gdev = torch.device("cuda", torch.cuda.current_device())
+            cargs = argparse.Namespace(**vars(args))
+            cargs.mode, cargs.fp16, cargs.half_tables = "compat", False, False
+            H_, W_ = args.wl["H"], args.wl["W"]
+            pose = torch.from_numpy(pose_of(args, 0)[None])
+            fro, frd = scene.get_rays(pose, intrinsics_of(args), H_, W_)
+            fro, frd = fro.to(gdev), frd.to(gdev)
+            gkw = dict(perturb=False, dt_gamma=args.wl["dt_gamma"], max_steps=1024, T_thresh=1e-4)
+            if args.model == "palette":
+                gkw["gui_mode"] = False
+
+            def run(n_frames):
+                mg = build_model(cargs, gdev, args.model)
+                with torch.no_grad():
+                    r = mg.render(fro, frd, **gkw)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(n_frames):
+                        r = mg.render(fro, frd, **gkw)
+                    torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / n_frames * 1e3, r
+
+            ours_ms, ours_r = run(3)
+            with ref_ops.swapped_in():
+                ref_ms, ref_r = run(3)
+            ref_gpu = {"ms_per_frame": ref_ms, "ms_per_frame_this_repository_same_loop": ours_ms, "frames": 3,
+                       "value": int(ref_r["rendered"].sum()) / (ref_ms * 1e-3), "unit": "samples/s", "kind": "reference",
+                       "rendered_equal": int(ref_r["rendered"].sum()) == int(ours_r["rendered"].sum()),
+                       "max_abs_rgb_between_the_two": float((ref_r["image"] - ours_r["image"]).abs().max()),
+                       "what": f"{H_}x{W_} -m {args.model} frame, pose 0, per-op loop: the reference's raymarching.cu / shencoder.cu kernels (compiled for gfx950 by torch's hipify + hipcc) "
+                               "against this repository's per-op kernels under the very same loop; hash grid and MLPs identical in both"}
+    except Exception as e:      # noqa: BLE001 -- a baseline that cannot run is reported, never fatal
+        ref_gpu = {"error": repr(e)}
     one, allc = legs["1_thread"], legs["all_cores"]
     n = int(ref["rendered"].item())
     what = (f"centre {args.cpu_crop}x{args.cpu_crop} crop of pose 0 of the {args.wl['H']}x{args.wl['W']} frame ({ro.shape[1]} rays, {n} rendered samples; -m {args.model}, "
@@ -310,7 +351,8 @@ def cpu_baseline(args, crop_rays):
     rec = {"value": allc["value"], "unit": "samples/s", "cores": allc["cores"], "host_cores": cores, "kind": "port",
            "sample": what + f", {allc['seconds']:.1f} s on {allc['cores']} OpenMP threads + {allc['torch_threads']} torch threads of a {cores}-core host)",
            "one_thread": {"value": one["value"], "unit": "samples/s", "cores": 1, "seconds": one["seconds"], "sample": what + ", 1 thread)"},
-           "all_cores_max_abs_rgb_vs_1_thread": allc.get("max_abs_rgb_vs_1_thread"), "uniform_path_config0": uniform}
+           "all_cores_max_abs_rgb_vs_1_thread": allc.get("max_abs_rgb_vs_1_thread"), "uniform_path_config0": uniform,
+           "reference_kernels_mi355x": ref_gpu}
     return rec, ref
 
 
