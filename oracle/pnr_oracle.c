@@ -12,10 +12,17 @@
  *   - renderer control flow (n_step schedule, compaction, composite call order, bg mix, depth
  *     normalisation): pinned by importing nerf/renderer.py and palette/renderer.py in the build
  *     container with these oracle ops injected (tests/golden/gen_golden.py).
- *   - kernel-level arithmetic of march / composite / grid / HSV: the reference ships no golden
- *     vectors or known-answer tests for them and its CUDA sources cannot be built here (no nvcc,
- *     no CUDA headers) => "parity unpinned" by the reference for those kernels; they are
- *     cross-checked against independent NumPy/PyTorch formulations in tests/.
+ *   - operator wrappers (level offsets, per_level_scale, the [L,B,C] permute, autocast casts, the autograd Functions): the reference's own
+ *     gridencoder/grid.py, shencoder/sphere_harmonics.py and raymarching/raymarching.py imported over this library through
+ *     oracle/native_facade.py (tests/golden/gen_golden.py); regenerating every fixture through them changed no bit.
+ *   - kernel-level arithmetic of march / composite / Morton / packbits / near-far / SH / HSV: the reference ships no golden vectors for
+ *     them, but raymarching.cu, shencoder.cu and palette.cu compile unmodified for gfx950 through torch's hipify + hipcc
+ *     (oracle/ref_build.py: build_hip -> oracle/_ref/ref_*.so), and tests/test_gpu_reference_kernels.py runs them on the MI355X next to
+ *     this repository's kernels: bit-identical for march / composite / Morton / packbits / near-far, <= 2e-6 for the rest.  This library
+ *     agrees with the kernels of this repository bit for bit on the same functions, hence with the reference's.
+ *   - hash-grid encoder kernels: gridencoder.cu does not compile for gfx950 (atomicAdd(__half2*, __half2) is missing in ROCm 7.2 HIP),
+ *     so its arithmetic is pinned through the reference's GridEncoder wrapper over this restatement and by independent int64 / float64
+ *     formulations in tests/ -- "parity unpinned by execution" for that one extension.
  *
  * Canonical scalar spec (shared *by description*, not by header, with the HIP kernels):
  *   - IEEE fp32, no implicit contraction (-ffp-contract=off); the places where the reference's

@@ -1,13 +1,18 @@
 #!/usr/bin/env python3
 """Builds oracle/_ref/ -- the part of the REFERENCE that compiles here from its own sources, where they lie (TEST INFRASTRUCTURE).
 
-What is buildable: `palette/src/bindings.cpp` (plain C++ / pybind11; holds compute_RGB_histogram, bindings.cpp:40-91).  It is compiled
-UNMODIFIED from /root/reference with g++ against the torch / pybind11 headers of this image.  The reference links it with palette.cu (CUDA:
-no nvcc, no CUDA headers here -> unbuildable, and no stand-in is written for it); the two symbols bindings.cpp takes from palette.cu
-(rgb_to_hsv / hsv_to_rgb, palette/src/palette_func.h) are provided by this repo's PRODUCT binding of the C ABI for that extension
-(palettenerf_amd/csrc/shim/palette_func_hip.cpp -> libpnr_hip.so), i.e. the module is the reference's `_palette_func` as it would be built on an
-MI355X box: reference pybind layer + reference histogram code + this repo's HIP kernels.  Everything else under /root/reference on the
-hot path is CUDA (raymarching.cu, gridencoder.cu, shencoder.cu, palette.cu) and stays unbuilt.
+Two builds:
+
+1. `build()` (CPU, runs anywhere): `palette/src/bindings.cpp` (plain C++ / pybind11; holds compute_RGB_histogram, bindings.cpp:40-91), compiled
+   UNMODIFIED from /root/reference with g++ against the torch / pybind11 headers of this image.  The two symbols it takes from palette.cu
+   (rgb_to_hsv / hsv_to_rgb, palette/src/palette_func.h) come from this repo's PRODUCT binding of the C ABI for that extension
+   (palettenerf_amd/csrc/shim/palette_func_hip.cpp -> libpnr_hip.so): reference pybind layer + reference histogram code + this repo's kernels.
+2. `build_hip()` (round 4): the reference's CUDA extensions themselves -- raymarching/src/{raymarching.cu,bindings.cpp},
+   shencoder/src/{shencoder.cu,bindings.cpp}, palette/src/{palette.cu,bindings.cpp} -- compiled UNMODIFIED for gfx950 with
+   torch.utils.cpp_extension (torch's own hipify pass + hipcc; no header, library or tool is stood in for).  The sources are read where they lie;
+   hipify writes its translated copies into a scratch directory under /tmp; only the resulting ref_<name>.so files are copied into oracle/_ref/.
+   gridencoder/src/gridencoder.cu does NOT compile (atomicAdd(__half2*, __half2) has no overload in ROCm 7.2's HIP headers) and is left unbuilt.
+   tests/test_gpu_reference_kernels.py and profiles/reference_kernels.py run these modules on the MI355X next to this repository's kernels.
 
 Use: tests/golden/gen_golden.py imports the module to write tests/golden/hist.npz; tests/test_oracle.py checks the oracle's
 compute_RGB_histogram against the module directly when it is present.  Outputs only into oracle/_ref/ (git-ignored, travels to the GPU box).

@@ -197,141 +197,7 @@ __device__ int g_march_timing_iter = 3;
 #else
 #define PNR_STAMP(k) do { } while (0)
 #endif
-// ------------------------------------------------------------------------------------------
-// Wave-cooperative march tail.  A march launch used to last as long as its slowest ray: ~95 % of the waves are done after 8.5 us, the
-// launch waits for the few rays that walk 7-13 cells through partly filled bricks at ~1.3 us per probe -- one lane busy, 63 idle
-// (profiles/march_timing.py).  Once at most kCoopRays rays of a wave are still marching, the whole wave works for them: the rays are
-// parked in LDS and each gets a group of 64 / 32 / 16 lanes; lane k of a group runs the ordinary march_probe() -- the very same code, so
-// every probe is bit for bit the reference's -- at the k-th LATTICE POINT after the ray's current t (lattice.hpp: the values a ray can
-// visit form a fixed sequence; lattice_steps() gives the k-th one in closed form for a constant step, a k-step loop otherwise).  Which of
-// those points the reference actually visits is then a chain: from a visited empty point it goes to the first lattice point at or beyond
-// that probe's exit parameter (the probe returns it; its index among the group's points comes from a binary search), from a visited
-// occupied point -- a sample -- to the next point.  One scalar walker per group follows the chain from point 0 (readlane), hands the
-// sample rows to the lanes that hold them, and stops at n_step samples, at `far`, or at the end of the window, where the next batch
-// continues.  Probes at points the reference never visits are discarded.  13 dependent probes become one or two batches.
-// ------------------------------------------------------------------------------------------
-#ifndef PNR_COOP_RAYS
-#define PNR_COOP_RAYS 2       // measured 1 / 2 / 4: lego 4.07 / 4.07 / 4.13 ms -- with 4 rays a group is 16 lattice points (3.5 cells): one batch then buys what 3 probes buy
-#endif
-constexpr int kCoopRays = PNR_COOP_RAYS;   // 1, 2 or 4
-struct CoopShared {                 // per wave
-    float f[kCoopRays][12];         // ox oy oz dx dy dz t far last_t
-    int32_t i[kCoopRays][4];        // first row of the ray's slots (n * n_step), samples so far, still marching, (unused)
-    float tl[PNR_WAVE];             // the lattice point every lane probed in this batch
-};
-__device__ __forceinline__ void wave_lds_sync() {   // LDS operations of one wave execute in order; this only pins the compiler's order
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-__device__ __forceinline__ float readlane_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
-__device__ __forceinline__ float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-
-template <bool MIP, bool POW2>
-__device__ __forceinline__ uint32_t march_coop_tail(CoopShared& sh, const MarchParams& p, const uint8_t* __restrict__ grid, const uint32_t* mip_lds,
-                                                    uint32_t n_step, bool active, const RayCtx& c, float t, float far, float last_t, uint32_t n,
-                                                    uint32_t step, float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas) {
-    const int lane = threadIdx.x & (PNR_WAVE - 1);
-    const unsigned long long am = __ballot(active);
-    const int nrays = __popcll(am);
-    const int my_slot = __popcll(am & ((1ull << lane) - 1ull));
-    if (active) {
-        float* f = sh.f[my_slot];
-        f[0] = c.ox; f[1] = c.oy; f[2] = c.oz; f[3] = c.dx; f[4] = c.dy; f[5] = c.dz; f[6] = t; f[7] = far; f[8] = last_t;
-        int32_t* q = sh.i[my_slot];
-        q[0] = (int32_t)(n * n_step); q[1] = (int32_t)step; q[2] = 1;
-    }
-    const bool const_step = p.dt_gamma == 0.0f;
-    const float d_const = clampf(0.0f, p.dt_min, p.dt_max);
-    for (;;) {
-        wave_lds_sync();
-        uint32_t mask = 0;
-        for (int r = 0; r < nrays; r++) mask |= (sh.i[r][2] != 0 ? 1u : 0u) << r;
-        mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)mask);
-        if (mask == 0) break;
-        const int ns = __popc(mask);
-        const int glog = ns > 2 ? 2 : ((ns == 2 || !const_step) ? 1 : 0);   // 4 / 2 / 1 groups; a growing step is walked point by point: windows of at most 32
-        const int wlog = 6 - glog, W = 1 << wlog;
-        const int g = lane >> wlog, k = lane & (W - 1);
-        int slot = -1;
-        { uint32_t m = mask; for (int i = 0; i < g; i++) m &= m - 1u; if (m) slot = __ffs((int)m) - 1; }
-        const bool has = slot >= 0;
-        const float* f = sh.f[has ? slot : 0];
-        RayCtx hc;
-        {
-            const float o[3] = {f[0], f[1], f[2]}, dd[3] = {f[3], f[4], f[5]};
-            ctx_init(hc, o, dd, p, grid, mip_lds);
-        }
-        const float t0 = f[6], far_s = f[7];
-        float tk;
-        if (const_step) tk = lattice_steps(t0, d_const, (uint32_t)k);
-        else {
-            tk = t0;
-            for (int j = 0; j < W - 1; j++) { const float nt = tk + clampf(tk * p.dt_gamma, p.dt_min, p.dt_max); tk = j < k ? nt : tk; }
-        }
-        float q = tk, x = 0.0f, y = 0.0f, z = 0.0f, dt = 0.0f;
-        int hit = 0;
-        if (has && tk < far_s) hit = march_probe<MIP, POW2>(hc, q, x, y, z, dt) ? 1 : 0;
-        // index of q (a lattice point: it was reached by lattice steps from tk) among the group's points; the group's end = beyond the window
-        sh.tl[lane] = tk;
-        wave_lds_sync();
-        int lo = k + 1, hi = W;
-#pragma unroll
-        for (int it = 0; it < 6; it++) {
-            if (lo < hi) { const int mid = (lo + hi) >> 1; if (sh.tl[(g << wlog) + mid] < q) lo = mid + 1; else hi = mid; }
-        }
-        const int nxt = (g << wlog) + lo;
-        int emit_row = -1;
-        float emit_last = 0.0f;
-        for (int gg = 0; gg < (1 << glog); gg++) {
-            uint32_t m = mask;
-            for (int i = 0; i < gg; i++) m &= m - 1u;
-            if (!m) break;
-            const int s = __ffs((int)m) - 1;
-            int cur = gg << wlog;
-            const int end = cur + W;
-            const int row0 = __builtin_amdgcn_readfirstlane(sh.i[s][0]);
-            const uint32_t done0 = (uint32_t)__builtin_amdgcn_readfirstlane(sh.i[s][1]);
-            float lt = uniform_f(sh.f[s][8]);
-            const float far_l = uniform_f(sh.f[s][7]);
-            uint32_t ne = 0;
-            float tnext = far_l;
-            bool fin = false;
-            for (;;) {
-                const float tc = readlane_f(tk, cur);
-                if (!(tc < far_l)) { fin = true; break; }
-                if (__builtin_amdgcn_readlane(hit, cur)) {
-                    if (lane == cur) { emit_row = row0 + (int)(done0 + ne); emit_last = lt; }
-                    const float tn = tc + readlane_f(dt, cur);       // `t += dt` (raymarching.cu:389)
-                    lt = tn; tnext = tn; ne++;
-                    if (done0 + ne >= n_step) { fin = true; break; }
-                    if (++cur == end) break;
-                } else {
-                    tnext = readlane_f(q, cur);
-                    const int j = __builtin_amdgcn_readlane(nxt, cur);
-                    if (j >= end) break;
-                    cur = j;
-                }
-            }
-            if (lane == (gg << wlog)) {
-                sh.i[s][1] = (int32_t)(done0 + ne);
-                sh.f[s][8] = lt; sh.f[s][6] = tnext;
-                sh.i[s][2] = (!fin && tnext < far_l) ? 1 : 0;
-            }
-        }
-        if (emit_row >= 0) {
-            float* px = xyzs + (size_t)emit_row * 3;
-            float* pd = dirs + (size_t)emit_row * 3;
-            float* pl = deltas + (size_t)emit_row * 2;
-            px[0] = x; px[1] = y; px[2] = z;
-            pd[0] = hc.dx; pd[1] = hc.dy; pd[2] = hc.dz;
-            const float tn = tk + dt;
-            pl[0] = dt; pl[1] = tn - emit_last;
-        }
-    }
-    wave_lds_sync();
-    return active ? (uint32_t)sh.i[my_slot][1] : step;
-}
-
+// (the wave-cooperative march tail -- march_coop_tail, CoopShared, kCoopRays -- lives in march_core.hpp: the drop-in march kernels use it too)
 #ifndef PNR_MARCH_WAVES
 #define PNR_MARCH_WAVES 4     // waves per SIMD the march kernel WITH the in-wave cooperative tail is compiled for (register budget 512 / PNR_MARCH_WAVES): it needs 114 VGPRs;
                               // squeezed into 80 (6 waves, all chunks of a later iteration resident at once) it spills and the lego frame is 0.3 ms slower (4.38 vs 4.07 ms)

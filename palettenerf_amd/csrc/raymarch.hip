@@ -198,6 +198,46 @@ __global__ void __launch_bounds__(kBlock) k_march_train_count(
     if (threadIdx.x == 0) scratch[kScanHdr + blockIdx.x] = total;
 }
 
+// The counting pass with every wave working for four rays at a time (march_coop_tail with sample recording): a training batch is a few
+// thousand rays, i.e. 64 waves at one ray per lane on 1024 SIMDs, each paced by its longest ray at ~1.3 us per probe -- one probe per sample
+// inside an object.  Here a ray's next 16 (then 32, 64 as its neighbours finish) lattice points are probed at once, so the dense interior
+// costs one batch per 16-64 samples, and the batch is spread over N / 4 waves.  Same counts and the same t_store as k_march_train_count
+// (the probes are the same march_probe() calls; tests/test_gpu_ops.py compares both with the oracle).  The per-chunk sums k_scan_block_sums
+// wants are formed by k_chunk_sums.
+constexpr int kTrainCoopRays = 4;
+template <bool MIP, bool POW2>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) k_march_train_count_coop(
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid, MarchParams p, uint32_t N,
+    const float* __restrict__ nears, const float* __restrict__ fars, const float* __restrict__ noises, int32_t* __restrict__ counts /* [N] */,
+    const uint32_t* __restrict__ mip, float* __restrict__ t_store) {
+    __shared__ CoopSharedT<kTrainCoopRays> coop[kBlock / PNR_WAVE];
+    const uint32_t* mip_lds = stage_mip(mip, MIP ? p.mip_words : 0);
+    const uint32_t wave = threadIdx.x / PNR_WAVE, lane = threadIdx.x & (PNR_WAVE - 1);
+    const uint32_t n = (blockIdx.x * (kBlock / PNR_WAVE) + wave) * kTrainCoopRays + lane;
+    const bool keep = lane < (uint32_t)kTrainCoopRays && n < N;
+    RayCtx c = {};
+    float t = 0.0f, far = -FLT_MAX;
+    if (keep) {
+        ctx_init(c, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, p, grid, mip_lds);
+        const BoxHit bh = clip_to_box(c, fars[n]);
+        far = bh.far;
+        t = nears[n];
+        t = fmaf(clampf(t * c.dt_gamma, c.dt_min, c.dt_max), noises[n], t);
+        t = skip_to_box<MIP && POW2>(c, bh, t);
+    }
+    const bool active = keep && t < far;
+    uint32_t steps = 0;
+    if (__ballot(active) != 0ull)
+        steps = march_coop_tail<MIP, POW2, true>(coop[wave], p, grid, mip_lds, p.max_steps, active, c, t, far, t, n, 0u, nullptr, nullptr, nullptr, t_store);
+    if (keep) counts[n] = (int32_t)steps;
+}
+__global__ void __launch_bounds__(kBlock) k_chunk_sums(int32_t* __restrict__ scratch, uint32_t N) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    int total;
+    (void)block_exclusive_scan(n < N ? scratch[kScanHdr + gridDim.x + n] : 0, &total);
+    if (threadIdx.x == 0) scratch[kScanHdr + blockIdx.x] = total;
+}
+
 template <bool MIP, bool POW2>
 __global__ void __launch_bounds__(kBlock) k_march_train_write(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid, MarchParams p, uint32_t N, uint32_t M,
@@ -319,13 +359,21 @@ __global__ void __launch_bounds__(kBlock) k_spread_ray_to_sample(const float* __
 // ------------------------------------------------------------------------------------------
 // inference march (reference raymarching.cu:907-1011)
 // ------------------------------------------------------------------------------------------
+#ifndef PNR_OP_MARCH_COOP
+#define PNR_OP_MARCH_COOP 1   // 0: the plain SIMT loop (every lane walks its own ray to the end) -- the A/B of the cooperative tail in the drop-in kernel
+#endif
+// A launch lasts as long as its slowest ray (~1.3 us per probe of one lane while the other 63 idle).  Once at most kCoopRays rays of a wave
+// are still marching the whole wave works for them (march_coop_tail, march_core.hpp: the same march_probe() at the ray's next lattice
+// points, so every sample is bit for bit what the one-lane walk writes).  Lanes without a ray stay in the loop for that reason.
 template <bool MIP, bool POW2>
-__global__ void __launch_bounds__(kBlock) k_march_rays(
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) k_march_rays(
     uint32_t n_alive, uint32_t n_step, const int32_t* __restrict__ rays_alive, const float* __restrict__ rays_t,
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, MarchParams p, const uint8_t* __restrict__ grid,
     const float* __restrict__ fars, float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas,
     const float* __restrict__ noises, const uint32_t* __restrict__ mip, uint32_t fill_rows) {
+    __shared__ CoopShared coop[kBlock / PNR_WAVE];
     const uint32_t* mip_lds = stage_mip(mip, MIP ? p.mip_words : 0);
+    const uint32_t wave = threadIdx.x / PNR_WAVE;
     // fill_rows != 0 (pnr_march_rays_fill): the buffers arrive uninitialised -- every slot a ray leaves unfilled and the alignment rows
     // [n_alive * n_step, fill_rows) are zeroed here, so the caller's three zero-fill launches (raymarching.py:384-386) are not needed
     if (fill_rows)
@@ -334,34 +382,53 @@ __global__ void __launch_bounds__(kBlock) k_march_rays(
             dirs[(size_t)r * 3] = 0.0f; dirs[(size_t)r * 3 + 1] = 0.0f; dirs[(size_t)r * 3 + 2] = 0.0f;
             deltas[(size_t)r * 2] = 0.0f; deltas[(size_t)r * 2 + 1] = 0.0f;
         }
-    for (uint32_t n = blockIdx.x * kBlock + threadIdx.x; n < n_alive; n += gridDim.x * kBlock) {
-        const int index = rays_alive[n];
-        RayCtx c;
-        ctx_init(c, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, p, grid, mip_lds);
-        float* px = xyzs + (size_t)n * n_step * 3;
-        float* pd = dirs + (size_t)n * n_step * 3;
-        float* pl = deltas + (size_t)n * n_step * 2;
-        float t = rays_t[index];
-        const BoxHit bh = clip_to_box(c, fars[index]);
-        const float far = bh.far;
-        t = fmaf(clampf(t * c.dt_gamma, c.dt_min, c.dt_max), noises ? noises[n] : 0.0f, t);  // noise is slot-indexed (quirk 5)
-        float last_t = t, x, y, z, dt;
-        t = skip_to_box<MIP && POW2>(c, bh, t);
+    for (uint32_t base = blockIdx.x * kBlock; base < n_alive; base += gridDim.x * kBlock) {   // (workgroup-uniform trip count)
+        const uint32_t n = base + threadIdx.x;
+        const bool keep = n < n_alive;
+        RayCtx c = {};
+        float t = 0.0f, far = -FLT_MAX, last_t = 0.0f;
         uint32_t step = 0;
-        while (t < far && step < n_step) {
-            if (march_probe<MIP, POW2>(c, t, x, y, z, dt)) {
-                px[0] = x; px[1] = y; px[2] = z;
-                pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
-                t += dt;
-                pl[0] = dt; pl[1] = t - last_t;
-                last_t = t;
-                px += 3; pd += 3; pl += 2; step++;
+        if (keep) {
+            const int index = rays_alive[n];
+            ctx_init(c, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, p, grid, mip_lds);
+            t = rays_t[index];
+            const BoxHit bh = clip_to_box(c, fars[index]);
+            far = bh.far;
+            t = fmaf(clampf(t * c.dt_gamma, c.dt_min, c.dt_max), noises ? noises[n] : 0.0f, t);  // noise is slot-indexed (quirk 5)
+            last_t = t;
+            t = skip_to_box<MIP && POW2>(c, bh, t);
+        }
+        bool active = keep && t < far && n_step != 0;
+        for (;;) {
+            const unsigned long long am = __ballot(active);
+            if (am == 0ull) break;
+            if (PNR_OP_MARCH_COOP && p.coop && __popcll(am) <= kCoopRays) break;
+            if (active) {
+                float x, y, z, dt;
+                if (march_probe<MIP, POW2>(c, t, x, y, z, dt)) {
+                    const size_t row = (size_t)n * n_step + step;
+                    float* px = xyzs + row * 3;
+                    float* pd = dirs + row * 3;
+                    float* pl = deltas + row * 2;
+                    px[0] = x; px[1] = y; px[2] = z;
+                    pd[0] = c.dx; pd[1] = c.dy; pd[2] = c.dz;
+                    t += dt;
+                    pl[0] = dt; pl[1] = t - last_t;
+                    last_t = t;
+                    step++;
+                }
+                active = t < far && step < n_step;
             }
         }
-        if (fill_rows)
+        if (PNR_OP_MARCH_COOP && p.coop && __ballot(active) != 0ull)
+            step = march_coop_tail<MIP, POW2>(coop[wave], p, grid, mip_lds, n_step, active, c, t, far, last_t, n, step, xyzs, dirs, deltas);
+        if (fill_rows && keep)
             for (; step < n_step; step++) {
+                const size_t row = (size_t)n * n_step + step;
+                float* px = xyzs + row * 3;
+                float* pd = dirs + row * 3;
+                float* pl = deltas + row * 2;
                 px[0] = 0.0f; px[1] = 0.0f; px[2] = 0.0f; pd[0] = 0.0f; pd[1] = 0.0f; pd[2] = 0.0f; pl[0] = 0.0f; pl[1] = 0.0f;
-                px += 3; pd += 3; pl += 2;
             }
     }
 }
@@ -508,6 +575,7 @@ int g_opt_iteration_margin = getenv("PNR_ITERATION_MARGIN") ? atoi(getenv("PNR_I
 int g_opt_palette_waves12 = getenv("PNR_PALETTE_WAVES8") ? 0 : 1;   // specialised PaletteNeRF field kernel: 12-wave workgroups (three waves per SIMD)
 int g_opt_dynamic_tiles = getenv("PNR_DYNAMIC_TILES") ? 1 : 0;   // measured: garden 14.6 -> 20.2 ms with it on (one contended counter, scattered tiles): off
 int g_opt_grid_fast = getenv("PNR_NO_GRID_FAST") ? 0 : 1;   // pnr_grid_encode_forward: the D = 3, C = 2 kernel (k_grid_fwd_d3c2) instead of the generic one (A/B; same bits)
+int g_opt_train_coop = getenv("PNR_NO_TRAIN_COOP") ? 0 : 1;   // training march: wave-cooperative counting pass (k_march_train_count_coop)
 int g_opt_grid_nt = getenv("PNR_GRID_NT") ? atoi(getenv("PNR_GRID_NT")) : 0;   // experiment: non-temporal stores (1) / input loads (2) in k_grid_fwd_d3c2
 int g_opt_adam_variant = 0;   // experiment switch of adam.hip (which multiply-adds are contracted); 0 = torch's kernels on this platform
 
@@ -530,6 +598,7 @@ int pnr_set_option(const char* name, int value) {
     if (!strcmp(name, "palette_waves12")) { g_opt_palette_waves12 = value != 0; return PNR_OK; }
     if (!strcmp(name, "dynamic_tiles")) { g_opt_dynamic_tiles = value != 0; return PNR_OK; }
     if (!strcmp(name, "grid_fast")) { g_opt_grid_fast = value != 0; return PNR_OK; }
+    if (!strcmp(name, "train_coop")) { g_opt_train_coop = value != 0; return PNR_OK; }
     if (!strcmp(name, "grid_nt")) { g_opt_grid_nt = value & 3; return PNR_OK; }
     if (!strcmp(name, "adam_variant")) { g_opt_adam_variant = value & 7; return PNR_OK; }
     if (!strcmp(name, "iteration_margin")) { g_opt_iteration_margin = value < 0 ? 0 : (value > 64 ? 64 : value); return PNR_OK; }
@@ -640,9 +709,18 @@ int pnr_march_rays_train_mip(const float* rays_o, const float* rays_d, const uin
     const MarchParams p = make_march_params(bound, dt_gamma, max_steps, C, H, use_mip);
     const uint32_t lds = mip_lds_bytes(p);
     const uint32_t* m = static_cast<const uint32_t*>(mip);
+    // measured (profiles/scratch/train_coop_ab.py, us per call incl. the emit pass, one ray per lane -> cooperative): 4096 rays 206 -> 162 (slab, dt_gamma 1/128),
+    // 726 -> 256 (lego, 0), 507 -> 235 (slab, 0); 40 000 rays 704 -> 441 and 760 -> 695 with a constant step, but 247 -> 300 and 232 -> 239 with a growing one
+    // (its windows are walked point by point and there are enough waves already): cooperative for training-sized batches or a constant step
+    const bool coop_count = p.coop != 0 && g_opt_train_coop != 0 && (uint64_t)N * max_steps < (1ull << 31) && (dt_gamma == 0.0f || N <= 16384u);
 #define PNR_LAUNCH_TRAIN(MIPV, P2V)                                                                                                           \
-    hipLaunchKernelGGL((k_march_train_count<MIPV, P2V>), dim3(nb), dim3(kBlock), lds, s, rays_o, rays_d, grid, p, N, nears, fars, noises, sc, m, \
-                       t_store);                                                                                                               \
+    if (coop_count) {                                                                                                                          \
+        hipLaunchKernelGGL((k_march_train_count_coop<MIPV, P2V>), dim3(cdiv(N, (kBlock / PNR_WAVE) * kTrainCoopRays)), dim3(kBlock), lds, s, rays_o, \
+                           rays_d, grid, p, N, nears, fars, noises, sc + kScanHdr + nb, m, t_store);                                           \
+        hipLaunchKernelGGL(k_chunk_sums, dim3(nb), dim3(kBlock), 0, s, sc, N);                                                                 \
+    } else                                                                                                                                     \
+        hipLaunchKernelGGL((k_march_train_count<MIPV, P2V>), dim3(nb), dim3(kBlock), lds, s, rays_o, rays_d, grid, p, N, nears, fars, noises, sc, m, \
+                           t_store);                                                                                                           \
     hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, sc, nb, counter, N, (int32_t*)nullptr);                                    \
     if (t_store)                                                                                                                               \
         hipLaunchKernelGGL(k_march_train_emit, dim3(nb, 16), dim3(kBlock), 0, s, rays_o, rays_d, p, N, M, nears, noises, t_store, xyzs, dirs, deltas, \

@@ -138,16 +138,23 @@ def test_march_rays_train_bit_exact(cuda, s0, mip_mode, dt_gamma, min_near, boun
     on, of = oracle.near_far_from_aabb(ro, rd, aabb, min_near)
     cnt = np.zeros(2, np.int32)
     ox, od, odl, orays = oracle.march_rays_train(ro, rd, bound, bf, 2, 128, on, of, cnt, align=128, force_all_rays=True, dt_gamma=dt_gamma)
-    counter = torch.zeros(2, dtype=torch.int32, device=cuda)
-    x, d, dl, rays = raymarching.march_rays_train(dev(ro, cuda), dev(rd, cuda), bound, dev(bf, cuda), 2, 128, dev(on, cuda), dev(of, cuda), counter,
-                                                  -1, False, 128, True, dt_gamma, 1024)
     assert int(cnt[0]) > 10000
-    np.testing.assert_array_equal(host(counter), cnt)            # total sample count and ray count: bit-exact
-    np.testing.assert_array_equal(host(rays), orays)             # per-ray (id, offset, count): bit-exact, deterministic row order
-    assert x.shape == ox.shape
-    np.testing.assert_array_equal(host(x), ox)                   # positions bit-exact (canonical fmaf spec on both sides)
-    np.testing.assert_array_equal(host(d), od)
-    np.testing.assert_array_equal(host(dl), odl)
+    from palettenerf_amd import _lib
+    lib = _lib.load()
+    try:
+        for coop in (1, 0):   # the counting pass: four rays per wave cooperatively (k_march_train_count_coop) / one ray per lane
+            assert lib.pnr_set_option(b"train_coop", coop) == 0
+            counter = torch.zeros(2, dtype=torch.int32, device=cuda)
+            x, d, dl, rays = raymarching.march_rays_train(dev(ro, cuda), dev(rd, cuda), bound, dev(bf, cuda), 2, 128, dev(on, cuda), dev(of, cuda), counter,
+                                                          -1, False, 128, True, dt_gamma, 1024)
+            np.testing.assert_array_equal(host(counter), cnt)            # total sample count and ray count: bit-exact
+            np.testing.assert_array_equal(host(rays), orays)             # per-ray (id, offset, count): bit-exact, deterministic row order
+            assert x.shape == ox.shape
+            np.testing.assert_array_equal(host(x), ox)                   # positions bit-exact (canonical fmaf spec on both sides)
+            np.testing.assert_array_equal(host(d), od)
+            np.testing.assert_array_equal(host(dl), odl)
+    finally:
+        lib.pnr_set_option(b"train_coop", 1)
 
 
 def test_march_rays_train_perturbed_and_mean_count_overflow(cuda, s0):
@@ -256,12 +263,19 @@ def test_march_rays_inference_bit_exact(cuda, s0, mip_mode, n_step, bound):
     # allocator's blocks first so that a slot the kernel forgot cannot pass as the reference's zero-fill by luck
     for rows in (ox.shape[0] * 3, ox.shape[0] * 3, ox.shape[0] * 2):
         torch.empty(rows, device=cuda).fill_(float("nan"))
-    x, d, dl = raymarching.march_rays(len(alive), n_step, dev(alive, cuda), dev(rays_t, cuda), dev(ro, cuda), dev(rd, cuda), bound, dev(bf, cuda), 2, 128,
-                                      dev(on, cuda), dev(of, cuda), 128, False, 1.0 / 256, 1024)
-    assert x.shape == ox.shape and x.shape[0] % 128 == 0 and x.shape[0] > len(alive) * n_step - 1
-    np.testing.assert_array_equal(host(x), ox)
-    np.testing.assert_array_equal(host(d), od)
-    np.testing.assert_array_equal(host(dl), odl)
+    from palettenerf_amd import _lib
+    lib = _lib.load()
+    try:
+        for coop in (1, 0):   # the last rays of a wave marched by the whole wave (march_coop_tail) / every lane to the end of its own ray
+            assert lib.pnr_set_option(b"coop_march", coop) == 0
+            x, d, dl = raymarching.march_rays(len(alive), n_step, dev(alive, cuda), dev(rays_t, cuda), dev(ro, cuda), dev(rd, cuda), bound, dev(bf, cuda), 2, 128,
+                                              dev(on, cuda), dev(of, cuda), 128, False, 1.0 / 256, 1024)
+            assert x.shape == ox.shape and x.shape[0] % 128 == 0 and x.shape[0] > len(alive) * n_step - 1
+            np.testing.assert_array_equal(host(x), ox)
+            np.testing.assert_array_equal(host(d), od)
+            np.testing.assert_array_equal(host(dl), odl)
+    finally:
+        lib.pnr_set_option(b"coop_march", 1)
     assert int((odl[:, 0] > 0).sum()) > 0
 
 
