@@ -484,7 +484,10 @@ int pnr_linear_wgrad(const void* x, int x_dtype, const void* dy, int dy_dtype, u
  * of nerf/network.py:33-93 and palette/network.py:60-153 under autograd: per layer a GEMM + activation kernel forward, two GEMMs + an
  * activation kernel backward).  2 or 3 layers, every width <= 64, hidden activation 0 = ReLU, 1 = ELU(alpha 1), optionally torch.sigmoid on the output;
  * fp32 (exact fma chains on v_mfma_f32_32x32x2_f32).  weights w_l are [dims[l+1]][dims[l]] row-major as nn.Linear stores them.
- *   pnr_mlp_pack      weights -> MFMA-ordered blob of pnr_mlp_packed_bytes (W_l and W_l^T); call again after every optimiser step
+ *   pnr_mlp_pack      weights -> MFMA-ordered blob of pnr_mlp_packed_bytes (W_l and W_l^T, once as fp32 and once as split-fp16 pairs scaled by one power
+ *                     of two per layer); call again after every optimiser step
+ *   The forward runs on the fp16 matrix pipe with split operands (22-bit products, fp32 accumulation, per-tile power-of-two scaling; outputs within 2e-6
+ *   of the exact launch relative to the largest output); pnr_set_option("mlp_f16x3", 0) selects the exact fp32 instructions.  The backward is fp32.
  *   pnr_mlp_forward   x [B, dims[0]] -> y [B, dims[n_layers]]
  *   pnr_mlp_backward  x, dy [B, dims[n_layers]] -> dx [B, dims[0]] (NULL: not wanted), dw_l [dims[l+1]][dims[l]] (NULL: not wanted);
  *                     hidden activations are recomputed from x; dw is reduced deterministically through `workspace`.

@@ -62,24 +62,60 @@ static bool make_plan(const pnr_mlp_desc* d, MlpPlan& p) {
 struct MlpWeights { const float* w[3]; };
 struct MlpGrads { float* dw[3]; };
 
-// packed slot of a matrix M [rows][cols] (row-major source given by `transposed`): [row tile][k tile][r 0..15][lane] = M[rt*32 + lane%32][kt*32 + frag_row(r, lane/32)]
+// The blob pnr_mlp_pack writes: [fp32 part: packed_floats floats][split-fp16 part: the same byte size][inverse weight scales: 4 floats].
+//   fp32 slot of a matrix M [rows][cols]: [row tile][k tile][r 0..15][lane] = M[rt*32 + lane%32][kt*32 + frag_row(r, lane/32)]
+//   fp16 slot (same byte offset inside its part, same size): [row tile][k block kb = 0..2*NKT-1] blocks of 2 KiB = [hi: 64 lanes x 8 halfs][lo: same],
+//     element j of lane = the split of M[rt*32 + lane%32][f16_col_from_frag(kb, lane/32, j)] * wscale_l, where wscale_l is the power of two that
+//     puts max|W_l| into [2^14, 2^15) (fp16 holds 11 bits from 2^-14 up: weights at the usual 1/sqrt(fan_in) scale would leave their lo halves
+//     subnormal); 1 / wscale_l is stored behind the two parts and folded into the kernels' unscaling of each layer's accumulators.
+__host__ __device__ inline uint32_t mlp_f16_part_floats(const MlpPlan& p) { return p.packed_floats; }           // offset of the fp16 part, in floats
+__host__ __device__ inline uint32_t mlp_scales_floats(const MlpPlan& p) { return 2u * p.packed_floats; }       // offset of the 4 inverse scales
+__device__ __forceinline__ float pow2_scale_for(float mx, float* inv) {   // s = 2^k with s * mx in [2^14, 2^15); mx == 0 or not finite: 1
+    int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+    if (e == 0 || e == 255) { *inv = 1.0f; return 1.0f; }
+    e = e < 15 ? 15 : (e > 250 ? 250 : e);
+    *inv = __uint_as_float((uint32_t)(e - 14) << 23);          // 2^(e - 127 - 14)
+    return __uint_as_float((uint32_t)(268 - e) << 23);         // 2^(14 - (e - 127))
+}
+constexpr uint32_t kPackChunks = 4;     // workgroups per slot (each repeats the layer's max: 16 loads per thread, one wave reduction)
 __global__ void __launch_bounds__(256) k_mlp_pack(MlpPlan p, MlpWeights ws, float* __restrict__ packed) {
-    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= p.packed_floats) return;
-    for (uint32_t slot = 0; slot < 2 * p.n_layers; slot++) {
-        const bool tr = slot >= p.n_layers;
-        const uint32_t l = tr ? slot - p.n_layers : slot;
-        const uint32_t off = tr ? p.wt_off[l] : p.w_off[l];
-        const uint32_t in = p.dims[l], out = p.dims[l + 1];
-        const uint32_t rows = tr ? in : out, cols = tr ? out : in;
-        const uint32_t nkt = plan_tiles(p, tr ? l + 1 : l), size = plan_tiles(p, tr ? l : l + 1) * nkt * 1024;
-        if (e < off || e >= off + size) continue;
-        const uint32_t q = e - off, lane = q & 63, r = (q >> 6) & 15, t = q >> 10, kt = t % nkt, rt = t / nkt;
-        const uint32_t row = rt * 32 + (lane & 31), col = kt * 32 + (uint32_t)frag_row((int)r, (int)(lane >> 5));
-        float v = 0.0f;
-        if (row < rows && col < cols) v = tr ? ws.w[l][(size_t)col * in + row] : ws.w[l][(size_t)row * in + col];
-        packed[e] = v;
-        return;
+    // slot blockIdx.x (W_l: l, W_l^T: n_layers + l), quarter blockIdx.y of it: the layer's max|w| first, then both formats of the quarter
+    __shared__ float red[4];
+    const uint32_t slot = blockIdx.x;
+    const bool tr = slot >= p.n_layers;
+    const uint32_t l = tr ? slot - p.n_layers : slot;
+    const uint32_t in = p.dims[l], out = p.dims[l + 1];
+    float mx = 0.0f;
+    for (uint32_t e = threadIdx.x; e < in * out; e += 256) mx = fmaxf(mx, fabsf(ws.w[l][e]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    float winv;
+    const float wscale = pow2_scale_for(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), &winv);
+    if (!tr && blockIdx.y == 0 && threadIdx.x == 0) packed[mlp_scales_floats(p) + l] = winv;
+    const uint32_t off = tr ? p.wt_off[l] : p.w_off[l];
+    const uint32_t rows = tr ? in : out, cols = tr ? out : in;
+    const uint32_t nkt = plan_tiles(p, tr ? l + 1 : l), size = plan_tiles(p, tr ? l : l + 1) * nkt * 1024;
+    _Float16* hpart = reinterpret_cast<_Float16*>(packed + mlp_f16_part_floats(p) + off);
+    for (uint32_t q = blockIdx.y * 256 + threadIdx.x; q < size; q += 256 * kPackChunks) {
+        {   // fp32 element q of the slot
+            const uint32_t lane = q & 63, r = (q >> 6) & 15, t = q >> 10, kt = t % nkt, rt = t / nkt;
+            const uint32_t row = rt * 32 + (lane & 31), col = kt * 32 + (uint32_t)frag_row((int)r, (int)(lane >> 5));
+            float v = 0.0f;
+            if (row < rows && col < cols) v = tr ? ws.w[l][(size_t)col * in + row] : ws.w[l][(size_t)row * in + col];
+            packed[off + q] = v;
+        }
+        {   // fp16 pair q of the slot: block b = q / 512, lane, element j
+            const uint32_t b = q >> 9, lane = (q >> 3) & 63, j = q & 7, kb = b % (2 * nkt), rt = b / (2 * nkt);
+            const uint32_t row = rt * 32 + (lane & 31), col = (uint32_t)f16_col_from_frag((int)kb, (int)(lane >> 5), (int)j);
+            float v = 0.0f;
+            if (row < rows && col < cols) v = (tr ? ws.w[l][(size_t)col * in + row] : ws.w[l][(size_t)row * in + col]) * wscale;
+            const _Float16 hi = (_Float16)v;
+            const _Float16 lo = (_Float16)(v - (float)hi);
+            hpart[(size_t)b * 1024 + lane * 8 + j] = hi;
+            hpart[(size_t)b * 1024 + 512 + lane * 8 + j] = lo;
+        }
     }
 }
 
@@ -281,6 +317,38 @@ __device__ __forceinline__ void wgrad_accumulate(f32x16 (&acc)[2][2], const floa
 template <int NL, int TI, int TO>
 __host__ __device__ constexpr int tiles_at(int d) { return d == 0 ? TI : (d == NL ? TO : 2); }
 
+// reduce the 4 waves' dW through LDS (`red`: the staging area, 8 tiles of 2080 floats >= 64 x 64 x 3), then one partial row per workgroup
+template <int NL, int TI, int TO>
+__device__ __forceinline__ void mlp_dw_to_partial(const MlpPlan& p, const f32x16 (&dw0)[2][2], const f32x16 (&dw1)[2][2], const f32x16 (&dw2)[2][2], float* __restrict__ red,
+                                                  float* __restrict__ partial, int lane, int wave) {
+    __syncthreads();
+    float* out = partial + (size_t)blockIdx.x * p.dw_floats;
+    const int c = lane & 31, hh = lane >> 5;
+    for (int wv = 0; wv < kMlpWaves; wv++) {
+        if (wave == wv) {
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+                const uint32_t in = p.dims[l], outd = p.dims[l + 1];
+#pragma unroll
+                for (int rt = 0; rt < tiles_at<NL, TI, TO>(l + 1); rt++)
+#pragma unroll
+                    for (int ct = 0; ct < tiles_at<NL, TI, TO>(l); ct++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const uint32_t row = rt * 32 + frag_row(r, hh), col = ct * 32 + c;
+                            if (row < outd && col < in) {
+                                float* q = red + p.dw_off[l] + row * in + col;
+                                const float v = l == 0 ? dw0[rt][ct][r] : (l == 1 ? dw1[rt][ct][r] : dw2[rt][ct][r]);
+                                *q = (wv == 0 ? 0.0f : *q) + v;
+                            }
+                        }
+            }
+        }
+        __syncthreads();
+    }
+    for (uint32_t e = threadIdx.x; e < p.dw_floats; e += kMlpThreads) out[e] = red[e];
+}
+
 template <int NL, int TI, int TO, int ACT>
 __global__ void __launch_bounds__(kMlpThreads) k_mlp_fwd(MlpPlan p, const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ x_tail, uint32_t B,
                                                          float* __restrict__ y) {
@@ -413,34 +481,177 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd(MlpPlan p, const float*
         }
         wave_sync();
     }
-    // reduce the 4 waves' dW through LDS (the staging area: 8 tiles of 2080 floats >= 64 x 64 x 3), then one partial row per workgroup
-    float* red = lds + p.packed_floats;
-    __syncthreads();
-    float* out = partial + (size_t)blockIdx.x * p.dw_floats;
-    const int c = lane & 31, hh = lane >> 5;
-    for (int wv = 0; wv < kMlpWaves; wv++) {
-        if (wave == wv) {
+    mlp_dw_to_partial<NL, TI, TO>(p, dw0, dw1, dw2, lds + p.packed_floats, partial, lane, wave);
+}
+
+// ------------------------------------------------------------------------------------------
+// The FORWARD launch on the fp16 matrix pipe ("f16x3", field_core.hpp: every operand v = hi + lo with hi = fp16(v), lo = fp16(v - hi), a product is
+// a_hi.b_hi + a_hi.b_lo + a_lo.b_hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation -- 22-bit products at 1/5.3 of the fp32 pipe's cycles).
+//  * Range: encoder features start at 1e-4 (gridencoder/grid.py:107), below fp16's normal range, and nothing bounds a user's activations, so every operand
+//    tile is multiplied by the power of two that puts its largest magnitude (wave reduction: 4 DPP steps + 4 readlanes) into [2^14, 2^15) before it is
+//    split; the weights get one such power per layer at pack time.  A fragment is carried as (stored values, integer exponent): powers of two commute
+//    with the products and with ReLU, so un-scaling costs integer arithmetic on the exponent, not an instruction per value; the scaling itself rides on
+//    the conversions (v_fma_mix*: fp32 multiply-add, one rounding to f16).
+//  * Measured (626 k rows): 32-64-64-16 ReLU 100 -> 55 us, 35-64-15 ELU 108 -> 79 us; outputs within 2e-6 of the float64 layer loop relative to the
+//    largest output, as the fp32 launch (tests/test_gpu_ops.py::test_fused_mlp_forward_backward_match_float64).
+//  The BACKWARD stays on the exact fp32 instructions (mlp_backward_impl says why).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dpp_max_shr(float v, int which) {
+    int t;
+    const int b = __float_as_int(v);
+    if (which == 1) t = __builtin_amdgcn_update_dpp(b, b, 0x111, 0xf, 0xf, false);        // row_shr:1
+    else if (which == 2) t = __builtin_amdgcn_update_dpp(b, b, 0x112, 0xf, 0xf, false);   // row_shr:2
+    else if (which == 4) t = __builtin_amdgcn_update_dpp(b, b, 0x114, 0xf, 0xf, false);   // row_shr:4
+    else t = __builtin_amdgcn_update_dpp(b, b, 0x118, 0xf, 0xf, false);                   // row_shr:8
+    return fmaxf(v, __int_as_float(t));
+}
+// Every fragment is carried as (stored values, exponent e) with true = stored * 2^e, e a wave-uniform integer: powers of two commute with the
+// matrix products and with ReLU, so the unscaling of a layer's accumulators costs no instruction per value -- it is integer arithmetic on e.
+// biased exponent (0 = the tile is all zeros, 255: an Inf / NaN somewhere) of the largest |stored value| of a tile; wave-uniform
+template <int NT>
+__device__ __forceinline__ int tile_max_exp(const f32x16 (&a)[2]) {
+    float m = 0.0f;
 #pragma unroll
-            for (int l = 0; l < NL; l++) {
-                const uint32_t in = p.dims[l], outd = p.dims[l + 1];
+    for (int t = 0; t < NT; t++)
 #pragma unroll
-                for (int rt = 0; rt < tiles_at<NL, TI, TO>(l + 1); rt++)
+        for (int r = 0; r < 16; r++) m = fmaxf(m, fabsf(a[t][r]));
+    m = dpp_max_shr(m, 1); m = dpp_max_shr(m, 2); m = dpp_max_shr(m, 4); m = dpp_max_shr(m, 8);   // lane 15 of every row of 16: the row's maximum
+    const int b = __float_as_int(m);     // non-negative floats order like their bit patterns
+    uint32_t u = (uint32_t)__builtin_amdgcn_readlane(b, 15);
+    u = max(u, (uint32_t)__builtin_amdgcn_readlane(b, 31));
+    u = max(u, (uint32_t)__builtin_amdgcn_readlane(b, 47));
+    u = max(u, (uint32_t)__builtin_amdgcn_readlane(b, 63));
+    return (int)((u >> 23) & 0xffu);
+}
+// k with 2^k * (largest |stored|) in [2^14, 2^15) (0 for an all-zero or non-finite tile)
+__device__ __forceinline__ int split_exp(int max_biased_exp) { return (max_biased_exp == 0 || max_biased_exp == 255) ? 0 : 141 - max_biased_exp; }
+__device__ __forceinline__ float pow2i(int k) {   // 2^k, k clamped to the normal range
+    k = k < -126 ? -126 : (k > 127 ? 127 : k);
+    return __uint_as_float((uint32_t)(k + 127) << 23);
+}
+__device__ __forceinline__ int exp_of_pow2(float v) { return (int)((__float_as_uint(v) >> 23) & 0xffu) - 127; }
+// hi = fp16(v * s), lo = fp16(v * s - hi) for a power of two s: the scaling rides on the conversions (v_fma_mix*: fp32 fma, ONE rounding to f16) -- two
+// instructions per value and half
+__device__ __forceinline__ void split_scaled(const f32x16& a, int half_idx, float s, h8& hi, h8& lo) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 hw, lw;
 #pragma unroll
-                    for (int ct = 0; ct < tiles_at<NL, TI, TO>(l); ct++)
-#pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            const uint32_t row = rt * 32 + frag_row(r, hh), col = ct * 32 + c;
-                            if (row < outd && col < in) {
-                                float* q = red + p.dw_off[l] + row * in + col;
-                                const float v = l == 0 ? dw0[rt][ct][r] : (l == 1 ? dw1[rt][ct][r] : dw2[rt][ct][r]);
-                                *q = (wv == 0 ? 0.0f : *q) + v;
-                            }
-                        }
-            }
-        }
-        __syncthreads();
+    for (int j = 0; j < 8; j += 2) {
+        const float v0 = a[half_idx * 8 + j], v1 = a[half_idx * 8 + j + 1];
+        uint32_t hb, lb;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hb) : "v"(v0), "v"(s));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hb) : "v"(v1), "v"(s));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lb) : "v"(v0), "v"(s), "v"(hb));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lb) : "v"(v1), "v"(s), "v"(hb));
+        hw[j / 2] = hb; lw[j / 2] = lb;
     }
-    for (uint32_t e = threadIdx.x; e < p.dw_floats; e += kMlpThreads) out[e] = red[e];
+    asm volatile("s_nop 3" : "+v"(hw), "+v"(lw));   // inline-asm VALU writes -> MFMA reads: the compiler's hazard recogniser does not see them (field_core.hpp: split8)
+    hi = __builtin_bit_cast(h8, hw);
+    lo = __builtin_bit_cast(h8, lw);
+}
+struct HOp { h8 hi[4], lo[4]; };        // a tile of up to 64 features (or, transposed, 2 x 32 features by 2 k-blocks of 16 samples) as MFMA operands
+template <int NT>
+__device__ __forceinline__ void split_tiles(const f32x16 (&a)[2], int k, HOp& o) {
+    const float s = pow2i(k);
+#pragma unroll
+    for (int t = 0; t < NT; t++) { split_scaled(a[t], 0, s, o.hi[2 * t], o.lo[2 * t]); split_scaled(a[t], 1, s, o.hi[2 * t + 1], o.lo[2 * t + 1]); }
+}
+// out[rt] = sum_kb W[rt][kb] . b[kb]
+template <int NRT, int NKB>
+__device__ __forceinline__ void layer_h(const unsigned char* __restrict__ slot, const HOp& b, f32x16 (&out)[2], int lane) {
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++) {
+        out[rt] = zero16();
+#pragma unroll
+        for (int kb = 0; kb < NKB; kb++) {
+            const unsigned char* blk = slot + (size_t)(rt * NKB + kb) * 2048;
+            const h8 ahi = *reinterpret_cast<const h8*>(blk + lane * 16);
+            const h8 alo = *reinterpret_cast<const h8*>(blk + 1024 + lane * 16);
+            out[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, b.hi[kb], out[rt], 0, 0, 0);
+            out[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, b.lo[kb], out[rt], 0, 0, 0);
+            out[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, b.hi[kb], out[rt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keeps the weight reads of later blocks from being hoisted above this group (register blow-up)
+    }
+}
+// hidden activation of a layer's accumulators (stored, e): ReLU commutes with the power of two and keeps e; ELU needs the true value (e becomes 0)
+template <int NT, int ACT>
+__device__ __forceinline__ void act_stored(f32x16 (&v)[2], int e) {
+    if constexpr (ACT == 0) {
+#pragma unroll
+        for (int t = 0; t < NT; t++) v[t] = relu16(v[t]);
+    } else {
+        const float u = pow2i(e);
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) v[t][r] = act_fwd(v[t][r] * u, ACT);
+    }
+}
+template <int NL, int TI, int TO, int ACT>
+__global__ void __launch_bounds__(kMlpThreads) k_mlp_fwd_h(MlpPlan p, const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ x_tail, uint32_t B,
+                                                           float* __restrict__ y) {
+    extern __shared__ float lds[];
+    const uint32_t wfloats = p.wt_off[0];   // forward slots only
+    {
+        const float* src = packed + mlp_f16_part_floats(p);
+        for (uint32_t i = threadIdx.x * 4; i < wfloats; i += kMlpThreads * 4) *reinterpret_cast<float4*>(&lds[i]) = *reinterpret_cast<const float4*>(&src[i]);
+    }
+    const unsigned char* w = reinterpret_cast<const unsigned char*>(lds);
+    const int kw0 = -exp_of_pow2(packed[mlp_scales_floats(p)]), kw1 = -exp_of_pow2(packed[mlp_scales_floats(p) + 1]),
+              kw2 = NL == 3 ? -exp_of_pow2(packed[mlp_scales_floats(p) + 2]) : 0;       // log2 of the layers' weight scales
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* stage = lds + wfloats + wave * kStageFloats;
+    __syncthreads();
+    const uint32_t nblock_tiles = (B + 32 * kMlpWaves - 1) / (32 * kMlpWaves);
+    float xr[16 * TI];
+    if (p.lm) raw_load_lm<TI>(xr, x, x_tail, p.tail, (blockIdx.x * kMlpWaves + wave) * 32, B, lane);
+    else raw_load<TI>(xr, x, (blockIdx.x * kMlpWaves + wave) * 32, B, p.dims[0], lane);
+    for (uint32_t bt = blockIdx.x; bt < nblock_tiles; bt += gridDim.x) {
+        const uint32_t row0 = (bt * kMlpWaves + wave) * 32;
+        if (p.lm) raw_to_stage_lm<TI>(stage, xr, p.tail, p.tail_magic, row0, B, lane);
+        else raw_to_stage<TI>(stage, xr, row0, B, p.dims[0], p.magic[0], lane);
+        wave_sync();
+        if (p.lm) raw_load_lm<TI>(xr, x, x_tail, p.tail, ((bt + gridDim.x) * kMlpWaves + wave) * 32, B, lane);
+        else raw_load<TI>(xr, x, ((bt + gridDim.x) * kMlpWaves + wave) * 32, B, p.dims[0], lane);
+        f32x16 a[2], o[2];
+        HOp b;
+        frag_from_stage<TI>(stage, lane, a);
+        int k = split_exp(tile_max_exp<TI>(a)), e;
+        split_tiles<TI>(a, k, b);
+        layer_h<2, 2 * TI>(w + (size_t)p.w_off[0] * 4, b, o, lane);
+        e = -k - kw0;
+        act_stored<2, ACT>(o, e);
+        if (ACT != 0) e = 0;
+        k = split_exp(tile_max_exp<2>(o));
+        split_tiles<2>(o, k, b);
+        if constexpr (NL == 3) {
+            layer_h<2, 4>(w + (size_t)p.w_off[1] * 4, b, a, lane);
+            e = e - k - kw1;
+            act_stored<2, ACT>(a, e);
+            if (ACT != 0) e = 0;
+            k = split_exp(tile_max_exp<2>(a));
+            split_tiles<2>(a, k, b);
+            layer_h<TO, 4>(w + (size_t)p.w_off[2] * 4, b, o, lane);
+            const float u = pow2i(e - k - kw2);
+#pragma unroll
+            for (int t = 0; t < TO; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[t][r] *= u;
+        } else {
+            layer_h<TO, 4>(w + (size_t)p.w_off[1] * 4, b, a, lane);
+            const float u = pow2i(e - k - kw1);
+#pragma unroll
+            for (int t = 0; t < TO; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[t][r] = a[t][r] * u;
+        }
+        wave_sync();
+        frag_to_stage<TO>(stage, lane, o);
+        wave_sync();
+        stage_to_global<TO>(stage, y, row0, B, p.dims[NL], p.magic[NL], lane, p.out_act != 0);
+        wave_sync();
+    }
 }
 
 // dw[e] = sum over the workgroup partials in a fixed order (8 groups of 32 columns per workgroup)
@@ -477,7 +688,7 @@ extern "C" {
 
 uint64_t pnr_mlp_packed_bytes(const pnr_mlp_desc* desc) {
     MlpPlan p;
-    return make_plan(desc, p) ? (uint64_t)p.packed_floats * 4 : 0;
+    return make_plan(desc, p) ? ((uint64_t)p.packed_floats * 2 + 4) * 4 : 0;
 }
 
 int pnr_mlp_pack(const pnr_mlp_desc* desc, const float* w0, const float* w1, const float* w2, float* packed, pnr_stream_t stream) {
@@ -485,7 +696,7 @@ int pnr_mlp_pack(const pnr_mlp_desc* desc, const float* w0, const float* w1, con
     if (!make_plan(desc, p)) return PNR_ERR_UNSUPPORTED;
     if (!w0 || !w1 || (p.n_layers == 3 && !w2) || !packed) return PNR_ERR_INVALID;
     MlpWeights ws{{w0, w1, w2}};
-    hipLaunchKernelGGL(k_mlp_pack, dim3(cdiv(p.packed_floats, 256)), dim3(256), 0, as_stream(stream), p, ws, packed);
+    hipLaunchKernelGGL(k_mlp_pack, dim3(2 * p.n_layers, kPackChunks), dim3(256), 0, as_stream(stream), p, ws, packed);
     return check_launch();
 }
 
@@ -503,6 +714,9 @@ int pnr_mlp_pack(const pnr_mlp_desc* desc, const float* w0, const float* w1, con
             hipLaunchKernelGGL((KERNEL<NLV, TIV, TOV, 1>), dim3(grid), dim3(kMlpThreads), lds, s, __VA_ARGS__);                                \
         }                                                                                                                                      \
     } while (0)
+#ifdef PNR_MLP_MINI   /* compile-time experiments only: one instantiation, so that a resource-usage build takes seconds */
+#define PNR_MLP_SWITCH(KERNEL, ...) do { hipLaunchKernelGGL((KERNEL<3, 1, 1, 0>), dim3(grid), dim3(kMlpThreads), lds, s, __VA_ARGS__); } while (0)
+#else
 #define PNR_MLP_SWITCH(KERNEL, ...)                                                                   \
     do {                                                                                              \
         const int ti = (int)tiles32(p.dims[0]), to = (int)tiles32(p.dims[p.n_layers]);                \
@@ -518,6 +732,7 @@ int pnr_mlp_pack(const pnr_mlp_desc* desc, const float* w0, const float* w1, con
             else PNR_MLP_DISPATCH(KERNEL, 3, 2, 2, __VA_ARGS__);                                      \
         }                                                                                             \
     } while (0)
+#endif
 
 // lm_levels: 0 = x is row-major [B, dims[0]]; 16 = x is a level-major encoder output [16][B][2] followed by x_tail [B, dims[0] - 32]
 static int plan_sources(MlpPlan& p, uint32_t lm_levels, const float* x_tail) {
@@ -542,7 +757,8 @@ static int mlp_forward_impl(const pnr_mlp_desc* desc, const float* packed, const
     if (lds > 160 * 1024) return PNR_ERR_UNSUPPORTED;
     hipStream_t s = as_stream(stream);
     const uint32_t tiles = cdiv(B, 32 * kMlpWaves), grid = tiles < 2 * kMlpMaxBlocks ? tiles : 2 * kMlpMaxBlocks;   // two workgroups per CU
-    PNR_MLP_SWITCH(k_mlp_fwd, p, packed, x, x_tail, B, y);
+    if (g_opt_mlp_f16x3) PNR_MLP_SWITCH(k_mlp_fwd_h, p, packed, x, x_tail, B, y);
+    else PNR_MLP_SWITCH(k_mlp_fwd, p, packed, x, x_tail, B, y);
     return check_launch();
 }
 
@@ -580,8 +796,11 @@ static int mlp_backward_impl(const pnr_mlp_desc* desc, const float* packed, cons
     if (lds > 160 * 1024 || p.dw_floats > (uint32_t)(kMlpWaves * 2 * kStageFloats)) return PNR_ERR_UNSUPPORTED;
     const uint32_t blocks = mlp_blocks(B), grid = blocks;
     float* partial = static_cast<float*>(workspace);
+    // (the backward stays on the exact fp32 matrix instructions: three split-fp16 formulations were built and measured slower or barely faster --
+    //  one wave per tile spills its 128 weight-gradient accumulators, two cooperating waves per tile are bound by their step-by-step hand-over:
+    //  profiles/EXPERIMENTS.md, round 4)
     PNR_MLP_SWITCH(k_mlp_bwd, p, packed, x, x_tail, dy, y, B, dx, partial);
-    hipLaunchKernelGGL(k_mlp_dw_reduce, dim3(cdiv(p.dw_floats, 32)), dim3(256), 0, s, partial, blocks, p, gr);
+    hipLaunchKernelGGL(k_mlp_dw_reduce, dim3(cdiv(p.dw_floats, 32)), dim3(256), 0, s, partial, grid, p, gr);
     return check_launch();
 }
 
