@@ -654,6 +654,231 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_fwd_h(MlpPlan p, const floa
     }
 }
 
+// ---- the backward on the fp16 pipe ----------------------------------------------------------------------------------------------------
+// Same tile walk as k_mlp_bwd (recompute h, stage a (gradient, activation) pair sample-major in the wave's LDS tiles per layer, weight gradient with the
+// SAMPLE as the k dimension, propagate through W^T), every product split-fp16.  The weight gradient's operands are read from the staged fp32 tiles
+// as "lane = feature, 8 consecutive samples" (conflict-free column walks), scaled and split on the way into the matrix instruction -- no transposed
+// copies are kept in registers (a first version formed them with a second set of matrix instructions and spilled; profiles/EXPERIMENTS.md).
+// The launch-long sum of a layer is (stored, P) with dW = stored * 2^-P per wave: a tile's two operands are scaled by 2^kg and 2^ka with
+// kg + ka - (e_g + e_a) = P, so its matrix instructions accumulate straight into the sum; kg puts the gradient side at 2^14, ka is what P leaves for the
+// activation side -- anywhere below its own 2^14 is fine (fp16 keeps an absolute 2^-25 there, and a tile whose gradients are that much smaller than the
+// established scale contributes correspondingly little).  Only when ka would overflow the activation side is P lowered and the stored sum rescaled.
+struct DwScale { int P; bool have; };
+__device__ __forceinline__ void split_scaled8(const float (&v)[8], float s, h8& hi, h8& lo) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 hw, lw;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        uint32_t hb, lb;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hb) : "v"(v[j]), "v"(s));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hb) : "v"(v[j + 1]), "v"(s));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lb) : "v"(v[j]), "v"(s), "v"(hb));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lb) : "v"(v[j + 1]), "v"(s), "v"(hb));
+        hw[j / 2] = hb; lw[j / 2] = lb;
+    }
+    asm volatile("s_nop 3" : "+v"(hw), "+v"(lw));
+    hi = __builtin_bit_cast(h8, hw);
+    lo = __builtin_bit_cast(h8, lw);
+}
+// feature `col` of the staged tile, samples kb*16 + hh*8 .. +7, scaled by s and split
+__device__ __forceinline__ void column_op(const float* __restrict__ buf, int col, int kb, int hh, float s, h8& hi, h8& lo) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = buf[(kb * 16 + hh * 8 + j) * kStage + col];
+    split_scaled8(v, s, hi, lo);
+}
+template <int NRT, int NCT>
+__device__ __forceinline__ void wgrad_lds(f32x16 (&dw)[2][2], DwScale& st, const float* __restrict__ G, int e_g, int mg, const float* __restrict__ A, int e_a, int ma, int lane) {
+    if (mg == 0 || ma == 0) return;     // an all-zero side: nothing to add (wave-uniform)
+    const int kg = split_exp(mg), ka_top = split_exp(ma);
+    int ka = st.P + e_g + e_a - kg;
+    if (!st.have || ka > ka_top) {
+        const int Pn = kg + (ka_top - 4) - e_g - e_a;
+        if (st.have) {
+            const float f = Pn - st.P < -126 ? 0.0f : pow2i(Pn - st.P);
+#pragma unroll
+            for (int rt = 0; rt < NRT; rt++)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ct++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) dw[rt][ct][r] *= f;
+        }
+        st.P = Pn; st.have = true;
+        ka = ka_top - 4;
+    }
+    const int c = lane & 31, hh = lane >> 5;
+    const float sg = pow2i(kg), sa = pow2i(ka);
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {       // 16 samples at a time: 24 operand registers live instead of 48
+        h8 ahi[2], alo[2];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ct++) column_op(A, ct * 32 + c, kb, hh, sa, ahi[ct], alo[ct]);
+#pragma unroll
+        for (int rt = 0; rt < NRT; rt++) {
+            h8 ghi, glo;
+            column_op(G, rt * 32 + c, kb, hh, sg, ghi, glo);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ct++) {
+                dw[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(glo, ahi[ct], dw[rt][ct], 0, 0, 0);
+                dw[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ghi, alo[ct], dw[rt][ct], 0, 0, 0);
+                dw[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ghi, ahi[ct], dw[rt][ct], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// g (stored) *= act'(h): the exponent of g is untouched (h: the stored activation; ReLU only needs its sign, ELU stores true values)
+template <int NT, int ACT>
+__device__ __forceinline__ void act_grad_stored(f32x16 (&g)[2], const f32x16 (&h)[2]) {
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            if constexpr (ACT == 0) g[t][r] = h[t][r] > 0.0f ? g[t][r] : 0.0f;
+            else g[t][r] *= act_grad(h[t][r], ACT);
+        }
+}
+
+template <int NL, int TI, int TO, int ACT>
+__global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd_h(MlpPlan p, const float* __restrict__ packed, const float* __restrict__ x, const float* __restrict__ x_tail, const float* __restrict__ dy,
+                                                           const float* __restrict__ yout, uint32_t B, float* __restrict__ dx, float* __restrict__ partial) {
+    extern __shared__ float lds[];
+    {
+        const float* src = packed + mlp_f16_part_floats(p);
+        for (uint32_t i = threadIdx.x * 4; i < p.packed_floats; i += kMlpThreads * 4) *reinterpret_cast<float4*>(&lds[i]) = *reinterpret_cast<const float4*>(&src[i]);
+    }
+    const unsigned char* w = reinterpret_cast<const unsigned char*>(lds);
+    const int kw0 = -exp_of_pow2(packed[mlp_scales_floats(p)]), kw1 = -exp_of_pow2(packed[mlp_scales_floats(p) + 1]),
+              kw2 = NL == 3 ? -exp_of_pow2(packed[mlp_scales_floats(p) + 2]) : 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* GA = lds + p.packed_floats + wave * 2 * kStageFloats;   // gradient side of the weight-gradient products
+    float* GB = GA + kStageFloats;                                 // activation side
+    __syncthreads();
+    f32x16 dw0[2][2], dw1[2][2], dw2[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) { dw0[i][j] = zero16(); dw1[i][j] = zero16(); dw2[i][j] = zero16(); }
+    DwScale st0{0, false}, st1{0, false}, st2{0, false};
+    const uint32_t nblock_tiles = (B + 32 * kMlpWaves - 1) / (32 * kMlpWaves);
+    float xr[16 * TI], yn[16 * TO], sn[16 * TO];
+    if (p.lm) raw_load_lm<TI>(xr, x, x_tail, p.tail, (blockIdx.x * kMlpWaves + wave) * 32, B, lane);
+    else raw_load<TI>(xr, x, (blockIdx.x * kMlpWaves + wave) * 32, B, p.dims[0], lane);
+    raw_load<TO>(yn, dy, (blockIdx.x * kMlpWaves + wave) * 32, B, p.dims[NL], lane);
+    if (yout) raw_load<TO>(sn, yout, (blockIdx.x * kMlpWaves + wave) * 32, B, p.dims[NL], lane);
+    for (uint32_t bt = blockIdx.x; bt < nblock_tiles; bt += gridDim.x) {
+        const uint32_t row0 = (bt * kMlpWaves + wave) * 32;
+        if (p.lm) raw_to_stage_lm<TI>(GB, xr, p.tail, p.tail_magic, row0, B, lane);
+        else raw_to_stage<TI>(GB, xr, row0, B, p.dims[0], p.magic[0], lane);
+        if (yout) {   // dZ = dY (1 - y) y: sigmoid_backward, in the raw layout both tiles share
+#pragma unroll
+            for (int k = 0; k < 16 * TO; k++) yn[k] = (yn[k] * (1.0f - sn[k])) * sn[k];
+        }
+        raw_to_stage<TO>(GA, yn, row0, B, p.dims[NL], p.magic[NL], lane);
+        wave_sync();
+        const uint32_t next0 = ((bt + gridDim.x) * kMlpWaves + wave) * 32;
+        raw_load<TO>(yn, dy, next0, B, p.dims[NL], lane);          // the next tile's dY flies during this tile's matrix work
+        if (yout) raw_load<TO>(sn, yout, next0, B, p.dims[NL], lane);
+        f32x16 h1[2], h2[2], g[2], t[2];
+        HOp b;
+        // forward again: x -> h1 (-> h2)
+        frag_from_stage<TI>(GB, lane, t);
+        const int mx = tile_max_exp<TI>(t), kx = split_exp(mx);
+        split_tiles<TI>(t, kx, b);
+        layer_h<2, 2 * TI>(w + (size_t)p.w_off[0] * 4, b, h1, lane);
+        const int e1s = -kx - kw0;
+        act_stored<2, ACT>(h1, e1s);
+        const int e1 = ACT != 0 ? 0 : e1s;
+        const int m1 = tile_max_exp<2>(h1);
+        int mg, kg, eg = 0;
+        if constexpr (NL == 3) {
+            const int k1 = split_exp(m1);
+            split_tiles<2>(h1, k1, b);
+            layer_h<2, 4>(w + (size_t)p.w_off[1] * 4, b, h2, lane);
+            const int e2s = e1 - k1 - kw1;
+            act_stored<2, ACT>(h2, e2s);
+            const int e2 = ACT != 0 ? 0 : e2s;
+            const int m2 = tile_max_exp<2>(h2);
+            frag_from_stage<TO>(GA, lane, g);
+            mg = tile_max_exp<TO>(g); kg = split_exp(mg);
+            // layer 2: GA = dY, GB <- h2
+            wave_sync();
+            frag_to_stage<2>(GB, lane, h2);
+            wave_sync();
+            wgrad_lds<TO, 2>(dw2, st2, GA, 0, mg, GB, e2, m2, lane);
+            split_tiles<TO>(g, kg, b);
+            layer_h<2, 2 * TO>(w + (size_t)p.wt_off[2] * 4, b, t, lane);          // dH2 = W2^T dY
+            eg = -kg - kw2;
+            act_grad_stored<2, ACT>(t, h2);
+            mg = tile_max_exp<2>(t); kg = split_exp(mg);
+            // layer 1: GA <- dZ2, GB <- h1
+            wave_sync();
+            frag_to_stage<2>(GA, lane, t);
+            frag_to_stage<2>(GB, lane, h1);
+            wave_sync();
+            wgrad_lds<2, 2>(dw1, st1, GA, eg, mg, GB, e1, m1, lane);
+            split_tiles<2>(t, kg, b);
+            layer_h<2, 4>(w + (size_t)p.wt_off[1] * 4, b, g, lane);               // dH1 = W1^T dZ2
+            eg = eg - kg - kw1;
+            act_grad_stored<2, ACT>(g, h1);
+        } else {
+            frag_from_stage<TO>(GA, lane, g);
+            mg = tile_max_exp<TO>(g); kg = split_exp(mg);
+            // layer 1 (the last): GA = dY, GB <- h1
+            wave_sync();
+            frag_to_stage<2>(GB, lane, h1);
+            wave_sync();
+            wgrad_lds<TO, 2>(dw1, st1, GA, 0, mg, GB, e1, m1, lane);
+            split_tiles<TO>(g, kg, b);
+            layer_h<2, 2 * TO>(w + (size_t)p.wt_off[1] * 4, b, t, lane);          // dH1 = W1^T dY
+            eg = -kg - kw1;
+            act_grad_stored<2, ACT>(t, h1);
+            g[0] = t[0]; g[1] = t[1];
+        }
+        // layer 0: GA <- dZ1, GB <- X
+        mg = tile_max_exp<2>(g); kg = split_exp(mg);
+        wave_sync();
+        frag_to_stage<2>(GA, lane, g);
+        if (p.lm) raw_to_stage_lm<TI>(GB, xr, p.tail, p.tail_magic, row0, B, lane);
+        else raw_to_stage<TI>(GB, xr, row0, B, p.dims[0], p.magic[0], lane);
+        wave_sync();
+        if (p.lm) raw_load_lm<TI>(xr, x, x_tail, p.tail, next0, B, lane);   // X is needed twice per tile: its prefetch starts after the second use
+        else raw_load<TI>(xr, x, next0, B, p.dims[0], lane);
+        wgrad_lds<2, TI>(dw0, st0, GA, eg, mg, GB, 0, mx, lane);
+        if (dx) {
+            split_tiles<2>(g, kg, b);
+            layer_h<TI, 4>(w + (size_t)p.wt_off[0] * 4, b, t, lane);              // dX = W0^T dZ1
+            const float u = pow2i(eg - kg - kw0);
+#pragma unroll
+            for (int tt = 0; tt < TI; tt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) t[tt][r] *= u;
+            wave_sync();
+            frag_to_stage<TI>(GA, lane, t);
+            wave_sync();
+            if (p.lm) stage_to_global_lm(GA, dx, row0, B, lane);
+            else stage_to_global<TI>(GA, dx, row0, B, p.dims[0], p.magic[0], lane);
+        }
+        wave_sync();
+    }
+    {   // back to true units: dW = stored * 2^-P (per wave, per layer)
+        const float f0 = st0.have ? pow2i(-st0.P) : 1.0f, f1 = st1.have ? pow2i(-st1.P) : 1.0f, f2 = st2.have ? pow2i(-st2.P) : 1.0f;
+#pragma unroll
+        for (int l = 0; l < NL; l++)     // (only the tiles a layer has: touching the others would keep 64 more accumulator registers alive through the loop)
+#pragma unroll
+            for (int i = 0; i < tiles_at<NL, TI, TO>(l + 1); i++)
+#pragma unroll
+                for (int j = 0; j < tiles_at<NL, TI, TO>(l); j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        if (l == 0) dw0[i][j][r] *= f0;
+                        else if (l == 1) dw1[i][j][r] *= f1;
+                        else dw2[i][j][r] *= f2;
+                    }
+    }
+    mlp_dw_to_partial<NL, TI, TO>(p, dw0, dw1, dw2, lds + p.packed_floats, partial, lane, wave);
+}
+
 // dw[e] = sum over the workgroup partials in a fixed order (8 groups of 32 columns per workgroup)
 __global__ void __launch_bounds__(256) k_mlp_dw_reduce(const float* __restrict__ partial, uint32_t nparts, MlpPlan p, MlpGrads gr) {
     __shared__ float red[8][32];
@@ -796,10 +1021,12 @@ static int mlp_backward_impl(const pnr_mlp_desc* desc, const float* packed, cons
     if (lds > 160 * 1024 || p.dw_floats > (uint32_t)(kMlpWaves * 2 * kStageFloats)) return PNR_ERR_UNSUPPORTED;
     const uint32_t blocks = mlp_blocks(B), grid = blocks;
     float* partial = static_cast<float*>(workspace);
-    // (the backward stays on the exact fp32 matrix instructions: three split-fp16 formulations were built and measured slower or barely faster --
-    //  one wave per tile spills its 128 weight-gradient accumulators, two cooperating waves per tile are bound by their step-by-step hand-over:
-    //  profiles/EXPERIMENTS.md, round 4)
-    PNR_MLP_SWITCH(k_mlp_bwd, p, packed, x, x_tail, dy, y, B, dx, partial);
+    // the split-fp16 backward where it holds its tile without (much) scratch: two layers unless both ends are 64 wide, three layers with 32-wide ends --
+    // every stack of both fields; the wider instantiations spill twice what the fp32 ones do and stay on those
+    const uint32_t ti = tiles32(p.dims[0]), to = tiles32(p.dims[p.n_layers]);
+    const bool h_fits = p.n_layers == 2 ? !(ti == 2 && to == 2) : (ti == 1 && to == 1);
+    if (g_opt_mlp_f16x3 && h_fits) PNR_MLP_SWITCH(k_mlp_bwd_h, p, packed, x, x_tail, dy, y, B, dx, partial);
+    else PNR_MLP_SWITCH(k_mlp_bwd, p, packed, x, x_tail, dy, y, B, dx, partial);
     hipLaunchKernelGGL(k_mlp_dw_reduce, dim3(cdiv(p.dw_floats, 32)), dim3(256), 0, s, partial, grid, p, gr);
     return check_launch();
 }

@@ -1,11 +1,7 @@
 #!/bin/bash
 R=$PWD; export TMPDIR=/tmp; O=$R/gpurun_out/r04; mkdir -p $O
-timeout 1200 python -m pytest tests/test_gpu_ops.py tests/test_gpu_frames.py tests/test_gpu_fullsize.py -m gpu -x -q -k "mlp or train or grad or converge" > $O/pytest_mlph.log 2>&1; echo "rc $?" >> $O/pytest_mlph.log
+timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "mlp" > $O/pytest_mlph.log 2>&1; echo "rc $?" >> $O/pytest_mlph.log
 cd /tmp; rm -rf /tmp/prof_tp
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_tp -o p -- python3 $R/profiles/train_step_bench.py --model palette --steps 20 --warmup 5 > $O/train_palette_h_prof.log 2>&1
 db=$(find /tmp/prof_tp -name '*.db' | head -1)
 python3 $R/profiles/summarize.py $db > $O/train_palette_h.txt
-cd $R
-timeout 300 python profiles/train_step_bench.py --model palette --steps 50 --warmup 5 > $O/train_palette_h.log 2>&1
-timeout 300 python profiles/train_step_bench.py --model nerf --steps 50 --warmup 5 > $O/train_nerf_h.log 2>&1
-timeout 300 python profiles/grad_tolerance.py > $O/grad_tolerance2.log 2>&1
