@@ -61,7 +61,8 @@ int pnr_abi_version(void);
  * the frame loops enqueue beyond the previous frame's count before their first look at the control block; "hosted_tail" (default 1): the frame
  * loops' march launches hand the rays they have not finished within "march_budget" (default 2; "march_budget0" for a frame's first launch, default
  * 0 = that launch finishes every ray itself) sample-less probes to the first workgroups of the lookup launch that follows -- same rows, bit for bit;
- * "march_blocks" (default 0 = automatic): workgroup cap of such a budgeted march launch; "train_coop" (default 1): pnr_march_rays_train*'s counting pass
+ * "march_blocks" (default 0 = automatic): workgroup cap of such a budgeted march launch; "coarse_image" (default 1): pnr_grid_encode_backward_binned accumulates the
+ * coarsest levels (tables of at most 16 384 rows) as LDS images instead of records; "mlp_f16x3" (default 1): the training MLP launches use split-fp16 products; "train_coop" (default 1): pnr_march_rays_train*'s counting pass
  * marches four rays per wave cooperatively (same counts, same rows); "coop_march" also governs the cooperative tail of pnr_march_rays* */
 int pnr_set_option(const char* name, int value);
 

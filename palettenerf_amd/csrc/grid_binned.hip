@@ -291,7 +291,67 @@ __global__ void __launch_bounds__(1024) k_bin_gather(const BinJob* __restrict__ 
     }
 }
 
-struct BinLayout { uint64_t counts, rec_off, cursor, n_jobs, jobs, rec_row, rec_val, total; uint32_t bucket_bound, job_bound; };
+// ------------------------------------------------------------------------------------------
+// The coarsest levels (tables of at most 2 x kBinRows rows: 17^3 and 25^3 of the shipped grids) without records.  Every sample lands in the same few
+// thousand rows there; as records they were 10 M per level squeezed into one or two buckets (run merging by wave shuffles, crowded cursors, split gather
+// jobs: ~100 us per level).  Here a workgroup keeps an fp64 image of (half of) the level in LDS, walks its share of the samples with the lanes of a wave
+// ~chunk/64 samples apart (different rays: different cells, no same-address pile-ups), adds the 8 x 2 weighted gradients with LDS atomics, and dumps
+// the image as fp32; k_coarse_reduce sums the workgroups' images in a fixed order into the table gradient.  No global atomics, deterministic.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kImgThreads = 1024;
+constexpr uint32_t kMaxImgJobs = 8;
+constexpr uint32_t kImgBlocks = 256;     // image workgroups in total (one per CU: 128 KiB of LDS each)
+struct ImgJobs { uint32_t n, level[kMaxImgJobs], row_lo[kMaxImgJobs]; };
+__global__ void __launch_bounds__(kImgThreads) k_coarse_image(const float* __restrict__ grad, const float* __restrict__ inputs, const int32_t* __restrict__ offsets, uint32_t B,
+                                                              LevelParams lp, uint32_t gridtype, bool align_corners, ImgJobs jobs, float* __restrict__ partial /* [n][gridDim.x][kBinRows * 2] */) {
+    extern __shared__ double img[];   // [kBinRows][2]
+    const uint32_t level = jobs.level[blockIdx.y], row_lo = jobs.row_lo[blockIdx.y];
+    const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+    const uint32_t nrows = hashmap_size > row_lo ? (hashmap_size - row_lo < kBinRows ? hashmap_size - row_lo : kBinRows) : 0u;
+    for (uint32_t i = threadIdx.x; i < kBinRows * 2; i += kImgThreads) img[i] = 0.0;
+    __syncthreads();
+    const uint32_t chunk = (B + gridDim.x - 1) / gridDim.x;                    // samples of this workgroup
+    const uint32_t per_lane = (chunk + 63) / 64, per_thread = (per_lane + kImgThreads / 64 - 1) / (kImgThreads / 64);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t first = blockIdx.x * chunk, last = first + chunk < B ? first + chunk : B;
+    const uint32_t lane_first = first + lane * per_lane, lane_last = lane_first + per_lane < last ? lane_first + per_lane : last;
+    for (uint32_t j = 0; j < per_thread; j++) {
+        const uint32_t b = lane_first + wave * per_thread + j;
+        if (b >= lane_last) break;
+        const Corners c = corners_of(inputs, b, B, lp.scale[level], lp.resolution[level], hashmap_size, gridtype, align_corners);
+        if (!c.active) continue;
+        const float2 g = *reinterpret_cast<const float2*>(grad + ((size_t)level * B + b) * 2);
+#pragma unroll
+        for (uint32_t idx = 0; idx < 8; idx++) {
+            const uint32_t r = c.row[idx] - row_lo;
+            if (r < nrows) { atomicAdd(&img[r * 2], (double)(c.w[idx] * g.x)); atomicAdd(&img[r * 2 + 1], (double)(c.w[idx] * g.y)); }
+        }
+    }
+    __syncthreads();
+    float* out = partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (kBinRows * 2);
+    for (uint32_t i = threadIdx.x; i < nrows * 2; i += kImgThreads) out[i] = (float)img[i];
+}
+__global__ void __launch_bounds__(256) k_coarse_reduce(const int32_t* __restrict__ offsets, ImgJobs jobs, uint32_t G, const float* __restrict__ partial, float* __restrict__ grad_grid) {
+    const uint32_t level = jobs.level[blockIdx.y], row_lo = jobs.row_lo[blockIdx.y];
+    const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+    const uint32_t nrows = hashmap_size > row_lo ? (hashmap_size - row_lo < kBinRows ? hashmap_size - row_lo : kBinRows) : 0u;
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= nrows * 2) return;
+    const float* src = partial + (size_t)blockIdx.y * G * (kBinRows * 2) + e;
+    float s = 0.0f;
+    uint32_t g = 0;
+    for (; g + 8 <= G; g += 8) {          // eight loads in flight; summed in workgroup order either way
+        float v[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) v[u] = src[(size_t)(g + u) * (kBinRows * 2)];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) s += v[u];
+    }
+    for (; g < G; g++) s += src[(size_t)g * (kBinRows * 2)];
+    grad_grid[((size_t)offsets[level] + row_lo) * 2 + e] += s;
+}
+
+struct BinLayout { uint64_t counts, rec_off, cursor, n_jobs, jobs, rec_row, rec_val, img, total; uint32_t bucket_bound, job_bound; };
 static BinLayout bin_layout(uint32_t B, uint32_t L, uint64_t total_rows) {
     BinLayout l;
     const uint64_t n_rec = (uint64_t)B * L * 8;
@@ -306,6 +366,7 @@ static BinLayout bin_layout(uint32_t B, uint32_t L, uint64_t total_rows) {
     l.jobs = o; o = al(o + (uint64_t)l.job_bound * sizeof(BinJob));
     l.rec_row = o; o = al(o + n_rec * 2);
     l.rec_val = o; o = al(o + n_rec * 8);
+    l.img = o; o = al(o + (uint64_t)kImgBlocks * kBinRows * 2 * 4);       // the coarse levels' per-workgroup images
     l.total = o;
     return l;
 }
@@ -338,17 +399,40 @@ int pnr_grid_encode_backward_binned(const float* grad, const float* inputs, cons
     float2* rec_val = reinterpret_cast<float2*>(ws + lay.rec_val);
     const LevelParams lp = make_level_params(L, S, H);
     if (hipMemsetAsync(counts, 0, (size_t)lay.bucket_bound * 4, s) != hipSuccess) return PNR_ERR_LAUNCH;
-    uint32_t nc = 0;   // levels whose cells are wide compared with the sample spacing: run-combined records (as k_grid_bwd<COMBINE>)
+    // leading levels whose whole table is at most two LDS images: accumulated in place (k_coarse_image), no records
+    ImgJobs ij;
+    ij.n = 0;
+    uint32_t ni = 0;
+    if (g_opt_coarse_image) {
+        while (ni < L) {
+            const uint64_t side = (uint64_t)lp.resolution[ni] + (align_corners ? 0u : 1u);
+            const uint64_t rows_bound = (side * side * side + 7) / 8 * 8;
+            const uint32_t halves = (uint32_t)((rows_bound + kBinRows - 1) / kBinRows);
+            if (halves > 2 || ij.n + halves > kMaxImgJobs) break;
+            for (uint32_t h = 0; h < halves; h++) { ij.level[ij.n] = ni; ij.row_lo[ij.n] = h * kBinRows; ij.n++; }
+            ni++;
+        }
+    }
+    if (ij.n) {
+        static bool img_attr[kMaxDevices] = {};
+        if (!ensure_dynamic_lds(k_coarse_image, kBinRows * 2 * 8, img_attr)) return PNR_ERR_LAUNCH;
+        const uint32_t G = kImgBlocks / ij.n;
+        float* partial = reinterpret_cast<float*>(ws + lay.img);
+        hipLaunchKernelGGL(k_coarse_image, dim3(G, ij.n), dim3(kImgThreads), kBinRows * 2 * 8, s, grad, inputs, offsets, B, lp, gridtype, align_corners != 0, ij, partial);
+        hipLaunchKernelGGL(k_coarse_reduce, dim3(cdiv(kBinRows * 2, 256), ij.n), dim3(256), 0, s, offsets, ij, G, partial, grad_embeddings);
+        if (ni == L) return check_launch();
+    }
+    uint32_t nc = ni;   // levels whose cells are wide compared with the sample spacing: run-combined records (as k_grid_bwd<COMBINE>)
     // (with fp64 LDS accumulation only the two coarsest levels still gain from merging runs: 3.47 -> 3.29 ms/step against the former bound of 384)
     while (nc < L && lp.scale[nc] <= 24.0f) nc++;
     const uint32_t gx = cdiv(B, kBinThreads * kBinSamples);
     const uint32_t hist_bytes = lay.bucket_bound * 4;
     const bool ac = align_corners != 0;
-    if (nc) hipLaunchKernelGGL(k_bin_count<true>, dim3(gx, nc), dim3(kBinThreads), hist_bytes, s, inputs, offsets, B, lp, gridtype, ac, counts, 0u);
+    if (nc > ni) hipLaunchKernelGGL(k_bin_count<true>, dim3(gx, nc - ni), dim3(kBinThreads), hist_bytes, s, inputs, offsets, B, lp, gridtype, ac, counts, ni);
     if (nc < L) hipLaunchKernelGGL(k_bin_count<false>, dim3(gx, L - nc), dim3(kBinThreads), hist_bytes, s, inputs, offsets, B, lp, gridtype, ac, counts, nc);
     hipLaunchKernelGGL(k_bin_plan, dim3(1), dim3(1024), 0, s, offsets, L, counts, rec_off, cursor, jobs, n_jobs);
-    if (nc) hipLaunchKernelGGL(k_bin_scatter<true>, dim3(gx, nc), dim3(kBinThreads), 2 * hist_bytes, s, grad, inputs, offsets, B, lp, gridtype, ac, cursor,
-                               rec_row, rec_val, 0u);
+    if (nc > ni) hipLaunchKernelGGL(k_bin_scatter<true>, dim3(gx, nc - ni), dim3(kBinThreads), 2 * hist_bytes, s, grad, inputs, offsets, B, lp, gridtype, ac, cursor,
+                                    rec_row, rec_val, ni);
     if (nc < L) hipLaunchKernelGGL(k_bin_scatter<false>, dim3(gx, L - nc), dim3(kBinThreads), 2 * hist_bytes, s, grad, inputs, offsets, B, lp, gridtype, ac,
                                    cursor, rec_row, rec_val, nc);
     static bool attr_set[kMaxDevices] = {};

@@ -1086,6 +1086,17 @@ def test_grid_backward_binned_matches_oracle(cuda, case, monkeypatch):
     rtol, atol = (5e-4, 5e-3) if case == "clustered" else (1e-5, 2e-6 * max(1.0, scale))
     np.testing.assert_allclose(binned, ogg, rtol=rtol, atol=atol)
     assert abs(float(binned.astype(np.float64).sum()) - float(ogg.astype(np.float64).sum())) < 1e-3 * max(1.0, float(np.abs(ogg).astype(np.float64).sum()) * 1e-4)
+    # the coarsest levels as records (run-merged, split gather jobs) instead of LDS images: the round-1..3 path, still what a table with larger coarse levels takes
+    from palettenerf_amd import _lib
+    lib = _lib.load()
+    try:
+        assert lib.pnr_set_option(b"coarse_image", 0) == 0
+        te.grad = None
+        out = gridencoder.grid_encode(dev(x, cuda), te, dev(offsets, cuda), pls, 16 if case != "small_table" else 4, False, gridtype, False)
+        (out * dev(g, cuda)).sum().backward()
+        np.testing.assert_allclose(host(te.grad), ogg, rtol=rtol, atol=atol)
+    finally:
+        lib.pnr_set_option(b"coarse_image", 1)
     monkeypatch.setattr(gridencoder, "BINNED_MIN_ROWS", 1 << 30)
     te.grad = None
     out = gridencoder.grid_encode(dev(x, cuda), te, dev(offsets, cuda), pls, 16 if case != "small_table" else 4, False, gridtype, False)
