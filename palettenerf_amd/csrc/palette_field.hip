@@ -208,22 +208,51 @@ __device__ __forceinline__ float torch_lerp(float a, float b, float w) { const f
 // NB: 0 = any number of bases (loops predicated up to PNR_MAX_BASIS), otherwise exactly NB bases (the shipped default 4: no predication,
 // no second offsets_radiance tile)
 // WAVES: waves per workgroup (8, or 12 = three per SIMD where registers and LDS allow it); a workgroup tile is WAVES x 32 samples
+// All arguments in one struct.  The kernel takes the ones its matrix phase needs from the parameter itself; the fifteen pointers only the epilogue
+// uses are read from the kernel-argument segment where the epilogue starts, through a pointer the compiler cannot see through -- held from the
+// kernel's entry they were 30 scalar registers that lived through the whole tile loop in a kernel that spills 120 of them to vector-register lanes
+// (a v_readlane per use, ~160 per tile).
+struct PalArgs {
+    const FrameCtlView* ctl; uint32_t B; const float* enc; const float* enc_pal; const float* enc_clip; uint32_t level_stride; const float* dirs;
+    const float* deltas; const unsigned char* packed; uint32_t packed_bytes; PaletteParams pp; float* sigmas; float* rgbs; float* aux; uint32_t stage_stride;
+    const int32_t* rays_alive; const float* weights_sum; float* aux_map; float T_thresh; const float* xyzs; const EditParams* ep; int32_t* overflow_flag;
+    uint32_t* tile_counter; RayState rs;
+};
+typedef const __attribute__((address_space(4))) PalArgs* PalArgsK;
+#ifndef PNR_PAL_KARGS
+#define PNR_PAL_KARGS 1     // 0: the loads are visible to the compiler again, which hoists them to the kernel's entry (the A/B of this change)
+#endif
+__device__ __forceinline__ PalArgsK launder(PalArgsK p) {
+#if PNR_PAL_KARGS
+    asm volatile("" : "+s"(p));
+#endif
+    return p;
+}
+
 template <int PREC, int EDIT, bool CHECK, int NB, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtlView* __restrict__ ctl, uint32_t B_arg, const float* __restrict__ enc,
-                                                                   const float* __restrict__ enc_pal, const float* __restrict__ enc_clip,
-                                                                   uint32_t level_stride, const float* __restrict__ dirs,
-                                                                   const float* __restrict__ deltas, const unsigned char* __restrict__ packed,
-                                                                   uint32_t packed_bytes, PaletteParams pp, float* __restrict__ sigmas,
-                                                                   float* __restrict__ rgbs, float* __restrict__ aux, uint32_t stage_stride,
-                                                                   const int32_t* __restrict__ rays_alive, const float* __restrict__ weights_sum,
-                                                                   float* __restrict__ aux_map, float T_thresh, const float* __restrict__ xyzs,
-                                                                   const EditParams* __restrict__ ep, int32_t* __restrict__ overflow_flag,
-                                                                   uint32_t* __restrict__ tile_counter, RayState rs) {
+__global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
+    const PalArgsK ka = (PalArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+    const FrameCtlView* __restrict__ ctl = A_.ctl;
+    const uint32_t B_arg = A_.B;
+    const float* __restrict__ enc = A_.enc;
+    const float* __restrict__ enc_pal = A_.enc_pal;
+    const float* __restrict__ enc_clip = A_.enc_clip;
+    const uint32_t level_stride = A_.level_stride;
+    const float* __restrict__ dirs = A_.dirs;
+    const float* __restrict__ deltas = A_.deltas;
+    const unsigned char* __restrict__ packed = A_.packed;
+    const uint32_t packed_bytes = A_.packed_bytes;
+    const PaletteParams& pp = A_.pp;
+    const uint32_t stage_stride = A_.stage_stride;
+    const int32_t* __restrict__ rays_alive = A_.rays_alive;
+    const float* __restrict__ weights_sum = A_.weights_sum;
+    uint32_t* __restrict__ tile_counter = A_.tile_counter;
+    const bool has_aux_map = A_.aux_map != nullptr, has_ray_state = A_.rs.rays_t != nullptr;
     if (ctl && ctl->done) return;
     const uint32_t B = ctl ? (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step : B_arg;
     // rows of a ray are consecutive.  Whole rays per wave tile (rpw rows of its 32) when the kernel also composites the ray state; otherwise 32 rows,
     // and the aux composite runs here only with 1, 2, 4 or 8 samples per ray (a ray's rows then sit inside one wave tile anyway)
-    const bool ray_tiles = stage_stride && ctl && aux_map && rs.rays_t;
+    const bool ray_tiles = stage_stride && ctl && has_aux_map && has_ray_state;
     const uint32_t rpw = ray_tiles ? (32u / (uint32_t)ctl->n_step) * (uint32_t)ctl->n_step : 32u;
     const uint32_t nwt = (B + rpw - 1) / rpw;    // wave tiles of this launch
     if (blockIdx.x >= nwt) return;               // (wave 0 of workgroup b takes wave tile b first: a workgroup beyond nwt has nothing at all)
@@ -236,7 +265,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
     constexpr int kLoopNb = NB ? NB : kMaxNb;
     // rows of a ray are consecutive; with 1, 2, 4 or 8 samples per ray they sit inside one 32-row wave tile and the aux composite
     // can run here (fstep = samples per ray), otherwise the composite launch does it
-    const uint32_t fstep = (stage_stride && ctl && aux_map && ctl->n_step <= 8 && (ray_tiles || (32 % ctl->n_step) == 0)) ? (uint32_t)ctl->n_step : 0u;
+    const uint32_t fstep = (stage_stride && ctl && has_aux_map && ctl->n_step <= 8 && (ray_tiles || (32 % ctl->n_step) == 0)) ? (uint32_t)ctl->n_step : 0u;
     const bool fuse_composite = fstep != 0;
     // Work is handed out per 32-sample wave tile: the static persistent schedule (workgroup b takes tiles b, b + grid, ...), or -- an experiment
     // kept behind pnr_set_option("dynamic_tiles") -- every wave fetching its next wave tile from a device counter (tile_counter, zeroed by the
@@ -262,9 +291,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
         const bool valid = mine && (!deltas || deltas[(size_t)(mine ? n : 0) * 2] != 0.0f);
         if (!__any(valid)) {
             // nothing to evaluate -- but with the ray state composited here, the rays of this wave tile (all their rows dead) must still leave the alive list
-            if (rs.rays_t) {
+            if (has_ray_state) {
                 const uint32_t l = (uint32_t)(lane & 31), ns = (uint32_t)ctl->n_step;
-                if (h == 0 && l < rpw && (l % ns) == 0 && n / ns < (uint32_t)ctl->n_alive) rs.rays_alive[n / ns] = -1;
+                if (h == 0 && l < rpw && (l % ns) == 0 && n / ns < (uint32_t)ctl->n_alive) launder(ka)->rs.rays_alive[n / ns] = -1;
             }
             continue;
         }
@@ -421,6 +450,17 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(const FrameCtl
 
         // ---------------- scalar epilogue on the lower half-wave: the palette colour-basis composite
         asm volatile("" : "+s"(toff));
+        // the epilogue's arguments, from the kernel-argument segment (scalar loads here, not registers held since the kernel's entry)
+        const PalArgsK kc = launder(ka);
+        float* __restrict__ const sigmas = kc->sigmas;
+        float* __restrict__ const rgbs = kc->rgbs;
+        float* __restrict__ const aux = kc->aux;
+        float* __restrict__ const aux_map = kc->aux_map;
+        const float T_thresh = kc->T_thresh;
+        const float* __restrict__ const xyzs = kc->xyzs;
+        const EditParams* __restrict__ const ep = kc->ep;
+        int32_t* __restrict__ const overflow_flag = kc->overflow_flag;
+        const RayState rs = {kc->rs.rays_t, kc->rs.weights_sum, kc->rs.depth, kc->rs.image, kc->rs.rays_alive, kc->rs.counts_cur};
         float rgb_out[3] = {0.0f, 0.0f, 0.0f};   // this row's final colour, kept for the ray-state composite below
         if (valid && h == 0) {
             const PaletteTables& T = *reinterpret_cast<const PaletteTables*>(w + toff);
@@ -823,16 +863,19 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
         if (hipMemcpyAsync(ring.dev + edit_slot, &e, sizeof(EditParams), hipMemcpyHostToDevice, s) != hipSuccess) return PNR_ERR_LAUNCH;
         ep_dev = ring.dev + edit_slot;
     }
+    PalArgs ka;
+    ka.ctl = static_cast<const FrameCtlView*>(a->ctl); ka.B = a->B; ka.enc = a->enc; ka.enc_pal = a->enc_palette; ka.enc_clip = a->enc_clip;
+    ka.level_stride = a->level_stride; ka.dirs = a->dirs; ka.deltas = a->deltas; ka.packed = static_cast<const unsigned char*>(a->packed);
+    ka.packed_bytes = packed_bytes; ka.pp = pp; ka.sigmas = a->sigmas; ka.rgbs = a->rgbs; ka.aux = a->aux; ka.stage_stride = stage_stride;
+    ka.rays_alive = fuse ? a->rays_alive : nullptr; ka.weights_sum = fuse ? a->weights_sum : nullptr; ka.aux_map = fuse ? a->aux_map : nullptr;
+    ka.T_thresh = a->T_thresh; ka.xyzs = a->xyzs; ka.ep = ep_dev; ka.overflow_flag = a->overflow_flag; ka.tile_counter = static_cast<uint32_t*>(a->tile_counter);
+    ka.rs = rs;
     static bool attr_set[4][4][kMaxDevices] = {};   // [PREC + 2 * CHECK][EDIT]
 #define PNR_LAUNCH_PAL(PREC, EDIT, CHECK) PNR_LAUNCH_PAL_NB(PREC, EDIT, CHECK, 0, 8, attr_set[PREC + (CHECK ? 2 : 0)][EDIT])
 #define PNR_LAUNCH_PAL_NB(PREC, EDIT, CHECK, NB, WAVES, FLAGS)                                                                                 \
     do {                                                                                                                                       \
         if (!ensure_dynamic_lds(k_palette_field_fwd<PREC, EDIT, CHECK, NB, WAVES>, kLdsLimit, FLAGS)) return PNR_ERR_LAUNCH;                   \
-        hipLaunchKernelGGL((k_palette_field_fwd<PREC, EDIT, CHECK, NB, WAVES>), dim3(grid), dim3(WAVES * 64), lds, s,                          \
-                           static_cast<const FrameCtlView*>(a->ctl), a->B, a->enc, a->enc_palette, a->enc_clip, a->level_stride, a->dirs,      \
-                           a->deltas, static_cast<const unsigned char*>(a->packed), packed_bytes, pp, a->sigmas, a->rgbs, a->aux,              \
-                           stage_stride, fuse ? a->rays_alive : nullptr, fuse ? a->weights_sum : nullptr, fuse ? a->aux_map : nullptr,         \
-                           a->T_thresh, a->xyzs, ep_dev, a->overflow_flag, static_cast<uint32_t*>(a->tile_counter), rs);                      \
+        hipLaunchKernelGGL((k_palette_field_fwd<PREC, EDIT, CHECK, NB, WAVES>), dim3(grid), dim3(WAVES * 64), lds, s, ka);                     \
     } while (0)
     if (fp16 && a->overflow_flag) {   // the instantiation that watches its split operands
         if (edit_mode == 0) PNR_LAUNCH_PAL(1, 0, true); else if (edit_mode == 1) PNR_LAUNCH_PAL(1, 1, true); else PNR_LAUNCH_PAL(1, 2, true);
