@@ -126,11 +126,11 @@ def test_training_entry_points_validate_without_gpu():
         return d
 
     colour = desc([31, 64, 64, 3])
-    # W and W^T slots: (2x1 + 2x2 + 1x2) tiles each way, 4 KiB per tile
-    assert lib.pnr_mlp_packed_bytes(ctypes.byref(colour)) == 2 * (2 + 4 + 2) * 4096
+    # W and W^T slots: (2x1 + 2x2 + 1x2) tiles each way, 4 KiB per tile -- once as fp32 and once as split-fp16 pairs -- and the layers' inverse scales
+    assert lib.pnr_mlp_packed_bytes(ctypes.byref(colour)) == 2 * 2 * (2 + 4 + 2) * 4096 + 16
     assert lib.pnr_mlp_backward_workspace_bytes(ctypes.byref(colour), u32(627000)) == 256 * (31 * 64 + 64 * 64 + 64 * 3) * 4
     assert lib.pnr_mlp_packed_bytes(ctypes.byref(desc([31, 65, 3]))) == 0            # a width above 64
-    assert lib.pnr_mlp_packed_bytes(ctypes.byref(desc([31, 64, 64, 3], act=_lib.MLP_OUT_SIGMOID))) == 2 * (2 + 4 + 2) * 4096   # + sigmoid on the output
+    assert lib.pnr_mlp_packed_bytes(ctypes.byref(desc([31, 64, 64, 3], act=_lib.MLP_OUT_SIGMOID))) == 2 * 2 * (2 + 4 + 2) * 4096 + 16   # + sigmoid on the output
     assert lib.pnr_mlp_backward(ctypes.byref(desc([31, 64, 64, 3], act=_lib.MLP_OUT_SIGMOID)), *[ctypes.c_void_p(8)] * 2, None, ctypes.c_void_p(8), u32(8),
                                 *[None] * 4, ctypes.c_void_p(8), u64(1 << 30), None) == -1                                                # ... needs the forward's y
     assert lib.pnr_mlp_backward_lm(ctypes.byref(desc([32, 64, 16], act=_lib.MLP_OUT_SIGMOID)), ctypes.c_void_p(8), ctypes.c_void_p(8), u32(16), None,
@@ -157,7 +157,8 @@ def test_training_entry_points_validate_without_gpu():
     assert lib.pnr_sh_encode_cat_forward(None, None, u32(15), None, u32(8), u32(4), None) == -1     # null pointers
     assert lib.pnr_sh_encode_cat_forward(None, None, u32(15), None, u32(0), u32(4), None) == 0
     # the round-3 switches of the frame loops (speed only): names exist, values are clamped, unknown names are refused
-    for name, value in ((b"hosted_tail", 1), (b"march_budget", 2), (b"march_budget0", 0), (b"march_blocks", 0), (b"coop_march", 1)):
+    for name, value in ((b"hosted_tail", 1), (b"march_budget", 2), (b"march_budget0", 0), (b"march_blocks", 0), (b"coop_march", 1),
+                        (b"train_coop", 1), (b"mlp_f16x3", 1), (b"coarse_image", 1)):      # (round 4)
         assert lib.pnr_set_option(name, value) == 0
     assert lib.pnr_set_option(b"no_such_switch", 1) != 0 and lib.pnr_set_option(None, 1) != 0
     assert lib.pnr_abi_version() >= 5
