@@ -457,6 +457,12 @@ int pnr_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint3
  * C*C + tail_cols <= 64.  (No Jacobian: directions get no gradient on this path; the tail's gradient is the column slice of the output's.) */
 int pnr_sh_encode_cat_forward(const float* inputs, const float* tail, uint32_t tail_cols, float* outputs, uint32_t B, uint32_t C,
                               pnr_stream_t stream);
+/* The seam between sigma_net and color_net of the NeRF field in training (nerf/network.py:109-121: `sigma = trunc_exp(h[..., 0])`, `geo_feat = h[..., 1:]`,
+ * `torch.cat([encoder_dir(d), geo_feat], -1)`) as one launch each way, so that autograd does not zero-fill, slice-copy and add two [B, hw] gradients:
+ *   forward   h [B, hw] row-major, dirs [B, 3]  ->  sigma [B] = exp(h[:, 0]),  out [B, C*C + hw - 1] = [SH_C(dirs), h[:, 1:]]
+ *   backward  grad_h [B, hw] = [dsigma * exp(clamp(h[:, 0], -15, 15)), dout[:, C*C:]]   (activation.py:14-17; dsigma / dout may be NULL = zeros) */
+int pnr_sigma_geo_cat_forward(const float* h, uint32_t hw, const float* dirs, uint32_t C, uint32_t B, float* sigma, float* out, pnr_stream_t stream);
+int pnr_sigma_geo_cat_backward(const float* h, uint32_t hw, const float* dsigma, const float* dout, uint32_t C, uint32_t B, float* grad_h, pnr_stream_t stream);
 int pnr_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t C,
                            const float* dy_dx, float* grad_inputs, pnr_stream_t stream);
 

@@ -55,6 +55,8 @@ SIGNATURES = {
     "pnr_palette_render_frame": [_ptr, _ptr],
     "pnr_sh_encode_forward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr],
     "pnr_sh_encode_cat_forward": [_ptr, _ptr, _u32, _ptr, _u32, _u32, _ptr],
+    "pnr_sigma_geo_cat_forward": [_ptr, _u32, _ptr, _u32, _u32, _ptr, _ptr, _ptr],
+    "pnr_sigma_geo_cat_backward": [_ptr, _u32, _ptr, _ptr, _u32, _u32, _ptr, _ptr],
     "pnr_sh_encode_backward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr, _ptr],
     "pnr_rgb_to_hsv": [_u32, _ptr, _ptr, _ptr],
     "pnr_hsv_to_rgb": [_u32, _ptr, _ptr, _ptr],

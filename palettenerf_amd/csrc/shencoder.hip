@@ -84,7 +84,8 @@ __global__ void __launch_bounds__(256) k_sh_bwd(const float* __restrict__ grad, 
 // A workgroup's 256 rows are put together in LDS (row stride W = C2 + t) and leave as one contiguous block of 16-byte stores.
 template <int DEG>
 __global__ void __launch_bounds__(256) k_sh_cat_fwd(const float* __restrict__ inputs, const float* __restrict__ tail, uint32_t t,
-                                                    float* __restrict__ outputs, uint32_t B) {
+                                                    float* __restrict__ outputs, uint32_t B, uint32_t tail_stride /* floats per source row */,
+                                                    uint32_t tail_off /* first source column */, float* __restrict__ sigma /* or null: exp(source column 0) */) {
     extern __shared__ float tile[];
     constexpr int C2 = DEG * DEG;
     const uint32_t W = C2 + t, row0 = blockIdx.x * 256, b = row0 + threadIdx.x, nrows = B - row0 < 256u ? B - row0 : 256u;
@@ -109,11 +110,12 @@ __global__ void __launch_bounds__(256) k_sh_cat_fwd(const float* __restrict__ in
             }
         }
     }
-    const float* tsrc = tail + (size_t)row0 * t;
+    const float* tsrc = tail + (size_t)row0 * tail_stride;
     for (uint32_t i = threadIdx.x; i < nrows * t; i += 256) {
         const uint32_t r = i / t, c = i - r * t;
-        tile[r * W + C2 + c] = tsrc[i];
+        tile[r * W + C2 + c] = tsrc[(size_t)r * tail_stride + tail_off + c];
     }
+    if (sigma && threadIdx.x < nrows) sigma[row0 + threadIdx.x] = expf(tsrc[(size_t)threadIdx.x * tail_stride]);   // trunc_exp's forward (activation.py:11-13)
     __syncthreads();
     float* dst = outputs + (size_t)row0 * W;      // 256 W floats per workgroup: 16-byte aligned for every W
     const uint32_t total = nrows * W, quads = total / 4;
@@ -123,9 +125,23 @@ __global__ void __launch_bounds__(256) k_sh_cat_fwd(const float* __restrict__ in
 }
 
 template <int DEG>
-static int launch_sh_cat(const float* inputs, const float* tail, uint32_t t, float* outputs, uint32_t B, hipStream_t s) {
-    hipLaunchKernelGGL((k_sh_cat_fwd<DEG>), dim3(cdiv(B, 256)), dim3(256), 256 * (DEG * DEG + t) * sizeof(float), s, inputs, tail, t, outputs, B);
+static int launch_sh_cat(const float* inputs, const float* tail, uint32_t t, float* outputs, uint32_t B, hipStream_t s, uint32_t tail_stride = 0, uint32_t tail_off = 0,
+                         float* sigma = nullptr) {
+    hipLaunchKernelGGL((k_sh_cat_fwd<DEG>), dim3(cdiv(B, 256)), dim3(256), 256 * (DEG * DEG + t) * sizeof(float), s, inputs, tail, t, outputs, B,
+                       tail_stride ? tail_stride : t, tail_off, sigma);
     return check_launch();
+}
+// grad_h[b] = [dsigma[b] * exp(clamp(h[b][0], -15, 15)), dout[b][C2 : C2 + hw - 1]]: trunc_exp's backward (activation.py:14-17) and the column slice, one pass
+__global__ void __launch_bounds__(256) k_sigma_geo_cat_bwd(const float* __restrict__ h, uint32_t hw, const float* __restrict__ dsigma, const float* __restrict__ dout, uint32_t C2,
+                                                           uint32_t B, float* __restrict__ grad_h) {
+    // blockDim = (columns rounded up to a power of two, 256 / that): consecutive lanes walk a row, no division
+    const uint32_t c = threadIdx.x, b = blockIdx.x * blockDim.y + threadIdx.y;
+    if (c >= hw || b >= B) return;
+    const size_t i = (size_t)b * hw + c;
+    float v = 0.0f;
+    if (c == 0) { if (dsigma) v = dsigma[b] * expf(fminf(fmaxf(h[i], -15.0f), 15.0f)); }
+    else if (dout) v = dout[(size_t)b * (C2 + hw - 1) + C2 + c - 1];
+    grad_h[i] = v;
 }
 
 template <int DEG>
@@ -141,6 +157,33 @@ static int launch_sh(const float* inputs, float* outputs, uint32_t B, uint32_t D
 using namespace pnr;
 
 extern "C" {
+
+int pnr_sigma_geo_cat_forward(const float* h, uint32_t hw, const float* dirs, uint32_t C, uint32_t B, float* sigma, float* out, pnr_stream_t stream) {
+    if (C < 1 || C > 8 || hw < 2 || C * C + hw - 1 > 64) return PNR_ERR_UNSUPPORTED;
+    if (B == 0) return PNR_OK;
+    if (!h || !dirs || !sigma || !out) return PNR_ERR_INVALID;
+    hipStream_t s = as_stream(stream);
+    switch (C) {
+        case 1: return launch_sh_cat<1>(dirs, h, hw - 1, out, B, s, hw, 1, sigma);
+        case 2: return launch_sh_cat<2>(dirs, h, hw - 1, out, B, s, hw, 1, sigma);
+        case 3: return launch_sh_cat<3>(dirs, h, hw - 1, out, B, s, hw, 1, sigma);
+        case 4: return launch_sh_cat<4>(dirs, h, hw - 1, out, B, s, hw, 1, sigma);
+        case 5: return launch_sh_cat<5>(dirs, h, hw - 1, out, B, s, hw, 1, sigma);
+        case 6: return launch_sh_cat<6>(dirs, h, hw - 1, out, B, s, hw, 1, sigma);
+        default: return launch_sh_cat<7>(dirs, h, hw - 1, out, B, s, hw, 1, sigma);   // C == 8 has no room for a tail
+    }
+}
+
+int pnr_sigma_geo_cat_backward(const float* h, uint32_t hw, const float* dsigma, const float* dout, uint32_t C, uint32_t B, float* grad_h, pnr_stream_t stream) {
+    if (C < 1 || C > 8 || hw < 2 || C * C + hw - 1 > 64) return PNR_ERR_UNSUPPORTED;
+    if (B == 0) return PNR_OK;
+    if (!h || !grad_h) return PNR_ERR_INVALID;
+    if ((uint64_t)B * hw >= (1ull << 32)) return PNR_ERR_UNSUPPORTED;
+    uint32_t bx = 2;
+    while (bx < hw) bx <<= 1;
+    hipLaunchKernelGGL(k_sigma_geo_cat_bwd, dim3(cdiv(B, 256 / bx)), dim3(bx, 256 / bx), 0, as_stream(stream), h, hw, dsigma, dout, C * C, B, grad_h);
+    return check_launch();
+}
 
 int pnr_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C, float* dy_dx, pnr_stream_t stream) {
     if (D != 3) return PNR_ERR_UNSUPPORTED;        // "SH encoder only support input dim == 3" (sphere_harmonics.py:69)

@@ -14,7 +14,7 @@ from .linear import Linear
 from .mlp import MIN_ROWS as _MLP_MIN_ROWS, encode_mlp, run_mlp
 from .palette_utils import palette_heads
 from .renderer import NeRFRenderer, PaletteRenderer
-from .shencoder import sh_encode_cat
+from .shencoder import sh_encode_cat, sigma_geo_cat
 
 
 def _mlp(dims):
@@ -75,9 +75,8 @@ class NeRFNetwork(NeRFRenderer):
                 self._fused = NeRFFieldFused(self)
             return self._fused(x, d)
         h = encode_mlp(self.encoder, x, self.bound, None, self.sigma_net)
-        sigma = trunc_exp(h[..., 0])
-        geo_feat = h[..., 1:]
-        return sigma, _run(self.color_net, sh_encode_cat(self.encoder_dir, d, geo_feat), out=torch.sigmoid)
+        sigma, cat = sigma_geo_cat(self.encoder_dir, h, d)      # trunc_exp(h[..., 0]); cat([encoder_dir(d), h[..., 1:]]): one launch each way
+        return sigma, _run(self.color_net, cat, out=torch.sigmoid)
 
     def density(self, x):
         """nerf/network.py:126-143"""

@@ -65,6 +65,48 @@ class _sh_encode_cat(Function):
         return None, grad[:, ctx.width:], None
 
 
+class _sigma_geo_cat(Function):
+    """(trunc_exp(h[:, 0]), torch.cat([sh_encode(dirs, degree), h[:, 1:]], -1)) -- the seam between sigma_net and color_net (nerf/network.py:109-121) --
+    as one launch forward and one backward: autograd's own backward of the select and the slice zero-fills two [B, hw] tensors, copies into both and adds
+    them (~80 us on a 627 k-sample training batch)."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, h, dirs, degree):
+        h = require(h.contiguous(), torch.float32, "h")
+        dirs = require(dirs.contiguous(), torch.float32, "inputs")
+        n, hw = h.shape
+        sigma = torch.empty(n, dtype=torch.float32, device=h.device)
+        out = torch.empty(n, degree * degree + hw - 1, dtype=torch.float32, device=h.device)
+        call("pnr_sigma_geo_cat_forward", ptr(h), _u32(hw), ptr(dirs), _u32(degree), _u32(n), ptr(sigma), ptr(out))
+        ctx.save_for_backward(h)
+        ctx.degree = degree
+        return sigma, out
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, dsigma, dout):
+        (h,) = ctx.saved_tensors
+        n, hw = h.shape
+        grad_h = torch.empty_like(h)
+        dsigma = None if dsigma is None else require(dsigma.contiguous(), torch.float32, "dsigma")
+        dout = None if dout is None else require(dout.contiguous(), torch.float32, "dout")
+        call("pnr_sigma_geo_cat_backward", ptr(h), _u32(hw), ptr(dsigma), ptr(dout), _u32(ctx.degree), _u32(n), ptr(grad_h))
+        return grad_h, None, None
+
+
+def sigma_geo_cat(encoder, h, dirs):
+    """sigma, colour-net input of the NeRF field from sigma_net's output h [B, 1 + geo] and the view directions; the fused launch when it can be
+    (see sh_encode_cat), the reference's composition otherwise."""
+    from .activation import trunc_exp
+    ok = (isinstance(encoder, SHEncoder) and h.is_cuda and h.ndim == 2 and dirs.ndim == 2 and dirs.shape[0] == h.shape[0] and h.shape[0] > 0 and h.shape[1] >= 2
+          and not dirs.requires_grad and encoder.output_dim + h.shape[1] - 1 <= 64 and h.dtype == torch.float32 and dirs.dtype == torch.float32
+          and not torch.is_autocast_enabled())
+    if not ok:
+        return trunc_exp(h[..., 0]), sh_encode_cat(encoder, dirs, h[..., 1:])
+    return _sigma_geo_cat.apply(h, dirs, encoder.degree)
+
+
 def sh_encode_cat(encoder, dirs, tail):
     """`torch.cat([encoder(dirs), tail], dim=-1)` for an SHEncoder: one launch when it can be (CUDA, [B,3] directions that need no gradient,
     degree^2 + tail columns <= 64), the plain composition otherwise."""

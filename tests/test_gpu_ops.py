@@ -1414,6 +1414,37 @@ def test_fused_mlp_forward_split_fp16_against_the_exact_fp32_launch(cuda, dims, 
     assert float(got[:32].abs().max()) == 0.0 or act == "elu"
 
 
+def test_sigma_geo_cat_matches_the_reference_composition(cuda):
+    """shencoder.sigma_geo_cat -- trunc_exp(h[:, 0]) and cat([SH(d), h[:, 1:]]) as one launch each way (pnr_sigma_geo_cat_*) -- against the composition the
+    reference writes (nerf/network.py:109-121 with activation.py's trunc_exp): forward bit for bit, the gradient of h to 1 ulp of exp (a logit beyond the
+    clamp included)."""
+    from palettenerf_amd import shencoder as she
+    from palettenerf_amd.activation import trunc_exp
+    torch.manual_seed(3)
+    B = 70001
+    enc = she.SHEncoder(degree=4)
+    h = torch.randn(B, 16, device=cuda)
+    h[5, 0], h[6, 0] = 20.0, -20.0                        # beyond the clamp of the gradient
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device=cuda), dim=-1)
+    w_s, w_c = torch.randn(B, device=cuda), torch.randn(B, 31, device=cuda)
+    h1 = h.clone().requires_grad_(True)
+    s1, c1 = she.sigma_geo_cat(enc, h1, d)
+    assert type(s1.grad_fn).__name__.startswith("_sigma_geo_cat")
+    ((s1 * w_s).sum() + (c1 * w_c).sum()).backward()
+    h2 = h.clone().requires_grad_(True)
+    s2, c2 = trunc_exp(h2[..., 0]), torch.cat([enc(d), h2[..., 1:]], dim=-1)
+    ((s2 * w_s).sum() + (c2 * w_c).sum()).backward()
+    assert torch.equal(c1, c2)
+    np.testing.assert_allclose(host(s1), host(s2), rtol=2e-7)
+    np.testing.assert_allclose(host(h1.grad), host(h2.grad), rtol=3e-7, atol=0)
+    # only one of the two outputs used
+    h3 = h.clone().requires_grad_(True)
+    s3, _ = she.sigma_geo_cat(enc, h3, d)
+    (s3 * w_s).sum().backward()
+    assert float(h3.grad[:, 1:].abs().max()) == 0.0
+    np.testing.assert_allclose(host(h3.grad[:, 0]), host(h2.grad[:, 0]), rtol=3e-7)
+
+
 @pytest.mark.parametrize("tail_w,dims,act", [(0, (32, 64, 16), "relu"), (3, (35, 64, 15), "elu"), (0, (32, 64, 64, 3), "relu")])
 def test_encode_mlp_keeps_the_encoder_output_level_major(cuda, tail_w, dims, act):
     """mlp.encode_mlp (grid lookup -> [tail] -> MLP with the encoder output level-major end to end, pnr_mlp_*_lm + the binned table gradient)
