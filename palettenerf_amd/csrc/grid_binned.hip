@@ -35,7 +35,7 @@ __device__ __forceinline__ uint32_t level_bucket_base(const int32_t* __restrict_
 }
 
 // the 8 (row, weight) pairs of one sample on one level: gridencoder.cu:100-175 indexing, identical to k_grid_bwd
-struct Corners { uint32_t row[8]; float w[8]; bool active; };
+struct Corners { uint32_t row[8]; float w[8]; bool active; uint32_t cell; /* the cell's lower corner, 10 bits per axis (run merging: levels of at most 1023 cells a side) */ };
 __device__ __forceinline__ Corners corners_of(const float* __restrict__ inputs, uint32_t b, uint32_t B, float scale, uint32_t resolution,
                                               uint32_t hashmap_size, uint32_t gridtype, bool align_corners) {
     Corners c;
@@ -63,6 +63,7 @@ __device__ __forceinline__ Corners corners_of(const float* __restrict__ inputs, 
         c.w[idx] = w;
         if (align_corners) c.row[idx] = grid_index<3, 1>(gridtype, true, hashmap_size, resolution, pl);
     }
+    c.cell = c.active ? (pg[0] | (pg[1] << 10) | (pg[2] << 20)) : 0xFFFFFFFFu;
     // the row index per kind of level (grid_core.hpp: dense levels need no `%`, hashed levels with a power-of-two size a mask): the general form's
     // 32-bit modulo is ~25 instructions per corner, eight corners, in each of the three sweeps
     if (!align_corners) corner_rows_by_kind<1>(level_kind(gridtype, hashmap_size, resolution), gridtype, hashmap_size, resolution, pg, c.row);
@@ -90,6 +91,29 @@ __device__ __forceinline__ float run_sum(float v, const Run& r, int lane) {
     return v;
 }
 
+// Mid levels: consecutive samples of a ray that sit in the SAME CELL share all eight rows; their 8 x 2 weighted gradients are summed first and the
+// run's last lane writes the eight records.  One comparison of the cell per lane (not one per corner) and a segmented sum on the DPP path (row_shr
+// inside a row of 16 lanes: vector instructions, where the coarse levels' merge above costs 12 LDS-pipe shuffles per corner); runs are cut at
+// 16-lane boundaries.  With a step of t/128 a sample spends 12, 8, 5.6, 3.9, 2.7, 1.9 steps in a cell of levels 2..7: a third of all records go.
+struct CellRun { bool tail; uint32_t k; };     // k: lanes of the same run in front of this one (0..15)
+__device__ __forceinline__ CellRun cell_run_of(uint32_t cell, int lane) {
+    const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)~cell, (int)cell, 0x111, 0xf, 0xf, false);   // row_shr:1; a row's first lane sees ~cell: a head
+    const bool head = prev != cell || cell == 0xFFFFFFFFu;
+    const unsigned long long heads = __ballot(head);
+    CellRun r;
+    r.k = (uint32_t)(lane - (63 - __clzll((long long)(heads & ((2ull << lane) - 1ull)))));
+    r.tail = lane == PNR_WAVE - 1 || ((heads >> (lane + 1)) & 1ull);
+    return r;
+}
+template <int D> __device__ __forceinline__ float dpp_row_shr0(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + D, 0xf, 0xf, true)); }
+__device__ __forceinline__ float cell_run_sum(float v, uint32_t k) {
+    float t = dpp_row_shr0<1>(v); v += k >= 1u ? t : 0.0f;
+    t = dpp_row_shr0<2>(v); v += k >= 2u ? t : 0.0f;
+    t = dpp_row_shr0<4>(v); v += k >= 4u ? t : 0.0f;
+    t = dpp_row_shr0<8>(v); v += k >= 8u ? t : 0.0f;
+    return v;
+}
+
 // One LDS counter update per (wave, distinct bucket) instead of one per lane: on the dense levels a whole wave lands in one or
 // two buckets and per-lane atomics on a single LDS word serialise.  Returns the lane's rank inside its bucket's workgroup slice.
 __device__ __forceinline__ uint32_t reserve_in_bucket(uint32_t* hist, uint32_t bucket, bool emit, int lane, bool aggregate) {
@@ -110,7 +134,7 @@ __device__ __forceinline__ uint32_t reserve_in_bucket(uint32_t* hist, uint32_t b
 }
 
 // sweep 1: bucket counts
-template <bool COMBINE>
+template <int COMBINE>   // 0: a record per (sample, corner); 1: runs of equal rows merged per corner (coarse levels); 2: runs of samples in one cell merged (mid levels)
 __global__ void __launch_bounds__(kBinThreads) k_bin_count(const float* __restrict__ inputs, const int32_t* __restrict__ offsets, uint32_t B,
                                                            LevelParams lp, uint32_t gridtype, bool align_corners, uint32_t* __restrict__ counts,
                                                            uint32_t level0) {
@@ -125,13 +149,16 @@ __global__ void __launch_bounds__(kBinThreads) k_bin_count(const float* __restri
     for (uint32_t u = 0; u < kBinSamples; u++) {
         const uint32_t b = (blockIdx.x * kBinSamples + u) * kBinThreads + threadIdx.x;
         const Corners c = corners_of(inputs, b, B, lp.scale[level], lp.resolution[level], hashmap_size, gridtype, align_corners);
+        [[maybe_unused]] CellRun cr = {true, 0u};
+        if constexpr (COMBINE == 2) cr = cell_run_of(c.cell, lane);
 #pragma unroll
         for (uint32_t idx = 0; idx < 8; idx++) {
             bool emit = c.active;
-            if constexpr (COMBINE) {
+            if constexpr (COMBINE == 1) {
                 const Run r = run_of(c.active ? c.row[idx] : 0xFFFFFFFFu, lane);   // wave-collective: every lane takes part
                 emit = emit && r.tail;
             }
+            if constexpr (COMBINE == 2) emit = emit && cr.tail;
             reserve_in_bucket(hist, c.row[idx] / kBinRows, emit, lane, nb <= 8);
         }
     }
@@ -194,7 +221,7 @@ __global__ void __launch_bounds__(1024) k_bin_plan(const int32_t* __restrict__ o
 }
 
 // sweep 2: write the records into their buckets' segments
-template <bool COMBINE>
+template <int COMBINE>
 __global__ void __launch_bounds__(kBinThreads) k_bin_scatter(const float* __restrict__ grad, const float* __restrict__ inputs,
                                                              const int32_t* __restrict__ offsets, uint32_t B, LevelParams lp, uint32_t gridtype,
                                                              bool align_corners, uint32_t* __restrict__ cursor, uint16_t* __restrict__ rec_row,
@@ -219,11 +246,18 @@ __global__ void __launch_bounds__(kBinThreads) k_bin_scatter(const float* __rest
         float2 g = make_float2(0.0f, 0.0f);
         if (c[u].active) g = *reinterpret_cast<const float2*>(grad + ((size_t)level * B + b) * 2);
         emit_bits[u] = 0;
+        [[maybe_unused]] CellRun cr = {true, 0u};
+        if constexpr (COMBINE == 2) cr = cell_run_of(c[u].cell, lane);
 #pragma unroll
         for (uint32_t idx = 0; idx < 8; idx++) {
             bool emit = c[u].active;
             float vx = c[u].w[idx] * g.x, vy = c[u].w[idx] * g.y;
-            if constexpr (COMBINE) {
+            if constexpr (COMBINE == 2) {
+                vx = cell_run_sum(c[u].active ? vx : 0.0f, cr.k);
+                vy = cell_run_sum(c[u].active ? vy : 0.0f, cr.k);
+                emit = emit && cr.tail;
+            }
+            if constexpr (COMBINE == 1) {
                 const Run r = run_of(c[u].active ? c[u].row[idx] : 0xFFFFFFFFu, lane);
                 vx = run_sum(c[u].active ? vx : 0.0f, r, lane);
                 vy = run_sum(c[u].active ? vy : 0.0f, r, lane);
@@ -425,16 +459,21 @@ int pnr_grid_encode_backward_binned(const float* grad, const float* inputs, cons
     uint32_t nc = ni;   // levels whose cells are wide compared with the sample spacing: run-combined records (as k_grid_bwd<COMBINE>)
     // (with fp64 LDS accumulation only the two coarsest levels still gain from merging runs: 3.47 -> 3.29 ms/step against the former bound of 384)
     while (nc < L && lp.scale[nc] <= 24.0f) nc++;
+    uint32_t nm = nc;   // mid levels: samples of one cell merged (cells of at most 1023 a side, wide enough for a step to stay inside for ~2 samples)
+    if (g_opt_cell_merge) while (nm < L && lp.scale[nm] <= 256.0f) nm++;
     const uint32_t gx = cdiv(B, kBinThreads * kBinSamples);
     const uint32_t hist_bytes = lay.bucket_bound * 4;
     const bool ac = align_corners != 0;
-    if (nc > ni) hipLaunchKernelGGL(k_bin_count<true>, dim3(gx, nc - ni), dim3(kBinThreads), hist_bytes, s, inputs, offsets, B, lp, gridtype, ac, counts, ni);
-    if (nc < L) hipLaunchKernelGGL(k_bin_count<false>, dim3(gx, L - nc), dim3(kBinThreads), hist_bytes, s, inputs, offsets, B, lp, gridtype, ac, counts, nc);
+    if (nc > ni) hipLaunchKernelGGL(k_bin_count<1>, dim3(gx, nc - ni), dim3(kBinThreads), hist_bytes, s, inputs, offsets, B, lp, gridtype, ac, counts, ni);
+    if (nm > nc) hipLaunchKernelGGL(k_bin_count<2>, dim3(gx, nm - nc), dim3(kBinThreads), hist_bytes, s, inputs, offsets, B, lp, gridtype, ac, counts, nc);
+    if (nm < L) hipLaunchKernelGGL(k_bin_count<0>, dim3(gx, L - nm), dim3(kBinThreads), hist_bytes, s, inputs, offsets, B, lp, gridtype, ac, counts, nm);
     hipLaunchKernelGGL(k_bin_plan, dim3(1), dim3(1024), 0, s, offsets, L, counts, rec_off, cursor, jobs, n_jobs);
-    if (nc > ni) hipLaunchKernelGGL(k_bin_scatter<true>, dim3(gx, nc - ni), dim3(kBinThreads), 2 * hist_bytes, s, grad, inputs, offsets, B, lp, gridtype, ac, cursor,
+    if (nc > ni) hipLaunchKernelGGL(k_bin_scatter<1>, dim3(gx, nc - ni), dim3(kBinThreads), 2 * hist_bytes, s, grad, inputs, offsets, B, lp, gridtype, ac, cursor,
                                     rec_row, rec_val, ni);
-    if (nc < L) hipLaunchKernelGGL(k_bin_scatter<false>, dim3(gx, L - nc), dim3(kBinThreads), 2 * hist_bytes, s, grad, inputs, offsets, B, lp, gridtype, ac,
-                                   cursor, rec_row, rec_val, nc);
+    if (nm > nc) hipLaunchKernelGGL(k_bin_scatter<2>, dim3(gx, nm - nc), dim3(kBinThreads), 2 * hist_bytes, s, grad, inputs, offsets, B, lp, gridtype, ac, cursor,
+                                    rec_row, rec_val, nc);
+    if (nm < L) hipLaunchKernelGGL(k_bin_scatter<0>, dim3(gx, L - nm), dim3(kBinThreads), 2 * hist_bytes, s, grad, inputs, offsets, B, lp, gridtype, ac,
+                                   cursor, rec_row, rec_val, nm);
     static bool attr_set[kMaxDevices] = {};
     if (!ensure_dynamic_lds(k_bin_gather, kBinRows * 2 * 8, attr_set)) return PNR_ERR_LAUNCH;
     const uint32_t gather_blocks = lay.job_bound < 1024u ? lay.job_bound : 1024u;

@@ -158,7 +158,7 @@ def test_training_entry_points_validate_without_gpu():
     assert lib.pnr_sh_encode_cat_forward(None, None, u32(15), None, u32(0), u32(4), None) == 0
     # the round-3 switches of the frame loops (speed only): names exist, values are clamped, unknown names are refused
     for name, value in ((b"hosted_tail", 1), (b"march_budget", 2), (b"march_budget0", 0), (b"march_blocks", 0), (b"coop_march", 1),
-                        (b"train_coop", 1), (b"mlp_f16x3", 1), (b"coarse_image", 1)):      # (round 4)
+                        (b"train_coop", 1), (b"mlp_f16x3", 1), (b"coarse_image", 1), (b"cell_merge", 1)):      # (round 4)
         assert lib.pnr_set_option(name, value) == 0
     assert lib.pnr_set_option(b"no_such_switch", 1) != 0 and lib.pnr_set_option(None, 1) != 0
     assert lib.pnr_abi_version() >= 5

@@ -1090,13 +1090,15 @@ def test_grid_backward_binned_matches_oracle(cuda, case, monkeypatch):
     from palettenerf_amd import _lib
     lib = _lib.load()
     try:
-        assert lib.pnr_set_option(b"coarse_image", 0) == 0
-        te.grad = None
-        out = gridencoder.grid_encode(dev(x, cuda), te, dev(offsets, cuda), pls, 16 if case != "small_table" else 4, False, gridtype, False)
-        (out * dev(g, cuda)).sum().backward()
-        np.testing.assert_allclose(host(te.grad), ogg, rtol=rtol, atol=atol)
+        for switch in (b"coarse_image", b"cell_merge"):      # ... and the mid levels without the merge of a cell's samples (a record per sample and corner)
+            assert lib.pnr_set_option(switch, 0) == 0
+            te.grad = None
+            out = gridencoder.grid_encode(dev(x, cuda), te, dev(offsets, cuda), pls, 16 if case != "small_table" else 4, False, gridtype, False)
+            (out * dev(g, cuda)).sum().backward()
+            np.testing.assert_allclose(host(te.grad), ogg, rtol=rtol, atol=atol)
     finally:
         lib.pnr_set_option(b"coarse_image", 1)
+        lib.pnr_set_option(b"cell_merge", 1)
     monkeypatch.setattr(gridencoder, "BINNED_MIN_ROWS", 1 << 30)
     te.grad = None
     out = gridencoder.grid_encode(dev(x, cuda), te, dev(offsets, cuda), pls, 16 if case != "small_table" else 4, False, gridtype, False)
