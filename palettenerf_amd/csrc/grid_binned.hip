@@ -21,8 +21,23 @@ namespace pnr {
 
 constexpr uint32_t kBinRows = 8192;     // rows per bucket (x 2 channels x 4 B = 64 KiB)
 constexpr uint32_t kBinChunk = 131072;  // records per gather workgroup (a uniformly hit bucket of a 627 k batch holds ~78 k: it stays in one piece)
-constexpr uint32_t kBinSamples = 4;     // samples per thread in count / scatter: 1024 per workgroup
-constexpr uint32_t kBinThreads = 256;
+// samples per thread x threads per workgroup of the count and the scatter sweeps (measured on the 627 k-sample batch, us, hashed + merged levels:
+//   count   256 x 4: 47 + 40   512 x 4: 35 + 31   1024 x 4: 31 + 26   512 x 8: 33 + 33   512 x 2: 52 + 41   1024 x 1: 58 + 47   -- a histogram wants few, large workgroups
+//   scatter 256 x 4: 284 + 142  512 x 2: 272 + 110  1024 x 1: 263 + 119  512 x 4: 291 + 149  256 x 2: 299 + 133  1024 x 2: 288 + 122  -- the scatter wants few registers per thread)
+#ifndef PNR_COUNT_SAMPLES
+#define PNR_COUNT_SAMPLES 4
+#endif
+#ifndef PNR_COUNT_THREADS
+#define PNR_COUNT_THREADS 1024
+#endif
+#ifndef PNR_SCAT_SAMPLES
+#define PNR_SCAT_SAMPLES 2
+#endif
+#ifndef PNR_SCAT_THREADS
+#define PNR_SCAT_THREADS 512
+#endif
+constexpr uint32_t kCountSamples = PNR_COUNT_SAMPLES, kCountThreads = PNR_COUNT_THREADS;
+constexpr uint32_t kBinSamples = PNR_SCAT_SAMPLES, kBinThreads = PNR_SCAT_THREADS;
 constexpr uint32_t kMaxBucketsPerLaunch = 8192;  // LDS histogram bound (counts of one level's buckets)
 
 struct BinJob { uint32_t row_base, nrows, rec_begin, rec_end, exclusive; };
@@ -135,7 +150,7 @@ __device__ __forceinline__ uint32_t reserve_in_bucket(uint32_t* hist, uint32_t b
 
 // sweep 1: bucket counts
 template <int COMBINE>   // 0: a record per (sample, corner); 1: runs of equal rows merged per corner (coarse levels); 2: runs of samples in one cell merged (mid levels)
-__global__ void __launch_bounds__(kBinThreads) k_bin_count(const float* __restrict__ inputs, const int32_t* __restrict__ offsets, uint32_t B,
+__global__ void __launch_bounds__(kCountThreads) k_bin_count(const float* __restrict__ inputs, const int32_t* __restrict__ offsets, uint32_t B,
                                                            LevelParams lp, uint32_t gridtype, bool align_corners, uint32_t* __restrict__ counts,
                                                            uint32_t level0) {
     extern __shared__ uint32_t hist[];
@@ -143,11 +158,11 @@ __global__ void __launch_bounds__(kBinThreads) k_bin_count(const float* __restri
     const int lane = threadIdx.x & (PNR_WAVE - 1);
     const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
     const uint32_t nb = (hashmap_size + kBinRows - 1) / kBinRows;
-    for (uint32_t k = threadIdx.x; k < nb; k += kBinThreads) hist[k] = 0;
+    for (uint32_t k = threadIdx.x; k < nb; k += kCountThreads) hist[k] = 0;
     __syncthreads();
 #pragma unroll
-    for (uint32_t u = 0; u < kBinSamples; u++) {
-        const uint32_t b = (blockIdx.x * kBinSamples + u) * kBinThreads + threadIdx.x;
+    for (uint32_t u = 0; u < kCountSamples; u++) {
+        const uint32_t b = (blockIdx.x * kCountSamples + u) * kCountThreads + threadIdx.x;
         const Corners c = corners_of(inputs, b, B, lp.scale[level], lp.resolution[level], hashmap_size, gridtype, align_corners);
         [[maybe_unused]] CellRun cr = {true, 0u};
         if constexpr (COMBINE == 2) cr = cell_run_of(c.cell, lane);
@@ -164,7 +179,7 @@ __global__ void __launch_bounds__(kBinThreads) k_bin_count(const float* __restri
     }
     __syncthreads();
     const uint32_t base = level_bucket_base(offsets, level);
-    for (uint32_t k = threadIdx.x; k < nb; k += kBinThreads)
+    for (uint32_t k = threadIdx.x; k < nb; k += kCountThreads)
         if (hist[k]) atomicAdd(&counts[base + k], hist[k]);
 }
 
@@ -461,12 +476,12 @@ int pnr_grid_encode_backward_binned(const float* grad, const float* inputs, cons
     while (nc < L && lp.scale[nc] <= 24.0f) nc++;
     uint32_t nm = nc;   // mid levels: samples of one cell merged (cells of at most 1023 a side, wide enough for a step to stay inside for ~2 samples)
     if (g_opt_cell_merge) while (nm < L && lp.scale[nm] <= 256.0f) nm++;
-    const uint32_t gx = cdiv(B, kBinThreads * kBinSamples);
+    const uint32_t gx = cdiv(B, kBinThreads * kBinSamples), gxc = cdiv(B, kCountThreads * kCountSamples);
     const uint32_t hist_bytes = lay.bucket_bound * 4;
     const bool ac = align_corners != 0;
-    if (nc > ni) hipLaunchKernelGGL(k_bin_count<1>, dim3(gx, nc - ni), dim3(kBinThreads), hist_bytes, s, inputs, offsets, B, lp, gridtype, ac, counts, ni);
-    if (nm > nc) hipLaunchKernelGGL(k_bin_count<2>, dim3(gx, nm - nc), dim3(kBinThreads), hist_bytes, s, inputs, offsets, B, lp, gridtype, ac, counts, nc);
-    if (nm < L) hipLaunchKernelGGL(k_bin_count<0>, dim3(gx, L - nm), dim3(kBinThreads), hist_bytes, s, inputs, offsets, B, lp, gridtype, ac, counts, nm);
+    if (nc > ni) hipLaunchKernelGGL(k_bin_count<1>, dim3(gxc, nc - ni), dim3(kCountThreads), hist_bytes, s, inputs, offsets, B, lp, gridtype, ac, counts, ni);
+    if (nm > nc) hipLaunchKernelGGL(k_bin_count<2>, dim3(gxc, nm - nc), dim3(kCountThreads), hist_bytes, s, inputs, offsets, B, lp, gridtype, ac, counts, nc);
+    if (nm < L) hipLaunchKernelGGL(k_bin_count<0>, dim3(gxc, L - nm), dim3(kCountThreads), hist_bytes, s, inputs, offsets, B, lp, gridtype, ac, counts, nm);
     hipLaunchKernelGGL(k_bin_plan, dim3(1), dim3(1024), 0, s, offsets, L, counts, rec_off, cursor, jobs, n_jobs);
     if (nc > ni) hipLaunchKernelGGL(k_bin_scatter<1>, dim3(gx, nc - ni), dim3(kBinThreads), 2 * hist_bytes, s, grad, inputs, offsets, B, lp, gridtype, ac, cursor,
                                     rec_row, rec_val, ni);

@@ -1,9 +1,8 @@
 #!/bin/bash
 R=$PWD; export TMPDIR=/tmp; O=$R/gpurun_out/r04; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_frames.py -m gpu -x -q -k "grid or mlp or binned or train or converge" > $O/pytest_bins.log 2>&1; echo "rc $?" >> $O/pytest_bins.log
-for v in main nomerge; do
+for v in main; do
 cd /tmp; rm -rf /tmp/prof_tp
-if [ $v = main ]; then unset PNR_NO_CELL_MERGE; else export PNR_NO_CELL_MERGE=1; fi
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_tp -o p -- python3 $R/profiles/train_step_bench.py --model nerf --steps 20 --warmup 5 > $O/train_nerf_$v.log 2>&1
 db=$(find /tmp/prof_tp -name '*.db' | head -1)
 python3 $R/profiles/summarize.py $db > $O/train_nerf_$v.txt
