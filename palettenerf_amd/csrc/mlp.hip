@@ -485,7 +485,7 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd(MlpPlan p, const float*
 }
 
 // ------------------------------------------------------------------------------------------
-// The FORWARD launch on the fp16 matrix pipe ("f16x3", field_core.hpp: every operand v = hi + lo with hi = fp16(v), lo = fp16(v - hi), a product is
+// The launches on the fp16 matrix pipe ("f16x3", field_core.hpp: every operand v = hi + lo with hi = fp16(v), lo = fp16(v - hi), a product is
 // a_hi.b_hi + a_hi.b_lo + a_lo.b_hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation -- 22-bit products at 1/5.3 of the fp32 pipe's cycles).
 //  * Range: encoder features start at 1e-4 (gridencoder/grid.py:107), below fp16's normal range, and nothing bounds a user's activations, so every operand
 //    tile is multiplied by the power of two that puts its largest magnitude (wave reduction: 4 DPP steps + 4 readlanes) into [2^14, 2^15) before it is
@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd(MlpPlan p, const float*
 //    the conversions (v_fma_mix*: fp32 multiply-add, one rounding to f16).
 //  * Measured (626 k rows): 32-64-64-16 ReLU 100 -> 55 us, 35-64-15 ELU 108 -> 79 us; outputs within 2e-6 of the float64 layer loop relative to the
 //    largest output, as the fp32 launch (tests/test_gpu_ops.py::test_fused_mlp_forward_backward_match_float64).
-//  The BACKWARD stays on the exact fp32 instructions (mlp_backward_impl says why).
+//  The backward in the same arithmetic follows below (k_mlp_bwd_h); both have their exact fp32 twins above (pnr_set_option("mlp_f16x3", 0)).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float dpp_max_shr(float v, int which) {
     int t;
