@@ -279,6 +279,36 @@ def test_march_rays_inference_bit_exact(cuda, s0, mip_mode, n_step, bound):
     assert int((odl[:, 0] > 0).sum()) > 0
 
 
+@pytest.mark.parametrize("n_rays,n_step,max_steps", [(1, 32, 1024), (3, 1, 1024), (5, 7, 64), (63, 16, 1024), (65, 2, 16), (130, 32, 1024)])
+def test_march_kernels_cooperative_paths_on_tiny_and_ragged_batches(cuda, s0, n_rays, n_step, max_steps):
+    """The wave-cooperative machinery of the drop-in march kernels at its edges: fewer rays than a wave's cooperative slots, a last wave with one ray,
+    more samples per ray than a 16-lane window, a step budget below a window -- pnr_march_rays (cooperative tail) and pnr_march_rays_train (four rays
+    per wave) against the oracle, bit for bit."""
+    grid, bf = s0
+    ro, rd = rays_of(16, 16, elev=20.0, azim=10.0)
+    sel = np.linspace(0, ro.shape[0] - 1, n_rays).astype(np.int64)
+    ro, rd = np.ascontiguousarray(ro[sel]), np.ascontiguousarray(rd[sel])
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    on, of = oracle.near_far_from_aabb(ro, rd, aabb, 0.2)
+    alive = np.arange(n_rays, dtype=np.int32)
+    ox, od, odl = oracle.march_rays(n_rays, n_step, alive, on, ro, rd, 2.0, bf, 2, 128, on, of, align=128, dt_gamma=0.0, max_steps=max_steps)
+    x, d, dl = raymarching.march_rays(n_rays, n_step, dev(alive, cuda), dev(on, cuda), dev(ro, cuda), dev(rd, cuda), 2.0, dev(bf, cuda), 2, 128,
+                                      dev(on, cuda), dev(of, cuda), 128, False, 0.0, max_steps)
+    np.testing.assert_array_equal(host(x), ox)
+    np.testing.assert_array_equal(host(d), od)
+    np.testing.assert_array_equal(host(dl), odl)
+    for dt_gamma in (0.0, 1.0 / 128):
+        cnt = np.zeros(2, np.int32)
+        tx, td, tdl, trays = oracle.march_rays_train(ro, rd, 2.0, bf, 2, 128, on, of, cnt, align=128, force_all_rays=True, dt_gamma=dt_gamma, max_steps=max_steps)
+        counter = torch.zeros(2, dtype=torch.int32, device=cuda)
+        gx, gd, gdl, grays = raymarching.march_rays_train(dev(ro, cuda), dev(rd, cuda), 2.0, dev(bf, cuda), 2, 128, dev(on, cuda), dev(of, cuda), counter,
+                                                          -1, False, 128, True, dt_gamma, max_steps)
+        np.testing.assert_array_equal(host(counter), cnt)
+        np.testing.assert_array_equal(host(grays), trays)
+        np.testing.assert_array_equal(host(gx), tx)
+        np.testing.assert_array_equal(host(gdl), tdl)
+
+
 def test_compact_alive_is_stable_and_exact(cuda):
     rng = np.random.default_rng(5)
     for n in (1, 63, 64, 65, 255, 256, 257, 100000, 640000):
