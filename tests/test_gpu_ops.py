@@ -1446,6 +1446,41 @@ def test_fused_mlp_forward_split_fp16_against_the_exact_fp32_launch(cuda, dims, 
     assert float(got[:32].abs().max()) == 0.0 or act == "elu"
 
 
+@pytest.mark.parametrize("B", [1, 31, 33, 129, 4097])
+def test_fused_mlp_split_fp16_on_small_and_ragged_batches(cuda, B, monkeypatch):
+    """Both arithmetic forms of the fused MLP launches on batches smaller than a wave tile, one row past a tile, one workgroup and a bit: forward and
+    every gradient of the split-fp16 launches against the exact fp32 ones (2e-6 / 2e-5 of the largest entry), an all-zero dY included."""
+    import torch.nn.functional as F
+    from palettenerf_amd import mlp, _lib
+    lib = _lib.load()
+    monkeypatch.setattr(mlp, "MIN_ROWS", 1)
+    torch.manual_seed(B)
+    dims = (32, 64, 64, 16)
+    net = torch.nn.ModuleList([torch.nn.Linear(dims[i], dims[i + 1], bias=False) for i in range(3)]).to(cuda)
+    x0 = torch.randn(B, dims[0], device=cuda)
+    wy = torch.randn(B, dims[-1], device=cuda)
+    res = {}
+    try:
+        for opt in (0, 1):
+            assert lib.pnr_set_option(b"mlp_f16x3", opt) == 0
+            x = x0.clone().requires_grad_(True)
+            for l in net:
+                l.weight.grad = None
+            y = mlp.run_mlp(net, x, F.relu, None)
+            assert type(y.grad_fn).__name__.startswith("_FusedMLP")
+            (y * wy).sum().backward()
+            res[opt] = [y.detach().clone(), x.grad.clone()] + [l.weight.grad.clone() for l in net]
+        x = x0.clone().requires_grad_(True)
+        (mlp.run_mlp(net, x, F.relu, None) * 0.0).sum().backward()           # dY == 0: every tile takes the "nothing to add" path
+        assert float(x.grad.abs().max()) == 0.0
+    finally:
+        lib.pnr_set_option(b"mlp_f16x3", 1)
+    for k, (a, b) in enumerate(zip(res[1], res[0])):
+        ref = float(b.abs().max())
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) <= (2e-6 if k == 0 else 2e-5) * max(ref, 1e-30), (k, float((a - b).abs().max()), ref)
+
+
 def test_sigma_geo_cat_matches_the_reference_composition(cuda):
     """shencoder.sigma_geo_cat -- trunc_exp(h[:, 0]) and cat([SH(d), h[:, 1:]]) as one launch each way (pnr_sigma_geo_cat_*) -- against the composition the
     reference writes (nerf/network.py:109-121 with activation.py's trunc_exp): forward bit for bit, the gradient of h to 1 ulp of exp (a logit beyond the
