@@ -204,17 +204,18 @@ __global__ void __launch_bounds__(kBlock) k_march_train_count(
 // costs one batch per 16-64 samples, and the batch is spread over N / 4 waves.  Same counts and the same t_store as k_march_train_count
 // (the probes are the same march_probe() calls; tests/test_gpu_ops.py compares both with the oracle).  The per-chunk sums k_scan_block_sums
 // wants are formed by k_chunk_sums.
-constexpr int kTrainCoopRays = 4;
-template <bool MIP, bool POW2>
+// NR rays per wave: 1 for training-sized batches (4096 rays: one wave per ray, windows of 64 lattice points; 169 -> 149 us slab, 254 -> 218 us lego),
+// 4 above (40 000 rays, constant step: 444 us against 505 with one ray per wave -- enough waves either way, fewer of them to schedule)
+template <bool MIP, bool POW2, int NR>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4))) k_march_train_count_coop(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid, MarchParams p, uint32_t N,
     const float* __restrict__ nears, const float* __restrict__ fars, const float* __restrict__ noises, int32_t* __restrict__ counts /* [N] */,
     const uint32_t* __restrict__ mip, float* __restrict__ t_store) {
-    __shared__ CoopSharedT<kTrainCoopRays> coop[kBlock / PNR_WAVE];
+    __shared__ CoopSharedT<NR> coop[kBlock / PNR_WAVE];
     const uint32_t* mip_lds = stage_mip(mip, MIP ? p.mip_words : 0);
     const uint32_t wave = threadIdx.x / PNR_WAVE, lane = threadIdx.x & (PNR_WAVE - 1);
-    const uint32_t n = (blockIdx.x * (kBlock / PNR_WAVE) + wave) * kTrainCoopRays + lane;
-    const bool keep = lane < (uint32_t)kTrainCoopRays && n < N;
+    const uint32_t n = (blockIdx.x * (kBlock / PNR_WAVE) + wave) * NR + lane;
+    const bool keep = lane < (uint32_t)NR && n < N;
     RayCtx c = {};
     float t = 0.0f, far = -FLT_MAX;
     if (keep) {
@@ -721,8 +722,12 @@ int pnr_march_rays_train_mip(const float* rays_o, const float* rays_d, const uin
     const bool coop_count = p.coop != 0 && g_opt_train_coop != 0 && (uint64_t)N * max_steps < (1ull << 31) && (dt_gamma == 0.0f || N <= 16384u);
 #define PNR_LAUNCH_TRAIN(MIPV, P2V)                                                                                                           \
     if (coop_count) {                                                                                                                          \
-        hipLaunchKernelGGL((k_march_train_count_coop<MIPV, P2V>), dim3(cdiv(N, (kBlock / PNR_WAVE) * kTrainCoopRays)), dim3(kBlock), lds, s, rays_o, \
-                           rays_d, grid, p, N, nears, fars, noises, sc + kScanHdr + nb, m, t_store);                                           \
+        if (N <= 8192u)                                                                                                                        \
+            hipLaunchKernelGGL((k_march_train_count_coop<MIPV, P2V, 1>), dim3(cdiv(N, kBlock / PNR_WAVE)), dim3(kBlock), lds, s, rays_o,       \
+                               rays_d, grid, p, N, nears, fars, noises, sc + kScanHdr + nb, m, t_store);                                       \
+        else                                                                                                                                   \
+            hipLaunchKernelGGL((k_march_train_count_coop<MIPV, P2V, 4>), dim3(cdiv(N, (kBlock / PNR_WAVE) * 4)), dim3(kBlock), lds, s, rays_o, \
+                               rays_d, grid, p, N, nears, fars, noises, sc + kScanHdr + nb, m, t_store);                                       \
         hipLaunchKernelGGL(k_chunk_sums, dim3(nb), dim3(kBlock), 0, s, sc, N);                                                                 \
     } else                                                                                                                                     \
         hipLaunchKernelGGL((k_march_train_count<MIPV, P2V>), dim3(nb), dim3(kBlock), lds, s, rays_o, rays_d, grid, p, N, nears, fars, noises, sc, m, \
