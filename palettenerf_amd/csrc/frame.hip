@@ -25,6 +25,12 @@
 uint64_t pnr_internal_edit_device_bytes();
 int pnr_internal_edit_upload(const pnr_palette_edit* edit, void* dst, hipStream_t s);
 
+#ifndef PNR_FRAME_LEVEL_PAIRS
+#define PNR_FRAME_LEVEL_PAIRS 1
+#endif
+#ifndef PNR_FRAME_LEVEL_PAIRS_PAL
+#define PNR_FRAME_LEVEL_PAIRS_PAL 0
+#endif
 namespace pnr {
 
 struct FrameCtl {  // 64 bytes, two copies ping-ponged by iteration parity
@@ -761,6 +767,12 @@ __device__ __forceinline__ void hosted_march_tail(const FrameCtl* ctl, const Gri
 template <int KIND>
 __device__ __forceinline__ void frame_grid_body(const FrameCtl* __restrict__ ctl, const GridArgs& g, const HostedArgs& h) {
     if (ctl->done) return;
+    // GK_SINGLE with PNR_FRAME_LEVEL_PAIRS: a workgroup takes two levels, the y-th finest and the y-th coarsest, for each of its rows (8 instead of 16
+    // workgroup rows per table): the row's position is read once, a scattered and a dense level share a thread
+    constexpr uint32_t kLv = KIND == GK_SINGLE ? (PNR_FRAME_LEVEL_PAIRS == 2 ? 4u : (PNR_FRAME_LEVEL_PAIRS ? 2u : 1u))
+                                               : ((KIND == GK_PAIR && PNR_FRAME_LEVEL_PAIRS_PAL) ? 2u : 1u);   // levels per workgroup row
+    constexpr bool kPairs = kLv > 1;
+    constexpr uint32_t kNY = 16u / kLv;
     uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z, nbx = gridDim.x;
     if (h.blocks) {   // launch-uniform: a one-dimensional launch, the hosted workgroups first
         if (bx < h.blocks) {
@@ -770,7 +782,7 @@ __device__ __forceinline__ void frame_grid_body(const FrameCtl* __restrict__ ctl
             return;
         }
         const uint32_t id = bx - h.blocks, yz = id / h.gx;
-        bx = id - yz * h.gx; by = yz & 15u; bz = yz >> 4; nbx = h.gx;
+        bx = id - yz * h.gx; by = yz % kNY; bz = yz / kNY; nbx = h.gx;
     }
     const uint32_t stride = nbx * 256u;
     const uint32_t rows = (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step;
@@ -783,6 +795,8 @@ __device__ __forceinline__ void frame_grid_body(const FrameCtl* __restrict__ ctl
     if (timing && threadIdx.x == 0) tmm[0] = wall_clock64();
 #endif
     const LevelCtx lc = level_ctx(g, level);
+    [[maybe_unused]] const LevelCtx lc2 = level_ctx(g, kPairs ? by : level);
+    [[maybe_unused]] const LevelCtx lc3 = level_ctx(g, kLv == 4 ? 11u - by : level), lc4 = level_ctx(g, kLv == 4 ? 4u + by : level);
     const void* table = g.table[KIND == GK_SINGLE ? bz : 0];
     float* enc0 = g.enc[KIND == GK_SINGLE ? bz : 0];
     for (uint32_t b = bx * 256u + threadIdx.x; b < rows; b += stride) {
@@ -790,6 +804,8 @@ __device__ __forceinline__ void frame_grid_body(const FrameCtl* __restrict__ ctl
         const uint32_t fl = h.rowflag ? h.rowflag[b] : 0u;
         if (d0 == 0.0f || fl) continue;
         grid_row<KIND>(g, lc, level, table, enc0, b);
+        if constexpr (kLv == 4) { grid_row<KIND>(g, lc3, 11u - by, table, enc0, b); grid_row<KIND>(g, lc4, 4u + by, table, enc0, b); }
+        if constexpr (kPairs) grid_row<KIND>(g, lc2, by, table, enc0, b);
     }
 #ifdef PNR_HOSTED_TIMING
     if (timing && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tmm[1] = wall_clock64(); }
@@ -1312,10 +1328,10 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
                 PNR_LAUNCH_GRID(k_frame_grid_triple, dim3(gxc, 16));
             } else if (pair_table) {
                 ga.table[0] = pair_table;
-                PNR_LAUNCH_GRID(k_frame_grid_pair, dim3(gxc, 16));
+                PNR_LAUNCH_GRID(k_frame_grid_pair, dim3(gxc, PNR_FRAME_LEVEL_PAIRS_PAL ? 8 : 16));
             } else {
                 for (int k = 0; k < 3; k++) ga.table[k] = tables[k];
-                PNR_LAUNCH_GRID(k_frame_grid, dim3(gxc, 16, n_enc));
+                PNR_LAUNCH_GRID(k_frame_grid, dim3(gxc, PNR_FRAME_LEVEL_PAIRS == 2 ? 4 : (PNR_FRAME_LEVEL_PAIRS ? 8 : 16), n_enc));
             }
 #undef PNR_LAUNCH_GRID
             if (pal) {
