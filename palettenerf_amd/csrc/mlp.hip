@@ -190,7 +190,7 @@ __device__ __forceinline__ void raw_load(float (&v)[16 * NT], const float* __res
 }
 template <int NT>
 __device__ __forceinline__ void raw_to_stage(float* __restrict__ buf, const float (&v)[16 * NT], uint32_t row0, uint32_t B, uint32_t width, uint32_t magic,
-                                             int lane) {
+                                             int lane, const int kStage = pnr::kStage /* row stride of this tile (the X tile of the split-fp16 backward is narrower) */) {
     const uint32_t total = B * width, base = row0 * width;
 #pragma unroll
     for (int kt = 0; kt < NT; kt++)
@@ -246,7 +246,7 @@ __device__ __forceinline__ void raw_load_lm(float (&v)[16 * NT], const float* __
 }
 template <int NT>
 __device__ __forceinline__ void raw_to_stage_lm(float* __restrict__ buf, const float (&v)[16 * NT], uint32_t wt, uint32_t tail_magic, uint32_t row0, uint32_t B,
-                                                int lane) {
+                                                int lane, const int kStage = pnr::kStage) {
     const uint32_t r0 = (uint32_t)lane >> 1, ch = (uint32_t)lane & 1u;
     const bool live = row0 + r0 < B;
 #pragma unroll
@@ -274,7 +274,7 @@ __device__ __forceinline__ void stage_to_global_lm(const float* __restrict__ buf
 }
 
 template <int NT>
-__device__ __forceinline__ void frag_from_stage(const float* __restrict__ buf, int lane, f32x16 (&a)[2]) {
+__device__ __forceinline__ void frag_from_stage(const float* __restrict__ buf, int lane, f32x16 (&a)[2], const int kStage = pnr::kStage) {
     const int s = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int t = 0; t < NT; t++)
@@ -681,14 +681,15 @@ __device__ __forceinline__ void split_scaled8(const float (&v)[8], float s, h8& 
     lo = __builtin_bit_cast(h8, lw);
 }
 // feature `col` of the staged tile, samples kb*16 + hh*8 .. +7, scaled by s and split
-__device__ __forceinline__ void column_op(const float* __restrict__ buf, int col, int kb, int hh, float s, h8& hi, h8& lo) {
+__device__ __forceinline__ void column_op(const float* __restrict__ buf, int col, int kb, int hh, float s, h8& hi, h8& lo, const int kStage = pnr::kStage) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) v[j] = buf[(kb * 16 + hh * 8 + j) * kStage + col];
     split_scaled8(v, s, hi, lo);
 }
 template <int NRT, int NCT>
-__device__ __forceinline__ void wgrad_lds(f32x16 (&dw)[2][2], DwScale& st, const float* __restrict__ G, int e_g, int mg, const float* __restrict__ A, int e_a, int ma, int lane) {
+__device__ __forceinline__ void wgrad_lds(f32x16 (&dw)[2][2], DwScale& st, const float* __restrict__ G, int e_g, int mg, const float* __restrict__ A, int e_a, int ma, int lane,
+                                          const int a_stride = kStage) {
     if (mg == 0 || ma == 0) return;     // an all-zero side: nothing to add (wave-uniform)
     const int kg = split_exp(mg), ka_top = split_exp(ma);
     int ka = st.P + e_g + e_a - kg;
@@ -712,7 +713,7 @@ __device__ __forceinline__ void wgrad_lds(f32x16 (&dw)[2][2], DwScale& st, const
     for (int kb = 0; kb < 2; kb++) {       // 16 samples at a time: 24 operand registers live instead of 48
         h8 ahi[2], alo[2];
 #pragma unroll
-        for (int ct = 0; ct < NCT; ct++) column_op(A, ct * 32 + c, kb, hh, sa, ahi[ct], alo[ct]);
+        for (int ct = 0; ct < NCT; ct++) column_op(A, ct * 32 + c, kb, hh, sa, ahi[ct], alo[ct], a_stride);
 #pragma unroll
         for (int rt = 0; rt < NRT; rt++) {
             h8 ghi, glo;
@@ -753,6 +754,10 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd_h(MlpPlan p, const floa
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* GA = lds + p.packed_floats + wave * 2 * kStageFloats;   // gradient side of the weight-gradient products
     float* GB = GA + kStageFloats;                                 // activation side
+    // the X tile keeps a (narrower) tile of its own: staged once per tile, read as fragments for the recomputation and as columns for layer 0's weight
+    // gradient; the next tile's X is requested right behind the staging and its registers are free for the whole tile (k_mlp_bwd stages X twice and holds them)
+    constexpr int kXStage = 32 * TI + 1;
+    float* GX = lds + p.packed_floats + kMlpWaves * 2 * kStageFloats + wave * 33 * kXStage;
     __syncthreads();
     f32x16 dw0[2][2], dw1[2][2], dw2[2][2];
 #pragma unroll
@@ -768,8 +773,8 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd_h(MlpPlan p, const floa
     if (yout) raw_load<TO>(sn, yout, (blockIdx.x * kMlpWaves + wave) * 32, B, p.dims[NL], lane);
     for (uint32_t bt = blockIdx.x; bt < nblock_tiles; bt += gridDim.x) {
         const uint32_t row0 = (bt * kMlpWaves + wave) * 32;
-        if (p.lm) raw_to_stage_lm<TI>(GB, xr, p.tail, p.tail_magic, row0, B, lane);
-        else raw_to_stage<TI>(GB, xr, row0, B, p.dims[0], p.magic[0], lane);
+        if (p.lm) raw_to_stage_lm<TI>(GX, xr, p.tail, p.tail_magic, row0, B, lane, kXStage);
+        else raw_to_stage<TI>(GX, xr, row0, B, p.dims[0], p.magic[0], lane, kXStage);
         if (yout) {   // dZ = dY (1 - y) y: sigmoid_backward, in the raw layout both tiles share
 #pragma unroll
             for (int k = 0; k < 16 * TO; k++) yn[k] = (yn[k] * (1.0f - sn[k])) * sn[k];
@@ -777,12 +782,14 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd_h(MlpPlan p, const floa
         raw_to_stage<TO>(GA, yn, row0, B, p.dims[NL], p.magic[NL], lane);
         wave_sync();
         const uint32_t next0 = ((bt + gridDim.x) * kMlpWaves + wave) * 32;
-        raw_load<TO>(yn, dy, next0, B, p.dims[NL], lane);          // the next tile's dY flies during this tile's matrix work
+        raw_load<TO>(yn, dy, next0, B, p.dims[NL], lane);          // the next tile's dY and X fly during this tile's matrix work
         if (yout) raw_load<TO>(sn, yout, next0, B, p.dims[NL], lane);
+        if (p.lm) raw_load_lm<TI>(xr, x, x_tail, p.tail, next0, B, lane);
+        else raw_load<TI>(xr, x, next0, B, p.dims[0], lane);
         f32x16 h1[2], h2[2], g[2], t[2];
         HOp b;
         // forward again: x -> h1 (-> h2)
-        frag_from_stage<TI>(GB, lane, t);
+        frag_from_stage<TI>(GX, lane, t, kXStage);
         const int mx = tile_max_exp<TI>(t), kx = split_exp(mx);
         split_tiles<TI>(t, kx, b);
         layer_h<2, 2 * TI>(w + (size_t)p.w_off[0] * 4, b, h1, lane);
@@ -835,16 +842,12 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd_h(MlpPlan p, const floa
             act_grad_stored<2, ACT>(t, h1);
             g[0] = t[0]; g[1] = t[1];
         }
-        // layer 0: GA <- dZ1, GB <- X
+        // layer 0: GA <- dZ1, the activation side is the X tile
         mg = tile_max_exp<2>(g); kg = split_exp(mg);
         wave_sync();
         frag_to_stage<2>(GA, lane, g);
-        if (p.lm) raw_to_stage_lm<TI>(GB, xr, p.tail, p.tail_magic, row0, B, lane);
-        else raw_to_stage<TI>(GB, xr, row0, B, p.dims[0], p.magic[0], lane);
         wave_sync();
-        if (p.lm) raw_load_lm<TI>(xr, x, x_tail, p.tail, next0, B, lane);   // X is needed twice per tile: its prefetch starts after the second use
-        else raw_load<TI>(xr, x, next0, B, p.dims[0], lane);
-        wgrad_lds<2, TI>(dw0, st0, GA, eg, mg, GB, 0, mx, lane);
+        wgrad_lds<2, TI>(dw0, st0, GA, eg, mg, GX, 0, mx, lane, kXStage);
         if (dx) {
             split_tiles<2>(g, kg, b);
             layer_h<TI, 4>(w + (size_t)p.wt_off[0] * 4, b, t, lane);              // dX = W0^T dZ1
@@ -1025,8 +1028,12 @@ static int mlp_backward_impl(const pnr_mlp_desc* desc, const float* packed, cons
     // every stack of both fields; the wider instantiations spill twice what the fp32 ones do and stay on those
     const uint32_t ti = tiles32(p.dims[0]), to = tiles32(p.dims[p.n_layers]);
     const bool h_fits = p.n_layers == 2 ? !(ti == 2 && to == 2) : (ti == 1 && to == 1);
-    if (g_opt_mlp_f16x3 && h_fits) PNR_MLP_SWITCH(k_mlp_bwd_h, p, packed, x, x_tail, dy, y, B, dx, partial);
-    else PNR_MLP_SWITCH(k_mlp_bwd, p, packed, x, x_tail, dy, y, B, dx, partial);
+    const size_t lds_h = lds + (size_t)kMlpWaves * 33 * (32 * ti + 1) * 4;       // + the X tiles of k_mlp_bwd_h
+    if (g_opt_mlp_f16x3 && h_fits && lds_h <= 160 * 1024) {
+        const size_t lds_fp32 = lds;
+        (void)lds_fp32;
+        { const size_t lds = lds_h; PNR_MLP_SWITCH(k_mlp_bwd_h, p, packed, x, x_tail, dy, y, B, dx, partial); }
+    } else PNR_MLP_SWITCH(k_mlp_bwd, p, packed, x, x_tail, dy, y, B, dx, partial);
     hipLaunchKernelGGL(k_mlp_dw_reduce, dim3(cdiv(p.dw_floats, 32)), dim3(256), 0, s, partial, grid, p, gr);
     return check_launch();
 }
