@@ -782,10 +782,6 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd_h(MlpPlan p, const floa
         raw_to_stage<TO>(GA, yn, row0, B, p.dims[NL], p.magic[NL], lane);
         wave_sync();
         const uint32_t next0 = ((bt + gridDim.x) * kMlpWaves + wave) * 32;
-        raw_load<TO>(yn, dy, next0, B, p.dims[NL], lane);          // the next tile's dY and X fly during this tile's matrix work
-        if (yout) raw_load<TO>(sn, yout, next0, B, p.dims[NL], lane);
-        if (p.lm) raw_load_lm<TI>(xr, x, x_tail, p.tail, next0, B, lane);
-        else raw_load<TI>(xr, x, next0, B, p.dims[0], lane);
         f32x16 h1[2], h2[2], g[2], t[2];
         HOp b;
         // forward again: x -> h1 (-> h2)
@@ -818,6 +814,15 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd_h(MlpPlan p, const floa
             eg = -kg - kw2;
             act_grad_stored<2, ACT>(t, h2);
             mg = tile_max_exp<2>(t); kg = split_exp(mg);
+            // h1 again (from the X tile, which is still staged): 12-24 matrix instructions against 32 registers that would otherwise sit through layer 2
+            {
+                f32x16 xin[2];
+                HOp bx;
+                frag_from_stage<TI>(GX, lane, xin, kXStage);
+                split_tiles<TI>(xin, kx, bx);
+                layer_h<2, 2 * TI>(w + (size_t)p.w_off[0] * 4, bx, h1, lane);
+                act_stored<2, ACT>(h1, e1s);
+            }
             // layer 1: GA <- dZ2, GB <- h1
             wave_sync();
             frag_to_stage<2>(GA, lane, t);
@@ -842,6 +847,12 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd_h(MlpPlan p, const floa
             act_grad_stored<2, ACT>(t, h1);
             g[0] = t[0]; g[1] = t[1];
         }
+        // the next tile's dY and X: requested here, a layer and the dX store ahead of their use (earlier, their 32-48 registers sit through the tile's
+        // register-tightest stretch)
+        raw_load<TO>(yn, dy, next0, B, p.dims[NL], lane);
+        if (yout) raw_load<TO>(sn, yout, next0, B, p.dims[NL], lane);
+        if (p.lm) raw_load_lm<TI>(xr, x, x_tail, p.tail, next0, B, lane);
+        else raw_load<TI>(xr, x, next0, B, p.dims[0], lane);
         // layer 0: GA <- dZ1, the activation side is the X tile
         mg = tile_max_exp<2>(g); kg = split_exp(mg);
         wave_sync();
