@@ -11,6 +11,8 @@
 // are written sample-major into a per-wave LDS tile and read back as "lane = feature, k = sample parity".  dW lives in accumulator
 // registers for the whole launch, is reduced over the 4 waves through LDS and over workgroups by a second tiny launch in a fixed
 // order (deterministic, no atomics).  HBM traffic: X and dY read once, dX written once.
+// Two arithmetic forms of each launch: the exact fp32 matrix instructions described above (k_mlp_fwd / k_mlp_bwd) and, by default since round 4, split-fp16
+// products with per-tile power-of-two scaling on v_mfma_f32_32x32x16_f16 (k_mlp_fwd_h / k_mlp_bwd_h, further down); pnr_mlp_pack writes the weights in both.
 #include "field_core.hpp"
 
 namespace pnr {
