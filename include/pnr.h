@@ -244,6 +244,11 @@ int pnr_grid_encode_forward(const float* inputs, const void* embeddings, const i
 int pnr_grid_encode_forward_layout(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
                                    uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
                                    uint32_t gridtype, int align_corners, int dtype, int layout, pnr_stream_t stream);
+/* Two tables of the same geometry (D = 3, C = 2, fp32; the same `offsets`) at the same points in one pass: `pair_embeddings` holds them interleaved row by row,
+ * [row][table 0 | table 1][2] (16-byte rows, 16-byte aligned); out0 / out1 [L, B, 2] are bit for bit what pnr_grid_encode_forward returns for table 0 / table 1.
+ * (palette/network.py:156-262 looks `encoder` and `encoder_palette` up at the same x.) */
+int pnr_grid_encode_forward_pair(const float* inputs, const float* pair_embeddings, const int32_t* offsets, float* out0, float* out1, uint32_t B, uint32_t L, float S,
+                                 uint32_t H, uint32_t gridtype, int align_corners, pnr_stream_t stream);
 /* replaces grid_encode_backward, gridencoder.h:13, gridencoder.cu:449-479.
  * grad is [L,B,C]; grad_embeddings caller-zeroed; dy_dx/grad_inputs may both be NULL. */
 int pnr_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,

@@ -40,6 +40,7 @@ SIGNATURES = {
     "pnr_compact_alive": [_u32, _ptr, _ptr, _ptr, _ptr, _ptr],
     "pnr_grid_encode_forward": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _u32, _ptr, _u32, _int, _int, _ptr],
     "pnr_grid_encode_forward_layout": [_ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _u32, _ptr, _u32, _int, _int, _int, _ptr],
+    "pnr_grid_encode_forward_pair": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _f32, _u32, _u32, _int, _ptr],
     "pnr_grid_encode_backward": [_ptr, _ptr, _ptr, _ptr, _ptr, _u32, _u32, _u32, _u32, _f32, _u32, _ptr, _ptr, _u32, _int, _int, _ptr],
     "pnr_nerf_field_packed_bytes": [],
     "pnr_nerf_field_pack": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _int, _ptr],

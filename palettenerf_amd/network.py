@@ -11,10 +11,30 @@ import torch.nn.functional as F
 from .activation import trunc_exp
 from .encoding import get_encoder
 from .linear import Linear
-from .mlp import MIN_ROWS as _MLP_MIN_ROWS, encode_mlp, run_mlp
+from .mlp import MIN_ROWS as _MLP_MIN_ROWS, encode_mlp, encode_mlp_fused_ok, run_mlp
 from .palette_utils import palette_heads
 from .renderer import NeRFRenderer, PaletteRenderer
 from .shencoder import sh_encode_cat, sigma_geo_cat
+
+
+PAIR_LOOKUP = True      # PaletteNeRF training: `encoder` (frozen density) and `encoder_palette` looked up in one launch (fused.grid_encode_raw_pair)
+
+
+class _Probe:
+    """What encode_mlp_fused_ok looks at in a tail tensor that does not exist yet (diffuse.detach(): [B, 3], no gradient)."""
+
+    def __init__(self, like, width):
+        self.requires_grad, self.shape = False, (like.shape[0], width)
+
+
+def pairable(a, b):
+    from .fused import pairable as f
+    return f(a, b)
+
+
+def grid_encode_raw_pair(a, b, x01):
+    from .fused import grid_encode_raw_pair as f
+    return f(a, b, x01)
 
 
 def _mlp(dims):
@@ -137,8 +157,15 @@ class PaletteNetwork(PaletteRenderer):
         """palette/network.py:156-185.  Returns sigma, clip_feat, omega, offsets_radiance, view_dep, diffuse.
         frozen_density: the caller detaches sigma (PaletteNeRF training, palette/renderer.py:333-334; geo_feat is detached here anyway), so
         encoder + sigma_net may run as the fused no-gradient density kernel."""
+        enc_pal = None
         if frozen_density and x.is_cuda and _fused_arch_ok(self):   # also under autocast: fp32 tables and MFMA chains, no gradient needed
-            sigma, geo_feat = density_fused(self)(x)
+            enc_density = None
+            if PAIR_LOOKUP and x.ndim == 2 and not torch.is_autocast_enabled() and pairable(self.encoder, self.encoder_palette) \
+                    and encode_mlp_fused_ok(self.encoder_palette, x, _Probe(x, 3), self.basis_net, F.elu):
+                # both tables are read at the same points (palette/network.py:161, 257): one pair lookup instead of two (fused.grid_encode_raw_pair)
+                x01 = ((x + self.bound) / (2 * self.bound)).contiguous()
+                enc_density, enc_pal = grid_encode_raw_pair(self.encoder, self.encoder_palette, x01)
+            sigma, geo_feat = density_fused(self)(x, enc=enc_density)
         else:
             h = encode_mlp(self.encoder, x, self.bound, None, self.sigma_net)
             sigma = trunc_exp(h[..., 0])
@@ -153,7 +180,7 @@ class PaletteNetwork(PaletteRenderer):
                 clip_feat = z.expand(*sigma.shape, self.opt.clip_dim)
             else:
                 clip_feat = sigma.new_zeros(*sigma.shape, self.opt.clip_dim)   # palette/network.py:179 (zeros_like of a repeat there)
-        omega, offsets_radiance, view_dep, diffuse = self.color(x, d, geo_feat=geo_feat)
+        omega, offsets_radiance, view_dep, diffuse = self.color(x, d, geo_feat=geo_feat, enc_palette=enc_pal)
         return sigma, clip_feat, omega, offsets_radiance, view_dep, diffuse
 
     def density(self, x):
@@ -165,14 +192,15 @@ class PaletteNetwork(PaletteRenderer):
 
     density._pnr_fused_density = True
 
-    def color(self, x, d, mask=None, geo_feat=None, **kwargs):
-        """palette/network.py:223-280 (unmasked form: the march path never passes a mask)."""
+    def color(self, x, d, mask=None, geo_feat=None, enc_palette=None, **kwargs):
+        """palette/network.py:223-280 (unmasked form: the march path never passes a mask).
+        enc_palette: encoder_palette's raw level-major output at x when forward() has looked it up together with the density table."""
         if mask is not None:
             raise NotImplementedError("masked colour queries belong to the non-cuda_ray path, which is dead code in the reference")
         g = geo_feat.detach()
         diffuse = _run(self.diff_net, g, out=torch.sigmoid)
         view_dep = _run(self.color_net, sh_encode_cat(self.encoder_dir, d, g), out=torch.sigmoid)
-        h = encode_mlp(self.encoder_palette, x, self.bound, diffuse.detach(), self.basis_net, act=F.elu)   # cat([encoder_palette(x), diffuse]) -> basis_net
+        h = encode_mlp(self.encoder_palette, x, self.bound, diffuse.detach(), self.basis_net, act=F.elu, enc=enc_palette)   # cat([encoder_palette(x), diffuse]) -> basis_net
         if _fused_heads_ok(self, h):
             offsets_radiance, omega = palette_heads(h, self.offsets_radiance_net, self.omega_net[0])
         else:

@@ -1481,6 +1481,27 @@ def test_fused_mlp_split_fp16_on_small_and_ragged_batches(cuda, B, monkeypatch):
         assert float((a - b).abs().max()) <= (2e-6 if k == 0 else 2e-5) * max(ref, 1e-30), (k, float((a - b).abs().max()), ref)
 
 
+def test_grid_pair_lookup_is_bit_identical_to_two_lookups(cuda):
+    """pnr_grid_encode_forward_pair (two tables of one geometry at the same points in one pass, rows interleaved) against two calls of the lookup op:
+    bit for bit, out-of-range points included; the interleaved copy follows in-place updates of either table."""
+    from palettenerf_amd import fused
+    torch.manual_seed(2)
+    ea = gridencoder.GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=4096).to(cuda)
+    eb = gridencoder.GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=4096).to(cuda)
+    ea.embeddings.data.uniform_(-0.5, 0.5)
+    eb.embeddings.data.uniform_(-0.5, 0.5)
+    assert fused.pairable(ea, eb)
+    x01 = torch.rand(30011, 3, device=cuda)
+    x01[7] = 1.5                                   # outside [0, 1]: zeros in both
+    x01[8, 1] = -0.1
+    for _ in range(2):
+        a, b = fused.grid_encode_raw_pair(ea, eb, x01)
+        assert torch.equal(a, fused.grid_encode_raw(ea, x01)) and torch.equal(b, fused.grid_encode_raw(eb, x01))
+        assert float(a[:, 7].abs().max()) == 0.0 and float(b[:, 8].abs().max()) == 0.0
+        with torch.no_grad():
+            eb.embeddings.add_(0.25)               # an optimiser step: the pair table must be rebuilt
+
+
 def test_sigma_geo_cat_matches_the_reference_composition(cuda):
     """shencoder.sigma_geo_cat -- trunc_exp(h[:, 0]) and cat([SH(d), h[:, 1:]]) as one launch each way (pnr_sigma_geo_cat_*) -- against the composition the
     reference writes (nerf/network.py:109-121 with activation.py's trunc_exp): forward bit for bit, the gradient of h to 1 ulp of exp (a logit beyond the
