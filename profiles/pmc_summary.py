@@ -10,7 +10,7 @@ import sys
 KERNELS = {"k_grid_fwd_d3c2": "grid_fwd_d3c2", "k_grid_fwd<": "grid_fwd_generic", "k_nerf_field_fwd": "nerf_field_fwd", "k_march_rays": "march_rays", "k_composite_rays": "composite_rays",
            "k_frame_grid": "frame_grid", "k_frame_field": "frame_field", "k_palette_field_fwd": "palette_field", "k_frame_march": "frame_march",
            "k_frame_composite": "frame_composite", "k_occ_lookup": "occ_lookup", "k_occ_sigma": "occ_sigma", "k_occ_ema": "occ_ema", "k_occ_pack": "occ_pack", "k_occ_points": "occ_points",
-           "k_fused": "fused", "k_bin_gather": "bin_gather", "k_bin_scatter": "bin_scatter", "k_bin_count": "bin_count", "k_linear_wgrad<": "linear_wgrad", "k_mlp_bwd": "mlp_bwd", "k_mlp_fwd": "mlp_fwd"}
+           "k_fused": "fused", "k_bin_gather": "bin_gather", "k_bin_scatter": "bin_scatter", "k_bin_count": "bin_count", "k_linear_wgrad<": "linear_wgrad", "k_mlp_bwd": "mlp_bwd", "k_mlp_fwd": "mlp_fwd", "k_coarse_image": "coarse_image", "k_march_train_count": "march_train_count", "k_grid_fwd_d3c2_pair": "grid_fwd_pair"}
 
 
 def main(root):
