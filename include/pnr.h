@@ -500,7 +500,10 @@ int pnr_linear_wgrad(const void* x, int x_dtype, const void* dy, int dy_dtype, u
  *   pnr_mlp_pack      weights -> MFMA-ordered blob of pnr_mlp_packed_bytes (W_l and W_l^T, once as fp32 and once as split-fp16 pairs scaled by one power
  *                     of two per layer); call again after every optimiser step
  *   The forward runs on the fp16 matrix pipe with split operands (22-bit products, fp32 accumulation, per-tile power-of-two scaling; outputs within 2e-6
- *   of the exact launch relative to the largest output); pnr_set_option("mlp_f16x3", 0) selects the exact fp32 instructions.  The backward is fp32.
+ *   of the exact launch relative to the largest output); pnr_set_option("mlp_f16x3", 0) selects the exact fp32 instructions.  The backward runs in
+ *   the same split-fp16 arithmetic (k_mlp_bwd_h) for the shapes whose tile it holds without scratch -- two layers unless both ends are 64 wide, three
+ *   layers with ends <= 32 wide: every stack of both fields -- and on the exact fp32 instructions otherwise, so a wide stack's forward (split-fp16) and
+ *   backward (fp32) differ in arithmetic; gradients of both agree with the exact launches to 2e-6 of the largest entry (profiles/r04_grad_tolerance.txt).
  *   pnr_mlp_forward   x [B, dims[0]] -> y [B, dims[n_layers]]
  *   pnr_mlp_backward  x, dy [B, dims[n_layers]] -> dx [B, dims[0]] (NULL: not wanted), dw_l [dims[l+1]][dims[l]] (NULL: not wanted);
  *                     hidden activations are recomputed from x; dw is reduced deterministically through `workspace`.

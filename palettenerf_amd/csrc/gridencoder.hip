@@ -177,7 +177,10 @@ k_grid_fwd_d3c2(const float* __restrict__ inputs, const T* __restrict__ grid, co
     for (uint32_t d = 0; d < 3; d++)
         if (stride <= hashmap_size) stride *= side;
     const bool hashed = gridtype == 0u && stride > hashmap_size;
-    const bool dense = (uint64_t)side * side * side <= (uint64_t)hashmap_size;   // (64-bit: implies every per-dimension test above and no uint32 wrap)
+    // (64-bit: implies every per-dimension test above and no uint32 wrap.)  Not with align_corners: there side == resolution and an input of exactly
+    // 1.0 gives pg + 1 == side, an index that may reach side^3 >= hashmap_size -- the reference wraps it with `%` (gridencoder.cu:49-72), so those
+    // levels take the generic form below
+    const bool dense = !align_corners && (uint64_t)side * side * side <= (uint64_t)hashmap_size;
     uint32_t idxs[8];
     if (dense) {                                                       // index < side^3 <= size: the reference's `%` is the identity
 #pragma unroll

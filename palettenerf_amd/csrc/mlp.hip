@@ -525,8 +525,14 @@ __device__ __forceinline__ int tile_max_exp(const f32x16 (&a)[2]) {
     u = max(u, (uint32_t)__builtin_amdgcn_readlane(b, 63));
     return (int)((u >> 23) & 0xffu);
 }
-// k with 2^k * (largest |stored|) in [2^14, 2^15) (0 for an all-zero or non-finite tile)
-__device__ __forceinline__ int split_exp(int max_biased_exp) { return (max_biased_exp == 0 || max_biased_exp == 255) ? 0 : 141 - max_biased_exp; }
+// k with 2^k * (largest |stored|) in [2^14, 2^15) (0 for an all-zero or non-finite tile).  k is clamped HERE to what pow2i can represent (a tile
+// whose largest magnitude is below 2^-113 would ask for k > 127): the exponent bookkeeping (e = -k - kw, P, eg) is integer arithmetic on this very
+// value, so the scale applied by pow2i(k) and the un-scale carried in e always agree -- such a tile is merely lifted less far
+__device__ __forceinline__ int split_exp(int max_biased_exp) {
+    if (max_biased_exp == 0 || max_biased_exp == 255) return 0;
+    const int k = 141 - max_biased_exp;      // >= -113: never below pow2i's lower clamp
+    return k > 127 ? 127 : k;
+}
 __device__ __forceinline__ float pow2i(int k) {   // 2^k, k clamped to the normal range
     k = k < -126 ? -126 : (k > 127 ? 127 : k);
     return __uint_as_float((uint32_t)(k + 127) << 23);

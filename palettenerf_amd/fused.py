@@ -25,29 +25,85 @@ def grid_encode_raw(encoder, x01):
     return out
 
 
-_PAIR_TABLES = {}
+class _PairCopy:
+    """The interleaved [rows][2][2] copy of two encoders' tables that the training pair lookup reads.  It lives ON the first encoder (attribute
+    `_pnr_pair`: freed with the model, no global registry, no id() aliasing after a model is freed) and remembers its partner by weak reference.
+    A half is re-copied when torch can tell its table changed (_pkey: Parameter identity, storage, version -- optimiser steps, load_state_dict,
+    in-place ops).  Writes through `.data` move none of those: invalidate_fused_caches(model) drops the copy (load_state_dict and
+    initialize_palette call it), and as a safety net every call leaves a sampled checksum of both tables (pnr_checksum, one tiny launch, read
+    back asynchronously) that the NEXT call compares with the one taken when the copy was made -- a silent `.data` rewrite is therefore noticed
+    one call late, the copy rebuilt and a warning raised; PNR_PARANOID_CACHE=1 rebuilds on every call."""
+
+    def __init__(self, enc_b, ea):
+        import weakref
+        self.partner = weakref.ref(enc_b)
+        self.keys = [None, None]
+        self.table = torch.empty(ea.shape[0], 2, 2, dtype=torch.float32, device=ea.device)
+        self.sum_dev = torch.zeros(2, dtype=torch.int64, device=ea.device)
+        self.sum_host = torch.zeros(2, dtype=torch.int64).pin_memory()
+        self.sum_event = None       # recorded behind the asynchronous read-back of the last call's checksums
+        self.sum_ref = [None, None]  # checksums of the tables as they were when their halves were copied
+
+    def matches(self, enc_b, ea):
+        return self.partner() is enc_b and self.table.device == ea.device and self.table.shape[0] == ea.shape[0]
+
+    def lagged_check(self):
+        """Look at the previous call's checksums (complete by now: a whole training step lies between two calls); a half whose table was rewritten
+        behind torch's counters is marked stale."""
+        if self.sum_event is None:
+            return
+        self.sum_event.synchronize()
+        now = self.sum_host.tolist()
+        self.sum_event = None
+        for i in (0, 1):
+            if self.sum_ref[i] is None:
+                self.sum_ref[i] = now[i]
+            elif self.sum_ref[i] != now[i]:
+                import warnings
+                warnings.warn("pair lookup: a hash table was rewritten behind torch's version counters (a `.data` write) -- the interleaved copy "
+                              "was stale for one call; call invalidate_fused_caches(model) after such writes")
+                self.keys[i] = None
+                self.sum_ref[i] = None
+
+    def refresh(self, tabs):
+        with torch.no_grad():       # only the half whose table has changed (PaletteNeRF training: the density table is frozen)
+            for i, t in enumerate(tabs):
+                k = _pkey(t)
+                if self.keys[i] != k or PARANOID:
+                    self.table[:, i].copy_(t.detach())
+                    self.keys[i] = k
+                    self.sum_ref[i] = None      # the checksum this call takes becomes the reference
+        n = 2
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tabs])
+        sizes = (ctypes.c_uint64 * n)(*[t.numel() * t.element_size() for t in tabs])
+        strides = (_u32 * n)(*[TABLE_CHECK_STRIDE] * n)
+        call("pnr_checksum", ptrs, sizes, strides, _u32(n), ptr(self.sum_dev))
+        self.sum_host.copy_(self.sum_dev, non_blocking=True)
+        self.sum_event = torch.cuda.Event()
+        self.sum_event.record()
+
+
+def drop_pair_copies(model):
+    """Forget the training pair lookup's interleaved table copies held by the model's encoders (see _PairCopy)."""
+    for name in ("encoder", "encoder_palette", "encoder_clip"):
+        enc = getattr(model, name, None)
+        if enc is not None and "_pnr_pair" in getattr(enc, "__dict__", {}):
+            del enc.__dict__["_pnr_pair"]
 
 
 def grid_encode_raw_pair(enc_a, enc_b, x01):
     """Two hash-grid encoders of the same geometry at the same points in one launch (pnr_grid_encode_forward_pair): returns their two raw
     level-major [L,B,2] outputs, each bit for bit what grid_encode_raw gives.  The tables are read from an interleaved copy [rows][2][2] that is
     rebuilt (one strided copy, ~30 us for 2 x 49 MB) whenever either parameter has changed since -- every optimiser step in training, where the pair
-    still costs ~1.3 lookups + that copy instead of 2 lookups."""
+    still costs ~1.3 lookups + that copy instead of 2 lookups.  The copy's life and staleness rules: _PairCopy."""
     ea, eb = enc_a.embeddings, enc_b.embeddings
-    key = (id(enc_a), id(enc_b))
-    va, vb = (ea.data_ptr(), ea._version), (eb.data_ptr(), eb._version)
-    hit = _PAIR_TABLES.get(key)
-    if hit is None or hit[2].device != ea.device or hit[2].shape[0] != ea.shape[0]:
-        hit = [None, None, torch.empty(ea.shape[0], 2, 2, dtype=torch.float32, device=ea.device)]
-        _PAIR_TABLES[key] = hit
-    with torch.no_grad():       # only the half whose table has changed (PaletteNeRF training: the density table is frozen)
-        if hit[0] != va:
-            hit[2][:, 0].copy_(ea.detach())
-            hit[0] = va
-        if hit[1] != vb:
-            hit[2][:, 1].copy_(eb.detach())
-            hit[1] = vb
-    pair = hit[2]
+    hit = enc_a.__dict__.get("_pnr_pair")
+    if hit is None or not hit.matches(enc_b, ea):
+        hit = _PairCopy(enc_b, ea)
+        enc_a.__dict__["_pnr_pair"] = hit      # (__dict__: a plain attribute, not a registered buffer -- it must stay out of state_dict)
+    hit.lagged_check()
+    hit.refresh((ea, eb))
+    pair = hit.table
     B = x01.shape[0]
     L = enc_a.num_levels
     out0 = torch.empty(L, B, 2, device=x01.device, dtype=torch.float32)
@@ -103,6 +159,7 @@ def invalidate_fused_caches(model):
         f = getattr(model, attr, None)
         if f is not None:
             f.invalidate_caches()
+    drop_pair_copies(model)
     for ref in list(model.__dict__.get("_fused_twins", [])):      # handles made by pipeline.clone_for_concurrent_frames: same weights, own blobs
         twin = ref()
         if twin is not None and twin is not model:

@@ -105,18 +105,20 @@ class _EncodeMLP(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, x01, embeddings, offsets, meta, tail, act, *weights):
+    def forward(ctx, x01, embeddings, offsets, meta, tail, act, enc_pre, *weights):
+        # enc_pre: the encoder's raw level-major output [L, B, 2] at x01 when the caller has looked it up already (pair lookup); an explicit,
+        # non-differentiable input (the table's gradient flows through `embeddings` as always), saved for backward like a lookup made here
         from .gridencoder import _u32, _f32, _int     # ctypes aliases
-        S, H, gridtype, align_corners = meta[:4]
-        enc_pre = meta[4] if len(meta) > 4 else None       # the encoder's raw level-major output when the caller has looked it up already (pair lookup)
-        meta = meta[:4]
+        S, H, gridtype, align_corners = meta
         x01 = x01.contiguous()
         B = x01.shape[0]
         L = offsets.shape[0] - 1
         dev = x01.device
         emb = embeddings.detach().contiguous()
         if enc_pre is not None:
-            enc = enc_pre
+            enc = enc_pre.detach().contiguous()
+            if enc.shape != (L, B, 2) or enc.dtype != torch.float32:
+                raise RuntimeError("encode_mlp: enc must be the raw level-major lookup [L, B, 2] fp32 at these points")
         else:
             enc = torch.empty(L, B, 2, device=dev, dtype=torch.float32)
             call("pnr_grid_encode_forward", ptr(x01), ptr(emb), ptr(offsets), ptr(enc), _u32(B), _u32(3), _u32(2), _u32(L), _f32(S), _u32(H), None, _u32(gridtype),
@@ -150,7 +152,7 @@ class _EncodeMLP(torch.autograd.Function):
         want_emb = ctx.needs_input_grad[1]
         denc = torch.empty(L, B, 2, device=dev, dtype=torch.float32) if want_emb else None
         n = len(dims) - 1
-        dws = [torch.empty(dims[l + 1], dims[l], dtype=torch.float32, device=dev) if ctx.needs_input_grad[6 + l] else None for l in range(n)]
+        dws = [torch.empty(dims[l + 1], dims[l], dtype=torch.float32, device=dev) if ctx.needs_input_grad[7 + l] else None for l in range(n)]
         nbytes = int(lib.pnr_mlp_backward_workspace_bytes(ctypes.byref(desc), B))
         ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
         call("pnr_mlp_backward_lm", ctypes.byref(desc), ptr(packed), ptr(enc), ctypes.c_uint32(L), ptr(tail_c), ptr(dy2), ctypes.c_uint32(B), ptr(denc),
@@ -162,11 +164,12 @@ class _EncodeMLP(torch.autograd.Function):
             gws = torch.empty(gb // 4 + 1, dtype=torch.int32, device=dev)
             call("pnr_grid_encode_backward_binned", ptr(denc), ptr(x01), ptr(offsets), ptr(grad_emb), _u32(B), _u32(3), _u32(2), _u32(L), _f32(S), _u32(H),
                  _u32(gridtype), _int(int(align_corners)), ctypes.c_uint64(ctx.rows), ptr(gws), ctypes.c_uint64(gb))
-        return (None, grad_emb, None, None, None, None, *dws)
+        return (None, grad_emb, None, None, None, None, None, *dws)
 
 
 def encode_mlp_fused_ok(encoder, x, tail, net, act=F.relu):
-    """True when encode_mlp(encoder, x, ., tail, net, act) takes its fused path (callers that want to hand it a lookup they already have ask first)."""
+    """True when encode_mlp(encoder, x, ., tail, net, act) takes its fused path -- THE predicate: encode_mlp itself decides with this very function,
+    so a caller that asks first (to hand over a lookup it already has) and encode_mlp cannot disagree."""
     from .gridencoder import BINNED_MIN_ROWS
     ok = (enabled and x.is_cuda and torch.is_grad_enabled() and not x.requires_grad and (tail is None or not tail.requires_grad)
           and getattr(encoder, "num_levels", 0) == 16 and getattr(encoder, "level_dim", 0) == 2 and getattr(encoder, "input_dim", 0) == 3
@@ -180,28 +183,18 @@ def encode_mlp_fused_ok(encoder, x, tail, net, act=F.relu):
 def encode_mlp(encoder, x, bound, tail, net, act=F.relu, enc=None):
     """`_run(net, cat([encoder(x, bound), tail]), act)` -- fused end to end when it can be (CUDA fp32 hash grid with 16 levels x 2 features,
     a large batch, no gradient wanted for x or tail), the plain composition otherwise.
-    enc: the encoder's raw level-major output [16, B, 2] at x when the caller has it already (fused path only: check encode_mlp_fused_ok first)."""
-    from .gridencoder import BINNED_MIN_ROWS
+    enc: the encoder's raw level-major output [16, B, 2] at x when the caller has it already -- a non-differentiable hint: the fused path reads it
+    instead of looking the rows up again; when the fused path is refused it is ignored and the lookup recomputed (never an error in mid-step)."""
     import numpy as np
-    ok = (enabled and x.is_cuda and torch.is_grad_enabled() and not x.requires_grad and (tail is None or not tail.requires_grad)
-          and getattr(encoder, "num_levels", 0) == 16 and getattr(encoder, "level_dim", 0) == 2 and getattr(encoder, "input_dim", 0) == 3
-          and hasattr(encoder, "embeddings") and encoder.embeddings.dtype == torch.float32 and x.numel() // 3 >= max(MIN_ROWS, BINNED_MIN_ROWS)
-          and x.numel() // 3 * 16 * 8 < 2 ** 32)
-    if ok:
-        ok = net[0].in_features == 32 + (0 if tail is None else tail.shape[-1]) and fusable(net, _Rows(x.numel() // 3, net[0].in_features, x), act)
-    if not ok:
-        if enc is not None:
-            raise RuntimeError("encode_mlp: a precomputed lookup can only be handed to the fused path (encode_mlp_fused_ok)")
+    if not encode_mlp_fused_ok(encoder, x, tail, net, act):
         h = encoder(x, bound=bound)
         if tail is not None:
             h = torch.cat([h, tail], dim=-1)
         return run_mlp(net, h, act)
     x01 = ((x + bound) / (2 * bound)).reshape(-1, 3)   # same two roundings as GridEncoder.forward (gridencoder/grid.py:142)
     meta = (float(np.log2(encoder.per_level_scale)), int(encoder.base_resolution), int(encoder.gridtype_id), bool(encoder.align_corners))
-    if enc is not None:
-        meta = meta + (enc,)
     t2 = None if tail is None else tail.reshape(-1, tail.shape[-1])
-    y = _EncodeMLP.apply(x01, encoder.embeddings, encoder.offsets, meta, t2, _ACT[act], *[l.weight for l in net])
+    y = _EncodeMLP.apply(x01, encoder.embeddings, encoder.offsets, meta, t2, _ACT[act], enc, *[l.weight for l in net])
     return y.reshape(*x.shape[:-1], y.shape[-1])
 
 

@@ -23,6 +23,28 @@ def test_workloads_name_every_gpu_config_of_baseline_json():
     assert bench.parse(["--model", "palette"]).workload == "lego_palette"
 
 
+def test_more_than_one_rank_defaults_to_the_north_star_question(monkeypatch):
+    """N > 1 without flags = configs[4]: ONE garden frame split over the ranks (strong scaling); N = 1 = configs[1]; explicit flags win."""
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    a = bench.parse(["--gpus", "8"])
+    assert (a.workload, a.scaling, a.defaulted_for_ranks, a.wl["config"], a.wl["model"]) == ("garden", "strong", True, 4, "palette")
+    a = bench.parse([])
+    assert (a.workload, a.scaling, a.defaulted_for_ranks) == ("lego", "weak", False)
+    for flags, want in ((["--workload", "lego"], ("lego", "weak")), (["--scaling", "weak"], ("lego", "weak")), (["--model", "palette"], ("lego_palette", "weak")),
+                        (["--workload", "garden"], ("garden", "strong")), (["--workload", "garden", "--scaling", "weak"], ("garden", "weak"))):
+        a = bench.parse(["--gpus", "4"] + flags)
+        assert (a.workload, a.scaling) == want and not a.defaulted_for_ranks, flags
+    a = bench.parse(["--dist-default"])                  # the same defaults over a one-rank communicator (the -m gpu test of the N > 1 line)
+    assert (a.workload, a.scaling, a.gpus) == ("garden", "strong", 1)
+    monkeypatch.setenv("WORLD_SIZE", "2")                # under the driver's launcher the rank count comes from the environment
+    a = bench.parse(["--gpus", "2", "--steps", "5"])
+    assert (a.workload, a.scaling) == ("garden", "strong")
+    again = bench.parse(bench.core_argv(a))              # a child pass repeats the resolved workload and scaling, not the defaults of its own rank count
+    monkeypatch.delenv("WORLD_SIZE")
+    again1 = bench.parse(bench.core_argv(a))
+    assert (again.workload, again.scaling) == (again1.workload, again1.scaling) == ("garden", "strong")
+
+
 def test_gpus_flag_spawns_that_many_ranks(tmp_path, monkeypatch):
     """The spawn path really produces WORLD_SIZE == --gpus ranks (a stand-in script records what each rank sees)."""
     probe = tmp_path / "probe.py"

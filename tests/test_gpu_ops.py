@@ -452,6 +452,25 @@ def test_grid_encode_tiled_and_align_corners(cuda):
         np.testing.assert_array_equal(host(out), oracle.grid_encode_forward(x, emb, offsets, pls, 8, gridtype=gridtype, align_corners=ac))
 
 
+def test_grid_encode_align_corners_wraps_the_corner_beyond_a_dense_level(cuda):
+    """align_corners: side == resolution, so an input of exactly 1.0 puts the +1 corner at index side on that axis and (z == 1.0) the row index at
+    or beyond side^3 -- the reference wraps it with `% hashmap_size` (gridencoder.cu:49-72).  Its weight is 0, so a kernel that skips the wrap on
+    dense levels gives the same numbers UNLESS the stray row (the next level's first rows) is not finite: those rows are NaN here."""
+    rng = np.random.default_rng(23)
+    L, H = 4, 8
+    offsets = oracle.grid_offsets(3, L, 2.0, H, 19, align_corners=True)      # 8^3, 16^3, 32^3, 64^3 rows: all dense, sizes == side^3
+    emb = (rng.random((int(offsets[-1]), 2)) - 0.5).astype(np.float32)
+    x = np.minimum(0.5 + 0.5 * rng.random((4001, 3)), 0.999).astype(np.float32)   # coordinates in [0.5, 1): no genuine read of a level's first rows
+    x[:64, 2] = 1.0     # corner z + 1 == side: index side^3 + x + y side -- wrapped: rows >= (side/2 - 1)(side + 1) of this level; not wrapped: the next level's first rows
+    for lv in range(1, L):
+        side = H << (lv - 1)                                           # resolution of the level BEFORE this one
+        emb[offsets[lv]: offsets[lv] + side * side + side + 8] = np.nan
+    want = oracle.grid_encode_forward(x, emb, offsets, 2.0, H, gridtype=0, align_corners=True)
+    assert np.isfinite(want).all()
+    out = gridencoder.grid_encode(dev(x, cuda), dev(emb, cuda), dev(offsets, cuda), 2.0, H, False, 0, True)
+    np.testing.assert_array_equal(host(out), want)
+
+
 def test_grid_encode_forward_fp16_table_bit_exact(cuda):
     rng = np.random.default_rng(21)
     pls, offsets, emb, x = _grid_setup(rng, 16, 16, 19, 4096, 2, 10007)
@@ -1500,6 +1519,48 @@ def test_grid_pair_lookup_is_bit_identical_to_two_lookups(cuda):
         assert float(a[:, 7].abs().max()) == 0.0 and float(b[:, 8].abs().max()) == 0.0
         with torch.no_grad():
             eb.embeddings.add_(0.25)               # an optimiser step: the pair table must be rebuilt
+
+
+def test_grid_pair_copy_lives_on_the_encoder_and_notices_data_writes(cuda):
+    """The training pair lookup's interleaved copy (fused._PairCopy): held by the first encoder (no global registry), dropped by
+    invalidate_fused_caches, and a `.data` rewrite -- which moves neither identity nor version -- is noticed by the sampled checksum one call late."""
+    import warnings
+    from palettenerf_amd import fused
+
+    class _M:                                     # what invalidate_fused_caches walks: a model's encoders
+        pass
+    torch.manual_seed(4)
+    mk = lambda: gridencoder.GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=4096).to(cuda)
+    m = _M()
+    m.encoder, m.encoder_palette = mk(), mk()
+    for e in (m.encoder, m.encoder_palette):
+        e.embeddings.data.uniform_(-0.5, 0.5)
+    assert not hasattr(fused, "_PAIR_TABLES")
+    x01 = torch.rand(5003, 3, device=cuda)
+    same = lambda: all(torch.equal(p, fused.grid_encode_raw(e, x01)) for p, e in zip(fused.grid_encode_raw_pair(m.encoder, m.encoder_palette, x01), (m.encoder, m.encoder_palette)))
+    assert same()
+    assert "_pnr_pair" in m.encoder.__dict__ and "_pnr_pair" not in m.encoder.state_dict()
+    # 1. a `.data` write followed by invalidate_fused_caches: fresh at once
+    m.encoder.embeddings.data.uniform_(-0.25, 0.25)
+    fused.invalidate_fused_caches(m)
+    assert "_pnr_pair" not in m.encoder.__dict__
+    assert same()
+    # 2. a `.data` write nobody announces: stale for exactly one call, then noticed (warning) and rebuilt
+    m.encoder_palette.embeddings.data.uniform_(-0.125, 0.125)
+    assert not same()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert same()
+    assert any("rewritten behind torch's version counters" in str(x.message) for x in w)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert same()
+    assert not w
+    # 3. another partner: the copy is rebuilt for it
+    other = mk()
+    other.embeddings.data.uniform_(-0.5, 0.5)
+    a, b = fused.grid_encode_raw_pair(m.encoder, other, x01)
+    assert torch.equal(b, fused.grid_encode_raw(other, x01)) and torch.equal(a, fused.grid_encode_raw(m.encoder, x01))
 
 
 def test_sigma_geo_cat_matches_the_reference_composition(cuda):

@@ -11,7 +11,8 @@ What holds (measured, profiles/r04_reference_kernels.json), and is asserted here
                 forward and backward
   to rounding   composite_rays_train (this repository's 16-lanes-per-ray scan adds in another order: <= 2e-6 of the largest value),
                 SH (product form against the reference's expanded polynomials: <= 1e-6), HSV (<= 2e-7 relative)
-The build container has no GPU, the GPU box no reference checkout: the .so files are built there and loaded here."""
+The build container has no GPU, the GPU box no reference checkout: the .so files are built there and loaded here.  Missing files FAIL these
+tests under `-m gpu` (PNR_ALLOW_NO_REF=1 turns that into a skip for trees built without the reference)."""
 import numpy as np
 import pytest
 import torch
@@ -23,9 +24,15 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def ref(cuda):
+    import os
     from oracle import ref_build, ref_ops
     if not ref_ops.available():
-        pytest.skip("oracle/_ref/ref_*.so are not built (oracle/ref_build.py needs the reference checkout at build time)")
+        # the suite's strongest check: on a GPU box its absence is a FAILURE (a lost build step must not leave the suite green), unless the caller
+        # says explicitly that this tree was built without the reference checkout
+        msg = "oracle/_ref/ref_*.so are not built (oracle/ref_build.py: build_hip needs the reference checkout at build time)"
+        if os.environ.get("PNR_ALLOW_NO_REF") == "1":
+            pytest.skip(msg + " -- PNR_ALLOW_NO_REF=1")
+        pytest.fail(msg + "; set PNR_ALLOW_NO_REF=1 to run the GPU suite without the reference's kernels")
     return {"rm": ref_build.load_hip("raymarching"), "sh": ref_build.load_hip("shencoder"), "pal": ref_build.load_hip("palette")}
 
 
