@@ -18,6 +18,10 @@ ARCH = "gfx950"
 # -ffp-contract=off: the canonical scalar spec uses explicit fmaf() only.
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("PNR_EXTRA_HIPCC_FLAGS", "").split()   # experiment builds only (e.g. -DPNR_MARCH_STATS)
+# Per-unit flags.  palette_field: without the SLP vectoriser -- it pairs the epilogue's scalar fp32 math into v_pk_* instructions whose constant operands
+# must sit in register PAIRS, hoists those pairs (and a dozen other loop invariants) out of the tile loop and then spills them: 94 -> 10 spilled scalar
+# registers, 20 -> 0 bytes of scratch per lane, 162 -> 157 vector registers for the shipped kernel; same arithmetic, same bits (round 5).
+UNIT_FLAGS = {"palette_field": ["-fno-slp-vectorize"]}
 
 
 def hipcc():
@@ -46,7 +50,7 @@ def _compile(src):
     hdr_m = max(hdr_m, os.path.getmtime(os.path.join(HERE, "..", "include", "pnr.h")))
     if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_m):
         return obj
-    subprocess.check_call([hipcc(), *FLAGS, "-c", src, "-o", obj])
+    subprocess.check_call([hipcc(), *FLAGS, *UNIT_FLAGS.get(os.path.basename(src)[:-4], []), "-c", src, "-o", obj])
     return obj
 
 
@@ -61,7 +65,7 @@ def build_variant(name, extra_flags, only=None, verbose=False):
         base = os.path.basename(src)[:-4]
         if only is None or base in only:
             obj = os.path.join(vobj, base + ".o")
-            subprocess.check_call([hipcc(), *FLAGS, *extra_flags, "-c", src, "-o", obj])
+            subprocess.check_call([hipcc(), *FLAGS, *UNIT_FLAGS.get(base, []), *extra_flags, "-c", src, "-o", obj])
         else:
             obj = os.path.join(OBJ, base + ".o")
         objs.append(obj)

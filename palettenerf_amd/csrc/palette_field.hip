@@ -139,6 +139,21 @@ __device__ __forceinline__ f32x16 dense64(f32x16 acc, const unsigned char* __res
     return acc;
 }
 
+// 64 -> 64 layer: BOTH output tiles per k-block, so that a block's activation split (8 registers) is formed once and is dead before the next one --
+// two dense64 calls either keep all four splits alive across both (32 registers: the difference between three and four waves per SIMD) or form them
+// twice.  Per accumulator the blocks arrive in the same order as in dense64: same bits.
+template <int PREC, bool CHECK>
+__device__ __forceinline__ void dense64x2(f32x16& o0, f32x16& o1, const unsigned char* __restrict__ w, int q0, const f32x16& a0, const f32x16& a1, int lane, SplitWatch<CHECK>* sw) {
+    o0 = zero16(); o1 = zero16();
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) {
+        const BOp<PREC> b = frag_op<PREC, CHECK>(kb < 2 ? a0 : a1, kb & 1, sw);
+        o0 = mma_blk<PREC>(o0, w + (q0 + kb) * kF16BlockBytes, b, lane);
+        o1 = mma_blk<PREC>(o1, w + (q0 + 4 + kb) * kF16BlockBytes, b, lane);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 __device__ __forceinline__ void scale8x2(float x[2][8], float s) {
 #pragma unroll
     for (int j = 0; j < 8; j++) { x[0][j] *= s; x[1][j] *= s; }
@@ -164,6 +179,7 @@ struct PaletteParams {
     float density_scale, offsets_weight, view_dep_weight;
     int nb, clip_dim, pred_clip, aux_stride;
     float enc_scale[3];             // power-of-two prescales of enc / enc_palette / enc_clip (split-fp16 path only; 1 = none)
+    float enc_scale_inv[3];         // their exact reciprocals, formed on the host (a division in the kernel is a dozen instructions the compiler hoists and keeps)
 };
 // RegionEdit / Stylizer parameters (pnr_palette_edit) as the kernel reads them from device memory
 struct EditParams {
@@ -188,6 +204,30 @@ constexpr int kPalThreads = 512;
 #endif
 #ifndef PNR_PAL_EARLY_RAY
 #define PNR_PAL_EARLY_RAY 1     // garden 13.2 -> 13.0 ms (162 registers, no scratch)
+#endif
+// Round 5.  What the parts of this kernel cost alone (profiles/r05_pal_parts.txt, stand-alone op, 1.09 M rows, timing-only PNR_PAL_FAKE builds): the matrix
+// phase 171 us of 213, everything behind it (scalar epilogue, staging, stores) ~40 us; and what they need: the matrix phase 118 registers, the old tail 157
+// plus a 4.6 KB staging slab per wave -- the tail, not the layers, held the kernel at three waves per SIMD.  The specialised 4-basis kernels ("wide":
+// NB == 4, PNR_PAL_WIDE_WAVES waves, no clip head, rows of 36 floats) therefore take a tail of their own that stages NOTHING in LDS:
+//   * a sample's 34-value aux row stays in its lane's registers; with one sample per ray (every heavy launch) the lane itself does the ray's
+//     aux_map read-modify-write, nine 16-byte loads in flight at once; with 2 .. 8 samples per ray the ray's leader lane pulls the following lanes'
+//     rows through ds_bpermute and runs the same fmaf chain in the same order (bit-identical to the staged form either way);
+//   * the ray state (rays_t, depth, image) is requested when the matrix phase ends and used behind the scalar epilogue;
+//   * PNR_PAL_EARLY_ENC: the tile's encoder rows and directions are requested BEFORE the slot's `delta` has decided whether the row is alive (one trip
+//     to memory instead of two dependent ones; a dead lane's loads are wasted), and the delta pair stays in two registers for the epilogue's alpha and
+//     the ray-state step (it was loaded three times).
+// LDS: the weights + 384 bytes per wave, so 16 waves (four per SIMD) fit where 12 slabs did not leave room for a thirteenth.
+#ifndef PNR_PAL_EARLY_ENC
+#define PNR_PAL_EARLY_ENC 1
+#endif
+#ifndef PNR_PAL_FAKE
+#define PNR_PAL_FAKE 0          // timing-only builds (WRONG results): 1 = no matrix phase (the loads stay), 2 = nothing behind the matrix phase (no epilogue, composite, stores)
+#endif
+#ifndef PNR_PAL_WIDE_WAVES
+#define PNR_PAL_WIDE_WAVES 12   // waves per workgroup of the specialised 4-basis kernels ("wide": no clip head, rows of 36 floats, slabs in LDS).  Experiment builds: 8
+#endif
+#ifndef PNR_PAL_EARLY_ENC
+#define PNR_PAL_EARLY_ENC 1
 #endif
 
 
@@ -229,8 +269,26 @@ __device__ __forceinline__ PalArgsK launder(PalArgsK p) {
     return p;
 }
 
+// PNR_PAL_TIMING (diagnostic build, profiles/pal_timing.py): wave-level time per phase of a tile, summed over all waves and tiles of every launch since the
+// last reset.  Stamps are the 100 MHz wall clock; the stamp behind a load phase first waits for the loads, so "wait" phases hold the exposed latency.
+#ifdef PNR_PAL_TIMING
+enum { PT_TOP = 0, PT_ENC_WAIT, PT_SIGMA, PT_DIFF, PT_COLOR, PT_PAL_WAIT, PT_BASIS, PT_EPILOGUE, PT_LEADER, PT_AUXMAP, PT_RAYSTATE, PT_SKIP, PT_SETUP, PT_PREFETCH, PT_ACC_WAIT, PT_ACC, PT_N };
+__device__ unsigned long long g_pal_timing[PT_N + 3];   // + tiles, waves, kernel wall (first wave start .. last wave end is not tracked: wave residence sum)
+#define PAL_T(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = wall_clock64(); tacc[i] += now_ - tlast; tlast = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PAL_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define PAL_T(i) do {} while (0)
+#define PAL_WAIT_VM() do {} while (0)
+#endif
+
 template <int PREC, int EDIT, bool CHECK, int NB, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
+#ifdef PNR_PAL_TIMING
+    unsigned long long tacc[PT_N] = {};
+    unsigned long long tlast = wall_clock64();
+    const unsigned long long tstart = tlast;
+    unsigned long long ntiles = 0;
+#endif
     const PalArgsK ka = (PalArgsK)__builtin_amdgcn_kernarg_segment_ptr();
     const FrameCtlView* __restrict__ ctl = A_.ctl;
     const uint32_t B_arg = A_.B;
@@ -249,24 +307,32 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
     uint32_t* __restrict__ tile_counter = A_.tile_counter;
     const bool has_aux_map = A_.aux_map != nullptr, has_ray_state = A_.rs.rays_t != nullptr;
     if (ctl && ctl->done) return;
-    const uint32_t B = ctl ? (uint32_t)ctl->n_alive * (uint32_t)ctl->n_step : B_arg;
+    // the control block does not change while this kernel runs: read once (a use inside the tile loop would be a global load per use)
+    const uint32_t n_alive_k = ctl ? (uint32_t)__builtin_amdgcn_readfirstlane(ctl->n_alive) : 0u, n_step_k = ctl ? (uint32_t)__builtin_amdgcn_readfirstlane(ctl->n_step) : 0u;
+    const uint32_t B = ctl ? n_alive_k * n_step_k : B_arg;
     // rows of a ray are consecutive.  Whole rays per wave tile (rpw rows of its 32) when the kernel also composites the ray state; otherwise 32 rows,
     // and the aux composite runs here only with 1, 2, 4 or 8 samples per ray (a ray's rows then sit inside one wave tile anyway)
     const bool ray_tiles = stage_stride && ctl && has_aux_map && has_ray_state;
-    const uint32_t rpw = ray_tiles ? (32u / (uint32_t)ctl->n_step) * (uint32_t)ctl->n_step : 32u;
+    const uint32_t rpw = ray_tiles ? (32u / n_step_k) * n_step_k : 32u;
     const uint32_t nwt = (B + rpw - 1) / rpw;    // wave tiles of this launch
     if (blockIdx.x >= nwt) return;               // (wave 0 of workgroup b takes wave tile b first: a workgroup beyond nwt has nothing at all)
     extern __shared__ unsigned char w[];
     for (uint32_t i = threadIdx.x * 16; i < packed_bytes; i += WAVES * 64 * 16) lds_copy16(&packed[i], &w[i]);   // weights + the PaletteTables behind them
     lds_copy_wait();
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    PAL_T(PT_SETUP);
+    const int lane_k = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nb = NB ? NB : pp.nb;
     constexpr int kLoopNb = NB ? NB : kMaxNb;
     // rows of a ray are consecutive; with 1, 2, 4 or 8 samples per ray they sit inside one 32-row wave tile and the aux composite
     // can run here (fstep = samples per ray), otherwise the composite launch does it
-    const uint32_t fstep = (stage_stride && ctl && has_aux_map && ctl->n_step <= 8 && (ray_tiles || (32 % ctl->n_step) == 0)) ? (uint32_t)ctl->n_step : 0u;
+    const uint32_t fstep = (stage_stride && ctl && has_aux_map && n_step_k <= 8 && (ray_tiles || (32 % n_step_k) == 0)) ? n_step_k : 0u;
     const bool fuse_composite = fstep != 0;
+    // x / fstep for the small x of a tile (lane numbers, rows per tile) as (x * fM) >> 16 -- exact for x < 8192, fstep <= 8 -- and the per-tile quantities that
+    // do not depend on the lane as scalars: the compiler's own expansion of an integer division is ~20 instructions whose lane-dependent intermediate values
+    // it hoists out of the tile loop and then keeps (or spills) across the whole matrix phase
+    const uint32_t fM = fstep ? 65536u / fstep + 1u : 0u;
+    const uint32_t rays_pt = fstep ? (rpw * fM) >> 16 : 0u;      // whole rays per wave tile
     // Work is handed out per 32-sample wave tile: the static persistent schedule (workgroup b takes tiles b, b + grid, ...), or -- an experiment
     // kept behind pnr_set_option("dynamic_tiles") -- every wave fetching its next wave tile from a device counter (tile_counter, zeroed by the
     // iteration's march launch).  The idea: a launch of 11.08 workgroup tiles per CU takes the time of 12 with the static schedule.  Measured:
@@ -275,7 +341,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
         uint32_t wt;
         if (tile_counter) {
             uint32_t got = 0;
-            if (lane == 0) got = atomicAdd(tile_counter, 1u);
+            if (lane_k == 0) got = atomicAdd(tile_counter, 1u);
             wt = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
         } else {
             // wave-major: round `it` deals wave tile (it * WAVES + wave) * grid + b to wave `wave` of workgroup b, so the LAST, partial round of a
@@ -286,45 +352,90 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
             else wt = (blockIdx.x + it * gridDim.x) * WAVES + wave;
         }
         if (wt >= nwt) break;
+        // (the lane number goes through an opaque move once per tile: what is derived from it below -- row numbers, leader flags, LDS addresses, bit masks -- is
+        // then formed where it is used, a few instructions, instead of being hoisted out of the loop into registers that live through the matrix phase)
+        int lane = lane_k;
+        asm volatile("" : "+v"(lane));
+        const int h = lane >> 5;
+        const uint32_t lane_q = ((uint32_t)(lane & 31) * fM) >> 16, lane_k_in_ray = (uint32_t)(lane & 31) - lane_q * fstep;   // (lane & 31) / fstep, % fstep
         const uint32_t n = wt * rpw + (lane & 31);
         const bool mine = (uint32_t)(lane & 31) < rpw && n < B;
-        const bool valid = mine && (!deltas || deltas[(size_t)(mine ? n : 0) * 2] != 0.0f);
+        // the slot's (delta_0, delta_1): delta_0 == 0 marks a dead slot; kept for the epilogue's alpha and the ray-state step's t advance
+        f32x2 dl = {1.0f, 0.0f};
+        if (deltas && mine) dl = *reinterpret_cast<const f32x2*>(deltas + (size_t)n * 2);
+        constexpr bool kEarlyEnc = PNR_PAL_EARLY_ENC != 0 && WAVES == PNR_PAL_WIDE_WAVES;
+        float xs[2][8], xp[2][8];
+        float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+        if constexpr (kEarlyEnc) {   // requested before `dl` has arrived: rows of dead lanes are read too and replaced by zeros below
+            const uint32_t row_e = n < B ? n : (B - 1);
+            load_enc_raw(enc, level_stride, row_e, true, h, xs);
+            dx = dirs[(size_t)row_e * 3]; dy = dirs[(size_t)row_e * 3 + 1]; dz = dirs[(size_t)row_e * 3 + 2];
+        }
+        const bool valid = mine && dl.x != 0.0f;
         if (!__any(valid)) {
             // nothing to evaluate -- but with the ray state composited here, the rays of this wave tile (all their rows dead) must still leave the alive list
             if (has_ray_state) {
-                const uint32_t l = (uint32_t)(lane & 31), ns = (uint32_t)ctl->n_step;
-                if (h == 0 && l < rpw && (l % ns) == 0 && n / ns < (uint32_t)ctl->n_alive) launder(ka)->rs.rays_alive[n / ns] = -1;
+                const uint32_t l = (uint32_t)(lane & 31);      // (has_ray_state implies the fused tail: fstep == n_step)
+                if (h == 0 && l < rpw && lane_k_in_ray == 0 && wt * rays_pt + lane_q < n_alive_k) launder(ka)->rs.rays_alive[wt * rays_pt + lane_q] = -1;
             }
+            PAL_T(PT_SKIP);
             continue;
         }
+#ifdef PNR_PAL_TIMING
+        ntiles++;
+#endif
         const uint32_t row = n < B ? n : (B - 1);
 
         SplitWatch<CHECK> sw_, *sw = &sw_;
         // all global reads of the tile up front
         // (the 12-wave variant has three waves per SIMD to hide a load behind and 168 registers: it fetches the second table's features where they are used)
-        float xs[2][8], xp[2][8];
-        load_enc_raw(enc, level_stride, row, valid, h, xs);
-        if constexpr (WAVES == 8) load_enc_raw(enc_pal, level_stride, row, valid, h, xp);
+        if constexpr (kEarlyEnc) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) { xs[0][j] = valid ? xs[0][j] : 0.0f; xs[1][j] = valid ? xs[1][j] : 0.0f; }
+            dx = valid ? dx : 0.0f; dy = valid ? dy : 0.0f; dz = valid ? dz : 0.0f;
+        } else {
+            load_enc_raw(enc, level_stride, row, valid, h, xs);
+        }
+        if constexpr (WAVES != PNR_PAL_WIDE_WAVES) load_enc_raw(enc_pal, level_stride, row, valid, h, xp);
         // 12 waves: enc_palette's 16 levels x 32 rows x 8 bytes of this tile -> the wave's (idle) staging slab, 4 x 1 KiB, one level per 16 lanes.
         // Needs 16-byte aligned sources (even first row, even level stride) and 32 rows that exist in every level's run (level_stride rows are
         // allocated per level; rows beyond B hold stale values that their lanes replace by zeros below).  Wave-uniform.
         const uint32_t n0_tile = wt * rpw;
-        const bool pal_in_lds = PNR_PAL_EARLY_PAL && WAVES == 12 && stage_stride * 32u * 4u >= 4096u && ((level_stride | n0_tile) & 1u) == 0u && n0_tile + 32u <= level_stride;
+        const bool pal_in_lds = PNR_PAL_EARLY_PAL && WAVES == PNR_PAL_WIDE_WAVES && stage_stride * 32u * 4u >= 4096u && ((level_stride | n0_tile) & 1u) == 0u && n0_tile + 32u <= level_stride;
         if (pal_in_lds) {
             unsigned char* slab_b = w + packed_bytes + (size_t)wave * 32 * stage_stride * 4;
             const unsigned char* src = reinterpret_cast<const unsigned char*>(enc_pal) + ((size_t)(lane >> 4) * level_stride + n0_tile) * 8u + (uint32_t)(lane & 15) * 16u;
 #pragma unroll
             for (int i = 0; i < 4; i++) lds_copy16(src + (size_t)(4 * i) * level_stride * 8u, slab_b + i * 1024 + lane * 16);
         }
-        float dx = 0.0f, dy = 0.0f, dz = 0.0f;
-        if (valid) { dx = dirs[(size_t)row * 3]; dy = dirs[(size_t)row * 3 + 1]; dz = dirs[(size_t)row * 3 + 2]; }
+        if constexpr (!kEarlyEnc) {
+            if (valid) { dx = dirs[(size_t)row * 3]; dy = dirs[(size_t)row * 3 + 1]; dz = dirs[(size_t)row * 3 + 2]; }
+        }
         // the compositing step's first dependent load (slot -> ray id), requested now; its second (the ray's weights_sum) once sigma_net is done
-        const bool early_ray = PNR_PAL_EARLY_RAY && WAVES == 12 && fuse_composite;
-        const bool lead_lane = early_ray && (uint32_t)lane < rpw && (lane % fstep) == 0 && (n0_tile + lane) / fstep < (uint32_t)ctl->n_alive;
+        const bool early_ray = PNR_PAL_EARLY_RAY && WAVES == PNR_PAL_WIDE_WAVES && fuse_composite;
+        const uint32_t slot_t = wt * rays_pt + lane_q;      // the alive-list slot of this lane's ray
+        const bool lead_lane = early_ray && (uint32_t)lane < rpw && lane_k_in_ray == 0 && slot_t < n_alive_k;
         int early_index = 0;
         float early_ws = 0.0f;
-        if (lead_lane) early_index = rays_alive[(n0_tile + lane) / fstep];
+        if (lead_lane) early_index = rays_alive[slot_t];
 
+        PAL_T(PT_TOP);
+        PAL_WAIT_VM();
+        PAL_T(PT_ENC_WAIT);
+#if PNR_PAL_FAKE & 1
+        // (timing only) stand-ins formed from the loaded rows; the second table's rows and the slab request stay
+        constexpr bool kWide = NB == 4 && WAVES == PNR_PAL_WIDE_WAVES;
+        if (lead_lane) early_ws = weights_sum[early_index];
+        if constexpr (WAVES == PNR_PAL_WIDE_WAVES) load_enc_raw(enc_pal, level_stride, row, valid, h, xp);
+        const float sigma_logit = xs[0][0] + xp[0][0];
+        const float diffuse[3] = {xs[0][1], xs[0][2], xs[0][3]}, view_dep[3] = {xp[0][1] + dx, xp[0][2] + dy, xp[0][3] + dz};
+        f32x16 orr = zero16(), orr2 = zero16(), om = zero16(), clip = zero16(), clip2 = zero16();
+#pragma unroll
+        for (int j = 0; j < 8; j++) { orr[j] = xs[1][j]; orr[8 + j] = xp[1][j]; om[j] = xs[0][j]; }
+        uint32_t toff = packed_bytes - kTablesBytes;
+        asm volatile("" : "+s"(toff));
+        const bool pred_clip = false;
+#else
         // ---------------- sigma_net (prescaled by a power of two when the table's entries are tiny: undone exactly on its 16 outputs)
         const bool pre_s = PREC != 0 && pp.enc_scale[0] != 1.0f, pre_p = PREC != 0 && pp.enc_scale[1] != 1.0f, pre_c = PREC != 0 && pp.enc_scale[2] != 1.0f;
         if (pre_s) scale8x2(xs, pp.enc_scale[0]);
@@ -342,22 +453,26 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
         __builtin_amdgcn_sched_barrier(0);
         t0 = relu16(t0); t1 = relu16(t1);
         f32x16 g = dense64<PS, CHECK>(zero16(), w, PB_S1, t0, t1, lane, sw);   // rows 0..15: sigma logit, geo_feat 1..15
-        if (pre_s) g = scale16(g, 1.0f / pp.enc_scale[0]);
+        if (pre_s) g = scale16(g, pp.enc_scale_inv[0]);
         const float sigma_logit = g[0];
         const BOp<PREC> geo = frag_op<PREC, CHECK>(g, 0, sw);                           // the geo k-block, shared by diff_net and color_net
+        PAL_T(PT_SIGMA);
         if (lead_lane) early_ws = weights_sum[early_index];
+        constexpr bool kWide = NB == 4 && WAVES == PNR_PAL_WIDE_WAVES;   // the slab-free tail (see the top of the file)
+        PAL_T(PT_PREFETCH);
 
         // ---------------- diff_net: 15 -> 64 -> 64 -> 3
         t0 = mma_blk<PREC>(zero16(), w + (PB_D0 + 0) * kF16BlockBytes, geo, lane);
         t1 = mma_blk<PREC>(zero16(), w + (PB_D0 + 1) * kF16BlockBytes, geo, lane);
         __builtin_amdgcn_sched_barrier(0);
         t0 = relu16(t0); t1 = relu16(t1);
-        f32x16 u0 = dense64<PREC, CHECK>(zero16(), w, PB_D1, t0, t1, lane, sw);
-        f32x16 u1 = dense64<PREC, CHECK>(zero16(), w, PB_D1 + 4, t0, t1, lane, sw);
+        f32x16 u0, u1;
+        dense64x2<PREC, CHECK>(u0, u1, w, PB_D1, t0, t1, lane, sw);
         u0 = relu16(u0); u1 = relu16(u1);
         const f32x16 dif = dense64<PREC, CHECK>(zero16(), w, PB_D2, u0, u1, lane, sw);  // rows 0..2
         const float diffuse[3] = {sigmoidf(dif[0]), sigmoidf(dif[1]), sigmoidf(dif[2])};
 
+        PAL_T(PT_DIFF);
         // ---------------- color_net (view dependent): [SH16 ; geo15] -> 64 -> 64 -> 3
         {
             float sh[16], v[8];
@@ -372,15 +487,15 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
         }
         __builtin_amdgcn_sched_barrier(0);
         t0 = relu16(t0); t1 = relu16(t1);
-        u0 = dense64<PREC, CHECK>(zero16(), w, PB_C1, t0, t1, lane, sw);
-        u1 = dense64<PREC, CHECK>(zero16(), w, PB_C1 + 4, t0, t1, lane, sw);
+        dense64x2<PREC, CHECK>(u0, u1, w, PB_C1, t0, t1, lane, sw);
         u0 = relu16(u0); u1 = relu16(u1);
         const f32x16 vdt = dense64<PREC, CHECK>(zero16(), w, PB_C2, u0, u1, lane, sw);
         const float view_dep[3] = {sigmoidf(vdt[0]), sigmoidf(vdt[1]), sigmoidf(vdt[2])};
 
+        PAL_T(PT_COLOR);
         // ---------------- basis_net: [enc_palette(32) ; diffuse(3)] -> 64 (ELU) -> 15
         {
-            if constexpr (WAVES != 8) {
+            if constexpr (WAVES == PNR_PAL_WIDE_WAVES) {
                 if (pal_in_lds) {   // the rows requested at the top of the tile: level 8 kb + 4 h + q of row (lane & 31)
                     lds_copy_wait();
                     typedef __attribute__((address_space(3))) f32x2 lds_f32x2;
@@ -396,6 +511,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
                     load_enc_raw(enc_pal, level_stride, row, valid, h, xp);
                 }
             }
+            PAL_WAIT_VM();
+            PAL_T(PT_PAL_WAIT);
             const float ps = pre_p ? pp.enc_scale[1] : 1.0f;   // the whole 35-wide input row is scaled; the ELU needs the true pre-activations back
             if (pre_p) scale8x2(xp, ps);
             const BOp<PREC> b0 = make_op<PREC, CHECK>(xp[0], sw), b1 = make_op<PREC, CHECK>(xp[1], sw);
@@ -409,7 +526,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
             t1 = mma_blk<PREC>(t1, w + (PB_B0 + 5) * kF16BlockBytes, db, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (pre_p) { t0 = scale16(t0, 1.0f / pp.enc_scale[1]); t1 = scale16(t1, 1.0f / pp.enc_scale[1]); }
+        if (pre_p) { t0 = scale16(t0, pp.enc_scale_inv[1]); t1 = scale16(t1, pp.enc_scale_inv[1]); }
         t0 = elu16(t0); t1 = elu16(t1);
         const f32x16 p = dense64<PREC, CHECK>(zero16(), w, PB_B1, t0, t1, lane, sw);   // rows 0..14
 
@@ -432,7 +549,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
 
         // ---------------- clip_net (optional): 32 -> 64 -> clip_dim, output rows in the lower half-wave
         f32x16 clip = zero16(), clip2 = zero16();
-        if (pp.pred_clip) {
+        // (the 12-wave kernels never carry a clip head -- its eight blocks and 16 more columns per staged row do not fit next to 12 slabs, see the launcher --
+        // so there the head's two accumulator tiles and every branch on it go at compile time)
+        constexpr bool kClipHead = WAVES != PNR_PAL_WIDE_WAVES;
+        const bool pred_clip = kClipHead && pp.pred_clip;
+        if (pred_clip) {
             float xc[2][8];
             load_enc_raw(enc_clip, level_stride, row, valid, h, xc);
             if (pre_c) scale8x2(xc, pp.enc_scale[2]);
@@ -445,9 +566,19 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
             t0 = relu16(t0); t1 = relu16(t1);
             clip = dense64<PREC, CHECK>(zero16(), w, PB_CL1, t0, t1, lane, sw);
             if (pp.clip_dim > 16) clip2 = dense64<PREC, CHECK>(zero16(), w, PB_CL1B, t0, t1, lane, sw);
-            if (pre_c) { clip = scale16(clip, 1.0f / pp.enc_scale[2]); clip2 = scale16(clip2, 1.0f / pp.enc_scale[2]); }
+            if (pre_c) { clip = scale16(clip, pp.enc_scale_inv[2]); clip2 = scale16(clip2, pp.enc_scale_inv[2]); }
         }
 
+#endif
+#if PNR_PAL_FAKE & 2
+        {   // (timing only) keep the matrix phase's results alive, store nothing
+            float chk = sigma_logit + diffuse[0] + diffuse[1] + diffuse[2] + view_dep[0] + view_dep[1] + view_dep[2] + early_ws;
+#pragma unroll
+            for (int j = 0; j < 16; j++) chk += orr[j] + om[j] + orr2[j] + clip[j] + clip2[j];
+            if (chk == 123456.789f) launder(ka)->sigmas[n] = chk + dl.y;
+        }
+#else
+        PAL_T(PT_BASIS);
         // ---------------- scalar epilogue on the lower half-wave: the palette colour-basis composite
         asm volatile("" : "+s"(toff));
         // the epilogue's arguments, from the kernel-argument segment (scalar loads here, not registers held since the kernel's entry)
@@ -462,6 +593,21 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
         int32_t* __restrict__ const overflow_flag = kc->overflow_flag;
         const RayState rs = {kc->rs.rays_t, kc->rs.weights_sum, kc->rs.depth, kc->rs.image, kc->rs.rays_alive, kc->rs.counts_cur};
         float rgb_out[3] = {0.0f, 0.0f, 0.0f};   // this row's final colour, kept for the ray-state composite below
+        float rowv[36];                          // (4-basis 12-wave kernels: the row's values; dead rows never count)
+#pragma unroll
+        for (int q = 32; q < 36; q++) rowv[q] = 0.0f;
+        // the ray state of the tile's rays, requested here (wide kernels) and used behind the scalar epilogue.  Issued by every lane without a branch --
+        // early_index is 0 outside the leader lanes, and without a ray state the loads read `dirs` (always there) -- because behind a branch the
+        // compiler merges the loaded registers with the other path's zeros at once: a copy, and in front of it the wait this placement exists to avoid.
+        float rs_t = 0.0f, rs_d = 0.0f, rs_r = 0.0f, rs_g = 0.0f, rs_b = 0.0f;
+        if constexpr (kWide) {
+            const bool rs_early = early_ray && rs.rays_t != nullptr;
+            const float* __restrict__ p_t = rs_early ? rs.rays_t : dirs;
+            const float* __restrict__ p_d = rs_early ? rs.depth : dirs;
+            const float* __restrict__ p_i = rs_early ? rs.image : dirs;
+            rs_t = p_t[early_index]; rs_d = p_d[early_index];
+            rs_r = p_i[early_index * 3]; rs_g = p_i[early_index * 3 + 1]; rs_b = p_i[early_index * 3 + 2];
+        }
         if (valid && h == 0) {
             const PaletteTables& T = *reinterpret_cast<const PaletteTables*>(w + toff);
             float omega[kMaxNb], osum = 0.0f;
@@ -481,23 +627,18 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
             // into this wave's staging slab, from where the whole 32-row tile (contiguous in memory) goes out as 16-byte stores
             // staging layout behind the weights: WAVES slabs of 32 rows x stage_stride floats, then WAVES x 32 x 3 spare floats (per row: the
             // compositing weight; per ray leader: ray id and number of rows that count)
-            float* a = stage_stride ? reinterpret_cast<float*>(w + packed_bytes) + ((size_t)wave * 32 + (lane & 31)) * stage_stride
-                                    : aux + (size_t)n * pp.aux_stride;
+            float* a = (stage_stride && !kWide) ? reinterpret_cast<float*>(w + packed_bytes) + ((size_t)wave * 32 + (lane & 31)) * stage_stride
+                                                : aux + (size_t)n * pp.aux_stride;
             // `a` is LDS or global, so its stores would be flat_store (57 per tile through both the vector-memory and the LDS queue); the 12-wave
             // kernels always stage (the launcher sees to it): there the row is written with ds_write
             // ... and, with the shipped 4 bases, the first 32 floats of the row (compile-time positions) leave as eight 16-byte writes
             typedef __attribute__((address_space(3))) float lds_float;
-            constexpr bool kRowRegs = NB == 4 && WAVES == 12;
-            float rowv[32];
-            auto put_tail = [&](int idx, float v) {   // run-time positions (clip columns, padding)
-                if constexpr (WAVES == 12) reinterpret_cast<lds_float*>(reinterpret_cast<uintptr_t>(a))[idx] = v;
-                else a[idx] = v;
-            };
+            auto put_tail = [&](int idx, float v) { a[idx] = v; };   // run-time positions (clip columns, padding); never reached by the wide kernels
             auto put = [&](int idx, float v) {
-                if constexpr (kRowRegs) { if (idx < 32) rowv[idx] = v; else put_tail(idx, v); }
+                if constexpr (kWide) rowv[idx] = v;      // (compile-time positions, all below 34: the row stays in registers)
                 else put_tail(idx, v);
             };
-            float* ex = reinterpret_cast<float*>(w + packed_bytes) + (size_t)WAVES * 32 * stage_stride + (size_t)wave * 96;
+            float* ex = reinterpret_cast<float*>(w + packed_bytes) + (kWide ? (size_t)0 : (size_t)WAVES * 32 * stage_stride) + (size_t)wave * 96;
             if constexpr (EDIT == 3) {
                 // "network heads" (pnr_palette_edit.mode 3): the row is what PaletteNetwork.forward returns per sample (palette/network.py:156-190) --
                 // [omega nb (normalised) | offsets_radiance 3 nb + 1 (raw, bias added) | view_dep 3 | diffuse 3 | clip_feat clip_dim | 0-pad] -- and the
@@ -509,16 +650,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
 #pragma unroll
                 for (int k = 0; k < 3; k++) { put(4 * nb + 1 + k, view_dep[k]); put(4 * nb + 4 + k, diffuse[k]); }
                 int c = 4 * nb + 7;
-                if constexpr (kRowRegs) {
+                if constexpr (kWide) {      // (4 bases: 23 values; the rest of the row is padding)
 #pragma unroll
-                    for (int q = 23; q < 32; q++) rowv[q] = 0.0f;      // (4 bases: 23 values; the rest of the 32 staged floats)
-                    typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
-                    lds_f32x4* a4 = reinterpret_cast<lds_f32x4*>(reinterpret_cast<uintptr_t>(a));
-#pragma unroll
-                    for (int q = 0; q < 8; q++) { f32x4 v4; v4.x = rowv[4 * q]; v4.y = rowv[4 * q + 1]; v4.z = rowv[4 * q + 2]; v4.w = rowv[4 * q + 3]; a4[q] = v4; }
-                    c = 32;
+                    for (int q = 23; q < 36; q++) rowv[q] = 0.0f;
+                    c = pp.aux_stride;
                 }
-                if (pp.pred_clip) {
+                if (pred_clip) {
                     const int c0 = 4 * nb + 7;
 #pragma unroll
                     for (int k = 0; k < PNR_MAX_CLIP; k++) if (k < pp.clip_dim) put_tail(c0 + k, k < 16 ? clip[k & 15] : clip2[k & 15]);
@@ -545,7 +682,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
                     float d2 = 0.0f;
 #pragma unroll
                     for (int k = 0; k < PNR_MAX_CLIP; k++) if (k < ep->has_mean_clip) {   // without a clip head clip_feat is zeros (palette/network.py:179)
-                        const float c = (pp.pred_clip && k < pp.clip_dim) ? (k < 16 ? clip[k & 15] : clip2[k & 15]) : 0.0f;
+                        const float c = (pred_clip && k < pp.clip_dim) ? (k < 16 ? clip[k & 15] : clip2[k & 15]) : 0.0f;
                         const float d = c - ep->mean_clip[k];
                         d2 += d * d;
                     }
@@ -591,47 +728,44 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
                 }
             }
             int c = 6 + 7 * nb;
-            if constexpr (kRowRegs) {
-                typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
-                lds_f32x4* a4 = reinterpret_cast<lds_f32x4*>(reinterpret_cast<uintptr_t>(a));   // rows are 16-byte aligned: stage_stride is a multiple of 4
-#pragma unroll
-                for (int q = 0; q < 8; q++) { f32x4 v4; v4.x = rowv[4 * q]; v4.y = rowv[4 * q + 1]; v4.z = rowv[4 * q + 2]; v4.w = rowv[4 * q + 3]; a4[q] = v4; }
-            }
-            if (pp.pred_clip) {   // the clip head's outputs sit in registers: compile-time indices
+            if constexpr (!kWide) {     // (wide: the row stays in rowv)
+            if (pred_clip) {   // the clip head's outputs sit in registers: compile-time indices
 #pragma unroll
                 for (int k = 0; k < PNR_MAX_CLIP; k++) if (k < pp.clip_dim) put_tail(c + k, k < 16 ? clip[k & 15] : clip2[k & 15]);
                 c += pp.clip_dim;
             }
             for (; c < pp.aux_stride; c++) put_tail(c, 0.0f);   // (without a clip head the clip_dim columns are zeros too, as the reference's torch.zeros clip_feat)
+            }
             const float sigma = pp.density_scale * __expf(sigma_logit);
             if (!rs.rays_t) sigmas[n] = sigma;   // (with the ray state composited here nobody reads sigmas / rgbs)
-            if (fuse_composite) ex[(lane & 31) * 3] = 1.0f - __expf(-sigma * deltas[(size_t)n * 2]);   // alpha, exactly as k_frame_composite forms it
+            if (fuse_composite) ex[(lane & 31) * 3] = 1.0f - __expf(-sigma * dl.x);   // alpha, exactly as k_frame_composite forms it (dl.x = deltas[2 n])
             const float kvd = EDIT == 2 ? 1.0f : pp.view_dep_weight;   // the Stylizer adds view_dep unscaled (palette/renderer.py:181)
 #pragma unroll
             for (int k = 0; k < 3; k++) { rgb_out[k] = rgb[k] + kvd * view_dep[k]; if (!rs.rays_t) rgbs[(size_t)n * 3 + k] = rgb_out[k]; }
             }   // EDIT != 3
         }
         if constexpr (CHECK) { if (overflow_flag && sw_.overflowed()) *overflow_flag = 1; }
-        if (stage_stride) {   // same wave wrote the slab: DS operations of a wave complete in order
-            float* slab = reinterpret_cast<float*>(w + packed_bytes) + (size_t)wave * 32 * stage_stride;
-            float* ex = reinterpret_cast<float*>(w + packed_bytes) + (size_t)WAVES * 32 * stage_stride + (size_t)wave * 96;
+        PAL_T(PT_EPILOGUE);
+        if (stage_stride) {   // (non-wide: the same wave wrote the slab -- DS operations of a wave complete in order)
+            float* slab = reinterpret_cast<float*>(w + packed_bytes) + (size_t)wave * 32 * stage_stride;                          // (not in the wide kernels)
+            float* ex = reinterpret_cast<float*>(w + packed_bytes) + (kWide ? (size_t)0 : (size_t)WAVES * 32 * stage_stride) + (size_t)wave * 96;
             const uint32_t n0 = wt * rpw, nq = (uint32_t)pp.aux_stride / 4;
-            const unsigned long long live = __ballot(valid && h == 0);     // rows of dead / out-of-range slots hold stale slab data: skip them
+            const uint32_t live = (uint32_t)__ballot(valid && h == 0);     // (bits 0 .. 31: the rows) rows of dead / out-of-range slots hold no row: skip them
             if (fuse_composite) {
                 // aux_map[ray] += sum_k weight_k * row_k: the recurrence of raymarching.cu:1114-1185 (weights from the weights_sum of
                 // BEFORE this iteration, stop at a dead row, stop after the sample that sees T < T_thresh), same fmaf order.
-                // Leader lane of a ray: weights of its rows, how many count, and the ray id, left in the slab's spare columns.
-                const bool leader = (uint32_t)lane < rpw && (lane % fstep) == 0 && (n0 + lane) / fstep < (uint32_t)ctl->n_alive;
-                const uint32_t slot = (n0 + lane) / fstep;
+                // Leader lane of a ray: weights of its rows, how many count, and the ray id, left in the wave's spare LDS columns.
+                const uint32_t slot = wt * rays_pt + lane_q;
+                const bool leader = (uint32_t)lane < rpw && lane_k_in_ray == 0 && slot < n_alive_k;
                 int cnt = 0, index = 0;
                 float ws = 0.0f;
                 bool stopped = false;   // the last row that counts saw T < T_thresh
-                if (lane < 32 && (lane % fstep) == 0) {
-                    if (leader && ((live >> lane) & 1ull)) {
+                if (lane < 32 && lane_k_in_ray == 0) {
+                    if (leader && ((live >> lane) & 1u)) {
                         if (early_ray) { index = early_index; ws = early_ws; }
                         else { index = rays_alive[slot]; ws = weights_sum[index]; }
                         for (uint32_t k = 0; k < fstep; k++) {
-                            if (!((live >> (lane + k)) & 1ull)) break;
+                            if (!((live >> (lane + k)) & 1u)) break;
                             const float T = 1.0f - ws;
                             const float wgt = ex[(lane + k) * 3] * T;
                             ws += wgt;
@@ -646,14 +780,68 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
                     ex[lane * 3 + 1] = __int_as_float(index);
                     ex[lane * 3 + 2] = __int_as_float(cnt);
                 }
-                // the ray state is requested here and used behind the aux rows' composite below (the loads land under it)
+                PAL_T(PT_LEADER);
                 float t = 0.0f, d = 0.0f, r = 0.0f, g = 0.0f, b = 0.0f;
-                float dl1_0 = 0.0f;
+                float dl1_0 = dl.y;
+                if constexpr (kWide) {
+                    // The rows are in registers (rowv of the sample's lower-half lane); acc = fmaf(weight_k, value_k, acc) for k = 0, 1, ... -- the chain the
+                    // staged form below runs, in the same order.
+                    t = rs_t; d = rs_d; r = rs_r; g = rs_g; b = rs_b;
+                    const bool lead_acc = lane < 32 && lane_k_in_ray == 0 && cnt > 0;      // (cnt > 0 only on leader lanes with a live first row)
+                    f32x4* __restrict__ arow = reinterpret_cast<f32x4*>(aux_map + (size_t)index * 36);
+                    if (fstep == 1u) {     // (wave-uniform) one sample per ray -- every heavy launch: the row's own lane does the ray's read-modify-write
+                        if (lead_acc) {
+                            f32x4 acc[9];
+#pragma unroll
+                            for (int q = 0; q < 9; q++) acc[q] = arow[q];                          // nine requests in flight, one trip
+                            const float w0 = ex[lane * 3];
+#pragma unroll
+                            for (int c = 0; c < 34; c++) acc[c >> 2][c & 3] = fmaf(w0, rowv[c], acc[c >> 2][c & 3]);
+#pragma unroll
+                            for (int q = 0; q < 9; q++) arow[q] = acc[q];
+                        }
+                        PAL_T(PT_ACC);
+                    } else {
+                        // 2 .. 8 samples per ray (at most 16 rays in the tile): the rays' rows go through a small LDS image (16 x 144 bytes per wave) -- the
+                        // leader lane fetches its ray's row, round k lets the lane that holds row k add it (the wave's DS operations complete in order, so
+                        // round k + 1 reads what round k wrote), the leader writes the row back.  Same fmaf chain, same order.
+                        typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+                        float* img = reinterpret_cast<float*>(w + packed_bytes) + (size_t)WAVES * 96 + (size_t)wave * (16 * 36);
+                        lds_f32x4* srow = reinterpret_cast<lds_f32x4*>(reinterpret_cast<uintptr_t>(img + (lane_q & 15u) * 36u));
+                        const int ray_cnt = __shfl(cnt, (lane & 31) - (int)lane_k_in_ray);      // the count of this lane's ray (held by its leader lane)
+                        if (lead_acc) {
+                            f32x4 acc[9];
+#pragma unroll
+                            for (int q = 0; q < 9; q++) acc[q] = arow[q];
+#pragma unroll
+                            for (int q = 0; q < 9; q++) srow[q] = acc[q];
+                        }
+                        const bool counts = lane < 32 && (int)lane_k_in_ray < ray_cnt;
+                        const float my_w = counts ? ex[lane * 3] : 0.0f;
+#pragma unroll 1
+                        for (uint32_t k = 0; k < fstep; k++) {     // wave-uniform
+                            if (counts && lane_k_in_ray == k) {
+#pragma unroll
+                                for (int q = 0; q < 9; q++) {
+                                    f32x4 a4 = srow[q];
+                                    a4.x = fmaf(my_w, rowv[4 * q], a4.x); a4.y = fmaf(my_w, rowv[4 * q + 1], a4.y);
+                                    if (q < 8) { a4.z = fmaf(my_w, rowv[4 * q + 2], a4.z); a4.w = fmaf(my_w, rowv[4 * q + 3], a4.w); }   // (columns 34, 35 are padding)
+                                    srow[q] = a4;
+                                }
+                            }
+                        }
+                        PAL_T(PT_ACC);
+                        if (lead_acc) {
+#pragma unroll
+                            for (int q = 0; q < 9; q++) arow[q] = srow[q];
+                        }
+                    }
+                } else {
+                // the ray state is requested here and used behind the aux rows' composite below (the loads land under it)
                 if (rs.rays_t && leader) {
                     t = rs.rays_t[index]; d = rs.depth[index]; r = rs.image[index * 3]; g = rs.image[index * 3 + 1]; b = rs.image[index * 3 + 2];
-                    dl1_0 = deltas[(size_t)(n0 + lane) * 2 + 1];
                 }
-                const uint32_t rays_in_tile = rpw / fstep;
+                const uint32_t rays_in_tile = rays_pt;
                 for (uint32_t i = (uint32_t)lane; i < rays_in_tile * nq; i += 64) {
                     const uint32_t ray = i / nq, q = i - ray * nq, base = ray * fstep;
                     const int cnt = __float_as_int(ex[base * 3 + 2]);
@@ -669,15 +857,18 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
                     }
                     *dst = acc;
                 }
+                }
+                PAL_T(PT_AUXMAP);
                 if (rs.rays_t) {
                     // k_frame_composite's second phase (raymarching.cu:1025-1111) for the rays of this wave tile: the weights are the ones just formed
                     // (same alpha, same T recurrence), the rows' colours come from the lanes that hold them
                     for (uint32_t k = 0; k < fstep; k++) {   // wave-uniform
                         const int src = lane + (int)k;
                         const float r_k = __shfl(rgb_out[0], src), g_k = __shfl(rgb_out[1], src), b_k = __shfl(rgb_out[2], src);
+                        const float dl1_k = k == 0 ? dl1_0 : __shfl(dl.y, src);     // deltas[2 (n0 + lane + k) + 1], held by the row's own lane
                         if (leader && (int)k < cnt) {
                             const float wgt = ex[(lane + k) * 3];
-                            t += k == 0 ? dl1_0 : deltas[(size_t)(n0 + lane + k) * 2 + 1];
+                            t += dl1_k;
                             d = fmaf(wgt, t, d);
                             r = fmaf(wgt, r_k, r); g = fmaf(wgt, g_k, g); b = fmaf(wgt, b_k, b);
                         }
@@ -690,7 +881,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
                     }
                     const unsigned long long km = __ballot(keep);
                     if (km != 0ull) {   // consecutive slots: at most two chunks of the alive list
-                        const uint32_t c0 = (n0 / fstep) >> 8;
+                        const uint32_t c0 = (wt * rays_pt) >> 8;
                         const unsigned long long k0 = __ballot(keep && (slot >> 8) == c0);
                         if (lane == 0) {
                             if (k0) atomicAdd(&rs.counts_cur[c0], __popcll(k0));
@@ -698,15 +889,31 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
                         }
                     }
                 }
+            } else if constexpr (kWide) {     // rows straight from the registers to the caller's aux buffer (stand-alone op; frames whose composite is a launch of its own)
+                if (valid && h == 0) {
+                    f32x4* __restrict__ dst = reinterpret_cast<f32x4*>(aux + (size_t)n * 36);
+#pragma unroll
+                    for (int q = 0; q < 9; q++) dst[q] = f32x4{rowv[4 * q], rowv[4 * q + 1], rowv[4 * q + 2], rowv[4 * q + 3]};
+                }
             } else {
                 for (uint32_t i = (uint32_t)lane; i < 32 * nq; i += 64) {
                     const uint32_t row = i / nq, q = i - row * nq;
-                    if ((live >> row) & 1ull)
+                    if ((live >> row) & 1u)
                         *reinterpret_cast<float4*>(aux + (size_t)(n0 + row) * pp.aux_stride + q * 4) = *reinterpret_cast<const float4*>(slab + row * stage_stride + q * 4);
                 }
             }
         }
+#endif
+        PAL_T(PT_RAYSTATE);
     }
+#ifdef PNR_PAL_TIMING
+    if ((threadIdx.x & 63) == 0) {
+        for (int i = 0; i < PT_N; i++) atomicAdd(&g_pal_timing[i], tacc[i]);
+        atomicAdd(&g_pal_timing[PT_N], ntiles);
+        atomicAdd(&g_pal_timing[PT_N + 1], 1ull);
+        atomicAdd(&g_pal_timing[PT_N + 2], wall_clock64() - tstart);
+    }
+#endif
 }
 
 }  // namespace pnr
@@ -745,6 +952,19 @@ int pnr_internal_edit_upload(const pnr_palette_edit* edit, void* dst, hipStream_
 }
 
 extern int g_opt_palette_waves12;
+
+#ifdef PNR_PAL_TIMING
+// diagnostic builds only (not in include/pnr.h): out != NULL: copy the PT_N + 3 accumulators out; reset != 0: zero them
+extern "C" int pnr_debug_pal_timing(unsigned long long* out, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return PNR_ERR_LAUNCH;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(pnr::g_pal_timing), sizeof(unsigned long long) * (pnr::PT_N + 3)) != hipSuccess) return PNR_ERR_LAUNCH;
+    if (reset) {
+        unsigned long long z[pnr::PT_N + 3] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pnr::g_pal_timing), z, sizeof(z)) != hipSuccess) return PNR_ERR_LAUNCH;
+    }
+    return PNR_OK;
+}
+#endif
 
 extern "C" {
 
@@ -818,7 +1038,7 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
     PaletteParams pp;
     pp.density_scale = a->density_scale; pp.offsets_weight = a->offsets_weight; pp.view_dep_weight = a->view_dep_weight;
     pp.nb = (int)a->num_basis; pp.clip_dim = (int)a->clip_dim; pp.pred_clip = a->pred_clip ? 1 : 0; pp.aux_stride = (int)a->aux_stride;
-    for (int k = 0; k < 3; k++) pp.enc_scale[k] = a->enc_scale[k] > 0.0f ? a->enc_scale[k] : 1.0f;
+    for (int k = 0; k < 3; k++) { pp.enc_scale[k] = a->enc_scale[k] > 0.0f ? a->enc_scale[k] : 1.0f; pp.enc_scale_inv[k] = 1.0f / pp.enc_scale[k]; }
     const uint32_t packed_bytes = (uint32_t)pnr_palette_field_packed_bytes(a->num_basis, a->clip_dim, pp.pred_clip);
     const uint32_t rows_ub = a->B;
     // one persistent workgroup per CU (100-126 KiB of LDS): 8 waves, or 12 for the specialised 4-basis kernel when its staging fits (three waves per SIMD
@@ -827,16 +1047,18 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
     const bool fp16 = a->precision != PNR_FIELD_FP32;
     const bool nb4 = fp16 && a->num_basis == 4 && !a->overflow_flag;
     const bool x2 = a->precision == PNR_FIELD_F16X2 && nb4 && edit_mode == 0;
-    const bool stages_pre = a->aux_stride == pnr_palette_aux_channels(a->num_basis, a->clip_dim) && pnr_palette_field_stages_aux(a->num_basis, a->clip_dim, pp.pred_clip);
-    const bool wide = nb4 && stages_pre && g_opt_palette_waves12 && packed_bytes + 12u * 32u * (a->aux_stride + 3u) * 4u <= 160u * 1024u;   // (the 12-wave kernels write their aux rows to LDS unconditionally)
-    const uint32_t waves = wide ? 12u : 8u;
+    // "wide": the specialised kernels for the shipped shape -- 4 bases, no clip head, rows of 36 floats -- whose tail stages nothing in LDS (see the top of
+    // the file): PNR_PAL_WIDE_WAVES waves per workgroup (16: four per SIMD at <= 128 registers) next to 100 KiB of weights + 384 bytes per wave
+    const bool wide = nb4 && g_opt_palette_waves12 && !pp.pred_clip && a->aux_stride == 36u && a->aux_stride == pnr_palette_aux_channels(a->num_basis, a->clip_dim);
+    const uint32_t waves = wide ? (uint32_t)PNR_PAL_WIDE_WAVES : 8u;
     const uint32_t ntiles = cdiv(rows_ub ? rows_ub : 1, 28);   // wave tiles (a wave tile holds 28 ... 32 rows when it holds whole rays): dealt wave-major, see the kernel
     const uint32_t grid = ntiles < 256u ? ntiles : 256u;
     constexpr uint32_t kLdsLimit = 160 * 1024;
-    // staging slab for coalesced aux rows: 8 waves x 32 rows x (aux_stride + 4) floats, when it fits next to the weights
-    const bool stages = a->aux_stride == pnr_palette_aux_channels(a->num_basis, a->clip_dim) && pnr_palette_field_stages_aux(a->num_basis, a->clip_dim, pp.pred_clip);
+    // staging slab for coalesced aux rows (8-wave kernels): 8 waves x 32 rows x (aux_stride + 3) floats, when it fits next to the weights.  The wide kernels
+    // keep their rows in registers: `stage_stride` only tells them that the fused tail is available, their LDS holds 96 + 576 floats per wave behind the weights (per-row weights; the rows of up to 16 rays with 2 .. 8 samples each)
+    const bool stages = wide || (a->aux_stride == pnr_palette_aux_channels(a->num_basis, a->clip_dim) && pnr_palette_field_stages_aux(a->num_basis, a->clip_dim, pp.pred_clip));
     const uint32_t stage_stride = stages ? a->aux_stride : 0;
-    const uint32_t lds = packed_bytes + (stages ? waves * 32 * (stage_stride + 3) * 4 : 0);
+    const uint32_t lds = packed_bytes + (wide ? waves * (96 + 16 * 36) * 4 : (stages ? waves * 32 * (stage_stride + 3) * 4 : 0));
     const bool fuse = a->ctl && a->rays_alive && a->weights_sum && a->aux_map;
     RayState rs = {};
     if (fuse && stages && a->rays_t && a->depth && a->image && a->rays_alive_rw && a->counts_cur) {
@@ -882,13 +1104,13 @@ int pnr_palette_field_forward(const pnr_palette_field_args* a, pnr_stream_t stre
     } else if (fp16) {
         static bool attr_nb4[8][kMaxDevices] = {};
         // the shipped default of 4 bases (main_palette.py:76): specialised epilogue, 12-wave workgroups when the staging fits
-        if (x2 && wide) PNR_LAUNCH_PAL_NB(2, 0, false, 4, 12, attr_nb4[6]);
+        if (x2 && wide) PNR_LAUNCH_PAL_NB(2, 0, false, 4, PNR_PAL_WIDE_WAVES, attr_nb4[6]);
         else if (x2) PNR_LAUNCH_PAL_NB(2, 0, false, 4, 8, attr_nb4[7]);
-        else if (edit_mode == 3 && nb4 && wide) { static bool attr_heads[kMaxDevices] = {}; PNR_LAUNCH_PAL_NB(1, 3, false, 4, 12, attr_heads); }
+        else if (edit_mode == 3 && nb4 && wide) { static bool attr_heads[kMaxDevices] = {}; PNR_LAUNCH_PAL_NB(1, 3, false, 4, PNR_PAL_WIDE_WAVES, attr_heads); }
         else if (edit_mode == 3) PNR_LAUNCH_PAL(1, 3, false);
-        else if (nb4 && wide && edit_mode == 0) PNR_LAUNCH_PAL_NB(1, 0, false, 4, 12, attr_nb4[0]);
-        else if (nb4 && wide && edit_mode == 1) PNR_LAUNCH_PAL_NB(1, 1, false, 4, 12, attr_nb4[1]);
-        else if (nb4 && wide) PNR_LAUNCH_PAL_NB(1, 2, false, 4, 12, attr_nb4[2]);
+        else if (nb4 && wide && edit_mode == 0) PNR_LAUNCH_PAL_NB(1, 0, false, 4, PNR_PAL_WIDE_WAVES, attr_nb4[0]);
+        else if (nb4 && wide && edit_mode == 1) PNR_LAUNCH_PAL_NB(1, 1, false, 4, PNR_PAL_WIDE_WAVES, attr_nb4[1]);
+        else if (nb4 && wide) PNR_LAUNCH_PAL_NB(1, 2, false, 4, PNR_PAL_WIDE_WAVES, attr_nb4[2]);
         else if (nb4 && edit_mode == 0) PNR_LAUNCH_PAL_NB(1, 0, false, 4, 8, attr_nb4[3]);
         else if (nb4 && edit_mode == 1) PNR_LAUNCH_PAL_NB(1, 1, false, 4, 8, attr_nb4[4]);
         else if (nb4) PNR_LAUNCH_PAL_NB(1, 2, false, 4, 8, attr_nb4[5]);
