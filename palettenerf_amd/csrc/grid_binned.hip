@@ -89,6 +89,17 @@ __device__ __forceinline__ Corners corners_of(const float* __restrict__ inputs, 
     return c;
 }
 
+// A sample whose gradient on this level is exactly zero writes no record (round 5).  Training batches are full of them: composite_rays_train stops a ray at
+// the sample where its transmittance falls below T_thresh (raymarching.cu:660-672), every sample behind it gets an exact zero from the composite's
+// backward and therefore from the MLP's -- on a trained scene most of a ray.  Adding zeros changes no sum; every sweep applies the same test, so the counts,
+// the slices and the records agree.  (A dead sample also ends a merged run: two records where there was one, still the same sums.)
+__device__ __forceinline__ float2 drop_dead(Corners& c, const float* __restrict__ grad, uint32_t level, uint32_t b, uint32_t B) {
+    float2 g = make_float2(0.0f, 0.0f);
+    if (c.active) g = *reinterpret_cast<const float2*>(grad + ((size_t)level * B + b) * 2);
+    if (g.x == 0.0f && g.y == 0.0f) { c.active = false; c.cell = 0xFFFFFFFFu; }
+    return g;
+}
+
 // Runs of consecutive lanes that hit the same table row (coarse levels: samples arrive ordered along rays, ~25 per cell on
 // level 0) are merged into ONE record carried by the run's last lane -- same ballot + segmented-scan scheme as k_grid_bwd<COMBINE>.
 struct Run { bool tail; int start; };
@@ -154,7 +165,7 @@ __device__ __forceinline__ uint32_t reserve_in_bucket(uint32_t* hist, uint32_t b
 
 // sweep 1: bucket counts
 template <int COMBINE>   // 0: a record per (sample, corner); 1: runs of equal rows merged per corner (coarse levels); 2: runs of samples in one cell merged (mid levels)
-__global__ void __launch_bounds__(kCountThreads) k_bin_count(const float* __restrict__ inputs, const int32_t* __restrict__ offsets, uint32_t B,
+__global__ void __launch_bounds__(kCountThreads) k_bin_count(const float* __restrict__ grad, const float* __restrict__ inputs, const int32_t* __restrict__ offsets, uint32_t B,
                                                            LevelParams lp, uint32_t gridtype, bool align_corners, uint32_t* __restrict__ counts,
                                                            uint32_t level0) {
     extern __shared__ uint32_t hist[];
@@ -167,7 +178,8 @@ __global__ void __launch_bounds__(kCountThreads) k_bin_count(const float* __rest
 #pragma unroll
     for (uint32_t u = 0; u < kCountSamples; u++) {
         const uint32_t b = (blockIdx.x * kCountSamples + u) * kCountThreads + threadIdx.x;
-        const Corners c = corners_of(inputs, b, B, lp.scale[level], lp.resolution[level], hashmap_size, gridtype, align_corners);
+        Corners c = corners_of(inputs, b, B, lp.scale[level], lp.resolution[level], hashmap_size, gridtype, align_corners);
+        drop_dead(c, grad, level, b, B);
         [[maybe_unused]] CellRun cr = {true, 0u};
         if constexpr (COMBINE == 2) cr = cell_run_of(c.cell, lane);
 #pragma unroll
@@ -236,7 +248,7 @@ __global__ void __launch_bounds__(1024) k_bin_plan(const int32_t* __restrict__ o
         if (threadIdx.x == 0) { carry[0] += tot0; carry[1] += tot1; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { rec_off[total_buckets] = carry[0]; *n_jobs = carry[1]; }
+    if (threadIdx.x == 0) { rec_off[total_buckets] = carry[0]; n_jobs[0] = carry[1]; n_jobs[1] = 0; /* the gather's job cursor */ }
 }
 
 // sweep 2: write the records into their buckets' segments
@@ -262,8 +274,7 @@ __global__ void __launch_bounds__(kBinThreads) k_bin_scatter(const float* __rest
     for (uint32_t u = 0; u < kBinSamples; u++) {
         const uint32_t b = (blockIdx.x * kBinSamples + u) * kBinThreads + threadIdx.x;
         c[u] = corners_of(inputs, b, B, lp.scale[level], lp.resolution[level], hashmap_size, gridtype, align_corners);
-        float2 g = make_float2(0.0f, 0.0f);
-        if (c[u].active) g = *reinterpret_cast<const float2*>(grad + ((size_t)level * B + b) * 2);
+        const float2 g = drop_dead(c[u], grad, level, b, B);
         emit_bits[u] = 0;
         [[maybe_unused]] CellRun cr = {true, 0u};
         if constexpr (COMBINE == 2) cr = cell_run_of(c[u].cell, lane);
@@ -305,14 +316,107 @@ __global__ void __launch_bounds__(kBinThreads) k_bin_scatter(const float* __rest
     }
 }
 
+// sweep 2, staged (round 5): the same records, written COALESCED.  Above, a lane writes its eight records where their buckets' slices are: the 64 lanes of a
+// store instruction go to ~64 different cache lines, 8 (+ 2) bytes each -- the sweep ran at 1.4-1.9 TB/s of record bytes, bound by requests, not by bytes
+// (profiles/r04_pmc_train.txt: 171 M wait cycles against 41 M active).  Here the workgroup's 8192 records are first ordered by bucket in LDS (96 KiB: the ranks
+// inside a bucket are the ones reserve_in_bucket hands out anyway, the buckets' LDS offsets an exclusive scan of the workgroup's histogram) and then copied out
+// by position: consecutive lanes write consecutive records of one bucket's slice -- runs of ~128 records, 16 full lines per store instruction.
+constexpr uint32_t kStgThreads = 1024;                   // one sample per thread
+constexpr uint32_t kStgRecords = kStgThreads * 8;
+template <int COMBINE>
+__global__ void __launch_bounds__(kStgThreads) k_bin_scatter_staged(const float* __restrict__ grad, const float* __restrict__ inputs, const int32_t* __restrict__ offsets,
+                                                                    uint32_t B, LevelParams lp, uint32_t gridtype, bool align_corners, uint32_t* __restrict__ cursor,
+                                                                    uint16_t* __restrict__ rec_row, float2* __restrict__ rec_val, uint32_t level0, uint32_t nb_max) {
+    extern __shared__ uint32_t lds[];   // [nb_max] counts | [nb_max] slice bases (global) | [nb_max + 1] LDS offsets | staged values float2[8192] | rows u16[8192] | buckets u16[8192]
+    const uint32_t level = level0 + blockIdx.y;
+    const int lane = threadIdx.x & (PNR_WAVE - 1);
+    const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+    const uint32_t nb = (hashmap_size + kBinRows - 1) / kBinRows;
+    uint32_t* hist = lds;
+    uint32_t* slice = lds + nb_max;
+    uint32_t* lofs = lds + 2 * nb_max;
+    float2* st_val = reinterpret_cast<float2*>(lds + ((3 * nb_max + 1 + 3) & ~3u));
+    uint16_t* st_row = reinterpret_cast<uint16_t*>(st_val + kStgRecords);
+    uint16_t* st_bkt = st_row + kStgRecords;
+    for (uint32_t k = threadIdx.x; k < nb; k += kStgThreads) hist[k] = 0;
+    __syncthreads();
+    const uint32_t b = blockIdx.x * kStgThreads + threadIdx.x;
+    Corners c = corners_of(inputs, b, B, lp.scale[level], lp.resolution[level], hashmap_size, gridtype, align_corners);
+    float wy[8];
+    uint32_t rank[8], emit_bits = 0;
+    {
+        const float2 g = drop_dead(c, grad, level, b, B);
+        [[maybe_unused]] CellRun cr = {true, 0u};
+        if constexpr (COMBINE == 2) cr = cell_run_of(c.cell, lane);
+#pragma unroll
+        for (uint32_t idx = 0; idx < 8; idx++) {
+            bool emit = c.active;
+            float vx = c.w[idx] * g.x, vy = c.w[idx] * g.y;
+            if constexpr (COMBINE == 2) {
+                vx = cell_run_sum(c.active ? vx : 0.0f, cr.k);
+                vy = cell_run_sum(c.active ? vy : 0.0f, cr.k);
+                emit = emit && cr.tail;
+            }
+            if constexpr (COMBINE == 1) {
+                const Run r = run_of(c.active ? c.row[idx] : 0xFFFFFFFFu, lane);
+                vx = run_sum(c.active ? vx : 0.0f, r, lane);
+                vy = run_sum(c.active ? vy : 0.0f, r, lane);
+                emit = emit && r.tail;
+            }
+            c.w[idx] = vx;
+            wy[idx] = vy;
+            rank[idx] = reserve_in_bucket(hist, c.row[idx] / kBinRows, emit, lane, nb <= 8);
+            if (emit) emit_bits |= 1u << idx;
+        }
+    }
+    __syncthreads();
+    const uint32_t base = level_bucket_base(offsets, level);
+    for (uint32_t k = threadIdx.x; k < nb; k += kStgThreads) slice[k] = hist[k] ? atomicAdd(&cursor[base + k], hist[k]) : 0u;
+    if (threadIdx.x < PNR_WAVE) {     // exclusive scan of the workgroup's histogram: where a bucket's records start in the staging arrays
+        uint32_t carry = 0;
+        for (uint32_t k0 = 0; k0 < nb; k0 += PNR_WAVE) {
+            const uint32_t k = k0 + (uint32_t)lane, v = k < nb ? hist[k] : 0u;
+            const uint32_t inc = (uint32_t)wave_inclusive_scan((int)v);
+            if (k < nb) lofs[k] = carry + inc - v;
+            carry += (uint32_t)__shfl((int)inc, PNR_WAVE - 1, PNR_WAVE);
+        }
+        if (lane == 0) lofs[nb] = carry;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t idx = 0; idx < 8; idx++) {
+        if (!((emit_bits >> idx) & 1u)) continue;
+        const uint32_t bucket = c.row[idx] / kBinRows, p = lofs[bucket] + rank[idx];
+        st_val[p] = make_float2(c.w[idx], wy[idx]);
+        st_row[p] = (uint16_t)(c.row[idx] % kBinRows);
+        st_bkt[p] = (uint16_t)bucket;
+    }
+    __syncthreads();
+    const uint32_t total = lofs[nb];
+    for (uint32_t p = threadIdx.x; p < total; p += kStgThreads) {
+        const uint32_t bucket = st_bkt[p], gp = slice[bucket] + (p - lofs[bucket]);
+        rec_row[gp] = st_row[p];
+        rec_val[gp] = st_val[p];
+    }
+}
+
 // sweep 3: accumulate one job's records in LDS, add the bucket image to the table
-__global__ void __launch_bounds__(1024) k_bin_gather(const BinJob* __restrict__ jobs, const uint32_t* __restrict__ n_jobs,
+__global__ void __launch_bounds__(1024) k_bin_gather(const BinJob* __restrict__ jobs, uint32_t* __restrict__ n_jobs /* [0] jobs, [1] cursor */,
                                                      const uint16_t* __restrict__ rec_row, const float2* __restrict__ rec_val,
                                                      float* __restrict__ grad_grid) {
     // fp64 accumulators: on gfx950 ds_add_f64 runs at 1.3 T lane-atomics/s where ds_add_f32 manages 0.2 T/s (profiles/micro/lds_atomics.hip),
     // and the bucket sums come out order-independent to fp32 precision as a bonus; 128 KiB of the CU's 160 KiB LDS
     extern __shared__ double acc[];   // [kBinRows][2]
-    for (uint32_t job = blockIdx.x; job < *n_jobs; job += gridDim.x) {
+    // one resident workgroup per CU, jobs handed out through a cursor (round 5: dealt by block index, a quarter of the CUs sat through a fourth round of
+    // jobs while the others had finished three)
+    __shared__ uint32_t next_job;
+    const uint32_t total_jobs = n_jobs[0];
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) next_job = atomicAdd(&n_jobs[1], 1u);
+        __syncthreads();
+        const uint32_t job = next_job;
+        if (job >= total_jobs) break;
         const BinJob jb = jobs[job];
         for (uint32_t i = threadIdx.x; i < jb.nrows * 2; i += 1024) acc[i] = 0.0;
         __syncthreads();
@@ -371,9 +475,9 @@ __global__ void __launch_bounds__(kImgThreads) k_coarse_image(const float* __res
     for (uint32_t j = 0; j < per_thread; j++) {
         const uint32_t b = lane_first + wave * per_thread + j;
         if (b >= lane_last) break;
-        const Corners c = corners_of(inputs, b, B, lp.scale[level], lp.resolution[level], hashmap_size, gridtype, align_corners);
+        Corners c = corners_of(inputs, b, B, lp.scale[level], lp.resolution[level], hashmap_size, gridtype, align_corners);
+        const float2 g = drop_dead(c, grad, level, b, B);
         if (!c.active) continue;
-        const float2 g = *reinterpret_cast<const float2*>(grad + ((size_t)level * B + b) * 2);
 #pragma unroll
         for (uint32_t idx = 0; idx < 8; idx++) {
             const uint32_t r = c.row[idx] - row_lo;
@@ -415,7 +519,7 @@ static BinLayout bin_layout(uint32_t B, uint32_t L, uint64_t total_rows) {
     l.counts = o; o = al(o + (uint64_t)l.bucket_bound * 4);
     l.rec_off = o; o = al(o + ((uint64_t)l.bucket_bound + 1) * 4);
     l.cursor = o; o = al(o + (uint64_t)l.bucket_bound * 4);
-    l.n_jobs = o; o = al(o + 4);
+    l.n_jobs = o; o = al(o + 8);
     l.jobs = o; o = al(o + (uint64_t)l.job_bound * sizeof(BinJob));
     l.rec_row = o; o = al(o + n_rec * 2);
     l.rec_val = o; o = al(o + n_rec * 8);
@@ -483,19 +587,31 @@ int pnr_grid_encode_backward_binned(const float* grad, const float* inputs, cons
     const uint32_t gx = cdiv(B, kBinThreads * kBinSamples), gxc = cdiv(B, kCountThreads * kCountSamples);
     const uint32_t hist_bytes = lay.bucket_bound * 4;
     const bool ac = align_corners != 0;
-    if (nc > ni) hipLaunchKernelGGL(k_bin_count<1>, dim3(gxc, nc - ni), dim3(kCountThreads), hist_bytes, s, inputs, offsets, B, lp, gridtype, ac, counts, ni);
-    if (nm > nc) hipLaunchKernelGGL(k_bin_count<2>, dim3(gxc, nm - nc), dim3(kCountThreads), hist_bytes, s, inputs, offsets, B, lp, gridtype, ac, counts, nc);
-    if (nm < L) hipLaunchKernelGGL(k_bin_count<0>, dim3(gxc, L - nm), dim3(kCountThreads), hist_bytes, s, inputs, offsets, B, lp, gridtype, ac, counts, nm);
+    if (nc > ni) hipLaunchKernelGGL(k_bin_count<1>, dim3(gxc, nc - ni), dim3(kCountThreads), hist_bytes, s, grad, inputs, offsets, B, lp, gridtype, ac, counts, ni);
+    if (nm > nc) hipLaunchKernelGGL(k_bin_count<2>, dim3(gxc, nm - nc), dim3(kCountThreads), hist_bytes, s, grad, inputs, offsets, B, lp, gridtype, ac, counts, nc);
+    if (nm < L) hipLaunchKernelGGL(k_bin_count<0>, dim3(gxc, L - nm), dim3(kCountThreads), hist_bytes, s, grad, inputs, offsets, B, lp, gridtype, ac, counts, nm);
     hipLaunchKernelGGL(k_bin_plan, dim3(1), dim3(1024), 0, s, offsets, L, counts, rec_off, cursor, jobs, n_jobs);
+    const uint32_t nb_max = lay.bucket_bound;      // (an upper bound of any level's bucket count: the host does not know the levels' sizes, the offsets live on the device)
+    const uint32_t stg_lds = ((3 * nb_max + 1 + 3) & ~3u) * 4 + kStgRecords * (8 + 2 + 2);
+    if (g_opt_scatter_staged && stg_lds <= 160 * 1024) {
+        static bool stg_attr[3][kMaxDevices] = {};
+        if (!ensure_dynamic_lds(k_bin_scatter_staged<0>, stg_lds, stg_attr[0]) || !ensure_dynamic_lds(k_bin_scatter_staged<1>, stg_lds, stg_attr[1]) ||
+            !ensure_dynamic_lds(k_bin_scatter_staged<2>, stg_lds, stg_attr[2])) return PNR_ERR_LAUNCH;
+        const uint32_t gs = cdiv(B, kStgThreads);
+        if (nc > ni) hipLaunchKernelGGL(k_bin_scatter_staged<1>, dim3(gs, nc - ni), dim3(kStgThreads), stg_lds, s, grad, inputs, offsets, B, lp, gridtype, ac, cursor, rec_row, rec_val, ni, nb_max);
+        if (nm > nc) hipLaunchKernelGGL(k_bin_scatter_staged<2>, dim3(gs, nm - nc), dim3(kStgThreads), stg_lds, s, grad, inputs, offsets, B, lp, gridtype, ac, cursor, rec_row, rec_val, nc, nb_max);
+        if (nm < L) hipLaunchKernelGGL(k_bin_scatter_staged<0>, dim3(gs, L - nm), dim3(kStgThreads), stg_lds, s, grad, inputs, offsets, B, lp, gridtype, ac, cursor, rec_row, rec_val, nm, nb_max);
+    } else {
     if (nc > ni) hipLaunchKernelGGL(k_bin_scatter<1>, dim3(gx, nc - ni), dim3(kBinThreads), 2 * hist_bytes, s, grad, inputs, offsets, B, lp, gridtype, ac, cursor,
                                     rec_row, rec_val, ni);
     if (nm > nc) hipLaunchKernelGGL(k_bin_scatter<2>, dim3(gx, nm - nc), dim3(kBinThreads), 2 * hist_bytes, s, grad, inputs, offsets, B, lp, gridtype, ac, cursor,
                                     rec_row, rec_val, nc);
     if (nm < L) hipLaunchKernelGGL(k_bin_scatter<0>, dim3(gx, L - nm), dim3(kBinThreads), 2 * hist_bytes, s, grad, inputs, offsets, B, lp, gridtype, ac,
                                    cursor, rec_row, rec_val, nm);
+    }
     static bool attr_set[kMaxDevices] = {};
     if (!ensure_dynamic_lds(k_bin_gather, kBinRows * 2 * 8, attr_set)) return PNR_ERR_LAUNCH;
-    const uint32_t gather_blocks = lay.job_bound < 1024u ? lay.job_bound : 1024u;
+    const uint32_t gather_blocks = lay.job_bound < 256u ? lay.job_bound : 256u;     // (128 KiB of LDS each: one per CU)
     hipLaunchKernelGGL(k_bin_gather, dim3(gather_blocks), dim3(1024), kBinRows * 2 * 8, s, jobs, n_jobs, rec_row, rec_val, grad_embeddings);
     return check_launch();
 }

@@ -17,7 +17,7 @@
 //
 // Matrix path: written once over field_core.hpp's block interface, instantiated for split-fp16 (3 MFMAs per K = 16 block) and exact
 // fp32 (8 v_mfma_f32_32x32x2_f32 per block); activations are chained through the register file exactly as in the NeRF kernel.
-// 50 blocks of 2 KiB in LDS for up to 5 palette bases without a clip head; +1 block for 6..10 bases (offsets_radiance then has up to
+// 42 blocks of 2 KiB in LDS (+ the two vector heads, 1.5 KiB) for up to 5 palette bases without a clip head; +1 block for 6..10 bases (offsets_radiance then has up to
 // 31 outputs: a second tile), +8 with the clip head (+4 more for clip_dim > 16).  Layers whose outputs feed scalar math (rgb heads,
 // offsets/radiance, omega, clip) place their rows in the lower half-wave so no cross-lane traffic is needed.
 #include "pnr_common.hpp"
@@ -34,9 +34,16 @@ enum { COL_LINEAR = 0, COL_FRAG = 1, COL_SH_GEO = 2, COL_GEO = 3, COL_ENC_DIFF =
 enum { ROW_ID = 0, ROW_HALF0 = 1, ROW_HALF0_B = 2 };   // HALF0_B: output rows 16..31 in the lower half-wave's 16 slots (a second tile)
 // first block of every layer
 enum {
-    PB_S0 = 0, PB_S1 = 4, PB_D0 = 8, PB_D1 = 10, PB_D2 = 18, PB_C0 = 22, PB_C1 = 26, PB_C2 = 34, PB_B0 = 38, PB_B1 = 44, PB_OR = 48, PB_OM = 49,
-    PB_OR2 = 50, PB_CL0 = 51, PB_CL1 = 55, PB_CL1B = 59, PB_END = 63
+    PB_S0 = 0, PB_S1 = 4, PB_D0 = 8, PB_D1 = 10, PB_C0 = 18, PB_C1 = 22, PB_B0 = 30, PB_B1 = 36, PB_OR = 40, PB_OM = 41,
+    PB_OR2 = 42, PB_CL0 = 43, PB_CL1 = 47, PB_CL1B = 51, PB_END = 55
 };
+// The two 64 -> 3 colour heads (diff_net[2], color_net[2]) are NOT matrix blocks (round 5): as a 32-row MFMA tile 29 of their 32 output rows are padding
+// -- 12 matrix instructions (384 matrix-pipe cycles) and four activation splits for three numbers.  They are fp32 dot products on the vector unit instead:
+// a lane holds 32 of its sample's 64 hidden features (its two accumulator tiles), multiplies them by its half of the three weight rows with v_pk_fma_f32
+// (48 instructions) and v_permlane32_swap adds the two half-waves' partial sums.  Exact fp32 products and sums (the split-fp16 form dropped a 2^-22 term),
+// one fixed order in every instantiation.  Their weights follow the blocks: per head [half-wave 2][output 3][tile 2][register 16] floats.
+constexpr uint32_t kVecHeadBytes = 2 * 3 * 2 * 16 * 4;     // 768
+constexpr uint32_t kVecBytes = 2 * kVecHeadBytes;          // diff_net[2], color_net[2]
 constexpr int kPalMaxBlocks = PB_END;
 // blocks a model shape needs (= what is packed and staged in LDS)
 __host__ __device__ constexpr int pal_blocks(int nb, int clip_dim, int pred_clip) {
@@ -61,6 +68,14 @@ __device__ __forceinline__ int pack_col(int kind, int kb, int h, int j) {
 }
 
 // PREC 1: block = [hi: 64 lanes x 8 halfs][lo: same]; PREC 0: block = [8 steps][64 lanes] fp32 (field_core.hpp: mma_blk)
+// w [3][64] row-major (nn.Linear) -> [half-wave h][output o][tile t][register r] = w[o][32 t + frag_row(r, h)]: what lane-half h multiplies its registers by
+__global__ void k_pack_vec_head(const float* __restrict__ w, float* __restrict__ out) {
+    const int i = threadIdx.x;     // 192 threads
+    if (i >= 192) return;
+    const int r = i & 15, t = (i >> 4) & 1, o = (i >> 5) % 3, h = i / 96;
+    out[i] = w[o * 64 + 32 * t + frag_row(r, h)];
+}
+
 template <int PREC>
 __global__ void __launch_bounds__(256) k_pack_blocks(PackTable t, unsigned char* __restrict__ packed) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -151,6 +166,30 @@ __device__ __forceinline__ void dense64x2(f32x16& o0, f32x16& o1, const unsigned
         o0 = mma_blk<PREC>(o0, w + (q0 + kb) * kF16BlockBytes, b, lane);
         o1 = mma_blk<PREC>(o1, w + (q0 + 4 + kb) * kF16BlockBytes, b, lane);
         __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// One 64 -> 3 head on the vector unit (see PB_* above): `vec` = this lane-half's 96 weights in LDS ([output][tile][register]), u0 / u1 = the lane's two
+// (ReLU'd) accumulator tiles.  out[o] = (sum over the lower half-wave's 32 features) + (sum over the upper half-wave's), the same bits in both lanes of a sample.
+__device__ __forceinline__ void head3_valu(const unsigned char* __restrict__ vec, const f32x16& u0, const f32x16& u1, float out[3]) {
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+    const lds_f32x4* wv = reinterpret_cast<const lds_f32x4*>(reinterpret_cast<uintptr_t>(vec));
+#pragma unroll
+    for (int o = 0; o < 3; o++) {
+        f32x2v acc = {0.0f, 0.0f};
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) {
+                const f32x4 ww = wv[(o * 2 + t) * 4 + r4];
+                const f32x16& u = t ? u1 : u0;
+                acc = __builtin_elementwise_fma(f32x2v{ww.x, ww.y}, f32x2v{u[4 * r4], u[4 * r4 + 1]}, acc);
+                acc = __builtin_elementwise_fma(f32x2v{ww.z, ww.w}, f32x2v{u[4 * r4 + 2], u[4 * r4 + 3]}, acc);
+            }
+        const float p = acc.x + acc.y;
+        const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(p), false, false);   // ([0]: the lower half-wave's p in every lane, [1]: the upper's)
+        out[o] = __uint_as_float(sw2[0]) + __uint_as_float(sw2[1]);
     }
 }
 
@@ -469,7 +508,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
         f32x16 u0, u1;
         dense64x2<PREC, CHECK>(u0, u1, w, PB_D1, t0, t1, lane, sw);
         u0 = relu16(u0); u1 = relu16(u1);
-        const f32x16 dif = dense64<PREC, CHECK>(zero16(), w, PB_D2, u0, u1, lane, sw);  // rows 0..2
+        // (the heads' weights sit behind the blocks; the address goes through the per-tile lane number so that the 24 reads are not hoisted out of the tile loop)
+        const unsigned char* vec_heads = w + (packed_bytes - kTablesBytes - kVecBytes) + (uint32_t)h * (kVecHeadBytes / 2);
+        float dif[3];
+        head3_valu(vec_heads, u0, u1, dif);
         const float diffuse[3] = {sigmoidf(dif[0]), sigmoidf(dif[1]), sigmoidf(dif[2])};
 
         PAL_T(PT_DIFF);
@@ -489,7 +531,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
         t0 = relu16(t0); t1 = relu16(t1);
         dense64x2<PREC, CHECK>(u0, u1, w, PB_C1, t0, t1, lane, sw);
         u0 = relu16(u0); u1 = relu16(u1);
-        const f32x16 vdt = dense64<PREC, CHECK>(zero16(), w, PB_C2, u0, u1, lane, sw);
+        float vdt[3];
+        head3_valu(vec_heads + kVecHeadBytes, u0, u1, vdt);
         const float view_dep[3] = {sigmoidf(vdt[0]), sigmoidf(vdt[1]), sigmoidf(vdt[2])};
 
         PAL_T(PT_COLOR);
@@ -592,6 +635,45 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
         const EditParams* __restrict__ const ep = kc->ep;
         int32_t* __restrict__ const overflow_flag = kc->overflow_flag;
         const RayState rs = {kc->rs.rays_t, kc->rs.weights_sum, kc->rs.depth, kc->rs.image, kc->rs.rays_alive, kc->rs.counts_cur};
+        // Leader lane of a ray (the compositing step's weights): the recurrence of raymarching.cu:1114-1185 over the ray's rows -- weights from the
+        // weights_sum of BEFORE this iteration, stop at a dead row, stop after the sample that sees T < T_thresh -- leaving per row the weight and per
+        // leader the ray id and the number of rows that count in the wave's spare LDS columns (ex).  It needs the rows' alphas only, so the wide kernels run
+        // it IN FRONT of the scalar epilogue: the 34 values of a row then never live across this piece of control flow.
+        float* const ex = reinterpret_cast<float*>(w + packed_bytes) + (kWide ? (size_t)0 : (size_t)WAVES * 32 * stage_stride) + (size_t)wave * 96;
+        const uint32_t live = (uint32_t)__ballot(valid && h == 0);     // (bits 0 .. 31: the rows) rows of dead / out-of-range slots hold no row
+        const uint32_t slot = wt * rays_pt + lane_q;
+        const bool leader = (uint32_t)lane < rpw && lane_k_in_ray == 0 && slot < n_alive_k;
+        int cnt = 0, index = 0;
+        float ws = 0.0f;
+        bool stopped = false;   // the last row that counts saw T < T_thresh
+        auto leader_phase = [&]() {
+            if (lane < 32 && lane_k_in_ray == 0) {
+                if (leader && ((live >> lane) & 1u)) {
+                    if (early_ray) { index = early_index; ws = early_ws; }
+                    else { index = rays_alive[slot]; ws = weights_sum[index]; }
+                    for (uint32_t k = 0; k < fstep; k++) {
+                        if (!((live >> (lane + k)) & 1u)) break;
+                        const float T = 1.0f - ws;
+                        const float wgt = ex[(lane + k) * 3] * T;
+                        ws += wgt;
+                        ex[(lane + k) * 3] = wgt;
+                        cnt++;
+                        if (T < T_thresh) { stopped = true; break; }
+                    }
+                } else if (leader && rs.rays_t) {
+                    if (early_ray) { index = early_index; ws = early_ws; }
+                    else { index = rays_alive[slot]; ws = weights_sum[index]; }
+                }
+                ex[lane * 3 + 1] = __int_as_float(index);
+                ex[lane * 3 + 2] = __int_as_float(cnt);
+            }
+        };
+        if constexpr (kWide) {
+            if (fuse_composite) {
+                if (valid && h == 0) ex[(lane & 31) * 3] = 1.0f - __expf(-(pp.density_scale * __expf(sigma_logit)) * dl.x);   // alpha, exactly as k_frame_composite forms it
+                leader_phase();
+            }
+        }
         float rgb_out[3] = {0.0f, 0.0f, 0.0f};   // this row's final colour, kept for the ray-state composite below
         float rowv[36];                          // (4-basis 12-wave kernels: the row's values; dead rows never count)
 #pragma unroll
@@ -638,7 +720,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
                 if constexpr (kWide) rowv[idx] = v;      // (compile-time positions, all below 34: the row stays in registers)
                 else put_tail(idx, v);
             };
-            float* ex = reinterpret_cast<float*>(w + packed_bytes) + (kWide ? (size_t)0 : (size_t)WAVES * 32 * stage_stride) + (size_t)wave * 96;
             if constexpr (EDIT == 3) {
                 // "network heads" (pnr_palette_edit.mode 3): the row is what PaletteNetwork.forward returns per sample (palette/network.py:156-190) --
                 // [omega nb (normalised) | offsets_radiance 3 nb + 1 (raw, bias added) | view_dep 3 | diffuse 3 | clip_feat clip_dim | 0-pad] -- and the
@@ -738,7 +819,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
             }
             const float sigma = pp.density_scale * __expf(sigma_logit);
             if (!rs.rays_t) sigmas[n] = sigma;   // (with the ray state composited here nobody reads sigmas / rgbs)
-            if (fuse_composite) ex[(lane & 31) * 3] = 1.0f - __expf(-sigma * dl.x);   // alpha, exactly as k_frame_composite forms it (dl.x = deltas[2 n])
+            if constexpr (!kWide) { if (fuse_composite) ex[(lane & 31) * 3] = 1.0f - __expf(-sigma * dl.x); }   // alpha, exactly as k_frame_composite forms it (dl.x = deltas[2 n]); wide: formed above
             const float kvd = EDIT == 2 ? 1.0f : pp.view_dep_weight;   // the Stylizer adds view_dep unscaled (palette/renderer.py:181)
 #pragma unroll
             for (int k = 0; k < 3; k++) { rgb_out[k] = rgb[k] + kvd * view_dep[k]; if (!rs.rays_t) rgbs[(size_t)n * 3 + k] = rgb_out[k]; }
@@ -748,38 +829,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
         PAL_T(PT_EPILOGUE);
         if (stage_stride) {   // (non-wide: the same wave wrote the slab -- DS operations of a wave complete in order)
             float* slab = reinterpret_cast<float*>(w + packed_bytes) + (size_t)wave * 32 * stage_stride;                          // (not in the wide kernels)
-            float* ex = reinterpret_cast<float*>(w + packed_bytes) + (kWide ? (size_t)0 : (size_t)WAVES * 32 * stage_stride) + (size_t)wave * 96;
             const uint32_t n0 = wt * rpw, nq = (uint32_t)pp.aux_stride / 4;
-            const uint32_t live = (uint32_t)__ballot(valid && h == 0);     // (bits 0 .. 31: the rows) rows of dead / out-of-range slots hold no row: skip them
             if (fuse_composite) {
                 // aux_map[ray] += sum_k weight_k * row_k: the recurrence of raymarching.cu:1114-1185 (weights from the weights_sum of
                 // BEFORE this iteration, stop at a dead row, stop after the sample that sees T < T_thresh), same fmaf order.
                 // Leader lane of a ray: weights of its rows, how many count, and the ray id, left in the wave's spare LDS columns.
-                const uint32_t slot = wt * rays_pt + lane_q;
-                const bool leader = (uint32_t)lane < rpw && lane_k_in_ray == 0 && slot < n_alive_k;
-                int cnt = 0, index = 0;
-                float ws = 0.0f;
-                bool stopped = false;   // the last row that counts saw T < T_thresh
-                if (lane < 32 && lane_k_in_ray == 0) {
-                    if (leader && ((live >> lane) & 1u)) {
-                        if (early_ray) { index = early_index; ws = early_ws; }
-                        else { index = rays_alive[slot]; ws = weights_sum[index]; }
-                        for (uint32_t k = 0; k < fstep; k++) {
-                            if (!((live >> (lane + k)) & 1u)) break;
-                            const float T = 1.0f - ws;
-                            const float wgt = ex[(lane + k) * 3] * T;
-                            ws += wgt;
-                            ex[(lane + k) * 3] = wgt;
-                            cnt++;
-                            if (T < T_thresh) { stopped = true; break; }
-                        }
-                    } else if (leader && rs.rays_t) {
-                        if (early_ray) { index = early_index; ws = early_ws; }
-                        else { index = rays_alive[slot]; ws = weights_sum[index]; }
-                    }
-                    ex[lane * 3 + 1] = __int_as_float(index);
-                    ex[lane * 3 + 2] = __int_as_float(cnt);
-                }
+                if constexpr (!kWide) leader_phase();      // (the wide kernels have run it in front of the scalar epilogue)
                 PAL_T(PT_LEADER);
                 float t = 0.0f, d = 0.0f, r = 0.0f, g = 0.0f, b = 0.0f;
                 float dl1_0 = dl.y;
@@ -969,7 +1024,7 @@ extern "C" int pnr_debug_pal_timing(unsigned long long* out, int reset) {
 extern "C" {
 
 uint64_t pnr_palette_field_packed_bytes(uint32_t num_basis, uint32_t clip_dim, int pred_clip) {
-    return (uint64_t)pal_blocks((int)num_basis, (int)clip_dim, pred_clip ? 1 : 0) * kF16BlockBytes + kTablesBytes;
+    return (uint64_t)pal_blocks((int)num_basis, (int)clip_dim, pred_clip ? 1 : 0) * kF16BlockBytes + kVecBytes + kTablesBytes;   // blocks | two vector heads | tables
 }
 uint32_t pnr_palette_aux_channels(uint32_t num_basis, uint32_t clip_dim) { return (6 + 7 * num_basis + clip_dim + 3) & ~3u; }
 
@@ -993,10 +1048,8 @@ int pnr_palette_field_pack(const pnr_palette_weights* pw, void* packed, pnr_stre
     add(pw->sigma1, 64, 16, 1, 4, COL_FRAG, ROW_ID);          // PB_S1
     add(pw->diff0, 15, 64, 2, 1, COL_GEO, ROW_ID);            // PB_D0
     add(pw->diff1, 64, 64, 2, 4, COL_FRAG, ROW_ID);           // PB_D1
-    add(pw->diff2, 64, 3, 1, 4, COL_FRAG, ROW_ID);            // PB_D2
     add(pw->color0, 31, 64, 2, 2, COL_SH_GEO, ROW_ID);        // PB_C0
     add(pw->color1, 64, 64, 2, 4, COL_FRAG, ROW_ID);          // PB_C1
-    add(pw->color2, 64, 3, 1, 4, COL_FRAG, ROW_ID);           // PB_C2
     add(pw->basis0, 35, 64, 2, 3, COL_ENC_DIFF, ROW_ID);      // PB_B0
     add(pw->basis1, 64, 15, 1, 4, COL_FRAG, ROW_ID);          // PB_B1
     add(pw->offsets_radiance, 15, 3 * nb + 1, 1, 1, COL_FRAG15, ROW_HALF0);  // PB_OR
@@ -1012,8 +1065,10 @@ int pnr_palette_field_pack(const pnr_palette_weights* pw, void* packed, pnr_stre
     const dim3 grid(cdiv((uint32_t)t.n * 512, 256));
     if (pw->precision != PNR_FIELD_FP32) hipLaunchKernelGGL(k_pack_blocks<1>, grid, dim3(256), 0, as_stream(stream), t, static_cast<unsigned char*>(packed));
     else hipLaunchKernelGGL(k_pack_blocks<0>, grid, dim3(256), 0, as_stream(stream), t, static_cast<unsigned char*>(packed));
-    hipLaunchKernelGGL(k_pack_tables, dim3(1), dim3(64), 0, as_stream(stream), pw->basis_color, pw->or_bias, nb,
-                       reinterpret_cast<float*>(static_cast<unsigned char*>(packed) + (size_t)t.n * kF16BlockBytes));
+    float* vec = reinterpret_cast<float*>(static_cast<unsigned char*>(packed) + (size_t)t.n * kF16BlockBytes);
+    hipLaunchKernelGGL(k_pack_vec_head, dim3(1), dim3(192), 0, as_stream(stream), pw->diff2, vec);
+    hipLaunchKernelGGL(k_pack_vec_head, dim3(1), dim3(192), 0, as_stream(stream), pw->color2, vec + kVecHeadBytes / 4);
+    hipLaunchKernelGGL(k_pack_tables, dim3(1), dim3(64), 0, as_stream(stream), pw->basis_color, pw->or_bias, nb, vec + kVecBytes / 4);
     return check_launch();
 }
 

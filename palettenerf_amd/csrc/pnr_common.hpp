@@ -133,6 +133,7 @@ extern int g_opt_grid_fast;          // stand-alone lookup op: k_grid_fwd_d3c2 f
 extern int g_opt_train_coop;  // training march: cooperative counting pass
 extern int g_opt_mlp_f16x3;  // training MLPs: split-fp16 matrix products (default) or exact fp32
 extern int g_opt_coarse_image;  // binned table gradient: LDS images for the coarsest levels
+extern int g_opt_scatter_staged;  // binned table gradient: LDS-ordered, coalesced record writes
 extern int g_opt_cell_merge;  // binned table gradient: cell-run merging on mid levels
 extern int g_opt_grid_nt;
 extern int g_opt_iteration_margin;   // frame loops: spare iterations enqueued beyond the previous frame's count before the first host look

@@ -25,6 +25,10 @@ def grid_encode_raw(encoder, x01):
     return out
 
 
+def _no_pair_copy():
+    return None
+
+
 class _PairCopy:
     """The interleaved [rows][2][2] copy of two encoders' tables that the training pair lookup reads.  It lives ON the first encoder (attribute
     `_pnr_pair`: freed with the model, no global registry, no id() aliasing after a model is freed) and remembers its partner by weak reference.
@@ -43,6 +47,13 @@ class _PairCopy:
         self.sum_host = torch.zeros(2, dtype=torch.int64).pin_memory()
         self.sum_event = None       # recorded behind the asynchronous read-back of the last call's checksums
         self.sum_ref = [None, None]  # checksums of the tables as they were when their halves were copied
+
+    # a copy or a pickle of the encoder (copy.deepcopy(model), torch.save(model)) does not take the derived table along: the copy rebuilds its own
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (_no_pair_copy, ())
 
     def matches(self, enc_b, ea):
         return self.partner() is enc_b and self.table.device == ea.device and self.table.shape[0] == ea.shape[0]

@@ -40,6 +40,10 @@ def main(argv=None):
     ap.add_argument("--res", type=float, default=0.25, help="fraction of 1008 x 756 (memory / teacher render time only; the step does not depend on it)")
     ap.add_argument("--optimizer", choices=["pnr", "torch"], default="pnr")
     ap.add_argument("--log-every", type=int, default=500)
+    ap.add_argument("--lr-schedule", choices=["reference", "constant"], default="reference",
+                    help="reference: LambdaLR(0.1 ** min(iter / iters, 1)) stepped every iteration, as main_palette.py:225-228 / main_nerf.py build it; constant: lr 1e-2 "
+                         "throughout (rounds 1-4 of this script: the held-out PSNR then wanders by +-2 dB from 2 000 steps on and fell 40.9 -> 36.9 dB between steps "
+                         "4 000 and 5 000 of round 3's run -- Adam at lr 1e-2 on 50 MB hash tables does not settle without the decay)")
     ap.add_argument("--dead-rows", action="store_true", help="after training: how many samples of a step get an all-zero gradient from the composites (profiles/dead_rows.py)")
     ap.add_argument("--torch-loss", action="store_true", help="the losses written with torch on the result dict instead of palettenerf_amd.train_loss")
     args = ap.parse_args(argv)
@@ -89,6 +93,7 @@ def main(argv=None):
     # ---------------- stage 1: vanilla NeRF (geometry)
     nerf = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=1.0, min_near=0.02).to(dev).train()
     o1 = make_opt(nerf.get_params(1e-2))
+    sched1 = torch.optim.lr_scheduler.LambdaLR(o1, lambda it: 0.1 ** min(it / max(1, args.nerf_steps), 1)) if args.lr_schedule == "reference" else None   # main_nerf.py:147
     t0 = time.perf_counter()
     for step in range(args.nerf_steps):
         if step % 16 == 0:
@@ -100,6 +105,8 @@ def main(argv=None):
         o1.zero_grad(set_to_none=True)
         loss.backward()
         o1.step()
+        if sched1 is not None:
+            sched1.step()
     torch.cuda.synchronize()
     t1 = time.perf_counter() - t0
     print(f"stage 1 (-m nerf): {args.nerf_steps} steps in {t1:.1f} s ({t1 / max(1, args.nerf_steps) * 1e3:.2f} ms/step incl. occupancy updates), held-out PSNR {evaluate(nerf):.2f} dB")
@@ -112,6 +119,7 @@ def main(argv=None):
     pal.to(dev).train()
     print(f"stage 2 initialised from the stage-1 checkpoint: {len(info['missing'])} palette-only entries start fresh, unexpected {info['unexpected']}")
     o2 = make_opt(pal.get_params(1e-2))
+    sched2 = torch.optim.lr_scheduler.LambdaLR(o2, lambda it: 0.1 ** min(it / max(1, args.steps), 1)) if args.lr_schedule == "reference" else None
     lam = dict(sparsity=2e-4, offsets=0.03, view_dep=0.1, palette=0.001)   # main_palette.py:83-89
     log = []
     torch.cuda.synchronize()
@@ -135,6 +143,8 @@ def main(argv=None):
             o2.zero_grad(set_to_none=True)
             loss.backward()
             o2.step()
+            if sched2 is not None:
+                sched2.step()
             continue
         loss = ((out["image"] - gt) ** 2).mean(-1)
         loss = loss + lam["sparsity"] * out["omega_sparsity"].mean() + lam["offsets"] * out["offsets_norm"].mean() + lam["view_dep"] * out["view_dep_norm"].mean()
@@ -143,6 +153,8 @@ def main(argv=None):
         o2.zero_grad(set_to_none=True)
         loss.backward()
         o2.step()
+        if sched2 is not None:
+            sched2.step()
     total = log[-1][2]
     samples = float(pal.step_counter[:, 0].float().mean())      # the last 16 steps' sample counts
     print(f"stage 2 (-m palette, configs[3]): {args.steps} steps in {total:.1f} s = {total / args.steps * 1e3:.2f} ms/step (optimizer: {args.optimizer}), "

@@ -1556,6 +1556,13 @@ def test_grid_pair_copy_lives_on_the_encoder_and_notices_data_writes(cuda):
         warnings.simplefilter("always")
         assert same()
     assert not w
+    # 2b. copy.deepcopy / pickling of an encoder that holds a copy (models are deep-copied by the optimiser tests and by users): the derived table (and the
+    #     HIP event it carries) stays behind, the copy of the encoder builds its own
+    import copy
+    twin = copy.deepcopy(m.encoder)
+    assert twin.__dict__.get("_pnr_pair") is None
+    a2, _ = fused.grid_encode_raw_pair(twin, m.encoder_palette, x01)
+    assert torch.equal(a2, fused.grid_encode_raw(m.encoder, x01))
     # 3. another partner: the copy is rebuilt for it
     other = mk()
     other.embeddings.data.uniform_(-0.5, 0.5)
