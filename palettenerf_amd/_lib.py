@@ -217,6 +217,13 @@ def check(rc, what):
         raise RuntimeError(f"{what}: {msg.decode() if msg else rc}")
 
 
+_FN = {}     # name -> the loaded entry point (a getattr on the CDLL per call is a dict miss + a descriptor each time)
+
+
 def call(name, *args):
-    rc = getattr(load(), name)(*args)
-    check(rc, name)
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(load(), name)
+    rc = fn(*args)
+    if rc:
+        check(rc, name)

@@ -6,14 +6,26 @@ import torch
 from . import _lib
 
 
+# Per-call host cost matters on the drop-in operator path (a frame through the reference's run_cuda is ~110 of these calls; VERDICT round 4 measured 17.6 us
+# for near_far_from_aabb through this wrapper against 4.2 us for the reference's pybind call): every entry point has its argtypes set once (_lib.load), so
+# pointers, sizes and the stream travel as plain Python ints / floats -- no ctypes object per argument -- and the current stream's handle comes from
+# torch's raw getter (no Stream object per call).
+try:
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:      # a torch without the private getter: the public way
+    _raw_stream = None
+
+
 def stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The current HIP stream of the current device, as an int (0 = the null stream)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def ptr(t):
-    if t is None:
-        return None
-    return ctypes.c_void_p(t.data_ptr())
+    """Device address of a tensor as an int (None for None): entry points declare c_void_p, ctypes converts."""
+    return None if t is None else t.data_ptr()
 
 
 def require_cuda(*tensors):

@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256) k_nerf_field_pack_f16x3(const float* __re
     else if (q < 8) { const int kb = q - 4; if (i < 16) v = Ws1[i * 64 + f16_col_from_frag(kb, h, j)]; }
     else if (q < 12) { const int rt = (q - 8) / 2, kb = (q - 8) % 2, col = f16_col_C0(kb, h, j); if (col >= 0) v = Wc0[(rt * 32 + i) * 31 + col]; }
     else if (q < 20) { const int rt = (q - 12) / 4, kb = (q - 12) % 4; v = Wc1[(rt * 32 + i) * 64 + f16_col_from_frag(kb, h, j)]; }
-    else { const int kb = q - 20; if (i < 3) v = Wc2[i * 64 + f16_col_from_frag(kb, h, j)]; }
+    else v = 0.0f;      // (blocks 20 .. 23: color_net[2] is a vector head now -- k_pack_vec_head writes its 768 bytes over the start of block 20)
     const _Float16 hi = (_Float16)v;
     const _Float16 lo = (_Float16)(v - (float)hi);
     _Float16* blk = reinterpret_cast<_Float16*>(packed + (size_t)q * kF16BlockBytes);
@@ -149,10 +149,11 @@ int pnr_nerf_field_pack(const float* w_sigma0, const float* w_sigma1, const floa
     if (precision == PNR_FIELD_FP32)
         hipLaunchKernelGGL(k_nerf_field_pack, dim3(cdiv(kPackedFloats, 256)), dim3(256), 0, as_stream(stream), w_sigma0, w_sigma1, w_color0, w_color1,
                            w_color2, packed, sigma_only ? kC0 : kPackedFloats);
-    else if (precision == PNR_FIELD_F16X3 || precision == PNR_FIELD_F16X2)
+    else if (precision == PNR_FIELD_F16X3 || precision == PNR_FIELD_F16X2) {
         hipLaunchKernelGGL(k_nerf_field_pack_f16x3, dim3(cdiv(kF16Blocks * 512, 256)), dim3(256), 0, as_stream(stream), w_sigma0, w_sigma1, w_color0,
                            w_color1, w_color2, reinterpret_cast<unsigned char*>(packed), (sigma_only ? 8 : kF16Blocks) * 512);
-    else
+        if (!sigma_only) hipLaunchKernelGGL(k_pack_vec_head, dim3(1), dim3(192), 0, as_stream(stream), w_color2, packed + 20 * kF16BlockBytes / 4);
+    } else
         return PNR_ERR_UNSUPPORTED;
     return check_launch();
 }

@@ -213,6 +213,40 @@ template <int PREC> __device__ __forceinline__ f32x16 mma_blk(f32x16 acc, const 
     }
 }
 
+// One 64 -> 3 head on the vector unit (palette_field.hip explains why: as a 32-row MFMA tile 29 of the 32 output rows are padding): `vec` = this lane-half's 96 weights in LDS ([output][tile][register]), u0 / u1 = the lane's two
+// (ReLU'd) accumulator tiles.  out[o] = (sum over the lower half-wave's 32 features) + (sum over the upper half-wave's), the same bits in both lanes of a sample.
+__device__ __forceinline__ void head3_valu(const unsigned char* __restrict__ vec, const f32x16& u0, const f32x16& u1, float out[3]) {
+    typedef float f32x2v __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+    const lds_f32x4* wv = reinterpret_cast<const lds_f32x4*>(reinterpret_cast<uintptr_t>(vec));
+#pragma unroll
+    for (int o = 0; o < 3; o++) {
+        f32x2v acc = {0.0f, 0.0f};
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) {
+                const f32x4 ww = wv[(o * 2 + t) * 4 + r4];
+                const f32x16& u = t ? u1 : u0;
+                acc = __builtin_elementwise_fma(f32x2v{ww.x, ww.y}, f32x2v{u[4 * r4], u[4 * r4 + 1]}, acc);
+                acc = __builtin_elementwise_fma(f32x2v{ww.z, ww.w}, f32x2v{u[4 * r4 + 2], u[4 * r4 + 3]}, acc);
+            }
+        const float p = acc.x + acc.y;
+        const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(p), false, false);   // ([0]: the lower half-wave's p in every lane, [1]: the upper's)
+        out[o] = __uint_as_float(sw2[0]) + __uint_as_float(sw2[1]);
+    }
+}
+
+constexpr uint32_t kVecHeadHalfBytes = 3 * 2 * 16 * 4;     // one lane-half's 96 weights
+// w [3][64] row-major (nn.Linear) -> [half-wave h][output o][tile t][register r] = w[o][32 t + frag_row(r, h)]: what lane-half h multiplies its registers by
+static __global__ void k_pack_vec_head(const float* __restrict__ w, float* __restrict__ out) {
+    const int i = threadIdx.x;     // 192 threads
+    if (i >= 192) return;
+    const int r = i & 15, t = (i >> 4) & 1, o = (i >> 5) % 3, h = i / 96;
+    out[i] = w[o * 64 + 32 * t + frag_row(r, h)];
+}
+
+
 struct FieldOut { float sigma_logit, o0, o1, o2; };
 
 // One wave-tile (32 samples) of the NeRF field, split-fp16 matrix path.  w: the 48 KiB blob in LDS.
@@ -325,20 +359,9 @@ __device__ __forceinline__ FieldOut nerf_field_tile_f16x3(const unsigned char* _
     __builtin_amdgcn_sched_barrier(0);
     d0 = relu16(d0); d1 = relu16(d1);
 
-    // color_net[2]: 64 -> 3
-    f32x16 o = zero16();
-#if PNR_NERF_SPLIT_PER_BLOCK
-#pragma unroll
-    for (int kb = 0; kb < 4; kb++) {
-        splitx_frag_w<LO>(sw, kb < 2 ? d0 : d1, kb & 1, bh[0], bl[0]);
-        o = mmax<LO>(o, w + (20 + kb) * kF16BlockBytes, bh[0], bl[0], lane);
-    }
-#else
-    splitx_frag_w<LO>(sw, d0, 0, bh[0], bl[0]); splitx_frag_w<LO>(sw, d0, 1, bh[1], bl[1]);
-    splitx_frag_w<LO>(sw, d1, 0, bh[2], bl[2]); splitx_frag_w<LO>(sw, d1, 1, bh[3], bl[3]);
-#pragma unroll
-    for (int kb = 0; kb < 4; kb++) o = mmax<LO>(o, w + (20 + kb) * kF16BlockBytes, bh[kb], bl[kb], lane);
-#endif
+    // color_net[2]: 64 -> 3 -- fp32 dot products on the vector unit (round 5; its weights sit where block 20 was: [half-wave][output][tile][register])
+    float o[3];
+    head3_valu(w + 20 * kF16BlockBytes + (uint32_t)h * kVecHeadHalfBytes, d0, d1, o);
     out.o0 = o[0]; out.o1 = o[1]; out.o2 = o[2];
     return out;
 }

@@ -68,14 +68,6 @@ __device__ __forceinline__ int pack_col(int kind, int kb, int h, int j) {
 }
 
 // PREC 1: block = [hi: 64 lanes x 8 halfs][lo: same]; PREC 0: block = [8 steps][64 lanes] fp32 (field_core.hpp: mma_blk)
-// w [3][64] row-major (nn.Linear) -> [half-wave h][output o][tile t][register r] = w[o][32 t + frag_row(r, h)]: what lane-half h multiplies its registers by
-__global__ void k_pack_vec_head(const float* __restrict__ w, float* __restrict__ out) {
-    const int i = threadIdx.x;     // 192 threads
-    if (i >= 192) return;
-    const int r = i & 15, t = (i >> 4) & 1, o = (i >> 5) % 3, h = i / 96;
-    out[i] = w[o * 64 + 32 * t + frag_row(r, h)];
-}
-
 template <int PREC>
 __global__ void __launch_bounds__(256) k_pack_blocks(PackTable t, unsigned char* __restrict__ packed) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -166,30 +158,6 @@ __device__ __forceinline__ void dense64x2(f32x16& o0, f32x16& o1, const unsigned
         o0 = mma_blk<PREC>(o0, w + (q0 + kb) * kF16BlockBytes, b, lane);
         o1 = mma_blk<PREC>(o1, w + (q0 + 4 + kb) * kF16BlockBytes, b, lane);
         __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// One 64 -> 3 head on the vector unit (see PB_* above): `vec` = this lane-half's 96 weights in LDS ([output][tile][register]), u0 / u1 = the lane's two
-// (ReLU'd) accumulator tiles.  out[o] = (sum over the lower half-wave's 32 features) + (sum over the upper half-wave's), the same bits in both lanes of a sample.
-__device__ __forceinline__ void head3_valu(const unsigned char* __restrict__ vec, const f32x16& u0, const f32x16& u1, float out[3]) {
-    typedef float f32x2v __attribute__((ext_vector_type(2)));
-    typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
-    const lds_f32x4* wv = reinterpret_cast<const lds_f32x4*>(reinterpret_cast<uintptr_t>(vec));
-#pragma unroll
-    for (int o = 0; o < 3; o++) {
-        f32x2v acc = {0.0f, 0.0f};
-#pragma unroll
-        for (int t = 0; t < 2; t++)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; r4++) {
-                const f32x4 ww = wv[(o * 2 + t) * 4 + r4];
-                const f32x16& u = t ? u1 : u0;
-                acc = __builtin_elementwise_fma(f32x2v{ww.x, ww.y}, f32x2v{u[4 * r4], u[4 * r4 + 1]}, acc);
-                acc = __builtin_elementwise_fma(f32x2v{ww.z, ww.w}, f32x2v{u[4 * r4 + 2], u[4 * r4 + 3]}, acc);
-            }
-        const float p = acc.x + acc.y;
-        const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(p), false, false);   // ([0]: the lower half-wave's p in every lane, [1]: the upper's)
-        out[o] = __uint_as_float(sw2[0]) + __uint_as_float(sw2[1]);
     }
 }
 

@@ -75,10 +75,11 @@ def test_palette_field_sizes_and_limits_without_gpu():
     from palettenerf_amd import _lib
     lib = _lib.load()
     u32, i32 = ctypes.c_uint32, ctypes.c_int
-    assert lib.pnr_palette_field_packed_bytes(u32(4), u32(0), i32(0)) == 50 * 2048 + 256        # 50 K = 16 blocks + palette / bias tables
-    assert lib.pnr_palette_field_packed_bytes(u32(8), u32(0), i32(0)) == 51 * 2048 + 256        # + the second offsets_radiance tile
-    assert lib.pnr_palette_field_packed_bytes(u32(4), u32(16), i32(1)) == 59 * 2048 + 256       # + clip_net
-    assert lib.pnr_palette_field_packed_bytes(u32(4), u32(32), i32(1)) == 63 * 2048 + 256       # + its second output tile
+    tail = 2 * 768 + 256                       # the two 64 -> 3 heads as fp32 vectors (round 5: no longer 8 matrix blocks) + the palette / bias tables
+    assert lib.pnr_palette_field_packed_bytes(u32(4), u32(0), i32(0)) == 42 * 2048 + tail        # 42 matrix blocks of 2 KiB
+    assert lib.pnr_palette_field_packed_bytes(u32(8), u32(0), i32(0)) == 43 * 2048 + tail        # + the second offsets_radiance tile
+    assert lib.pnr_palette_field_packed_bytes(u32(4), u32(16), i32(1)) == 51 * 2048 + tail       # + clip_net
+    assert lib.pnr_palette_field_packed_bytes(u32(4), u32(32), i32(1)) == 55 * 2048 + tail       # + its second output tile
     assert lib.pnr_palette_aux_channels(u32(4), u32(16)) == 52 and lib.pnr_palette_aux_channels(u32(8), u32(16)) == 80
     assert lib.pnr_palette_field_stages_aux(u32(4), u32(0), i32(0)) == 1 and lib.pnr_palette_field_stages_aux(u32(10), u32(32), i32(1)) == 0
     a = _lib.PaletteFieldArgs()
