@@ -231,7 +231,7 @@ constexpr int kPalThreads = 512;
 #define PNR_PAL_FAKE 0          // timing-only builds (WRONG results): 1 = no matrix phase (the loads stay), 2 = nothing behind the matrix phase (no epilogue, composite, stores)
 #endif
 #ifndef PNR_PAL_WIDE_WAVES
-#define PNR_PAL_WIDE_WAVES 12   // waves per workgroup of the specialised 4-basis kernels ("wide": no clip head, rows of 36 floats, slabs in LDS).  Experiment builds: 8
+#define PNR_PAL_WIDE_WAVES 16   // waves per workgroup of the specialised 4-basis kernels ("wide": no clip head, rows of 36 floats, slabs in LDS).  Experiment builds: 8
 #endif
 #ifndef PNR_PAL_EARLY_ENC
 #define PNR_PAL_EARLY_ENC 1
@@ -642,6 +642,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
                 leader_phase();
             }
         }
+        const int ray_cnt_w = (kWide && fstep > 1u) ? __shfl(cnt, (lane & 31) - (int)lane_k_in_ray) : cnt;   // the count of this lane's ray (held by its leader lane)
         float rgb_out[3] = {0.0f, 0.0f, 0.0f};   // this row's final colour, kept for the ray-state composite below
         float rowv[36];                          // (4-basis 12-wave kernels: the row's values; dead rows never count)
 #pragma unroll
@@ -792,6 +793,64 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
 #pragma unroll
             for (int k = 0; k < 3; k++) { rgb_out[k] = rgb[k] + kvd * view_dep[k]; if (!rs.rays_t) rgbs[(size_t)n * 3 + k] = rgb_out[k]; }
             }   // EDIT != 3
+            if constexpr (kWide) {
+                // The row goes where it belongs from inside this block (round 5): its 34 values then never cross a merge of the control flow -- carried
+                // through the leader phase and the composite's branches they were what kept a 128-register build of this kernel spilling.
+                // acc = fmaf(weight_k, value_k, acc) for k = 0, 1, ...: the chain the staged form of the 8-wave kernels runs, in the same order.
+                if (fuse_composite) {
+                        const bool lead_acc = lane < 32 && lane_k_in_ray == 0 && cnt > 0;      // (cnt > 0 only on leader lanes with a live first row)
+                        f32x4* __restrict__ arow = reinterpret_cast<f32x4*>(aux_map + (size_t)index * 36);
+                        if (fstep == 1u) {     // (wave-uniform) one sample per ray -- every heavy launch: the row's own lane does the ray's read-modify-write
+                            if (lead_acc) {
+                                f32x4 acc[9];
+    #pragma unroll
+                                for (int q = 0; q < 9; q++) acc[q] = arow[q];                          // nine requests in flight, one trip
+                                const float w0 = ex[lane * 3];
+    #pragma unroll
+                                for (int c = 0; c < 34; c++) acc[c >> 2][c & 3] = fmaf(w0, rowv[c], acc[c >> 2][c & 3]);
+    #pragma unroll
+                                for (int q = 0; q < 9; q++) arow[q] = acc[q];
+                            }
+                        } else {
+                            // 2 .. 8 samples per ray (at most 16 rays in the tile): the rays' rows go through a small LDS image (16 x 144 bytes per wave) -- the
+                            // leader lane fetches its ray's row, round k lets the lane that holds row k add it (the wave's DS operations complete in order, so
+                            // round k + 1 reads what round k wrote), the leader writes the row back.  Same fmaf chain, same order.
+                            typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+                            float* img = reinterpret_cast<float*>(w + packed_bytes) + (size_t)WAVES * 96 + (size_t)wave * (16 * 36);
+                            lds_f32x4* srow = reinterpret_cast<lds_f32x4*>(reinterpret_cast<uintptr_t>(img + (lane_q & 15u) * 36u));
+                                                    if (lead_acc) {
+                                f32x4 acc[9];
+    #pragma unroll
+                                for (int q = 0; q < 9; q++) acc[q] = arow[q];
+    #pragma unroll
+                                for (int q = 0; q < 9; q++) srow[q] = acc[q];
+                            }
+                            const bool counts = lane < 32 && (int)lane_k_in_ray < ray_cnt_w;
+                            const float my_w = counts ? ex[lane * 3] : 0.0f;
+    #pragma unroll 1
+                            for (uint32_t k = 0; k < fstep; k++) {     // wave-uniform
+                                if (counts && lane_k_in_ray == k) {
+    #pragma unroll
+                                    for (int q = 0; q < 9; q++) {
+                                        f32x4 a4 = srow[q];
+                                        a4.x = fmaf(my_w, rowv[4 * q], a4.x); a4.y = fmaf(my_w, rowv[4 * q + 1], a4.y);
+                                        if (q < 8) { a4.z = fmaf(my_w, rowv[4 * q + 2], a4.z); a4.w = fmaf(my_w, rowv[4 * q + 3], a4.w); }   // (columns 34, 35 are padding)
+                                        srow[q] = a4;
+                                    }
+                                }
+                            }
+                            if (lead_acc) {
+    #pragma unroll
+                                for (int q = 0; q < 9; q++) arow[q] = srow[q];
+                            }
+                        }
+
+                } else {     // rows straight from the registers to the caller's aux buffer (stand-alone op; frames whose composite is a launch of its own)
+                    f32x4* __restrict__ dst = reinterpret_cast<f32x4*>(aux + (size_t)n * 36);
+#pragma unroll
+                    for (int q = 0; q < 9; q++) dst[q] = f32x4{rowv[4 * q], rowv[4 * q + 1], rowv[4 * q + 2], rowv[4 * q + 3]};
+                }
+            }
         }
         if constexpr (CHECK) { if (overflow_flag && sw_.overflowed()) *overflow_flag = 1; }
         PAL_T(PT_EPILOGUE);
@@ -807,58 +866,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
                 float t = 0.0f, d = 0.0f, r = 0.0f, g = 0.0f, b = 0.0f;
                 float dl1_0 = dl.y;
                 if constexpr (kWide) {
-                    // The rows are in registers (rowv of the sample's lower-half lane); acc = fmaf(weight_k, value_k, acc) for k = 0, 1, ... -- the chain the
-                    // staged form below runs, in the same order.
-                    t = rs_t; d = rs_d; r = rs_r; g = rs_g; b = rs_b;
-                    const bool lead_acc = lane < 32 && lane_k_in_ray == 0 && cnt > 0;      // (cnt > 0 only on leader lanes with a live first row)
-                    f32x4* __restrict__ arow = reinterpret_cast<f32x4*>(aux_map + (size_t)index * 36);
-                    if (fstep == 1u) {     // (wave-uniform) one sample per ray -- every heavy launch: the row's own lane does the ray's read-modify-write
-                        if (lead_acc) {
-                            f32x4 acc[9];
-#pragma unroll
-                            for (int q = 0; q < 9; q++) acc[q] = arow[q];                          // nine requests in flight, one trip
-                            const float w0 = ex[lane * 3];
-#pragma unroll
-                            for (int c = 0; c < 34; c++) acc[c >> 2][c & 3] = fmaf(w0, rowv[c], acc[c >> 2][c & 3]);
-#pragma unroll
-                            for (int q = 0; q < 9; q++) arow[q] = acc[q];
-                        }
-                        PAL_T(PT_ACC);
-                    } else {
-                        // 2 .. 8 samples per ray (at most 16 rays in the tile): the rays' rows go through a small LDS image (16 x 144 bytes per wave) -- the
-                        // leader lane fetches its ray's row, round k lets the lane that holds row k add it (the wave's DS operations complete in order, so
-                        // round k + 1 reads what round k wrote), the leader writes the row back.  Same fmaf chain, same order.
-                        typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
-                        float* img = reinterpret_cast<float*>(w + packed_bytes) + (size_t)WAVES * 96 + (size_t)wave * (16 * 36);
-                        lds_f32x4* srow = reinterpret_cast<lds_f32x4*>(reinterpret_cast<uintptr_t>(img + (lane_q & 15u) * 36u));
-                        const int ray_cnt = __shfl(cnt, (lane & 31) - (int)lane_k_in_ray);      // the count of this lane's ray (held by its leader lane)
-                        if (lead_acc) {
-                            f32x4 acc[9];
-#pragma unroll
-                            for (int q = 0; q < 9; q++) acc[q] = arow[q];
-#pragma unroll
-                            for (int q = 0; q < 9; q++) srow[q] = acc[q];
-                        }
-                        const bool counts = lane < 32 && (int)lane_k_in_ray < ray_cnt;
-                        const float my_w = counts ? ex[lane * 3] : 0.0f;
-#pragma unroll 1
-                        for (uint32_t k = 0; k < fstep; k++) {     // wave-uniform
-                            if (counts && lane_k_in_ray == k) {
-#pragma unroll
-                                for (int q = 0; q < 9; q++) {
-                                    f32x4 a4 = srow[q];
-                                    a4.x = fmaf(my_w, rowv[4 * q], a4.x); a4.y = fmaf(my_w, rowv[4 * q + 1], a4.y);
-                                    if (q < 8) { a4.z = fmaf(my_w, rowv[4 * q + 2], a4.z); a4.w = fmaf(my_w, rowv[4 * q + 3], a4.w); }   // (columns 34, 35 are padding)
-                                    srow[q] = a4;
-                                }
-                            }
-                        }
-                        PAL_T(PT_ACC);
-                        if (lead_acc) {
-#pragma unroll
-                            for (int q = 0; q < 9; q++) arow[q] = srow[q];
-                        }
-                    }
+                    t = rs_t; d = rs_d; r = rs_r; g = rs_g; b = rs_b;      // (the rows have gone into aux_map inside the scalar epilogue's block)
                 } else {
                 // the ray state is requested here and used behind the aux rows' composite below (the loads land under it)
                 if (rs.rays_t && leader) {
@@ -912,13 +920,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
                         }
                     }
                 }
-            } else if constexpr (kWide) {     // rows straight from the registers to the caller's aux buffer (stand-alone op; frames whose composite is a launch of its own)
-                if (valid && h == 0) {
-                    f32x4* __restrict__ dst = reinterpret_cast<f32x4*>(aux + (size_t)n * 36);
-#pragma unroll
-                    for (int q = 0; q < 9; q++) dst[q] = f32x4{rowv[4 * q], rowv[4 * q + 1], rowv[4 * q + 2], rowv[4 * q + 3]};
-                }
-            } else {
+            } else if constexpr (!kWide) {
                 for (uint32_t i = (uint32_t)lane; i < 32 * nq; i += 64) {
                     const uint32_t row = i / nq, q = i - row * nq;
                     if ((live >> row) & 1u)
