@@ -397,9 +397,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
         // all global reads of the tile up front
         // (the 12-wave variant has three waves per SIMD to hide a load behind and 168 registers: it fetches the second table's features where they are used)
         if constexpr (kEarlyEnc) {
+            // Dead lanes keep what they loaded (rows that exist: the caller-clamped row): a sample is a COLUMN of every matrix product and the cross-lane steps
+            // pair the two half-wave lanes of ONE sample, so a dead lane's values reach nobody, and nothing it computes is stored.  Only the operand watch of
+            // the CHECK instantiations looks at every lane: there they are zeroed as before.  (35 selects per tile.)
+            if constexpr (CHECK) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) { xs[0][j] = valid ? xs[0][j] : 0.0f; xs[1][j] = valid ? xs[1][j] : 0.0f; }
-            dx = valid ? dx : 0.0f; dy = valid ? dy : 0.0f; dz = valid ? dz : 0.0f;
+                for (int j = 0; j < 8; j++) { xs[0][j] = valid ? xs[0][j] : 0.0f; xs[1][j] = valid ? xs[1][j] : 0.0f; }
+                dx = valid ? dx : 0.0f; dy = valid ? dy : 0.0f; dz = valid ? dz : 0.0f;
+            }
         } else {
             load_enc_raw(enc, level_stride, row, valid, h, xs);
         }
@@ -519,7 +524,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
                             xp[kb][2 * q] = valid ? v.x : 0.0f; xp[kb][2 * q + 1] = valid ? v.y : 0.0f;
                         }
                 } else {
-                    load_enc_raw(enc_pal, level_stride, row, valid, h, xp);
+                    load_enc_raw(enc_pal, level_stride, row, valid || (kEarlyEnc && !CHECK), h, xp);     // (dead lanes: see the first table's rows above)
                 }
             }
             PAL_WAIT_VM();
