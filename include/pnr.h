@@ -63,7 +63,8 @@ int pnr_abi_version(void);
  * 0 = that launch finishes every ray itself) sample-less probes to the first workgroups of the lookup launch that follows -- same rows, bit for bit;
  * "march_blocks" (default 0 = automatic): workgroup cap of such a budgeted march launch; "coarse_image" (default 1): pnr_grid_encode_backward_binned accumulates the
  * coarsest levels (tables of at most 16 384 rows) as LDS images instead of records; "cell_merge" (default 1): on its mid levels the samples of a ray that sit in
- * one cell are summed before their records are written; "mlp_f16x3" (default 1): the training MLP launches use split-fp16 products; "train_coop" (default 1): pnr_march_rays_train*'s counting pass
+ * one cell are summed before their records are written; "scatter_staged" (default 1): its records are ordered by bucket in LDS and written coalesced
+ * (0 = every lane writes its own records); "mlp_f16x3" (default 1): the training MLP launches use split-fp16 products; "train_coop" (default 1): pnr_march_rays_train*'s counting pass
  * marches four rays per wave cooperatively (same counts, same rows); "coop_march" also governs the cooperative tail of pnr_march_rays* */
 int pnr_set_option(const char* name, int value);
 

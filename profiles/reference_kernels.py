@@ -71,6 +71,13 @@ def main():
     nears, fars = raymarching.near_far_from_aabb(ro, rd, aabb, 0.2)
     out["near_far_from_aabb"] = {"nears": cmp(nears, n_ref), "fars": cmp(fars, f_ref), "ref_us": timed(lambda: rm.near_far_from_aabb(ro, rd, aabb, H * W, 0.2, n_ref, f_ref)),
                                  "ours_us": timed(lambda: raymarching.near_far_from_aabb(ro, rd, aabb, 0.2))}
+    # like for like with ref_us (a bare binding call on preallocated outputs; `ours_us` above is the whole operator: autograd.Function, three .contiguous(),
+    # two allocations): the C-ABI entry through ctypes with plain ints
+    from palettenerf_amd import _lib as _plib
+    from palettenerf_amd._torch_glue import stream_ptr
+    n2, f2 = torch.empty_like(n_ref), torch.empty_like(f_ref)
+    p_ro, p_rd, p_ab, p_n, p_f = ro.data_ptr(), rd.data_ptr(), aabb.data_ptr(), n2.data_ptr(), f2.data_ptr()
+    out["near_far_from_aabb"]["ours_bare_call_us"] = timed(lambda: _plib.call("pnr_near_far_from_aabb", p_ro, p_rd, p_ab, H * W, 0.2, p_n, p_f, stream_ptr()))
     # ---------------------------------------------------------------- march_rays_train (a 200 x 200 window of the frame: 40 000 rays)
     bitfield = raymarching.packbits(grid, 0.5)
     rows = torch.arange(300, 500)[:, None] * W + torch.arange(300, 500)[None, :]
