@@ -228,7 +228,7 @@ constexpr int kPalThreads = 512;
 #define PNR_PAL_EARLY_ENC 1
 #endif
 #ifndef PNR_PAL_FAKE
-#define PNR_PAL_FAKE 0          // timing-only builds (WRONG results): 1 = no matrix phase (the loads stay), 2 = nothing behind the matrix phase (no epilogue, composite, stores)
+#define PNR_PAL_FAKE 0          // timing-only builds (WRONG results): 1 = no matrix phase (the loads stay), 2 = nothing behind the matrix phase (no epilogue, composite, stores), 4 = nothing behind it on every second tile
 #endif
 #ifndef PNR_PAL_WIDE_WAVES
 #define PNR_PAL_WIDE_WAVES 16   // waves per workgroup of the specialised 4-basis kernels ("wide": no clip head, rows of 36 floats, slabs in LDS).  Experiment builds: 8
@@ -594,6 +594,15 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
             if (chk == 123456.789f) launder(ka)->sigmas[n] = chk + dl.y;
         }
 #else
+#if PNR_PAL_FAKE & 4
+        if (it & 1u) {   // (timing only) every second tile of a wave skips everything behind the matrix phase: what half the tail's work would buy
+            float chk = sigma_logit + diffuse[0] + diffuse[1] + diffuse[2] + view_dep[0] + view_dep[1] + view_dep[2] + early_ws;
+#pragma unroll
+            for (int j = 0; j < 16; j++) chk += orr[j] + om[j];
+            if (chk == 123456.789f) launder(ka)->sigmas[n] = chk + dl.y;
+            continue;
+        }
+#endif
         PAL_T(PT_BASIS);
         // ---------------- scalar epilogue on the lower half-wave: the palette colour-basis composite
         asm volatile("" : "+s"(toff));
