@@ -648,17 +648,38 @@ def mfma_leg(m, model_kind, rows, device, precision, reps=30):
     return rec
 
 
-def l2_bound_of(samples_per_launch, n_tables_rows, launch_ms):
+def gather_ceilings(timeout=90):
+    """The random-row gather ceilings of THIS box: profiles/micro/gather_rate (built from gather_rate.hip by __graft_entry__.build) run as a child
+    process -- 8-byte rows, every lane a random row, 8 loads in flight per lane, over a 4 MB (L2-resident) and a 50 MB (the whole hash table) range.
+    Returns {"l2_resident", "table_50mb"} in lane-loads per clock per CU at the binary's nominal 2.4 GHz, or None when the binary is not there."""
+    exe = os.path.join(ROOT, "profiles", "micro", "gather_rate")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=timeout).stdout
+    except (OSError, subprocess.TimeoutExpired):
+        return None
+    got = {}
+    for line in out.splitlines():
+        if line.startswith("8-byte rows (fp32 row)") and "per clock per CU" in line:
+            mb = float(line.split("table")[1].split("MB")[0])
+            val = float(line.split("=")[1].split("per clock")[0])
+            got[{4.0: "l2_resident", 50.0: "table_50mb"}.get(mb, str(mb))] = val
+    return got if "l2_resident" in got and "table_50mb" in got else None
+
+
+def l2_bound_of(samples_per_launch, n_tables_rows, launch_ms, ceilings=None):
     """The lookup kernel's other bound: divergent lane-requests per clock per CU.  Every (sample, level) issues 8 row gathers; the
-    ceilings are profiles/micro/gather_rate.hip's (every lane a random row, 8 loads in flight per lane): 0.43 per clock per CU over an
-    L2-resident 4 MB table, 0.106 over the whole 50 MB table (constants measured in round 2, not re-measured in this run)."""
+    ceilings are profiles/micro/gather_rate.hip's (every lane a random row, 8 loads in flight per lane) over an L2-resident 4 MB table and over
+    the whole 50 MB table -- measured in this run when `ceilings` (gather_ceilings()) is given, else round 2's constants 0.43 / 0.106."""
     reqs = samples_per_launch * 16 * 8 * n_tables_rows
     per_clk_cu = reqs / (launch_ms * 1e-3) / (CLOCK_GHZ * 1e9) / 256.0
+    c_l2, c_50 = (ceilings["l2_resident"], ceilings["table_50mb"]) if ceilings else (0.43, 0.106)
     return {"lane_requests_per_launch": reqs, "lane_requests_per_clk_per_cu": per_clk_cu, "clock_ghz_assumed": CLOCK_GHZ,
-            "random_row_ceiling_l2_resident": 0.43, "random_row_ceiling_50mb_table": 0.106,
-            "ratio_to_l2_resident_random_ceiling": per_clk_cu / 0.43,
-            "note": "rows gathered per clock per CU; above the random-row ceilings because neighbouring lanes share 128-byte lines (8x8-pixel wave tiles, level-major launch); "
-                    "ceilings from profiles/micro/gather_rate.hip (committed microbenchmark, not re-run here)"}
+            "random_row_ceiling_l2_resident": c_l2, "random_row_ceiling_50mb_table": c_50,
+            "ratio_to_l2_resident_random_ceiling": per_clk_cu / c_l2,
+            "ceilings_source": "profiles/micro/gather_rate run in this bench run" if ceilings else "round-2 constants (profiles/micro/gather_rate not built here)",
+            "note": "rows gathered per clock per CU; above the random-row ceilings because neighbouring lanes share 128-byte lines (8x8-pixel wave tiles, level-major launch)"}
 
 
 def measure_traffic(argv_core, kernel_substr="k_frame_grid", timeout=240):
@@ -1122,7 +1143,8 @@ def main(argv=None):
                          "algorithmic_bytes_per_launch": per_sample * k_units / max(1, n_launches)},
         }
         if native and k_ms > 0 and n_launches > 0:
-            out["roofline"]["l2_bound"] = l2_bound_of(k_units / n_launches / n_tables, 1, k_ms / n_launches)
+            out["roofline"]["l2_bound"] = l2_bound_of(k_units / n_launches / n_tables, 1, k_ms / n_launches,
+                                                      ceilings=None if (args.no_extras or use_dist) else gather_ceilings())
             try:    # north_star: MFMA utilisation of the fused field kernel against the gfx950 peak
                 out["roofline"]["mfma"] = mfma_leg(m, args.model, max(1024, int(k_units / n_launches / n_tables)), device, args.field_precision)
             except RuntimeError as e:
