@@ -198,14 +198,10 @@ struct EditParams {
 };
 
 constexpr int kPalThreads = 512;
-// 12-wave kernels (three waves per SIMD, registers and LDS both full): two requests a tile used to wait for where it needed them are issued at the
-// top of the tile at no cost in registers --
-//   PNR_PAL_EARLY_PAL  the second table's rows (enc_palette, needed by basis_net two thirds into the tile) go straight into this wave's aux staging
-//                      slab with global_load_lds: the slab is idle until the epilogue writes the tile's aux rows into it;
-//   PNR_PAL_EARLY_RAY  a ray leader's slot -> ray id (and then its weights_sum) for the compositing step at the END of the tile.
-#ifndef PNR_PAL_EARLY_PAL
-#define PNR_PAL_EARLY_PAL 0     // measured (profiles/scratch/r04_ab_palette.sh, garden): 13.2 -> 13.55 ms with it on (168 registers + 12 B of scratch): off
-#endif
+// Wide kernels: a request a tile used to wait for where it needed it is issued at the top of the tile --
+//   PNR_PAL_EARLY_RAY  a ray leader's slot -> ray id (and then its weights_sum) for the compositing step.
+// (Round 4 also tried the second table's rows through global_load_lds into the then-idle staging slab, PNR_PAL_EARLY_PAL: slower, EXPERIMENTS.md; the slab
+// is gone since round 5 and that code with it.)
 #ifndef PNR_PAL_WAVE_MAJOR
 #define PNR_PAL_WAVE_MAJOR 1    // wave tiles dealt wave-major (see the tile loop); 0 = workgroup-major, for the A/B
 #endif
@@ -409,17 +405,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
             load_enc_raw(enc, level_stride, row, valid, h, xs);
         }
         if constexpr (WAVES != PNR_PAL_WIDE_WAVES) load_enc_raw(enc_pal, level_stride, row, valid, h, xp);
-        // 12 waves: enc_palette's 16 levels x 32 rows x 8 bytes of this tile -> the wave's (idle) staging slab, 4 x 1 KiB, one level per 16 lanes.
-        // Needs 16-byte aligned sources (even first row, even level stride) and 32 rows that exist in every level's run (level_stride rows are
-        // allocated per level; rows beyond B hold stale values that their lanes replace by zeros below).  Wave-uniform.
-        const uint32_t n0_tile = wt * rpw;
-        const bool pal_in_lds = PNR_PAL_EARLY_PAL && WAVES == PNR_PAL_WIDE_WAVES && stage_stride * 32u * 4u >= 4096u && ((level_stride | n0_tile) & 1u) == 0u && n0_tile + 32u <= level_stride;
-        if (pal_in_lds) {
-            unsigned char* slab_b = w + packed_bytes + (size_t)wave * 32 * stage_stride * 4;
-            const unsigned char* src = reinterpret_cast<const unsigned char*>(enc_pal) + ((size_t)(lane >> 4) * level_stride + n0_tile) * 8u + (uint32_t)(lane & 15) * 16u;
-#pragma unroll
-            for (int i = 0; i < 4; i++) lds_copy16(src + (size_t)(4 * i) * level_stride * 8u, slab_b + i * 1024 + lane * 16);
-        }
         if constexpr (!kEarlyEnc) {
             if (valid) { dx = dirs[(size_t)row * 3]; dy = dirs[(size_t)row * 3 + 1]; dz = dirs[(size_t)row * 3 + 2]; }
         }
@@ -512,18 +497,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
         // ---------------- basis_net: [enc_palette(32) ; diffuse(3)] -> 64 (ELU) -> 15
         {
             if constexpr (WAVES == PNR_PAL_WIDE_WAVES) {
-                if (pal_in_lds) {   // the rows requested at the top of the tile: level 8 kb + 4 h + q of row (lane & 31)
-                    lds_copy_wait();
-                    typedef __attribute__((address_space(3))) f32x2 lds_f32x2;
-                    const lds_f32x2* sl = reinterpret_cast<const lds_f32x2*>(reinterpret_cast<uintptr_t>(w + packed_bytes + (size_t)wave * 32 * stage_stride * 4));
-#pragma unroll
-                    for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const f32x2 v = sl[(8 * kb + 4 * h + q) * 32 + (lane & 31)];
-                            xp[kb][2 * q] = valid ? v.x : 0.0f; xp[kb][2 * q + 1] = valid ? v.y : 0.0f;
-                        }
-                } else {
+                {
                     load_enc_raw(enc_pal, level_stride, row, valid || (kEarlyEnc && !CHECK), h, xp);     // (dead lanes: see the first table's rows above)
                 }
             }
@@ -697,7 +671,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
             // `a` is LDS or global, so its stores would be flat_store (57 per tile through both the vector-memory and the LDS queue); the 12-wave
             // kernels always stage (the launcher sees to it): there the row is written with ds_write
             // ... and, with the shipped 4 bases, the first 32 floats of the row (compile-time positions) leave as eight 16-byte writes
-            typedef __attribute__((address_space(3))) float lds_float;
             auto put_tail = [&](int idx, float v) { a[idx] = v; };   // run-time positions (clip columns, padding); never reached by the wide kernels
             auto put = [&](int idx, float v) {
                 if constexpr (kWide) rowv[idx] = v;      // (compile-time positions, all below 34: the row stays in registers)
