@@ -223,7 +223,31 @@ class _PrecisionGuard:
     def _guard_bound(self, tmax, scales):
         raise NotImplementedError
 
+    def _held(self):
+        """Context manager for one call of the stand-alone ops: the guard is evaluated once and its answer held until the call returns (effective_precision,
+        enc_scales and _pack each ask; every answer walks the model's parameters -- 36 % of the host time of a drop-in frame with dropin.fuse_field)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def hold():
+            self._guard_hold = True
+            try:
+                yield
+            finally:
+                self._guard_hold = False
+                self._guard_held = None
+        return hold()
+
     def _guard(self):
+        held = self.__dict__.get("_guard_held")
+        if held is not None:
+            return held
+        state = self._guard_now()
+        if self.__dict__.get("_guard_hold"):
+            self._guard_held = state
+        return state
+
+    def _guard_now(self):
         tables = self._guard_tables()
         key = tuple(_pkey(w) for w in self._guard_weights()) + tuple(_pkey(t) for t in tables)
         if getattr(self, "_guard_key", None) != key or PARANOID:
@@ -474,8 +498,9 @@ class NeRFFieldFused(_PrecisionGuard, _SourceWatch):
         B = x.shape[0]
         sigmas = torch.empty(B, dtype=torch.float32, device=x.device)
         rgbs = torch.empty(B, 3, dtype=torch.float32, device=x.device)
-        call("pnr_nerf_field_forward", ptr(enc), ptr(require(d.contiguous(), torch.float32, "dirs")), ptr(self._pack()), _u32(B), ptr(sigmas),
-             ptr(rgbs), _int(self.effective_precision()), _f32(self.enc_scales()[0]), units=B)
+        with self._held():
+            call("pnr_nerf_field_forward", ptr(enc), ptr(require(d.contiguous(), torch.float32, "dirs")), ptr(self._pack()), _u32(B), ptr(sigmas),
+                 ptr(rgbs), _int(self.effective_precision()), _f32(self.enc_scales()[0]), units=B)
         return sigmas, rgbs
 
 
@@ -512,7 +537,8 @@ class DensityFused(NeRFFieldFused):
         B = x.shape[0]
         sigmas = torch.empty(B, dtype=torch.float32, device=x.device)
         geo = torch.empty(B, 15, dtype=torch.float32, device=x.device) if want_geo else None
-        call("pnr_nerf_density_forward", ptr(enc), ptr(self._pack()), _u32(B), ctypes.c_float(scale), ptr(sigmas), ptr(geo), _int(self.effective_precision()), _f32(self.enc_scales()[0]), units=B)
+        with self._held():
+            call("pnr_nerf_density_forward", ptr(enc), ptr(self._pack()), _u32(B), ctypes.c_float(scale), ptr(sigmas), ptr(geo), _int(self.effective_precision()), _f32(self.enc_scales()[0]), units=B)
         return sigmas, geo
 
 
