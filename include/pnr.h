@@ -292,8 +292,8 @@ typedef struct pnr_nerf_frame_args {
     uint32_t N;
     const float* rays_o;           /* [N,3] */
     const float* rays_d;           /* [N,3] */
-    const float* nears;            /* [N]   (pnr_near_far_from_aabb) */
-    const float* fars;             /* [N]   */
+    float* nears;                  /* [N]   in (pnr_near_far_from_aabb); with `aabb` set: OUT, written by the call */
+    float* fars;                   /* [N]   likewise */
     const uint8_t* bitfield;       /* density bitfield, uint8[C*H^3/8] */
     const void* mip;               /* pnr_build_occupancy_mip output, or NULL */
     float bound;
@@ -324,7 +324,8 @@ typedef struct pnr_nerf_frame_args {
                                       wave; NULL = as given.  The frame then runs on copies of the per-ray inputs gathered into that
                                       order; outputs are scattered back, indexed by ray id either way, and do not depend on the order */
     int finish;                    /* bit mask: apply the caller-side epilogue of run_cuda (nerf/renderer.py:382-384) before returning --
-                                      bit 0: image += (1 - weights_sum) * bg_color;  bit 1: depth = max(depth - near, 0) / (far - near)
+                                      bit 0: image += (1 - weights_sum) * bg_color;  bit 1: depth = max(depth - near, 0) / (far - near);
+                                      bit 2 (pnr_palette_render_frame): aux_map[:, 0:3] (direct_rgb) += (1 - weights_sum) * bg_color (palette/renderer.py:529)
                                       (same fp32 operations, in the same order, as the reference's torch expressions) */
     float bg_color[3];             /* used when finish != 0 and bg_map == NULL (the reference's default is 1) */
     const float* bg_map;           /* optional per-ray background [N,3] (device) for finish */
@@ -335,6 +336,12 @@ typedef struct pnr_nerf_frame_args {
                                       split-fp16 field, see pnr_nerf_field_forward; 0 or 1 = none */
     int watch_overflow;            /* PNR_FIELD_F16X3 only: the field kernels watch the operands they split for magnitudes beyond fp16's range
                                       (65 504) and report through stats[5]; for weights whose activations the caller cannot bound (~1 VALU per operand) */
+    const float* aabb;             /* optional (device, 6 floats: xmin ymin zmin xmax ymax zmax): the call computes `nears` / `fars` itself, inside its first
+                                      launch, with pnr_near_far_from_aabb's arithmetic (raymarching.cu:95-148; same bits) and WRITES them to `nears` / `fars`
+                                      (by ray id) -- run_cuda's near_far_from_aabb call (nerf/renderer.py:268) folded into the frame; NULL: `nears` / `fars` are inputs */
+    float min_near;                /* used with `aabb` */
+    float* depth_raw;              /* optional [N] out: the un-normalised depth by ray id when finish bit 1 rewrites `depth`
+                                      (PaletteNeRF's depth_origin, palette/renderer.py:522) */
 } pnr_nerf_frame_args;
 uint64_t pnr_nerf_frame_workspace_bytes(uint32_t N);
 int pnr_nerf_render_frame(const pnr_nerf_frame_args* args, pnr_stream_t stream);

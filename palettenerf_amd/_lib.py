@@ -135,7 +135,8 @@ class NerfFrameArgs(ctypes.Structure):
                 ("C", _u32), ("H", _u32), ("dt_gamma", _f32), ("max_steps", _u32), ("T_thresh", _f32), ("embeddings", _ptr), ("offsets", _ptr),
                 ("num_levels", _u32), ("S", _f32), ("base_resolution", _u32), ("gridtype", _u32), ("packed_weights", _ptr), ("field_precision", _int), ("density_scale", _f32),
                 ("weights_sum", _ptr), ("depth", _ptr), ("image", _ptr), ("workspace", _ptr), ("workspace_bytes", _u64), ("stats", _ptr), ("kernel_ms", _ptr), ("ray_order", _ptr),
-                ("finish", _int), ("bg_color", _f32 * 3), ("bg_map", _ptr), ("table_dtype", _int), ("enc_scale", _f32 * 3), ("watch_overflow", _int)]
+                ("finish", _int), ("bg_color", _f32 * 3), ("bg_map", _ptr), ("table_dtype", _int), ("enc_scale", _f32 * 3), ("watch_overflow", _int),
+                ("aabb", _ptr), ("min_near", _f32), ("depth_raw", _ptr)]
 
 
 MAX_BASIS, MAX_CLIP = 10, 32   # PNR_MAX_BASIS, PNR_MAX_CLIP

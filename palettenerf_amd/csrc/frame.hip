@@ -64,7 +64,7 @@ constexpr uint32_t kHostedBlocks = 256;   // workgroups of a lookup launch that 
 #define PNR_MAX_MARCH_BLOCKS 4096   // (2048: a frame of 2 500 chunks gave 452 workgroups a second chunk behind their block barriers; first launch 88.1 -> 86.4 us on average)
 #endif
 constexpr uint32_t kMaxMarchBlocks = PNR_MAX_MARCH_BLOCKS;
-// What the hosted march tail needs on top of the lookup's own arguments.  The frame-constant part lives in the workspace (k_frame_init
+// What the hosted march tail needs on top of the lookup's own arguments.  The frame-constant part lives in the workspace (k_frame_begin
 // writes it there from its own arguments): the lookup kernels' argument block stays the size it had.
 struct HostedConst {
     const int32_t* qctr_all;      // [2][kQueueCtrs]: per iteration parity, [0] rays queued
@@ -88,20 +88,60 @@ __device__ __forceinline__ int schedule_n_step(int N, int n_alive) {  // nerf/re
     return n_alive > 0 ? max(min(N / n_alive, 8), 1) : 1;
 }
 
-__global__ void __launch_bounds__(kRayBlock) k_frame_init(uint32_t N, const float* __restrict__ nears, int32_t* __restrict__ alive,
-                                                          float* __restrict__ rays_t, float* __restrict__ weights_sum, float* __restrict__ depth,
-                                                          float* __restrict__ image, FrameCtl* __restrict__ ctl, int32_t* __restrict__ counts,
-                                                          int32_t* __restrict__ scratch_hdr, int32_t* __restrict__ qctr_all, HostedConst hc,
-                                                          HostedConst* __restrict__ hc_out) {
+// A frame's first launch.  Per ray (thread i = processing slot i): the optional gather into processing order (pnr_nerf_frame_args::ray_order -- the frame
+// runs on copies of the per-ray inputs in that order and on outputs kept in that order, scattered back to ray ids at the end; per-ray results do not
+// depend on the slot a ray occupies (no perturbation on this path), and listing rays tile by tile (8x8 pixels per wave) keeps the 64 rays of a wave
+// spatially compact, which the hash-grid gathers and the march like), the optional near / far against the box (pnr_nerf_frame_args::aabb:
+// pnr_near_far_from_aabb's arithmetic, written by ray id as that op writes them), and the state "in front of iteration 0" as k_frame_march expects it
+// from a previous iteration: a full alive list whose chunks all survive (identity compaction), nothing marched yet.  (Three launches until round 5:
+// near/far from the caller, sort, init -- at an eighth of a frame each costs more in launch than in work.)
+struct FrameBegin {
+    const int32_t* order;                       // NULL: slot = ray id
+    const float *rays_o, *rays_d;
+    const float *nears_in, *fars_in;            // read when aabb == NULL
+    const float* aabb; float min_near;          // else: computed here ...
+    float *nears_out, *fars_out;                // ... and written by ray id
+    float *so, *sd, *sf;                        // order != NULL: the inputs in processing order (the near only seeds rays_t)
+    float* aux_zero; uint32_t aux_stride;       // PaletteNeRF: the frame's aux map (processing order), zeroed here; stride a multiple of 4 floats
+};
+__global__ void __launch_bounds__(kRayBlock) k_frame_begin(uint32_t N, FrameBegin fb, int32_t* __restrict__ alive,
+                                                           float* __restrict__ rays_t, float* __restrict__ weights_sum, float* __restrict__ depth,
+                                                           float* __restrict__ image, FrameCtl* __restrict__ ctl, int32_t* __restrict__ counts,
+                                                           int32_t* __restrict__ scratch_hdr, int32_t* __restrict__ qctr_all, HostedConst hc,
+                                                           HostedConst* __restrict__ hc_out) {
     const uint32_t i = blockIdx.x * kRayBlock + threadIdx.x;
     if (i < N) {
+        const uint32_t r = fb.order ? (uint32_t)fb.order[i] : i;
+        float near, far;
+        if (fb.order || fb.aabb) {
+            float o[3], d[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { o[k] = fb.rays_o[(size_t)r * 3 + k]; d[k] = fb.rays_d[(size_t)r * 3 + k]; }
+            if (fb.aabb) {
+                near_far_of(o[0], o[1], o[2], d[0], d[1], d[2], fb.aabb, fb.min_near, near, far);
+                fb.nears_out[r] = near; fb.fars_out[r] = far;
+            } else {
+                near = fb.nears_in[r]; far = fb.fars_in[r];
+            }
+            if (fb.order) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) { fb.so[i * 3 + k] = o[k]; fb.sd[i * 3 + k] = d[k]; }
+                fb.sf[i] = far;
+            }
+        } else {
+            near = fb.nears_in[r];
+        }
         alive[i] = (int32_t)i;   // the reference's arange (nerf/renderer.py:352)
-        rays_t[i] = nears[i];
+        rays_t[i] = near;
         weights_sum[i] = 0.0f; depth[i] = 0.0f;
         image[i * 3] = 0.0f; image[i * 3 + 1] = 0.0f; image[i * 3 + 2] = 0.0f;
     }
-    // The state "in front of iteration 0" as k_frame_march expects it from a previous iteration: a full alive list whose chunks all
-    // survive (identity compaction), nothing marched yet.
+    if (fb.aux_zero && blockIdx.x * kRayBlock < N) {    // the workgroup's rows are one contiguous run: 16 bytes per lane and store, coalesced
+        const uint32_t row0 = blockIdx.x * kRayBlock, rows = N - row0 < kRayBlock ? N - row0 : kRayBlock;
+        float4* base = reinterpret_cast<float4*>(fb.aux_zero + (size_t)row0 * fb.aux_stride);
+        const uint32_t n4 = rows * (fb.aux_stride / 4);
+        for (uint32_t k = threadIdx.x; k < n4; k += kRayBlock) base[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
     if (threadIdx.x == 0 && blockIdx.x * kRayBlock < N) counts[blockIdx.x] = (int32_t)(N - blockIdx.x * kRayBlock < kRayBlock ? N - blockIdx.x * kRayBlock : kRayBlock);
     if (i == 0) {
         FrameCtl c = {};
@@ -112,25 +152,13 @@ __global__ void __launch_bounds__(kRayBlock) k_frame_init(uint32_t N, const floa
         *hc_out = hc;
     }
 }
-
-// Optional processing order (pnr_nerf_frame_args::ray_order): the frame runs on copies of the per-ray inputs gathered into that
-// order and on outputs kept in that order, scattered back to ray ids at the end.  Per-ray results do not depend on the slot a
-// ray occupies (no perturbation on this path); listing rays tile by tile (8x8 pixels per wave) keeps the 64 rays of a wave
-// spatially compact, which the hash-grid gathers and the march like, and the copies keep every per-ray access coalesced.
-__global__ void __launch_bounds__(kRayBlock) k_frame_sort_inputs(uint32_t N, const int32_t* __restrict__ order, const float* __restrict__ rays_o,
-                                                                 const float* __restrict__ rays_d, const float* __restrict__ nears,
-                                                                 const float* __restrict__ fars, float* __restrict__ so, float* __restrict__ sd,
-                                                                 float* __restrict__ sn, float* __restrict__ sf) {
-    const uint32_t i = blockIdx.x * kRayBlock + threadIdx.x;
-    if (i >= N) return;
-    const uint32_t r = (uint32_t)order[i];
-#pragma unroll
-    for (int k = 0; k < 3; k++) { so[i * 3 + k] = rays_o[(size_t)r * 3 + k]; sd[i * 3 + k] = rays_d[(size_t)r * 3 + k]; }
-    sn[i] = nears[r]; sf[i] = fars[r];
-}
 // The epilogue of run_cuda (nerf/renderer.py:382-384) on request: the same fp32 operations as the torch expressions
 //   image + (1 - weights_sum).unsqueeze(-1) * bg_color ;  torch.clamp(depth - nears, min=0) / (fars - nears)
-struct FrameFinish { int on; float bg[3]; const float* bg_map; const float* nears; const float* fars; };
+struct FrameFinish {
+    int on; float bg[3]; const float* bg_map; const float* nears; const float* fars;
+    float* depth_raw;        // optional: the un-normalised depth by ray id (palette/renderer.py:522 depth_origin)
+    const FrameCtl* ctl;     // optional: the launch is a no-op unless this control block says the frame is done (the speculative launch behind a chunk)
+};
 __device__ __forceinline__ float finish_channel(const FrameFinish& f, float v, float ws, uint32_t ray, uint32_t ch) {
     const float t = 1.0f - ws;
     const float bg = f.bg_map ? f.bg_map[(size_t)ray * 3 + ch] : f.bg[ch];
@@ -140,23 +168,37 @@ __device__ __forceinline__ float finish_depth(const FrameFinish& f, float d, uin
     return fmaxf(d - f.nears[ray], 0.0f) / (f.fars[ray] - f.nears[ray]);
 }
 
+// The frame's last launch: outputs from processing order back to ray ids (order == NULL: in place, sws == ws, ...) and run_cuda's epilogue on request
+// (fin.on bit 0: image, bit 1: depth, bit 2: the aux row's first three columns = PaletteNeRF's direct_rgb, palette/renderer.py:529-540)
 template <uint32_t LANES>   // lanes per ray: 16 (32 for rows of more than 64 floats) with an aux row to move (float4 each), 4 without
 __global__ void __launch_bounds__(kRayBlock) k_frame_unsort_outputs(uint32_t N, const int32_t* __restrict__ order, const float* __restrict__ sws,
                                                                     const float* __restrict__ sdepth, const float* __restrict__ simage,
                                                                     const float* __restrict__ saux, uint32_t aux_stride, float* __restrict__ ws,
                                                                     float* __restrict__ depth, float* __restrict__ image, float* __restrict__ aux,
                                                                     FrameFinish fin) {
+    if (fin.ctl && !fin.ctl->done) return;
     const uint32_t i = (blockIdx.x * kRayBlock + threadIdx.x) / LANES, q = threadIdx.x % LANES;
     if (i >= N) return;
-    const uint32_t r = order ? (uint32_t)order[i] : i;   // order == nullptr: finish in place (sws == ws, ...)
+    const uint32_t r = order ? (uint32_t)order[i] : i;
     if (q == 0) {
         const float d = sdepth[i];
         if (order) ws[r] = sws[i];
+        if (fin.depth_raw) fin.depth_raw[r] = d;
         depth[r] = (fin.on & 2) ? finish_depth(fin, d, r) : d;
     }
     if (q < 3) { const float v = simage[(size_t)i * 3 + q]; image[(size_t)r * 3 + q] = (fin.on & 1) ? finish_channel(fin, v, sws[i], r, q) : v; }
-    if (saux && q * 4 < aux_stride)
-        *reinterpret_cast<float4*>(aux + (size_t)r * aux_stride + q * 4) = *reinterpret_cast<const float4*>(saux + (size_t)i * aux_stride + q * 4);
+    if (saux) {
+        if (q * 4 < aux_stride) {
+            float4 v = *reinterpret_cast<const float4*>(saux + (size_t)i * aux_stride + q * 4);
+            if (q == 0 && (fin.on & 4)) {
+                const float w = sws[i];
+                v.x = finish_channel(fin, v.x, w, r, 0); v.y = finish_channel(fin, v.y, w, r, 1); v.z = finish_channel(fin, v.z, w, r, 2);
+            }
+            *reinterpret_cast<float4*>(aux + (size_t)r * aux_stride + q * 4) = v;
+        }
+    } else if (aux && (fin.on & 4) && q < 3) {   // in place
+        aux[(size_t)r * aux_stride + q] = finish_channel(fin, aux[(size_t)r * aux_stride + q], sws[i], r, q);
+    }
 }
 
 // reference raymarching.cu:907-1011, n_alive / n_step from the control block; also writes the delta == 0
@@ -1081,7 +1123,7 @@ struct FrameWorkspace {
     float *s_o, *s_d, *s_near, *s_far, *s_ws, *s_depth, *s_image, *s_aux;  // ray_order: inputs / outputs in processing order
     int32_t* scratch;
     int32_t* partials[2];   // the march's per-workgroup sample counts (+ the hosted tail's): written by iteration i, summed by iteration i + 1
-    HostedConst* hosted;    // hosted march tail: frame constants (written by k_frame_init)
+    HostedConst* hosted;    // hosted march tail: frame constants (written by k_frame_begin)
     int32_t* qctr;          // straggler queue: two counter sets ...
     StragglerRec* qrecs;    // ... its records (one iteration's worth: a march launch fills it, the lookup launch that follows empties it) ...
     uint8_t* rowflag;       // ... and the per-row "belongs to a queued ray" flags
@@ -1181,15 +1223,12 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     FrameWorkspace w = carve(a->workspace, N, aux_stride, with_clip);
     if (a->workspace_bytes < w.bytes) return PNR_ERR_INVALID;
     const bool sorted = a->ray_order != nullptr;
-    const float *in_o = a->rays_o, *in_d = a->rays_d, *in_near = a->nears, *in_far = a->fars;
+    const float *in_o = a->rays_o, *in_d = a->rays_d, *in_far = a->fars;   // (the nears are only read by the first launch: rays_t)
     float *out_ws = a->weights_sum, *out_depth = a->depth, *out_image = a->image, *out_aux = pal ? pal->aux_map : nullptr;
     if (sorted) {
-        hipLaunchKernelGGL(k_frame_sort_inputs, dim3(cdiv(N, kRayBlock)), dim3(kRayBlock), 0, s, N, a->ray_order, a->rays_o, a->rays_d, a->nears, a->fars,
-                           w.s_o, w.s_d, w.s_near, w.s_far);
-        in_o = w.s_o; in_d = w.s_d; in_near = w.s_near; in_far = w.s_far;
+        in_o = w.s_o; in_d = w.s_d; in_far = w.s_far;
         out_ws = w.s_ws; out_depth = w.s_depth; out_image = w.s_image; out_aux = pal ? w.s_aux : nullptr;
     }
-    if (pal && hipMemsetAsync(out_aux, 0, (size_t)N * aux_stride * 4, s) != hipSuccess) return PNR_ERR_LAUNCH;
     const float* tables[3] = {a->embeddings, pal ? pal->embeddings_palette : nullptr, with_clip ? pal->embeddings_clip : nullptr};
     const uint32_t n_enc = pal ? (with_clip ? 3u : 2u) : 1u;
     const int aux_fused = (pal && g_opt_aux_fusion && pnr_palette_field_stages_aux(pal->num_basis, pal->clip_dim, pal->pred_clip)) ? 1 : 0;
@@ -1247,7 +1286,15 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     HostedConst hconst = {};
     hconst.qctr_all = w.qctr; hconst.qrecs = w.qrecs; hconst.rays_o = in_o; hconst.rays_d = in_d; hconst.bitfield = a->bitfield; hconst.mip = mip; hconst.p = mp;
     hconst.xyzs = w.xyzs; hconst.dirs = w.dirs; hconst.deltas = w.deltas; hconst.partials[0] = w.partials[0]; hconst.partials[1] = w.partials[1];
-    hipLaunchKernelGGL(k_frame_init, dim3(cdiv(N, kRayBlock)), dim3(kRayBlock), 0, s, N, in_near, w.alive[1], w.rays_t, out_ws, out_depth, out_image,
+    FrameBegin fb = {};
+    fb.order = a->ray_order; fb.rays_o = a->rays_o; fb.rays_d = a->rays_d; fb.nears_in = a->nears; fb.fars_in = a->fars;
+    fb.aabb = a->aabb; fb.min_near = a->min_near; fb.nears_out = a->nears; fb.fars_out = a->fars;
+    fb.so = w.s_o; fb.sd = w.s_d; fb.sf = w.s_far;
+    if (pal) {   // the aux map starts at zero (palette/renderer.py:436-441): inside the first launch when rows are float4-aligned
+        if ((aux_stride & 3u) == 0 && (reinterpret_cast<uintptr_t>(out_aux) & 15u) == 0) { fb.aux_zero = out_aux; fb.aux_stride = aux_stride; }
+        else if (hipMemsetAsync(out_aux, 0, (size_t)N * aux_stride * 4, s) != hipSuccess) return PNR_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(k_frame_begin, dim3(cdiv(N, kRayBlock)), dim3(kRayBlock), 0, s, N, fb, w.alive[1], w.rays_t, out_ws, out_depth, out_image,
                        w.ctl, counts_of(1), w.scratch, w.qctr, hconst, w.hosted);
     // optional live timing of the roofline kernel: HIP events on the launch stream around every k_frame_grid launch
     std::vector<hipEvent_t>& ev = dev_state.ev;
@@ -1257,6 +1304,25 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
         return ev[ev_used++];
     };
     const bool timing = a->kernel_ms != nullptr;
+    FrameFinish fin = {};
+    fin.on = a->finish; fin.bg[0] = a->bg_color[0]; fin.bg[1] = a->bg_color[1]; fin.bg[2] = a->bg_color[2];
+    fin.bg_map = a->bg_map; fin.nears = a->nears; fin.fars = a->fars;   // indexed by ray id
+    fin.depth_raw = a->depth_raw;
+    auto launch_last = [&](const FrameCtl* done_ctl) {
+        fin.ctl = done_ctl;
+        if (sorted && pal && aux_stride > 64)
+            hipLaunchKernelGGL(k_frame_unsort_outputs<32>, dim3(cdiv(N, kRayBlock / 32)), dim3(kRayBlock), 0, s, N, a->ray_order, w.s_ws, w.s_depth, w.s_image,
+                               w.s_aux, aux_stride, a->weights_sum, a->depth, a->image, pal->aux_map, fin);
+        else if (sorted && pal)
+            hipLaunchKernelGGL(k_frame_unsort_outputs<16>, dim3(cdiv(N * 16, kRayBlock)), dim3(kRayBlock), 0, s, N, a->ray_order, w.s_ws, w.s_depth, w.s_image,
+                               w.s_aux, aux_stride, a->weights_sum, a->depth, a->image, pal->aux_map, fin);
+        else if (sorted)
+            hipLaunchKernelGGL(k_frame_unsort_outputs<4>, dim3(cdiv(N * 4, kRayBlock)), dim3(kRayBlock), 0, s, N, a->ray_order, w.s_ws, w.s_depth, w.s_image,
+                               (const float*)nullptr, 0u, a->weights_sum, a->depth, a->image, (float*)nullptr, fin);
+        else if (fin.on || fin.depth_raw)   // unsorted frame: the same kernel in place
+            hipLaunchKernelGGL(k_frame_unsort_outputs<4>, dim3(cdiv(N * 4, kRayBlock)), dim3(kRayBlock), 0, s, N, (const int32_t*)nullptr, a->weights_sum, a->depth,
+                               a->image, (const float*)nullptr, aux_stride, a->weights_sum, a->depth, a->image, pal ? pal->aux_map : (float*)nullptr, fin);
+    };
     uint32_t alive_ub = N;   // host-side upper bound of n_alive (it only shrinks)
     // Iterations enqueued between two looks at the control block.  Consecutive frames of a camera path need nearly the same
     // number of iterations, so the first chunk is the previous frame's count (one look per frame when the guess holds; launches
@@ -1273,7 +1339,7 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     for (;;) {
         for (uint32_t k = 0; k < chunk; k++, iter++) {
             FrameCtl* cur = w.ctl + (iter & 1);                 // this iteration's control block, written by its march launch
-            const FrameCtl* prev = w.ctl + ((iter + 1) & 1);    // the previous iteration's (k_frame_init's in front of iteration 0)
+            const FrameCtl* prev = w.ctl + ((iter + 1) & 1);    // the previous iteration's (k_frame_begin's in front of iteration 0)
             int32_t* alive_in = w.alive[iter & 1];              // this iteration's compacted list (the march writes it, the composite punches holes)
             const int32_t* alive_prev = w.alive[(iter + 1) & 1];
             const uint32_t ray_blocks = cdiv(alive_ub, kRayBlock);
@@ -1371,28 +1437,20 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
         // wait for THIS read-back, not for the stream: another host thread may already have queued the next frame behind it (pipeline.FramesInFlight
         // with a shared stream: frames back to back without the host's gap between them, kernels never overlapping)
         if (!dev_state.done_ev && hipEventCreateWithFlags(&dev_state.done_ev, hipEventDisableTiming) != hipSuccess) return PNR_ERR_LAUNCH;
-        if (hipEventRecord(dev_state.done_ev, s) != hipSuccess || hipEventSynchronize(dev_state.done_ev) != hipSuccess) return PNR_ERR_LAUNCH;
+        if (hipEventRecord(dev_state.done_ev, s) != hipSuccess) return PNR_ERR_LAUNCH;
+        // The frame's last launch goes out BEHIND the read-back and BEFORE the host waits for it: the kernel looks at the same control block and does
+        // nothing unless the frame is done, so a chunk that fell short costs an empty launch -- and when the guess holds (nearly always along a camera
+        // path) the host wakes up, returns and prepares the caller's next frame while this launch runs, instead of launching it after waking up
+        // (an eighth of the garden frame: 0.40 of 2.4 ms were the host's turnaround between frames).  The in-place finish of an unsorted frame is
+        // not idempotent across looks either way: guarded by the same flag.
+        launch_last(w.ctl + ((iter - 1) & 1));
+        if (hipEventSynchronize(dev_state.done_ev) != hipSuccess) return PNR_ERR_LAUNCH;     // (polling hipEventQuery instead measured the same: the runtime's wait already spins)
         if (host_ctl->done) break;
         alive_ub = (uint32_t)host_ctl->n_alive;
         if (looks == 0) chunk = predicted_iterations ? 4u : 8u;
         if (++looks >= 4 && chunk < 64) chunk *= 2;
     }
     predicted_iterations = (uint32_t)host_ctl->iterations;
-    FrameFinish fin;
-    fin.on = a->finish; fin.bg[0] = a->bg_color[0]; fin.bg[1] = a->bg_color[1]; fin.bg[2] = a->bg_color[2];
-    fin.bg_map = a->bg_map; fin.nears = a->nears; fin.fars = a->fars;   // indexed by ray id
-    if (sorted && pal && aux_stride > 64)
-        hipLaunchKernelGGL(k_frame_unsort_outputs<32>, dim3(cdiv(N, kRayBlock / 32)), dim3(kRayBlock), 0, s, N, a->ray_order, w.s_ws, w.s_depth, w.s_image,
-                           w.s_aux, aux_stride, a->weights_sum, a->depth, a->image, pal->aux_map, fin);
-    else if (sorted && pal)
-        hipLaunchKernelGGL(k_frame_unsort_outputs<16>, dim3(cdiv(N * 16, kRayBlock)), dim3(kRayBlock), 0, s, N, a->ray_order, w.s_ws, w.s_depth, w.s_image,
-                           w.s_aux, aux_stride, a->weights_sum, a->depth, a->image, pal->aux_map, fin);
-    else if (sorted)
-        hipLaunchKernelGGL(k_frame_unsort_outputs<4>, dim3(cdiv(N * 4, kRayBlock)), dim3(kRayBlock), 0, s, N, a->ray_order, w.s_ws, w.s_depth, w.s_image,
-                           (const float*)nullptr, 0u, a->weights_sum, a->depth, a->image, (float*)nullptr, fin);
-    else if (fin.on)   // unsorted frame: the same kernel in place
-        hipLaunchKernelGGL(k_frame_unsort_outputs<4>, dim3(cdiv(N * 4, kRayBlock)), dim3(kRayBlock), 0, s, N, (const int32_t*)nullptr, a->weights_sum, a->depth,
-                           a->image, (const float*)nullptr, 0u, a->weights_sum, a->depth, a->image, (float*)nullptr, fin);
     if (timing) {  // only the iterations that did work (the tail of the last chunk are no-op launches)
         float total = 0.0f;
         uint32_t counted = 0;

@@ -9,6 +9,28 @@
 
 namespace pnr {
 
+// near / far of one ray against an axis-aligned box (reference raymarching.cu:95-148): pnr_near_far_from_aabb's kernel and the frame loops' first
+// kernel (pnr_nerf_frame_args::aabb) both call this, so the two ways of getting a frame's nears / fars agree bit for bit
+__device__ __forceinline__ void near_far_of(float ox, float oy, float oz, float dx, float dy, float dz, const float* __restrict__ aabb, float min_near,
+                                            float& near_out, float& far_out) {
+    const float rdx = 1.0f / dx, rdy = 1.0f / dy, rdz = 1.0f / dz;
+    float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx, tmp;
+    if (near > far) { tmp = near; near = far; far = tmp; }
+    float ny = (aabb[1] - oy) * rdy, fy = (aabb[4] - oy) * rdy;
+    if (ny > fy) { tmp = ny; ny = fy; fy = tmp; }
+    if (near > fy || ny > far) { near_out = far_out = FLT_MAX; return; }
+    if (ny > near) near = ny;
+    if (fy < far) far = fy;
+    float nz = (aabb[2] - oz) * rdz, fz = (aabb[5] - oz) * rdz;
+    if (nz > fz) { tmp = nz; nz = fz; fz = tmp; }
+    if (near > fz || nz > far) { near_out = far_out = FLT_MAX; return; }
+    if (nz > near) near = nz;
+    if (fz < far) far = fz;
+    if (near < min_near) near = min_near;
+    near_out = near;
+    far_out = far;
+}
+
 // ------------------------------------------------------------------------------------------
 // per-ray constants + the march state machine (reference raymarching.cu:336-349, 362-403)
 //

@@ -28,29 +28,13 @@ __global__ void __launch_bounds__(256) k_build_mip(const unsigned long long* __r
 // utils
 // ------------------------------------------------------------------------------------------
 
-// reference raymarching.cu:95-148
+// reference raymarching.cu:95-148 (near_far_of: march_core.hpp, shared with the frame loops' first kernel)
 __global__ void __launch_bounds__(kBlock) k_near_far(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                      const float* __restrict__ aabb, uint32_t N, float min_near,
                                                      float* __restrict__ nears, float* __restrict__ fars) {
     const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
     if (n >= N) return;
-    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
-    const float rdx = 1.0f / rays_d[n * 3], rdy = 1.0f / rays_d[n * 3 + 1], rdz = 1.0f / rays_d[n * 3 + 2];
-    float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx, tmp;
-    if (near > far) { tmp = near; near = far; far = tmp; }
-    float ny = (aabb[1] - oy) * rdy, fy = (aabb[4] - oy) * rdy;
-    if (ny > fy) { tmp = ny; ny = fy; fy = tmp; }
-    if (near > fy || ny > far) { nears[n] = fars[n] = FLT_MAX; return; }
-    if (ny > near) near = ny;
-    if (fy < far) far = fy;
-    float nz = (aabb[2] - oz) * rdz, fz = (aabb[5] - oz) * rdz;
-    if (nz > fz) { tmp = nz; nz = fz; fz = tmp; }
-    if (near > fz || nz > far) { nears[n] = fars[n] = FLT_MAX; return; }
-    if (nz > near) near = nz;
-    if (fz < far) far = fz;
-    if (near < min_near) near = min_near;
-    nears[n] = near;
-    fars[n] = far;
+    near_far_of(rays_o[n * 3], rays_o[n * 3 + 1], rays_o[n * 3 + 2], rays_d[n * 3], rays_d[n * 3 + 1], rays_d[n * 3 + 2], aabb, min_near, nears[n], fars[n]);
 }
 
 // reference raymarching.cu:166-201
@@ -588,7 +572,7 @@ using namespace pnr;
 
 extern "C" {
 
-int pnr_abi_version(void) { return 5; }
+int pnr_abi_version(void) { return 6; }
 
 int pnr_set_option(const char* name, int value) {
     if (!name) return PNR_ERR_INVALID;

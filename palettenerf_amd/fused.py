@@ -3,12 +3,13 @@ hash-grid lookup feeding the MFMA tiny-MLP kernel directly, no permute/copy, no 
 import ctypes
 import math
 import os
+import threading
 
 import numpy as np
 import torch
 
 from . import _lib
-from ._torch_glue import call, ptr, require
+from ._torch_glue import call, ptr, require, stream_ptr
 
 _u32, _f32, _int = ctypes.c_uint32, ctypes.c_float, ctypes.c_int
 
@@ -154,11 +155,29 @@ def tile_ray_order(pixel_index, W, tile=8):
 PARANOID = os.environ.get("PNR_PARANOID_CACHE") == "1"   # rebuild every derived blob on every use (debugging aid for code that writes through `.data`)
 
 
+_held_keys = threading.local()     # .memo: {id(tensor): key} while a frame / field call holds its answers (_PrecisionGuard._held), else absent / None
+
+
 def _pkey(p):
     """Identity of a parameter's CURRENT value as far as torch can tell: the Parameter object, its storage and its version counter.
     In-place torch ops, optimizer steps and load_state_dict bump the version; replacing the Parameter changes the identity.  Writes through
-    `p.data` (torch_ema's copy_to / restore, `p.data.uniform_()`) change neither: call invalidate_fused_caches(model) after those."""
-    return (id(p), p.data_ptr(), p._version)
+    `p.data` (torch_ema's copy_to / restore, `p.data.uniform_()`) change neither: call invalidate_fused_caches(model) after those.
+    Inside a held call a tensor's key is formed once (the source watch, the guard and the packer each ask for the same twenty tensors)."""
+    memo = getattr(_held_keys, "memo", None)
+    if memo is None:
+        return (id(p), p.data_ptr(), p._version)
+    k = memo.get(id(p))
+    if k is None:
+        k = memo[id(p)] = (id(p), p.data_ptr(), p._version)
+    return k
+
+
+def _weight_of(module, *path):
+    """module.<path[0]>[path[1]]....weight through the modules' own dictionaries: what `m.sigma_net[0].weight` returns, without nn.Module.__getattr__'s
+    fallback chain and ModuleList's index arithmetic per step (a frame asks for a dozen weights; the walk was a tenth of its host time)."""
+    for name in path:
+        module = module._modules[str(name)]
+    return module._parameters["weight"]
 
 
 def invalidate_fused_caches(model):
@@ -218,7 +237,7 @@ class _PrecisionGuard:
         raise NotImplementedError
 
     def _guard_weights(self):
-        return self._weights()
+        return self._w()
 
     def _guard_bound(self, tmax, scales):
         raise NotImplementedError
@@ -231,12 +250,28 @@ class _PrecisionGuard:
         @contextlib.contextmanager
         def hold():
             self._guard_hold = True
+            outer = getattr(_held_keys, "memo", None)
+            if outer is None:
+                _held_keys.memo = {}
             try:
                 yield
             finally:
                 self._guard_hold = False
                 self._guard_held = None
+                self._weights_held = None
+                if outer is None:
+                    _held_keys.memo = None
         return hold()
+
+    def _w(self):
+        """self._weights(), looked up once per held call (a dozen nn.Module attribute walks, asked for by the guard, the packer and the source watch)."""
+        held = self.__dict__.get("_weights_held")
+        if held is not None:
+            return held
+        ws = self._weights()
+        if self.__dict__.get("_guard_hold"):
+            self._weights_held = ws
+        return ws
 
     def _guard(self):
         held = self.__dict__.get("_guard_held")
@@ -324,9 +359,11 @@ class _SourceWatch:
         if getattr(self, "_watch_dev", None) is None or self._watch_dev.device != dev or self._watch_dev.numel() < n:
             self._watch_dev = torch.zeros(max(n, 24), dtype=torch.int64, device=dev)
             self._watch_host = torch.zeros(max(n, 24), dtype=torch.int64).pin_memory()
-        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _ in srcs])
-        sizes = (ctypes.c_uint64 * n)(*[t.numel() * t.element_size() for t, _ in srcs])
-        strides = (_u32 * n)(*[int(st) for _, st in srcs])
+        if getattr(self, "_watch_args_key", None) != keys:     # (the keys hold the data pointers: same keys, same argument arrays)
+            self._watch_args = ((ctypes.c_void_p * n)(*[t.data_ptr() for t, _ in srcs]), (ctypes.c_uint64 * n)(*[t.numel() * t.element_size() for t, _ in srcs]),
+                                (_u32 * n)(*[int(st) for _, st in srcs]))
+            self._watch_args_key = keys
+        ptrs, sizes, strides = self._watch_args
         call("pnr_checksum", ptrs, sizes, strides, _u32(n), ptr(self._watch_dev))
         self._watch_host.copy_(self._watch_dev, non_blocking=True)     # complete once the frame's own read-back is (same stream)
         return record, n
@@ -345,6 +382,21 @@ class _SourceWatch:
         warnings.warn("fused field: parameters were rewritten behind torch's version counters (a `.data` write); the packed blobs were rebuilt and "
                       "the frame rendered again -- invalidate_fused_caches(model) after such writes avoids the double render")
         self.invalidate_caches()
+
+
+def _set_near_far(a, nears, fars, aabb, min_near, N, dev):
+    """nears / fars of a frame-args struct: given, or (aabb set, both None) left to the frame call's first launch (pnr_nerf_frame_args::aabb)."""
+    a.aabb = None
+    if nears is None or fars is None:
+        if aabb is None:
+            raise RuntimeError("render_frame needs nears / fars or the box they follow from (aabb)")
+        if not (aabb.is_cuda and aabb.dtype == torch.float32 and aabb.is_contiguous() and aabb.numel() == 6):
+            raise RuntimeError("aabb must be 6 contiguous fp32 values on the device")
+        nears = torch.empty(N, dtype=torch.float32, device=dev)
+        fars = torch.empty(N, dtype=torch.float32, device=dev)
+        a.aabb, a.min_near = aabb.data_ptr(), float(min_near)
+    a.nears, a.fars = nears.data_ptr(), fars.data_ptr()
+    return nears, fars
 
 
 def _set_finish(a, bg_color, N, mask):
@@ -391,19 +443,20 @@ class NeRFFieldFused(_PrecisionGuard, _SourceWatch):
 
     def _weights(self):
         m = self.model
-        return [m.sigma_net[0].weight, m.sigma_net[1].weight, m.color_net[0].weight, m.color_net[1].weight, m.color_net[2].weight]
+        return [_weight_of(m, "sigma_net", 0), _weight_of(m, "sigma_net", 1), _weight_of(m, "color_net", 0), _weight_of(m, "color_net", 1), _weight_of(m, "color_net", 2)]
 
     def invalidate_caches(self):
         self.versions = None
         self._emb_half = None
         self._guard_key = None
         self._watch_ref = None       # the next frame rebuilds every blob: its source checksums become the reference
+        self._guard_held = self._weights_held = None   # (a held call that retries asks again)
 
     def _guard_tables(self):
         return [self.model.encoder.embeddings]
 
     def _watched(self):
-        return [(w, 1) for w in self._weights()] + [(self.model.encoder.embeddings, TABLE_CHECK_STRIDE)]
+        return [(w, 1) for w in self._w()] + [(self.model.encoder.embeddings, TABLE_CHECK_STRIDE)]
 
     def _guard_bound(self, tmax, scales):
         ws = self._weights()
@@ -416,7 +469,7 @@ class NeRFFieldFused(_PrecisionGuard, _SourceWatch):
         return max(enc, h1, geo, c0, c1)
 
     def _pack(self, prec=None):
-        ws = self._weights()
+        ws = self._w()
         prec = self.effective_precision() if prec is None else prec
         versions = tuple(_pkey(w) for w in ws) + (prec,)
         if self.packed is None or versions != self.versions or PARANOID:
@@ -429,11 +482,16 @@ class NeRFFieldFused(_PrecisionGuard, _SourceWatch):
         return self.packed
 
     @torch.no_grad()
-    def render_frame(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color=None):
+    def render_frame(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color=None, aabb=None, min_near=0.0):
         """One inference frame through the device-driven loop (pnr_nerf_render_frame).  Returns
         (weights_sum [N], depth [N], image [N,3], stats dict).  bg_color None: raw accumulations (bg mix and depth normalisation are
         the caller's); a number, 3 numbers or an [N,3] tensor: the call also applies run_cuda's epilogue (image + (1 - ws) bg,
-        normalised depth) -- stats['finished'] says so."""
+        normalised depth) -- stats['finished'] says so.  aabb (device tensor of 6 floats) with nears = fars = None: the call computes
+        near / far in its first launch (near_far_from_aabb's arithmetic); stats['nears'], stats['fars'] hold them."""
+        with self._held():
+            return self._render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color, aabb, min_near)
+
+    def _render_frame(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color, aabb, min_near):
         from . import raymarching
         m = self.model
         N = rays_o.shape[0]
@@ -457,7 +515,7 @@ class NeRFFieldFused(_PrecisionGuard, _SourceWatch):
         a.table_dtype = 1 if self.table_half else 0
         a.N = N
         a.rays_o, a.rays_d = rays_o.data_ptr(), rays_d.data_ptr()
-        a.nears, a.fars = nears.data_ptr(), fars.data_ptr()
+        nears, fars = _set_near_far(a, nears, fars, aabb, min_near, N, dev)
         a.bitfield = m.density_bitfield.data_ptr()
         a.mip = mip.data_ptr() if mip is not None else None
         a.bound, a.C, a.H = float(m.bound), int(m.cascade), int(m.grid_size)
@@ -479,16 +537,16 @@ class NeRFFieldFused(_PrecisionGuard, _SourceWatch):
         finished = _set_finish(a, bg_color, N, 3)
         for t, name in ((rays_o, "rays_o"), (rays_d, "rays_d"), (nears, "nears"), (fars, "fars")):
             require(t, torch.float32, name)
-        rc = lib.pnr_nerf_render_frame(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        rc = lib.pnr_nerf_render_frame(ctypes.byref(a), stream_ptr())
         _lib.check(rc, "pnr_nerf_render_frame")
         if not self._watch_end(watch_state):
             self._watch_failed()
-            return self.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color=bg_color)
+            return self._render_frame(rays_o, rays_d, None if aabb is not None else nears, None if aabb is not None else fars, dt_gamma, max_steps, T_thresh, bg_color, aabb, min_near)
         if watch and stats[5]:
             self._note_overflow()
-            return self.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color=bg_color)
+            return self._render_frame(rays_o, rays_d, None if aabb is not None else nears, None if aabb is not None else fars, dt_gamma, max_steps, T_thresh, bg_color, aabb, min_near)
         return ws, depth, image, {"iterations": int(stats[0]), "rendered": int(stats[1]), "rows": int(stats[2]), "enqueued": int(stats[3]), "looks": int(stats[4]),
-                                  "grid_ms": float(kms[0]), "grid_launches": int(kms[1]), "finished": finished}
+                                  "grid_ms": float(kms[0]), "grid_launches": int(kms[1]), "finished": finished, "nears": nears, "fars": fars}
 
     @torch.no_grad()
     def __call__(self, x, d):
@@ -575,11 +633,10 @@ class PaletteFieldFused(_PrecisionGuard, _SourceWatch):
 
     def _weights(self):
         m = self.model
-        ws = [m.sigma_net[0].weight, m.sigma_net[1].weight, m.diff_net[0].weight, m.diff_net[1].weight, m.diff_net[2].weight,
-              m.color_net[0].weight, m.color_net[1].weight, m.color_net[2].weight, m.basis_net[0].weight, m.basis_net[1].weight,
-              m.offsets_radiance_net.weight, m.omega_net[0].weight]
+        ws = [_weight_of(m, *path) for path in (("sigma_net", 0), ("sigma_net", 1), ("diff_net", 0), ("diff_net", 1), ("diff_net", 2), ("color_net", 0), ("color_net", 1),
+                                                ("color_net", 2), ("basis_net", 0), ("basis_net", 1), ("offsets_radiance_net",), ("omega_net", 0))]
         if self.pred_clip:
-            ws += [m.clip_net[0].weight, m.clip_net[1].weight]
+            ws += [_weight_of(m, "clip_net", 0), _weight_of(m, "clip_net", 1)]
         return ws
 
     def _tables(self):
@@ -591,9 +648,10 @@ class PaletteFieldFused(_PrecisionGuard, _SourceWatch):
         self.versions = None
         self._pair_key = self._triple_key = self._guard_key = None
         self._watch_ref = None       # the next frame rebuilds every blob: its source checksums become the reference
+        self._guard_held = self._weights_held = None   # (a held call that retries asks again)
 
     def _watched(self):
-        return [(w, 1) for w in self._weights() + self._tables()] + [(t, TABLE_CHECK_STRIDE) for t in self._guard_tables()]
+        return [(w, 1) for w in self._w() + self._tables()] + [(t, TABLE_CHECK_STRIDE) for t in self._guard_tables()]
 
     def _guard_tables(self):
         m = self.model
@@ -619,7 +677,7 @@ class PaletteFieldFused(_PrecisionGuard, _SourceWatch):
         return max(sites)
 
     def _pack(self, prec=None):
-        ws = self._weights()
+        ws = self._w()
         prec = self.effective_precision() if prec is None else prec
         versions = tuple(_pkey(w) for w in ws + self._tables()) + (prec,)
         if self.packed is None or versions != self.versions or PARANOID:
@@ -721,9 +779,16 @@ class PaletteFieldFused(_PrecisionGuard, _SourceWatch):
             self._triple, self._triple_key = out, key
         return self._triple
 
-    def render_frame(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh):
+    def render_frame(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color=None, aabb=None, min_near=0.0):
         """One PaletteNeRF inference frame through the device-driven loop (pnr_palette_render_frame).
-        Returns (weights_sum [N], depth [N], image [N,3], aux_map [N, aux_channels], stats); raw accumulations."""
+        Returns (weights_sum [N], depth [N], image [N,3], aux_map [N, aux_channels], stats).  bg_color None: raw accumulations; a number, 3 numbers
+        or an [N,3] tensor: the call's last launch also applies run_cuda's epilogue (palette/renderer.py:520-540: image and aux_map[:, 0:3] = direct_rgb
+        blended with the background, depth normalised, the raw depth kept in stats['depth_raw']) -- stats['finished'] says so.  aabb with
+        nears = fars = None: near / far computed by the call's first launch (stats['nears'], stats['fars'])."""
+        with torch.no_grad(), self._held():
+            return self._render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color, aabb, min_near)
+
+    def _render_frame(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color, aabb, min_near):
         from . import raymarching
         m = self.model
         N = rays_o.shape[0]
@@ -753,7 +818,7 @@ class PaletteFieldFused(_PrecisionGuard, _SourceWatch):
         a = p.base
         a.N = N
         a.rays_o, a.rays_d = rays_o.data_ptr(), rays_d.data_ptr()
-        a.nears, a.fars = nears.data_ptr(), fars.data_ptr()
+        nears, fars = _set_near_far(a, nears, fars, aabb, min_near, N, dev)
         a.bitfield = m.density_bitfield.data_ptr()
         a.mip = mip.data_ptr() if mip is not None else None
         a.bound, a.C, a.H = float(m.bound), int(m.cascade), int(m.grid_size)
@@ -772,6 +837,9 @@ class PaletteFieldFused(_PrecisionGuard, _SourceWatch):
         a.kernel_ms = ctypes.cast(kms, ctypes.c_void_p) if getattr(self, "time_grid_kernel", False) else None
         order = getattr(self, "ray_order", None)
         a.ray_order = order.data_ptr() if order is not None and order.numel() == N else None
+        finished = _set_finish(a, bg_color, N, 7)
+        depth_raw = torch.empty(N, dtype=torch.float32, device=dev) if finished else None
+        a.depth_raw = depth_raw.data_ptr() if finished else None
         p.embeddings_palette = require(m.encoder_palette.embeddings.detach(), torch.float32, "embeddings").data_ptr()
         p.embeddings_clip = require(m.encoder_clip.embeddings.detach(), torch.float32, "embeddings").data_ptr() if self.pred_clip else None
         p.num_basis, p.clip_dim, p.pred_clip = self.nb, self.clip_dim, int(self.pred_clip)
@@ -788,16 +856,18 @@ class PaletteFieldFused(_PrecisionGuard, _SourceWatch):
         a.table_dtype = 1 if self.table_half else 0
         for t, name in ((rays_o, "rays_o"), (rays_d, "rays_d"), (nears, "nears"), (fars, "fars")):
             require(t, torch.float32, name)
-        rc = lib.pnr_palette_render_frame(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        rc = lib.pnr_palette_render_frame(ctypes.byref(p), stream_ptr())
         _lib.check(rc, "pnr_palette_render_frame")
+        again = (None if aabb is not None else nears, None if aabb is not None else fars)
         if not self._watch_end(watch_state):
             self._watch_failed()
-            return self.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh)
+            return self._render_frame(rays_o, rays_d, *again, dt_gamma, max_steps, T_thresh, bg_color, aabb, min_near)
         if watch and stats[5]:
             self._note_overflow()
-            return self.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh)
+            return self._render_frame(rays_o, rays_d, *again, dt_gamma, max_steps, T_thresh, bg_color, aabb, min_near)
         return ws, depth, image, aux_map, {"iterations": int(stats[0]), "rendered": int(stats[1]), "rows": int(stats[2]), "enqueued": int(stats[3]), "looks": int(stats[4]),
-                                           "grid_ms": float(kms[0]), "grid_launches": int(kms[1])}
+                                           "grid_ms": float(kms[0]), "grid_launches": int(kms[1]), "finished": finished, "depth_raw": depth_raw,
+                                           "nears": nears, "fars": fars}
 
     @torch.no_grad()
     def network_forward(self, x, d):

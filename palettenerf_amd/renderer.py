@@ -435,7 +435,10 @@ class NeRFRenderer(_OccupancyMaintenance, _RendererBase):
         if rays_gt is not None:
             rays_gt = rays_gt.contiguous().view(-1, 3)
         N = rays_o.shape[0]
-        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer, self.min_near)
+        aabb = self.aabb_train if self.training else self.aabb_infer
+        # the device-driven frame computes near / far inside its own first launch (same arithmetic, one launch and one operator call less per frame)
+        native_frame = not self.training and self.march_mode == "native" and rays_o.is_cuda and aabb.is_cuda
+        nears, fars = (None, None) if native_frame else raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
         if self.bg_radius > 0:
             sph = raymarching.sph_from_ray(rays_o, rays_d, self.bg_radius)
             bg_color = self.background(sph, rays_d)
@@ -479,9 +482,11 @@ class NeRFRenderer(_OccupancyMaintenance, _RendererBase):
             was_half = self._fused.table_half
             self._fused.table_half = was_half or torch.is_autocast_enabled()
             try:
-                weights_sum, depth_acc, image_acc, stats = self._fused.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color=bg_color)
+                weights_sum, depth_acc, image_acc, stats = self._fused.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color=bg_color,
+                                                                                    aabb=aabb if native_frame else None, min_near=self.min_near)
             finally:
                 self._fused.table_half = was_half
+            nears, fars = stats["nears"], stats["fars"]
             if stats["finished"]:   # the frame call applied the epilogue below itself (same fp32 operations, one launch less each)
                 image, depth = image_acc, depth_acc
             else:
@@ -651,7 +656,15 @@ class PaletteRenderer(_RendererBase):
         N = rays_o.shape[0]
         device = rays_o.device
         nb, clip_dim = self.num_basis, self.opt.clip_dim
-        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer, self.min_near)
+        aabb = self.aabb_train if self.training else self.aabb_infer
+        # under fp16 autocast only the native loop takes the fused path (fp16 tables, fp32-accurate field); it has no clip-head variant there
+        autocast_ok = not torch.is_autocast_enabled() or (self.march_mode == "native" and not perturb and not self.opt.pred_clip)
+        # RegionEdit and the Stylizer run inside the fused field kernel's epilogue (pnr_palette_edit): editing costs no extra launch
+        use_fused = not self.training and bool(getattr(self, "fused_field", False)) and autocast_ok
+        native = use_fused and self.march_mode == "native" and not perturb
+        # the device-driven frame computes near / far inside its own first launch (same arithmetic, one launch and one operator call less per frame)
+        native_near_far = native and rays_o.is_cuda and aabb.is_cuda
+        nears, fars = (None, None) if native_near_far else raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
         if self.bg_radius > 0:
             sph = raymarching.sph_from_ray(rays_o, rays_d, self.bg_radius)
             bg_color = self.background(sph, rays_d)
@@ -735,13 +748,8 @@ class PaletteRenderer(_RendererBase):
             return results
 
         f32 = dict(dtype=torch.float32, device=device)
-        # under fp16 autocast only the native loop takes the fused path (fp16 tables, fp32-accurate field); it has no clip-head variant there
-        autocast_ok = not torch.is_autocast_enabled() or (self.march_mode == "native" and not perturb and not self.opt.pred_clip)
-        # RegionEdit and the Stylizer run inside the fused field kernel's epilogue (pnr_palette_edit): editing costs no extra launch
-        use_fused = bool(getattr(self, "fused_field", False)) and autocast_ok
         if use_fused and self.stylizer is not None and not gui_mode:
             raise RuntimeError("the Stylizer renders in gui_mode only (palette/renderer.py:481-488 defines no basis maps for it)")
-        native = use_fused and self.march_mode == "native" and not perturb
         if use_fused:
             if getattr(self, "_fused", None) is None:
                 from .fused import PaletteFieldFused
@@ -806,15 +814,19 @@ class PaletteRenderer(_RendererBase):
             was_half = self._fused.table_half
             self._fused.table_half = was_half or torch.is_autocast_enabled()     # -O mode: fp16 tables with the reference's half interpolation
             try:
-                ws_n, depth_n, image_n, aux_map, stats = self._fused.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh)
+                ws_n, depth_n, image_n, aux_map, stats = self._fused.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color=bg_color,
+                                                                                  aabb=aabb if native_near_far else None, min_near=self.min_near)
             finally:
                 self._fused.table_half = was_half
+            nears, fars = stats["nears"], stats["fars"]
+            finished = stats["finished"]    # the frame call's last launch applied the epilogue below itself (same fp32 operations; eleven launches less)
             st = _MarchState.__new__(_MarchState)
             st.weights_sum, st.depth, st.image, st.n_samples = ws_n, depth_n, image_n, stats["rows"]
             st.rendered = torch.tensor([stats["rendered"]], dtype=torch.int64)   # host tensor: the count came back with the control block
             results["iterations"], results["grid_ms"], results["grid_launches"] = stats["iterations"], stats["grid_ms"], stats["grid_launches"]
             results["host_looks"] = stats["looks"]
         else:
+            finished = False
             st = self._infer_loop(rays_o, rays_d, nears, fars, perturb, dt_gamma, max_steps, shade_fused if use_fused else shade)
         if use_fused:  # unpack the composited aux row into the reference's maps
             direct_rgb_map, view_dep_rgb_map = aux_map[:, 0:3], aux_map[:, 3:6]
@@ -824,9 +836,12 @@ class PaletteRenderer(_RendererBase):
             if self._fused.clip_dim == clip_dim:
                 clip_feat_map = aux_map[:, 6 + 7 * nb:6 + 7 * nb + clip_dim]
         weights_sum = st.weights_sum
-        image = st.image + (1 - weights_sum).unsqueeze(-1) * bg_color
-        depth_origin = st.depth.clone()
-        depth = torch.clamp(st.depth - nears, min=0) / (fars - nears)
+        if finished:
+            image, depth, depth_origin = st.image, st.depth, stats["depth_raw"]
+        else:
+            image = st.image + (1 - weights_sum).unsqueeze(-1) * bg_color
+            depth_origin = st.depth.clone()
+            depth = torch.clamp(st.depth - nears, min=0) / (fars - nears)
         results["depth"] = depth.view(*prefix)
         results["depth_origin"] = depth_origin.view(*prefix)
         results["image"] = image.view(*prefix, 3)
@@ -835,7 +850,7 @@ class PaletteRenderer(_RendererBase):
         results["n_samples"] = st.n_samples
         results["rendered"] = st.rendered
         if not gui_mode:
-            results["direct_rgb"] = (direct_rgb_map + (1 - weights_sum).unsqueeze(-1) * bg_color).view(*prefix, 3)
+            results["direct_rgb"] = (direct_rgb_map if finished else direct_rgb_map + (1 - weights_sum).unsqueeze(-1) * bg_color).reshape(*prefix, 3)
             results["view_dep_rgb"] = view_dep_rgb_map.reshape(*prefix, 3)
             results["basis_rgb"] = basis_rgb_map.reshape(*prefix, nb * 3)
             results["unscaled_basis_rgb"] = unscaled_basis_rgb_map.reshape(*prefix, nb * 3)

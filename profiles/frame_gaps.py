@@ -6,7 +6,7 @@ import sys
 
 c = sqlite3.connect(sys.argv[1])
 rows = list(c.execute("select name, start, end from kernels order by start"))
-starts = [i for i, r in enumerate(rows) if "k_frame_sort_inputs" in r[0]] or [i for i, r in enumerate(rows) if "k_frame_init" in r[0]]
+starts = [i for i, r in enumerate(rows) if "k_frame_begin" in r[0]] or [i for i, r in enumerate(rows) if "k_frame_sort_inputs" in r[0]] or [i for i, r in enumerate(rows) if "k_frame_init" in r[0]]
 ends = [i for i, r in enumerate(rows) if "k_frame_unsort" in r[0]]
 frames = []
 for s in starts:

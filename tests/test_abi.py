@@ -167,3 +167,37 @@ def test_training_entry_points_validate_without_gpu():
     from palettenerf_amd import _lib as L
     names = [f[0] for f in L.PaletteFieldArgs._fields_]
     assert names[-6:] == ["rays_t", "weights_sum_rw", "depth", "image", "rays_alive_rw", "counts_cur"] and L.PaletteFieldArgs().rays_t is None
+
+
+def test_ctypes_mirrors_have_the_layout_gcc_gives_the_header_structs(tmp_path):
+    """Every argument struct of include/pnr.h against its ctypes mirror (palettenerf_amd/_lib.py): size and the offset of EVERY field, as gcc lays the
+    header's struct out -- a field added on one side only (or in another place) would shift what the library reads without any error."""
+    import subprocess
+    from palettenerf_amd import _lib
+    pairs = {"pnr_adam_tensor": _lib.AdamTensor, "pnr_adam_scalars": _lib.AdamScalars, "pnr_mlp_desc": _lib.MlpDesc, "pnr_occupancy_args": _lib.OccupancyArgs,
+             "pnr_nerf_frame_args": _lib.NerfFrameArgs, "pnr_palette_edit": _lib.PaletteEdit, "pnr_palette_frame_args": _lib.PaletteFrameArgs,
+             "pnr_palette_weights": _lib.PaletteWeights, "pnr_palette_field_args": _lib.PaletteFieldArgs, "pnr_train_loss_args": _lib.TrainLossArgs}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "pnr.h"', 'int main(void) {']
+    for cname, mirror in pairs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, *_ in mirror._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])     # (a field name the header lacks fails to compile)
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, mirror in pairs.items():
+        assert int(got[cname]) == ctypes.sizeof(mirror), cname
+        for fname, *_ in mirror._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(mirror, fname).offset, f"{cname}.{fname}"
+    # and the header has no field the mirror lacks: the sizes agree (above) and every mirrored field sits where the header puts it, so a missing field
+    # could only hide in tail padding -- count the members gcc sees against the mirror's
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "pnr.h")).read(), flags=re.S)
+    for cname, mirror in pairs.items():
+        m = re.search(r"typedef struct(?: \w+)? \{([^}]*)\} " + cname + ";", hdr)
+        assert m, cname
+        body = re.sub(r"\[[^\]]*\]", "", m.group(1))
+        n_members = sum(len(decl.split(",")) for decl in body.split(";") if decl.strip())
+        assert n_members == len(mirror._fields_), (cname, n_members, len(mirror._fields_))

@@ -926,3 +926,51 @@ def test_palette_frame_f16x2_is_inside_the_colour_contract(cuda):
         m._fused.precision = 1
         e1 = m.render(ro, rd, **kw)
     assert torch.equal(e1["image"], e2["image"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["nerf", "palette"])
+@pytest.mark.parametrize("sorted_rays", [True, False])
+def test_frame_call_computes_near_far_and_epilogue_itself(cuda, kind, sorted_rays):
+    """pnr_{nerf,palette}_frame_args::aabb / finish / depth_raw (round 5): the frame call's first launch computes near / far (near_far_from_aabb's
+    arithmetic, raymarching.cu:95-148) and its last launch applies run_cuda's epilogue (nerf/renderer.py:382-384, palette/renderer.py:520-540:
+    background blend of image and direct_rgb, depth normalisation, depth_origin).  Bit for bit what the operator call and the torch expressions give
+    around a frame call that is handed nears / fars and asked for raw accumulations -- with a ray order (gathered copies) and without (in place)."""
+    from palettenerf_amd.fused import NeRFFieldFused, PaletteFieldFused, tile_ray_order
+    if kind == "nerf":
+        m = network.NeRFNetwork(bound=2, cuda_ray=True, min_near=0.05)
+    else:
+        m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True, density_scale=100.0, min_near=0.05)
+    scene.seed_field_(m, 0)
+    m = m.to(cuda).eval()
+    m.density_grid.copy_(torch.from_numpy(scene.brick_density_grid()).to(cuda))
+    raymarching.packbits(m.density_grid, 0.5, m.density_bitfield)
+    f = (NeRFFieldFused if kind == "nerf" else PaletteFieldFused)(m)
+    H, W = 96, 128
+    ro, rd = scene.get_rays(torch.from_numpy(scene.lookat_pose(azimuth_deg=25.0))[None], scene.intrinsics_from_fov(H, W), H, W)
+    ro, rd = ro[0].to(cuda).contiguous(), rd[0].to(cuda).contiguous()
+    N = H * W
+    ro[: N // 8, 0] += 10.0       # an eighth of the rays pass beside the box ...
+    ro[N // 8: N // 4] *= 0.1     # ... and another starts inside it (near clamped to min_near)
+    f.ray_order = tile_ray_order(torch.arange(N), W, 8).to(cuda) if sorted_rays else None
+    nears, fars = raymarching.near_far_from_aabb(ro, rd, m.aabb_infer, m.min_near)
+    assert bool((nears == m.min_near).any()) and bool((nears > m.min_near).any()) and bool((fars < 3.0e38).any()) and bool((fars > 3.0e38).any())
+    bg = torch.rand(N, 3, device=cuda)
+    for bg_color in (1, (0.2, 0.5, 0.9), bg):
+        raw = f.render_frame(ro, rd, nears, fars, 0.0, 1024, 1e-4)
+        done = f.render_frame(ro, rd, None, None, 0.0, 1024, 1e-4, bg_color=bg_color, aabb=m.aabb_infer, min_near=m.min_near)
+        st_raw, st = raw[-1], done[-1]
+        assert st["finished"] and not st_raw.get("finished") and st["rendered"] == st_raw["rendered"] > 10_000
+        assert torch.equal(st["nears"], nears) and torch.equal(st["fars"], fars)
+        ws, depth, image = raw[0], raw[1], raw[2]
+        bgt = bg_color if torch.is_tensor(bg_color) else torch.tensor([bg_color] * 3 if isinstance(bg_color, int) else bg_color, dtype=torch.float32, device=cuda)
+        assert torch.equal(done[0], ws)
+        assert torch.equal(done[2], image + (1 - ws).unsqueeze(-1) * bgt)
+        want_depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+        assert torch.equal(done[1].isnan(), want_depth.isnan())      # rays that miss the box: (FLT_MAX - FLT_MAX) in the denominator, quirk 7
+        ok = ~want_depth.isnan()
+        assert torch.equal(done[1][ok], want_depth[ok])
+        if kind == "palette":
+            assert torch.equal(st["depth_raw"], depth)
+            assert torch.equal(done[3][:, 3:], raw[3][:, 3:])
+            assert torch.equal(done[3][:, 0:3], raw[3][:, 0:3] + (1 - ws).unsqueeze(-1) * bgt)
