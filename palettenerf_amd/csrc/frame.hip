@@ -1368,6 +1368,16 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
             else if (pow2) PNR_LAUNCH_MARCH(false, true, 1);
             else PNR_LAUNCH_MARCH(false, false, 1);
 #undef PNR_LAUNCH_MARCH
+            if (k + 1 == chunk) {
+                // The look: the march launch is the only writer of the control block (sample and row totals of everything in front of it, the overflow flag,
+                // `done`), so the chunk's last one is read back right behind itself -- the host wakes up while that iteration's lookup and field
+                // launches (empty when the frame is done, which is what the chunk length bets on) and the frame's last launch are still running.
+                // Wait for THIS read-back, not for the stream: another host thread may already have queued the next frame behind it (pipeline.FramesInFlight
+                // with a shared stream: frames back to back without the host's gap between them, kernels never overlapping)
+                if (hipMemcpyAsync(host_ctl, cur, sizeof(FrameCtl), hipMemcpyDeviceToHost, s) != hipSuccess) return PNR_ERR_LAUNCH;
+                if (!dev_state.done_ev && hipEventCreateWithFlags(&dev_state.done_ev, hipEventDisableTiming) != hipSuccess) return PNR_ERR_LAUNCH;
+                if (hipEventRecord(dev_state.done_ev, s) != hipSuccess) return PNR_ERR_LAUNCH;
+            }
             const uint32_t gx = cdiv(rows_ub, 256);
             const uint32_t gxc = gx < 1024u ? gx : 1024u;
             HostedArgs ha = {};
@@ -1433,11 +1443,6 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
                                    counts_of(iter), (const float*)w.aux, out_aux, aux_stride, aux_fused, composite_fused);
             prev_partials = gm.x + ha.blocks;
         }
-        if (hipMemcpyAsync(host_ctl, w.ctl + ((iter - 1) & 1), sizeof(FrameCtl), hipMemcpyDeviceToHost, s) != hipSuccess) return PNR_ERR_LAUNCH;   // the last launched iteration's
-        // wait for THIS read-back, not for the stream: another host thread may already have queued the next frame behind it (pipeline.FramesInFlight
-        // with a shared stream: frames back to back without the host's gap between them, kernels never overlapping)
-        if (!dev_state.done_ev && hipEventCreateWithFlags(&dev_state.done_ev, hipEventDisableTiming) != hipSuccess) return PNR_ERR_LAUNCH;
-        if (hipEventRecord(dev_state.done_ev, s) != hipSuccess) return PNR_ERR_LAUNCH;
         // The frame's last launch goes out BEHIND the read-back and BEFORE the host waits for it: the kernel looks at the same control block and does
         // nothing unless the frame is done, so a chunk that fell short costs an empty launch -- and when the guess holds (nearly always along a camera
         // path) the host wakes up, returns and prepares the caller's next frame while this launch runs, instead of launching it after waking up

@@ -343,6 +343,19 @@ class _RendererBase(nn.Module):
         return out
 
 
+def _zero_map(owner, name, shape, like):
+    """An all-zero map the reference allocates afresh per frame (nerf/renderer.py:386 rgb_norm, palette/renderer.py:441 clip_feat without a clip head):
+    the native frame path hands out one cached tensor per shape instead (a fill launch and its host time per frame otherwise) -- as long as nobody has
+    written into it: torch counts in-place writes (`_version`), a touched map is replaced."""
+    key = "_zero_" + name
+    cached = owner.__dict__.get(key)
+    if cached is not None and cached[0].shape == shape and cached[0].device == like.device and cached[0]._version == cached[1]:
+        return cached[0]
+    z = torch.zeros(*shape, dtype=torch.float32, device=like.device)
+    owner.__dict__[key] = (z, z._version)
+    return z
+
+
 class NeRFRenderer(_OccupancyMaintenance, _RendererBase):
     """nerf/renderer.py:61-125"""
 
@@ -494,7 +507,7 @@ class NeRFRenderer(_OccupancyMaintenance, _RendererBase):
                 depth = torch.clamp(depth_acc - nears, min=0) / (fars - nears)
             image = image.view(*prefix, 3)
             depth = depth.view(*prefix)
-            rgb_norm_map = torch.zeros_like(image[..., 0])
+            rgb_norm_map = _zero_map(self, "rgb_norm", tuple(prefix), image)
             results["n_samples"] = stats["rows"]
             results["rendered"] = torch.tensor([stats["rendered"]], dtype=torch.int64)   # host tensor: the count came back with the control block
             results["iterations"], results["host_looks"] = stats["iterations"], stats["looks"]
@@ -763,7 +776,7 @@ class PaletteRenderer(_RendererBase):
             unscaled_basis_rgb_map = torch.zeros(N, 3 * nb, **f32)
             basis_acc_map = torch.zeros(N, nb, **f32)
         if not use_fused or self._fused.clip_dim != clip_dim:
-            clip_feat_map = torch.zeros(N, clip_dim, **f32)
+            clip_feat_map = _zero_map(self, "clip_feat", (N, clip_dim), rays_o) if native else torch.zeros(N, clip_dim, **f32)
 
         def shade_fused(st, n_alive, n_step, xyzs, dirs, deltas):
             # one fused field launch + ONE flex composite over the packed aux row instead of ~40 launches and 6 flex composites
