@@ -564,22 +564,28 @@ __device__ __forceinline__ void split_tiles(const f32x16 (&a)[2], int k, HOp& o)
 #pragma unroll
     for (int t = 0; t < NT; t++) { split_scaled(a[t], 0, s, o.hi[2 * t], o.lo[2 * t]); split_scaled(a[t], 1, s, o.hi[2 * t + 1], o.lo[2 * t + 1]); }
 }
-// out[rt] = sum_kb W[rt][kb] . b[kb]
+// out[rt] = sum_kb W[rt][kb] . b[kb].  The launch runs one wave per SIMD, so nothing hides an LDS read but the wave's own matrix instructions: the NEXT block's
+// weights are requested in front of this block's three products (a 1-deep software pipeline; the scheduling barrier behind every block keeps the compiler
+// from pulling later reads further up, which blew the register budget, and from sinking this one back to its use, where every block waited ~100 cycles).
 template <int NRT, int NKB>
 __device__ __forceinline__ void layer_h(const unsigned char* __restrict__ slot, const HOp& b, f32x16 (&out)[2], int lane) {
+    constexpr int N = NRT * NKB;
+    h8 ahi = *reinterpret_cast<const h8*>(slot + lane * 16), alo = *reinterpret_cast<const h8*>(slot + 1024 + lane * 16);
 #pragma unroll
-    for (int rt = 0; rt < NRT; rt++) {
-        out[rt] = zero16();
-#pragma unroll
-        for (int kb = 0; kb < NKB; kb++) {
-            const unsigned char* blk = slot + (size_t)(rt * NKB + kb) * 2048;
-            const h8 ahi = *reinterpret_cast<const h8*>(blk + lane * 16);
-            const h8 alo = *reinterpret_cast<const h8*>(blk + 1024 + lane * 16);
-            out[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, b.hi[kb], out[rt], 0, 0, 0);
-            out[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, b.lo[kb], out[rt], 0, 0, 0);
-            out[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, b.hi[kb], out[rt], 0, 0, 0);
+    for (int i = 0; i < N; i++) {
+        const int rt = i / NKB, kb = i % NKB;
+        h8 nhi = ahi, nlo = alo;
+        if (i + 1 < N) {
+            const unsigned char* nblk = slot + (size_t)(i + 1) * 2048;
+            nhi = *reinterpret_cast<const h8*>(nblk + lane * 16);
+            nlo = *reinterpret_cast<const h8*>(nblk + 1024 + lane * 16);
         }
-        __builtin_amdgcn_sched_barrier(0);   // keeps the weight reads of later blocks from being hoisted above this group (register blow-up)
+        if (kb == 0) out[rt] = zero16();
+        out[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, b.hi[kb], out[rt], 0, 0, 0);
+        out[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, b.lo[kb], out[rt], 0, 0, 0);
+        out[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, b.hi[kb], out[rt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        ahi = nhi; alo = nlo;
     }
 }
 // hidden activation of a layer's accumulators (stored, e): ReLU commutes with the power of two and keeps e; ELU needs the true value (e becomes 0)
@@ -688,13 +694,6 @@ __device__ __forceinline__ void split_scaled8(const float (&v)[8], float s, h8& 
     hi = __builtin_bit_cast(h8, hw);
     lo = __builtin_bit_cast(h8, lw);
 }
-// feature `col` of the staged tile, samples kb*16 + hh*8 .. +7, scaled by s and split
-__device__ __forceinline__ void column_op(const float* __restrict__ buf, int col, int kb, int hh, float s, h8& hi, h8& lo, const int kStage = pnr::kStage) {
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) v[j] = buf[(kb * 16 + hh * 8 + j) * kStage + col];
-    split_scaled8(v, s, hi, lo);
-}
 template <int NRT, int NCT>
 __device__ __forceinline__ void wgrad_lds(f32x16 (&dw)[2][2], DwScale& st, const float* __restrict__ G, int e_g, int mg, const float* __restrict__ A, int e_a, int ma, int lane,
                                           const int a_stride = kStage) {
@@ -717,15 +716,32 @@ __device__ __forceinline__ void wgrad_lds(f32x16 (&dw)[2][2], DwScale& st, const
     }
     const int c = lane & 31, hh = lane >> 5;
     const float sg = pow2i(kg), sa = pow2i(ka);
+    // The operands of the two 16-sample halves, in the order they are needed: A[0..NCT-1], G[0..NRT-1] per half.  One wave per SIMD: an operand's eight LDS
+    // reads are requested while the PREVIOUS operand is being split and multiplied (raw values of one operand ahead: 8 registers), the scheduling
+    // barrier pins them there -- left alone the compiler sank them to their use and every operand waited a full LDS round trip.
+    constexpr int kPerHalf = NCT + NRT, kOps = 2 * kPerHalf;
+    auto raw_of = [&](int i, float (&v)[8]) {
+        const int kb = i / kPerHalf, j = i % kPerHalf;
+        const float* __restrict__ buf = j < NCT ? A : G;
+        const int stride = j < NCT ? a_stride : kStage, col = (j < NCT ? j : j - NCT) * 32 + c;
 #pragma unroll
-    for (int kb = 0; kb < 2; kb++) {       // 16 samples at a time: 24 operand registers live instead of 48
-        h8 ahi[2], alo[2];
+        for (int q = 0; q < 8; q++) v[q] = buf[(kb * 16 + hh * 8 + q) * stride + col];
+    };
+    float cur[8], nxt[8];
+    raw_of(0, cur);
+    h8 ahi[2], alo[2];
 #pragma unroll
-        for (int ct = 0; ct < NCT; ct++) column_op(A, ct * 32 + c, kb, hh, sa, ahi[ct], alo[ct], a_stride);
-#pragma unroll
-        for (int rt = 0; rt < NRT; rt++) {
+    for (int i = 0; i < kOps; i++) {
+        const int j = i % kPerHalf;
+        asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));   // this operand has arrived ...
+        if (i + 1 < kOps) raw_of(i + 1, nxt);                                                                                                     // ... the next one is requested
+        __builtin_amdgcn_sched_barrier(0);
+        if (j < NCT) {
+            split_scaled8(cur, sa, ahi[j], alo[j]);
+        } else {
+            const int rt = j - NCT;
             h8 ghi, glo;
-            column_op(G, rt * 32 + c, kb, hh, sg, ghi, glo);
+            split_scaled8(cur, sg, ghi, glo);
 #pragma unroll
             for (int ct = 0; ct < NCT; ct++) {
                 dw[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(glo, ahi[ct], dw[rt][ct], 0, 0, 0);
@@ -734,6 +750,8 @@ __device__ __forceinline__ void wgrad_lds(f32x16 (&dw)[2][2], DwScale& st, const
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; q++) cur[q] = nxt[q];
     }
 }
 // g (stored) *= act'(h): the exponent of g is untouched (h: the stored activation; ReLU only needs its sign, ELU stores true values)
