@@ -538,20 +538,30 @@ __device__ __forceinline__ float pow2i(int k) {   // 2^k, k clamped to the norma
     return __uint_as_float((uint32_t)(k + 127) << 23);
 }
 __device__ __forceinline__ int exp_of_pow2(float v) { return (int)((__float_as_uint(v) >> 23) & 0xffu) - 127; }
+// Two value pairs split in ONE assembly statement, the two pairs' instructions interleaved: v_fma_mixhi_f16 writes half a register (op_sel), and on gfx950 the
+// next instruction that reads such a register needs a wait state -- as separate statements the compiler put an s_nop between them (five per eight values, 190
+// issue slots per tile of the backward at one wave per SIMD); here every consumer sits two instructions behind its producer.
+__device__ __forceinline__ void split_scaled4(float a0, float a1, float b0, float b1, float s, uint32_t& ha, uint32_t& hb, uint32_t& la, uint32_t& lb) {
+    asm("v_fma_mixlo_f16 %0, %4, %8, 0\n\t"
+        "v_fma_mixlo_f16 %1, %6, %8, 0\n\t"
+        "v_fma_mixhi_f16 %0, %5, %8, 0\n\t"
+        "v_fma_mixhi_f16 %1, %7, %8, 0\n\t"
+        "v_fma_mixlo_f16 %2, %4, %8, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %3, %6, %8, -%1 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %2, %5, %8, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %3, %7, %8, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(ha), "=&v"(hb), "=&v"(la), "=&v"(lb) : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(s));
+}
 // hi = fp16(v * s), lo = fp16(v * s - hi) for a power of two s: the scaling rides on the conversions (v_fma_mix*: fp32 fma, ONE rounding to f16) -- two
 // instructions per value and half
 __device__ __forceinline__ void split_scaled(const f32x16& a, int half_idx, float s, h8& hi, h8& lo) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     u32x4 hw, lw;
 #pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-        const float v0 = a[half_idx * 8 + j], v1 = a[half_idx * 8 + j + 1];
-        uint32_t hb, lb;
-        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hb) : "v"(v0), "v"(s));
-        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hb) : "v"(v1), "v"(s));
-        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lb) : "v"(v0), "v"(s), "v"(hb));
-        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lb) : "v"(v1), "v"(s), "v"(hb));
-        hw[j / 2] = hb; lw[j / 2] = lb;
+    for (int j = 0; j < 8; j += 4) {
+        uint32_t h0, h1, l0, l1;
+        split_scaled4(a[half_idx * 8 + j], a[half_idx * 8 + j + 1], a[half_idx * 8 + j + 2], a[half_idx * 8 + j + 3], s, h0, h1, l0, l1);
+        hw[j / 2] = h0; hw[j / 2 + 1] = h1; lw[j / 2] = l0; lw[j / 2 + 1] = l1;
     }
     asm volatile("s_nop 3" : "+v"(hw), "+v"(lw));   // inline-asm VALU writes -> MFMA reads: the compiler's hazard recogniser does not see them (field_core.hpp: split8)
     hi = __builtin_bit_cast(h8, hw);
@@ -682,13 +692,10 @@ __device__ __forceinline__ void split_scaled8(const float (&v)[8], float s, h8& 
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     u32x4 hw, lw;
 #pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-        uint32_t hb, lb;
-        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hb) : "v"(v[j]), "v"(s));
-        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hb) : "v"(v[j + 1]), "v"(s));
-        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lb) : "v"(v[j]), "v"(s), "v"(hb));
-        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lb) : "v"(v[j + 1]), "v"(s), "v"(hb));
-        hw[j / 2] = hb; lw[j / 2] = lb;
+    for (int j = 0; j < 8; j += 4) {
+        uint32_t h0, h1, l0, l1;
+        split_scaled4(v[j], v[j + 1], v[j + 2], v[j + 3], s, h0, h1, l0, l1);
+        hw[j / 2] = h0; hw[j / 2 + 1] = h1; lw[j / 2] = l0; lw[j / 2 + 1] = l1;
     }
     asm volatile("s_nop 3" : "+v"(hw), "+v"(lw));
     hi = __builtin_bit_cast(h8, hw);
