@@ -219,19 +219,25 @@ __device__ __forceinline__ void head3_valu(const unsigned char* __restrict__ vec
     typedef float f32x2v __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
     const lds_f32x4* wv = reinterpret_cast<const lds_f32x4*>(reinterpret_cast<uintptr_t>(vec));
+    // (the three outputs' chains advance together: a packed fp32 instruction whose result the next instruction reads costs a wait state on gfx950 -- three
+    // independent accumulators leave none; each accumulator still sees its own terms in the same order)
+    f32x2v acc[3] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+            const f32x16& u = t ? u1 : u0;
+            f32x4 ww[3];
+#pragma unroll
+            for (int o = 0; o < 3; o++) ww[o] = wv[(o * 2 + t) * 4 + r4];
+#pragma unroll
+            for (int o = 0; o < 3; o++) acc[o] = __builtin_elementwise_fma(f32x2v{ww[o].x, ww[o].y}, f32x2v{u[4 * r4], u[4 * r4 + 1]}, acc[o]);
+#pragma unroll
+            for (int o = 0; o < 3; o++) acc[o] = __builtin_elementwise_fma(f32x2v{ww[o].z, ww[o].w}, f32x2v{u[4 * r4 + 2], u[4 * r4 + 3]}, acc[o]);
+        }
 #pragma unroll
     for (int o = 0; o < 3; o++) {
-        f32x2v acc = {0.0f, 0.0f};
-#pragma unroll
-        for (int t = 0; t < 2; t++)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; r4++) {
-                const f32x4 ww = wv[(o * 2 + t) * 4 + r4];
-                const f32x16& u = t ? u1 : u0;
-                acc = __builtin_elementwise_fma(f32x2v{ww.x, ww.y}, f32x2v{u[4 * r4], u[4 * r4 + 1]}, acc);
-                acc = __builtin_elementwise_fma(f32x2v{ww.z, ww.w}, f32x2v{u[4 * r4 + 2], u[4 * r4 + 3]}, acc);
-            }
-        const float p = acc.x + acc.y;
+        const float p = acc[o].x + acc[o].y;
         const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(p), false, false);   // ([0]: the lower half-wave's p in every lane, [1]: the upper's)
         out[o] = __uint_as_float(sw2[0]) + __uint_as_float(sw2[1]);
     }
