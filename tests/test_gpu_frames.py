@@ -974,3 +974,53 @@ def test_frame_call_computes_near_far_and_epilogue_itself(cuda, kind, sorted_ray
             assert torch.equal(st["depth_raw"], depth)
             assert torch.equal(done[3][:, 3:], raw[3][:, 3:])
             assert torch.equal(done[3][:, 0:3], raw[3][:, 0:3] + (1 - ws).unsqueeze(-1) * bgt)
+
+
+@pytest.mark.gpu
+def test_kept_frame_arguments_follow_every_setting(cuda):
+    """The frame calls keep their argument struct between frames (fused.py: `_frame_plan`).  Everything the struct is filled from must be part of its key:
+    after each change of a setting, the same object's next frame equals the frame of a fresh PaletteFieldFused built after the change."""
+    from palettenerf_amd.fused import PaletteFieldFused, tile_ray_order
+    m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True, density_scale=100.0)
+    scene.seed_field_(m, 0)
+    m = m.to(cuda).eval()
+    m.density_grid.copy_(torch.from_numpy(scene.brick_density_grid()).to(cuda))
+    raymarching.packbits(m.density_grid, 0.5, m.density_bitfield)
+    H, W = 64, 96
+    ro, rd = scene.get_rays(torch.from_numpy(scene.lookat_pose(azimuth_deg=40.0))[None], scene.intrinsics_from_fov(H, W), H, W)
+    ro, rd = ro[0].to(cuda).contiguous(), rd[0].to(cuda).contiguous()
+    N = H * W
+    kept = PaletteFieldFused(m)
+
+    def frames_agree(what):
+        fresh = PaletteFieldFused(m)
+        fresh.ray_order, fresh.precision, fresh.table_half = kept.ray_order if hasattr(kept, "ray_order") else None, kept.precision, kept.table_half
+        a = kept.render_frame(ro, rd, None, None, 0.0, 1024, 1e-4, bg_color=1, aabb=m.aabb_infer, min_near=m.min_near)
+        b = fresh.render_frame(ro, rd, None, None, 0.0, 1024, 1e-4, bg_color=1, aabb=m.aabb_infer, min_near=m.min_near)
+        assert a[-1]["rendered"] == b[-1]["rendered"] > 1000, what
+        for x, y in zip(a[:4], b[:4]):
+            assert torch.equal(x, y), what
+        return a
+
+    kept.ray_order = None
+    base = frames_agree("first frame")
+    frames_agree("second frame, nothing changed")
+    m.view_dep_weight = 0.25
+    v = frames_agree("view_dep_weight")
+    assert not torch.equal(v[2], base[2])
+    m.offsets_weight = 0.5
+    frames_agree("offsets_weight")
+    m.density_scale = 50.0
+    d = frames_agree("density_scale")
+    assert not torch.equal(d[0], v[0])
+    kept.ray_order = tile_ray_order(torch.arange(N), W, 8).to(cuda)
+    frames_agree("ray_order")
+    kept.precision = 0
+    frames_agree("precision fp32")
+    kept.precision = 1
+    with torch.no_grad():
+        m.basis_color.add_(0.03)                       # an in-place torch op: the version counter moves
+    frames_agree("palette changed in place")
+    m.density_grid.mul_(0.0).add_(torch.from_numpy(scene.brick_density_grid()).to(cuda).roll(3, dims=1))
+    raymarching.packbits(m.density_grid, 0.5, m.density_bitfield)       # another occupancy grid: bitfield version, mip
+    frames_agree("occupancy grid")
