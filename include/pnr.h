@@ -515,7 +515,9 @@ int pnr_linear_wgrad(const void* x, int x_dtype, const void* dy, int dy_dtype, u
  *   pnr_mlp_forward   x [B, dims[0]] -> y [B, dims[n_layers]]
  *   pnr_mlp_backward  x, dy [B, dims[n_layers]] -> dx [B, dims[0]] (NULL: not wanted), dw_l [dims[l+1]][dims[l]] (NULL: not wanted);
  *                     hidden activations are recomputed from x; dw is reduced deterministically through `workspace`.
- *                     y: the forward's output, read only with PNR_MLP_OUT_SIGMOID (dZ = dY (1 - y) y; NULL otherwise). */
+ *                     y: the forward's output, read only with PNR_MLP_OUT_SIGMOID (dZ = dY (1 - y) y; NULL otherwise).
+ *   Every activation array (x, x_tail, y, dy, dx; the level-major forms' enc / denc) must start on a 16-byte boundary and hold at least four floats -- tiles move
+ *   as 16-byte requests (round 5); PNR_ERR_UNSUPPORTED otherwise. */
 typedef struct {
     uint32_t n_layers;      /* 2 or 3 */
     uint32_t dims[4];       /* dims[0] = input width ... dims[n_layers] = output width, each 1..64 */

@@ -14,6 +14,7 @@
 // Two arithmetic forms of each launch: the exact fp32 matrix instructions described above (k_mlp_fwd / k_mlp_bwd) and, by default since round 4, split-fp16
 // products with per-tile power-of-two scaling on v_mfma_f32_32x32x16_f16 (k_mlp_fwd_h / k_mlp_bwd_h, further down); pnr_mlp_pack writes the weights in both.
 #include "field_core.hpp"
+#include <initializer_list>
 
 namespace pnr {
 
@@ -171,39 +172,62 @@ __device__ __forceinline__ void mul_act_grad(f32x16 (&g)[2], const f32x16 (&h)[2
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 
 // sample-major staging tile of one wave: buf[sample 0..31][feature 0..63] (row stride kStage), row 32 = trash.
-// A wave's 32 x width tile is held raw in registers (element f = lane + 64 k of the row-major tile): the NEXT tile's global loads are
-// issued before the current tile's matrix work and land while it runs (one wave per SIMD: nothing else would hide them).  Everything is
-// branch-free: loads clamp their index and select 0 past the end of the array, lanes beyond the tile write the trash row.
+// A wave's 32 x width tile is held raw in registers: the NEXT tile's global loads are issued before the current tile's matrix work and land while it runs
+// (one wave per SIMD: nothing else would hide them).  The tile's 32 x width floats are ONE contiguous run that starts on a 16-byte boundary whatever the width
+// (the arrays are 16-byte aligned: the entry points check), so it moves as 16-byte requests: registers 4 k4 .. 4 k4 + 3 = elements 4 (lane + 64 k4) ... + 3 of the
+// row-major tile.  (Rounds 1-4 moved 4 bytes per request, every one with its own index clamp and bound select: a fifth of the vector instructions of a training
+// launch.)  The fast path has no bound checks at all; the launch's one partial tile is staged / stored by the rolled loops below, straight from / to global memory.
 template <int NT>
 __device__ __forceinline__ void raw_load(float (&v)[16 * NT], const float* __restrict__ g, uint32_t row0, uint32_t B, uint32_t width, int lane) {
     const uint32_t total = B * width, base = row0 * width;
+    const float4* __restrict__ g4 = reinterpret_cast<const float4*>(g);
+    const uint32_t last4 = (total - 4u) >> 2;     // (B >= 1 and width >= 4 or B >= 4 ... : total >= 4 is checked by the entry points)  requests beyond the tile -- or, in
+                                                  // the partial tile, beyond the array -- re-read the last float4 that lies inside the array; nothing but the load here:
+                                                  // any use of the value (even a select) would make the compiler wait for it on the spot and serialise the tile's loads
 #pragma unroll
-    for (int kt = 0; kt < NT; kt++)
-#pragma unroll
-    for (int kk = 0; kk < 16; kk++) {
-        const int k = kt * 16 + kk;
-        // nothing but the load here: any use of the value (even a select) would make the compiler wait for it on the spot and
-        // serialise the tile's loads; elements past the end of the array are zeroed when the tile is staged (raw_to_stage)
-        // (registers that lie wholly beyond the tile re-read a few lines of the following tiles: cheaper than 16 uniform branches, which
-        // also derail the register allocator)
-        const uint32_t e = base + (uint32_t)lane + 64u * k;
-        v[k] = g[e < total ? e : total - 1u];
+    for (int k4 = 0; k4 < 4 * NT; k4++) {
+        const uint32_t i = (base >> 2) + (uint32_t)lane + 64u * k4;
+        const float4 x = g4[i < last4 ? i : last4];
+        v[4 * k4] = x.x; v[4 * k4 + 1] = x.y; v[4 * k4 + 2] = x.z; v[4 * k4 + 3] = x.w;
     }
 }
 template <int NT>
-__device__ __forceinline__ void raw_to_stage(float* __restrict__ buf, const float (&v)[16 * NT], uint32_t row0, uint32_t B, uint32_t width, uint32_t magic,
-                                             int lane, const int kStage = pnr::kStage /* row stride of this tile (the X tile of the split-fp16 backward is narrower) */) {
-    const uint32_t total = B * width, base = row0 * width;
+__device__ __forceinline__ void raw_to_stage(float* __restrict__ buf, const float (&v)[16 * NT], const float* __restrict__ g, uint32_t row0, uint32_t B, uint32_t width,
+                                             uint32_t magic, int lane, const int kStage = pnr::kStage /* row stride of this tile (the X tile of the split-fp16 backward is narrower) */,
+                                             const float* __restrict__ g_sig = nullptr /* the forward's sigmoid output: the staged values are dY (1 - y) y (the caller applied that to v) */) {
+    if (row0 + 32u <= B) {       // (wave-uniform) a full tile: nothing to zero, and with a width that is a multiple of 4 a request's four values sit in one row
 #pragma unroll
-    for (int kt = 0; kt < NT; kt++)
+        for (int k4 = 0; k4 < 4 * NT; k4++) {
+            const uint32_t f0 = 4u * ((uint32_t)lane + 64u * k4);
+            if ((width & 3u) == 0) {
+                uint32_t r = __umulhi(f0, magic);
+                const uint32_t c = f0 - r * width;
+                r = r < 32u ? r : 32u;
+                float* d = buf + r * kStage + c;
+                d[0] = v[4 * k4]; d[1] = v[4 * k4 + 1]; d[2] = v[4 * k4 + 2]; d[3] = v[4 * k4 + 3];
+            } else {
 #pragma unroll
-    for (int kk = 0; kk < 16; kk++) {
-        const int k = kt * 16 + kk;
-        const uint32_t f = (uint32_t)lane + 64u * k;
-        uint32_t r = __umulhi(f, magic);
-        const uint32_t c = f - r * width;
-        r = r < 32u ? r : 32u;
-        buf[r * kStage + c] = base + f < total ? v[k] : 0.0f;
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t f = f0 + j;
+                    uint32_t r = __umulhi(f, magic);
+                    const uint32_t c = f - r * width;
+                    r = r < 32u ? r : 32u;
+                    buf[r * kStage + c] = v[4 * k4 + j];
+                }
+            }
+        }
+    } else {                     // the launch's partial tile (or a wave beyond the last row): element by element from global memory, zeros past the end
+        const uint32_t total = B * width, base = row0 * width;
+#pragma unroll 1
+        for (uint32_t f = (uint32_t)lane; f < 32u * width; f += 64u) {
+            const uint32_t r = __umulhi(f, magic), c = f - r * width;
+            float x = 0.0f;
+            if (base + f < total) {
+                x = g[base + f];
+                if (g_sig) { const float y = g_sig[base + f]; x = (x * (1.0f - y)) * y; }
+            }
+            buf[r * kStage + c] = x;
+        }
     }
     // zero the padding columns (they are MFMA operands too): lane = (row, parity), columns width + parity, width + parity + 2, ...
     for (uint32_t c = width + ((uint32_t)lane >> 5); c < 32u * NT; c += 2) buf[((uint32_t)lane & 31u) * kStage + c] = 0.0f;
@@ -212,66 +236,118 @@ template <int NT>
 __device__ __forceinline__ void stage_to_global(const float* __restrict__ buf, float* __restrict__ g, uint32_t row0, uint32_t B, uint32_t width, uint32_t magic, int lane,
                                                 bool sigmoid = false) {
     const uint32_t total = B * width, base = row0 * width;
+    if (row0 + 32u <= B) {
+        float4* __restrict__ g4 = reinterpret_cast<float4*>(g);
 #pragma unroll
-    for (int kt = 0; kt < NT; kt++)
+        for (int k4 = 0; k4 < 4 * NT; k4++) {
+            if (256u * k4 >= 32u * width) break;      // wave-uniform: requests wholly beyond the tile
+            const uint32_t f0 = 4u * ((uint32_t)lane + 64u * k4);
+            if (f0 < 32u * width) {
+                float x[4];
+                if ((width & 3u) == 0) {
+                    const uint32_t r = __umulhi(f0, magic), c = f0 - r * width;
+                    const float* sp = buf + r * kStage + c;
+                    x[0] = sp[0]; x[1] = sp[1]; x[2] = sp[2]; x[3] = sp[3];
+                } else {
 #pragma unroll
-    for (int kk = 0; kk < 16; kk++) {
-        const int k = kt * 16 + kk;
-        if (sigmoid && 64u * k >= 32u * width) break;   // wave-uniform: only the tile's real elements pay for the exponential
-        const uint32_t f = (uint32_t)lane + 64u * k;
-        const uint32_t r = __umulhi(f, magic), c = f - r * width;
-        if (r < 32u && base + f < total) {
-            float v = buf[r * kStage + c];
-            if (sigmoid) v = 1.0f / (1.0f + expf(-v));   // torch.sigmoid
-            g[base + f] = v;
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t f = f0 + j, r = __umulhi(f, magic), c = f - r * width;
+                        x[j] = buf[r * kStage + c];
+                    }
+                }
+                if (sigmoid) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) x[j] = 1.0f / (1.0f + expf(-x[j]));   // torch.sigmoid
+                }
+                g4[(base + f0) >> 2] = make_float4(x[0], x[1], x[2], x[3]);
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (uint32_t f = (uint32_t)lane; f < 32u * width; f += 64u) {
+            if (base + f < total) {
+                const uint32_t r = __umulhi(f, magic), c = f - r * width;
+                float x = buf[r * kStage + c];
+                if (sigmoid) x = 1.0f / (1.0f + expf(-x));
+                g[base + f] = x;
+            }
         }
     }
 }
 
 // X whose first 32 columns are a hash-grid encoder output in its native level-major layout enc [16][B][2] (no [B,32] copy is ever made) and
-// whose remaining `tail` columns (NT == 2) are a row-major [B][tail] tensor.  A level's 32 samples x 2 channels of a tile are 64
-// contiguous floats: one coalesced load per level, register k = level k; registers 16.. hold the tail like raw_load.
+// whose remaining `tail` columns (NT == 2) are a row-major [B][tail] tensor.  A level's 32 samples x 2 channels of a tile are 64 contiguous floats that start on an
+// 8-byte boundary (B may be odd): registers 2 k2, 2 k2 + 1 = both channels of sample lane & 31 on level 2 k2 + (lane >> 5) -- 8-byte requests, two levels per
+// instruction; registers 16.. hold the tail like raw_load.  Rows beyond B are clamped here and zeroed when the tile is staged.
 template <int NT>
 __device__ __forceinline__ void raw_load_lm(float (&v)[16 * NT], const float* __restrict__ enc, const float* __restrict__ tail_src, uint32_t wt, uint32_t row0,
                                             uint32_t B, int lane) {
-    const uint32_t total = B * 2u, e = row0 * 2u + (uint32_t)lane, ec = e < total ? e : total - 1u;
+    const float2* __restrict__ e2 = reinterpret_cast<const float2*>(enc);
+    const uint32_t s = (uint32_t)lane & 31u, hl = (uint32_t)lane >> 5;
+    const uint32_t row = row0 + s < B ? row0 + s : B - 1u;
 #pragma unroll
-    for (int k = 0; k < 16; k++) v[k] = enc[(size_t)k * total + ec];
+    for (int k2 = 0; k2 < 8; k2++) {
+        const float2 x = e2[(size_t)(2 * k2 + hl) * B + row];
+        v[2 * k2] = x.x; v[2 * k2 + 1] = x.y;
+    }
     if constexpr (NT == 2) {
         const uint32_t ttotal = B * wt, tbase = row0 * wt;
+        const float4* __restrict__ t4 = reinterpret_cast<const float4*>(tail_src);
+        const uint32_t last4 = ttotal >= 4u ? (ttotal - 4u) >> 2 : 0u;
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const uint32_t t = tbase + (uint32_t)lane + 64u * k;
-            v[16 + k] = ttotal ? tail_src[t < ttotal ? t : ttotal - 1u] : 0.0f;
+        for (int k4 = 0; k4 < 4; k4++) {
+            const uint32_t i = (tbase >> 2) + (uint32_t)lane + 64u * k4;
+            const float4 x = t4[i < last4 ? i : last4];
+            v[16 + 4 * k4] = x.x; v[16 + 4 * k4 + 1] = x.y; v[16 + 4 * k4 + 2] = x.z; v[16 + 4 * k4 + 3] = x.w;
         }
     }
 }
 template <int NT>
-__device__ __forceinline__ void raw_to_stage_lm(float* __restrict__ buf, const float (&v)[16 * NT], uint32_t wt, uint32_t tail_magic, uint32_t row0, uint32_t B,
-                                                int lane, const int kStage = pnr::kStage) {
-    const uint32_t r0 = (uint32_t)lane >> 1, ch = (uint32_t)lane & 1u;
-    const bool live = row0 + r0 < B;
+__device__ __forceinline__ void raw_to_stage_lm(float* __restrict__ buf, const float (&v)[16 * NT], const float* __restrict__ tail_src, uint32_t wt, uint32_t tail_magic,
+                                                uint32_t row0, uint32_t B, int lane, const int kStage = pnr::kStage) {
+    const uint32_t s = (uint32_t)lane & 31u, hl = (uint32_t)lane >> 5;
+    const bool full = row0 + 32u <= B;             // wave-uniform
+    if (full) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) buf[r0 * kStage + 2 * k + ch] = live ? v[k] : 0.0f;
+        for (int k2 = 0; k2 < 8; k2++) { float* d = buf + s * kStage + 2 * (2 * k2 + hl); d[0] = v[2 * k2]; d[1] = v[2 * k2 + 1]; }
+    } else {
+        const bool live = row0 + s < B;
+#pragma unroll
+        for (int k2 = 0; k2 < 8; k2++) { float* d = buf + s * kStage + 2 * (2 * k2 + hl); d[0] = live ? v[2 * k2] : 0.0f; d[1] = live ? v[2 * k2 + 1] : 0.0f; }
+    }
     if constexpr (NT == 2) {
-        const uint32_t ttotal = B * wt, tbase = row0 * wt;
+        if (full) {
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const uint32_t f = (uint32_t)lane + 64u * k;
-            uint32_t r = __umulhi(f, tail_magic);
-            const uint32_t c = f - r * wt;
-            r = r < 32u ? r : 32u;
-            buf[r * kStage + 32 + c] = tbase + f < ttotal ? v[16 + k] : 0.0f;
+            for (int k4 = 0; k4 < 4; k4++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t f = 4u * ((uint32_t)lane + 64u * k4) + j;
+                    uint32_t r = __umulhi(f, tail_magic);
+                    const uint32_t c = f - r * wt;
+                    r = r < 32u ? r : 32u;
+                    buf[r * kStage + 32 + c] = v[16 + 4 * k4 + j];
+                }
+        } else {
+            const uint32_t ttotal = B * wt, tbase = row0 * wt;
+#pragma unroll 1
+            for (uint32_t f = (uint32_t)lane; f < 32u * wt; f += 64u) {
+                const uint32_t r = __umulhi(f, tail_magic), c = f - r * wt;
+                buf[r * kStage + 32 + c] = tbase + f < ttotal ? tail_src[tbase + f] : 0.0f;
+            }
         }
         for (uint32_t c = 32u + wt + ((uint32_t)lane >> 5); c < 64u; c += 2) buf[((uint32_t)lane & 31u) * kStage + c] = 0.0f;
     }
 }
 // dX of the level-major columns back in level-major layout [16][B][2] (what the table-gradient kernels take)
 __device__ __forceinline__ void stage_to_global_lm(const float* __restrict__ buf, float* __restrict__ denc, uint32_t row0, uint32_t B, int lane) {
-    const uint32_t r0 = (uint32_t)lane >> 1, ch = (uint32_t)lane & 1u;
-    if (row0 + r0 < B) {
+    float2* __restrict__ d2 = reinterpret_cast<float2*>(denc);
+    const uint32_t s = (uint32_t)lane & 31u, hl = (uint32_t)lane >> 5;
+    if (row0 + s < B) {
 #pragma unroll
-        for (int k = 0; k < 16; k++) denc[((size_t)k * B + row0) * 2u + (uint32_t)lane] = buf[r0 * kStage + 2 * k + ch];
+        for (int k2 = 0; k2 < 8; k2++) {
+            const float* sp = buf + s * kStage + 2 * (2 * k2 + hl);
+            d2[(size_t)(2 * k2 + hl) * B + row0 + s] = make_float2(sp[0], sp[1]);
+        }
     }
 }
 
@@ -367,8 +443,8 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_fwd(MlpPlan p, const float*
     else raw_load<TI>(xr, x, (blockIdx.x * kMlpWaves + wave) * 32, B, p.dims[0], lane);
     for (uint32_t bt = blockIdx.x; bt < nblock_tiles; bt += gridDim.x) {
         const uint32_t row0 = (bt * kMlpWaves + wave) * 32;
-        if (p.lm) raw_to_stage_lm<TI>(stage, xr, p.tail, p.tail_magic, row0, B, lane);
-        else raw_to_stage<TI>(stage, xr, row0, B, p.dims[0], p.magic[0], lane);
+        if (p.lm) raw_to_stage_lm<TI>(stage, xr, x_tail, p.tail, p.tail_magic, row0, B, lane);
+        else raw_to_stage<TI>(stage, xr, x, row0, B, p.dims[0], p.magic[0], lane);
         wave_sync();
         if (p.lm) raw_load_lm<TI>(xr, x, x_tail, p.tail, ((bt + gridDim.x) * kMlpWaves + wave) * 32, B, lane);   // the next tile's loads fly during this one's matrix work
         else raw_load<TI>(xr, x, ((bt + gridDim.x) * kMlpWaves + wave) * 32, B, p.dims[0], lane);
@@ -417,13 +493,13 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd(MlpPlan p, const float*
     if (yout) raw_load<TO>(sn, yout, (blockIdx.x * kMlpWaves + wave) * 32, B, p.dims[NL], lane);
     for (uint32_t bt = blockIdx.x; bt < nblock_tiles; bt += gridDim.x) {
         const uint32_t row0 = (bt * kMlpWaves + wave) * 32;
-        if (p.lm) raw_to_stage_lm<TI>(GB, xr, p.tail, p.tail_magic, row0, B, lane);
-        else raw_to_stage<TI>(GB, xr, row0, B, p.dims[0], p.magic[0], lane);
+        if (p.lm) raw_to_stage_lm<TI>(GB, xr, x_tail, p.tail, p.tail_magic, row0, B, lane);
+        else raw_to_stage<TI>(GB, xr, x, row0, B, p.dims[0], p.magic[0], lane);
         if (yout) {   // dZ = dY (1 - y) y: sigmoid_backward, in the raw layout both tiles share
 #pragma unroll
             for (int k = 0; k < 16 * TO; k++) yn[k] = (yn[k] * (1.0f - sn[k])) * sn[k];
         }
-        raw_to_stage<TO>(GA, yn, row0, B, p.dims[NL], p.magic[NL], lane);
+        raw_to_stage<TO>(GA, yn, dy, row0, B, p.dims[NL], p.magic[NL], lane, kStage, yout);
         wave_sync();
         const uint32_t next0 = ((bt + gridDim.x) * kMlpWaves + wave) * 32;
         raw_load<TO>(yn, dy, next0, B, p.dims[NL], lane);          // the next tile's dY flies during this tile's matrix work
@@ -467,8 +543,8 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd(MlpPlan p, const float*
         // layer 0: GA <- dZ1, GB <- X
         wave_sync();
         frag_to_stage<2>(GA, lane, g);
-        if (p.lm) raw_to_stage_lm<TI>(GB, xr, p.tail, p.tail_magic, row0, B, lane);
-        else raw_to_stage<TI>(GB, xr, row0, B, p.dims[0], p.magic[0], lane);
+        if (p.lm) raw_to_stage_lm<TI>(GB, xr, x_tail, p.tail, p.tail_magic, row0, B, lane);
+        else raw_to_stage<TI>(GB, xr, x, row0, B, p.dims[0], p.magic[0], lane);
         wave_sync();
         if (p.lm) raw_load_lm<TI>(xr, x, x_tail, p.tail, next0, B, lane);   // X is needed twice per tile: its prefetch starts after the second use
         else raw_load<TI>(xr, x, next0, B, p.dims[0], lane);
@@ -633,8 +709,8 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_fwd_h(MlpPlan p, const floa
     else raw_load<TI>(xr, x, (blockIdx.x * kMlpWaves + wave) * 32, B, p.dims[0], lane);
     for (uint32_t bt = blockIdx.x; bt < nblock_tiles; bt += gridDim.x) {
         const uint32_t row0 = (bt * kMlpWaves + wave) * 32;
-        if (p.lm) raw_to_stage_lm<TI>(stage, xr, p.tail, p.tail_magic, row0, B, lane);
-        else raw_to_stage<TI>(stage, xr, row0, B, p.dims[0], p.magic[0], lane);
+        if (p.lm) raw_to_stage_lm<TI>(stage, xr, x_tail, p.tail, p.tail_magic, row0, B, lane);
+        else raw_to_stage<TI>(stage, xr, x, row0, B, p.dims[0], p.magic[0], lane);
         wave_sync();
         if (p.lm) raw_load_lm<TI>(xr, x, x_tail, p.tail, ((bt + gridDim.x) * kMlpWaves + wave) * 32, B, lane);
         else raw_load<TI>(xr, x, ((bt + gridDim.x) * kMlpWaves + wave) * 32, B, p.dims[0], lane);
@@ -806,13 +882,13 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd_h(MlpPlan p, const floa
     if (yout) raw_load<TO>(sn, yout, (blockIdx.x * kMlpWaves + wave) * 32, B, p.dims[NL], lane);
     for (uint32_t bt = blockIdx.x; bt < nblock_tiles; bt += gridDim.x) {
         const uint32_t row0 = (bt * kMlpWaves + wave) * 32;
-        if (p.lm) raw_to_stage_lm<TI>(GX, xr, p.tail, p.tail_magic, row0, B, lane, kXStage);
-        else raw_to_stage<TI>(GX, xr, row0, B, p.dims[0], p.magic[0], lane, kXStage);
+        if (p.lm) raw_to_stage_lm<TI>(GX, xr, x_tail, p.tail, p.tail_magic, row0, B, lane, kXStage);
+        else raw_to_stage<TI>(GX, xr, x, row0, B, p.dims[0], p.magic[0], lane, kXStage);
         if (yout) {   // dZ = dY (1 - y) y: sigmoid_backward, in the raw layout both tiles share
 #pragma unroll
             for (int k = 0; k < 16 * TO; k++) yn[k] = (yn[k] * (1.0f - sn[k])) * sn[k];
         }
-        raw_to_stage<TO>(GA, yn, row0, B, p.dims[NL], p.magic[NL], lane);
+        raw_to_stage<TO>(GA, yn, dy, row0, B, p.dims[NL], p.magic[NL], lane, kStage, yout);
         wave_sync();
         const uint32_t next0 = ((bt + gridDim.x) * kMlpWaves + wave) * 32;
         f32x16 h1[2], h2[2], g[2], t[2];
@@ -1007,6 +1083,15 @@ int pnr_mlp_pack(const pnr_mlp_desc* desc, const float* w0, const float* w1, con
 #endif
 
 // lm_levels: 0 = x is row-major [B, dims[0]]; 16 = x is a level-major encoder output [16][B][2] followed by x_tail [B, dims[0] - 32]
+// The launches move their tiles as 16-byte requests: every activation array must start on a 16-byte boundary (torch allocations do; a view that starts inside one may
+// not -- palettenerf_amd.mlp copies those) and hold at least four floats.
+static bool arrays_ok(std::initializer_list<const void*> ptrs, uint32_t B, const MlpPlan& p) {
+    for (const void* q : ptrs) if (q && (reinterpret_cast<uintptr_t>(q) & 15u) != 0) return false;
+    uint32_t wmin = p.dims[0] < p.dims[p.n_layers] ? p.dims[0] : p.dims[p.n_layers];
+    if (p.lm && p.tail && p.tail < wmin) wmin = p.tail;
+    return (uint64_t)B * wmin >= 4;
+}
+
 static int plan_sources(MlpPlan& p, uint32_t lm_levels, const float* x_tail) {
     if (lm_levels == 0) return PNR_OK;
     if (lm_levels != 16 || p.dims[0] < 32) return PNR_ERR_UNSUPPORTED;
@@ -1027,6 +1112,7 @@ static int mlp_forward_impl(const pnr_mlp_desc* desc, const float* packed, const
     if (int rc = plan_sources(p, lm_levels, x_tail)) return rc;
     const size_t lds = ((size_t)p.wt_off[0] + kMlpWaves * kStageFloats) * 4;
     if (lds > 160 * 1024) return PNR_ERR_UNSUPPORTED;
+    if (!arrays_ok({x, x_tail, y}, B, p)) return PNR_ERR_UNSUPPORTED;
     hipStream_t s = as_stream(stream);
     const uint32_t tiles = cdiv(B, 32 * kMlpWaves), grid = tiles < 2 * kMlpMaxBlocks ? tiles : 2 * kMlpMaxBlocks;   // two workgroups per CU
     if (g_opt_mlp_f16x3) PNR_MLP_SWITCH(k_mlp_fwd_h, p, packed, x, x_tail, B, y);
@@ -1068,6 +1154,7 @@ static int mlp_backward_impl(const pnr_mlp_desc* desc, const float* packed, cons
     if (lds > 160 * 1024 || p.dw_floats > (uint32_t)(kMlpWaves * 2 * kStageFloats)) return PNR_ERR_UNSUPPORTED;
     const uint32_t blocks = mlp_blocks(B), grid = blocks;
     float* partial = static_cast<float*>(workspace);
+    if (!arrays_ok({x, x_tail, y, dy, dx}, B, p)) return PNR_ERR_UNSUPPORTED;
     // the split-fp16 backward where it holds its tile without (much) scratch: two layers unless both ends are 64 wide, three layers with 32-wide ends --
     // every stack of both fields; the wider instantiations spill twice what the fp32 ones do and stay on those
     const uint32_t ti = tiles32(p.dims[0]), to = tiles32(p.dims[p.n_layers]);

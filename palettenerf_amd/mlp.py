@@ -15,6 +15,14 @@ from . import _lib
 from ._torch_glue import call, ptr
 
 MIN_ROWS = 8192
+
+
+def _al(t):
+    """`t`, contiguous and starting on a 16-byte boundary: the launches move their tiles as 16-byte requests (pnr_mlp_* refuse other arrays).  torch allocations are
+    aligned; a contiguous view that starts inside one (x[1:] of a 3-wide tensor) is copied."""
+    t = t.contiguous()
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
 _ACT = {F.relu: 0, F.elu: 1}
 enabled = True      # module switch (tests compare against the torch loop)
 
@@ -39,7 +47,7 @@ class _FusedMLP(torch.autograd.Function):
         packed = torch.empty(int(lib.pnr_mlp_packed_bytes(ctypes.byref(desc))) // 4, dtype=torch.float32, device=dev)
         ws = [w.detach().contiguous() for w in weights]
         call("pnr_mlp_pack", ctypes.byref(desc), ptr(ws[0]), ptr(ws[1]), ptr(ws[2]) if len(ws) == 3 else None, ptr(packed))
-        x2 = x.detach().reshape(-1, dims[0]).contiguous()
+        x2 = _al(x.detach().reshape(-1, dims[0]))
         B = x2.shape[0]
         y = torch.empty(B, dims[-1], dtype=torch.float32, device=dev)
         call("pnr_mlp_forward", ctypes.byref(desc), ptr(packed), ptr(x2), ctypes.c_uint32(B), ptr(y))
@@ -56,7 +64,7 @@ class _FusedMLP(torch.autograd.Function):
         lib = _lib.load()
         dev = x2.device
         B = x2.shape[0]
-        dy2 = dy.reshape(-1, dims[-1]).contiguous().float()
+        dy2 = _al(dy.reshape(-1, dims[-1]).float())
         dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
         n = len(dims) - 1
         dws = [torch.empty(dims[l + 1], dims[l], dtype=torch.float32, device=dev) if ctx.needs_input_grad[2 + l] else None for l in range(n)]
@@ -116,7 +124,7 @@ class _EncodeMLP(torch.autograd.Function):
         dev = x01.device
         emb = embeddings.detach().contiguous()
         if enc_pre is not None:
-            enc = enc_pre.detach().contiguous()
+            enc = _al(enc_pre.detach())
             if enc.shape != (L, B, 2) or enc.dtype != torch.float32:
                 raise RuntimeError("encode_mlp: enc must be the raw level-major lookup [L, B, 2] fp32 at these points")
         else:
@@ -130,7 +138,7 @@ class _EncodeMLP(torch.autograd.Function):
         packed = torch.empty(int(lib.pnr_mlp_packed_bytes(ctypes.byref(desc))) // 4, dtype=torch.float32, device=dev)
         ws = [w.detach().contiguous() for w in weights]
         call("pnr_mlp_pack", ctypes.byref(desc), ptr(ws[0]), ptr(ws[1]), ptr(ws[2]) if len(ws) == 3 else None, ptr(packed))
-        tail_c = None if tail is None else tail.detach().contiguous()
+        tail_c = None if tail is None else _al(tail.detach())
         y = torch.empty(B, dims[-1], dtype=torch.float32, device=dev)
         call("pnr_mlp_forward_lm", ctypes.byref(desc), ptr(packed), ptr(enc), ctypes.c_uint32(L), ptr(tail_c), ctypes.c_uint32(B), ptr(y))
         ctx.save_for_backward(x01, offsets, enc, tail_c, packed)
@@ -148,7 +156,7 @@ class _EncodeMLP(torch.autograd.Function):
         lib = _lib.load()
         dev = x01.device
         B, L = x01.shape[0], offsets.shape[0] - 1
-        dy2 = dy.reshape(-1, dims[-1]).contiguous().float()
+        dy2 = _al(dy.reshape(-1, dims[-1]).float())
         want_emb = ctx.needs_input_grad[1]
         denc = torch.empty(L, B, 2, device=dev, dtype=torch.float32) if want_emb else None
         n = len(dims) - 1

@@ -1,6 +1,8 @@
 """GPU parity tests proper: every HIP kernel, called through the C ABI (via the operator mirror),
 against the CPU oracle on the same seeded inputs.  Integer / index / count outputs must be
 bit-exact; fp32 outputs carry the tolerance written next to each assertion."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -1746,3 +1748,56 @@ def test_fused_adam_is_bit_identical_to_torch_adam(cuda):
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 4.0 and float(sd["state"][5]["step"]) == 3.0
     assert sd["state"].get(6, {}) == {}      # the tensor that never received a gradient has no optimiser state
     torch.optim.Adam(make_groups := [{"params": make()[:3]}, {"params": make()[3:]}], betas=(0.9, 0.99), eps=1e-15).load_state_dict(sd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,B,sig", [((3, 64, 15), 9001, False), ((35, 64, 3), 4097 + 13, True), ((15, 64, 64, 13), 8192 + 31, False), ((32, 64, 64, 16), 8192, False)])
+def test_fused_mlp_tile_moves_on_odd_widths_and_ragged_ends(cuda, dims, B, sig, monkeypatch):
+    """The fused MLP launches move their activation tiles as 16-byte requests (csrc/mlp.hip: raw_load / raw_to_stage / stage_to_global): a tile's 32 x width floats are
+    one aligned run whatever the width, requests may straddle rows, and the launch's partial tile goes through rolled loops.  Widths that are not multiples of 4,
+    batches that end inside a tile AND inside a 16-byte request (B x width not a multiple of 4), the sigmoid output, and an input view that starts off a 16-byte
+    boundary (mlp.py copies it; the C entry refuses it): forward and every gradient against the torch layer loop."""
+    import torch.nn.functional as F
+    from palettenerf_amd import mlp, _lib
+    monkeypatch.setattr(mlp, "MIN_ROWS", 1)
+    torch.manual_seed(sum(dims) + B)
+    n = len(dims) - 1
+    net = torch.nn.ModuleList([torch.nn.Linear(dims[i], dims[i + 1], bias=False) for i in range(n)]).to(cuda)
+    xfull = torch.randn(B + 1, dims[0], device=cuda)
+    x_view = xfull[1:]                               # contiguous, but starts dims[0] * 4 bytes into the allocation
+    out = torch.sigmoid if sig else None
+    wy = torch.randn(B, dims[-1], device=cuda)
+
+    def run(fused):
+        x = x_view.detach().clone().requires_grad_(True) if not fused else x_view.detach().requires_grad_(True)
+        for l in net:
+            l.weight.grad = None
+        if fused:
+            y = mlp.run_mlp(net, x, F.relu, out)
+            assert type(y.grad_fn).__name__.startswith("_FusedMLP")
+        else:
+            h = x
+            for i, l in enumerate(net):
+                h = l(h)
+                if i != n - 1:
+                    h = F.relu(h)
+            y = torch.sigmoid(h) if sig else h
+        (y * wy).sum().backward()
+        return [y.detach(), x.grad] + [l.weight.grad.clone() for l in net]
+    got, want = run(True), run(False)
+    for k, (a, b) in enumerate(zip(got, want)):
+        ref = float(b.abs().max())
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) <= (5e-6 if k == 0 else 5e-5) * max(ref, 1e-30), (k, float((a - b).abs().max()), ref)
+    # the C entry itself refuses an array that starts off a 16-byte boundary
+    if (x_view.data_ptr() % 16) != 0:
+        lib = _lib.load()
+        desc = _lib.MlpDesc()
+        desc.n_layers = n
+        for i, d in enumerate(dims):
+            desc.dims[i] = d
+        desc.activation = 0
+        packed = torch.empty(int(lib.pnr_mlp_packed_bytes(ctypes.byref(desc))) // 4, dtype=torch.float32, device=cuda)
+        y = torch.empty(B, dims[-1], device=cuda)
+        rc = lib.pnr_mlp_forward(ctypes.byref(desc), packed.data_ptr(), x_view.data_ptr(), B, y.data_ptr(), None)
+        assert rc == -2      # PNR_ERR_UNSUPPORTED
