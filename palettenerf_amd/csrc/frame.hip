@@ -549,12 +549,20 @@ template <uint32_t CMUL>
 __device__ __forceinline__ bool grid_corner_rows(const GridArgs& g, const LevelCtx& lc, uint32_t b, uint32_t idxs[8], float pos[3]) {
     float in[3];
     bool oob = false;
+    // the row's three coordinates requested together (one 12-byte load): left alone the compiler sinks each 4-byte load to its use and waits for it there -- three
+    // memory round trips in a row in front of the eight gathers.  One empty asm statement that names all three pins the point where they must have arrived.
+    // (Frame times did not move -- the launch has seven waves per SIMD to cover the trips -- but the hosted tail's spills did: k_frame_grid 44 -> 0 B of scratch
+    // per lane, the pair kernel 84 -> 56.)
+    float xyz[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) xyz[d] = g.xyzs[(size_t)b * 3 + d];
+    asm volatile("" : "+v"(xyz[0]), "+v"(xyz[1]), "+v"(xyz[2]));
 #pragma unroll
     for (int d = 0; d < 3; d++) {
         // GridEncoder.forward's (x + bound) / (2 bound) (gridencoder/grid.py:142).  With 2 * bound a power of two -- every shipped scene -- the division
         // is an exact scaling and so is the multiplication by the exact reciprocal: same bits, one v_mul instead of the ~10-instruction IEEE
         // division (three per (sample, level): an eighth of this kernel's vector instructions).  Any other bound divides.
-        const float sft = g.xyzs[(size_t)b * 3 + d] + g.bound;
+        const float sft = xyz[d] + g.bound;
         in[d] = g.inv_two_bound != 0.0f ? sft * g.inv_two_bound : sft / g.two_bound;
         oob |= (in[d] < 0.0f) | (in[d] > 1.0f);
     }
