@@ -373,3 +373,36 @@ def test_concurrent_frame_handles_share_weights_and_refuse_the_cpu():
     assert m._fused.model is m                              # the original is untouched
     with pytest.raises(RuntimeError):
         FramesInFlight(m, 2)                                # CPU model: the product path is the HIP library, nothing else
+
+
+def test_cached_zero_maps_are_replaced_once_written_and_parameter_keys_memoise_inside_a_held_call():
+    """Host-side caches of the native frame path (no GPU needed): renderer._zero_map hands out one all-zero tensor per shape until somebody writes into it
+    (torch's version counter), fused._pkey forms a tensor's key once inside a held call and afresh outside, fused._weight_of returns what attribute access
+    returns."""
+    from palettenerf_amd import fused
+    from palettenerf_amd.renderer import _zero_map
+
+    class Owner:
+        pass
+    o, like = Owner(), torch.zeros(1)
+    a = _zero_map(o, "clip_feat", (5, 3), like)
+    assert a.shape == (5, 3) and float(a.abs().sum()) == 0.0
+    assert _zero_map(o, "clip_feat", (5, 3), like) is a                     # cached
+    assert _zero_map(o, "clip_feat", (6, 3), like) is not a                 # another shape
+    b = _zero_map(o, "clip_feat", (6, 3), like)
+    b.add_(1.0)                                                             # a caller scribbles on the map ...
+    c = _zero_map(o, "clip_feat", (6, 3), like)
+    assert c is not b and float(c.abs().sum()) == 0.0                       # ... the next frame gets a clean one
+    assert _zero_map(o, "rgb_norm", (6, 3), like) is not c                  # names do not share entries
+
+    m = network.NeRFNetwork(bound=1, cuda_ray=False)
+    assert fused._weight_of(m, "sigma_net", 1) is m.sigma_net[1].weight and fused._weight_of(m, "color_net", 2) is m.color_net[2].weight
+    w = m.sigma_net[0].weight
+    k0 = fused._pkey(w)
+    f = fused.NeRFFieldFused(m)
+    with f._held():
+        k1 = fused._pkey(w)
+        with torch.no_grad():
+            w.add_(1.0)                                                     # (inside a held call the key is not re-read: the call's own answers stay consistent)
+        assert fused._pkey(w) is k1 and k1 == k0
+    assert fused._pkey(w) != k0                                             # outside: the version counter moved
