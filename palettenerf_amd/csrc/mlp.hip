@@ -654,9 +654,8 @@ __device__ __forceinline__ void split_tiles(const f32x16 (&a)[2], int k, HOp& o)
 // weights are requested in front of this block's three products (a 1-deep software pipeline; the scheduling barrier behind every block keeps the compiler
 // from pulling later reads further up, which blew the register budget, and from sinking this one back to its use, where every block waited ~100 cycles).
 template <int NRT, int NKB>
-__device__ __forceinline__ void layer_h(const unsigned char* __restrict__ slot, const HOp& b, f32x16 (&out)[2], int lane) {
+__device__ __forceinline__ void layer_h(const unsigned char* __restrict__ slot, const HOp& b, f32x16 (&out)[2], int lane, h8 ahi, h8 alo) {
     constexpr int N = NRT * NKB;
-    h8 ahi = *reinterpret_cast<const h8*>(slot + lane * 16), alo = *reinterpret_cast<const h8*>(slot + 1024 + lane * 16);
 #pragma unroll
     for (int i = 0; i < N; i++) {
         const int rt = i / NKB, kb = i % NKB;
@@ -673,6 +672,15 @@ __device__ __forceinline__ void layer_h(const unsigned char* __restrict__ slot, 
         __builtin_amdgcn_sched_barrier(0);
         ahi = nhi; alo = nlo;
     }
+}
+// the operand split of a layer's input and the layer: the FIRST block's weights are requested in front of the split (some 150 vector instructions), not behind it
+// where the layer's first product would wait a full LDS round trip for them
+template <int NT, int NRT, int NKB>
+__device__ __forceinline__ void split_layer(const unsigned char* __restrict__ slot, const f32x16 (&in)[2], int k, HOp& b, f32x16 (&out)[2], int lane) {
+    const h8 ahi = *reinterpret_cast<const h8*>(slot + lane * 16), alo = *reinterpret_cast<const h8*>(slot + 1024 + lane * 16);
+    __builtin_amdgcn_sched_barrier(0);
+    split_tiles<NT>(in, k, b);
+    layer_h<NRT, NKB>(slot, b, out, lane, ahi, alo);
 }
 // hidden activation of a layer's accumulators (stored, e): ReLU commutes with the power of two and keeps e; ELU needs the true value (e becomes 0)
 template <int NT, int ACT>
@@ -718,28 +726,25 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_fwd_h(MlpPlan p, const floa
         HOp b;
         frag_from_stage<TI>(stage, lane, a);
         int k = split_exp(tile_max_exp<TI>(a)), e;
-        split_tiles<TI>(a, k, b);
-        layer_h<2, 2 * TI>(w + (size_t)p.w_off[0] * 4, b, o, lane);
+        split_layer<TI, 2, 2 * TI>(w + (size_t)p.w_off[0] * 4, a, k, b, o, lane);
         e = -k - kw0;
         act_stored<2, ACT>(o, e);
         if (ACT != 0) e = 0;
         k = split_exp(tile_max_exp<2>(o));
-        split_tiles<2>(o, k, b);
         if constexpr (NL == 3) {
-            layer_h<2, 4>(w + (size_t)p.w_off[1] * 4, b, a, lane);
+            split_layer<2, 2, 4>(w + (size_t)p.w_off[1] * 4, o, k, b, a, lane);
             e = e - k - kw1;
             act_stored<2, ACT>(a, e);
             if (ACT != 0) e = 0;
             k = split_exp(tile_max_exp<2>(a));
-            split_tiles<2>(a, k, b);
-            layer_h<TO, 4>(w + (size_t)p.w_off[2] * 4, b, o, lane);
+            split_layer<2, TO, 4>(w + (size_t)p.w_off[2] * 4, a, k, b, o, lane);
             const float u = pow2i(e - k - kw2);
 #pragma unroll
             for (int t = 0; t < TO; t++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) o[t][r] *= u;
         } else {
-            layer_h<TO, 4>(w + (size_t)p.w_off[1] * 4, b, a, lane);
+            split_layer<2, TO, 4>(w + (size_t)p.w_off[1] * 4, o, k, b, a, lane);
             const float u = pow2i(e - k - kw1);
 #pragma unroll
             for (int t = 0; t < TO; t++)
@@ -896,8 +901,7 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd_h(MlpPlan p, const floa
         // forward again: x -> h1 (-> h2)
         frag_from_stage<TI>(GX, lane, t, kXStage);
         const int mx = tile_max_exp<TI>(t), kx = split_exp(mx);
-        split_tiles<TI>(t, kx, b);
-        layer_h<2, 2 * TI>(w + (size_t)p.w_off[0] * 4, b, h1, lane);
+        split_layer<TI, 2, 2 * TI>(w + (size_t)p.w_off[0] * 4, t, kx, b, h1, lane);
         const int e1s = -kx - kw0;
         act_stored<2, ACT>(h1, e1s);
         const int e1 = ACT != 0 ? 0 : e1s;
@@ -905,8 +909,7 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd_h(MlpPlan p, const floa
         int mg, kg, eg = 0;
         if constexpr (NL == 3) {
             const int k1 = split_exp(m1);
-            split_tiles<2>(h1, k1, b);
-            layer_h<2, 4>(w + (size_t)p.w_off[1] * 4, b, h2, lane);
+            split_layer<2, 2, 4>(w + (size_t)p.w_off[1] * 4, h1, k1, b, h2, lane);
             const int e2s = e1 - k1 - kw1;
             act_stored<2, ACT>(h2, e2s);
             const int e2 = ACT != 0 ? 0 : e2s;
@@ -918,8 +921,7 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd_h(MlpPlan p, const floa
             frag_to_stage<2>(GB, lane, h2);
             wave_sync();
             wgrad_lds<TO, 2>(dw2, st2, GA, 0, mg, GB, e2, m2, lane);
-            split_tiles<TO>(g, kg, b);
-            layer_h<2, 2 * TO>(w + (size_t)p.wt_off[2] * 4, b, t, lane);          // dH2 = W2^T dY
+            split_layer<TO, 2, 2 * TO>(w + (size_t)p.wt_off[2] * 4, g, kg, b, t, lane);          // dH2 = W2^T dY
             eg = -kg - kw2;
             act_grad_stored<2, ACT>(t, h2);
             mg = tile_max_exp<2>(t); kg = split_exp(mg);
@@ -928,8 +930,7 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd_h(MlpPlan p, const floa
                 f32x16 xin[2];
                 HOp bx;
                 frag_from_stage<TI>(GX, lane, xin, kXStage);
-                split_tiles<TI>(xin, kx, bx);
-                layer_h<2, 2 * TI>(w + (size_t)p.w_off[0] * 4, bx, h1, lane);
+                split_layer<TI, 2, 2 * TI>(w + (size_t)p.w_off[0] * 4, xin, kx, bx, h1, lane);
                 act_stored<2, ACT>(h1, e1s);
             }
             // layer 1: GA <- dZ2, GB <- h1
@@ -938,8 +939,7 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd_h(MlpPlan p, const floa
             frag_to_stage<2>(GB, lane, h1);
             wave_sync();
             wgrad_lds<2, 2>(dw1, st1, GA, eg, mg, GB, e1, m1, lane);
-            split_tiles<2>(t, kg, b);
-            layer_h<2, 4>(w + (size_t)p.wt_off[1] * 4, b, g, lane);               // dH1 = W1^T dZ2
+            split_layer<2, 2, 4>(w + (size_t)p.wt_off[1] * 4, t, kg, b, g, lane);               // dH1 = W1^T dZ2
             eg = eg - kg - kw1;
             act_grad_stored<2, ACT>(g, h1);
         } else {
@@ -950,8 +950,7 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd_h(MlpPlan p, const floa
             frag_to_stage<2>(GB, lane, h1);
             wave_sync();
             wgrad_lds<TO, 2>(dw1, st1, GA, 0, mg, GB, e1, m1, lane);
-            split_tiles<TO>(g, kg, b);
-            layer_h<2, 2 * TO>(w + (size_t)p.wt_off[1] * 4, b, t, lane);          // dH1 = W1^T dY
+            split_layer<TO, 2, 2 * TO>(w + (size_t)p.wt_off[1] * 4, g, kg, b, t, lane);          // dH1 = W1^T dY
             eg = -kg - kw1;
             act_grad_stored<2, ACT>(t, h1);
             g[0] = t[0]; g[1] = t[1];
@@ -969,8 +968,7 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd_h(MlpPlan p, const floa
         wave_sync();
         wgrad_lds<2, TI>(dw0, st0, GA, eg, mg, GX, 0, mx, lane, kXStage);
         if (dx) {
-            split_tiles<2>(g, kg, b);
-            layer_h<TI, 4>(w + (size_t)p.wt_off[0] * 4, b, t, lane);              // dX = W0^T dZ1
+            split_layer<2, TI, 4>(w + (size_t)p.wt_off[0] * 4, g, kg, b, t, lane);              // dX = W0^T dZ1
             const float u = pow2i(eg - kg - kw0);
 #pragma unroll
             for (int tt = 0; tt < TI; tt++)
