@@ -574,14 +574,22 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_bwd(MlpPlan p, const float*
 //    largest output, as the fp32 launch (tests/test_gpu_ops.py::test_fused_mlp_forward_backward_match_float64).
 //  The backward in the same arithmetic follows below (k_mlp_bwd_h); both have their exact fp32 twins above (pnr_set_option("mlp_f16x3", 0)).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float dpp_max_shr(float v, int which) {
-    int t;
-    const int b = __float_as_int(v);
-    if (which == 1) t = __builtin_amdgcn_update_dpp(b, b, 0x111, 0xf, 0xf, false);        // row_shr:1
-    else if (which == 2) t = __builtin_amdgcn_update_dpp(b, b, 0x112, 0xf, 0xf, false);   // row_shr:2
-    else if (which == 4) t = __builtin_amdgcn_update_dpp(b, b, 0x114, 0xf, 0xf, false);   // row_shr:4
-    else t = __builtin_amdgcn_update_dpp(b, b, 0x118, 0xf, 0xf, false);                   // row_shr:8
-    return fmaxf(v, __int_as_float(t));
+// The row-of-16 maximum of a register, as unsigned integers: |x| >= 0, so the integer order is the float order and NaN patterns sort above Inf.  One assembly
+// statement: the integer maximum takes its DPP operand directly (lanes without a source keep their own value: the destination is the operand), and a DPP read of
+// a register a vector instruction has just written needs two wait states -- as builtins every step was a move, the wait, the DPP move, a canonicalising
+// v_max_f32 and the maximum.  Lane 15 of every row holds the row's maximum afterwards.
+__device__ __forceinline__ uint32_t dpp_row_max_u32(uint32_t b) {
+    asm("s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0"
+        : "+v"(b));
+    return b;
 }
 // Every fragment is carried as (stored values, exponent e) with true = stored * 2^e, e a wave-uniform integer: powers of two commute with the
 // matrix products and with ReLU, so the unscaling of a layer's accumulators costs no instruction per value -- it is integer arithmetic on e.
@@ -593,12 +601,12 @@ __device__ __forceinline__ int tile_max_exp(const f32x16 (&a)[2]) {
     for (int t = 0; t < NT; t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) m = fmaxf(m, fabsf(a[t][r]));
-    m = dpp_max_shr(m, 1); m = dpp_max_shr(m, 2); m = dpp_max_shr(m, 4); m = dpp_max_shr(m, 8);   // lane 15 of every row of 16: the row's maximum
-    const int b = __float_as_int(m);     // non-negative floats order like their bit patterns
-    uint32_t u = (uint32_t)__builtin_amdgcn_readlane(b, 15);
-    u = max(u, (uint32_t)__builtin_amdgcn_readlane(b, 31));
-    u = max(u, (uint32_t)__builtin_amdgcn_readlane(b, 47));
-    u = max(u, (uint32_t)__builtin_amdgcn_readlane(b, 63));
+    uint32_t b = __float_as_uint(m);     // non-negative floats order like their bit patterns
+    b = dpp_row_max_u32(b);              // lane 15 of every row of 16: the row's maximum
+    uint32_t u = (uint32_t)__builtin_amdgcn_readlane((int)b, 15);
+    u = max(u, (uint32_t)__builtin_amdgcn_readlane((int)b, 31));
+    u = max(u, (uint32_t)__builtin_amdgcn_readlane((int)b, 47));
+    u = max(u, (uint32_t)__builtin_amdgcn_readlane((int)b, 63));
     return (int)((u >> 23) & 0xffu);
 }
 // k with 2^k * (largest |stored|) in [2^14, 2^15) (0 for an all-zero or non-finite tile).  k is clamped HERE to what pow2i can represent (a tile
