@@ -1168,6 +1168,9 @@ def main(argv=None):
                 finally:
                     m._fused.time_grid_kernel = False
                     _l.pnr_set_option(b"hosted_tail", 1)
+            out["roofline"]["note_events"] = ("avg_launch_ms: HIP events carried by the lookup launches of the FIRST timed step (hipExtLaunchKernelGGL start / stop); an instrumented launch "
+                                              "includes its completion signal and release fence and reads ~6 us longer than rocprofv3's dispatch time stamps for the same launch "
+                                              "(profiles/frame_launch_avgs.py on a kernel trace of this command): `achieved` / `frac` are the conservative figures")
             out["roofline"]["note_hosted_tail"] = ("the timed launches host the march tail: their first workgroups march the rays the march launch handed over and look those rows up "
                                                    "(algorithmic bytes count the lookup only; `lookup_alone` is the kernel without that work)")
         if F_main > 1:

@@ -9,9 +9,11 @@ prof() {  # name, program args...
   rm -rf /tmp/prof_$name
   timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -o p -- python3 "$@" > $R/gpurun_out/r05/$name.log 2>&1
   db=$(find /tmp/prof_$name -name '*.db' | head -1)
-  { echo "# rocprofv3 --kernel-trace --stats -- python3 $(echo "$@" | sed "s#$R/##g")   (round 5)"; python3 $R/profiles/summarize.py $db; } > $R/gpurun_out/r05/$name.txt
+  { echo "# rocprofv3 --kernel-trace --stats -- python3 $(echo "$@" | sed "s#$R/##g")   (round 5)"; python3 $R/profiles/summarize.py $db;
+    grep -o '"roofline": {"bound": "hbm", "kernel": "[^"]*", "achieved": [0-9.]*, "peak": [0-9.]*, "unit": "GB/s", "frac": [0-9.]*' $R/gpurun_out/r05/$name.log | head -1 | sed 's/^/# the same run, bench.py line: /';
+    grep -o '"avg_launch_ms": [0-9.]*' $R/gpurun_out/r05/$name.log | head -1 | sed 's/^/# the same run, bench.py line (HIP events carried by the working lookup launches of the first timed step): /'; } > $R/gpurun_out/r05/$name.txt
 }
-prof bench_lego $R/bench.py --workload lego --steps 15 --warmup 3 --no-cpu-baseline --no-extras --no-traffic
+prof bench_lego $R/bench.py --workload lego --no-cpu-baseline --no-extras --no-traffic     # (bench.py's default steps / warmup: the driver's command without the legs behind the headline)
 prof bench_lego_palette $R/bench.py --workload lego_palette --steps 15 --warmup 3 --no-cpu-baseline --no-extras --no-traffic
 prof bench_garden $R/bench.py --workload garden --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-traffic
 prof bench_lego_compat $R/bench.py --workload lego --mode compat --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-traffic
