@@ -81,6 +81,9 @@ def parse(argv=None):
                     help="extra leg (1 GPU): the same camera path with F frames in flight, one host thread + stream + fused-field object each (video throughput)")
     ap.add_argument("--shard-emulation", type=int, default=0, metavar="S",
                     help="1 GPU: also render each of the S tile shards of pose 0 on its own and report max / mean shard ms (load balance of the S-GPU split)")
+    ap.add_argument("--emulate-shard", default=None, metavar="R/N",
+                    help="1 GPU, no communicator: render only rank R's share of an N-way tile split of every frame (what rank R of `--gpus N --scaling strong` renders); "
+                         "the PMC child passes of an N > 1 run use it so that roofline.traffic is per launch of the SAME shard-sized launches as roofline.achieved")
     ap.add_argument("--no-interleave", action="store_true", help="-m palette: separate hash-table lookups instead of the interleaved copy (A/B)")
     ap.add_argument("--pred-clip", action="store_true", help="-m palette with the clip-feature head (main_palette.py --pred_clip): third hash table + clip_net")
     ap.add_argument("--num-basis", type=int, default=4)
@@ -110,6 +113,12 @@ def parse(argv=None):
         wl["H"] = wl["W"] = args.res
     args.wl = wl
     args.model = wl["model"]
+    args.shard = None
+    if args.emulate_shard:
+        r, n = (int(v) for v in args.emulate_shard.split("/"))
+        if not 0 <= r < n:
+            ap.error("--emulate-shard R/N needs 0 <= R < N")
+        args.shard = (r, n)
     return args
 
 
@@ -682,6 +691,46 @@ def l2_bound_of(samples_per_launch, n_tables_rows, launch_ms, ceilings=None):
             "note": "rows gathered per clock per CU; above the random-row ceilings because neighbouring lanes share 128-byte lines (8x8-pixel wave tiles, level-major launch)"}
 
 
+LAUNCHER_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_ERROR_FILE",
+                "PNR_BENCH_FORCE_DIST")
+
+
+def child_env(**more):
+    """Environment of a child pass of this script: never the launcher's rank variables (parse() switches the workload and scaling defaults on WORLD_SIZE, and a
+    child must not try to join the parent's communicator)."""
+    env = {k: v for k, v in os.environ.items() if k not in LAUNCHER_ENV}
+    env.update(more)
+    return env
+
+
+L2_PEAK_GBS = 34500.0   # MI355X_MICROARCH.md, "L2 (per XCD)": 4 MiB x 8, ~34.5 TB/s aggregate
+
+
+def roofline_block(kernel_name, achieved, traffic, traffic_info, n_launches, k_ms, k_units, per_sample, n_tables):
+    """The lookup kernel's roofline object.  `achieved` = algorithmic GB/s (SURVEY 8d bytes per sample x live samples / launch time).  While that stays below the
+    HBM peak the bound is HBM (configs[1]: one 50 MB table, 0.7-0.8 of 8 TB/s).  When it does NOT -- the PaletteNeRF lookups read two or three tables through ONE
+    interleaved row per corner and each row serves the eight-fold corner re-use of neighbouring samples out of L2 / Infinity Cache: 17 TB/s of algorithmic bytes
+    -- HBM is not what bounds the kernel and a fraction of its peak above 1 says nothing.  The bound is then the on-die path: `peak` = the guide's aggregate L2
+    bandwidth, `hbm_frac_of_measured_traffic` = the HBM-side bytes the PMC passes measured / launch time / 8 TB/s is what HBM itself sees."""
+    avg_ms = k_ms / max(1, n_launches)
+    on_die = achieved > HBM_PEAK_GBS
+    peak = L2_PEAK_GBS if on_die else HBM_PEAK_GBS
+    r = {"bound": "l2" if on_die else "hbm", "kernel": kernel_name, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+         "traffic": traffic, "traffic_source": traffic_info, "launches": n_launches, "avg_launch_ms": avg_ms,
+         "avg_live_samples_per_launch": k_units / max(1, n_launches) / n_tables,
+         "algorithmic_bytes_per_sample": per_sample * n_tables, "algorithmic_bytes_per_launch": per_sample * k_units / max(1, n_launches),
+         "algorithmic_over_hbm_peak": achieved / HBM_PEAK_GBS}
+    if traffic and avg_ms > 0:
+        r["hbm_frac_of_measured_traffic"] = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        r["traffic_over_algorithmic"] = traffic / max(1.0, r["algorithmic_bytes_per_launch"])
+    if on_die:
+        r["note"] = ("algorithmic bytes per second exceed the HBM peak: the interleaved table rows are re-used out of L2 / Infinity Cache, so the kernel is priced against the "
+                     "aggregate L2 bandwidth (MI355X_MICROARCH.md: ~34.5 TB/s); `traffic` = HBM-side bytes per launch from the PMC passes, `hbm_frac_of_measured_traffic` what "
+                     "HBM itself sees, `l2_bound` the row-gather rate against this box's random-row ceilings")
+    return r
+
+
 def measure_traffic(argv_core, kernel_substr="k_frame_grid", timeout=240):
     """roofline.traffic measured in THIS run: two child passes of this script's headline workload under `rocprofv3 --pmc <counter> --kernel-trace`
     (FETCH_SIZE and WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md, PMC slots), 2 + 3 frames each; HBM-side bytes per lookup launch =
@@ -698,7 +747,7 @@ def measure_traffic(argv_core, kernel_substr="k_frame_grid", timeout=240):
         return None, {"error": "already running under a profiler"}
     vals, info = {}, {}
     tmp = tempfile.mkdtemp(prefix="pnr_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = child_env(TMPDIR="/tmp")
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out_dir = os.path.join(tmp, counter)
@@ -883,7 +932,9 @@ def main(argv=None):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        import datetime
+        # (30 min: rank 0 measures roofline.traffic in two child passes while the others wait at a barrier)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=30))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -896,7 +947,10 @@ def main(argv=None):
     nb = int(getattr(m, "num_basis", 0))
     n_views = world if args.scaling == "weak" else 1
     VH = n_views * H   # the views stacked vertically: one (n_views * H) x W image
-    idx, n_max = pdist.shard_indices(VH, W, rank, world)
+    if args.shard is not None and not use_dist:      # one GPU standing in for rank R of an N-way split (no communicator): the PMC child passes of an N > 1 run
+        idx, n_max = pdist.shard_indices(VH, W, args.shard[0], args.shard[1])
+    else:
+        idx, n_max = pdist.shard_indices(VH, W, rank, world)
     bank = RayBank(args, n_views, idx, device)
     kw = dict(perturb=False, dt_gamma=wl["dt_gamma"], max_steps=1024, T_thresh=1e-4)
     if args.model == "palette":
@@ -1074,10 +1128,10 @@ def main(argv=None):
         if args.scaling == "strong" and native and not args.fp16:
             one = torch.zeros(2, dtype=torch.float64, device=device)
             if rank == 0:
+                saved_order = m._fused.ray_order
                 try:
                     idx_all, _ = pdist.shard_indices(VH, W, 0, 1)
                     bank1 = RayBank(args, 1, idx_all, device)
-                    saved_order = m._fused.ray_order
                     m._fused.ray_order = tile_ray_order(idx_all, W, 8).to(device)
                     n1 = max(3, min(args.steps, 10))
                     for i in range(n1 + 2):
@@ -1085,10 +1139,11 @@ def main(argv=None):
                     timed_frames(m, bank1, kw, 2, args.fp16, first_step=args.warmup)
                     ms1, rend1 = timed_frames(m, bank1, kw, n1, args.fp16, first_step=args.warmup)
                     one[0], one[1] = ms1, rend1
-                    m._fused.ray_order = saved_order
                     del bank1
-                except RuntimeError as e:      # reported; the headline stands
-                    dist_info["single_gpu_error"] = str(e)
+                except Exception as e:      # noqa: BLE001 -- reported; the headline stands, and rank 0 MUST reach the broadcast the other ranks wait in
+                    dist_info["single_gpu_error"] = repr(e)
+                finally:
+                    m._fused.ray_order = saved_order
             dist.broadcast(one, src=0)         # (also the barrier that keeps the other ranks behind rank 0's solo frames)
             if float(one[0]) > 0:
                 dist_info["single_gpu_ms_per_step"] = float(one[0])
@@ -1113,8 +1168,14 @@ def main(argv=None):
         achieved = (k_units * per_sample) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         # HBM-side bytes per lookup launch, MEASURED IN THIS RUN: two child passes of the same workload under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE)
         traffic, traffic_info = None, None
-        if native and world == 1 and not use_dist and not args.no_traffic and F_main == 1:
-            traffic, traffic_info = measure_traffic(core_argv(args))
+        if native and not args.no_traffic and F_main == 1:
+            # N = 1: two child passes of this very command.  N > 1 (or the one-rank communicator of the tests): the children are SINGLE-GPU passes on this rank's
+            # device that render rank 0's shard of the same split (--emulate-shard 0/N: the same rays, the same shard-sized launches; no communicator, the
+            # launcher's environment stripped) -- nothing about a PMC pass needs the collective.  The other ranks wait at the barrier below.
+            targv = core_argv(args)
+            if use_dist:
+                targv = [a for a in targv] + (["--emulate-shard", f"0/{world}"] if world > 1 else [])
+            traffic, traffic_info = measure_traffic(targv, timeout=240 if not use_dist else 180)
         field_note = {"f16x3": "field: f16x3 split products, fp32 accumulate", "f16x2": "field: f16x3 for sigma_net, colour layers with activations rounded once to f16", "fp32": "field: exact fp32 MFMA"}[args.field_precision]
         dtype_label = ("f16 tables + autocast" if args.fp16 else "f32") + (f" ({field_note})" if getattr(m, "fused_field", False) else "")
         raw_steps = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
@@ -1134,17 +1195,15 @@ def main(argv=None):
                        "gathered_floats_per_ray": K if use_dist else 0, "rccl_ranks": dist.get_world_size() if use_dist else 1,
                        "parallelism": f"32x32 ray tiles of {n_views} view(s) round-robin over {world} GPUs + one all_gather/step" if world > 1 else "single GPU",
                        **({"defaulted_for_ranks": True} if args.defaulted_for_ranks else {}), **(dist_info or {})},
-            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_info,
-                         "launches": n_launches,
-                         "avg_launch_ms": k_ms / max(1, n_launches), "avg_live_samples_per_launch": k_units / max(1, n_launches) / (n_tables if native else 1),
-                         "algorithmic_bytes_per_sample": per_sample * (n_tables if native else 1),
-                         "algorithmic_bytes_per_launch": per_sample * k_units / max(1, n_launches)},
+            "roofline": roofline_block(kernel_name, achieved, traffic, traffic_info, n_launches, k_ms, k_units, per_sample, n_tables if native else 1),
         }
+        if dist_info:      # what a strong-scaling curve should be read from, at the top level (the N = 1 run of the driver is configs[1], another workload)
+            for k in ("strong_speedup_vs_single_gpu_in_this_job", "single_gpu_ms_per_step", "shard_render_ms_per_rank", "all_gather_ms"):
+                if k in dist_info:
+                    out[k] = dist_info[k]
         if native and k_ms > 0 and n_launches > 0:
             out["roofline"]["l2_bound"] = l2_bound_of(k_units / n_launches / n_tables, 1, k_ms / n_launches,
-                                                      ceilings=None if (args.no_extras or use_dist) else gather_ceilings())
+                                                      ceilings=None if args.no_extras else gather_ceilings())
             try:    # north_star: MFMA utilisation of the fused field kernel against the gfx950 peak
                 out["roofline"]["mfma"] = mfma_leg(m, args.model, max(1024, int(k_units / n_launches / n_tables)), device, args.field_precision)
             except RuntimeError as e:
@@ -1176,9 +1235,6 @@ def main(argv=None):
         if F_main > 1:
             out["roofline"]["note_frames_in_flight"] = (f"{F_main} frames in flight: the timed launches share the chip with another frame's kernels, and "
                                                         "ms_per_step is elapsed / steps, not the latency of a frame")
-        if achieved > HBM_PEAK_GBS:
-            out["roofline"]["note"] = ("algorithmic bytes per second exceed the HBM peak: table rows are re-used out of L2 / Infinity Cache "
-                                       "(the HBM-side bytes per launch are in `traffic`)")
     if use_dist:
         dist.barrier()
     extra = {}
@@ -1358,6 +1414,29 @@ def main(argv=None):
                 mm._fused.ray_order = m._fused.ray_order
                 timed_frames(mm, bank, kw, 3, True)
                 extra["fp16_mode_ms_per_step"], extra["fp16_mode_rendered_per_step"] = timed_frames(mm, bank, kw, n, True, first_step=args.warmup)
+                # the lookup kernel of THAT mode against SURVEY 8(d)'s fp16 figure (588 B per sample): the frame of the headline's first timed step once more with the
+                # in-library HIP events around every lookup launch (k_frame_grid_h1: half rows, the reference's at::Half accumulator)
+                mm._fused.time_grid_kernel = True
+                try:
+                    ro16, rd16 = bank.get(args.warmup)
+                    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                        r16 = mm.render(ro16, rd16, **kw)
+                    torch.cuda.synchronize()
+                finally:
+                    mm._fused.time_grid_kernel = False
+                h_ms, h_n, h_live = float(r16.get("grid_ms", 0.0)), int(r16.get("grid_launches", 0)), int(r16["rendered"].sum())
+                if h_ms > 0 and h_n > 0:
+                    h_ach = h_live * GRID_BYTES_PER_SAMPLE_FP16 / (h_ms * 1e-3) / 1e9
+                    written = 12 + 16 * 8 * 2 * 2 + 32 * 4
+                    out["roofline_fp16"] = {"bound": "hbm", "kernel": "k_frame_grid_h1 (device-driven frame loop, fp16 table: the reference's -O mode)", "achieved": h_ach, "peak": HBM_PEAK_GBS,
+                                            "unit": "GB/s", "frac": h_ach / HBM_PEAK_GBS, "traffic": None, "launches": h_n, "avg_launch_ms": h_ms / h_n,
+                                            "avg_live_samples_per_launch": h_live / h_n, "algorithmic_bytes_per_sample": GRID_BYTES_PER_SAMPLE_FP16,
+                                            "algorithmic_bytes_per_launch": GRID_BYTES_PER_SAMPLE_FP16 * h_live / h_n,
+                                            "frac_counting_the_fp32_outputs_it_writes": h_live * written / (h_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                            "ms_per_step": extra["fp16_mode_ms_per_step"],
+                                            "note": "SURVEY 8(d)'s fp16 figure (half rows AND half outputs: 588 B); this kernel hands the field fp32 features (652 B written and read). The launch "
+                                                    "lasts as long as the fp32 table's: the gather is bound by row requests per clock (one L2 line per hashed row), not by bytes -- "
+                                                    "half the bytes in the same time is half the fraction"}
                 del mm
             except RuntimeError as e:
                 extra["fp16_mode_error"] = str(e)

@@ -32,6 +32,7 @@ extern "C" {
 #define PNR_ERR_INVALID (-1)      /* null pointer / bad size                                  */
 #define PNR_ERR_UNSUPPORTED (-2)  /* C not in {1,2,4,8}, D not in 1..5, n_channel > 128, ...  */
 #define PNR_ERR_LAUNCH (-3)       /* hipGetLastError() != hipSuccess after a launch           */
+#define PNR_ERR_ALIGNMENT (-4)    /* pnr_mlp_*: an activation array that does not start on a 16-byte boundary or holds fewer than four floats */
 
 #define PNR_DTYPE_F32 0
 #define PNR_DTYPE_F16 1
@@ -517,7 +518,7 @@ int pnr_linear_wgrad(const void* x, int x_dtype, const void* dy, int dy_dtype, u
  *                     hidden activations are recomputed from x; dw is reduced deterministically through `workspace`.
  *                     y: the forward's output, read only with PNR_MLP_OUT_SIGMOID (dZ = dY (1 - y) y; NULL otherwise).
  *   Every activation array (x, x_tail, y, dy, dx; the level-major forms' enc / denc) must start on a 16-byte boundary and hold at least four floats -- tiles move
- *   as 16-byte requests (round 5); PNR_ERR_UNSUPPORTED otherwise. */
+ *   as 16-byte requests (round 5); PNR_ERR_ALIGNMENT otherwise (a contiguous view such as x[1:] of a 3-wide tensor starts inside an allocation: copy it). */
 typedef struct {
     uint32_t n_layers;      /* 2 or 3 */
     uint32_t dims[4];       /* dims[0] = input width ... dims[n_layers] = output width, each 1..64 */

@@ -1118,7 +1118,7 @@ static int mlp_forward_impl(const pnr_mlp_desc* desc, const float* packed, const
     if (int rc = plan_sources(p, lm_levels, x_tail)) return rc;
     const size_t lds = ((size_t)p.wt_off[0] + kMlpWaves * kStageFloats) * 4;
     if (lds > 160 * 1024) return PNR_ERR_UNSUPPORTED;
-    if (!arrays_ok({x, x_tail, y}, B, p)) return PNR_ERR_UNSUPPORTED;
+    if (!arrays_ok({x, x_tail, y}, B, p)) return PNR_ERR_ALIGNMENT;
     hipStream_t s = as_stream(stream);
     const uint32_t tiles = cdiv(B, 32 * kMlpWaves), grid = tiles < 2 * kMlpMaxBlocks ? tiles : 2 * kMlpMaxBlocks;   // two workgroups per CU
     if (g_opt_mlp_f16x3) PNR_MLP_SWITCH(k_mlp_fwd_h, p, packed, x, x_tail, B, y);
@@ -1160,7 +1160,7 @@ static int mlp_backward_impl(const pnr_mlp_desc* desc, const float* packed, cons
     if (lds > 160 * 1024 || p.dw_floats > (uint32_t)(kMlpWaves * 2 * kStageFloats)) return PNR_ERR_UNSUPPORTED;
     const uint32_t blocks = mlp_blocks(B), grid = blocks;
     float* partial = static_cast<float*>(workspace);
-    if (!arrays_ok({x, x_tail, y, dy, dx}, B, p)) return PNR_ERR_UNSUPPORTED;
+    if (!arrays_ok({x, x_tail, y, dy, dx}, B, p)) return PNR_ERR_ALIGNMENT;
     // the split-fp16 backward where it holds its tile without (much) scratch: two layers unless both ends are 64 wide, three layers with 32-wide ends --
     // every stack of both fields; the wider instantiations spill twice what the fp32 ones do and stay on those
     const uint32_t ti = tiles32(p.dims[0]), to = tiles32(p.dims[p.n_layers]);

@@ -812,6 +812,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
     #pragma unroll
                                 for (int q = 0; q < 9; q++) srow[q] = acc[q];
                             }
+                            // The rounds hand the row from lane to lane through LDS: between two of them the compiler must neither keep a lane's own copy of `srow` nor move
+                            // an access across (a wave barrier + a compiler fence: no instruction on the device, where a wave's DS operations complete in order anyway).
+                            auto round_fence = [] { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); };
+                            round_fence();
                             const bool counts = lane < 32 && (int)lane_k_in_ray < ray_cnt_w;
                             const float my_w = counts ? ex[lane * 3] : 0.0f;
     #pragma unroll 1
@@ -825,6 +829,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_palette_field_fwd(PalArgs A_) {
                                         srow[q] = a4;
                                     }
                                 }
+                                round_fence();
                             }
                             if (lead_acc) {
     #pragma unroll

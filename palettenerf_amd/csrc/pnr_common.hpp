@@ -96,14 +96,6 @@ __device__ __forceinline__ void lds_copy16(const void* gsrc, void* lds) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 __device__ __forceinline__ void lds_copy_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// The same request written as inline assembly, for a PREFETCH whose data is used much later: behind the builtin the compiler (which cannot tell the
-// destination from the other dynamic LDS of the kernel) waits vmcnt(0) before the next LDS read -- the request becomes a synchronous trip to memory.
-// Here it does not know an LDS write is in flight; the CALLER must lds_copy_wait() before reading the destination.  The compiler's own vmcnt waits
-// stay safe: memory reads return in order, so counting fewer requests than are outstanding only makes a wait wait for more.
-// lds_base: wave-uniform LDS byte address; lane l's 16 bytes land at lds_base + 16 l (whichever lanes are active).
-__device__ __forceinline__ void lds_prefetch16(const void* gsrc, uint32_t lds_base) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(lds_base) : "memory");
-}
 __device__ __forceinline__ uint32_t lds_address(const void* p) { return (uint32_t)reinterpret_cast<uintptr_t>(p); }   // LDS aperture: the low 32 bits are the LDS offset
 
 // wave64 inclusive prefix sum of an int (DPP-free, shuffle based)

@@ -572,7 +572,7 @@ using namespace pnr;
 
 extern "C" {
 
-int pnr_abi_version(void) { return 6; }
+int pnr_abi_version(void) { return 7; }
 
 int pnr_set_option(const char* name, int value) {
     if (!name) return PNR_ERR_INVALID;
@@ -604,6 +604,7 @@ const char* pnr_error_string(int code) {
         case PNR_ERR_INVALID: return "invalid argument (null pointer or bad size)";
         case PNR_ERR_UNSUPPORTED: return "unsupported configuration";
         case PNR_ERR_LAUNCH: return "HIP kernel launch failed";
+        case PNR_ERR_ALIGNMENT: return "an activation array does not start on a 16-byte boundary or holds fewer than four floats (pnr_mlp_* move tiles as 16-byte requests: copy such a view)";
         default: return "unknown error";
     }
 }

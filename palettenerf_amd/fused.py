@@ -527,7 +527,6 @@ class NeRFFieldFused(_PrecisionGuard, _SourceWatch):
             a.bound, a.C, a.H = float(m.bound), int(m.cascade), int(m.grid_size)
             a.embeddings, a.offsets = emb.data_ptr(), enc.offsets.data_ptr()
             a.num_levels, a.S, a.base_resolution, a.gridtype = enc.num_levels, float(np.log2(enc.per_level_scale)), enc.base_resolution, enc.gridtype_id
-            a.packed_weights = self._pack(prec).data_ptr()
             a.field_precision, a.watch_overflow = int(prec), int(watch)
             for k, v in enumerate(self.enc_scales(prec)):
                 a.enc_scale[k] = v
@@ -536,6 +535,9 @@ class NeRFFieldFused(_PrecisionGuard, _SourceWatch):
             a.ray_order = order.data_ptr() if order is not None else None
             plan = self._frame_plan = (plan_key, a, prec, watch, (emb, self._ws, order))     # (the tensors whose addresses the struct holds)
         a, prec, watch = plan[1], plan[2], plan[3]
+        # The packed blob is NOT part of the plan: the stand-alone ops on this object (`self(x, d)` from network.forward) repack it in place for THEIR precision
+        # (effective_precision() is fp32 where frame_precision() keeps split-fp16 with a watch).  _pack is a key compare when nothing changed.
+        a.packed_weights = self._pack(prec).data_ptr()
         mip = raymarching.occupancy_mip(m.density_bitfield, m.cascade, m.grid_size, m.bound)
         stats = (ctypes.c_uint64 * 6)()
         a.rays_o, a.rays_d = rays_o.data_ptr(), rays_d.data_ptr()
@@ -839,7 +841,6 @@ class PaletteFieldFused(_PrecisionGuard, _SourceWatch):
             a.embeddings = require(enc.embeddings.detach(), torch.float32, "embeddings").data_ptr()
             a.offsets = enc.offsets.data_ptr()
             a.num_levels, a.S, a.base_resolution, a.gridtype = enc.num_levels, float(np.log2(enc.per_level_scale)), enc.base_resolution, enc.gridtype_id
-            a.packed_weights = self._pack(prec).data_ptr()
             a.field_precision, a.watch_overflow = int(prec), int(watch)
             for k, v in enumerate(self.enc_scales(prec)):
                 a.enc_scale[k] = v
@@ -860,6 +861,7 @@ class PaletteFieldFused(_PrecisionGuard, _SourceWatch):
             plan = self._frame_plan = (plan_key, p, prec, watch, (self._ws, order, pair, triple))     # (the tensors whose addresses the struct holds)
         p, prec, watch = plan[1], plan[2], plan[3]
         a = p.base
+        a.packed_weights = self._pack(prec).data_ptr()     # every frame (NeRFFieldFused._render_frame explains): a stand-alone call may have packed ANOTHER tensor since
         mip = raymarching.occupancy_mip(m.density_bitfield, m.cascade, m.grid_size, m.bound)
         stats = (ctypes.c_uint64 * 6)()
         kms = (ctypes.c_float * 2)()

@@ -1024,3 +1024,54 @@ def test_kept_frame_arguments_follow_every_setting(cuda):
     m.density_grid.mul_(0.0).add_(torch.from_numpy(scene.brick_density_grid()).to(cuda).roll(3, dims=1))
     raymarching.packbits(m.density_grid, 0.5, m.density_bitfield)       # another occupancy grid: bitfield version, mip
     frames_agree("occupancy grid")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["nerf", "palette"])
+def test_kept_frame_arguments_survive_a_stand_alone_field_call_at_another_precision(cuda, kind):
+    """weights that fail the STATIC fp16 bound run the stand-alone ops (`model.forward` -> `self._fused(x, d)`) on the exact fp32 path
+    (effective_precision() == 0) while the frame loops keep split-fp16 with the overflow watch (frame_precision()).  The stand-alone call repacks the blob for
+    ITS precision -- in place (NeRF) or into a new tensor (PaletteNeRF) -- so the frame call must not keep the blob's address or layout in its kept argument
+    struct: frame, stand-alone call, frame again = the same frame bit for bit, and equal to a fresh object's frame."""
+    from palettenerf_amd.fused import NeRFFieldFused, PaletteFieldFused
+    if kind == "nerf":
+        m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=100.0)
+        cls = NeRFFieldFused
+    else:
+        m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True, density_scale=100.0)
+        cls = PaletteFieldFused
+    scene.seed_field_(m, 3)
+    m = m.to(cuda).eval()
+    m.density_grid.copy_(torch.from_numpy(scene.brick_density_grid()).to(cuda))
+    raymarching.packbits(m.density_grid, 0.5, m.density_bitfield)
+    H, W = 48, 64
+    ro, rd = scene.get_rays(torch.from_numpy(scene.lookat_pose(azimuth_deg=25.0))[None], scene.intrinsics_from_fov(H, W), H, W)
+    ro, rd = ro[0].to(cuda).contiguous(), rd[0].to(cuda).contiguous()
+
+    def pessimistic(obj):
+        obj._guard_bound = lambda tmax, scales: 1.0e9      # "trained weights": the product of L1 norms is far beyond fp16, the activations are not
+        return obj
+
+    kept = pessimistic(cls(m))
+    assert kept.effective_precision() == 0 and kept.frame_precision() == (1, True)
+    frame = lambda obj: obj.render_frame(ro, rd, None, None, 0.0, 1024, 1e-4, bg_color=1, aabb=m.aabb_infer, min_near=m.min_near)
+    first = frame(kept)
+    assert first[-1]["rendered"] > 1000
+    x = (torch.rand(4096, 3, device=cuda) * 2 - 1) * 1.5
+    d = torch.nn.functional.normalize(torch.randn(4096, 3, device=cuda), dim=-1)
+    for rounds in range(2):
+        alone = kept(x, d)                                   # fp32 layout now sits in (or replaced) the blob the first frame used
+        assert kept.versions[-1] == 0
+        torch.empty(1 << 22, device=cuda).fill_(float("nan"))   # whatever the allocator hands out next must not be what the frame reads
+        again = frame(kept)
+        assert kept.versions[-1] == 1
+        assert again[-1]["rendered"] == first[-1]["rendered"]
+        for a, b in zip(first[:-1], again[:-1]):
+            assert torch.equal(a, b)
+    fresh = frame(pessimistic(cls(m)))
+    for a, b in zip(first[:-1], fresh[:-1]):
+        assert torch.equal(a, b)
+    kept.precision = 0                                       # and the stand-alone result itself is the exact-fp32 one
+    exact = kept(x, d)
+    for a, b in zip(alone, exact):
+        assert torch.equal(a, b)

@@ -312,6 +312,17 @@ def test_bench_default_line_for_more_than_one_rank_over_rccl(cuda):
     assert line["value"] > 0 and cfg["rendered_samples_per_step"] == cfg["single_gpu_samples_per_step"]
     weak = line["extra"]["weak"]
     assert weak["workload"].startswith("configs[1]") and weak["pipelined"]["value"] > 0 and weak["gathered_floats_per_ray"] == 5
+    # round 6: the numbers a strong-scaling curve is read from sit at the top level, and the roofline object stands on its own -- a fraction of a peak that can
+    # bound the kernel (the interleaved PaletteNeRF lookup is served on-die: L2, not HBM) next to HBM-side traffic MEASURED in this run (two single-GPU PMC child passes)
+    for k in ("strong_speedup_vs_single_gpu_in_this_job", "single_gpu_ms_per_step", "shard_render_ms_per_rank", "all_gather_ms"):
+        assert line[k] == cfg[k]
+    roof = line["roofline"]
+    assert roof["bound"] in ("hbm", "l2") and 0 < roof["frac"] <= 1.0, roof
+    assert roof["traffic"] is not None and roof["traffic"] > 0, roof.get("traffic_source")
+    assert 0 < roof["hbm_frac_of_measured_traffic"] <= 1.0
+    if roof["bound"] == "l2":
+        assert roof["algorithmic_over_hbm_peak"] > 1.0 and roof["peak"] > 8000.0
+    assert "ceilings_source" in roof["l2_bound"]
 
 
 def test_headline_crop_against_the_live_oracle_and_its_committed_digest(cuda, golden_dir):
@@ -371,8 +382,9 @@ def test_palette_crops_against_the_live_oracle_and_their_committed_digests(cuda,
     # (b) the committed digest.  The march itself is bit-exact (ray-point counts: tests/test_gpu_ops.py, test_gpu_reference_kernels.py); `rendered` also counts
     # on WHEN a ray's transmittance falls below T_thresh, a comparison of floats that the two arithmetics (split-fp16 MFMA here, fp32 BLAS in the oracle)
     # decide differently for a handful of rays whose T sits within 1e-6 of the threshold: the lego crops match exactly, the garden crop (dt_gamma 1/128,
-    # 1.9 M samples) by 4 samples.  Such a ray ends one sample apart: at most T_thresh = 1e-4 of one sample's colour.
-    slack = 0 if name == "crop400_palette" else 32
+    # 1.9 M samples) by 4 samples (measured on three boxes, rounds 5-6).  Such a ray ends one sample apart: at most T_thresh = 1e-4 of one sample's colour.
+    # Slack = twice the measured 4; the per-pixel bound on those rays is north_star's colour contract, 1e-4 (measured 2.2e-5 on alpha, 3.8e-6 on rgb).
+    slack = 0 if name == "crop400_palette" else 8
     assert abs(int(g["rendered"].sum()) - int(fx["rendered"])) <= slack
     assert int((g["weights_sum"] > 0).sum()) == int(fx["hit_rays"])
     dg = gcp.digest(g, c)
@@ -386,5 +398,5 @@ def test_palette_crops_against_the_live_oracle_and_their_committed_digests(cuda,
     for k in gcp.MAPS + ("weights_sum",):
         a, b = g[k].detach().cpu().reshape(c * c, -1), o[k].reshape(c * c, -1)
         d = (a - b).abs().max(dim=1).values
-        assert int((d > 1e-5).sum()) <= slack and float(d.max()) <= (1e-5 if slack == 0 else 2e-4), (k, float(d.max()), int((d > 1e-5).sum()))
+        assert int((d > 1e-5).sum()) <= slack and float(d.max()) <= (1e-5 if slack == 0 else 1e-4), (k, float(d.max()), int((d > 1e-5).sum()))
     assert scene.psnr(g["image"].cpu().reshape(-1, 3), o["image"].reshape(-1, 3)) > 100.0

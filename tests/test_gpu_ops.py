@@ -1800,4 +1800,4 @@ def test_fused_mlp_tile_moves_on_odd_widths_and_ragged_ends(cuda, dims, B, sig, 
         packed = torch.empty(int(lib.pnr_mlp_packed_bytes(ctypes.byref(desc))) // 4, dtype=torch.float32, device=cuda)
         y = torch.empty(B, dims[-1], device=cuda)
         rc = lib.pnr_mlp_forward(ctypes.byref(desc), packed.data_ptr(), x_view.data_ptr(), B, y.data_ptr(), None)
-        assert rc == -2      # PNR_ERR_UNSUPPORTED
+        assert rc == -4 and b"16-byte" in lib.pnr_error_string(rc)      # PNR_ERR_ALIGNMENT: the error says what is wrong
