@@ -134,6 +134,21 @@ int pnr_composite_rays_flex(uint32_t n_alive, uint32_t n_step, uint32_t n_channe
                             const int32_t* rays_alive, const float* rays_t, const float* sigmas,
                             const float* input, const float* deltas, const float* weights_sum, float* output,
                             pnr_stream_t stream);
+/* SURVEY 8(b)'s "multi-map variant" (ABI 7): the six / seven composite_rays_flex calls one march iteration of PaletteRenderer.run_cuda issues over the SAME
+ * sigmas / deltas / rays_alive / weights_sum (palette/renderer.py:508-516) as ONE launch -- a ray's weights are formed once and folded into every map.  Each
+ * map's output is bit for bit what pnr_composite_rays_flex gives (same fmaf chain per channel).  Legal to batch because composite_rays_flex writes neither
+ * rays_alive nor rays_t nor weights_sum (raymarching.cu:1114-1185) and the reference issues all of them BEFORE the iteration's composite_rays (:517-519).
+ * maps: host array of n_maps <= PNR_FLEX_MAX_MAPS entries (n_channel <= 128 each; an entry with n_channel 0 is skipped); n_step > 8 runs the maps one by one. */
+#define PNR_FLEX_MAX_MAPS 8
+typedef struct {
+    uint32_t n_channel;
+    const float* input;     /* [n_alive * n_step, n_channel] */
+    float* output;          /* [N, n_channel], accumulated in place */
+} pnr_flex_map;
+int pnr_composite_rays_flex_multi(uint32_t n_alive, uint32_t n_step, float T_thresh, const int32_t* rays_alive,
+                                  const float* rays_t, const float* sigmas, const float* deltas,
+                                  const float* weights_sum, const pnr_flex_map* maps, uint32_t n_maps,
+                                  pnr_stream_t stream);
 
 /* MI355X-first additions: occupancy mip.  The bitfield is Morton-ordered, so a 4x4x4 brick of cells is one
  * aligned 8-byte word; pnr_build_occupancy_mip reduces every brick to an any-bit and an all-bit

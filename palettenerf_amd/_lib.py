@@ -31,6 +31,7 @@ SIGNATURES = {
     "pnr_march_rays": [_u32, _u32, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "pnr_composite_rays": [_u32, _u32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "pnr_composite_rays_flex": [_u32, _u32, _u32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "pnr_composite_rays_flex_multi": [_u32, _u32, _f32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _u32, _ptr],
     "pnr_occupancy_mip_bytes": [_u32, _u32],
     "pnr_build_occupancy_mip": [_ptr, _u32, _u32, _f32, _ptr, _ptr],
     "pnr_march_rays_mip": [_u32, _u32, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _u32, _u32, _u32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
@@ -114,6 +115,14 @@ class AdamScalars(ctypes.Structure):
 
 
 MLP_OUT_SIGMOID = 0x100   # PNR_MLP_OUT_SIGMOID
+
+
+FLEX_MAX_MAPS = 8
+
+
+class FlexMap(ctypes.Structure):
+    """Mirror of `pnr_flex_map` (include/pnr.h)."""
+    _fields_ = [("n_channel", _u32), ("input", _ptr), ("output", _ptr)]
 
 
 class MlpDesc(ctypes.Structure):

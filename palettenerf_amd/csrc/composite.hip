@@ -432,6 +432,84 @@ __global__ void __launch_bounds__(kBlock) k_composite_rays_flex(uint32_t n_alive
     }
 }
 
+// SURVEY 8(b)'s "multi-map variant" of composite_rays_flex: the reference's PaletteNeRF loop issues six (seven without gui_mode) flex composites per march
+// iteration over the SAME sigmas / deltas / rays_alive / weights_sum (palette/renderer.py:508-516), each a launch of one thread per ray that walks the ray's
+// samples again to rebuild the same weights and reads its input rows with a stride of n_channel floats between lanes (a wave's twelve 4-byte loads of a
+// 12-channel map each touch the same 24 lines).  Here a workgroup takes 64 consecutive alive rays:
+//   phase 1 (one thread per ray)  the weights w[k] of the ray's samples, ONCE (raymarching.cu:1150-1176: alpha, T = 1 - weights_sum, stop at a dead sample,
+//                                 stop after the sample that sees T < T_thresh) and how many count, into LDS;
+//   phase 2 (one thread per (ray, channel) element, map by map)  the workgroup's input block of a map is one contiguous run of 64 x n_step x n_channel
+//                                 floats: lanes walk it element by element -- coalesced for n_step == 1 (every heavy iteration), runs of n_channel floats
+//                                 otherwise -- and each element folds its ray's weights in sample order: per channel the same fmaf chain as
+//                                 k_composite_rays_flex, bit-identical outputs.
+// n_step <= kMultiSteps (the inference loop's n_step is at most 8: nerf/renderer.py:357).  A negative ray id (a list that was not compacted) is skipped.
+constexpr int kMultiSteps = 8;
+constexpr uint32_t kMultiRays = 64;      // rays per workgroup (a late iteration has a few thousand rays: 256 per workgroup left most CUs idle)
+constexpr uint32_t kMultiThreads = 256;
+struct FlexMaps {
+    uint32_t n_maps;
+    uint32_t n_channel[PNR_FLEX_MAX_MAPS];
+    uint32_t magic[PNR_FLEX_MAX_MAPS];      // floor(2^32 / n_channel) + 1: e / n_channel == umulhi(e, magic) for e < 2^16 x ...
+    const float* input[PNR_FLEX_MAX_MAPS];
+    float* output[PNR_FLEX_MAX_MAPS];
+};
+
+__global__ void __launch_bounds__(kMultiThreads) k_composite_rays_flex_multi(uint32_t n_alive, uint32_t n_step, float T_thresh, const int32_t* __restrict__ rays_alive,
+                                                                          const float* __restrict__ sigmas, const float* __restrict__ deltas,
+                                                                          const float* __restrict__ weights_sum, const FlexMaps maps) {
+    __shared__ float w_s[kMultiRays * kMultiSteps];
+    __shared__ int32_t idx_s[kMultiRays];
+    __shared__ uint32_t cnt_s[kMultiRays];
+    const uint32_t n0 = blockIdx.x * kMultiRays;
+    if (threadIdx.x < kMultiRays) {
+        const uint32_t r = threadIdx.x, n = n0 + r;
+        uint32_t cnt = 0;
+        int index = -1;
+        if (n < n_alive) {
+            index = rays_alive[n];
+            if (index >= 0) {
+                const float* s = sigmas + (size_t)n * n_step;
+                const float* dl = deltas + (size_t)n * n_step * 2;
+                float ws = weights_sum[index];
+#pragma unroll
+                for (int k = 0; k < kMultiSteps; k++) {
+                    if ((uint32_t)k >= n_step || cnt != (uint32_t)k) continue;     // (cnt == k: every earlier sample counted and none stopped the ray)
+                    if (dl[2 * k] == 0) continue;
+                    const float alpha = alpha_of(s[k], dl[2 * k]);
+                    const float T = 1.0f - ws;
+                    const float w = alpha * T;
+                    ws += w;
+                    w_s[r * kMultiSteps + k] = w;
+                    cnt = (T < T_thresh) ? 0x80000000u | (uint32_t)(k + 1) : (uint32_t)(k + 1);     // (the sample that sees T < T_thresh still counts; nothing behind it does)
+                }
+                cnt &= 0x7fffffffu;
+            }
+        }
+        idx_s[r] = index;
+        cnt_s[r] = cnt;
+    }
+    __syncthreads();
+    const uint32_t rays_here = min(kMultiRays, n_alive - n0);
+    for (uint32_t m = 0; m < maps.n_maps; m++) {
+        const uint32_t nc = maps.n_channel[m], magic = maps.magic[m];
+        const float* __restrict__ in_base = maps.input[m] + (size_t)n0 * n_step * nc;
+        float* __restrict__ out = maps.output[m];
+        const uint32_t total = rays_here * nc;
+        for (uint32_t e = threadIdx.x; e < total; e += kMultiThreads) {
+            const uint32_t r = nc == 1u ? e : __umulhi(e, magic), c = e - r * nc;     // (2^32 / 1 + 1 does not fit the magic's 32 bits)
+            const uint32_t cnt = cnt_s[r];
+            if (cnt == 0) continue;
+            float* o = out + (size_t)idx_s[r] * nc + c;
+            const float* in = in_base + (size_t)r * n_step * nc + c;
+            float acc = *o;
+#pragma unroll
+            for (int k = 0; k < kMultiSteps; k++)
+                if ((uint32_t)k < cnt) acc = fmaf(w_s[r * kMultiSteps + k], in[(size_t)k * nc], acc);
+            *o = acc;
+        }
+    }
+}
+
 }  // namespace pnr
 
 using namespace pnr;
@@ -514,8 +592,43 @@ int pnr_composite_rays_flex(uint32_t n_alive, uint32_t n_step, uint32_t n_channe
     if (n_channel > PNR_CHANNEL_MAXIMUM) return PNR_ERR_UNSUPPORTED;
     if (n_alive == 0 || n_channel == 0) return PNR_OK;
     if (!rays_alive || !sigmas || !input || !deltas || !weights_sum || !output) return PNR_ERR_INVALID;
+    if (n_step <= (uint32_t)kMultiSteps && g_opt_flex_coop) {     // the inference loop's schedule: the workgroup-cooperative form (coalesced rows; same bits)
+        FlexMaps fm;
+        fm.n_maps = 1; fm.n_channel[0] = n_channel; fm.magic[0] = (uint32_t)((1ull << 32) / n_channel) + 1u; fm.input[0] = input; fm.output[0] = output;
+        hipLaunchKernelGGL(k_composite_rays_flex_multi, dim3(cdiv(n_alive, kMultiRays)), dim3(kMultiThreads), 0, as_stream(stream), n_alive, n_step, T_thresh, rays_alive,
+                           sigmas, deltas, weights_sum, fm);
+        return check_launch();
+    }
     hipLaunchKernelGGL(k_composite_rays_flex, dim3(cdiv(n_alive, kBlock)), dim3(kBlock), 0, as_stream(stream), n_alive, n_step, n_channel,
                        T_thresh, rays_alive, sigmas, input, deltas, weights_sum, output);
+    return check_launch();
+}
+
+int pnr_composite_rays_flex_multi(uint32_t n_alive, uint32_t n_step, float T_thresh, const int32_t* rays_alive, const float* rays_t, const float* sigmas,
+                                  const float* deltas, const float* weights_sum, const pnr_flex_map* maps, uint32_t n_maps, pnr_stream_t stream) {
+    (void)rays_t;
+    if (n_maps > PNR_FLEX_MAX_MAPS) return PNR_ERR_UNSUPPORTED;
+    if (n_maps > 0 && !maps) return PNR_ERR_INVALID;
+    FlexMaps fm;
+    fm.n_maps = 0;
+    for (uint32_t m = 0; m < n_maps; m++) {
+        if (maps[m].n_channel > PNR_CHANNEL_MAXIMUM) return PNR_ERR_UNSUPPORTED;
+        if (maps[m].n_channel == 0) continue;                                   // (as pnr_composite_rays_flex: nothing to do for an empty map)
+        if (n_alive > 0 && (!maps[m].input || !maps[m].output)) return PNR_ERR_INVALID;
+        fm.n_channel[fm.n_maps] = maps[m].n_channel; fm.magic[fm.n_maps] = (uint32_t)((1ull << 32) / maps[m].n_channel) + 1u;
+        fm.input[fm.n_maps] = maps[m].input; fm.output[fm.n_maps] = maps[m].output;
+        fm.n_maps++;
+    }
+    if (n_alive == 0 || fm.n_maps == 0) return PNR_OK;
+    if (!rays_alive || !sigmas || !deltas || !weights_sum) return PNR_ERR_INVALID;
+    if (n_step > (uint32_t)kMultiSteps) {     // beyond the inference loop's schedule: the maps one by one through the single-map kernel (same results, n_maps launches)
+        for (uint32_t m = 0; m < fm.n_maps; m++)
+            hipLaunchKernelGGL(k_composite_rays_flex, dim3(cdiv(n_alive, kBlock)), dim3(kBlock), 0, as_stream(stream), n_alive, n_step, fm.n_channel[m], T_thresh,
+                               rays_alive, sigmas, fm.input[m], deltas, weights_sum, fm.output[m]);
+        return check_launch();
+    }
+    hipLaunchKernelGGL(k_composite_rays_flex_multi, dim3(cdiv(n_alive, kMultiRays)), dim3(kMultiThreads), 0, as_stream(stream), n_alive, n_step, T_thresh, rays_alive, sigmas,
+                       deltas, weights_sum, fm);
     return check_launch();
 }
 

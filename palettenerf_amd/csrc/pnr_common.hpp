@@ -128,4 +128,5 @@ extern int g_opt_coarse_image;  // binned table gradient: LDS images for the coa
 extern int g_opt_scatter_staged;  // binned table gradient: LDS-ordered, coalesced record writes
 extern int g_opt_cell_merge;  // binned table gradient: cell-run merging on mid levels
 extern int g_opt_grid_nt;
+extern int g_opt_flex_coop;   // drop-in composite_rays_flex: workgroup-cooperative kernel (composite.hip)
 extern int g_opt_iteration_margin;   // frame loops: spare iterations enqueued beyond the previous frame's count before the first host look

@@ -565,6 +565,7 @@ int g_opt_mlp_f16x3 = getenv("PNR_MLP_FP32") ? 0 : 1;   // training MLP launches
 int g_opt_coarse_image = getenv("PNR_NO_COARSE_IMAGE") ? 0 : 1;   // binned table gradient: the coarsest levels accumulated as LDS images (grid_binned.hip: k_coarse_image)
 int g_opt_scatter_staged = getenv("PNR_NO_SCATTER_STAGED") ? 0 : 1;   // binned table gradient: records ordered by bucket in LDS and written coalesced (grid_binned.hip: k_bin_scatter_staged)
 int g_opt_cell_merge = getenv("PNR_NO_CELL_MERGE") ? 0 : 1;   // binned table gradient: mid levels merge the samples of one cell before writing records
+int g_opt_flex_coop = getenv("PNR_NO_FLEX_COOP") ? 0 : 1;   // composite_rays_flex (n_step <= 8): the workgroup-cooperative kernel (coalesced rows) instead of one thread per ray; same bits
 int g_opt_grid_nt = getenv("PNR_GRID_NT") ? atoi(getenv("PNR_GRID_NT")) : 0;   // experiment: non-temporal stores (1) / input loads (2) in k_grid_fwd_d3c2
 int g_opt_adam_variant = 0;   // experiment switch of adam.hip (which multiply-adds are contracted); 0 = torch's kernels on this platform
 
@@ -592,6 +593,7 @@ int pnr_set_option(const char* name, int value) {
     if (!strcmp(name, "coarse_image")) { g_opt_coarse_image = value != 0; return PNR_OK; }
     if (!strcmp(name, "cell_merge")) { g_opt_cell_merge = value != 0; return PNR_OK; }
     if (!strcmp(name, "scatter_staged")) { g_opt_scatter_staged = value != 0; return PNR_OK; }
+    if (!strcmp(name, "flex_coop")) { g_opt_flex_coop = value != 0; return PNR_OK; }
     if (!strcmp(name, "grid_nt")) { g_opt_grid_nt = value & 3; return PNR_OK; }
     if (!strcmp(name, "adam_variant")) { g_opt_adam_variant = value & 7; return PNR_OK; }
     if (!strcmp(name, "iteration_margin")) { g_opt_iteration_margin = value < 0 ? 0 : (value > 64 ? 64 : value); return PNR_OK; }

@@ -57,10 +57,18 @@ def fuse_field(model, precision="f16x3"):
     if hasattr(model, "encoder_palette"):
         # PaletteNetwork (palette/network.py): forward(x, d) -> (sigma, clip_feat, omega, offsets_radiance, view_dep, diffuse) from two (three) lookups +
         # ONE fused launch (12-14 layers, SH, ELU, the heads' softplus normalisation; pnr_palette_field_forward with the network-heads row).  The
-        # colour-basis composite, RegionEdit / Stylizer and the seven composite_rays_flex calls stay the reference renderer's own code.
+        # colour-basis composite and RegionEdit / Stylizer stay the reference renderer's own code; its seven composite_rays_flex calls stay where they are and reach
+        # the device as one launch (below).
         fused = PaletteFieldFused(model)
         fused.precision = {"fp32": 0, "f16x3": 1, "f16x2": 1}[precision]
-        run = fused.network_forward
+
+        def run(x, d):
+            out = fused.network_forward(x, d)
+            # what follows an inference forward() in run_cuda are the iteration's six / seven composite_rays_flex calls and then composite_rays
+            # (palette/renderer.py:508-519): they are collected and issued as ONE pnr_composite_rays_flex_multi launch in front of that composite_rays
+            # (raymarching._FlexQueue: same bits; the deferral ends with that call)
+            _rm.arm_flex_deferral()
+            return out
     else:
         fused = NeRFFieldFused(model)
         fused.precision = {"fp32": 0, "f16x3": 1, "f16x2": 2}[precision]

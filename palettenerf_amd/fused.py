@@ -917,8 +917,19 @@ class PaletteFieldFused(_PrecisionGuard, _SourceWatch):
         B = x.shape[0]
         dev = x.device
         x01 = ((x + m.bound) / (2 * m.bound)).contiguous()
-        enc = grid_encode_raw(m.encoder, x01)
-        enc_pal = grid_encode_raw(m.encoder_palette, x01)
+        pair = None
+        if self.interleave_tables and not self.pred_clip and not self.table_half and pairable(m.encoder, m.encoder_palette):
+            pair = self._pair_table()       # the native loop's interleaved copy (rebuilt when either table changes): one 16-byte gather serves both lookups
+        if pair is not None:
+            L = m.encoder.num_levels
+            enc = torch.empty(L, B, 2, device=dev, dtype=torch.float32)
+            enc_pal = torch.empty(L, B, 2, device=dev, dtype=torch.float32)
+            e0 = m.encoder
+            call("pnr_grid_encode_forward_pair", ptr(require(x01, torch.float32, "inputs")), ptr(pair), ptr(e0.offsets), ptr(enc), ptr(enc_pal), _u32(B), _u32(L),
+                 _f32(np.log2(e0.per_level_scale)), _u32(e0.base_resolution), _u32(e0.gridtype_id), _int(int(e0.align_corners)), units=B)
+        else:
+            enc = grid_encode_raw(m.encoder, x01)
+            enc_pal = grid_encode_raw(m.encoder_palette, x01)
         enc_clip = grid_encode_raw(m.encoder_clip, x01) if self.pred_clip else None
         sigmas = torch.empty(B, dtype=torch.float32, device=dev)
         rgbs = torch.empty(B, 3, dtype=torch.float32, device=dev)

@@ -323,7 +323,14 @@ class _march_rays(Function):
         return xyzs, dirs, deltas
 
 
-march_rays = _march_rays.apply
+_march_rays_now = _march_rays.apply
+
+
+def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, near, far, align=-1, perturb=False, dt_gamma=0, max_steps=1024):
+    """raymarching/raymarching.py:347-398."""
+    if _flex_queue.shared is not None or _flex_queue.armed:
+        _flex_queue.flush()
+    return _march_rays_now(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, near, far, align, perturb, dt_gamma, max_steps)
 
 
 class _composite_rays(Function):
@@ -341,7 +348,15 @@ class _composite_rays(Function):
         return tuple()
 
 
-composite_rays = _composite_rays.apply
+_composite_rays_now = _composite_rays.apply
+
+
+def composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh=1e-2):
+    """raymarching/raymarching.py:401-423 (in place; returns an empty tuple).  Queued flex composites (defer_flex_composites) are issued first: this call is the
+    writer of what they read."""
+    if _flex_queue.shared is not None or _flex_queue.armed:
+        _flex_queue.flush()
+    return _composite_rays_now(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh)
 
 
 class _composite_rays_flex(Function):
@@ -359,7 +374,92 @@ class _composite_rays_flex(Function):
         return tuple()
 
 
-composite_rays_flex = _composite_rays_flex.apply
+_composite_rays_flex_now = _composite_rays_flex.apply
+
+
+def composite_rays_flex_multi(n_alive, n_step, rays_alive, rays_t, sigmas, deltas, weights_sum, maps, T_thresh=1e-2):
+    """SURVEY 8(b)'s multi-map variant: every (n_channel, input, output) of `maps` composited by ONE launch (pnr_composite_rays_flex_multi) -- what the
+    six / seven `composite_rays_flex` calls of one march iteration of PaletteRenderer.run_cuda compute (palette/renderer.py:508-516), each output bit for
+    bit the single call's.  More than PNR_FLEX_MAX_MAPS maps are issued in groups."""
+    sigmas, deltas = require(sigmas.contiguous(), torch.float32, "sigmas"), require(deltas.contiguous(), torch.float32, "deltas")
+    require(rays_alive, torch.int32, "rays_alive"), require(weights_sum, torch.float32, "weights_sum")
+    keep = []
+    for g in range(0, len(maps), _lib.FLEX_MAX_MAPS):
+        group = maps[g:g + _lib.FLEX_MAX_MAPS]
+        arr = (_lib.FlexMap * len(group))()
+        for i, (n_channel, inp, out) in enumerate(group):
+            inp = require(inp.contiguous(), torch.float32, "input")
+            keep.append(inp)
+            arr[i].n_channel, arr[i].input, arr[i].output = int(n_channel), inp.data_ptr(), require(out, torch.float32, "output").data_ptr()
+        call("pnr_composite_rays_flex_multi", int(n_alive), int(n_step), float(T_thresh), ptr(rays_alive), ptr(rays_t), ptr(sigmas), ptr(deltas), ptr(weights_sum),
+             ctypes.cast(arr, ctypes.c_void_p), len(group))
+    return tuple()
+
+
+class _FlexQueue:
+    """Opt-in deferral of composite_rays_flex (dropin.fuse_field switches it on; defer_flex_composites(False) off).  The reference's PaletteNeRF loop calls
+    composite_rays_flex six or seven times per march iteration and THEN composite_rays (palette/renderer.py:508-519).  composite_rays_flex reads sigmas / input /
+    deltas / rays_alive / weights_sum and writes only its own `output` (raymarching.cu:1114-1185), so the calls of an iteration commute with each other and may be
+    issued at any point before the next writer of what they read -- composite_rays (weights_sum, rays_alive).  With deferral on, a call is queued (the tensors are
+    held) and the queue is issued as ONE pnr_composite_rays_flex_multi launch in front of the next composite_rays / march_rays / compact_alive of this module, or
+    by flush_flex_composites() -- call that before reading a flex output that no composite_rays follows.  Calls whose shared arguments differ from the queue's
+    flush it first.  Results are bit for bit those of the immediate calls."""
+
+    def __init__(self):
+        self.on = False
+        self.armed = False     # one-shot: on until the next flush (dropin.fuse_field arms it behind every fused PaletteNetwork.forward of an inference iteration)
+        self.shared = None     # (n_alive, n_step, rays_alive, rays_t, sigmas, deltas, weights_sum, T_thresh)
+        self.maps = []
+
+    def push(self, n_alive, n_step, n_channel, rays_alive, rays_t, sigmas, input, deltas, weights_sum, output, T_thresh):
+        sh = self.shared
+        if sh is not None and not (sh[0] == n_alive and sh[1] == n_step and sh[2] is rays_alive and sh[4] is sigmas and sh[5] is deltas and sh[6] is weights_sum
+                                   and sh[7] == T_thresh):
+            self.flush()
+        if self.shared is None:
+            self.shared = (n_alive, n_step, rays_alive, rays_t, sigmas, deltas, weights_sum, T_thresh)
+        self.maps.append((n_channel, input, output))
+
+    def flush(self):
+        self.armed = False
+        if self.shared is None:
+            return
+        (n_alive, n_step, rays_alive, rays_t, sigmas, deltas, weights_sum, T_thresh), maps = self.shared, self.maps
+        self.shared, self.maps = None, []
+        if len(maps) == 1:
+            _composite_rays_flex_now(n_alive, n_step, maps[0][0], rays_alive, rays_t, sigmas, maps[0][1], deltas, weights_sum, maps[0][2], T_thresh)
+        else:
+            composite_rays_flex_multi(n_alive, n_step, rays_alive, rays_t, sigmas, deltas, weights_sum, maps, T_thresh)
+
+
+_flex_queue = _FlexQueue()
+
+
+def defer_flex_composites(on=True):
+    """Switch the deferral of composite_rays_flex on or off (_FlexQueue explains); returns the previous setting."""
+    was = _flex_queue.on
+    if not on:
+        _flex_queue.flush()
+    _flex_queue.on = bool(on)
+    return was
+
+
+def flush_flex_composites():
+    _flex_queue.flush()
+
+
+def arm_flex_deferral():
+    """Defer the composite_rays_flex calls from here up to the next composite_rays / march_rays / compact_alive / flush_flex_composites (one march iteration of
+    the reference's loop), then fall back to immediate calls."""
+    _flex_queue.armed = True
+
+
+def composite_rays_flex(n_alive, n_step, n_channel, rays_alive, rays_t, sigmas, input, deltas, weights_sum, output, T_thresh=1e-2):
+    """raymarching/raymarching.py:425-447 (in place on `output`; returns an empty tuple)."""
+    if (_flex_queue.on or _flex_queue.armed) and not torch.is_autocast_enabled() and sigmas.dtype == torch.float32 and input.dtype == torch.float32:
+        _flex_queue.push(n_alive, n_step, n_channel, rays_alive, rays_t, sigmas, input, deltas, weights_sum, output, T_thresh)
+        return tuple()
+    return _composite_rays_flex_now(n_alive, n_step, n_channel, rays_alive, rays_t, sigmas, input, deltas, weights_sum, output, T_thresh)
 
 
 class _spread_ray_to_sample(Function):
@@ -382,6 +482,8 @@ spread_ray_to_sample = _spread_ray_to_sample.apply
 def compact_alive(rays_alive, n_alive=None, out=None, count=None):
     """Device-side, order-preserving replacement of `rays_alive[rays_alive >= 0]`
     (nerf/renderer.py:376).  Returns (compacted ids buffer, device int32[1] count); no host sync."""
+    if _flex_queue.shared is not None or _flex_queue.armed:
+        _flex_queue.flush()
     n = rays_alive.shape[0] if n_alive is None else n_alive
     if out is None:
         out = torch.empty_like(rays_alive)

@@ -413,6 +413,115 @@ def test_composite_rays_inference_in_place(cuda, n_step):
         np.testing.assert_allclose(host(g[k]), o[k], **EXP_TOL)
 
 
+@pytest.mark.parametrize("n_step", [1, 2, 5, 8, 11])
+def test_composite_rays_flex_multi_is_bit_identical_to_the_single_calls(cuda, n_step):
+    """SURVEY 8(b)'s multi-map variant (pnr_composite_rays_flex_multi): the seven flex composites of one PaletteNeRF march iteration (palette/renderer.py:508-516:
+    3, 3, nb, 3 nb, 3 nb, clip_dim channels + a wide one) as one launch == the seven single launches bit for bit == the oracle (2e-5); dead slots, rays that
+    cross T_thresh inside the run, n_step beyond the kernel's eight-step form (falls back to single launches), a zero-channel map, more than eight maps."""
+    rng = np.random.default_rng(80 + n_step)
+    N, n_alive = 4000, 2500
+    alive = np.sort(rng.choice(N, n_alive, replace=False)).astype(np.int32)
+    M = n_alive * n_step
+    sig = (rng.random(M) * 90).astype(np.float32)
+    dl = np.stack([rng.random(M) * 0.02 + 0.003, rng.random(M) * 0.05 + 0.003], 1).astype(np.float32)
+    dl[rng.random(M) < 0.12] = 0
+    ws = (rng.random(N) * 1.0).astype(np.float32)            # some rays already past 1 - T_thresh
+    chans = [3, 3, 4, 12, 12, 0, 16, 50, 1, 128]
+    ins = [rng.standard_normal((M, max(c, 1))).astype(np.float32)[:, :c] for c in chans]
+    outs = [rng.standard_normal((N, max(c, 1))).astype(np.float32)[:, :c] for c in chans]
+    g_alive, g_ws, g_sig, g_dl = dev(alive, cuda), dev(ws, cuda), dev(sig, cuda), dev(dl, cuda)
+    rays_t = torch.zeros(N, device=cuda)
+    single = [dev(np.ascontiguousarray(o), cuda) for o in outs]
+    g_ins = [dev(np.ascontiguousarray(i), cuda) for i in ins]
+    for c, i, o in zip(chans, g_ins, single):
+        if c:
+            raymarching.composite_rays_flex(n_alive, n_step, c, g_alive, rays_t, g_sig, i, g_dl, g_ws, o, 1e-4)
+    multi = [dev(np.ascontiguousarray(o), cuda) for o in outs]
+    r = raymarching.composite_rays_flex_multi(n_alive, n_step, g_alive, rays_t, g_sig, g_dl, g_ws, list(zip(chans, g_ins, multi)), 1e-4)
+    assert r == tuple()
+    for c, a, b in zip(chans, single, multi):
+        assert torch.equal(a, b), c
+    # the single call itself runs on the cooperative kernel (n_step <= 8): the one-thread-per-ray kernel it replaced gives the same bits
+    from palettenerf_amd import _lib as plib
+    lib = plib.load()
+    assert lib.pnr_set_option(b"flex_coop", 0) == 0
+    try:
+        for c, i, o, want in zip(chans, g_ins, outs, single):
+            if c:
+                plain = dev(np.ascontiguousarray(o), cuda)
+                raymarching.composite_rays_flex(n_alive, n_step, c, g_alive, rays_t, g_sig, i, g_dl, g_ws, plain, 1e-4)
+                assert torch.equal(plain, want), c
+    finally:
+        lib.pnr_set_option(b"flex_coop", 1)
+    np.testing.assert_array_equal(host(g_ws), ws)
+    np.testing.assert_array_equal(host(g_alive), alive)
+    for m in (7, 8, 0):      # 50 channels, one channel, three
+        o_out = np.ascontiguousarray(outs[m]).copy()
+        oracle.composite_rays_flex(n_alive, n_step, chans[m], alive.copy(), np.zeros(N, np.float32), sig, np.ascontiguousarray(ins[m]), dl, ws.copy(), o_out, 1e-4)
+        np.testing.assert_allclose(host(multi[m]), o_out, rtol=2e-5, atol=2e-5)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        raymarching.composite_rays_flex_multi(n_alive, n_step, g_alive, rays_t, g_sig, g_dl, g_ws, [(129, g_ins[0], multi[0])], 1e-4)
+
+
+def test_deferred_flex_composites_reach_the_device_as_one_launch_with_the_same_bits(cuda):
+    """raymarching.arm_flex_deferral() (what dropin.fuse_field does behind every fused PaletteNetwork.forward): the flex composites that follow are queued and
+    issued by the next composite_rays -- which must still see them done BEFORE it moves weights_sum -- as one pnr_composite_rays_flex_multi call; the deferral ends
+    there (the next flex call is immediate again)."""
+    from palettenerf_amd import _torch_glue
+    rng = np.random.default_rng(91)
+    N, n_alive, n_step = 3000, 1700, 4
+    alive = np.sort(rng.choice(N, n_alive, replace=False)).astype(np.int32)
+    M = n_alive * n_step
+    sig, rgb = dev((rng.random(M) * 60).astype(np.float32), cuda), dev(rng.random((M, 3)).astype(np.float32), cuda)
+    dl = np.stack([rng.random(M) * 0.02 + 0.003, rng.random(M) * 0.05 + 0.003], 1).astype(np.float32)
+    dl[rng.random(M) < 0.1] = 0
+    dl = dev(dl, cuda)
+    chans = [3, 3, 4, 12, 12, 16]
+    ins = [dev(rng.standard_normal((M, c)).astype(np.float32), cuda) for c in chans]
+
+    def state():
+        g = torch.Generator().manual_seed(5)
+        return dict(alive=dev(alive, cuda), t=torch.rand(N, generator=g).to(cuda), ws=(torch.rand(N, generator=g) * 0.7).to(cuda), dep=torch.rand(N, generator=g).to(cuda),
+                    img=torch.rand(N, 3, generator=g).to(cuda), outs=[torch.rand(N, c, generator=g).to(cuda) for c in chans])
+
+    def iteration(st, arm):
+        if arm:
+            raymarching.arm_flex_deferral()
+        for c, i, o in zip(chans, ins, st["outs"]):
+            assert raymarching.composite_rays_flex(n_alive, n_step, c, st["alive"], st["t"], sig, i, dl, st["ws"], o, 1e-4) == tuple()
+        raymarching.composite_rays(n_alive, n_step, st["alive"], st["t"], sig, rgb, dl, st["ws"], st["dep"], st["img"], 1e-4)
+
+    a, b = state(), state()
+    iteration(a, False)
+    prof = _torch_glue.profile_kernels(["pnr_composite_rays_flex", "pnr_composite_rays_flex_multi"])
+    try:
+        iteration(b, True)
+        assert len(prof["pnr_composite_rays_flex"]) == 0 and len(prof["pnr_composite_rays_flex_multi"]) == 1
+        out = torch.zeros(N, 3, device=cuda)        # the deferral has ended with composite_rays: an immediate call again
+        f = state()                                 # (a fresh alive list: composite_rays has marked b's terminated rays with -1, as the reference does)
+        raymarching.composite_rays_flex(n_alive, n_step, 3, f["alive"], f["t"], sig, ins[0], dl, f["ws"], out, 1e-4)
+        assert len(prof["pnr_composite_rays_flex"]) == 1
+    finally:
+        _torch_glue.profile_kernels(None)
+    for k in ("alive", "t", "ws", "dep", "img"):
+        assert torch.equal(a[k], b[k]), k
+    for x, y in zip(a["outs"], b["outs"]):
+        assert torch.equal(x, y)
+    # the persistent switch, and a call whose shared arguments differ from the queue's flushes the queue first
+    was = raymarching.defer_flex_composites(True)
+    try:
+        c, d = state(), state()
+        raymarching.composite_rays_flex(n_alive, n_step, 3, c["alive"], c["t"], sig, ins[0], dl, c["ws"], c["outs"][0], 1e-4)
+        raymarching.composite_rays_flex(n_alive, n_step, 3, d["alive"], d["t"], sig, ins[1], dl, d["ws"], d["outs"][1], 1e-4)     # another ray state: flushes c's
+        raymarching.flush_flex_composites()
+    finally:
+        raymarching.defer_flex_composites(was)
+    e = state()
+    raymarching.composite_rays_flex(n_alive, n_step, 3, e["alive"], e["t"], sig, ins[0], dl, e["ws"], e["outs"][0], 1e-4)
+    raymarching.composite_rays_flex(n_alive, n_step, 3, e["alive"], e["t"], sig, ins[1], dl, e["ws"], e["outs"][1], 1e-4)
+    assert torch.equal(c["outs"][0], e["outs"][0]) and torch.equal(d["outs"][1], e["outs"][1])
+
+
 def test_spread_ray_to_sample(cuda):
     rng = np.random.default_rng(9)
     N = 700
