@@ -453,6 +453,35 @@ def timed_frames_median(m, bank, kw, steps, first_step=0):
     return ms[steps // 2], sum(ms) / steps, rendered // steps
 
 
+def timed_frames_queue(m, bank, kw, steps, first_step=0):
+    """`steps` frames through pipeline.render_queue (model.render_prepare / render_launch / render_finish over pnr_*_render_frame_submit / _finish): one frame
+    on the device at a time, the host's work for frame i + 1 done under frame i's kernels.  Per-frame time = host time between two consecutive frames'
+    completions (a completion is the return of render_finish: the frame's read-back has arrived); median and mean over `steps` frames, rendered per frame."""
+    import gc
+    import torch
+    from palettenerf_amd.pipeline import render_queue
+    for i in range(steps + 1):
+        bank.get(first_step + i)
+    done, rendered = [], [0]
+    torch.cuda.synchronize()
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    gc.disable()
+
+    def consume(i, r):
+        done.append(time.perf_counter())
+        rendered[0] += int(r["rendered"].sum())
+
+    try:
+        render_queue(m, lambda i: bank.get(first_step + i), steps + 1, consume=consume, **kw)
+        torch.cuda.synchronize()
+    finally:
+        if gc_was_on:
+            gc.enable()
+    ms = sorted((done[i + 1] - done[i]) * 1e3 for i in range(steps))
+    return ms[steps // 2], sum(ms) / steps, rendered[0] // (steps + 1)
+
+
 # ------------------------------------------------------------------------------------------------ configs[3]: the training step
 def make_training_step(model_kind, rays, device, fp16=False, torch_adam=False, torch_loss=False):
     """configs[3]-shaped training step (main_palette.py:223 / palette/utils.py:481 on LLFF-like input): `rays` random rays per step from a
@@ -1064,7 +1093,44 @@ def main(argv=None):
     else:
         t0 = time.perf_counter()
         step_ev[0].record()
-    for i in range(args.steps if F_main == 1 else 0):
+    # N > 1 ranks (round 6): a rank's shard frames go through render_prepare / render_launch / render_finish -- one frame on the device at a time, the host's work
+    # for frame i + 1 (outputs, argument struct, the next pose's rays) done under frame i's kernels, frame i + 1 enqueued before frame i's rows are packed for the
+    # all-gather (which therefore overlaps frame i + 1's render, as before).  0.15 ms of host turnaround per 2.1 ms shard frame otherwise.
+    queued = use_dist and native and F_main == 1 and not args.fp16
+    if queued:
+        q_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        m._fused.time_grid_kernel = bool(timed_native)
+        cur = m.render_prepare(*bank.get(args.warmup), **kw)
+        q_ev[0][0].record()
+        cur = m.render_launch(cur)
+        for i in range(args.steps):
+            nxt = None
+            if i + 1 < args.steps:
+                m._fused.time_grid_kernel = False
+                nxt = m.render_prepare(*bank.get(args.warmup + i + 1), **kw)
+            done = cur
+            ok = m.render_wait(done)
+            q_ev[i][1].record()
+            if not ok:                       # (never on this script's fixed weights: the frame is rendered again before anything else is enqueued)
+                r = m.render_result(done)
+            if nxt is not None:
+                q_ev[i + 1][0].record()
+                cur = m.render_launch(nxt)   # frame i + 1 is on the device before frame i's result dict is built and its rows are packed
+            if ok:
+                r = m.render_result(done)
+            handle = gatherer.start(gather_parts(args, r, nb))
+            if pending:
+                _full = gatherer.finish(pending.pop())
+            pending.append(handle)
+            rendered_host += int(r["rendered"])
+            rows += r["n_samples"]
+            looks += int(r.get("host_looks", 0))
+            iterations += int(r.get("iterations", 0))
+            if timed_native and i == 0:
+                native_ms, native_launches, native_live = r.get("grid_ms", 0.0), r.get("grid_launches", 0), int(r["rendered"])
+            step_ev[i + 1].record()
+        render_ev.extend(q_ev)
+    for i in range(args.steps if (F_main == 1 and not queued) else 0):
         # HIP events around every grid-encode launch cost ~6 us each (two per iteration): instrument the launches of the
         # FIRST timed step only, so the measurement lives inside the timed region without distorting it
         if timed_native:
@@ -1191,7 +1257,7 @@ def main(argv=None):
                        "evaluated_rows_per_step_rank0": rows // args.steps, "density_scale": args.density_scale, "dt_gamma": wl["dt_gamma"], "march_mode": m.march_mode,
                        "fused_field": bool(getattr(m, "fused_field", False)), "field_precision": args.field_precision, "half_tables": bool(half_rows), "ray_order": args.ray_order,
                        "iterations_per_frame_rank0": iterations / max(1, args.steps), "host_looks_per_frame": looks / max(1, args.steps),
-                       "frames_in_flight": F_main,
+                       "frames_in_flight": F_main, "host_prepares_next_frame_under_this_one": bool(queued),
                        "gathered_floats_per_ray": K if use_dist else 0, "rccl_ranks": dist.get_world_size() if use_dist else 1,
                        "parallelism": f"32x32 ray tiles of {n_views} view(s) round-robin over {world} GPUs + one all_gather/step" if world > 1 else "single GPU",
                        **({"defaulted_for_ranks": True} if args.defaulted_for_ranks else {}), **(dist_info or {})},
@@ -1475,19 +1541,27 @@ def main(argv=None):
                 gbank = RayBank(gargs, 1, full_idx, device)
                 gm._fused.ray_order = tile_ray_order(full_idx, gW, 8).to(device)
                 timed_frames(gm, gbank, gkw, 2, False)
-                full_ms, full_mean, full_rend = timed_frames_median(gm, gbank, gkw, 15)
-                times, means, samples = [], [], []
+                full_ms1, full_mean1, full_rend = timed_frames_median(gm, gbank, gkw, 15)
+                full_ms, full_mean, _ = timed_frames_queue(gm, gbank, gkw, 15)
+                times, means, samples, times1 = [], [], [], []
                 for sh in range(8):
                     sidx, _ = pdist.shard_indices(gH, gW, sh, 8)
                     sbank = RayBank(gargs, 1, sidx, device)
                     gm._fused.ray_order = tile_ray_order(sidx, gW, 8).to(device)
                     timed_frames(gm, sbank, gkw, 2, False)
-                    ms_, mean_, rend = timed_frames_median(gm, sbank, gkw, 21)
+                    ms1_, _, rend = timed_frames_median(gm, sbank, gkw, 21)
+                    ms_, mean_, _ = timed_frames_queue(gm, sbank, gkw, 21)
+                    times1.append(ms1_)
                     times.append(ms_)
                     means.append(mean_)
                     samples.append(rend)
                 extra["garden_shard_emulation_8"] = {"full_frame_ms": full_ms, "full_frame_ms_mean": full_mean, "full_frame_samples": full_rend, "shard_ms": times, "shard_ms_mean": means,
-                                                     "timing": "median of 15 (full frame) / 21 (each shard) frames (device time between events behind consecutive frames); means beside them -- 7 frames until round 5: a 10 ms disturbance on the box moved a shard's median by 15 %",
+                                                     "how": "round 6: a rank's frames through pipeline.render_queue (render_prepare / render_launch / render_finish over pnr_*_render_frame_submit / _finish): one frame on the device at a "
+                                                            "time, the host's work for frame i + 1 under frame i's kernels -- what the N > 1 loop of this script does; the full frame is timed the same way",
+                                                     "one_call_per_frame": {"full_frame_ms": full_ms1, "full_frame_ms_mean": full_mean1, "shard_ms": times1, "max_shard_ms": max(times1),
+                                                                            "speedup_before_all_gather": full_ms1 / max(times1),
+                                                                            "what": "rounds 1-5's way: m.render() per frame (the host turns around between two frames), device time between events"},
+                                                     "timing": "median of 15 (full frame) / 21 (each shard) frames (host time between consecutive frames' completions); means beside them",
                                                      "shard_samples": samples,
                                                      "max_shard_ms": max(times), "imbalance_max_over_mean": max(times) / (sum(times) / 8),
                                                      "speedup_before_all_gather": full_ms / max(times),

@@ -361,6 +361,14 @@ typedef struct pnr_nerf_frame_args {
 } pnr_nerf_frame_args;
 uint64_t pnr_nerf_frame_workspace_bytes(uint32_t N);
 int pnr_nerf_render_frame(const pnr_nerf_frame_args* args, pnr_stream_t stream);
+/* The same frame in two calls (ABI 7).  _submit enqueues the frame's first launch, as many march iterations as the previous frame needed, the frame's last
+ * launch and the 64-byte control-block read-back, and returns WITHOUT waiting: the host is free to prepare its next frame (rays, argument struct, outputs)
+ * while this one runs -- the loop being replaced (nerf/renderer.py:344-380, palette/renderer.py:430-550) holds the host for the whole frame.  _finish waits for
+ * the read-back, enqueues further iterations while the frame is not done (the iteration count is data) and fills `stats` / `kernel_ms`.  Rules: _finish follows
+ * _submit on the same host thread, device and stream with the SAME argument struct (its address identifies the frame; PNR_ERR_INVALID otherwise); one
+ * submitted frame per host thread and device; nothing the frame reads or writes may be touched in between.  pnr_nerf_render_frame == _submit + _finish. */
+int pnr_nerf_render_frame_submit(const pnr_nerf_frame_args* args, pnr_stream_t stream);
+int pnr_nerf_render_frame_finish(const pnr_nerf_frame_args* args, pnr_stream_t stream);
 
 /* Appearance editing heads of the PaletteNeRF inference loop, evaluated inside the fused field kernel's epilogue (HOST struct).
  *   mode 1  RegionEdit.forward (palette/renderer.py:121-147): per basis, final colour -> HSV (pnr_rgb_to_hsv's arithmetic), hue += delta_hsv[b][0]
@@ -411,6 +419,8 @@ int pnr_interleave_tables(const float* a, const float* b, uint64_t rows, float* 
 int pnr_interleave_tables3(const float* a, const float* b, const float* c, uint64_t rows, float* out, pnr_stream_t stream);
 uint64_t pnr_palette_frame_workspace_bytes(uint32_t N, uint32_t num_basis, uint32_t clip_dim, int pred_clip);
 int pnr_palette_render_frame(const pnr_palette_frame_args* args, pnr_stream_t stream);
+int pnr_palette_render_frame_submit(const pnr_palette_frame_args* args, pnr_stream_t stream);   /* as pnr_nerf_render_frame_submit / _finish */
+int pnr_palette_render_frame_finish(const pnr_palette_frame_args* args, pnr_stream_t stream);
 
 /* Fused PaletteNeRF field + palette colour-basis composite (palette/network.py:156-280, palette/renderer.py:470-500, RegionEdit /
  * Stylizer included).  Split-fp16 or exact-fp32 matrix path (`precision`).  All weights are row-major [out][in]

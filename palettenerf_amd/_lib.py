@@ -49,12 +49,16 @@ SIGNATURES = {
     "pnr_nerf_density_forward": [_ptr, _ptr, _u32, _f32, _ptr, _ptr, _int, _f32, _ptr],
     "pnr_nerf_frame_workspace_bytes": [_u32],
     "pnr_nerf_render_frame": [_ptr, _ptr],
+    "pnr_nerf_render_frame_submit": [_ptr, _ptr],
+    "pnr_nerf_render_frame_finish": [_ptr, _ptr],
     "pnr_palette_field_packed_bytes": [_u32, _u32, _int],
     "pnr_palette_aux_channels": [_u32, _u32],
     "pnr_palette_field_pack": [_ptr, _ptr, _ptr],
     "pnr_palette_field_forward": [_ptr, _ptr],
     "pnr_palette_frame_workspace_bytes": [_u32, _u32, _u32, _int],
     "pnr_palette_render_frame": [_ptr, _ptr],
+    "pnr_palette_render_frame_submit": [_ptr, _ptr],
+    "pnr_palette_render_frame_finish": [_ptr, _ptr],
     "pnr_sh_encode_forward": [_ptr, _ptr, _u32, _u32, _u32, _ptr, _ptr],
     "pnr_sh_encode_cat_forward": [_ptr, _ptr, _u32, _ptr, _u32, _u32, _ptr],
     "pnr_sigma_geo_cat_forward": [_ptr, _u32, _ptr, _u32, _u32, _ptr, _ptr, _ptr],

@@ -1204,19 +1204,38 @@ uint64_t pnr_palette_frame_workspace_bytes(uint32_t N, uint32_t num_basis, uint3
     return carve(nullptr, N, pnr_palette_aux_channels(num_basis, clip_dim), pred_clip != 0).bytes;
 }
 
-static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_frame_args* pal, pnr_stream_t stream);
+// phase: kWhole = the frame call; kSubmit = enqueue the frame's first chunk of iterations, its last launch and the control-block read-back, then return WITHOUT
+// waiting (the caller prepares its next frame while this one runs); kFinish = wait for that read-back, enqueue further chunks while the frame is not done (the
+// iteration count is data), fill stats / kernel_ms.  kFinish must follow kSubmit on the same host thread, device, stream and argument struct, with nothing of the
+// frame's buffers touched in between; kWhole = kSubmit + kFinish.
+enum FramePhase { kWhole = 0, kSubmit = 1, kFinish = 2 };
+static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_frame_args* pal, pnr_stream_t stream, FramePhase phase);
 
-int pnr_nerf_render_frame(const pnr_nerf_frame_args* a, pnr_stream_t stream) { return render_frame_impl(a, nullptr, stream); }
+int pnr_nerf_render_frame(const pnr_nerf_frame_args* a, pnr_stream_t stream) { return render_frame_impl(a, nullptr, stream, kWhole); }
+int pnr_nerf_render_frame_submit(const pnr_nerf_frame_args* a, pnr_stream_t stream) { return render_frame_impl(a, nullptr, stream, kSubmit); }
+int pnr_nerf_render_frame_finish(const pnr_nerf_frame_args* a, pnr_stream_t stream) { return render_frame_impl(a, nullptr, stream, kFinish); }
 
-int pnr_palette_render_frame(const pnr_palette_frame_args* p, pnr_stream_t stream) {
+static int palette_frame_check(const pnr_palette_frame_args* p) {
     if (!p) return PNR_ERR_INVALID;
     if (p->num_basis < 1 || p->num_basis > PNR_MAX_BASIS || p->clip_dim > PNR_MAX_CLIP) return PNR_ERR_UNSUPPORTED;
     if (p->edit && (p->edit->mode < 0 || p->edit->mode > 2)) return PNR_ERR_UNSUPPORTED;
     if (p->base.N && (!p->embeddings_palette || !p->aux_map || (p->pred_clip && !p->embeddings_clip))) return PNR_ERR_INVALID;
-    return render_frame_impl(&p->base, p, stream);
+    return PNR_OK;
+}
+int pnr_palette_render_frame(const pnr_palette_frame_args* p, pnr_stream_t stream) {
+    if (int rc = palette_frame_check(p)) return rc;
+    return render_frame_impl(&p->base, p, stream, kWhole);
+}
+int pnr_palette_render_frame_submit(const pnr_palette_frame_args* p, pnr_stream_t stream) {
+    if (int rc = palette_frame_check(p)) return rc;
+    return render_frame_impl(&p->base, p, stream, kSubmit);
+}
+int pnr_palette_render_frame_finish(const pnr_palette_frame_args* p, pnr_stream_t stream) {
+    if (int rc = palette_frame_check(p)) return rc;
+    return render_frame_impl(&p->base, p, stream, kFinish);
 }
 
-static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_frame_args* pal, pnr_stream_t stream) {
+static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_frame_args* pal, pnr_stream_t stream, FramePhase phase) {
     if (!a) return PNR_ERR_INVALID;
     if (a->N == 0) return PNR_OK;
     if (!a->rays_o || !a->rays_d || !a->nears || !a->fars || !a->bitfield || !a->embeddings || !a->offsets || !a->packed_weights || !a->weights_sum ||
@@ -1258,8 +1277,10 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
         pf.overflow_flag = a->watch_overflow ? w.scratch + 1 : nullptr;
         pf.tile_counter = g_opt_dynamic_tiles ? w.scratch + 2 : nullptr;
         if (pal->edit && pal->edit->mode != 0) {   // RegionEdit / Stylizer: parameters uploaded once for the whole frame
-            const int rc = pnr_internal_edit_upload(pal->edit, w.edit, s);
-            if (rc != PNR_OK) return rc;
+            if (phase != kFinish) {
+                const int rc = pnr_internal_edit_upload(pal->edit, w.edit, s);
+                if (rc != PNR_OK) return rc;
+            }
             pf.edit = pal->edit; pf.edit_device = w.edit;
         }
     }
@@ -1269,6 +1290,8 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     // (released when the host thread ends: a pool that replaces its worker threads does not accumulate pinned blocks and events)
     struct PerDevice {
         FrameCtl* host_ctl = nullptr; std::vector<hipEvent_t> ev; uint32_t predicted_iterations = 0; hipEvent_t done_ev = nullptr;
+        // a frame submitted and not yet finished (pnr_*_render_frame_submit): what its finish call continues from
+        struct Pending { bool on = false; const void* args = nullptr; int iter = 0; uint32_t alive_ub = 0, chunk = 0, looks = 0, prev_partials = 0; size_t ev_used = 0; } pending;
         ~PerDevice() {
             if (host_ctl) (void)hipHostFree(host_ctl);
             if (done_ev) (void)hipEventDestroy(done_ev);
@@ -1298,12 +1321,18 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     fb.order = a->ray_order; fb.rays_o = a->rays_o; fb.rays_d = a->rays_d; fb.nears_in = a->nears; fb.fars_in = a->fars;
     fb.aabb = a->aabb; fb.min_near = a->min_near; fb.nears_out = a->nears; fb.fars_out = a->fars;
     fb.so = w.s_o; fb.sd = w.s_d; fb.sf = w.s_far;
-    if (pal) {   // the aux map starts at zero (palette/renderer.py:436-441): inside the first launch when rows are float4-aligned
-        if ((aux_stride & 3u) == 0 && (reinterpret_cast<uintptr_t>(out_aux) & 15u) == 0) { fb.aux_zero = out_aux; fb.aux_stride = aux_stride; }
-        else if (hipMemsetAsync(out_aux, 0, (size_t)N * aux_stride * 4, s) != hipSuccess) return PNR_ERR_LAUNCH;
+    auto& pending = dev_state.pending;
+    if (phase == kFinish) {
+        if (!pending.on || pending.args != static_cast<const void*>(pal ? static_cast<const void*>(pal) : static_cast<const void*>(a))) return PNR_ERR_INVALID;   // no frame of THIS struct was submitted on this thread and device
+    } else {
+        if (pending.on) return PNR_ERR_INVALID;   // one frame in flight per host thread and device: finish the submitted one first
+        if (pal) {   // the aux map starts at zero (palette/renderer.py:436-441): inside the first launch when rows are float4-aligned
+            if ((aux_stride & 3u) == 0 && (reinterpret_cast<uintptr_t>(out_aux) & 15u) == 0) { fb.aux_zero = out_aux; fb.aux_stride = aux_stride; }
+            else if (hipMemsetAsync(out_aux, 0, (size_t)N * aux_stride * 4, s) != hipSuccess) return PNR_ERR_LAUNCH;
+        }
+        hipLaunchKernelGGL(k_frame_begin, dim3(cdiv(N, kRayBlock)), dim3(kRayBlock), 0, s, N, fb, w.alive[1], w.rays_t, out_ws, out_depth, out_image,
+                           w.ctl, counts_of(1), w.scratch, w.qctr, hconst, w.hosted);
     }
-    hipLaunchKernelGGL(k_frame_begin, dim3(cdiv(N, kRayBlock)), dim3(kRayBlock), 0, s, N, fb, w.alive[1], w.rays_t, out_ws, out_depth, out_image,
-                       w.ctl, counts_of(1), w.scratch, w.qctr, hconst, w.hosted);
     // optional live timing of the roofline kernel: HIP events on the launch stream around every k_frame_grid launch
     std::vector<hipEvent_t>& ev = dev_state.ev;
     size_t ev_used = 0;
@@ -1344,7 +1373,11 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     uint32_t looks = 0;
     uint32_t prev_partials = 0;   // workgroups of the previous march launch (= sample partials to add up)
     int iter = 0;
-    for (;;) {
+    if (phase == kFinish) {   // continue where the submit call stopped: its chunk, the frame's last launch and the read-back are in the stream
+        iter = pending.iter; alive_ub = pending.alive_ub; chunk = pending.chunk; looks = pending.looks; prev_partials = pending.prev_partials; ev_used = pending.ev_used;
+        pending.on = false;
+    }
+    auto enqueue_chunk = [&]() -> int {
         for (uint32_t k = 0; k < chunk; k++, iter++) {
             FrameCtl* cur = w.ctl + (iter & 1);                 // this iteration's control block, written by its march launch
             const FrameCtl* prev = w.ctl + ((iter + 1) & 1);    // the previous iteration's (k_frame_begin's in front of iteration 0)
@@ -1457,11 +1490,23 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
         // (an eighth of the garden frame: 0.40 of 2.4 ms were the host's turnaround between frames).  The in-place finish of an unsorted frame is
         // not idempotent across looks either way: guarded by the same flag.
         launch_last(w.ctl + ((iter - 1) & 1));
+        return PNR_OK;
+    };
+    if (phase != kFinish) {
+        if (int rc = enqueue_chunk()) return rc;
+        if (phase == kSubmit) {
+            pending.on = true; pending.args = pal ? static_cast<const void*>(pal) : static_cast<const void*>(a);
+            pending.iter = iter; pending.alive_ub = alive_ub; pending.chunk = chunk; pending.looks = looks; pending.prev_partials = prev_partials; pending.ev_used = ev_used;
+            return check_launch();
+        }
+    }
+    for (;;) {
         if (hipEventSynchronize(dev_state.done_ev) != hipSuccess) return PNR_ERR_LAUNCH;     // (polling hipEventQuery instead measured the same: the runtime's wait already spins)
         if (host_ctl->done) break;
         alive_ub = (uint32_t)host_ctl->n_alive;
         if (looks == 0) chunk = predicted_iterations ? 4u : 8u;
         if (++looks >= 4 && chunk < 64) chunk *= 2;
+        if (int rc = enqueue_chunk()) return rc;
     }
     predicted_iterations = (uint32_t)host_ctl->iterations;
     if (timing) {  // only the iterations that did work (the tail of the last chunk are no-op launches)

@@ -347,7 +347,8 @@ class _SourceWatch:
         """[(tensor, stride in 4-byte words)]: everything a cached blob of this object is derived from."""
         raise NotImplementedError
 
-    def _watch_begin(self):
+    def _watch_begin(self, slot=0):
+        """slot: 0 / 1 -- a frame prepared while the previous one is still running (frame_prepare / frame_launch / frame_finish) takes the other read-back row."""
         srcs = self._watched()
         keys = tuple(_pkey(t) for t, _ in srcs)
         had = getattr(self, "_watch_keys", None)
@@ -356,22 +357,24 @@ class _SourceWatch:
             self.invalidate_caches()
         self._watch_keys = keys
         n, dev = len(srcs), srcs[0][0].device
-        if getattr(self, "_watch_dev", None) is None or self._watch_dev.device != dev or self._watch_dev.numel() < n:
-            self._watch_dev = torch.zeros(max(n, 24), dtype=torch.int64, device=dev)
-            self._watch_host = torch.zeros(max(n, 24), dtype=torch.int64).pin_memory()
+        if getattr(self, "_watch_dev", None) is None or self._watch_dev.device != dev or self._watch_dev.shape[1] < n:
+            self._watch_dev = torch.zeros(2, max(n, 24), dtype=torch.int64, device=dev)
+            self._watch_host = torch.zeros(2, max(n, 24), dtype=torch.int64).pin_memory()
+            self._watch_rows = [(self._watch_dev[k], self._watch_host[k]) for k in (0, 1)]     # (row views made once: a view per frame is host time)
         if getattr(self, "_watch_args_key", None) != keys:     # (the keys hold the data pointers: same keys, same argument arrays)
             self._watch_args = ((ctypes.c_void_p * n)(*[t.data_ptr() for t, _ in srcs]), (ctypes.c_uint64 * n)(*[t.numel() * t.element_size() for t, _ in srcs]),
                                 (_u32 * n)(*[int(st) for _, st in srcs]))
             self._watch_args_key = keys
         ptrs, sizes, strides = self._watch_args
-        call("pnr_checksum", ptrs, sizes, strides, _u32(n), ptr(self._watch_dev))
-        self._watch_host.copy_(self._watch_dev, non_blocking=True)     # complete once the frame's own read-back is (same stream)
-        return record, n
+        drow, hrow = self._watch_rows[slot]
+        call("pnr_checksum", ptrs, sizes, strides, _u32(n), ptr(drow))
+        hrow.copy_(drow, non_blocking=True)     # complete once the frame's own read-back is (same stream)
+        return record, n, slot
 
     def _watch_end(self, state):
         """True: the frame just rendered used blobs that match their sources."""
-        record, n = state
-        now = tuple(self._watch_host[:n].tolist())
+        record, n, slot = state
+        now = tuple(self._watch_rows[slot][1][:n].tolist())
         if record:
             self._watch_ref = now
             return True
@@ -424,6 +427,27 @@ def _set_finish(a, bg_color, N, mask):
     return True
 
 
+class StaleFrame(RuntimeError):
+    """frame_launch of a frame that was prepared before the object's blobs were rebuilt (invalidate_caches): prepare it again."""
+
+
+class _FrameToken:
+    """A frame between frame_prepare and frame_finish: its argument struct, outputs, host-side stats arrays and what a re-render needs."""
+    __slots__ = ("a", "p", "out", "stats", "kms", "watch_state", "watch", "finished", "nears", "fars", "again", "keep", "stream", "depth_raw", "edit", "valid", "gen")
+
+    def __init__(self, **kw):
+        self.valid = None
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+def _frame_valid(fused, tok):
+    """0: the finished frame's outputs stand; 1: its blobs did not match their sources (a `.data` write); 2: an operand left fp16's range under the watch."""
+    if not fused._watch_end(tok.watch_state):
+        return 1
+    return 2 if (tok.watch and tok.stats[5]) else 0
+
+
 class NeRFFieldFused(_PrecisionGuard, _SourceWatch):
     """Caches the MFMA-ordered weight blob of a NeRFNetwork and evaluates (sigma, rgb) for sample batches."""
 
@@ -452,6 +476,7 @@ class NeRFFieldFused(_PrecisionGuard, _SourceWatch):
         self._watch_ref = None       # the next frame rebuilds every blob: its source checksums become the reference
         self._guard_held = self._weights_held = None   # (a held call that retries asks again)
         self._frame_plan = None      # the frame call's kept argument struct points into the blobs
+        self._gen = self.__dict__.get("_gen", 0) + 1     # frames prepared before this point hold pointers into the old blobs (frame_launch refuses them)
 
     def _guard_tables(self):
         return [self.model.encoder.embeddings]
@@ -492,13 +517,54 @@ class NeRFFieldFused(_PrecisionGuard, _SourceWatch):
         with self._held():
             return self._render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color, aabb, min_near)
 
+    # The same frame in three steps (round 6; pnr_nerf_render_frame_submit / _finish): frame_prepare does everything in front of the library call (outputs, argument
+    # struct, source checksums) and may run while the PREVIOUS frame is still on the device; frame_launch enqueues the frame and returns at once; frame_finish waits
+    # for it and returns what render_frame returns.  A caller with a queue of frames (a video path, a rank's shard loop) runs
+    #     tok = prepare(0); launch(tok);  for i in 1..: nxt = prepare(i); out = finish(tok); launch(nxt); tok = nxt; consume(out)
+    # so that the host's work for frame i + 1 lies under frame i's kernels.  Two argument structs alternate (a frame's struct must stay as it was until its finish).
+    @torch.no_grad()
+    def frame_prepare(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color=None, aabb=None, min_near=0.0):
+        with self._held():
+            return self._frame_prepare(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color, aabb, min_near)
+
+    def frame_launch(self, tok):
+        if tok.gen != self.__dict__.get("_gen", 0):
+            raise StaleFrame("the frame was prepared before the packed blobs were rebuilt")
+        tok.stream = stream_ptr()
+        _lib.check(_lib.load().pnr_nerf_render_frame_submit(ctypes.byref(tok.a), tok.stream), "pnr_nerf_render_frame_submit")
+        return tok
+
+    def frame_wait(self, tok):
+        """The library's finish call alone: waits for the frame (and enqueues what it still needs).  True: the frame's outputs are valid -- the caller may enqueue
+        its next frame before it asks for frame_result(); False: the frame has to be rendered again (sources rewritten behind torch's counters, an fp16
+        overflow), which frame_result() does -- ask for it BEFORE launching another frame."""
+        _lib.check(_lib.load().pnr_nerf_render_frame_finish(ctypes.byref(tok.a), tok.stream), "pnr_nerf_render_frame_finish")
+        tok.valid = _frame_valid(self, tok)
+        return tok.valid == 0
+
+    @torch.no_grad()
+    def frame_result(self, tok):
+        with self._held():
+            return self._frame_post(tok)
+
+    def frame_finish(self, tok):
+        self.frame_wait(tok)
+        return self.frame_result(tok)
+
     def _render_frame(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color, aabb, min_near):
+        tok = self._frame_prepare(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color, aabb, min_near)
+        rc = _lib.load().pnr_nerf_render_frame(ctypes.byref(tok.a), stream_ptr())
+        _lib.check(rc, "pnr_nerf_render_frame")
+        return self._frame_post(tok)
+
+    def _frame_prepare(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color, aabb, min_near):
         from . import raymarching
         m = self.model
         N = rays_o.shape[0]
         dev = rays_o.device
         lib = _lib.load()
-        watch_state = self._watch_begin()
+        slot = self._slot = 1 - self.__dict__.get("_slot", 1)
+        watch_state = self._watch_begin(slot)
         ws = torch.empty(N, dtype=torch.float32, device=dev)
         depth = torch.empty(N, dtype=torch.float32, device=dev)
         image = torch.empty(N, 3, dtype=torch.float32, device=dev)
@@ -512,7 +578,10 @@ class NeRFFieldFused(_PrecisionGuard, _SourceWatch):
         plan_key = (self._watch_keys, N, dev, int(self.precision), bool(self.table_half), self.__dict__.get("_overflowed_key"), None if order is None else (id(order), order.data_ptr()),
                     float(m.bound), int(m.cascade), int(m.grid_size), float(m.density_scale), enc.num_levels, enc.per_level_scale, enc.base_resolution, enc.gridtype_id,
                     _pkey(enc.offsets))
-        plan = self.__dict__.get("_frame_plan")
+        plans = self.__dict__.get("_frame_plan")
+        if plans is None:
+            plans = self._frame_plan = {}
+        plan = plans.get(slot)
         if plan is None or plan[0] != plan_key or PARANOID:
             nbytes = int(lib.pnr_nerf_frame_workspace_bytes(N))
             if getattr(self, "_ws", None) is None or self._ws.numel() < nbytes or self._ws.device != dev:
@@ -533,7 +602,7 @@ class NeRFFieldFused(_PrecisionGuard, _SourceWatch):
             a.density_scale = float(m.density_scale)
             a.workspace, a.workspace_bytes = self._ws.data_ptr(), nbytes
             a.ray_order = order.data_ptr() if order is not None else None
-            plan = self._frame_plan = (plan_key, a, prec, watch, (emb, self._ws, order))     # (the tensors whose addresses the struct holds)
+            plan = plans[slot] = (plan_key, a, prec, watch, (emb, self._ws, order))     # (the tensors whose addresses the struct holds)
         a, prec, watch = plan[1], plan[2], plan[3]
         # The packed blob is NOT part of the plan: the stand-alone ops on this object (`self(x, d)` from network.forward) repack it in place for THEIR precision
         # (effective_precision() is fp32 where frame_precision() keeps split-fp16 with a watch).  _pack is a key compare when nothing changed.
@@ -552,16 +621,22 @@ class NeRFFieldFused(_PrecisionGuard, _SourceWatch):
         finished = _set_finish(a, bg_color, N, 3)
         for t, name in ((rays_o, "rays_o"), (rays_d, "rays_d"), (nears, "nears"), (fars, "fars")):
             require(t, torch.float32, name)
-        rc = lib.pnr_nerf_render_frame(ctypes.byref(a), stream_ptr())
-        _lib.check(rc, "pnr_nerf_render_frame")
-        if not self._watch_end(watch_state):
+        return _FrameToken(gen=self.__dict__.get("_gen", 0), a=a, out=(ws, depth, image), stats=stats, kms=kms, watch_state=watch_state, watch=watch, finished=finished, nears=nears, fars=fars,
+                           again=(rays_o, rays_d, None if aabb is not None else nears, None if aabb is not None else fars, dt_gamma, max_steps, T_thresh, bg_color, aabb, min_near),
+                           keep=(mip, bg_color))
+
+    def _frame_post(self, tok):
+        valid = tok.valid if tok.valid is not None else _frame_valid(self, tok)
+        if valid == 1:
             self._watch_failed()
-            return self._render_frame(rays_o, rays_d, None if aabb is not None else nears, None if aabb is not None else fars, dt_gamma, max_steps, T_thresh, bg_color, aabb, min_near)
-        if watch and stats[5]:
+            return self._render_frame(*tok.again)
+        stats, kms = tok.stats, tok.kms
+        if valid == 2:
             self._note_overflow()
-            return self._render_frame(rays_o, rays_d, None if aabb is not None else nears, None if aabb is not None else fars, dt_gamma, max_steps, T_thresh, bg_color, aabb, min_near)
+            return self._render_frame(*tok.again)
+        ws, depth, image = tok.out
         return ws, depth, image, {"iterations": int(stats[0]), "rendered": int(stats[1]), "rows": int(stats[2]), "enqueued": int(stats[3]), "looks": int(stats[4]),
-                                  "grid_ms": float(kms[0]), "grid_launches": int(kms[1]), "finished": finished, "nears": nears, "fars": fars}
+                                  "grid_ms": float(kms[0]), "grid_launches": int(kms[1]), "finished": tok.finished, "nears": tok.nears, "fars": tok.fars}
 
     @torch.no_grad()
     def __call__(self, x, d):
@@ -665,6 +740,7 @@ class PaletteFieldFused(_PrecisionGuard, _SourceWatch):
         self._watch_ref = None       # the next frame rebuilds every blob: its source checksums become the reference
         self._guard_held = self._weights_held = None   # (a held call that retries asks again)
         self._frame_plan = None      # the frame call's kept argument struct points into the blobs
+        self._gen = self.__dict__.get("_gen", 0) + 1     # frames prepared before this point hold pointers into the old blobs (frame_launch refuses them)
 
     def _watched(self):
         return [(w, 1) for w in self._w() + self._tables()] + [(t, TABLE_CHECK_STRIDE) for t in self._guard_tables()]
@@ -804,13 +880,45 @@ class PaletteFieldFused(_PrecisionGuard, _SourceWatch):
         with torch.no_grad(), self._held():
             return self._render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color, aabb, min_near)
 
+    # prepare / launch / finish: NeRFFieldFused explains (pnr_palette_render_frame_submit / _finish)
+    def frame_prepare(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color=None, aabb=None, min_near=0.0):
+        with torch.no_grad(), self._held():
+            return self._frame_prepare(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color, aabb, min_near)
+
+    def frame_launch(self, tok):
+        if tok.gen != self.__dict__.get("_gen", 0):
+            raise StaleFrame("the frame was prepared before the packed blobs were rebuilt")
+        tok.stream = stream_ptr()
+        _lib.check(_lib.load().pnr_palette_render_frame_submit(ctypes.byref(tok.p), tok.stream), "pnr_palette_render_frame_submit")
+        return tok
+
+    def frame_wait(self, tok):
+        _lib.check(_lib.load().pnr_palette_render_frame_finish(ctypes.byref(tok.p), tok.stream), "pnr_palette_render_frame_finish")
+        tok.valid = _frame_valid(self, tok)
+        return tok.valid == 0
+
+    def frame_result(self, tok):
+        with torch.no_grad(), self._held():
+            return self._frame_post(tok)
+
+    def frame_finish(self, tok):
+        self.frame_wait(tok)
+        return self.frame_result(tok)
+
     def _render_frame(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color, aabb, min_near):
+        tok = self._frame_prepare(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color, aabb, min_near)
+        rc = _lib.load().pnr_palette_render_frame(ctypes.byref(tok.p), stream_ptr())
+        _lib.check(rc, "pnr_palette_render_frame")
+        return self._frame_post(tok)
+
+    def _frame_prepare(self, rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color, aabb, min_near):
         from . import raymarching
         m = self.model
         N = rays_o.shape[0]
         dev = rays_o.device
         lib = _lib.load()
-        watch_state = self._watch_begin()
+        slot = self._slot = 1 - self.__dict__.get("_slot", 1)
+        watch_state = self._watch_begin(slot)
         ws = torch.empty(N, dtype=torch.float32, device=dev)
         depth = torch.empty(N, dtype=torch.float32, device=dev)
         image = torch.empty(N, 3, dtype=torch.float32, device=dev)
@@ -819,12 +927,15 @@ class PaletteFieldFused(_PrecisionGuard, _SourceWatch):
         if order is not None and order.numel() != N:
             order = None
         enc = m.encoder
-        # the kept argument struct (NeRFFieldFused._render_frame explains): key = identity and version of every source + frame size + the settings read below
+        # the kept argument struct (NeRFFieldFused._frame_prepare explains): key = identity and version of every source + frame size + the settings read below
         plan_key = (self._watch_keys, N, dev, int(self.precision), bool(self.table_half), bool(self.interleave_tables), self.__dict__.get("_overflowed_key"),
                     None if order is None else (id(order), order.data_ptr()), float(m.bound), int(m.cascade), int(m.grid_size), float(m.density_scale),
                     float(m.offsets_weight), float(m.view_dep_weight), enc.num_levels, enc.per_level_scale, enc.base_resolution, enc.gridtype_id,
                     tuple((_pkey(o.offsets), o.per_level_scale) for o in (enc, m.encoder_palette, m.encoder_clip)))
-        plan = self.__dict__.get("_frame_plan")
+        plans = self.__dict__.get("_frame_plan")
+        if plans is None:
+            plans = self._frame_plan = {}
+        plan = plans.get(slot)
         if plan is None or plan[0] != plan_key or PARANOID:
             nbytes = int(lib.pnr_palette_frame_workspace_bytes(N, self.nb, self.clip_dim, int(self.pred_clip)))
             if getattr(self, "_ws", None) is None or self._ws.numel() < nbytes or self._ws.device != dev:
@@ -858,10 +969,10 @@ class PaletteFieldFused(_PrecisionGuard, _SourceWatch):
             triple = self._triple_table() if (self.interleave_tables and self.pred_clip and not self.table_half) else None
             p.embeddings_triple = triple.data_ptr() if triple is not None else None
             a.table_dtype = 1 if self.table_half else 0
-            plan = self._frame_plan = (plan_key, p, prec, watch, (self._ws, order, pair, triple))     # (the tensors whose addresses the struct holds)
+            plan = plans[slot] = (plan_key, p, prec, watch, (self._ws, order, pair, triple))     # (the tensors whose addresses the struct holds)
         p, prec, watch = plan[1], plan[2], plan[3]
         a = p.base
-        a.packed_weights = self._pack(prec).data_ptr()     # every frame (NeRFFieldFused._render_frame explains): a stand-alone call may have packed ANOTHER tensor since
+        a.packed_weights = self._pack(prec).data_ptr()     # every frame (NeRFFieldFused._frame_prepare explains): a stand-alone call may have packed ANOTHER tensor since
         mip = raymarching.occupancy_mip(m.density_bitfield, m.cascade, m.grid_size, m.bound)
         stats = (ctypes.c_uint64 * 6)()
         kms = (ctypes.c_float * 2)()
@@ -881,18 +992,24 @@ class PaletteFieldFused(_PrecisionGuard, _SourceWatch):
         p.edit = ctypes.cast(ctypes.pointer(edit), ctypes.c_void_p) if edit is not None else None
         for t, name in ((rays_o, "rays_o"), (rays_d, "rays_d"), (nears, "nears"), (fars, "fars")):
             require(t, torch.float32, name)
-        rc = lib.pnr_palette_render_frame(ctypes.byref(p), stream_ptr())
-        _lib.check(rc, "pnr_palette_render_frame")
-        again = (None if aabb is not None else nears, None if aabb is not None else fars)
-        if not self._watch_end(watch_state):
+        return _FrameToken(gen=self.__dict__.get("_gen", 0), a=a, p=p, out=(ws, depth, image, aux_map), stats=stats, kms=kms, watch_state=watch_state, watch=watch, finished=finished, nears=nears, fars=fars,
+                           depth_raw=depth_raw, edit=edit,
+                           again=(rays_o, rays_d, None if aabb is not None else nears, None if aabb is not None else fars, dt_gamma, max_steps, T_thresh, bg_color, aabb, min_near),
+                           keep=(mip, bg_color, self.packed))
+
+    def _frame_post(self, tok):
+        valid = tok.valid if tok.valid is not None else _frame_valid(self, tok)
+        if valid == 1:
             self._watch_failed()
-            return self._render_frame(rays_o, rays_d, *again, dt_gamma, max_steps, T_thresh, bg_color, aabb, min_near)
-        if watch and stats[5]:
+            return self._render_frame(*tok.again)
+        stats, kms = tok.stats, tok.kms
+        if valid == 2:
             self._note_overflow()
-            return self._render_frame(rays_o, rays_d, *again, dt_gamma, max_steps, T_thresh, bg_color, aabb, min_near)
+            return self._render_frame(*tok.again)
+        ws, depth, image, aux_map = tok.out
         return ws, depth, image, aux_map, {"iterations": int(stats[0]), "rendered": int(stats[1]), "rows": int(stats[2]), "enqueued": int(stats[3]), "looks": int(stats[4]),
-                                           "grid_ms": float(kms[0]), "grid_launches": int(kms[1]), "finished": finished, "depth_raw": depth_raw,
-                                           "nears": nears, "fars": fars}
+                                           "grid_ms": float(kms[0]), "grid_launches": int(kms[1]), "finished": tok.finished, "depth_raw": tok.depth_raw,
+                                           "nears": tok.nears, "fars": tok.fars}
 
     @torch.no_grad()
     def network_forward(self, x, d):

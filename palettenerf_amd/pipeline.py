@@ -149,6 +149,36 @@ class FramesInFlight:
         return out
 
 
+def render_queue(model, rays_of, n_frames, consume=None, **kwargs):
+    """Frames 0 .. n_frames-1 ONE AT A TIME on the device, the host's work for frame i + 1 done while frame i runs (round 6: model.render_prepare /
+    render_launch / render_finish over pnr_*_render_frame_submit / _finish).  One host thread, one stream, one workspace; a frame's kernels never share
+    the chip with another frame's (FramesInFlight overlaps frames; this only removes the host's turnaround between them -- what a rank rendering its
+    shard of every frame of a video needs: 0.15 of a 2.1 ms shard frame).  `rays_of(i)` -> (rays_o, rays_d) on the device; `consume(i, results)` is called
+    when frame i is complete, while frame i + 1 is already running.  Returns the list of results (or of consume's return values)."""
+    out = [None] * n_frames
+    if n_frames == 0:
+        return out
+    with torch.no_grad():
+        ro, rd = rays_of(0)
+        cur = model.render_launch(model.render_prepare(ro, rd, **kwargs))
+        for i in range(n_frames):
+            nxt = None
+            if i + 1 < n_frames:
+                ro, rd = rays_of(i + 1)
+                nxt = model.render_prepare(ro, rd, **kwargs)     # outputs, argument struct, source checksums: under frame i's kernels
+            done = cur
+            if model.render_wait(done):
+                if nxt is not None:
+                    cur = model.render_launch(nxt)               # frame i + 1 is on the device before frame i's result dict is even built
+                r = model.render_result(done)
+            else:                                                # (sources rewritten behind torch's counters, an fp16 overflow: the frame is rendered again first)
+                r = model.render_result(done)
+                if nxt is not None:
+                    cur = model.render_launch(nxt)
+            out[i] = consume(i, r) if consume is not None else r
+    return out
+
+
 def render_path(model, poses, intrinsics, H, W, frames_in_flight=2, linear_to_srgb=False, to_host=True, **render_kwargs):
     """The inner loop of the reference's `Trainer.test` over a camera path (nerf/utils.py:704-731, palette/utils.py:993-1044) without the file
     writer: for every pose  get_rays (:133-147) -> model.render -> [linear_to_srgb for linear-colour scenes] -> `(pred * 255).astype(np.uint8)`

@@ -319,6 +319,44 @@ class _RendererBase(nn.Module):
             step += n_step
         return st
 
+    # One inference frame of the device-driven loop in three steps (march_mode "native" only; round 6).  A caller with a queue of frames -- a video path, a rank's
+    # shard loop -- overlaps its own work for frame i + 1 with frame i's kernels:
+    #     h = m.render_prepare(rays(0), ...); m.render_launch(h)
+    #     for i in 1..: nxt = m.render_prepare(rays(i), ...); out = m.render_finish(h); m.render_launch(nxt); h = nxt; consume(out)
+    # render_prepare allocates the outputs and fills the argument struct (it may run while the previous frame is on the device), render_launch enqueues the frame
+    # and returns at once (pnr_*_render_frame_submit), render_finish waits and returns exactly what render() returns.  Parameters must not change in between.
+    def render_prepare(self, rays_o, rays_d, **kwargs):
+        if not (self.cuda_ray and not self.training and self.march_mode == "native"):
+            raise RuntimeError("render_prepare / render_launch / render_finish exist for march_mode = 'native' inference frames")
+        with torch.no_grad():
+            pending = self.run_cuda(rays_o, rays_d, _phase="prepare", **kwargs)
+        pending.redo = lambda: self.render_prepare(rays_o, rays_d, **kwargs)
+        return pending
+
+    def render_launch(self, pending):
+        """Enqueue a prepared frame; returns the pending frame to finish (a NEW one when the model's blobs were rebuilt since render_prepare -- a frame in
+        front of it found its sources rewritten -- and the frame had to be prepared again)."""
+        from .fused import StaleFrame
+        try:
+            pending.fused.frame_launch(pending.tok)
+        except StaleFrame:
+            pending = pending.redo()
+            pending.fused.frame_launch(pending.tok)
+        return pending
+
+    def render_finish(self, pending):
+        with torch.no_grad():
+            return pending.complete(pending.fused.frame_finish(pending.tok))
+
+    def render_wait(self, pending):
+        """render_finish in two halves: wait for the frame (True: its outputs are valid and render_result() only builds the result dict -- the caller may
+        render_launch its next frame first; False: ask for render_result() before launching anything: the frame is rendered again)."""
+        return pending.fused.frame_wait(pending.tok)
+
+    def render_result(self, pending):
+        with torch.no_grad():
+            return pending.complete(pending.fused.frame_result(pending.tok))
+
     def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
         """nerf/renderer.py:564-603 / palette/renderer.py:554-573 -- never staged when cuda_ray."""
         if self.cuda_ray:
@@ -341,6 +379,14 @@ class _RendererBase(nn.Module):
                 out["image"][b:b + 1, head:tail] = r["image"]
                 out["weights_sum"][b * N + head:b * N + tail] = r["weights_sum"]
         return out
+
+
+class PendingFrame:
+    """A native-loop frame between render_prepare and render_finish (fused.py: frame_prepare / frame_launch / frame_finish)."""
+    __slots__ = ("fused", "tok", "complete", "redo")
+
+    def __init__(self, fused, tok, complete):
+        self.fused, self.tok, self.complete, self.redo = fused, tok, complete, None
 
 
 def _zero_map(owner, name, shape, like):
@@ -494,24 +540,39 @@ class NeRFRenderer(_OccupancyMaintenance, _RendererBase):
             # (gridencoder/grid.py:36-39), the field stays on its fp32-accurate matrix path; outputs are fp32 as the reference's are
             was_half = self._fused.table_half
             self._fused.table_half = was_half or torch.is_autocast_enabled()
+            frame_args = (rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh)
+            frame_kw = dict(bg_color=bg_color, aabb=aabb if native_frame else None, min_near=self.min_near)
             try:
-                weights_sum, depth_acc, image_acc, stats = self._fused.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color=bg_color,
-                                                                                    aabb=aabb if native_frame else None, min_near=self.min_near)
+                if kwargs.get("_phase") == "prepare":   # render_prepare(): everything in front of the library call, now; the frame itself in render_launch / render_finish
+                    tok = self._fused.frame_prepare(*frame_args, **frame_kw)
+                else:
+                    ret = self._fused.render_frame(*frame_args, **frame_kw)
             finally:
                 self._fused.table_half = was_half
-            nears, fars = stats["nears"], stats["fars"]
-            if stats["finished"]:   # the frame call applied the epilogue below itself (same fp32 operations, one launch less each)
-                image, depth = image_acc, depth_acc
-            else:
-                image = image_acc + (1 - weights_sum).unsqueeze(-1) * bg_color
-                depth = torch.clamp(depth_acc - nears, min=0) / (fars - nears)
-            image = image.view(*prefix, 3)
-            depth = depth.view(*prefix)
-            rgb_norm_map = _zero_map(self, "rgb_norm", tuple(prefix), image)
-            results["n_samples"] = stats["rows"]
-            results["rendered"] = torch.tensor([stats["rendered"]], dtype=torch.int64)   # host tensor: the count came back with the control block
-            results["iterations"], results["host_looks"] = stats["iterations"], stats["looks"]
-            results["grid_ms"], results["grid_launches"] = stats["grid_ms"], stats["grid_launches"]
+
+            def complete(ret):
+                weights_sum, depth_acc, image_acc, stats = ret
+                nears, fars = stats["nears"], stats["fars"]
+                if stats["finished"]:   # the frame call applied the epilogue below itself (same fp32 operations, one launch less each)
+                    image, depth = image_acc, depth_acc
+                else:
+                    image = image_acc + (1 - weights_sum).unsqueeze(-1) * bg_color
+                    depth = torch.clamp(depth_acc - nears, min=0) / (fars - nears)
+                image = image.view(*prefix, 3)
+                depth = depth.view(*prefix)
+                results["n_samples"] = stats["rows"]
+                results["rendered"] = torch.tensor([stats["rendered"]], dtype=torch.int64)   # host tensor: the count came back with the control block
+                results["iterations"], results["host_looks"] = stats["iterations"], stats["looks"]
+                results["grid_ms"], results["grid_launches"] = stats["grid_ms"], stats["grid_launches"]
+                results["depth"] = depth
+                results["image"] = image
+                results["rgb_norm"] = _zero_map(self, "rgb_norm", tuple(prefix), image)
+                results["weights_sum"] = weights_sum
+                return results
+
+            if kwargs.get("_phase") == "prepare":
+                return PendingFrame(self._fused, tok, complete)
+            return complete(ret)
         else:
             def shade(st, n_alive, n_step, xyzs, dirs, deltas):
                 sigmas, rgbs = self(xyzs, dirs)
@@ -823,49 +884,62 @@ class PaletteRenderer(_RendererBase):
             # must come last: the only composite that mutates rays_alive / rays_t / weights_sum (palette/renderer.py:517-519)
             raymarching.composite_rays(*a, st.rays_alive, st.rays_t, sigmas, rgbs, deltas, st.weights_sum, st.depth, st.image, T_thresh)
 
+        def tail(st, aux_map, finished, stats, nears, fars):
+            nonlocal clip_feat_map, direct_rgb_map, view_dep_rgb_map, basis_acc_map, basis_rgb_map, unscaled_basis_rgb_map
+            if use_fused:  # unpack the composited aux row into the reference's maps
+                direct_rgb_map, view_dep_rgb_map = aux_map[:, 0:3], aux_map[:, 3:6]
+                basis_acc_map = aux_map[:, 6:6 + nb]
+                basis_rgb_map = aux_map[:, 6 + nb:6 + 4 * nb]
+                unscaled_basis_rgb_map = aux_map[:, 6 + 4 * nb:6 + 7 * nb]
+                if self._fused.clip_dim == clip_dim:
+                    clip_feat_map = aux_map[:, 6 + 7 * nb:6 + 7 * nb + clip_dim]
+            weights_sum = st.weights_sum
+            if finished:
+                image, depth, depth_origin = st.image, st.depth, stats["depth_raw"]
+            else:
+                image = st.image + (1 - weights_sum).unsqueeze(-1) * bg_color
+                depth_origin = st.depth.clone()
+                depth = torch.clamp(st.depth - nears, min=0) / (fars - nears)
+            results["depth"] = depth.view(*prefix)
+            results["depth_origin"] = depth_origin.view(*prefix)
+            results["image"] = image.view(*prefix, 3)
+            results["weights_sum"] = weights_sum
+            results["clip_feat"] = clip_feat_map.reshape(*prefix, clip_dim)
+            results["n_samples"] = st.n_samples
+            results["rendered"] = st.rendered
+            if not gui_mode:
+                results["direct_rgb"] = (direct_rgb_map if finished else direct_rgb_map + (1 - weights_sum).unsqueeze(-1) * bg_color).reshape(*prefix, 3)
+                results["view_dep_rgb"] = view_dep_rgb_map.reshape(*prefix, 3)
+                results["basis_rgb"] = basis_rgb_map.reshape(*prefix, nb * 3)
+                results["unscaled_basis_rgb"] = unscaled_basis_rgb_map.reshape(*prefix, nb * 3)
+                results["basis_acc"] = basis_acc_map.reshape(*prefix, nb)
+            return results
+
         if native:  # device-driven loop: same schedule and arithmetic, no per-iteration host sync (pnr_palette_render_frame)
             was_half = self._fused.table_half
             self._fused.table_half = was_half or torch.is_autocast_enabled()     # -O mode: fp16 tables with the reference's half interpolation
+            frame_args = (rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh)
+            frame_kw = dict(bg_color=bg_color, aabb=aabb if native_near_far else None, min_near=self.min_near)
             try:
-                ws_n, depth_n, image_n, aux_map, stats = self._fused.render_frame(rays_o, rays_d, nears, fars, dt_gamma, max_steps, T_thresh, bg_color=bg_color,
-                                                                                  aabb=aabb if native_near_far else None, min_near=self.min_near)
+                if kwargs.get("_phase") == "prepare":   # render_prepare(): the frame itself goes out in render_launch / render_finish
+                    tok = self._fused.frame_prepare(*frame_args, **frame_kw)
+                else:
+                    ret = self._fused.render_frame(*frame_args, **frame_kw)
             finally:
                 self._fused.table_half = was_half
-            nears, fars = stats["nears"], stats["fars"]
-            finished = stats["finished"]    # the frame call's last launch applied the epilogue below itself (same fp32 operations; eleven launches less)
-            st = _MarchState.__new__(_MarchState)
-            st.weights_sum, st.depth, st.image, st.n_samples = ws_n, depth_n, image_n, stats["rows"]
-            st.rendered = torch.tensor([stats["rendered"]], dtype=torch.int64)   # host tensor: the count came back with the control block
-            results["iterations"], results["grid_ms"], results["grid_launches"] = stats["iterations"], stats["grid_ms"], stats["grid_launches"]
-            results["host_looks"] = stats["looks"]
-        else:
-            finished = False
-            st = self._infer_loop(rays_o, rays_d, nears, fars, perturb, dt_gamma, max_steps, shade_fused if use_fused else shade)
-        if use_fused:  # unpack the composited aux row into the reference's maps
-            direct_rgb_map, view_dep_rgb_map = aux_map[:, 0:3], aux_map[:, 3:6]
-            basis_acc_map = aux_map[:, 6:6 + nb]
-            basis_rgb_map = aux_map[:, 6 + nb:6 + 4 * nb]
-            unscaled_basis_rgb_map = aux_map[:, 6 + 4 * nb:6 + 7 * nb]
-            if self._fused.clip_dim == clip_dim:
-                clip_feat_map = aux_map[:, 6 + 7 * nb:6 + 7 * nb + clip_dim]
-        weights_sum = st.weights_sum
-        if finished:
-            image, depth, depth_origin = st.image, st.depth, stats["depth_raw"]
-        else:
-            image = st.image + (1 - weights_sum).unsqueeze(-1) * bg_color
-            depth_origin = st.depth.clone()
-            depth = torch.clamp(st.depth - nears, min=0) / (fars - nears)
-        results["depth"] = depth.view(*prefix)
-        results["depth_origin"] = depth_origin.view(*prefix)
-        results["image"] = image.view(*prefix, 3)
-        results["weights_sum"] = weights_sum
-        results["clip_feat"] = clip_feat_map.reshape(*prefix, clip_dim)
-        results["n_samples"] = st.n_samples
-        results["rendered"] = st.rendered
-        if not gui_mode:
-            results["direct_rgb"] = (direct_rgb_map if finished else direct_rgb_map + (1 - weights_sum).unsqueeze(-1) * bg_color).reshape(*prefix, 3)
-            results["view_dep_rgb"] = view_dep_rgb_map.reshape(*prefix, 3)
-            results["basis_rgb"] = basis_rgb_map.reshape(*prefix, nb * 3)
-            results["unscaled_basis_rgb"] = unscaled_basis_rgb_map.reshape(*prefix, nb * 3)
-            results["basis_acc"] = basis_acc_map.reshape(*prefix, nb)
-        return results
+
+            def complete(ret):
+                ws_n, depth_n, image_n, aux_n, stats = ret
+                st = _MarchState.__new__(_MarchState)
+                st.weights_sum, st.depth, st.image, st.n_samples = ws_n, depth_n, image_n, stats["rows"]
+                st.rendered = torch.tensor([stats["rendered"]], dtype=torch.int64)   # host tensor: the count came back with the control block
+                results["iterations"], results["grid_ms"], results["grid_launches"] = stats["iterations"], stats["grid_ms"], stats["grid_launches"]
+                results["host_looks"] = stats["looks"]
+                # finished: the frame call's last launch applied the epilogue itself (same fp32 operations; eleven launches less)
+                return tail(st, aux_n, stats["finished"], stats, stats["nears"], stats["fars"])
+
+            if kwargs.get("_phase") == "prepare":
+                return PendingFrame(self._fused, tok, lambda ret: complete(ret))
+            return complete(ret)
+        st = self._infer_loop(rays_o, rays_d, nears, fars, perturb, dt_gamma, max_steps, shade_fused if use_fused else shade)
+        return tail(st, aux_map if use_fused else None, False, None, nears, fars)

@@ -1075,3 +1075,88 @@ def test_kept_frame_arguments_survive_a_stand_alone_field_call_at_another_precis
     exact = kept(x, d)
     for a, b in zip(alone, exact):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["nerf", "palette"])
+def test_prepare_launch_finish_frames_equal_frames_rendered_one_by_one(cuda, kind):
+    """pnr_*_render_frame_submit / _finish under model.render_prepare / render_launch / render_finish (pipeline.render_queue): frame i + 1 is PREPARED while
+    frame i runs -- two argument structs and two checksum rows alternate -- and every frame is bit for bit the frame render() gives, also when the submit call's
+    guess of the iteration count falls short (poses far apart: the finish call then enqueues the rest) and with a ray order.  The C calls refuse a finish
+    without a submit, a second submit before the finish, and a finish with another struct."""
+    import ctypes
+    from palettenerf_amd import _lib, network, renderer, scene
+    from palettenerf_amd.fused import NeRFFieldFused, PaletteFieldFused, tile_ray_order
+    from palettenerf_amd.pipeline import render_queue
+    if kind == "nerf":
+        m = network.NeRFNetwork(bound=2, cuda_ray=True, density_scale=40.0)
+    else:
+        m = network.PaletteNetwork(renderer.default_opt(), bound=2, cuda_ray=True, density_scale=40.0)
+    scene.seed_field_(m, 0)
+    m = m.to(cuda).eval()
+    m.density_grid.copy_(torch.from_numpy(scene.brick_density_grid()).to(cuda))
+    raymarching.packbits(m.density_grid, 0.5, m.density_bitfield)
+    m.march_mode, m.fused_field, m.count_rendered = "native", True, True
+    m._fused = NeRFFieldFused(m) if kind == "nerf" else PaletteFieldFused(m)
+    H, W = 96, 128
+    m._fused.ray_order = tile_ray_order(torch.arange(H * W), W, 8).to(cuda)
+    intr = scene.intrinsics_from_fov(H, W)
+    rays = []
+    for i in range(6):
+        # (poses 2 and 3 look past the object: few iterations; the frame behind them needs many more than the submit call enqueues)
+        pose = scene.lookat_pose_from((3.0, 1.0, 0.5), target=(6.0, 2.5, 0.5)) if i in (2, 3) else scene.lookat_pose(azimuth_deg=20.0 + 61.0 * i, elevation_deg=25.0)
+        pose = torch.from_numpy(pose)[None]
+        ro, rd = scene.get_rays(pose, intr, H, W)
+        rays.append((ro.to(cuda), rd.to(cuda)))
+    kw = dict(perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+    if kind == "palette":
+        kw["gui_mode"] = False
+    keys = ("image", "depth", "weights_sum") + (("basis_rgb", "basis_acc", "view_dep_rgb", "direct_rgb", "depth_origin") if kind == "palette" else ())
+    with torch.no_grad():
+        want = []
+        for ro, rd in rays:
+            r = m.render(ro, rd, **kw)
+            want.append({k: r[k].clone() for k in keys} | {"rendered": int(r["rendered"].sum()), "iterations": r["iterations"]})
+    assert len({w["iterations"] for w in want}) > 1
+    order = []
+    for rounds in range(2):
+        got = render_queue(m, lambda i: rays[i], len(rays), consume=lambda i, r: (order.append(i), r)[1], **kw)
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert int(g["rendered"].sum()) == w["rendered"], i
+            for k in keys:
+                a, b = g[k].cpu().numpy(), w[k].cpu().numpy()
+                np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+                np.testing.assert_array_equal(np.nan_to_num(a), np.nan_to_num(b), err_msg=f"frame {i} {k}")
+    assert order == list(range(len(rays))) * 2
+    assert max(int(g["host_looks"]) for g in got) > 1          # at least one frame's first chunk fell short: its finish call enqueued the rest
+    # weights rewritten behind torch's counters BEFORE a queue run: frame 0's checksum fails in render_wait, it is rendered again (blobs rebuilt), and frame 1 --
+    # prepared meanwhile against the OLD blobs -- is refused by frame_launch and prepared again inside render_launch
+    m.color_net[1].weight.data.mul_(-1.0)
+    with pytest.warns(UserWarning, match="rewritten behind torch's version counters"):
+        got = render_queue(m, lambda i: rays[i], len(rays), **kw)
+    import warnings
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("error")
+        for i, (ro, rd) in enumerate(rays):
+            r = m.render(ro, rd, **kw)
+            assert int(r["rendered"].sum()) == int(got[i]["rendered"].sum())
+            assert not torch.equal(torch.nan_to_num(r["image"]), torch.nan_to_num(want[i]["image"])) or int(r["rendered"].sum()) == 0
+            for k in keys:
+                assert torch.equal(torch.nan_to_num(r[k], nan=-7.0), torch.nan_to_num(got[i][k], nan=-7.0)), (i, k)
+    m.color_net[1].weight.data.mul_(-1.0)
+    m.invalidate_fused_caches()
+    # the C calls' own rules
+    lib = _lib.load()
+    ro, rd = rays[0]
+    f = m._fused
+    tok_a = f.frame_prepare(ro[0], rd[0], None, None, 0.0, 1024, 1e-4, bg_color=1, aabb=m.aabb_infer, min_near=m.min_near)
+    tok_b = f.frame_prepare(ro[0], rd[0], None, None, 0.0, 1024, 1e-4, bg_color=1, aabb=m.aabb_infer, min_near=m.min_near)
+    sub = lib.pnr_nerf_render_frame_submit if kind == "nerf" else lib.pnr_palette_render_frame_submit
+    fin = lib.pnr_nerf_render_frame_finish if kind == "nerf" else lib.pnr_palette_render_frame_finish
+    arg = (lambda t: ctypes.byref(t.a)) if kind == "nerf" else (lambda t: ctypes.byref(t.p))
+    assert fin(arg(tok_a), None) == -1                         # nothing submitted
+    f.frame_launch(tok_a)
+    assert sub(arg(tok_b), tok_a.stream) == -1                 # one submitted frame per host thread and device
+    assert fin(arg(tok_b), tok_a.stream) == -1                 # not the struct that was submitted
+    out = f.frame_finish(tok_a)
+    assert out[-1]["rendered"] == want[0]["rendered"] and torch.equal(out[2].view(-1, 3), want[0]["image"].view(-1, 3))
