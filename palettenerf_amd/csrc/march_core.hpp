@@ -66,6 +66,10 @@ struct RayCtx {
     // partly filled brick cell by cell pays one dependent global load per brick instead of one per cell
     mutable uint32_t cached_brick;
     mutable unsigned long long cached_bits;
+    // the empty block whose jump was last REFUSED because a lattice point sits in the exit plane's window (and in the inner planes'): the plane, the lattice and
+    // therefore the verdict are the same from every later cell of that block, so the attempt (~1.5 plain probes) is not repeated there -- the slowest rays of a
+    // frame's first launch took 33 refused jumps in a row (profiles/march_stats.py, kind 7).  Skipping an attempt is always exact: a jump is an optional shortcut.
+    mutable uint32_t nojump_key;
 #ifdef PNR_MARCH_TIMING
     mutable uint32_t n_loads;
 #endif
@@ -109,6 +113,7 @@ __device__ __forceinline__ void ctx_init(RayCtx& c, const float* __restrict__ o,
     c.box = mip_lds ? reinterpret_cast<const float*>(mip_lds + 2 * p.mip_words) : nullptr;
     c.block_skip = mip_lds != nullptr && (p.H % 64u) == 0 && p.block_skip != 0;
     c.cached_brick = 0xffffffffu; c.cached_bits = 0ull;
+    c.nojump_key = 0xffffffffu;
 #ifdef PNR_MARCH_TIMING
     c.n_loads = 0;
 #endif
@@ -231,6 +236,9 @@ __device__ __forceinline__ int empty_block_log2(const RayCtx& c, uint32_t index)
 // one-cell step.
 // JUMPS = false compiles the block jumps out: every empty probe is the reference's own one-cell step (same results, since a jump is an
 // exact shortcut; fewer registers and a shorter chain for the hosted march tail, whose rays walk partly filled bricks where jumps rarely apply).
+#ifndef PNR_MARCH_NOJUMP_MEMO
+#define PNR_MARCH_NOJUMP_MEMO 1
+#endif
 template <bool MIP, bool POW2, bool JUMPS = true>
 __device__ __forceinline__ bool march_probe(const RayCtx& c, float& t, float& x, float& y, float& z, float& dt, int* kind = nullptr) {
     const float t0 = t;
@@ -264,7 +272,9 @@ __device__ __forceinline__ bool march_probe(const RayCtx& c, float& t, float& x,
     if constexpr (MIP && POW2 && JUMPS) {
         int sh = c.block_skip ? empty_block_log2(c, index) : 0;
         if (kind) *kind = sh == 0 ? 1 : 5;   // instrumented builds only: 0 emit, 1 cell step in a non-empty brick, 2/3/4 block jump, 5 block checks failed
+        [[maybe_unused]] const uint32_t jump_key = ((index >> (3 * sh)) << 3) | (uint32_t)sh;     // (level, aligned block of 2^sh cells a side in Morton order, sh)
         if (sh == 0) { if (cell_occupied<MIP>(c, index)) { if (kind) *kind = 0; return true; } }
+        else if (PNR_MARCH_NOJUMP_MEMO && jump_key == c.nojump_key) { if (kind) *kind = 7; }
         else {
             const float s = (float)(1 << sh);
             const float lox = (float)((nx >> sh) << sh), loy = (float)((ny >> sh) << sh), loz = (float)((nz >> sh) << sh);
@@ -309,6 +319,7 @@ __device__ __forceinline__ bool march_probe(const RayCtx& c, float& t, float& x,
                     lattice_advance(t0, d, b, q, prev);
                     if (q - b > 2.0f * eps && b - prev > 2.0f * eps) { t = q; if (kind) *kind = 2; return false; }
                 }
+                if (PNR_MARCH_NOJUMP_MEMO) c.nojump_key = jump_key;     // the windows are taken (or the exit is a cell away): the same from the next cell of this block
             }
         }
     } else {
