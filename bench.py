@@ -1231,6 +1231,8 @@ def main(argv=None):
         if native:  # events recorded inside pnr_*_render_frame around every grid launch of the first timed step; LIVE samples (delta > 0), dead slots are skipped by the kernel
             k_ms, k_units, n_launches = native_ms, native_live * n_tables, native_launches
             kernel_name = "k_frame_grid (device-driven frame loop)" if args.model == "nerf" else "k_frame_grid_pair/_triple (device-driven frame loop, tables interleaved)"
+            if half_rows:
+                kernel_name = ("k_frame_grid_h1" if args.model == "nerf" else "k_frame_grid_h2") + " (device-driven frame loop, fp16 table rows with the reference's half accumulator; fp32 features out)"
         achieved = (k_units * per_sample) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         # HBM-side bytes per lookup launch, MEASURED IN THIS RUN: two child passes of the same workload under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE)
         traffic, traffic_info = None, None

@@ -1,6 +1,6 @@
 """The four drop-in legs of bench.py alone (configs[1] / [2] through the operator API, with and without dropin.fuse_field)."""
-import json, sys
-sys.path.insert(0, ".")
+import json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 import bench
 args = bench.parse(["--no-cpu-baseline"])

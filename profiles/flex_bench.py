@@ -1,10 +1,11 @@
 """composite_rays_flex at the sizes of a PaletteNeRF 800x800 frame's march iterations (palette/renderer.py:508-516: maps of 3, 3, nb, 3 nb, 3 nb channels + clip_dim):
 the six single launches on the one-thread-per-ray kernel (pnr_set_option flex_coop 0), the six on the workgroup-cooperative kernel, and ONE pnr_composite_rays_flex_multi
 launch.  HIP events around each group, median of 30."""
+import os
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from palettenerf_amd import _lib, raymarching
 
 dev = torch.device("cuda")

@@ -18,5 +18,10 @@ bank = bench.RayBank(args, 1, idx, dev)
 m._fused.ray_order = tile_ray_order(idx, W, 8).to(dev)
 kw = dict(perturb=False, dt_gamma=args.wl["dt_gamma"], max_steps=1024, T_thresh=1e-4, gui_mode=False)
 bench.timed_frames(m, bank, kw, 3, False)
-med, mean, rend = bench.timed_frames_median(m, bank, kw, 15)
-print(f"shards {shards}: {idx.numel()} rays, median {med:.3f} ms, mean {mean:.3f} ms, {rend} samples per frame")
+if "--one-call" in sys.argv:     # rounds 1-5: m.render() per frame, the host turns around between two frames
+    med, mean, rend = bench.timed_frames_median(m, bank, kw, 15)
+    how = "one call per frame"
+else:                            # round 6: render_prepare / render_launch / render_wait / render_result (pipeline.render_queue): frame i + 1 prepared under frame i's kernels
+    med, mean, rend = bench.timed_frames_queue(m, bank, kw, 15)
+    how = "prepare / launch / finish queue"
+print(f"shards {shards}: {idx.numel()} rays, median {med:.3f} ms, mean {mean:.3f} ms, {rend} samples per frame ({how})")

@@ -20,7 +20,7 @@ def main(path, top=40):
     try:
         per = {}
         for name, start, end in c.execute("select name, start, end from kernels"):
-            if "k_frame_grid" in name or "k_frame_field" in name or "k_palette_field" in name:
+            if "k_frame_grid" in name or "k_frame_field" in name or "k_palette_field" in name or "k_frame_march" in name or "k_composite_rays_flex" in name:
                 per.setdefault(name.split("(")[0][-48:], []).append((end - start) / 1e3)
         if per:
             print("# launches that did work (duration >= a quarter of the kernel's median): what bench.py's in-run events average over")
