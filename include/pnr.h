@@ -366,7 +366,8 @@ int pnr_nerf_render_frame(const pnr_nerf_frame_args* args, pnr_stream_t stream);
  * while this one runs -- the loop being replaced (nerf/renderer.py:344-380, palette/renderer.py:430-550) holds the host for the whole frame.  _finish waits for
  * the read-back, enqueues further iterations while the frame is not done (the iteration count is data) and fills `stats` / `kernel_ms`.  Rules: _finish follows
  * _submit on the same host thread, device and stream with the SAME argument struct (its address identifies the frame; PNR_ERR_INVALID otherwise); one
- * submitted frame per host thread and device; nothing the frame reads or writes may be touched in between.  pnr_nerf_render_frame == _submit + _finish. */
+ * submitted frame per host thread and device (a second _submit is PNR_ERR_INVALID; a whole-frame call drops a submitted frame that was never finished);
+ * nothing the frame reads or writes may be touched in between.  pnr_nerf_render_frame == _submit + _finish. */
 int pnr_nerf_render_frame_submit(const pnr_nerf_frame_args* args, pnr_stream_t stream);
 int pnr_nerf_render_frame_finish(const pnr_nerf_frame_args* args, pnr_stream_t stream);
 

@@ -1325,7 +1325,11 @@ static int render_frame_impl(const pnr_nerf_frame_args* a, const pnr_palette_fra
     if (phase == kFinish) {
         if (!pending.on || pending.args != static_cast<const void*>(pal ? static_cast<const void*>(pal) : static_cast<const void*>(a))) return PNR_ERR_INVALID;   // no frame of THIS struct was submitted on this thread and device
     } else {
-        if (pending.on) return PNR_ERR_INVALID;   // one frame in flight per host thread and device: finish the submitted one first
+        // one submitted frame per host thread and device: a second _submit is refused (finish the first one).  A WHOLE-frame call drops a submitted frame that
+        // was never finished (the caller gave it up -- an exception between its two halves): its launches are in the stream in front of this frame's, nothing
+        // waits for them any more, and this call would otherwise be refused for as long as the thread lives.
+        if (pending.on && phase == kSubmit) return PNR_ERR_INVALID;
+        pending.on = false;
         if (pal) {   // the aux map starts at zero (palette/renderer.py:436-441): inside the first launch when rows are float4-aligned
             if ((aux_stride & 3u) == 0 && (reinterpret_cast<uintptr_t>(out_aux) & 15u) == 0) { fb.aux_zero = out_aux; fb.aux_stride = aux_stride; }
             else if (hipMemsetAsync(out_aux, 0, (size_t)N * aux_stride * 4, s) != hipSuccess) return PNR_ERR_LAUNCH;

@@ -328,8 +328,8 @@ _march_rays_now = _march_rays.apply
 
 def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, near, far, align=-1, perturb=False, dt_gamma=0, max_steps=1024):
     """raymarching/raymarching.py:347-398."""
-    if _flex_queue.shared is not None or _flex_queue.armed:
-        _flex_queue.flush()
+    if _flex_queues.q.shared is not None or _flex_queues.q.armed:
+        _flex_queues.q.flush()
     return _march_rays_now(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, near, far, align, perturb, dt_gamma, max_steps)
 
 
@@ -354,8 +354,8 @@ _composite_rays_now = _composite_rays.apply
 def composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh=1e-2):
     """raymarching/raymarching.py:401-423 (in place; returns an empty tuple).  Queued flex composites (defer_flex_composites) are issued first: this call is the
     writer of what they read."""
-    if _flex_queue.shared is not None or _flex_queue.armed:
-        _flex_queue.flush()
+    if _flex_queues.q.shared is not None or _flex_queues.q.armed:
+        _flex_queues.q.flush()
     return _composite_rays_now(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh)
 
 
@@ -432,32 +432,39 @@ class _FlexQueue:
             composite_rays_flex_multi(n_alive, n_step, rays_alive, rays_t, sigmas, deltas, weights_sum, maps, T_thresh)
 
 
-_flex_queue = _FlexQueue()
+class _FlexQueues(__import__("threading").local):
+    """One queue per host thread: a thread's deferred composites must go out on that thread's stream, in front of that thread's next composite_rays."""
+
+    def __init__(self):
+        self.q = _FlexQueue()
+
+
+_flex_queues = _FlexQueues()
 
 
 def defer_flex_composites(on=True):
     """Switch the deferral of composite_rays_flex on or off (_FlexQueue explains); returns the previous setting."""
-    was = _flex_queue.on
+    was = _flex_queues.q.on
     if not on:
-        _flex_queue.flush()
-    _flex_queue.on = bool(on)
+        _flex_queues.q.flush()
+    _flex_queues.q.on = bool(on)
     return was
 
 
 def flush_flex_composites():
-    _flex_queue.flush()
+    _flex_queues.q.flush()
 
 
 def arm_flex_deferral():
     """Defer the composite_rays_flex calls from here up to the next composite_rays / march_rays / compact_alive / flush_flex_composites (one march iteration of
     the reference's loop), then fall back to immediate calls."""
-    _flex_queue.armed = True
+    _flex_queues.q.armed = True
 
 
 def composite_rays_flex(n_alive, n_step, n_channel, rays_alive, rays_t, sigmas, input, deltas, weights_sum, output, T_thresh=1e-2):
     """raymarching/raymarching.py:425-447 (in place on `output`; returns an empty tuple)."""
-    if (_flex_queue.on or _flex_queue.armed) and not torch.is_autocast_enabled() and sigmas.dtype == torch.float32 and input.dtype == torch.float32:
-        _flex_queue.push(n_alive, n_step, n_channel, rays_alive, rays_t, sigmas, input, deltas, weights_sum, output, T_thresh)
+    if (_flex_queues.q.on or _flex_queues.q.armed) and not torch.is_autocast_enabled() and sigmas.dtype == torch.float32 and input.dtype == torch.float32:
+        _flex_queues.q.push(n_alive, n_step, n_channel, rays_alive, rays_t, sigmas, input, deltas, weights_sum, output, T_thresh)
         return tuple()
     return _composite_rays_flex_now(n_alive, n_step, n_channel, rays_alive, rays_t, sigmas, input, deltas, weights_sum, output, T_thresh)
 
@@ -482,8 +489,8 @@ spread_ray_to_sample = _spread_ray_to_sample.apply
 def compact_alive(rays_alive, n_alive=None, out=None, count=None):
     """Device-side, order-preserving replacement of `rays_alive[rays_alive >= 0]`
     (nerf/renderer.py:376).  Returns (compacted ids buffer, device int32[1] count); no host sync."""
-    if _flex_queue.shared is not None or _flex_queue.armed:
-        _flex_queue.flush()
+    if _flex_queues.q.shared is not None or _flex_queues.q.armed:
+        _flex_queues.q.flush()
     n = rays_alive.shape[0] if n_alive is None else n_alive
     if out is None:
         out = torch.empty_like(rays_alive)

@@ -1160,3 +1160,10 @@ def test_prepare_launch_finish_frames_equal_frames_rendered_one_by_one(cuda, kin
     assert fin(arg(tok_b), tok_a.stream) == -1                 # not the struct that was submitted
     out = f.frame_finish(tok_a)
     assert out[-1]["rendered"] == want[0]["rendered"] and torch.equal(out[2].view(-1, 3), want[0]["image"].view(-1, 3))
+    # a submitted frame its caller gave up (an exception between the two halves): the next whole-frame call drops it instead of refusing every frame from now on
+    f.frame_launch(f.frame_prepare(ro[0], rd[0], None, None, 0.0, 1024, 1e-4, bg_color=1, aabb=m.aabb_infer, min_near=m.min_near))
+    with torch.no_grad():
+        r = m.render(rays[1][0], rays[1][1], **kw)
+    assert int(r["rendered"].sum()) == want[1]["rendered"] and torch.equal(torch.nan_to_num(r["image"]), torch.nan_to_num(want[1]["image"]))
+    got = render_queue(m, lambda i: rays[i], 3, **kw)
+    assert all(torch.equal(torch.nan_to_num(g["image"]), torch.nan_to_num(w["image"])) for g, w in zip(got, want))
