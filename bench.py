@@ -72,6 +72,8 @@ def parse(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip the extra driver-observed legs (exact-fp32 field, palette model)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic (FETCH_SIZE / WRITE_SIZE of the lookup kernel)")
     ap.add_argument("--extra-steps", type=int, default=20)
+    ap.add_argument("--one-call-per-frame", action="store_true",
+                    help="the timed frames as m.render() calls (the host turns around between two frames: rounds 1-5's loop) instead of the prepare / launch / finish queue")
     ap.add_argument("--shared-stream", action="store_true",
                     help="with --main-frames-in-flight F > 1: all F handles enqueue into one stream (frames back to back without the host's gap, kernels never overlap)")
     ap.add_argument("--main-frames-in-flight", type=int, default=1, metavar="F",
@@ -126,7 +128,7 @@ def core_argv(args):
     """The flags that define the headline workload (what a child pass of this script must repeat)."""
     a = ["--workload", args.workload, "--scaling", args.scaling, "--res", str(args.res), "--density-scale", repr(float(args.density_scale)), "--field-precision", args.field_precision,
          "--ray-order", args.ray_order, "--pose-step-deg", repr(float(args.pose_step_deg)), "--num-basis", str(args.num_basis)]
-    for flag, on in (("--fp16", args.fp16), ("--static-pose", args.static_pose), ("--no-interleave", args.no_interleave), ("--pred-clip", args.pred_clip),
+    for flag, on in (("--fp16", args.fp16), ("--one-call-per-frame", args.one_call_per_frame), ("--static-pose", args.static_pose), ("--no-interleave", args.no_interleave), ("--pred-clip", args.pred_clip),
                      ("--half-tables", args.half_tables)):
         if on:
             a.append(flag)
@@ -1093,24 +1095,31 @@ def main(argv=None):
     else:
         t0 = time.perf_counter()
         step_ev[0].record()
-    # N > 1 ranks (round 6): a rank's shard frames go through render_prepare / render_launch / render_finish -- one frame on the device at a time, the host's work
-    # for frame i + 1 (outputs, argument struct, the next pose's rays) done under frame i's kernels, frame i + 1 enqueued before frame i's rows are packed for the
-    # all-gather (which therefore overlaps frame i + 1's render, as before).  0.15 ms of host turnaround per 2.1 ms shard frame otherwise.
-    queued = use_dist and native and F_main == 1 and not args.fp16
+    # Round 6: the timed frames go through render_prepare / render_launch / render_wait / render_result -- one frame on the device at a time, the host's work for
+    # frame i + 1 (outputs, argument struct, the next pose's rays) done under frame i's kernels and frame i + 1 enqueued before frame i's result dict is built (and,
+    # with N > 1 ranks, before its rows are packed for the all-gather, which therefore overlaps frame i + 1's render as before).  The same loop at every N, so that a
+    # scaling curve compares like with like; 0.1-0.15 ms of host turnaround per frame otherwise (3 % of the 800 x 800 frame, 7 % of an eighth of the garden frame).
+    # --one-call-per-frame: m.render() per frame, as until round 5 (`extra.one_call_per_frame` holds that figure next to the headline).
+    queued = native and F_main == 1 and not args.one_call_per_frame
     if queued:
         q_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        def prepare(i):
+            with torch.autocast("cuda", dtype=torch.float16, enabled=args.fp16):
+                return m.render_prepare(*bank.get(args.warmup + i), **kw)
+
         m._fused.time_grid_kernel = bool(timed_native)
-        cur = m.render_prepare(*bank.get(args.warmup), **kw)
+        cur = prepare(0)
         q_ev[0][0].record()
         cur = m.render_launch(cur)
         for i in range(args.steps):
             nxt = None
             if i + 1 < args.steps:
                 m._fused.time_grid_kernel = False
-                nxt = m.render_prepare(*bank.get(args.warmup + i + 1), **kw)
+                nxt = prepare(i + 1)
             done = cur
             ok = m.render_wait(done)
             q_ev[i][1].record()
+            step_ev[i + 1].record()          # (behind frame i, in front of frame i + 1: a step's diagnostic time is its frame + the turnaround in front of it)
             if not ok:                       # (never on this script's fixed weights: the frame is rendered again before anything else is enqueued)
                 r = m.render_result(done)
             if nxt is not None:
@@ -1118,18 +1127,19 @@ def main(argv=None):
                 cur = m.render_launch(nxt)   # frame i + 1 is on the device before frame i's result dict is built and its rows are packed
             if ok:
                 r = m.render_result(done)
-            handle = gatherer.start(gather_parts(args, r, nb))
-            if pending:
-                _full = gatherer.finish(pending.pop())
-            pending.append(handle)
+            if use_dist:
+                handle = gatherer.start(gather_parts(args, r, nb))
+                if pending:
+                    _full = gatherer.finish(pending.pop())
+                pending.append(handle)
             rendered_host += int(r["rendered"])
             rows += r["n_samples"]
             looks += int(r.get("host_looks", 0))
             iterations += int(r.get("iterations", 0))
             if timed_native and i == 0:
                 native_ms, native_launches, native_live = r.get("grid_ms", 0.0), r.get("grid_launches", 0), int(r["rendered"])
-            step_ev[i + 1].record()
-        render_ev.extend(q_ev)
+        if use_dist:
+            render_ev.extend(q_ev)
     for i in range(args.steps if (F_main == 1 and not queued) else 0):
         # HIP events around every grid-encode launch cost ~6 us each (two per iteration): instrument the launches of the
         # FIRST timed step only, so the measurement lives inside the timed region without distorting it
@@ -1358,6 +1368,16 @@ def main(argv=None):
                              "rendered_samples_gpu": int(g["rendered"].sum()), "rendered_samples_oracle": int(ref["rendered"].sum()),
                              "sample": rec["sample"].split(" (")[0], "tolerance": "1e-4 abs (north_star)"}
         # --- extra driver-observed legs on the same box: the exact-fp32 field and the PaletteNeRF model (configs[2]) on the same camera path
+        if not args.no_extras and native and F_main == 1:
+            # the headline's frames as m.render() calls, one call per frame (rounds 1-5's timed loop; what the extra legs below are timed with as well)
+            try:
+                n1 = max(5, args.extra_steps)
+                timed_frames(m, bank, kw, 2, args.fp16, first_step=args.warmup)
+                ms1, rend1 = timed_frames(m, bank, kw, n1, args.fp16, first_step=args.warmup)
+                extra["one_call_per_frame"] = {"ms_per_step": ms1, "value": rend1 / (ms1 * 1e-3), "unit": "samples/s", "steps": n1,
+                                               "what": "the same frames as m.render() calls: the host prepares a frame only after the previous one has returned"}
+            except RuntimeError as e:
+                extra["one_call_per_frame_error"] = str(e)
         if not args.no_extras and native and args.workload == "lego" and not args.fp16:
             n = max(1, args.extra_steps)
             for name, kind, prec in (("fp32_field", "nerf", "fp32"), ("f16x2_field", "nerf", "f16x2"), ("palette", "palette", "f16x3"), ("palette_f16x2_field", "palette", "f16x2"),
