@@ -97,3 +97,29 @@ def test_bench_helpers_without_a_gpu():
     assert again.wl["dt_gamma"] == 0.01 and again.steps == 3
     b = bench.l2_bound_of(365482, 1, 0.0766)
     assert b["lane_requests_per_launch"] == 365482 * 128 and 0.9 < b["lane_requests_per_clk_per_cu"] < 1.1
+
+
+def test_child_passes_of_a_rank_never_see_the_launcher(monkeypatch):
+    """Round 6: rank 0 of an N > 1 run measures roofline.traffic in single-GPU child passes of this script.  Their environment carries none of the launcher's
+    rank variables (parse() switches its defaults on WORLD_SIZE; a child must not try to join the parent's communicator), --emulate-shard makes them render
+    rank 0's shard, and roofline_block prices a lookup whose algorithmic rate exceeds the HBM peak against the L2 bandwidth."""
+    for k, v in (("WORLD_SIZE", "8"), ("RANK", "0"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29500"), ("PNR_BENCH_FORCE_DIST", "1"), ("TORCHELASTIC_RUN_ID", "x")):
+        monkeypatch.setenv(k, v)
+    env = bench.child_env(TMPDIR="/tmp")
+    assert env["TMPDIR"] == "/tmp" and not any(k in env for k in bench.LAUNCHER_ENV)
+    assert "PATH" in env
+    a = bench.parse(["--gpus", "8"])
+    monkeypatch.delenv("WORLD_SIZE")
+    child = bench.parse(bench.core_argv(a) + ["--emulate-shard", "0/8", "--steps", "3"])
+    assert (child.workload, child.scaling, child.shard, child.gpus) == ("garden", "strong", (0, 8), 1)
+    with pytest.raises(SystemExit):
+        bench.parse(["--emulate-shard", "8/8"])
+    assert bench.parse(bench.core_argv(bench.parse(["--one-call-per-frame"]))).one_call_per_frame is True
+    # the roofline object's bound
+    hbm = bench.roofline_block("k", 6368.9, 3.04e8, {"x": 1}, 27, 27 * 0.0668, 27 * 365482, 1164, 1)
+    assert hbm["bound"] == "hbm" and abs(hbm["frac"] - 6368.9 / 8000.0) < 1e-9 and 0.5 < hbm["hbm_frac_of_measured_traffic"] < 0.6 and 0.7 < hbm["traffic_over_algorithmic"] < 0.73
+    l2 = bench.roofline_block("k", 17492.6, 6.16e8, None, 29, 29 * 0.1446, 29 * 2 * 1086526, 1164, 2)
+    assert l2["bound"] == "l2" and l2["peak"] == bench.L2_PEAK_GBS and 0.5 < l2["frac"] < 0.52 and l2["algorithmic_over_hbm_peak"] > 2.0 and 0.5 < l2["hbm_frac_of_measured_traffic"] < 0.56
+    assert l2["algorithmic_bytes_per_sample"] == 2328 and "note" in l2
+    none = bench.roofline_block("k", 100.0, None, None, 1, 1.0, 10, 1164, 1)
+    assert none["traffic"] is None and "hbm_frac_of_measured_traffic" not in none
