@@ -470,6 +470,7 @@ __global__ void __launch_bounds__(kRayBlock) __attribute__((amdgpu_waves_per_eu(
                 for (int kk = 0; kk < 8; kk++) g_march_kinds[(prev->iterations + 1) & 63][kk] = kinds[kk];
             atomicAdd(&g_march_stats[so + 0], probes); atomicAdd(&g_march_stats[so + 1], empties); atomicAdd(&g_march_stats[so + 3], 1ull);
             atomicAdd(&g_march_hist[so ? 1 : 0][probes > 31 ? 31 : (int)probes], 1u);
+            for (int kk = 0; kk < 8; kk++) if (kinds[kk]) atomicAdd(&g_march_kinds[so ? 63 : 62][kk], kinds[kk]);   // rows 62 / 63: kind totals of the first / later launches
         }
         {   // wave-level: max probes over the wave (what the wave actually executes)
             unsigned long long mx = probes;

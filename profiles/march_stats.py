@@ -33,6 +33,11 @@ lib.pnr_debug_march_kinds(kd)
 print("kinds of a slowest ray per iteration [emit, cell, -, s8?, ...]:")
 for it in range(30):
     print(it, list(kd)[it * 8:it * 8 + 8])
+names = ["emit", "cell step (mixed brick)", "block jump", "-", "-", "jump refused: margins / cascade / step", "jump refused: exit plane's window taken", "jump refused: inner planes too (or memo)"]
+for row, what in ((62, "first launch of a frame"), (63, "later launches")):
+    tot = list(kd)[row * 8:row * 8 + 8]
+    if sum(tot):
+        print(f"probe kinds, {what} (both frames):", ", ".join(f"{n}: {v} ({100.0 * v / sum(tot):.1f}%)" for n, v in zip(names, tot) if v))
 print("first launch:", list(out[0:4]), "later launches:", list(out[4:8]))
 print("probes", out[0], "empty", out[1], "sum over waves of max-lane probes x64", out[2] * 64, "ray-launches", out[3], "rendered", int(r["rendered"].item()))
 
