@@ -58,6 +58,22 @@ def test_argument_validation_without_gpu():
     assert lib.pnr_morton3d(None, u32(4), None, None) == -1
     # empty inputs are a no-op
     assert lib.pnr_morton3d(None, u32(0), None, None) == 0
+    # round 6 (ABI 7): the multi-map flex composite and the frame call's two halves validate before anything is launched
+    maps = (_lib.FlexMap * 9)()
+    for m in maps:
+        m.n_channel = 3
+    assert lib.pnr_composite_rays_flex_multi(u32(4), u32(1), f32(1e-4), None, None, None, None, None, ctypes.cast(maps, ctypes.c_void_p), u32(9), None) == -2   # more than PNR_FLEX_MAX_MAPS
+    assert lib.pnr_composite_rays_flex_multi(u32(4), u32(1), f32(1e-4), None, None, None, None, None, None, u32(2), None) == -1                                  # no map array
+    maps[0].n_channel = 129
+    assert lib.pnr_composite_rays_flex_multi(u32(4), u32(1), f32(1e-4), None, None, None, None, None, ctypes.cast(maps, ctypes.c_void_p), u32(1), None) == -2   # CHECK_CHANNEL per map
+    maps[0].n_channel = 3
+    assert lib.pnr_composite_rays_flex_multi(u32(4), u32(1), f32(1e-4), None, None, None, None, None, ctypes.cast(maps, ctypes.c_void_p), u32(1), None) == -1   # map without buffers
+    assert lib.pnr_composite_rays_flex_multi(u32(0), u32(1), f32(1e-4), None, None, None, None, None, ctypes.cast(maps, ctypes.c_void_p), u32(1), None) == 0    # no alive ray: a no-op
+    maps[0].n_channel = 0
+    assert lib.pnr_composite_rays_flex_multi(u32(4), u32(1), f32(1e-4), None, None, None, None, None, ctypes.cast(maps, ctypes.c_void_p), u32(1), None) == 0    # only empty maps: a no-op
+    for fn in (lib.pnr_nerf_render_frame_submit, lib.pnr_nerf_render_frame_finish, lib.pnr_palette_render_frame_submit, lib.pnr_palette_render_frame_finish):
+        assert fn(None, None) == -1
+    assert b"16-byte" in lib.pnr_error_string(-4) and lib.pnr_abi_version() >= 7
     assert lib.pnr_march_rays(u32(0), u32(4), *([None] * 4), f32(2), f32(0), u32(1024), u32(2), u32(128), *([None] * 8)) == 0
     # round 4 entry points: the layout flag and the self-filling march validate before they launch
     assert lib.pnr_grid_encode_forward_layout(None, None, None, None, u32(8), u32(3), u32(2), u32(16), f32(1.0), u32(16), None, u32(0), i32(0), i32(0), i32(2), None) == -1   # unknown layout
