@@ -755,6 +755,10 @@ def roofline_block(kernel_name, achieved, traffic, traffic_info, n_launches, k_m
     if traffic and avg_ms > 0:
         r["hbm_frac_of_measured_traffic"] = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         r["traffic_over_algorithmic"] = traffic / max(1.0, r["algorithmic_bytes_per_launch"])
+    if on_die and traffic and avg_ms > 0:
+        # which of the two ceilings the launch sits closer to: the L2's (algorithmic bytes) or HBM's (the bytes that actually crossed it)
+        hf = r["hbm_frac_of_measured_traffic"]
+        r["closer_ceiling"] = {"name": "hbm, by measured traffic" if hf > r["frac"] else "l2, by algorithmic bytes", "frac": max(hf, r["frac"])}
     if on_die:
         r["note"] = ("algorithmic bytes per second exceed the HBM peak: the interleaved table rows are re-used out of L2 / Infinity Cache, so the kernel is priced against the "
                      "aggregate L2 bandwidth (MI355X_MICROARCH.md: ~34.5 TB/s); `traffic` = HBM-side bytes per launch from the PMC passes, `hbm_frac_of_measured_traffic` what "

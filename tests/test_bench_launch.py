@@ -120,6 +120,6 @@ def test_child_passes_of_a_rank_never_see_the_launcher(monkeypatch):
     assert hbm["bound"] == "hbm" and abs(hbm["frac"] - 6368.9 / 8000.0) < 1e-9 and 0.5 < hbm["hbm_frac_of_measured_traffic"] < 0.6 and 0.7 < hbm["traffic_over_algorithmic"] < 0.73
     l2 = bench.roofline_block("k", 17492.6, 6.16e8, None, 29, 29 * 0.1446, 29 * 2 * 1086526, 1164, 2)
     assert l2["bound"] == "l2" and l2["peak"] == bench.L2_PEAK_GBS and 0.5 < l2["frac"] < 0.52 and l2["algorithmic_over_hbm_peak"] > 2.0 and 0.5 < l2["hbm_frac_of_measured_traffic"] < 0.56
-    assert l2["algorithmic_bytes_per_sample"] == 2328 and "note" in l2
+    assert l2["algorithmic_bytes_per_sample"] == 2328 and "note" in l2 and l2["closer_ceiling"]["name"].startswith("hbm") and l2["closer_ceiling"]["frac"] == l2["hbm_frac_of_measured_traffic"]
     none = bench.roofline_block("k", 100.0, None, None, 1, 1.0, 10, 1164, 1)
     assert none["traffic"] is None and "hbm_frac_of_measured_traffic" not in none
